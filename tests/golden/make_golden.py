@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own Python on CPU.
+
+Run ONLY in the build container (needs /root/reference; never on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What executes: the reference's unmodified ``LinkTransformer`` / ``mlp_score``
+(/root/reference/src/models/link_transformer.py, other_models.py, modules/layers.py,
+modules/node_encoder.py) and its ``get_ppr_matrix`` / ``create_sparse_ppr_matrix``
+(/root/reference/src/util/calc_ppr_scores.py:103-127,221-241), with the absent third-party
+packages replaced by the stand-ins in oracle/ref_shims.py.  Only DATA is written: inputs
+(graph, features, PPR triplets, weights, pair batches) and the reference's outputs.
+"""
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import ref_shims  # noqa: E402
+from oracle.fixture_weights import make_param  # noqa: E402
+
+ref_shims.install()
+
+from models.link_transformer import LinkTransformer  # noqa: E402  (reference)
+from models.other_models import mlp_score  # noqa: E402  (reference)
+from util import calc_ppr_scores as ref_ppr  # noqa: E402  (reference)
+
+torch.set_num_threads(4)
+
+
+# ----------------------------------------------------------------------------- graph helpers
+def rand_graph(rng, n, m, n_isolated=0, power=0.0, weighted=False):
+    """Undirected simple graph as a directed (both directions) edge list, sorted; optional int weights."""
+    live = n - n_isolated
+    if power > 0:
+        w = (np.arange(1, live + 1, dtype=np.float64)) ** (-power)
+        w /= w.sum()
+        a = rng.choice(live, size=3 * m, p=w)
+        b = rng.choice(live, size=3 * m, p=w)
+    else:
+        a = rng.integers(0, live, size=3 * m)
+        b = rng.integers(0, live, size=3 * m)
+    keep = a != b
+    lo, hi = np.minimum(a, b)[keep], np.maximum(a, b)[keep]
+    key = np.unique(lo * n + hi)
+    rng.shuffle(key)
+    key = np.sort(key[:m])
+    lo, hi = key // n, key % n
+    wts = rng.integers(1, 6, size=lo.size).astype(np.float32) if weighted else np.ones(lo.size, np.float32)
+    src = np.concatenate([lo, hi])
+    dst = np.concatenate([hi, lo])
+    ww = np.concatenate([wts, wts])
+    order = np.argsort(src * n + dst, kind="stable")
+    return np.stack([src[order], dst[order]]).astype(np.int64), ww[order]
+
+
+def reference_ppr(edge_index, n, eps, alpha=0.15):
+    """Reference PPR: calc_ppr_scores.py get_ppr_matrix -> create_sparse_ppr_matrix -> COO (row, col, f32 val)."""
+    nb, wt = ref_ppr.get_ppr_matrix(torch.from_numpy(edge_index), n, alpha, eps)
+    sp = ref_ppr.create_sparse_ppr_matrix(nb, wt)
+    coo = sp.to_torch_sparse_coo_tensor().coalesce()
+    ix = coo.indices().numpy()
+    return ix[0].astype(np.int64), ix[1].astype(np.int64), coo.values().numpy().astype(np.float32)
+
+
+def jitter_near(rng, val, thresholds, frac=0.25):
+    """Move a fraction of the PPR values to within a few ulps of the thresholds (exercises the
+    reference's fp32 `+t-t` round trip, link_transformer.py:290-291,316-317,464-476)."""
+    val = val.copy()
+    pick = np.nonzero((rng.random(val.size) < frac) & (val < 0.14))[0]
+    for i in pick:
+        th = np.float32(thresholds[rng.integers(0, len(thresholds))])
+        k = int(rng.integers(-6, 7))
+        v = th
+        for _ in range(abs(k)):
+            v = np.nextafter(v, np.float32(1.0 if k > 0 else 0.0), dtype=np.float32)
+        val[i] = v
+    return val
+
+
+def make_pairs(rng, n, edge_index, bs, isolated):
+    """Pair batch with a==b, existing edges (a~b), duplicates, isolated endpoints and random pairs."""
+    e = edge_index[:, rng.integers(0, edge_index.shape[1], size=bs // 3)]
+    r = rng.integers(0, n, size=(2, bs - e.shape[1] - 8))
+    same = np.repeat(rng.integers(0, n, size=(1, 3)), 2, axis=0)
+    iso = np.array([[isolated[0], isolated[0], int(r[0, 0])], [int(r[1, 0]), isolated[-1], isolated[0]]]) \
+        if len(isolated) else rng.integers(0, n, size=(2, 3))
+    dup = np.stack([e[:, 0], e[:, 0]], axis=1)
+    b = np.concatenate([e, r, same, iso, dup], axis=1)
+    return b[:, rng.permutation(b.shape[1])].astype(np.int64)
+
+
+# ----------------------------------------------------------------------------- one fixture
+def build_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, residual=False,
+               layer_norm=True, relu=True, weighted=False, n_isolated=0, power=0.0, jitter=False,
+               val_in_test=False):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    from torch_sparse import SparseTensor  # shim
+
+    edge_index, edge_w = rand_graph(rng, n, m, n_isolated, power, weighted)
+    x = rng.standard_normal((n, f_in)).astype(np.float32)
+    th_cn, th_1, th_n = thresholds
+
+    def adj_pack(ei, ew):
+        adj_t = SparseTensor.from_edge_index(torch.from_numpy(ei), torch.from_numpy(ew), [n, n])
+        mask = adj_t.to_symmetric().to_torch_sparse_coo_tensor().coalesce().bool().int()  # read_datasets.py:90-95
+        return adj_t, mask
+
+    adj_t, adj_mask = adj_pack(edge_index, edge_w)
+    pr, pc, pv = reference_ppr(edge_index, n, eps)
+    if jitter:
+        pv = jitter_near(rng, pv, [t for t in (th_1, th_n) if 0 < t < 1])
+    ppr = torch.sparse_coo_tensor(torch.from_numpy(np.stack([pr, pc])), torch.from_numpy(pv), (n, n)).coalesce()
+
+    data = {"x": torch.from_numpy(x), "adj_t": adj_t, "adj_mask": adj_mask, "ppr": ppr, "num_nodes": n}
+    out = {"edge_index": edge_index.astype(np.int32), "edge_weight": edge_w, "x": x,
+           "ppr_row": pr.astype(np.int32), "ppr_col": pc.astype(np.int32), "ppr_val": pv}
+    if val_in_test:  # read_datasets.py:97-113 : extra (validation) edges, weight 1, used when test_set=True
+        extra, _ = rand_graph(rng, n, m // 5, n_isolated, power, False)
+        full_ei = np.concatenate([edge_index, extra], axis=1)
+        full_w = np.concatenate([edge_w, np.ones(extra.shape[1], np.float32)])
+        full_adj_t = SparseTensor.from_edge_index(torch.from_numpy(full_ei), torch.from_numpy(full_w), [n, n])
+        full_mask = full_adj_t.to_torch_sparse_coo_tensor().coalesce().bool().int()  # read_datasets.py:109-110
+        fr, fc, fv = reference_ppr(full_ei, n, eps)
+        data.update(full_adj_t=full_adj_t, full_adj_mask=full_mask,
+                    ppr_test=torch.sparse_coo_tensor(torch.from_numpy(np.stack([fr, fc])),
+                                                     torch.from_numpy(fv), (n, n)).coalesce())
+        out.update(full_edge_index=full_ei.astype(np.int32), full_edge_weight=full_w,
+                   ppr_test_row=fr.astype(np.int32), ppr_test_col=fc.astype(np.int32), ppr_test_val=fv)
+    else:
+        data.update(full_adj_t=adj_t, full_adj_mask=adj_mask, ppr_test=ppr)
+
+    train_args = {"thresh_cn": th_cn, "thresh_1hop": th_1, "thresh_non1hop": th_n, "dim": dim,
+                  "trans_layers": 1, "num_heads": 1, "att_drop": 0.1, "dropout": 0.1, "gnn_drop": 0.1,
+                  "feat_drop": 0.1, "gcn_cache": False, "gnn_layers": gnn_layers, "residual": residual,
+                  "layer_norm": layer_norm, "relu": relu}
+    model = LinkTransformer(train_args, data, device="cpu")
+    score = mlp_score(model.out_dim, model.out_dim, 1, 2, 0.1)
+    # Non-trivial, version-independent values for every parameter (oracle/fixture_weights.py);
+    # only (name, shape, seed) are stored in the fixture.
+    shapes = {}
+    with torch.no_grad():
+        for tag, mod in (("model", model), ("score", score)):
+            sd = mod.state_dict()
+            for pname, p in sd.items():
+                shapes[f"{tag}.{pname}"] = list(p.shape)
+                p.copy_(torch.from_numpy(make_param(f"{tag}.{pname}", p.shape, seed)))
+    model.eval()
+    score.eval()
+
+    isolated = list(range(n - n_isolated, n))
+    batch = make_pairs(rng, n, edge_index, bs, isolated)
+    tb = torch.from_numpy(batch)
+    test_set = bool(val_in_test)
+
+    hooks = {}
+    h1 = model.att_layers[0].att.register_forward_hook(lambda m, i, o: hooks.__setitem__("att_pre_ln", (o[0] if isinstance(o, tuple) else o).detach().numpy().copy()))
+    h2 = model.att_layers[0].register_forward_hook(lambda m, i, o: hooks.__setitem__("att_post_ln", o[0].detach().numpy().copy()))
+    with torch.no_grad():
+        x_node = model.propagate(test_set=test_set)
+        infos = model.compute_node_mask(tb, test_set, None)
+        feats, attw = model(tb, test_set=test_set, return_weights=True)
+        pw, _ = model.calc_pairwise(tb, x_node, test_set=test_set)
+        ew = model.elementwise_lin(x_node[tb[0]] * x_node[tb[1]])
+        prob = score(feats)
+        hid = torch.relu(score.lins[0](feats))
+        logit = score.lins[1](hid).squeeze(-1)
+    h1.remove()
+    h2.remove()
+    assert torch.allclose(torch.sigmoid(logit), prob)
+
+    out.update(batch=batch, x_node=x_node.numpy(), pairwise_feats=pw.numpy(), elementwise_feats=ew.numpy(),
+               combined_feats=feats.numpy(), prob=prob.numpy(), logit=logit.numpy(),
+               att_pre_ln=hooks["att_pre_ln"], att_post_ln=hooks["att_post_ln"],
+               att_weights=attw.numpy())
+    for tag, info in zip(("cn", "onehop", "non1hop"), infos):
+        if info is None:
+            continue
+        out[f"sel_{tag}_ix"] = info[0].numpy().astype(np.int64)
+        out[f"sel_{tag}_pa"] = info[1].numpy().astype(np.float32)
+        out[f"sel_{tag}_pb"] = info[2].numpy().astype(np.float32)
+    cfg = dict(train_args)
+    cfg.update(n=n, f_in=f_in, eps=eps, test_set=test_set, pred_layers=2, seed=seed, param_shapes=shapes)
+    out["config_json"] = np.array(__import__("json").dumps(cfg))
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    sizes = {t: out[f"sel_{t}_ix"].shape[1] for t in ("cn", "onehop", "non1hop") if f"sel_{t}_ix" in out}
+    print(f"[golden] {name}: N={n} nnz={edge_index.shape[1]} ppr_nnz={pr.size} BS={batch.shape[1]} sel={sizes} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def build_ppr_case(name, seed, n, m, eps_list, n_isolated=0, power=0.0):
+    """PPR producer golden: graph -> (row, col, fp32 val) exactly as calc_ppr_scores.py emits them."""
+    rng = np.random.default_rng(seed)
+    edge_index, _ = rand_graph(rng, n, m, n_isolated, power, False)
+    out = {"edge_index": edge_index, "n": np.int64(n)}
+    for eps in eps_list:
+        r, c, v = reference_ppr(edge_index, n, eps)
+        tag = f"{eps:g}".replace("-", "m").replace(".", "p")
+        out[f"row_{tag}"], out[f"col_{tag}"], out[f"val_{tag}"] = r, c, v
+        print(f"[golden] {name}: eps={eps:g} nnz={r.size} ({r.size / n:.1f}/row)")
+    out["eps_list"] = np.array(eps_list, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+
+
+if __name__ == "__main__":
+    # mode "all", LN+ReLU, no residual, isolated nodes, PPR values jittered onto the thresholds
+    build_case("lp_all_d64", 1, n=320, m=900, f_in=24, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
+               eps=1e-3, bs=192, n_isolated=6, jitter=True)
+    # collab-like: integer edge weights, D=128, L=3, power-law degrees
+    build_case("lp_all_d128_weighted", 2, n=400, m=1600, f_in=40, dim=128, gnn_layers=3,
+               thresholds=(0, 1e-4, 1e-2), eps=5e-4, bs=160, weighted=True, power=0.8, n_isolated=3)
+    # ppa/citation2-like: residual (first layer F_in != D so no residual there), D=64, val edges at test time
+    build_case("lp_all_d64_residual_valtest", 3, n=360, m=1100, f_in=58, dim=64, gnn_layers=3,
+               thresholds=(0, 1e-3, 1e-2), eps=1e-3, bs=128, residual=True, power=0.5, val_in_test=True)
+    # ddi-like: dense neighbourhoods, mode "1-hop" (thresh_non1hop = 1), features already D wide, residual on all layers
+    build_case("lp_1hop_d64_dense", 4, n=150, m=3000, f_in=64, dim=64, gnn_layers=3, thresholds=(0, 6e-3, 1),
+               eps=2e-5, bs=96, residual=True)
+    # Cora-HeaRT-like: L=1, no LayerNorm, no ReLU, D=256 (replicate_heart.sh:4), eps 1e-4
+    build_case("lp_all_d256_noln", 5, n=260, m=520, f_in=96, dim=256, gnn_layers=1, thresholds=(0, 1e-2, 1e-2),
+               eps=1e-4, bs=96, layer_norm=False, relu=False, n_isolated=4, jitter=True)
+    build_ppr_case("ppr_push_small", 7, n=220, m=600, eps_list=[1e-3, 1e-4], n_isolated=5)
+    build_ppr_case("ppr_push_powerlaw", 8, n=300, m=1500, eps_list=[1e-3], power=0.9)
