@@ -1,0 +1,193 @@
+/*
+ * lpformer_hip.h -- C ABI of the MI355X (gfx950) LPFormer link-scoring library.
+ *
+ * Two shared objects export these symbols:
+ *   liblpformer_hip.so   (hipcc, --offload-arch=gfx950)  every entry point taking a stream
+ *   liblpformer_host.so  (g++ -fopenmp)                   lpf_ppr_push_cpu, lpf_host_free, lpf_host_abi_version
+ *
+ * The reference (HarryShomer/LPFormer) is 100 % Python and has no FFI of its own; each entry point
+ * below therefore cites the reference Python it replaces (paths relative to the reference repo root)
+ * and INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer (device pointers unless a name ends in
+ *     _host); no allocation, no exceptions, no hidden state: re-entrant per stream.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  Nothing synchronises the host
+ *     (graph-capturable) -- except the *_host functions, which run on the calling thread(s).
+ *   - return value: LPF_OK or a negative LPF_ERR_* code; lpf_strerror() names it.
+ *   - CSR graphs: rowptr int64[n+1], col int32[nnz] sorted ascending inside each row, no duplicates.
+ *   - feature matrices are row-major fp32 with an explicit leading dimension (in elements).
+ *   - fp32 rows handed to the GEMM must be 16-byte aligned with ld % 4 == 0.
+ */
+#ifndef LPFORMER_HIP_H
+#define LPFORMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPF_OK 0
+#define LPF_ERR_INVALID (-1)     /* bad argument (null pointer, size, alignment)        */
+#define LPF_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for        */
+#define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
+#define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
+
+#define LPF_ABI_VERSION 1
+
+/* GEMM / row-wise epilogue flags */
+#define LPF_FLAG_RELU 1u
+
+int lpf_abi_version(void);
+const char *lpf_strerror(int code);
+/* Last HIP runtime error string seen by this library on the calling thread ("" if none). */
+const char *lpf_last_hip_error(void);
+/* Fills cu_count / lds_bytes_per_cu / wave_size of the current device; LPF_ERR_NO_DEVICE if none. */
+int lpf_device_info(int *cu_count, int *lds_bytes_per_cu, int *wave_size, char *arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder (reference: src/models/other_models.py:61-76 GCN.forward -> torch_geometric GCNConv;
+ *          src/models/link_transformer.py:110-129 propagate)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* GCN symmetric normalisation on a CSR that already CONTAINS every diagonal entry
+ * (replaces torch_geometric.nn.conv.gcn_conv.gcn_norm, called from other_models.py:35,66):
+ *   w'_ij = (i==j ? 1 : w_ij);  deg_i = sum_j w'_ij;  w_out_ij = deg_i^-1/2 * w'_ij * deg_j^-1/2 (inf -> 0).
+ * w_in may be NULL (all ones).  dis_tmp: n floats of scratch (receives deg^-1/2). */
+int lpf_gcn_norm_csr(int64_t n, const int64_t *rowptr, const int32_t *col, const float *w_in,
+                     float *w_out, float *dis_tmp, void *stream);
+
+/* out[i,:] = epilogue( sum_j w_ij * H[col_ij,:] )   -- GCNConv.propagate + everything up to the next layer
+ * (other_models.py:66-74 and, for the last layer, link_transformer.py:127):
+ *   y = acc + bias;  if ln_g: y = LN(y; ln_g, ln_b);  if RELU: y = max(y,0);
+ *   if residual: y = residual[i,:] + y;  if ln2_g: y = LN(y; ln2_g, ln2_b)
+ * D % 4 == 0, D <= 256.  bias, ln_g, ln_b, residual, ln2_g, ln2_b may each be NULL. */
+int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
+                     const float *H, int64_t ldh, float *out, int64_t ldo, const float *bias,
+                     const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                     const float *ln2_g, const float *ln2_b, uint32_t flags, void *stream);
+
+/* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ addend[M,N]) (ReLU)   -- nn.Linear / PyG Linear:
+ * GCNConv.lin (other_models.py:66), lin_l / node half of lin_r (src/modules/layers.py:206-214),
+ * MLP linears (other_models.py:125-138), mlp_score (other_models.py:173-179).
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 accumulate.  lda, ldw % 4 == 0; bias/addend may be NULL. */
+int lpf_gemm_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W, int64_t ldw,
+                 const float *bias, const float *addend, int64_t ldadd, float *C, int64_t ldc,
+                 uint32_t flags, void *stream);
+
+/* y[i,:] = LN(x[i,:]; g, b) (then ReLU if flagged), in place allowed (nn.LayerNorm eps 1e-5, biased variance).
+ * other_models.py:131-132, layers.py:78.  D <= 1024. g/b NULL -> plain ReLU / identity. */
+int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *g, const float *b,
+                      float *y, int64_t ldy, uint32_t flags, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pair stage (reference: src/models/link_transformer.py:132-178 calc_pairwise and helpers)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* mul[k,:] = X[a_k,:] * X[b_k,:]  and  sum[k,:] = X[a_k,:] + X[b_k,:]   (link_transformer.py:101-102,143;
+ * layers.py:212-215 with lin_l hoisted: lin_l(xa)+lin_l(xb) = W_l(xa+xb) + 2 b_l).
+ * batch: int64 [2, bs] row-major (row 0 = a, row 1 = b) with row stride `batch_ld`.  mul or sum may be NULL. */
+int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, const float *X,
+                        int64_t ldx, float *mul, int64_t ldm, float *sum, int64_t lds, void *stream);
+
+/* Per-pair upper bound on staged entries and its exclusive scan (feeds lpf_select_nodes).
+ *   ub_k = 2*deg(a) + deg(b) + min(len T0[a], len T0[b])      (T0 = the CSR scanned for >1-hop nodes)
+ * stage_off: int64[bs+1] (stage_off[bs] = total).  t0_rowptr may be NULL (mode "1-hop": no >1-hop part). */
+int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
+                     const int64_t *t0_rowptr, int64_t *stage_off, void *stream);
+
+/* Node selection for a batch of pairs: compute_node_mask + get_ppr_vals + get_non_1hop_ppr
+ * (link_transformer.py:214-319,434-481), eval mode.  One wavefront per pair; integer/bit-exact.
+ *   adj_*     0/1 symmetric adjacency used for CN / 1-hop typing (data['adj_mask'] or the training override)
+ *   adjx_*    UNMASKED adjacency used to exclude neighbours from the >1-hop set (link_transformer.py:443);
+ *             pass the same arrays as adj_* in evaluation
+ *   ppr_*     PPR CSR (cols int32, vals fp32)
+ *   t0_*      CSR scanned for >1-hop candidates: either the PPR CSR itself or a per-theta_n prefiltered copy
+ *             (entries with fl32(fl32(p+1)-1) >= theta_n); NULL rowptr => skip (mode "1-hop")
+ * Staging layout for pair k at s = stage_off[k], dA = deg(a), dB = deg(b):
+ *   [s, s+dA)            CN run            (count stage_cnt[4k+0]) sorted by node
+ *   [s+dA, s+2dA)        1-hop run from N(a)\N(b) (stage_cnt[4k+1]) sorted
+ *   [s+2dA, s+2dA+dB)    1-hop run from N(b)\N(a) (stage_cnt[4k+2]) sorted
+ *   [s+2dA+dB, ...)      >1-hop run        (stage_cnt[4k+3]) sorted
+ * stage_node int32, stage_pa/pb fp32 (values AFTER the reference's fp32 round trip). */
+int lpf_select_nodes(int64_t bs, const int64_t *batch, int64_t batch_ld,
+                     const int64_t *adj_rowptr, const int32_t *adj_col,
+                     const int64_t *adjx_rowptr, const int32_t *adjx_col,
+                     const int64_t *ppr_rowptr, const int32_t *ppr_col, const float *ppr_val,
+                     const int64_t *t0_rowptr, const int32_t *t0_col, const float *t0_val,
+                     float th_cn, float th_1hop, float th_non1hop,
+                     const int64_t *stage_off, int32_t *stage_node, float *stage_pa, float *stage_pb,
+                     int32_t *stage_cnt, void *stream);
+
+/* Exclusive scans of the per-pair counts per type + totals:
+ *   type_ptr: int64[3*(bs+1)]  rows = (cn, 1-hop, >1-hop) ; type_ptr[t*(bs+1)+bs] = total of type t
+ *   counts_f: float[bs, ldc] receives the structural count features of get_structure_cnts
+ *             (link_transformer.py:340-356): n_cn, n_1hop, [n_non1hop if want_t0], n_cn+n_1hop */
+int lpf_select_scan(int64_t bs, const int32_t *stage_cnt, int64_t *type_ptr, float *counts_f, int64_t ldc,
+                    int32_t want_t0, void *stream);
+
+/* Compaction into the reference's layout: all CN entries sorted by (pair, node), then all 1-hop, then all
+ * >1-hop (link_transformer.py:161-162).  Entry e of type t lives at  type_base(t) + type_ptr[t][k] + j  with
+ * type_base = (0, total_cn, total_cn+total_1hop).  The two 1-hop runs are merged here. */
+int lpf_select_compact(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
+                       const int64_t *stage_off, const int32_t *stage_node, const float *stage_pa,
+                       const float *stage_pb, const int32_t *stage_cnt, const int64_t *type_ptr,
+                       int32_t *sel_pair, int32_t *sel_node, float *sel_pa, float *sel_pb, void *stream);
+
+/* Attention scores for every selected entry (layers.py:206-218 with get_pos_encodings
+ * link_transformer.py:182-211 folded in; algebra in DESIGN.md):
+ *   h_e = ReLU(LN_t(W1_t [pa,pb] + b1_t)) + ReLU(LN_t(W1_t [pb,pa] + b1_t))
+ *   k_e = Z[node_e] + Wfold_t h_e + bfold_t ;  score_e = sum_c att_c * leaky_relu(k_e,c * q[pair_e],c, 0.2)
+ * Host-prepared, parameter-only tables (lpformer_amd/fold.py builds them in float64, stores fp32):
+ *   pe_tab   float[3][D][4]  per type t and hidden unit k: (g_k (w0_k - mean w0), g_k (w1_k - mean w1),
+ *                            g_k (b_k - mean b), beta_k) -- first PE Linear with the LayerNorm centring folded in
+ *   pe_stat  float[3][8]     centred second moments over k of (w0, w1, b): C00, C11, Cbb, C01, C0b, C1b, 0, 0
+ *                            (LayerNorm variance of W1 [x,y] + b1 as a quadratic form in (x, y))
+ *   wfold_packed float[3][D/32][D/8][64][4]: element (t, c, sq, lane, u) = Wfold_t[32c + (lane&31)]
+ *                            [(lane>>5)*(D/2) + 4 sq + u]  with Wfold_t = W_r[:, D:] W2_t  (MFMA A-operand order)
+ *   bfold    float[3][D] = W_r[:, D:] (2 b2_t) ;  att float[D]
+ * The number of entries is read from type_ptr on the device; max_entries (host-side capacity) only sizes the grid.
+ * D in {32, 64, 128, 256}.  fp32 MFMA. */
+int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t bs, const int32_t *sel_pair,
+                        const int32_t *sel_node, const float *sel_pa, const float *sel_pb,
+                        const float *Z, int64_t ldz, const float *q, int64_t ldq,
+                        const float *pe_tab, const float *pe_stat, const float *wfold_packed, const float *bfold,
+                        const float *att, float *score, int64_t max_entries, void *stream);
+
+/* Per-pair segment softmax (PyG softmax: max-shift, denominator + 1e-16; layers.py:220) and the weighted sums
+ * that the output GEMM needs (layers.py:224 + scatter-sum):
+ *   G[k, 0:D]   = sum_e alpha_e Z[node_e]
+ *   G[k, (1+t)D : (2+t)D] = sum_{e of type t} alpha_e h_e          t = 0,1,2
+ *   G[k, 4D + t] = sum_{e of type t} alpha_e ;  G[k, 4D+3] = 1
+ * alpha_out (optional, NULL to skip): alpha per entry in the sel_* order (return_weights path, layers.py:73-75). */
+int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, const int32_t *sel_node,
+                                const float *sel_pa, const float *sel_pb, const float *score,
+                                const float *Z, int64_t ldz, const float *pe_tab, const float *pe_stat,
+                                float *G, int64_t ldg, float *alpha_out, void *stream);
+
+/* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
+ * logit or prob may be NULL. */
+int lpf_rowdot_sigmoid_f32(int64_t M, int32_t K, const float *A, int64_t lda, const float *w, float b,
+                           float *logit, float *prob, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host side (liblpformer_host.so)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Approximate personalised PageRank for every source node: calc_ppr (src/util/calc_ppr_scores.py:136-192)
+ * followed by create_sparse_ppr_matrix (:221-241).  Same LIFO push order and float64 arithmetic per source, so
+ * the produced index sets and fp32 values are bit-identical; OpenMP over sources (num_threads <= 0: all cores).
+ * indptr/indices: CSR of the coalesced directed edge list (get_ppr_matrix, :111-117), host memory.
+ * out_rowptr: caller-provided int64[n+1].  *out_col / *out_val: malloc'ed by the library, sized out_rowptr[n],
+ * rows sorted by column; release both with lpf_host_free. */
+int lpf_ppr_push_cpu(int64_t n, const int64_t *indptr_host, const int32_t *indices_host, double alpha, double eps,
+                     int64_t *out_rowptr_host, int32_t **out_col_host, float **out_val_host, int32_t num_threads);
+
+void lpf_host_free(void *p);
+int lpf_host_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPFORMER_HIP_H */

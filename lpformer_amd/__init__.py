@@ -1,0 +1,12 @@
+"""lpformer_amd -- MI355X-native LPFormer link-scoring forward pass (hand-written gfx950 HIP behind a C ABI).
+
+Public surface mirrors the reference (HarryShomer/LPFormer):
+    LinkTransformer, mlp_score          drop-ins for src/models/link_transformer.py / other_models.py
+    calc_ppr, get_ppr                   drop-ins for src/util/calc_ppr_scores.py (host C++/OpenMP push)
+    graph, data                         CSR containers and the data-dict builder
+"""
+from . import graph  # noqa: F401
+from .link_transformer import MLP, LinkTransformer, mlp_score  # noqa: F401
+from .ppr import calc_ppr, get_ppr  # noqa: F401
+
+__all__ = ["LinkTransformer", "mlp_score", "MLP", "calc_ppr", "get_ppr", "graph"]

@@ -1,0 +1,106 @@
+"""ctypes binding of the two C-ABI shared objects (include/lpformer_hip.h).
+
+There is no fallback: if ``liblpformer_hip.so`` is missing or a call fails, the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "liblpformer_hip.so")
+HOST_LIB_PATH = os.path.join(_HERE, "liblpformer_host.so")
+
+ABI_VERSION = 1
+FLAG_RELU = 1
+
+i32, i64, f32, f64, u32, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32, C.c_void_p
+
+# name -> argument types (every entry point returns int unless listed in _RESTYPE)
+HIP_PROTOTYPES = {
+    "lpf_abi_version": [],
+    "lpf_strerror": [C.c_int],
+    "lpf_last_hip_error": [],
+    "lpf_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
+    "lpf_gcn_norm_csr": [i64, vp, vp, vp, vp, vp, vp],
+    "lpf_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp],
+    "lpf_gemm_f32": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
+    "lpf_layernorm_f32": [i64, i32, vp, i64, vp, vp, vp, i64, u32, vp],
+    "lpf_pair_gather_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp],
+    "lpf_select_bound": [i64, vp, i64, vp, vp, vp, vp],
+    "lpf_select_nodes": [i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp],
+    "lpf_select_scan": [i64, vp, vp, vp, i64, i32, vp],
+    "lpf_select_compact": [i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
+    "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp],
+    "lpf_rowdot_sigmoid_f32": [i64, i32, vp, i64, vp, f32, vp, vp, vp],
+}
+HOST_PROTOTYPES = {
+    "lpf_ppr_push_cpu": [i64, vp, vp, f64, f64, vp, C.POINTER(vp), C.POINTER(vp), i32],
+    "lpf_host_free": [vp],
+    "lpf_host_abi_version": [],
+}
+_RESTYPE = {"lpf_strerror": C.c_char_p, "lpf_last_hip_error": C.c_char_p, "lpf_host_free": None}
+
+
+class LpfError(RuntimeError):
+    pass
+
+
+_hip = None
+_host = None
+
+
+def _bind(lib, protos):
+    for name, argtypes in protos.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    return lib
+
+
+def hip():
+    """The gfx950 kernel library.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise LpfError(f"{HIP_LIB_PATH} not found: build it with `make -C lpformer_amd/csrc` "
+                           "(or __graft_entry__.build()); lpformer_amd has no non-HIP fallback")
+        lib = _bind(C.CDLL(HIP_LIB_PATH), HIP_PROTOTYPES)
+        if lib.lpf_abi_version() != ABI_VERSION:
+            raise LpfError("liblpformer_hip.so ABI version mismatch; rebuild")
+        _hip = lib
+    return _hip
+
+
+def host():
+    """The host-side library (PPR producer)."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise LpfError(f"{HOST_LIB_PATH} not found: build it with `make -C lpformer_amd/csrc`")
+        lib = _bind(C.CDLL(HOST_LIB_PATH), HOST_PROTOTYPES)
+        if lib.lpf_host_abi_version() != ABI_VERSION:
+            raise LpfError("liblpformer_host.so ABI version mismatch; rebuild")
+        _host = lib
+    return _host
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        lib = hip()
+        msg = lib.lpf_strerror(rc).decode()
+        extra = lib.lpf_last_hip_error().decode()
+        raise LpfError(f"{what or 'lpformer_hip call'} failed: {msg}" + (f" [{extra}]" if extra else ""))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def device_info():
+    cu, lds, wave = C.c_int(), C.c_int(), C.c_int()
+    name = C.create_string_buffer(64)
+    check(hip().lpf_device_info(C.byref(cu), C.byref(lds), C.byref(wave), name, 64), "lpf_device_info")
+    return {"cu_count": cu.value, "lds_bytes_per_cu": lds.value, "wave_size": wave.value, "arch": name.value.decode()}

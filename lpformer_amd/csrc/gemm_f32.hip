@@ -1,0 +1,173 @@
+// fp32 GEMM on the gfx950 matrix cores:  C[M,N] = A[M,K] * W[N,K]^T (+bias) (+addend) (ReLU)
+//
+// v_mfma_f32_32x32x2_f32 (exact fp32 multiply-accumulate, 64 FLOP/clk/SIMD).  Both operands are K-contiguous
+// in memory (nn.Linear layout), so A and W tiles are staged the same way:
+//   global --float4--> registers --ds_write_b128--> LDS [rows][BK+4] --ds_read_b128--> MFMA operand registers
+// Inside a 32-wide K block lane (row = l&31, half = l>>5) owns k = 16*half + s for MFMA step s = 0..15 (any
+// bijection of k onto (step, half) is a valid summation order as long as A and W use the same one), which makes
+// every operand fetch a 16-byte LDS read; the +4 float row padding (144-byte stride) makes those reads
+// bank-conflict free.  Two LDS buffers, one barrier per K block, next tile's global loads in flight during the
+// MFMAs.  Block = 4 waves; wave w owns rows [32w, 32w+32) x all BN columns (BN/32 accumulators of 16 registers).
+#include "lpf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;  // padded LDS row stride (floats)
+
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int N, int K, const float *__restrict__ A,
+                                                       int64_t lda, const float *__restrict__ W, int64_t ldw,
+                                                       const float *__restrict__ bias,
+                                                       const float *__restrict__ addend, int64_t ldadd,
+                                                       float *__restrict__ C, int64_t ldc, uint32_t flags) {
+    constexpr int NT = BN / 32;            // accumulator tiles per wave
+    constexpr int A_F4 = BM * BK / 4 / 256;  // float4 loads per thread for the A tile (4)
+    constexpr int B_F4 = BN * BK / 4 / 256;  // for the W tile (4 or 2)
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    float4 ra[A_F4], rb[B_F4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < A_F4; ++r) {
+            int f = tid + 256 * r;
+            int row = f >> 3, c4 = f & 7;
+            int64_t m = m0 + row;
+            if (m >= M) m = M - 1;
+            int k = k0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K) {
+                v = *reinterpret_cast<const float4 *>(A + m * lda + k);
+                if (k + 3 >= K) {  // ragged K: zero what lies beyond it
+                    if (k + 1 >= K) v.y = 0.f;
+                    if (k + 2 >= K) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            ra[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < B_F4; ++r) {
+            int f = tid + 256 * r;
+            int row = f >> 3, c4 = f & 7;
+            int n = n0 + row;
+            if (n >= N) n = N - 1;
+            int k = k0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K) {
+                v = *reinterpret_cast<const float4 *>(W + (int64_t)n * ldw + k);
+                if (k + 3 >= K) {
+                    if (k + 1 >= K) v.y = 0.f;
+                    if (k + 2 >= K) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            rb[r] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float *As = lds + buf * (BM + BN) * LDK;
+        float *Bs = As + BM * LDK;
+#pragma unroll
+        for (int r = 0; r < A_F4; ++r) {
+            int f = tid + 256 * r;
+            *reinterpret_cast<float4 *>(As + (f >> 3) * LDK + 4 * (f & 7)) = ra[r];
+        }
+#pragma unroll
+        for (int r = 0; r < B_F4; ++r) {
+            int f = tid + 256 * r;
+            *reinterpret_cast<float4 *>(Bs + (f >> 3) * LDK + 4 * (f & 7)) = rb[r];
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    const int nkb = (K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) load_tiles((kb + 1) * BK);
+        const float *As = lds + buf * (BM + BN) * LDK + (wave * 32 + li) * LDK + lh * 16;
+        const float *Bs = lds + buf * (BM + BN) * LDK + BM * LDK + li * LDK + lh * 16;
+        float4 a4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a4[j] = *reinterpret_cast<const float4 *>(As + 4 * j);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            float4 b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4 *>(Bs + c * 32 * LDK + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc[c], 0, 0, 0);
+            }
+        }
+        if (kb + 1 < nkb) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: accumulator register r of lane (li, lh) is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li]
+    const bool relu = flags & LPF_FLAG_RELU;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int n = n0 + c * 32 + li;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= M) continue;
+            float v = acc[c][r] + bv;
+            if (addend) v += addend[m * ldadd + n];
+            if (relu) v = fmaxf(v, 0.f);
+            C[m * ldc + n] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lpf_gemm_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W,
+                            int64_t ldw, const float *bias, const float *addend, int64_t ldadd, float *C,
+                            int64_t ldc, uint32_t flags, void *stream) {
+    if (M == 0 || N == 0) return LPF_OK;
+    LPF_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && C);
+    LPF_REQUIRE(lda >= K && ldw >= K && ldc >= N && (lda & 3) == 0 && (ldw & 3) == 0);
+    LPF_REQUIRE(lpf_aligned16(A) && lpf_aligned16(W));
+    LPF_REQUIRE(!addend || ldadd >= N);
+    LPF_REQUIRE((M + BM - 1) / BM < (1ll << 31));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // pick the column tile that wastes fewer padded columns
+    const int pad128 = ((N + 127) / 128) * 128 - N, pad64 = ((N + 63) / 64) * 64 - N;
+    if (pad64 < pad128) {
+        dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + 63) / 64));
+        hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, s, M, N, K, A, lda, W, ldw, bias, addend, ldadd,
+                           C, ldc, flags);
+    } else {
+        dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + 127) / 128));
+        hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(256), 0, s, M, N, K, A, lda, W, ldw, bias, addend,
+                           ldadd, C, ldc, flags);
+    }
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -1,0 +1,51 @@
+// Shared helpers for the gfx950 kernels (wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lpformer_hip.h"
+
+#define LPF_WAVE 64
+
+void lpf_set_hip_error(hipError_t e);
+
+#define LPF_CHECK_LAUNCH()                      \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) {                \
+            lpf_set_hip_error(e__);             \
+            return LPF_ERR_LAUNCH;              \
+        }                                       \
+    } while (0)
+
+#define LPF_REQUIRE(cond)                 \
+    do {                                  \
+        if (!(cond)) return LPF_ERR_INVALID; \
+    } while (0)
+
+static inline bool lpf_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ int lpf_lane() { return (int)(threadIdx.x & 63); }
+
+// xor-butterfly reductions over the low `WIDTH` lanes of each aligned group (WIDTH power of two <= 64)
+template <int WIDTH>
+__device__ __forceinline__ float lpf_group_sum(float v) {
+#pragma unroll
+    for (int m = WIDTH >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float lpf_group_max(float v) {
+#pragma unroll
+    for (int m = WIDTH >> 1; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// first index i in [lo, hi) with a[i] >= key (a sorted ascending); returns hi if none
+__device__ __forceinline__ int64_t lpf_lower_bound(const int32_t *__restrict__ a, int64_t lo, int64_t hi, int32_t key) {
+    while (lo < hi) {
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}

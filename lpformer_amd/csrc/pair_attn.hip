@@ -1,0 +1,267 @@
+// Pairwise PPR-positional attention (src/modules/layers.py:161-224 + get_pos_encodings, link_transformer.py:182-211)
+// restructured so that the per-entry key vector k_e is never written to memory (algebra in DESIGN.md):
+//
+//   phase A  lpf_pair_scores_f32          score_e = att . leaky_relu((Z[v_e] + Wfold_t h_e + bfold_t) * q[pair_e])
+//            tiles of 32 same-type entries; h_e (first PE layer + LayerNorm + ReLU, both argument orders) is
+//            generated in registers as the B operand of v_mfma_f32_32x32x2_f32, Wfold_t streams in as the A operand
+//            from a pre-packed image (one contiguous 1 KiB wave read per 4 MFMA steps), accumulators hold
+//            k_e^T = [feature][entry]; the epilogue gathers Z / q rows in 16-byte pieces and reduces over features
+//            in-lane (+ one cross-half shuffle).  Bound: fp32 MFMA (2*D*D FLOP per entry).
+//   phase B  lpf_pair_softmax_gather_f32  per-pair segment softmax, then the alpha-weighted sums of Z rows and of
+//            h_e per type; a group of D/4 lanes owns a pair (16-byte pieces of each row).  Bound: gather bandwidth.
+//   phase C  is a plain GEMM (lpf_gemm_f32) on [sum alpha h_e | sum alpha | 1] with [Wfold | bfold | bias].
+#include "lpf_common.h"
+
+
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PeStat {
+    float c00, c11, cbb, c01, c0b, c1b;
+};
+
+// LayerNorm statistics of u_k = w0_k*x + w1_k*y + b_k over k, from the centred second moments of (w0, w1, b):
+// mean-free by construction (pe_tab already holds centred, gamma-scaled coefficients), so only 1/std is needed.
+__device__ __forceinline__ float pe_rstd(const PeStat &s, float x, float y) {
+    const float var = s.c00 * x * x + s.c11 * y * y + s.cbb + 2.0f * (s.c01 * x * y + s.c0b * x + s.c1b * y);
+    return 1.0f / sqrtf(fmaxf(var, 0.0f) + 1e-5f);
+}
+
+__device__ __forceinline__ float pe_hidden(const float4 k, float pa, float pb, float r_ab, float r_ba) {
+    const float u_ab = fmaf(k.x, pa, fmaf(k.y, pb, k.z));
+    const float u_ba = fmaf(k.x, pb, fmaf(k.y, pa, k.z));
+    return fmaxf(fmaf(r_ab, u_ab, k.w), 0.0f) + fmaxf(fmaf(r_ba, u_ba, k.w), 0.0f);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void pair_scores_kernel(
+    const int64_t *__restrict__ type_ptr, int64_t bs, const int32_t *__restrict__ sel_pair,
+    const int32_t *__restrict__ sel_node, const float *__restrict__ sel_pa, const float *__restrict__ sel_pb,
+    const float *__restrict__ Z, int64_t ldz, const float *__restrict__ q, int64_t ldq,
+    const float *__restrict__ pe_tab, const float *__restrict__ pe_stat, const float *__restrict__ wpk,
+    const float *__restrict__ bfold, const float *__restrict__ att, float *__restrict__ score) {
+    constexpr int D = 32 * NT;
+    constexpr int NSQ = D / 8;  // groups of 4 MFMA steps (each step consumes 2 values of k)
+    __shared__ float4 tab[3 * D];
+    for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) tab[i] = reinterpret_cast<const float4 *>(pe_tab)[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int lj = lane & 31, lh = lane >> 5;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n0 = type_ptr[bs], n1 = type_ptr[(bs + 1) + bs], n2 = type_ptr[2 * (bs + 1) + bs];
+    const int64_t t0 = (n0 + 31) >> 5, t1 = (n1 + 31) >> 5, t2 = (n2 + 31) >> 5;
+
+    for (int64_t tile = wave_id; tile < t0 + t1 + t2; tile += n_waves) {
+        int t;
+        int64_t idx, base, cnt;
+        if (tile < t0) { t = 0; idx = tile; base = 0; cnt = n0; }
+        else if (tile < t0 + t1) { t = 1; idx = tile - t0; base = n0; cnt = n1; }
+        else { t = 2; idx = tile - t0 - t1; base = n0 + n1; cnt = n2; }
+        const int64_t within = idx * 32 + lj;
+        const bool valid = within < cnt;
+        const int64_t e = base + within;
+        const float pa = valid ? sel_pa[e] : 0.f, pb = valid ? sel_pb[e] : 0.f;
+        const int32_t node = valid ? sel_node[e] : 0, pr = valid ? sel_pair[e] : 0;
+
+        PeStat st;
+        st.c00 = pe_stat[8 * t + 0]; st.c11 = pe_stat[8 * t + 1]; st.cbb = pe_stat[8 * t + 2];
+        st.c01 = pe_stat[8 * t + 3]; st.c0b = pe_stat[8 * t + 4]; st.c1b = pe_stat[8 * t + 5];
+        const float r_ab = pe_rstd(st, pa, pb), r_ba = pe_rstd(st, pb, pa);
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+        const float4 *wp = reinterpret_cast<const float4 *>(wpk) + (int64_t)t * NT * NSQ * 64 + lane;
+        const float4 *tb = tab + t * D + lh * (D / 2);
+        for (int sq = 0; sq < NSQ; ++sq) {
+            float4 wa[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) wa[c] = wp[(c * NSQ + sq) * 64];
+            float h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h[u] = pe_hidden(tb[4 * sq + u], pa, pb, r_ab, r_ba);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].x, h[0], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].y, h[1], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].z, h[2], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].w, h[3], acc[c], 0, 0, 0);
+            }
+        }
+        // acc[c][4g+u] = (Wfold_t h_e)[feature 32c + 8g + 4*lh + u] for entry lj
+        const float *zrow = Z + (int64_t)node * ldz;
+        const float *qrow = q + (int64_t)pr * ldq;
+        const float *bf = bfold + t * D;
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = 32 * c + 8 * g + 4 * lh;
+                const float4 z4 = *reinterpret_cast<const float4 *>(zrow + f0);
+                const float4 q4 = *reinterpret_cast<const float4 *>(qrow + f0);
+                const float4 b4 = *reinterpret_cast<const float4 *>(bf + f0);
+                const float4 a4 = *reinterpret_cast<const float4 *>(att + f0);
+                const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float x = (acc[c][4 * g + u] + zz[u] + bb[u]) * qq[u];
+                    x = x > 0.f ? x : 0.2f * x;
+                    part = fmaf(x, aa[u], part);
+                }
+            }
+        }
+        part += __shfl_xor(part, 32, 64);
+        if (valid && lh == 0) score[e] = part;
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
+    int D, int64_t bs, const int64_t *__restrict__ type_ptr, const int32_t *__restrict__ sel_node,
+    const float *__restrict__ sel_pa, const float *__restrict__ sel_pb, const float *__restrict__ score,
+    const float *__restrict__ Z, int64_t ldz, const float *__restrict__ pe_tab, const float *__restrict__ pe_stat,
+    float *__restrict__ Gout, int64_t ldg, float *__restrict__ alpha_out) {
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G, lig = lane % G;
+    const int off = 4 * lig;
+    const bool act = off < D;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t tot0 = type_ptr[bs], tot1 = type_ptr[(bs + 1) + bs];
+    const int64_t tbase[3] = {0, tot0, tot0 + tot1};
+
+    for (int64_t p0 = wave_id * RPW; p0 < bs; p0 += n_waves * RPW) {
+        const int64_t p = p0 + grp;
+        const bool live = p < bs;
+        int64_t beg[3];
+        int cnt[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int64_t lo = live ? type_ptr[t * (bs + 1) + p] : 0, hi = live ? type_ptr[t * (bs + 1) + p + 1] : 0;
+            beg[t] = tbase[t] + lo;
+            cnt[t] = (int)(hi - lo);
+        }
+        // segment softmax statistics over all of the pair's entries (PyG softmax: shift by max, denom + 1e-16)
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            for (int i = lig; i < cnt[t]; i += G) m = fmaxf(m, score[beg[t] + i]);
+        m = lpf_group_max<G>(m);
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            for (int i = lig; i < cnt[t]; i += G) den += expf(score[beg[t] + i] - m);
+        den = lpf_group_sum<G>(den) + 1e-16f;
+
+        float4 accz = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acch[3];
+        float asum[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            acch[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            asum[t] = 0.f;
+            if (cnt[t] == 0) continue;
+            PeStat st;
+            st.c00 = pe_stat[8 * t + 0]; st.c11 = pe_stat[8 * t + 1]; st.cbb = pe_stat[8 * t + 2];
+            st.c01 = pe_stat[8 * t + 3]; st.c0b = pe_stat[8 * t + 4]; st.c1b = pe_stat[8 * t + 5];
+            float4 k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                k[u] = act ? reinterpret_cast<const float4 *>(pe_tab)[t * D + off + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < cnt[t]; ++i) {
+                const int64_t e = beg[t] + i;
+                const float alpha = expf(score[e] - m) / den;
+                const float pa = sel_pa[e], pb = sel_pb[e];
+                const int32_t node = sel_node[e];
+                const float r_ab = pe_rstd(st, pa, pb), r_ba = pe_rstd(st, pb, pa);
+                if (act) {
+                    const float4 z = *reinterpret_cast<const float4 *>(Z + (int64_t)node * ldz + off);
+                    accz.x = fmaf(alpha, z.x, accz.x); accz.y = fmaf(alpha, z.y, accz.y);
+                    accz.z = fmaf(alpha, z.z, accz.z); accz.w = fmaf(alpha, z.w, accz.w);
+                    acch[t].x = fmaf(alpha, pe_hidden(k[0], pa, pb, r_ab, r_ba), acch[t].x);
+                    acch[t].y = fmaf(alpha, pe_hidden(k[1], pa, pb, r_ab, r_ba), acch[t].y);
+                    acch[t].z = fmaf(alpha, pe_hidden(k[2], pa, pb, r_ab, r_ba), acch[t].z);
+                    acch[t].w = fmaf(alpha, pe_hidden(k[3], pa, pb, r_ab, r_ba), acch[t].w);
+                }
+                asum[t] += alpha;
+                if (alpha_out && lig == 0) alpha_out[e] = alpha;
+            }
+        }
+        if (live) {
+            float *g = Gout + p * ldg;
+            if (act) {
+                *reinterpret_cast<float4 *>(g + off) = accz;
+                *reinterpret_cast<float4 *>(g + D + off) = acch[0];
+                *reinterpret_cast<float4 *>(g + 2 * D + off) = acch[1];
+                *reinterpret_cast<float4 *>(g + 3 * D + off) = acch[2];
+            }
+            if (lig == 0) *reinterpret_cast<float4 *>(g + 4 * D) = make_float4(asum[0], asum[1], asum[2], 1.0f);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t bs, const int32_t *sel_pair,
+                                   const int32_t *sel_node, const float *sel_pa, const float *sel_pb, const float *Z,
+                                   int64_t ldz, const float *q, int64_t ldq, const float *pe_tab,
+                                   const float *pe_stat, const float *wfold_packed, const float *bfold,
+                                   const float *att, float *score, int64_t max_entries, void *stream) {
+    if (bs == 0 || max_entries == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && type_ptr && sel_pair && sel_node && sel_pa && sel_pb && Z && q && pe_tab && pe_stat &&
+                wfold_packed && bfold && att && score && max_entries > 0);
+    LPF_REQUIRE((ldz & 3) == 0 && (ldq & 3) == 0 && ldz >= D && ldq >= D && lpf_aligned16(Z) && lpf_aligned16(q) &&
+                lpf_aligned16(pe_tab) && lpf_aligned16(wfold_packed) && lpf_aligned16(bfold) && lpf_aligned16(att));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the entry count lives on the device; size the grid from the host-side capacity and let waves stride over tiles
+    int64_t tiles = (max_entries + 31) / 32 + 3;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+#define LPF_SCORES_LAUNCH(NT)                                                                                      \
+    hipLaunchKernelGGL(pair_scores_kernel<NT>, dim3((unsigned)blocks), dim3(256), 0, s, type_ptr, bs, sel_pair,    \
+                       sel_node, sel_pa, sel_pb, Z, ldz, q, ldq, pe_tab, pe_stat, wfold_packed, bfold, att, score)
+    switch (D) {
+        case 32: LPF_SCORES_LAUNCH(1); break;
+        case 64: LPF_SCORES_LAUNCH(2); break;
+        case 128: LPF_SCORES_LAUNCH(4); break;
+        case 256: LPF_SCORES_LAUNCH(8); break;
+        default: return LPF_ERR_UNSUPPORTED;
+    }
+#undef LPF_SCORES_LAUNCH
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+extern "C" int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, const int32_t *sel_node,
+                                           const float *sel_pa, const float *sel_pb, const float *score,
+                                           const float *Z, int64_t ldz, const float *pe_tab, const float *pe_stat,
+                                           float *G, int64_t ldg, float *alpha_out, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && type_ptr && sel_node && sel_pa && sel_pb && score && Z && pe_tab && pe_stat && G);
+    if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
+    LPF_REQUIRE((ldz & 3) == 0 && ldz >= D && (ldg & 3) == 0 && ldg >= 4 * D + 4 && lpf_aligned16(Z) &&
+                lpf_aligned16(G) && lpf_aligned16(pe_tab));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int GG = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
+    int64_t blocks = (bs + 4 * (64 / GG) - 1) / (4 * (64 / GG));
+    if (blocks > 256 * 32) blocks = 256 * 32;
+#define LPF_SG_LAUNCH(GV)                                                                                       \
+    hipLaunchKernelGGL(pair_softmax_gather_kernel<GV>, dim3((unsigned)blocks), dim3(256), 0, s, D, bs, type_ptr, \
+                       sel_node, sel_pa, sel_pb, score, Z, ldz, pe_tab, pe_stat, G, ldg, alpha_out)
+    if (GG == 16) LPF_SG_LAUNCH(16);
+    else if (GG == 32) LPF_SG_LAUNCH(32);
+    else LPF_SG_LAUNCH(64);
+#undef LPF_SG_LAUNCH
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -1,0 +1,174 @@
+// GCN aggregation on gfx950: CSR SpMM with the whole per-layer epilogue fused, plus the one-time GCN normalisation.
+//
+// Layout: a row of D fp32 features is covered by G = D/4 lanes (16 B per lane, so one row read is one or two full
+// 128-byte lines per group); a 64-lane wave therefore works on 64/G rows at once (D=64 -> 4 rows, D=128 -> 2,
+// D=256 -> 1).  A group reads G edge (col, weight) pairs with one coalesced load, then broadcasts them lane by lane
+// (ds_bpermute) and gathers the neighbour rows four at a time so four 16-byte gathers are always in flight.  The
+// accumulator never leaves registers: bias, LayerNorm (group-wide butterfly reduction), ReLU, residual and the
+// final `gnn_norm` LayerNorm are applied before the single store.  Bound: HBM / L2 gather bandwidth.
+#include "lpf_common.h"
+
+namespace {
+
+template <int G>
+__device__ __forceinline__ float4 group_layernorm(float4 y, bool act, int D, const float *__restrict__ g,
+                                                  const float *__restrict__ b, int off) {
+    float s = act ? (y.x + y.y + y.z + y.w) : 0.f;
+    const float mean = lpf_group_sum<G>(s) / (float)D;
+    float4 d = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
+    float q = act ? (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) : 0.f;
+    const float var = lpf_group_sum<G>(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (act) {
+        const float4 gg = *reinterpret_cast<const float4 *>(g + off);
+        const float4 bb = *reinterpret_cast<const float4 *>(b + off);
+        y.x = d.x * rstd * gg.x + bb.x;
+        y.y = d.y * rstd * gg.y + bb.y;
+        y.z = d.z * rstd * gg.z + bb.z;
+        y.w = d.w * rstd * gg.w + bb.w;
+    }
+    return y;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const int64_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ col, const float *__restrict__ w,
+                                                       const float *__restrict__ H, int64_t ldh,
+                                                       float *__restrict__ out, int64_t ldo,
+                                                       const float *__restrict__ bias, const float *__restrict__ ln_g,
+                                                       const float *__restrict__ ln_b,
+                                                       const float *__restrict__ residual, int64_t ldr,
+                                                       const float *__restrict__ ln2_g,
+                                                       const float *__restrict__ ln2_b, uint32_t flags) {
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G, lig = lane % G;
+    const int gbase = grp * G;
+    const int off = 4 * lig;
+    const bool act = off < D;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+
+    for (int64_t row0 = wave_id * RPW; row0 < n; row0 += n_waves * RPW) {
+        const int64_t row = row0 + grp;
+        const bool live = row < n;
+        int64_t e0 = 0, e1 = 0;
+        if (live) {
+            e0 = rowptr[row];
+            e1 = rowptr[row + 1];
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t e = e0; e < e1; e += G) {
+            const int64_t mine = e + lig;
+            int32_t c = 0;
+            float wv = 0.f;
+            if (mine < e1) {
+                c = col[mine];
+                wv = w[mine];
+            }
+            const int cnt = (int)((e1 - e) < G ? (e1 - e) : G);
+            for (int t = 0; t < cnt; t += 4) {  // lanes past `cnt` carry (col 0, weight 0): harmless gathers
+                int32_t cc[4];
+                float ww[4];
+                float4 h[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    cc[u] = __shfl(c, gbase + ((t + u) & (G - 1)), 64);
+                    ww[u] = (t + u < G) ? __shfl(wv, gbase + ((t + u) & (G - 1)), 64) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    h[u] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x = fmaf(ww[u], h[u].x, acc.x);
+                    acc.y = fmaf(ww[u], h[u].y, acc.y);
+                    acc.z = fmaf(ww[u], h[u].z, acc.z);
+                    acc.w = fmaf(ww[u], h[u].w, acc.w);
+                }
+            }
+        }
+        // ---- fused epilogue (GCN.forward lines after conv(); propagate's gnn_norm for the last layer)
+        float4 y = acc;
+        if (bias && act) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + off);
+            y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+        }
+        if (ln_g) y = group_layernorm<G>(y, act, D, ln_g, ln_b, off);
+        if (flags & LPF_FLAG_RELU) {
+            y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+        }
+        if (residual && act && live) {
+            const float4 rv = *reinterpret_cast<const float4 *>(residual + row * ldr + off);
+            y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
+        }
+        if (ln2_g) y = group_layernorm<G>(y, act, D, ln2_g, ln2_b, off);
+        if (act && live) *reinterpret_cast<float4 *>(out + row * ldo + off) = y;
+    }
+}
+
+// deg^-1/2 with the diagonal forced to weight 1 (torch_sparse.fill_diag semantics)
+__global__ void gcn_deg_kernel(int64_t n, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                               const float *__restrict__ w, float *__restrict__ dis) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float deg = 0.f;
+    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) deg += (col[e] == i) ? 1.0f : (w ? w[e] : 1.0f);
+    float d = powf(deg, -0.5f);
+    dis[i] = isinf(d) ? 0.f : d;
+}
+
+__global__ void gcn_scale_kernel(int64_t n, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                 const float *__restrict__ w, const float *__restrict__ dis,
+                                 float *__restrict__ w_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float di = dis[i];
+    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const int32_t c = col[e];
+        const float v = (c == i) ? 1.0f : (w ? w[e] : 1.0f);
+        w_out[e] = (v * di) * dis[c];  // same association as gcn_norm: (w * dis[row]) * dis[col]
+    }
+}
+
+}  // namespace
+
+extern "C" int lpf_gcn_norm_csr(int64_t n, const int64_t *rowptr, const int32_t *col, const float *w_in,
+                                float *w_out, float *dis_tmp, void *stream) {
+    if (n == 0) return LPF_OK;
+    LPF_REQUIRE(n > 0 && rowptr && col && w_out && dis_tmp);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(gcn_deg_kernel, dim3(blocks), dim3(256), 0, s, n, rowptr, col, w_in, dis_tmp);
+    hipLaunchKernelGGL(gcn_scale_kernel, dim3(blocks), dim3(256), 0, s, n, rowptr, col, w_in, dis_tmp, w_out);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+extern "C" int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
+                                const float *H, int64_t ldh, float *out, int64_t ldo, const float *bias,
+                                const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                                const float *ln2_g, const float *ln2_b, uint32_t flags, void *stream) {
+    if (n == 0) return LPF_OK;
+    LPF_REQUIRE(n > 0 && rowptr && col && w && H && out);
+    if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
+    LPF_REQUIRE(ldh >= D && ldo >= D && (ldh & 3) == 0 && (ldo & 3) == 0 && lpf_aligned16(H) && lpf_aligned16(out));
+    LPF_REQUIRE((!ln_g) == (!ln_b) && (!ln2_g) == (!ln2_b));
+    LPF_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= D && lpf_aligned16(residual)));
+    LPF_REQUIRE(!bias || lpf_aligned16(bias));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int G = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
+    const int rpw = 64 / G;
+    int64_t blocks = (n + 4 * rpw - 1) / (4 * rpw);
+    if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond ~32 blocks per CU
+#define LPF_SPMM_LAUNCH(GG)                                                                                        \
+    hipLaunchKernelGGL(spmm_csr_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr, col, w, H, ldh, \
+                       out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags)
+    if (G == 16) LPF_SPMM_LAUNCH(16);
+    else if (G == 32) LPF_SPMM_LAUNCH(32);
+    else LPF_SPMM_LAUNCH(64);
+#undef LPF_SPMM_LAUNCH
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -1,0 +1,77 @@
+"""Parameter-only precomputation for the fused attention kernels (float64 on the host, stored as fp32).
+
+The reference evaluates, per selected node e of type t (src/models/link_transformer.py:182-211,
+src/modules/layers.py:206-218):
+
+    pe_e = g_t([pa,pb]) + g_t([pb,pa]),   g_t(x) = W2_t ReLU(LN_t(W1_t x + b1_t)) + b2_t
+    k_e  = W_r [X[v_e] ; pe_e] + b_r
+
+Writing W_r = [W_rx | W_rp] this is   k_e = Z[v_e] + Wfold_t h_e + bfold_t   with
+
+    Z      = X W_rx^T + b_r                         (once per encoder run, a GEMM)
+    h_e    = ReLU(LN_t(W1_t [pa,pb] + b1_t)) + ReLU(LN_t(W1_t [pb,pa] + b1_t))
+    Wfold_t = W_rp W2_t ,  bfold_t = W_rp (2 b2_t)
+
+and LN_t of the 2-input first layer has closed-form statistics: with u_k = w0_k x + w1_k y + b_k,
+mean_k u = m0 x + m1 y + mb and var_k u is the quadratic form of the centred second moments of (w0, w1, b).
+The tables below carry exactly those quantities (layouts documented in include/lpformer_hip.h).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+PE_KEYS = ("ppr_encoder_cn", "ppr_encoder_onehop", "ppr_encoder_non1hop")
+
+
+def _f64(t):
+    return t.detach().cpu().double().numpy()
+
+
+def pe_tables(state: dict, dim: int, n_types: int):
+    """pe_tab float32[3, D, 4], pe_stat float32[3, 8] from the ``ppr_encoder_*`` MLP parameters."""
+    tab = np.zeros((3, dim, 4), np.float64)
+    stat = np.zeros((3, 8), np.float64)
+    for t in range(n_types):
+        k = PE_KEYS[t]
+        w1, b1 = _f64(state[f"{k}.linears.0.weight"]), _f64(state[f"{k}.linears.0.bias"])  # [D,2], [D]
+        g, be = _f64(state[f"{k}.norm.weight"]), _f64(state[f"{k}.norm.bias"])
+        w0c, w1c, bc = w1[:, 0] - w1[:, 0].mean(), w1[:, 1] - w1[:, 1].mean(), b1 - b1.mean()
+        tab[t, :, 0], tab[t, :, 1], tab[t, :, 2], tab[t, :, 3] = g * w0c, g * w1c, g * bc, be
+        stat[t, :6] = [(w0c * w0c).mean(), (w1c * w1c).mean(), (bc * bc).mean(), (w0c * w1c).mean(),
+                       (w0c * bc).mean(), (w1c * bc).mean()]
+    return tab.astype(np.float32), stat.astype(np.float32)
+
+
+def fold_attention(state: dict, dim: int, n_types: int, prefix="att_layers.0.att"):
+    """Returns dict of fp32 arrays: w_rx [D,D], b_r [D], wfold [3,D,D], bfold [3,D], wfold_packed (MFMA A-operand
+    order), wcat [D, 3D+4] = [Wfold_0 | Wfold_1 | Wfold_2 | bfold_0 bfold_1 bfold_2 | att bias], w_l, b_l2 = 2 b_l."""
+    w_r, b_r = _f64(state[f"{prefix}.lin_r.weight"]), _f64(state[f"{prefix}.lin_r.bias"])
+    w_l, b_l = _f64(state[f"{prefix}.lin_l.weight"]), _f64(state[f"{prefix}.lin_l.bias"])
+    att, bias = _f64(state[f"{prefix}.att"]).reshape(-1), _f64(state[f"{prefix}.bias"])
+    assert w_r.shape == (dim, 2 * dim) and att.size == dim, "HIP path supports num_heads=1, one attention layer"
+    w_rx, w_rp = w_r[:, :dim], w_r[:, dim:]
+    wfold = np.zeros((3, dim, dim))
+    bfold = np.zeros((3, dim))
+    for t in range(n_types):
+        k = PE_KEYS[t]
+        w2, b2 = _f64(state[f"{k}.linears.1.weight"]), _f64(state[f"{k}.linears.1.bias"])
+        wfold[t] = w_rp @ w2
+        bfold[t] = w_rp @ (2.0 * b2)
+    wcat = np.concatenate([wfold[0], wfold[1], wfold[2], bfold.T, bias[:, None]], axis=1)  # [D, 3D+4]
+    return {
+        "w_rx": w_rx.astype(np.float32), "b_r": b_r.astype(np.float32),
+        "w_l": w_l.astype(np.float32), "b_l2": (2.0 * b_l).astype(np.float32),
+        "att": att.astype(np.float32), "wfold": wfold.astype(np.float32), "bfold": bfold.astype(np.float32),
+        "wfold_packed": pack_wfold(wfold.astype(np.float32)), "wcat": np.ascontiguousarray(wcat.astype(np.float32)),
+    }
+
+
+def pack_wfold(wfold: np.ndarray) -> np.ndarray:
+    """[3, D, D] (out, in) -> [3, D/32, D/8, 64, 4]: element (t, c, sq, lane, u) =
+    wfold[t, 32c + (lane & 31), (lane >> 5) * (D/2) + 4 sq + u]   (A operand of v_mfma_f32_32x32x2_f32, lane
+    (row, half) consuming k = half*D/2 + step)."""
+    _, d, _ = wfold.shape
+    nt, nsq = d // 32, d // 8
+    w = wfold.reshape(3, nt, 32, 2, nsq, 4)          # t, c, row, half, sq, u
+    w = w.transpose(0, 1, 4, 3, 2, 5)                 # t, c, sq, half, row, u
+    return np.ascontiguousarray(w.reshape(3, nt, nsq, 64, 4))

@@ -1,0 +1,148 @@
+"""CSR graph containers and builders (host side).
+
+The reference keeps its graph state as ``torch_sparse.SparseTensor`` / torch sparse COO tensors and materialises
+BS x N COO temporaries per batch (src/util/read_datasets.py:85-129, src/models/link_transformer.py:229-237).
+The MI355X path keeps three CSR structures with sorted int32 columns resident in HBM instead:
+
+* the GCN-normalised propagation matrix (diagonal forced to 1, ``gcn_norm`` semantics),
+* the 0/1 symmetric adjacency mask,
+* the PPR matrix (fp32 values), plus an optional per-threshold prefiltered copy for the >1-hop candidates.
+
+Everything here is one-time data preparation (the reference's ``cached=True`` / dataset-loading analogue).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+
+
+@dataclass
+class CSR:
+    """Host CSR: rowptr int64[n+1], col int32[nnz] sorted inside rows, optional fp32 values."""
+    rowptr: np.ndarray
+    col: np.ndarray
+    val: Optional[np.ndarray]
+    n: int
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.size)
+
+    def to_device(self, device) -> "DeviceCSR":
+        return DeviceCSR(torch.from_numpy(self.rowptr).to(device), torch.from_numpy(self.col).to(device),
+                         None if self.val is None else torch.from_numpy(self.val).to(device), self.n, self)
+
+    def to_torch_sparse_coo(self) -> torch.Tensor:
+        """Same object type the reference stores in data['ppr'] / data['adj_mask']."""
+        rows = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(self.rowptr))
+        idx = torch.from_numpy(np.stack([rows, self.col.astype(np.int64)]))
+        v = torch.ones(self.nnz) if self.val is None else torch.from_numpy(self.val)
+        return torch.sparse_coo_tensor(idx, v, (self.n, self.n)).coalesce()
+
+
+@dataclass
+class DeviceCSR:
+    rowptr: torch.Tensor  # int64
+    col: torch.Tensor     # int32
+    val: Optional[torch.Tensor]
+    n: int
+    host: Optional[CSR] = None
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.numel())
+
+
+def _from_scipy(m: sp.spmatrix, n: int, keep_val: bool) -> CSR:
+    m = m.tocsr()
+    m.sum_duplicates()
+    m.sort_indices()
+    return CSR(m.indptr.astype(np.int64), m.indices.astype(np.int32),
+               m.data.astype(np.float32) if keep_val else None, n)
+
+
+def csr_from_coo(row, col, val, n: int, *, keep_val=True) -> CSR:
+    """Sorted CSR from COO triplets; duplicate entries are summed (torch ``coalesce`` semantics)."""
+    row = np.asarray(row, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    data = np.ones(row.size, np.float32) if val is None else np.asarray(val, dtype=np.float32)
+    return _from_scipy(sp.coo_matrix((data, (row, col)), shape=(n, n)), n, keep_val and val is not None)
+
+
+def mask_csr(edge_index, n: int, *, symmetric=True) -> CSR:
+    """0/1 adjacency pattern.  symmetric=True mirrors ``adj_t.to_symmetric()...coalesce().bool().int()``
+    (src/util/read_datasets.py:88-95); False mirrors the un-symmetrised variants (:109-110, :234-235)."""
+    ei = np.asarray(edge_index, dtype=np.int64)
+    r, c = ei[0], ei[1]
+    if symmetric:
+        r, c = np.concatenate([r, c]), np.concatenate([c, r])
+    return csr_from_coo(r, c, None, n)
+
+
+def gcn_structure_csr(edge_index, edge_weight, n: int) -> CSR:
+    """Structure the GCN normalisation works on: off-diagonal entries (duplicates summed) plus EVERY diagonal
+    entry (``fill_diag`` replaces existing self-loops).  Values are the raw weights; the diagonal value is a
+    placeholder that ``lpf_gcn_norm_csr`` overrides with 1."""
+    ei = np.asarray(edge_index, dtype=np.int64)
+    w = np.ones(ei.shape[1], np.float32) if edge_weight is None else np.asarray(edge_weight, np.float32).reshape(-1)
+    off = ei[0] != ei[1]
+    d = np.arange(n, dtype=np.int64)
+    return csr_from_coo(np.concatenate([ei[0][off], d]), np.concatenate([ei[1][off], d]),
+                        np.concatenate([w[off], np.ones(n, np.float32)]), n)
+
+
+def prefilter_nonhop(ppr: CSR, thresh_non1hop: float) -> CSR:
+    """Entries that can pass the >1-hop test: p > 0 and fl32(fl32(p+1)-1) >= f32(theta_n)
+    (src/models/link_transformer.py:464-478).  A per-model index over the PPR matrix; selection results are
+    identical with or without it."""
+    v = ppr.val.astype(np.float32)
+    keep = (v > 0) & (((v + np.float32(1)) - np.float32(1)) >= np.float32(thresh_non1hop))
+    rows = np.repeat(np.arange(ppr.n, dtype=np.int64), np.diff(ppr.rowptr))[keep]
+    rowptr = np.zeros(ppr.n + 1, np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    np.cumsum(rowptr, out=rowptr)
+    return CSR(rowptr, ppr.col[keep].copy(), v[keep].copy(), ppr.n)
+
+
+def as_coo_numpy(obj):
+    """(row, col, val|None, n) from the graph objects the reference's data dict may hold:
+    torch sparse COO/CSR tensors, scipy matrices, torch_sparse.SparseTensor-like objects (``.coo()``), or CSR."""
+    if isinstance(obj, CSR):
+        rows = np.repeat(np.arange(obj.n, dtype=np.int64), np.diff(obj.rowptr))
+        return rows, obj.col.astype(np.int64), obj.val, obj.n
+    if isinstance(obj, torch.Tensor):
+        t = obj.detach().cpu()
+        if t.layout == torch.sparse_csr:
+            t = t.to_sparse_coo()
+        if t.layout != torch.sparse_coo:
+            raise TypeError("dense tensors are not accepted as graphs")
+        t = t.coalesce()
+        ix = t.indices().numpy()
+        return ix[0], ix[1], t.values().to(torch.float32).numpy(), int(t.shape[0])
+    if sp.issparse(obj):
+        m = obj.tocoo()
+        return m.row.astype(np.int64), m.col.astype(np.int64), m.data.astype(np.float32), int(m.shape[0])
+    if hasattr(obj, "coo") and hasattr(obj, "sparse_sizes"):  # torch_sparse.SparseTensor duck type
+        row, col, val = obj.coo()
+        n = int(obj.sparse_sizes()[0])
+        return (row.cpu().numpy(), col.cpu().numpy(),
+                None if val is None else val.detach().cpu().to(torch.float32).numpy(), n)
+    raise TypeError(f"unsupported graph container {type(obj)!r}")
+
+
+def gcn_norm_device(struct: DeviceCSR, stream=None) -> DeviceCSR:
+    """Run ``lpf_gcn_norm_csr`` on a structure from ``gcn_structure_csr``; returns a CSR sharing rowptr/col."""
+    dev = struct.rowptr.device
+    w_out = torch.empty(struct.nnz, dtype=torch.float32, device=dev)
+    dis = torch.empty(struct.n, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    _lib.check(_lib.hip().lpf_gcn_norm_csr(struct.n, _lib.ptr(struct.rowptr), _lib.ptr(struct.col),
+                                            _lib.ptr(struct.val), _lib.ptr(w_out), _lib.ptr(dis), st),
+               "lpf_gcn_norm_csr")
+    return DeviceCSR(struct.rowptr, struct.col, w_out, struct.n, None)

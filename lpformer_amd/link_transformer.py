@@ -1,0 +1,596 @@
+"""MI355X-native LPFormer link-scoring modules with the reference's module surface.
+
+Drop-in for the reference's ``models.link_transformer.LinkTransformer`` and ``models.other_models.mlp_score``
+(constructor arguments, method names, ``state_dict`` keys and return shapes; reference
+src/models/link_transformer.py:16-178, src/models/other_models.py:142-179), so the reference's evaluation loops
+(src/train/testing.py) run unchanged.  All arithmetic goes through the C-ABI kernels in ``liblpformer_hip.so``;
+torch supplies parameter containers, device memory and streams only.  There is no CPU or eager fallback: without a
+GPU and the built library every forward raises.
+
+Scope of this round: inference (``model.eval()``; dropout is the identity).  The training step (autograd through
+the fused kernels, random attention drop) is a later row of the plan and raises ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, fold, graph
+from ._lib import FLAG_RELU, check, ptr
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _glorot(t: torch.Tensor):
+    bound = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-bound, bound)
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.LpfError(f"{what}: tensors must live on an MI355X (got {t.device}); "
+                            "lpformer_amd has no CPU fallback")
+
+
+def _pad4(k: int) -> int:
+    return (k + 3) & ~3
+
+
+def _as_f32_rows(x: torch.Tensor) -> torch.Tensor:
+    """fp32, 2-D, unit inner stride, 16-byte aligned rows (ld % 4 == 0); copies only when needed."""
+    if x.dtype != torch.float32:
+        x = x.float()
+    if x.dim() != 2:
+        x = x.reshape(-1, x.shape[-1])
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or x.stride(0) < x.shape[1]:
+        k = x.shape[1]
+        buf = torch.zeros(x.shape[0], _pad4(k), dtype=torch.float32, device=x.device)
+        buf[:, :k] = x
+        x = buf[:, :k]
+    return x
+
+
+# ------------------------------------------------------------------------------------------ kernels wrappers
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, addend=None, relu=False, out=None) -> torch.Tensor:
+    """out = a @ w.T (+bias) (+addend) (ReLU) through ``lpf_gemm_f32``.  ``a``/``w`` rows must be 16-byte aligned."""
+    _require_gpu(a, "gemm")
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k, (a.shape, w.shape)
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    check(_lib.hip().lpf_gemm_f32(m, n, k, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(addend),
+                                  0 if addend is None else addend.stride(0), ptr(out), out.stride(0),
+                                  FLAG_RELU if relu else 0, _stream(a.device)), "lpf_gemm_f32")
+    return out
+
+
+def layernorm_(x: torch.Tensor, g, b, relu=False, out=None) -> torch.Tensor:
+    out = x if out is None else out
+    check(_lib.hip().lpf_layernorm_f32(x.shape[0], x.shape[1], ptr(x), x.stride(0), ptr(g), ptr(b), ptr(out),
+                                       out.stride(0), FLAG_RELU if relu else 0, _stream(x.device)),
+          "lpf_layernorm_f32")
+    return out
+
+
+class _PaddedLinear:
+    """fp32 weight with rows padded to a multiple of 4 floats (what lpf_gemm_f32 wants), refreshed when the
+    parameter changes."""
+
+    def __init__(self):
+        self._key = None
+        self._w = None
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        key = (weight.data_ptr(), weight._version, weight.device)
+        if key != self._key:
+            w = weight.detach()
+            if w.dtype != torch.float32 or w.shape[1] % 4 or not w.is_contiguous() or w.data_ptr() % 16:
+                buf = torch.zeros(w.shape[0], _pad4(w.shape[1]), dtype=torch.float32, device=w.device)
+                buf[:, :w.shape[1]] = w
+                w = buf[:, :weight.shape[1]]
+            self._w, self._key = w, key
+        return self._w
+
+
+# ------------------------------------------------------------------------------------------ parameter modules
+class MLP(nn.Module):
+    """Same parameters and semantics as the reference's ``MLP`` (src/models/other_models.py:80-138):
+    (Linear -> LayerNorm -> ReLU -> dropout)* -> Linear.  Eval-mode forward on the HIP kernels."""
+
+    def __init__(self, num_layers, in_channels, hid_channels, out_channels, drop=0, norm="layer", sigmoid=False,
+                 bias=True):
+        super().__init__()
+        if norm not in ("layer", None):
+            raise NotImplementedError("only LayerNorm MLPs are used by LPFormer")
+        self.dropout, self.sigmoid = drop, sigmoid
+        self.norm = nn.LayerNorm(hid_channels) if norm == "layer" else None
+        self.linears = nn.ModuleList()
+        if num_layers == 1:
+            self.linears.append(nn.Linear(in_channels, out_channels, bias=bias))
+        else:
+            self.linears.append(nn.Linear(in_channels, hid_channels, bias=bias))
+            for _ in range(num_layers - 2):
+                self.linears.append(nn.Linear(hid_channels, hid_channels, bias=bias))
+            self.linears.append(nn.Linear(hid_channels, out_channels, bias=bias))
+        self._pads = [_PaddedLinear() for _ in self.linears]
+
+    def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [M, K] fp32 device rows (16-byte aligned).  Optionally writes the result into ``out`` (a strided view)."""
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("training-mode dropout is not part of the HIP inference path")
+        h = x
+        for i, lin in enumerate(self.linears[:-1]):
+            w = self._pads[i].get(lin.weight)
+            hid = torch.empty(h.shape[0], _pad4(w.shape[0]), dtype=torch.float32, device=h.device)[:, :w.shape[0]]
+            gemm(h, w, lin.bias, out=hid)
+            if self.norm is not None:
+                layernorm_(hid, self.norm.weight, self.norm.bias, relu=True)
+            else:
+                layernorm_(hid, None, None, relu=True)
+            h = hid
+        last = self.linears[-1]
+        y = gemm(h, self._pads[-1].get(last.weight), last.bias, out=out)
+        return y
+
+    def forward(self, x):
+        _require_gpu(x, "MLP.forward")
+        with torch.no_grad():
+            lead = x.shape[:-1]
+            y = self.run(_as_f32_rows(x))
+            y = y.reshape(*lead, y.shape[-1]).squeeze(-1)
+            return torch.sigmoid(y) if self.sigmoid else y
+
+
+class mlp_score(nn.Module):  # noqa: N801  (name kept for drop-in compatibility)
+    """Score head with the reference's parameters (src/models/other_models.py:142-179): (Linear, ReLU, dropout)*
+    Linear, sigmoid; returns PROBABILITIES of shape [M] like the reference.  ``logits()`` exposes the pre-sigmoid
+    values."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout=0):
+        super().__init__()
+        self.lins = nn.ModuleList()
+        if num_layers == 1:
+            self.lins.append(nn.Linear(in_channels, out_channels))
+        else:
+            self.lins.append(nn.Linear(in_channels, hidden_channels))
+            for _ in range(num_layers - 2):
+                self.lins.append(nn.Linear(hidden_channels, hidden_channels))
+            self.lins.append(nn.Linear(hidden_channels, out_channels))
+        self.dropout = dropout
+        self._pads = [_PaddedLinear() for _ in self.lins]
+
+    def _run(self, x: torch.Tensor, want_prob: bool) -> torch.Tensor:
+        _require_gpu(x, "mlp_score.forward")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("training-mode dropout is not part of the HIP inference path")
+        with torch.no_grad():
+            h = _as_f32_rows(x)
+            for i, lin in enumerate(self.lins[:-1]):
+                h = gemm(h, self._pads[i].get(lin.weight), lin.bias, relu=True)
+            last = self.lins[-1]
+            if last.out_features == 1:
+                res = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
+                w = last.weight.detach().reshape(-1).contiguous()
+                b = float(last.bias.detach().item()) if last.bias is not None else 0.0
+                check(_lib.hip().lpf_rowdot_sigmoid_f32(h.shape[0], h.shape[1], ptr(h), h.stride(0), ptr(w), b,
+                                                        None if want_prob else ptr(res),
+                                                        ptr(res) if want_prob else None, _stream(h.device)),
+                      "lpf_rowdot_sigmoid_f32")
+                return res
+            y = gemm(h, self._pads[-1].get(last.weight), last.bias)
+            return torch.sigmoid(y).squeeze(-1) if want_prob else y.squeeze(-1)
+
+    def forward(self, x):
+        return self._run(x, True)
+
+    def logits(self, x):
+        return self._run(x, False)
+
+
+class _GCNConvParams(nn.Module):
+    """Parameter container named like PyG's GCNConv: ``lin.weight`` (no bias, glorot) and ``bias`` (zeros)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        _glorot(self.lin.weight)
+
+
+class GCN(nn.Module):
+    """Parameters of the reference's ``GCN`` (src/models/other_models.py:10-76); evaluated by LinkTransformer.propagate."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, residual=False, cached=False,
+                 normalize=True, layer_norm=True, relu=True):
+        super().__init__()
+        if not normalize:
+            raise NotImplementedError("GCN without normalisation is not used by LPFormer")
+        if not layer_norm and num_layers >= 3:
+            # the reference constructor crashes here (self.lns is None, other_models.py:41,46); keep it an error
+            raise ValueError("layer_norm=False requires gnn_layers <= 2 (as in the reference)")
+        if num_layers == 1:
+            hidden_channels = out_channels
+        self.relu, self.dropout, self.residual = relu, dropout, residual
+        self.convs = nn.ModuleList([_GCNConvParams(in_channels, hidden_channels)])
+        self.lns = nn.ModuleList([nn.LayerNorm(hidden_channels)]) if layer_norm else None
+        if num_layers > 1:
+            for _ in range(num_layers - 2):
+                self.convs.append(_GCNConvParams(hidden_channels, hidden_channels))
+                self.lns.append(nn.LayerNorm(hidden_channels))
+            self.convs.append(_GCNConvParams(hidden_channels, out_channels))
+            if layer_norm:
+                self.lns.append(nn.LayerNorm(hidden_channels))
+
+
+class NodeEncoder(nn.Module):
+    """Parameters of the reference's ``NodeEncoder`` (src/modules/node_encoder.py:8-44), including the unused
+    ``feat_transform`` Linear that lives in its state_dict."""
+
+    def __init__(self, data, train_args, device="cuda"):
+        super().__init__()
+        self.dim = train_args["dim"]
+        init_dim = self.dim if "emb" in data else data["x"].size(1)
+        self.feat_drop = train_args.get("feat_drop", 0)
+        self.feat_transform = nn.Linear(init_dim, self.dim)
+        self.gnn_encoder = GCN(init_dim, self.dim, self.dim, train_args["gnn_layers"], train_args.get("gnn_drop", 0),
+                               cached=train_args.get("gcn_cache"), residual=train_args["residual"],
+                               layer_norm=train_args["layer_norm"], relu=train_args["relu"])
+
+
+class LinkAttention(nn.Module):
+    """Parameters of the reference's ``LinkAttention`` (src/modules/layers.py:88-157): lin_l [H*C, D], lin_r
+    [H*C, 2D], att [1, H, C], bias [H*C]."""
+
+    def __init__(self, in_channels, out_channels, train_args, node_dim=None):
+        super().__init__()
+        self.heads = train_args["num_heads"]
+        nd = (in_channels if node_dim is None else node_dim) * 2
+        self.lin_l = nn.Linear(in_channels, self.heads * out_channels)
+        self.lin_r = nn.Linear(nd, self.heads * out_channels)
+        self.att = nn.Parameter(torch.empty(1, self.heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(self.heads * out_channels))
+        _glorot(self.lin_l.weight)
+        _glorot(self.lin_r.weight)
+        _glorot(self.att)
+
+
+class LinkTransformerLayer(nn.Module):
+    """Parameters of the reference's ``LinkTransformerLayer`` (src/modules/layers.py:17-82)."""
+
+    def __init__(self, dim, train_args, out_dim=None, node_dim=None):
+        super().__init__()
+        self.dropout = train_args.get("dropout", 0)
+        out_dim = dim if out_dim is None else out_dim
+        self.att = LinkAttention(dim, out_dim, train_args, node_dim=node_dim)
+        self.post_att_norm = nn.LayerNorm(out_dim * train_args["num_heads"])
+
+
+# ------------------------------------------------------------------------------------------ the model
+class LinkTransformer(nn.Module):
+    """LPFormer link-representation model on MI355X.
+
+    ``LinkTransformer(train_args, data, device)`` with the reference's ``train_args`` keys (thresh_cn, thresh_1hop,
+    thresh_non1hop, dim, trans_layers, num_heads, att_drop, dropout, gnn_drop, feat_drop, gcn_cache, gnn_layers,
+    residual, layer_norm, relu) and ``data`` dict (x, adj_t, full_adj_t, adj_mask, full_adj_mask, ppr, ppr_test).
+    Graph entries may be torch sparse tensors, torch_sparse.SparseTensor-like objects, scipy matrices or
+    ``lpformer_amd.graph.CSR``; they are converted to device CSR once and cached.
+
+    Methods mirror the reference: ``forward`` (:82-107), ``propagate`` (:110-129), ``calc_pairwise`` (:132-178),
+    ``compute_node_mask`` (:214-276), attributes ``out_dim`` and ``elementwise_lin``.
+    """
+
+    def __init__(self, train_args, data, device="cuda"):
+        super().__init__()
+        self.train_args, self.data, self.device = train_args, data, torch.device(device)
+        self.thresh_cn = train_args["thresh_cn"]
+        self.thresh_1hop = train_args["thresh_1hop"]
+        self.thresh_non1hop = train_args["thresh_non1hop"]
+        if self.thresh_non1hop == 1 and self.thresh_1hop == 1:
+            self.mask = "cn"
+        elif self.thresh_non1hop == 1 and self.thresh_1hop < 1:
+            self.mask = "1-hop"
+        else:
+            self.mask = "all"
+        self.dim = train_args["dim"]
+        self.att_drop = train_args.get("att_drop", 0)
+        self.num_layers = train_args["trans_layers"]
+        self.num_nodes = data["x"].shape[0]
+        self.out_dim = self.dim * 2
+
+        self.gnn_norm = nn.LayerNorm(self.dim)
+        self.node_encoder = NodeEncoder(data, train_args, device=device)
+        self.att_layers = nn.ModuleList()
+        inner = self.dim * 2 if self.num_layers > 1 else self.dim
+        self.att_layers.append(LinkTransformerLayer(self.dim, train_args, out_dim=inner))
+        for _ in range(self.num_layers - 2):
+            self.att_layers.append(LinkTransformerLayer(self.dim, train_args, node_dim=self.dim))
+        if self.num_layers > 1:
+            self.att_layers.append(LinkTransformerLayer(self.dim, train_args, out_dim=self.dim, node_dim=self.dim))
+        self.elementwise_lin = MLP(2, self.dim, self.dim, self.dim)
+        self.ppr_encoder_cn = MLP(2, 2, self.dim, self.dim)
+        if self.mask == "cn":
+            count_dim = 1
+        elif self.mask == "1-hop":
+            self.ppr_encoder_onehop = MLP(2, 2, self.dim, self.dim)
+            count_dim = 3
+        else:
+            count_dim = 4
+            self.ppr_encoder_onehop = MLP(2, 2, self.dim, self.dim)
+            self.ppr_encoder_non1hop = MLP(2, 2, self.dim, self.dim)
+        self.count_dim = count_dim
+        pairwise_dim = self.dim * train_args["num_heads"] + count_dim
+        self.pairwise_lin = MLP(2, pairwise_dim, pairwise_dim, self.dim)
+
+        # runtime state (not parameters)
+        self._graphs = {}      # (kind, id(obj)) -> DeviceCSR
+        self._folded = None    # (param version key, dict of device tensors)
+        self._z_cache = None   # (key, Z)
+        self._x_cache = None   # (key, padded features)
+        self._ws = {}          # named workspaces
+        self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
+        self.last_stats = {}
+
+    # ---------------------------------------------------------------------------------- support checks
+    def _check_supported(self):
+        if self.mask == "cn":
+            raise NotImplementedError("mask mode 'cn' (thresh_1hop == thresh_non1hop == 1) is unspecified: the "
+                                      "reference itself crashes in this mode on torch >= 2.1")
+        if self.num_layers != 1 or self.train_args["num_heads"] != 1:
+            raise NotImplementedError("the HIP path covers trans_layers=1, num_heads=1 (every shipped script); the "
+                                      "reference is shape-inconsistent for heads>1 with layers>1")
+        if self.dim not in (32, 64, 128, 256):
+            raise NotImplementedError("dim must be one of 32, 64, 128, 256 for the gfx950 kernels")
+        if self.training:
+            raise NotImplementedError("training step (autograd through the fused kernels) is not implemented in this "
+                                      "round: call model.eval()")
+        if "emb" in self.data:
+            raise NotImplementedError("data['emb'] is never set by the reference's readers and is not supported")
+
+    # ---------------------------------------------------------------------------------- graph state
+    def _data_obj(self, kind: str, test_set: bool):
+        if kind == "ppr":
+            return self.data["ppr_test"] if (test_set and "ppr_test" in self.data) else self.data["ppr"]
+        suffix = "mask" if kind == "mask" else "t"
+        return self.data[f"full_adj_{suffix}"] if test_set else self.data[f"adj_{suffix}"]
+
+    def _device_graph(self, kind: str, obj) -> graph.DeviceCSR:
+        """kind in {'prop' (GCN-normalised), 'mask', 'ppr', 't0' (prefiltered >1-hop candidates)}."""
+        key = (kind, id(obj))
+        hit = self._graphs.get(key)
+        if hit is not None and hit[0] is obj:
+            return hit[1]
+        dev = self.device
+        if kind == "t0":
+            host = self._device_graph("ppr", obj).host
+            g = graph.prefilter_nonhop(host, self.thresh_non1hop).to_device(dev)
+        else:
+            row, col, val, n = graph.as_coo_numpy(obj)
+            if kind == "prop":
+                g = graph.gcn_norm_device(graph.gcn_structure_csr(np.stack([row, col]), val, n).to_device(dev))
+            elif kind == "mask":
+                g = graph.csr_from_coo(row, col, None, n).to_device(dev)
+            else:
+                if val is None:
+                    raise ValueError("the PPR matrix needs values")
+                g = graph.csr_from_coo(row, col, val, n).to_device(dev)
+        self._graphs[key] = (obj, g)
+        return g
+
+    def _features(self) -> torch.Tensor:
+        x = self.data["x"]
+        key = (x.data_ptr(), x._version, x.device)
+        if self._x_cache is None or self._x_cache[0] != key:
+            self._x_cache = (key, _as_f32_rows(x.detach().to(self.device)))
+        return self._x_cache[1]
+
+    def _workspace(self, name: str, numel: int, dtype) -> torch.Tensor:
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            grow = int(numel * 1.25) + 64
+            t = torch.empty(grow, dtype=dtype, device=self.device)
+            self._ws[name] = t
+        return t
+
+    # ---------------------------------------------------------------------------------- folded weights
+    def _fold(self):
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params) + (str(self.device),)
+        if self._folded is not None and self._folded[0] == key:
+            return self._folded[1]
+        sd = {k: v for k, v in self.state_dict().items()}
+        n_types = 3 if self.mask == "all" else 2
+        out = fold.fold_attention(sd, self.dim, n_types)
+        out["pe_tab"], out["pe_stat"] = fold.pe_tables(sd, self.dim, n_types)
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
+        self._folded = (key, dev)
+        self._z_cache = None
+        return dev
+
+    # ---------------------------------------------------------------------------------- encoder
+    def propagate(self, adj=None, test_set=False):
+        """GCN encoder + ``gnn_norm`` -> [N, D] (reference :110-129).  L x (MFMA GEMM, fused CSR SpMM)."""
+        self._check_supported()
+        with torch.no_grad():
+            a_hat = self._device_graph("prop", self._data_obj("adj", test_set) if adj is None else adj)
+            enc = self.node_encoder.gnn_encoder
+            x = self._features()
+            st = _stream(self.device)
+            n_layers = len(enc.convs)
+            for i, conv in enumerate(enc.convs):
+                t = gemm(x, self._conv_pads[i].get(conv.lin.weight))
+                d = t.shape[1]
+                last = i == n_layers - 1
+                res = x if (enc.residual and x.shape[1] == d) else None
+                ln = enc.lns[i] if enc.lns is not None else None
+                out = torch.empty(self.num_nodes, d, dtype=torch.float32, device=self.device)
+                check(_lib.hip().lpf_spmm_csr_f32(
+                    self.num_nodes, d, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(t), t.stride(0),
+                    ptr(out), out.stride(0), ptr(conv.bias), ptr(ln.weight) if ln is not None else None,
+                    ptr(ln.bias) if ln is not None else None, ptr(res), 0 if res is None else res.stride(0),
+                    ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
+                    FLAG_RELU if enc.relu else 0, st), "lpf_spmm_csr_f32")
+                x = out
+            return x
+
+    def _node_keys(self, x_node: torch.Tensor, w) -> torch.Tensor:
+        """Z = X_node W_rx^T + b_r, once per encoder output (cached on the tensor's identity and version)."""
+        key = (x_node.data_ptr(), x_node._version, tuple(x_node.shape))
+        if self._z_cache is None or self._z_cache[0] != key:
+            self._z_cache = (key, gemm(_as_f32_rows(x_node), w["w_rx"], w["b_r"]))
+        return self._z_cache[1]
+
+    # ---------------------------------------------------------------------------------- selection
+    def _select(self, batch: torch.Tensor, test_set: bool, adj_mask=None):
+        """Runs the selection kernels; returns a dict of device arrays (type-major entries, reference order)."""
+        lib, st = _lib.hip(), _stream(self.device)
+        bs = batch.shape[1]
+        ppr = self._device_graph("ppr", self._data_obj("ppr", test_set))
+        adjx = self._device_graph("mask", self._data_obj("mask", test_set))
+        adj = adjx if adj_mask is None else self._device_graph("mask", adj_mask)
+        want_t0 = self.mask == "all"
+        t0 = self._device_graph("t0", self._data_obj("ppr", test_set)) if want_t0 else None
+
+        stage_off = self._workspace("stage_off", bs + 1, torch.int64)
+        check(lib.lpf_select_bound(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr),
+                                   ptr(t0.rowptr) if want_t0 else None, ptr(stage_off), st), "lpf_select_bound")
+        cap = int(stage_off[bs].item())  # one 8-byte read-back sizes the staging area
+        stage_node = self._workspace("stage_node", cap, torch.int32)
+        stage_pa = self._workspace("stage_pa", cap, torch.float32)
+        stage_pb = self._workspace("stage_pb", cap, torch.float32)
+        stage_cnt = self._workspace("stage_cnt", 4 * bs, torch.int32)
+        check(lib.lpf_select_nodes(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(adj.col), ptr(adjx.rowptr),
+                                   ptr(adjx.col), ptr(ppr.rowptr), ptr(ppr.col), ptr(ppr.val),
+                                   ptr(t0.rowptr) if want_t0 else None, ptr(t0.col) if want_t0 else None,
+                                   ptr(t0.val) if want_t0 else None, float(self.thresh_cn), float(self.thresh_1hop),
+                                   float(self.thresh_non1hop), ptr(stage_off), ptr(stage_node), ptr(stage_pa),
+                                   ptr(stage_pb), ptr(stage_cnt), st), "lpf_select_nodes")
+        ldf = _pad4(self.dim + self.count_dim)
+        feats = torch.zeros(bs, ldf, dtype=torch.float32, device=self.device)  # [att out | counts | pad]
+        type_ptr = self._workspace("type_ptr", 3 * (bs + 1), torch.int64)
+        check(lib.lpf_select_scan(bs, ptr(stage_cnt), ptr(type_ptr), feats.data_ptr() + 4 * self.dim, ldf,
+                                  1 if want_t0 else 0, st), "lpf_select_scan")
+        sel_pair = self._workspace("sel_pair", cap, torch.int32)
+        sel_node = self._workspace("sel_node", cap, torch.int32)
+        sel_pa = self._workspace("sel_pa", cap, torch.float32)
+        sel_pb = self._workspace("sel_pb", cap, torch.float32)
+        check(lib.lpf_select_compact(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(stage_off),
+                                     ptr(stage_node), ptr(stage_pa), ptr(stage_pb), ptr(stage_cnt), ptr(type_ptr),
+                                     ptr(sel_pair), ptr(sel_node), ptr(sel_pa), ptr(sel_pb), st),
+              "lpf_select_compact")
+        return {"bs": bs, "cap": cap, "type_ptr": type_ptr, "sel_pair": sel_pair, "sel_node": sel_node,
+                "sel_pa": sel_pa, "sel_pb": sel_pb, "feats": feats, "ldf": ldf}
+
+    def _prep_batch(self, batch) -> torch.Tensor:
+        batch = torch.as_tensor(batch).to(self.device)
+        if batch.dtype != torch.int64:
+            batch = batch.long()
+        if batch.dim() != 2 or batch.shape[0] != 2:
+            raise ValueError("batch must be a 2 x BS tensor of node ids")
+        if batch.stride(1) != 1:
+            batch = batch.contiguous()
+        return batch
+
+    def compute_node_mask(self, batch, test_set=False, adj=None):
+        """Reference-format selection result (:214-276): three tuples (ix int64 [2,n], ppr_src, ppr_tgt) for CN,
+        1-hop and >1-hop nodes (None for >1-hop in "1-hop" mode), each sorted by (pair position, node)."""
+        self._check_supported()
+        with torch.no_grad():
+            batch = self._prep_batch(batch)
+            s = self._select(batch, test_set, adj)
+            bs = s["bs"]
+            tp = s["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)
+            tot = tp[:, bs].tolist()
+            out, base = [], 0
+            for t in range(3):
+                if t == 2 and self.mask != "all":
+                    out.append(None)
+                    continue
+                sl = slice(base, base + tot[t])
+                ix = torch.stack([s["sel_pair"][sl].long(), s["sel_node"][sl].long()])
+                out.append((ix, s["sel_pa"][sl].clone(), s["sel_pb"][sl].clone()))
+                base += tot[t]
+            return tuple(out)
+
+    # ---------------------------------------------------------------------------------- pair stage
+    def calc_pairwise(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False, _out=None):
+        """Pairwise branch (:132-178): selection -> PE + attention -> counts -> ``pairwise_lin``.
+        Returns ([BS, D], att_weights or None)."""
+        self._check_supported()
+        _require_gpu(X_node, "calc_pairwise")
+        with torch.no_grad():
+            lib, st, d = _lib.hip(), _stream(self.device), self.dim
+            batch = self._prep_batch(batch)
+            bs = batch.shape[1]
+            w = self._fold()
+            x_node = _as_f32_rows(X_node)
+            z = self._node_keys(x_node, w)
+
+            qin = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+            check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0), None, 0,
+                                          ptr(qin), d, st), "lpf_pair_gather_f32")
+            q = gemm(qin, w["w_l"], w["b_l2"])
+
+            s = self._select(batch, test_set, adj_mask)
+            score = self._workspace("score", s["cap"], torch.float32)
+            check(lib.lpf_pair_scores_f32(d, ptr(s["type_ptr"]), bs, ptr(s["sel_pair"]), ptr(s["sel_node"]),
+                                          ptr(s["sel_pa"]), ptr(s["sel_pb"]), ptr(z), z.stride(0), ptr(q),
+                                          q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]),
+                                          ptr(w["bfold"]), ptr(w["att"]), ptr(score), s["cap"], st),
+                  "lpf_pair_scores_f32")
+            ldg = 4 * d + 4
+            g = torch.empty(bs, ldg, dtype=torch.float32, device=self.device)
+            alpha = torch.empty(s["cap"], dtype=torch.float32, device=self.device) if return_weights else None
+            check(lib.lpf_pair_softmax_gather_f32(d, bs, ptr(s["type_ptr"]), ptr(s["sel_node"]), ptr(s["sel_pa"]),
+                                                  ptr(s["sel_pb"]), ptr(score), ptr(z), z.stride(0),
+                                                  ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(g), ldg, ptr(alpha), st),
+                  "lpf_pair_softmax_gather_f32")
+            feats = s["feats"]
+            att_view = feats[:, :d]
+            gemm(g[:, d:], w["wcat"], None, addend=g[:, :d], out=att_view)      # sum_e alpha_e k_e + bias
+            layer = self.att_layers[0]
+            layernorm_(att_view, layer.post_att_norm.weight, layer.post_att_norm.bias)
+            self._last_att = att_view
+            out = self.pairwise_lin.run(feats[:, :d + self.count_dim], out=_out)
+
+            att_weights = None
+            if return_weights:
+                tp = s["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)
+                total = int(tp[:, bs].sum().item())
+                att_weights = torch.stack((s["sel_pair"][:total].float(), alpha[:total]))
+            return out, att_weights
+
+    def forward(self, batch, adj_prop=None, adj_mask=None, test_set=False, return_weights=False):
+        """Link representations [BS, 2D] = [elementwise branch | pairwise branch] (reference :82-107).  Like the
+        reference, every call re-runs the encoder; evaluation loops that propagate once should call ``propagate``
+        + ``elementwise_lin`` + ``calc_pairwise`` (src/train/testing.py:96-121)."""
+        self._check_supported()
+        with torch.no_grad():
+            batch = self._prep_batch(batch)
+            x_node = self.propagate(adj_prop, test_set)
+            out = self.pair_features(batch, x_node, test_set=test_set, adj_mask=adj_mask,
+                                     return_weights=return_weights)
+            return out
+
+    def pair_features(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False):
+        """[elementwise_lin(X[a]*X[b]) | calc_pairwise(...)] written straight into one [BS, 2D] buffer."""
+        self._check_supported()
+        with torch.no_grad():
+            lib, st, d = _lib.hip(), _stream(self.device), self.dim
+            batch = self._prep_batch(batch)
+            bs = batch.shape[1]
+            x_node = _as_f32_rows(X_node)
+            comb = torch.empty(bs, 2 * d, dtype=torch.float32, device=self.device)
+            prod = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+            check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0),
+                                          ptr(prod), d, None, 0, st), "lpf_pair_gather_f32")
+            self.elementwise_lin.run(prod, out=comb[:, :d])
+            _, attw = self.calc_pairwise(batch, x_node, test_set, adj_mask, return_weights, _out=comb[:, d:])
+            return (comb, attw) if return_weights else comb

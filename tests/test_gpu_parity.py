@@ -1,0 +1,143 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors recorded from the reference and against
+the CPU oracle.  Run on the GPU box: python -m pytest tests -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import lpformer_amd
+from lpformer_amd import graph
+from oracle import lpformer_oracle as O
+from tests.golden_util import LP_CASES, Fixture
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4  # north_star: link logits within 1e-4 in fp32
+
+
+def _build(fx, sparse_inputs=True):
+    """Model + score head on cuda:0 from a fixture; graph entries given as torch sparse COO tensors (the types the
+    reference's data dict holds) or as CSR containers."""
+    n, dev = fx.n, torch.device("cuda:0")
+    data = {"x": torch.from_numpy(fx["x"]).to(dev), "num_nodes": n}
+
+    def pack(prefix, ei_key, w_key, ppr_prefix):
+        ei = fx[ei_key].astype(np.int64)
+        adj_t = graph.csr_from_coo(ei[0], ei[1], fx[w_key], n)
+        mask = graph.mask_csr(ei, n, symmetric=True)
+        ppr = graph.csr_from_coo(fx[ppr_prefix + "row"], fx[ppr_prefix + "col"], fx[ppr_prefix + "val"], n)
+        if sparse_inputs:
+            return adj_t.to_torch_sparse_coo().to(dev), mask.to_torch_sparse_coo().to(dev).int(), \
+                ppr.to_torch_sparse_coo().to(dev)
+        return adj_t, mask, ppr
+
+    data["adj_t"], data["adj_mask"], data["ppr"] = pack("", "edge_index", "edge_weight", "ppr_")
+    if fx.test_set:
+        data["full_adj_t"], data["full_adj_mask"], data["ppr_test"] = pack("full_", "full_edge_index",
+                                                                            "full_edge_weight", "ppr_test_")
+    else:
+        data["full_adj_t"], data["full_adj_mask"], data["ppr_test"] = data["adj_t"], data["adj_mask"], data["ppr"]
+    cfg = {k: fx.cfg[k] for k in ("thresh_cn", "thresh_1hop", "thresh_non1hop", "dim", "trans_layers", "num_heads",
+                                  "att_drop", "dropout", "gnn_drop", "feat_drop", "gcn_cache", "gnn_layers",
+                                  "residual", "layer_norm", "relu")}
+    model = lpformer_amd.LinkTransformer(cfg, data, device=dev).to(dev)
+    score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, fx.cfg["pred_layers"]).to(dev)
+    m_sd, s_sd = fx.state_dicts()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in m_sd.items()}, strict=True)
+    score.load_state_dict({k: torch.from_numpy(v) for k, v in s_sd.items()}, strict=True)
+    return model.eval(), score.eval()
+
+
+def _err(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+@pytest.mark.parametrize("case", LP_CASES)
+def test_selection_bit_exact_vs_reference(case):
+    fx = Fixture(case)
+    model, _ = _build(fx)
+    infos = model.compute_node_mask(torch.from_numpy(fx["batch"]), test_set=fx.test_set)
+    for tag, info in zip(("cn", "onehop", "non1hop"), infos):
+        if f"sel_{tag}_ix" not in fx:
+            assert info is None
+            continue
+        ix, pa, pb = (t.cpu().numpy() for t in info)
+        np.testing.assert_array_equal(ix, fx[f"sel_{tag}_ix"])
+        np.testing.assert_array_equal(pa.view(np.uint32), fx[f"sel_{tag}_pa"].view(np.uint32))
+        np.testing.assert_array_equal(pb.view(np.uint32), fx[f"sel_{tag}_pb"].view(np.uint32))
+
+
+@pytest.mark.parametrize("case", LP_CASES)
+@pytest.mark.parametrize("sparse_inputs", [True, False])
+def test_forward_vs_reference(case, sparse_inputs):
+    fx = Fixture(case)
+    model, score = _build(fx, sparse_inputs)
+    batch = torch.from_numpy(fx["batch"]).cuda()
+    x_node = model.propagate(test_set=fx.test_set)
+    assert _err(x_node.cpu(), fx["x_node"]) <= TOL
+    # the call pattern of test_heart_negatives (src/train/testing.py:105-117)
+    ew = model.elementwise_lin(x_node[batch[0]] * x_node[batch[1]])
+    pw, _ = model.calc_pairwise(batch, x_node, test_set=fx.test_set)
+    assert _err(ew.cpu(), fx["elementwise_feats"]) <= TOL
+    assert _err(model._last_att.cpu(), fx["att_post_ln"]) <= TOL
+    assert _err(pw.cpu(), fx["pairwise_feats"]) <= TOL
+    prob = score(torch.cat((ew, pw), dim=-1))
+    assert _err(prob.cpu(), fx["prob"]) <= TOL
+    # the call pattern of test_edge (src/train/testing.py:86-88)
+    feats, attw = model(batch, test_set=fx.test_set, return_weights=True)
+    assert _err(feats.cpu(), fx["combined_feats"]) <= TOL
+    assert _err(score.logits(feats).cpu(), fx["logit"]) <= TOL
+    assert _err(score(feats).cpu(), fx["prob"]) <= TOL
+    np.testing.assert_array_equal(attw[0].cpu().numpy(), fx["att_weights"][0])
+    assert _err(attw[1].cpu(), fx["att_weights"][1]) <= TOL
+
+
+def test_vs_oracle_on_fresh_inputs():
+    """Seeded inputs that are not in any fixture: HIP path vs the CPU oracle (same weights)."""
+    from lpformer_amd import data as D
+    rng = np.random.default_rng(11)
+    n, dim = 700, 128
+    ei, w = D.chung_lu_graph(n, 2600, seed=5, max_weight=5)
+    x = rng.standard_normal((n, 48)).astype(np.float32)
+    ppr = lpformer_amd.calc_ppr(ei, n, 0.15, 2e-4)
+    d = D.build_data(ei, x, n, edge_weight=w, ppr=ppr)
+    cfg = D.train_args_for(dict(thresholds=(0.0, 1e-3, 5e-3), dim=dim, gnn_layers=2, residual=False))
+    dev = torch.device("cuda:0")
+    model = lpformer_amd.LinkTransformer(cfg, d, device=dev).to(dev).eval()
+    score = lpformer_amd.mlp_score(2 * dim, 2 * dim, 1, 2).to(dev).eval()
+    with torch.no_grad():
+        for p in list(model.parameters()) + list(score.parameters()):
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
+    batch = D.sample_pairs(ei, n, 1500, seed=2)
+    batch[:, :4] = np.array([[0, 5, 7, 7], [0, 5, 9, 9]])  # a == b and duplicate pairs
+    ocfg = dict(cfg, pred_layers=2)
+    ref = O.forward(batch, x, O.gcn_norm(ei, w, n), O.symmetric_mask_csr(ei, n),
+                    (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P, ocfg)
+    feats = model(torch.from_numpy(batch))
+    assert _err(feats.cpu(), ref["combined_feats"]) <= TOL
+    assert _err(score.logits(feats).cpu(), ref["logit"]) <= TOL
+    infos = model.compute_node_mask(torch.from_numpy(batch))
+    for tag, info in zip(("cn", "onehop", "non1hop"), infos):
+        np.testing.assert_array_equal(info[0].cpu().numpy(), ref["sel"][tag][0])
+        np.testing.assert_array_equal(info[1].cpu().numpy().view(np.uint32), ref["sel"][tag][1].view(np.uint32))
+        np.testing.assert_array_equal(info[2].cpu().numpy().view(np.uint32), ref["sel"][tag][2].view(np.uint32))
+    # size-independent properties: permuting the batch permutes the scores; swapping (a,b) leaves them unchanged
+    perm = torch.randperm(batch.shape[1])
+    s0 = score.logits(feats)
+    s1 = score.logits(model(torch.from_numpy(batch)[:, perm]))
+    assert _err(s0[perm.cuda()].cpu(), s1.cpu()) <= 1e-5
+    s2 = score.logits(model(torch.from_numpy(batch[::-1].copy())))
+    assert _err(s0.cpu(), s2.cpu()) <= 2e-5
+
+
+def test_empty_and_tiny_batches():
+    fx = Fixture("lp_all_d64")
+    model, score = _build(fx)
+    one = torch.from_numpy(fx["batch"][:, :1])
+    f1 = model(one, test_set=fx.test_set)
+    assert f1.shape == (1, 128)
+    assert _err(f1.cpu(), fx["combined_feats"][:1]) <= TOL
+    iso = torch.tensor([[fx.n - 1], [fx.n - 2]])  # two isolated nodes: no selected entries -> attention = bias
+    fi = model(iso, test_set=fx.test_set)
+    assert torch.isfinite(fi).all()

@@ -1,0 +1,148 @@
+"""CPU-only checks: C-ABI libraries load and export every declared symbol, host PPR producer is bit-exact against
+the reference's golden vectors and the oracle, module surface/state_dict keys match the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import lpformer_amd
+from lpformer_amd import _lib, fold, graph
+from oracle import lpformer_oracle as O
+from tests.golden_util import GOLDEN_DIR, LP_CASES, PPR_CASES, Fixture
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_header_symbols_exported():
+    """Every function declared in include/lpformer_hip.h is exported by one of the two libraries and bound."""
+    hdr = open(os.path.join(ROOT, "include", "lpformer_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lpf_[a-z0-9_]+)\s*\(", hdr))
+    bound = set(_lib.HIP_PROTOTYPES) | set(_lib.HOST_PROTOTYPES)
+    assert declared == bound, (declared ^ bound)
+    hip, host = _lib.hip(), _lib.host()  # loading must work without a GPU (no compute calls here)
+    for name in _lib.HIP_PROTOTYPES:
+        assert hasattr(hip, name)
+    for name in _lib.HOST_PROTOTYPES:
+        assert hasattr(host, name)
+    assert hip.lpf_abi_version() == _lib.ABI_VERSION == host.lpf_host_abi_version()
+    assert b"invalid" in hip.lpf_strerror(-1)
+
+
+@pytest.mark.parametrize("case", PPR_CASES)
+def test_host_ppr_push_matches_reference(case):
+    z = np.load(f"{GOLDEN_DIR}/{case}.npz")
+    n = int(z["n"])
+    for eps in z["eps_list"]:
+        tag = f"{eps:g}".replace("-", "m").replace(".", "p")
+        for threads in (1, 3):
+            csr = lpformer_amd.ppr.calc_ppr(z["edge_index"], n, 0.15, float(eps), num_threads=threads)
+            rows = np.repeat(np.arange(n), np.diff(csr.rowptr))
+            np.testing.assert_array_equal(rows, z[f"row_{tag}"])
+            np.testing.assert_array_equal(csr.col, z[f"col_{tag}"])
+            np.testing.assert_array_equal(csr.val.view(np.uint32), z[f"val_{tag}"].view(np.uint32))
+
+
+def test_host_ppr_push_matches_oracle_on_directed_graph():
+    rng = np.random.default_rng(3)
+    n = 90
+    ei = rng.integers(0, n, size=(2, 400))
+    ei = np.concatenate([ei, np.stack([np.arange(5), np.arange(5)])], axis=1)  # self loops, dangling nodes exist
+    rowptr, col = O.edge_csr(ei, n)
+    r, c, v = O.ppr_push(rowptr, col, 0.15, 1e-3)
+    csr = lpformer_amd.ppr.calc_ppr(ei, n, 0.15, 1e-3, num_threads=2)
+    np.testing.assert_array_equal(np.repeat(np.arange(n), np.diff(csr.rowptr)), r)
+    np.testing.assert_array_equal(csr.col, c)
+    np.testing.assert_array_equal(csr.val.view(np.uint32), v.view(np.uint32))
+
+
+def _model_for(fx, device="cpu"):
+    n = fx.n
+    data = {"x": torch.from_numpy(fx["x"]), "num_nodes": n}
+    cfg = {k: fx.cfg[k] for k in ("thresh_cn", "thresh_1hop", "thresh_non1hop", "dim", "trans_layers", "num_heads",
+                                  "att_drop", "dropout", "gnn_drop", "feat_drop", "gcn_cache", "gnn_layers",
+                                  "residual", "layer_norm", "relu")}
+    return lpformer_amd.LinkTransformer(cfg, data, device=device)
+
+
+@pytest.mark.parametrize("case", LP_CASES)
+def test_state_dict_keys_match_reference(case):
+    fx = Fixture(case)
+    model = _model_for(fx)
+    score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, fx.cfg["pred_layers"])
+    want = fx.cfg["param_shapes"]
+    got = {f"model.{k}": list(v.shape) for k, v in model.state_dict().items()}
+    got.update({f"score.{k}": list(v.shape) for k, v in score.state_dict().items()})
+    assert got == want
+    m_sd, s_sd = fx.state_dicts()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in m_sd.items()}, strict=True)
+    score.load_state_dict({k: torch.from_numpy(v) for k, v in s_sd.items()}, strict=True)
+
+
+def test_no_cpu_fallback():
+    fx = Fixture("lp_all_d64")
+    model = _model_for(fx).eval()
+    with pytest.raises(Exception):
+        model.elementwise_lin(torch.zeros(4, 64))
+    with pytest.raises(NotImplementedError):
+        model.train()
+        model.propagate()
+
+
+def test_graph_builders_match_oracle():
+    fx = Fixture("lp_all_d128_weighted")
+    n = fx.n
+    m_o = O.symmetric_mask_csr(fx.edge_index, n)
+    m = graph.mask_csr(fx.edge_index, n)
+    np.testing.assert_array_equal(m.rowptr, m_o[0])
+    np.testing.assert_array_equal(m.col, m_o[1])
+    s = graph.gcn_structure_csr(fx.edge_index, fx.edge_weight, n)
+    a_o = O.gcn_norm(fx.edge_index, fx.edge_weight, n)
+    np.testing.assert_array_equal(s.rowptr, a_o[0])
+    np.testing.assert_array_equal(s.col, a_o[1])
+    r, c, v = fx.ppr_coo
+    p = graph.csr_from_coo(r, c, v, n)
+    pf = graph.prefilter_nonhop(p, fx.cfg["thresh_non1hop"])
+    assert 0 < pf.nnz < p.nnz
+    coo = p.to_torch_sparse_coo()
+    r2, c2, v2, n2 = graph.as_coo_numpy(coo)
+    np.testing.assert_array_equal(r2, r)
+    np.testing.assert_array_equal(c2, c)
+    np.testing.assert_array_equal(v2, v)
+
+
+def test_fold_algebra_matches_oracle():
+    """k_e = Z[v] + Wfold h_e + bfold and the closed-form LayerNorm statistics reproduce the reference's
+    lin_r([X[v] ; pe_e]) (float64 check of the algebra the kernels rely on)."""
+    fx = Fixture("lp_all_d64")
+    P = fx.params
+    m_sd, _ = fx.state_dicts()
+    sd = {k: torch.from_numpy(v) for k, v in m_sd.items()}
+    d = fx.cfg["dim"]
+    w = fold.fold_attention(sd, d, 3)
+    tab, stat = fold.pe_tables(sd, d, 3)
+    rng = np.random.default_rng(0)
+    pa, pb = rng.random(50).astype(np.float32) * 0.1, rng.random(50).astype(np.float32) * 0.1
+    xv = rng.standard_normal((50, d)).astype(np.float32)
+    for t, tag in enumerate(("cn", "onehop", "non1hop")):
+        sel = {tag: (np.zeros((2, 50), np.int64), pa, pb)}
+        pes = O.pos_encodings(sel, P)
+        k_ref = O.linear(np.concatenate([xv, pes], axis=1), P["model.att_layers.0.att.lin_r.weight"],
+                         P["model.att_layers.0.att.lin_r.bias"])
+
+        def hidden(x, y):
+            var = (stat[t, 0] * x * x + stat[t, 1] * y * y + stat[t, 2]
+                   + 2 * (stat[t, 3] * x * y + stat[t, 4] * x + stat[t, 5] * y))
+            rstd = 1.0 / np.sqrt(var + 1e-5)
+            u = tab[t, :, 0][None] * x[:, None] + tab[t, :, 1][None] * y[:, None] + tab[t, :, 2][None]
+            return np.maximum(rstd[:, None] * u + tab[t, :, 3][None], 0)
+
+        h = hidden(pa, pb) + hidden(pb, pa)
+        k = xv @ w["w_rx"].T + w["b_r"] + h @ w["wfold"][t].T + w["bfold"][t]
+        assert np.abs(k - k_ref).max() < 2e-5
+    # packed image is a permutation of wfold
+    pk = w["wfold_packed"]
+    c, sq, lane, u = 1, 3, 45, 2
+    assert pk[2, c, sq, lane, u] == w["wfold"][2, 32 * c + (lane & 31), (lane >> 5) * (d // 2) + 4 * sq + u]
