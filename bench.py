@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: candidate link-pairs scored per second on a synthetic ogbl-collab-shaped graph.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config collab] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = the pair stage of the scoring path over one batch of candidate pairs with the encoder output
+resident in HBM (the reference's HeaRT / citation2 evaluation pattern, src/train/testing.py:96-121:
+``propagate()`` once, then per batch ``elementwise_lin(h[a]*h[b])``, ``calc_pairwise``, ``score_func``):
+endpoint gathers, q projection, PPR-thresholded node selection, PE + attention, count features, ``pairwise_lin``,
+``elementwise_lin`` and the ``mlp_score`` head, scores landing in device memory.  The encoder (L x GEMM + CSR SpMM,
+row-sharded with an RCCL all-gather per layer when N > 1) is timed separately and reported as ``encoder_ms``; the
+throughput including one encoder pass per batch (the reference's ``test_edge`` pattern) is ``value_incl_encoder``.
+
+Data are synthetic (no datasets offline): Chung-Lu power-law graph with ogbl-collab's node/edge counts and integer
+edge weights, N(0,1) features, PPR from the library's own push (alpha 0.15, eps 5e-5), random-init weights.
+Pairs are half existing edges, half uniform random; several distinct batches are cycled.
+
+Rank 0 prints ONE JSON line.  N > 1: weak scaling, every rank scores its own 32,768-pair batches, no collective
+on the pair path; time = max over ranks, value = pairs of all ranks / time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import lpformer_amd  # noqa: E402
+from lpformer_amd import data as D  # noqa: E402
+from lpformer_amd import dist as LD  # noqa: E402
+from lpformer_amd.profile import KernelTimer  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+
+
+def build_problem(cfg, rank, world, threads):
+    n = cfg["n"]
+    t0 = time.time()
+    ei, w = D.chung_lu_graph(n, cfg["edges"], gamma=cfg["gamma"], seed=0, max_weight=cfg["max_weight"])
+    x = np.random.default_rng(1).standard_normal((n, cfg["f_in"])).astype(np.float32)
+    t1 = time.time()
+    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr_threads=threads)
+    t2 = time.time()
+    return ei, w, x, data, {"graph_s": t1 - t0, "ppr_s": t2 - t1}
+
+
+def pair_stats(data, batch, thresholds):
+    """Per-batch structural sizes that the algorithmic byte/FLOP counts are built from."""
+    adj, ppr = data["adj_mask"], data["ppr"]
+    a, b = batch[0], batch[1]
+    deg = np.diff(adj.rowptr)
+    plen = np.diff(ppr.rowptr)
+    return {"sum_deg": int(deg[a].sum() + deg[b].sum()), "sum_ppr_len": int(plen[a].sum() + plen[b].sum())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="collab", choices=sorted(D.CONFIGS))
+    ap.add_argument("--batches", type=int, default=4, help="distinct candidate batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="pairs timed on the CPU oracle")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = LD.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    cfg = D.CONFIGS[args.config]
+    n, d, bs = cfg["n"], cfg["dim"], cfg["batch"]
+    host_threads = max(1, (os.cpu_count() or 8) // world)
+
+    ei, w, x, data, setup = build_problem(cfg, rank, world, host_threads)
+    targs = D.train_args_for(cfg)
+    torch.manual_seed(0)
+    model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev).eval()
+    score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
+    if world > 1:
+        model.set_row_shard(rank, world)
+
+    # candidate batches resident in HBM before the timed region; distinct per rank
+    batches_np = [D.sample_pairs(ei, n, bs, seed=1000 * rank + i) for i in range(args.batches)]
+    batches = [torch.from_numpy(b).to(dev) for b in batches_np]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    # ---- encoder (timed separately; output stays resident)
+    for _ in range(2):
+        h = model.propagate()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    enc_reps = 5
+    for _ in range(enc_reps):
+        h = model.propagate()
+    torch.cuda.synchronize()
+    barrier()
+    encoder_ms = LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / enc_reps, dev)
+
+    def step(i):
+        feats = model.pair_features(batches[i % len(batches)], h)
+        return score(feats)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    KernelTimer.reset()
+    KernelTimer.enabled = not args.no_kernel_timing
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = LD.max_over_ranks(time.perf_counter() - t0, dev)
+    KernelTimer.enabled = False
+    assert torch.isfinite(out).all()
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    pairs_per_s = world * bs * args.steps / elapsed
+    value_incl_encoder = world * bs / ((ms_per_step + encoder_ms) * 1e-3)
+
+    result = None
+    if rank == 0:
+        kt = KernelTimer.summary() if not args.no_kernel_timing else {}
+        # ---- roofline of the dominant kernel (largest share of the timed region)
+        roofline = None
+        kernels = {}
+        if kt:
+            tot = sum(v[1] for v in kt.values())
+            kernels = {k: {"launches": v[0], "ms_per_step": round(v[1] / args.steps, 4),
+                           "share": round(v[1] / tot, 3)} for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])}
+            dom = max(kt.items(), key=lambda kv: kv[1][1])[0]
+            # structural totals over the batches actually timed
+            tp = [model.compute_node_mask(b) for b in batches]
+            nsel = [sum(int(t[0].shape[1]) for t in sel if t is not None) for sel in tp]
+            stats = [pair_stats(data, b, cfg["thresholds"]) for b in batches_np]
+            used = [i % len(batches) for i in range(args.steps)]
+            mean = lambda arr: float(np.mean([arr[i] for i in used]))  # noqa: E731
+            n_sel, sum_deg, sum_ppr = mean(nsel), mean([s["sum_deg"] for s in stats]), \
+                mean([s["sum_ppr_len"] for s in stats])
+            launches_per_step = kt[dom][0] / args.steps
+            dur_s = kt[dom][2] * 1e-3
+            if dom == "pair_scores":
+                flops = n_sel * (2.0 * d * d + 20.0 * d)          # n_sel * (2 D^2 + ~20 D)
+                ach = flops / dur_s / 1e12
+                roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None}
+            else:
+                if dom == "select_nodes":
+                    # SURVEY 8(d) pair-stage bytes that belong to selection: adjacency rows + PPR rows + row
+                    # pointers + pair ids (the feature-row terms belong to the attention kernels)
+                    byts = 4.0 * sum_deg + 8.0 * sum_ppr + bs * (32 + 16)
+                elif dom == "pair_softmax_gather":
+                    byts = n_sel * (4.0 * d + 16.0) + bs * (4.0 * (4 * d + 4) + 24.0)
+                elif dom.startswith("gemm"):
+                    byts = None
+                else:
+                    byts = None
+                if byts is not None:
+                    ach = byts / dur_s / 1e9
+                    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+                else:
+                    roofline = {"kernel": dom, "bound": "mfma", "achieved": None, "peak": F32_MFMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": None, "traffic": None}
+            roofline["launch_ms"] = round(kt[dom][2], 4)
+            roofline["launches_per_step"] = launches_per_step
+            roofline["batch_stats"] = {"n_sel": n_sel, "sum_deg": sum_deg, "sum_ppr_len": sum_ppr}
+
+        # ---- CPU baseline: the oracle's pair stage on a bounded sample of the same workload
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import lpformer_oracle as O
+            torch.set_num_threads(os.cpu_count() or 8)
+            P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+            P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
+            sample = batches_np[0][:, :args.cpu_sample]
+            hx = h.cpu().numpy()
+            mask, ppr = data["adj_mask"], data["ppr"]
+            okw = dict(x=None, adj_norm=None, adj_mask=(mask.rowptr, mask.col.astype(np.int64)),
+                       ppr=(ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P=P, cfg=dict(targs, pred_layers=2),
+                       x_node=hx)
+            t0 = time.perf_counter()
+            ref = O.forward(sample, **okw)
+            cpu_s = time.perf_counter() - t0
+            # check the GPU scores of the same pairs against it while we are here
+            gl = score.logits(model.pair_features(batches[0][:, :args.cpu_sample], h)).cpu().numpy()
+            cpu = {"value": round(sample.shape[1] / cpu_s, 1), "unit": "pairs/s", "cores": os.cpu_count(),
+                   "kind": "port",
+                   "sample": f"{sample.shape[1]} pairs of batch 0 (pair stage, encoder output resident), numpy oracle "
+                             f"in {cpu_s:.1f} s",
+                   "max_abs_logit_diff_vs_gpu": float(np.abs(gl - ref['logit']).max())}
+
+        result = {
+            "metric": "candidate link-pairs scored/sec (whole node)", "value": round(pairs_per_s, 1),
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}-like synthetic graph (N={n}, {cfg['edges']} undirected edges, "
+                                   f"F={cfg['f_in']}, D={d}, L={cfg['gnn_layers']}, thresholds={cfg['thresholds']}, "
+                                   f"PPR eps={cfg['eps']}), {bs} candidate pairs per GPU per step, pair stage with "
+                                   "encoder output resident",
+                       "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
+                       "parallelism": f"pairs sharded x{world}, encoder row-sharded + all-gather" if world > 1
+                       else "single GPU"},
+            "encoder_ms": round(encoder_ms, 4), "value_incl_encoder": round(value_incl_encoder, 1),
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "setup_s": {k: round(v, 2) for k, v in setup.items()},
+        }
+        print(json.dumps(result), flush=True)
+    barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""Multi-GPU layout for the scoring path: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL).
+
+The reference is single-process, single-device (src/run.py:21,94); this layout is new.
+
+* Graph structures (CSR adjacency, PPR) and weights are replicated on every GPU (they fit 288 GB many times over).
+* The encoder is row-sharded: rank r owns a contiguous block of node rows.  Each GCN layer needs the previous
+  layer's full activations for its neighbour gather, so a layer is: GEMM + fused SpMM on the local rows, then one
+  ``all_gather`` of the layer output.  The last of them is "the" all-gather of node embeddings; afterwards every
+  rank holds X_node and derives Z = X W_rx^T + b_r locally.
+* Candidate pairs are independent units: a batch is split by pair index, no collective on the pair path
+  (weak scaling: per-GPU batch fixed).
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU); RCCL picks the algorithm, the message is one contiguous
+[rows, D] fp32 block per rank, so the all-gather is a single collective per layer (no bucketing needed).
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's environment; initialises the default group if world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def row_range(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced row block of rank `rank` (first n % world ranks get one extra row)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_pairs(batch: torch.Tensor, world: int, rank: int) -> torch.Tensor:
+    """Columns [lo, hi) of a [2, BS] candidate batch owned by `rank` (contiguous split by pair index)."""
+    lo, hi = row_range(batch.shape[1], world, rank)
+    return batch[:, lo:hi]
+
+
+def allgather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
+    """Assemble the full [n, D] matrix from every rank's row block (blocks follow ``row_range``)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    d = local.shape[1]
+    full = torch.empty(n, d, dtype=local.dtype, device=local.device)
+    sizes = [row_range(n, world, r) for r in range(world)]
+    if n % world == 0:
+        dist.all_gather_into_tensor(full, local.contiguous(), group=group)  # one ncclAllGather
+    else:
+        parts = [full[lo:hi] for lo, hi in sizes]
+        dist.all_gather(parts, local.contiguous(), group=group)
+    return full
+
+
+def gather_scores(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """Concatenate per-rank score vectors in rank order (only needed when one rank wants the whole batch)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    return allgather_rows(local.reshape(-1, 1), total, group).reshape(-1)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -20,7 +20,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, fold, graph
+from . import dist as lpf_dist
 from ._lib import FLAG_RELU, check, ptr
+from .profile import KernelTimer
 
 
 def _stream(device):
@@ -58,7 +60,8 @@ def _as_f32_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ kernels wrappers
-def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, addend=None, relu=False, out=None) -> torch.Tensor:
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, addend=None, relu=False, out=None,
+         tag="gemm") -> torch.Tensor:
     """out = a @ w.T (+bias) (+addend) (ReLU) through ``lpf_gemm_f32``.  ``a``/``w`` rows must be 16-byte aligned."""
     _require_gpu(a, "gemm")
     m, k = a.shape
@@ -66,17 +69,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, addend=None, relu=False, o
     assert w.shape[1] == k, (a.shape, w.shape)
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
-    check(_lib.hip().lpf_gemm_f32(m, n, k, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(addend),
-                                  0 if addend is None else addend.stride(0), ptr(out), out.stride(0),
-                                  FLAG_RELU if relu else 0, _stream(a.device)), "lpf_gemm_f32")
+    with KernelTimer.span(tag):
+        check(_lib.hip().lpf_gemm_f32(m, n, k, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(addend),
+                                      0 if addend is None else addend.stride(0), ptr(out), out.stride(0),
+                                      FLAG_RELU if relu else 0, _stream(a.device)), "lpf_gemm_f32")
     return out
 
 
 def layernorm_(x: torch.Tensor, g, b, relu=False, out=None) -> torch.Tensor:
     out = x if out is None else out
-    check(_lib.hip().lpf_layernorm_f32(x.shape[0], x.shape[1], ptr(x), x.stride(0), ptr(g), ptr(b), ptr(out),
-                                       out.stride(0), FLAG_RELU if relu else 0, _stream(x.device)),
-          "lpf_layernorm_f32")
+    with KernelTimer.span("layernorm"):
+        check(_lib.hip().lpf_layernorm_f32(x.shape[0], x.shape[1], ptr(x), x.stride(0), ptr(g), ptr(b), ptr(out),
+                                           out.stride(0), FLAG_RELU if relu else 0, _stream(x.device)),
+              "lpf_layernorm_f32")
     return out
 
 
@@ -337,6 +342,7 @@ class LinkTransformer(nn.Module):
         self._ws = {}          # named workspaces
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
         self.last_stats = {}
+        self._shard = (0, 1)   # (rank, world) for the row-sharded encoder
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self):
@@ -424,27 +430,40 @@ class LinkTransformer(nn.Module):
             x = self._features()
             st = _stream(self.device)
             n_layers = len(enc.convs)
+            rank, world = self._shard
+            lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
             for i, conv in enumerate(enc.convs):
-                t = gemm(x, self._conv_pads[i].get(conv.lin.weight))
+                # dense transform of ALL rows (cheap, replicated), aggregation of the local row block only
+                t = gemm(x, self._conv_pads[i].get(conv.lin.weight), tag="gemm_encoder")
                 d = t.shape[1]
                 last = i == n_layers - 1
-                res = x if (enc.residual and x.shape[1] == d) else None
+                res = x[lo:hi] if (enc.residual and x.shape[1] == d) else None
                 ln = enc.lns[i] if enc.lns is not None else None
-                out = torch.empty(self.num_nodes, d, dtype=torch.float32, device=self.device)
-                check(_lib.hip().lpf_spmm_csr_f32(
-                    self.num_nodes, d, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(t), t.stride(0),
-                    ptr(out), out.stride(0), ptr(conv.bias), ptr(ln.weight) if ln is not None else None,
-                    ptr(ln.bias) if ln is not None else None, ptr(res), 0 if res is None else res.stride(0),
-                    ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
-                    FLAG_RELU if enc.relu else 0, st), "lpf_spmm_csr_f32")
-                x = out
+                out = torch.empty(hi - lo, d, dtype=torch.float32, device=self.device)
+                with KernelTimer.span("spmm_csr"):
+                    check(_lib.hip().lpf_spmm_csr_f32(
+                        hi - lo, d, a_hat.rowptr.data_ptr() + 8 * lo, ptr(a_hat.col), ptr(a_hat.val), ptr(t),
+                        t.stride(0), ptr(out), out.stride(0), ptr(conv.bias),
+                        ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
+                        ptr(res), 0 if res is None else res.stride(0),
+                        ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
+                        FLAG_RELU if enc.relu else 0, st), "lpf_spmm_csr_f32")
+                # every rank needs the full layer output for the next neighbour gather; the last of these
+                # collectives is the all-gather of node embeddings (RCCL over xGMI)
+                x = lpf_dist.allgather_rows(out, self.num_nodes) if world > 1 else out
             return x
+
+    def set_row_shard(self, rank: int, world: int):
+        """Row-shard the encoder across `world` ranks of the default process group (see lpformer_amd/dist.py)."""
+        if not (0 <= rank < world):
+            raise ValueError("need 0 <= rank < world")
+        self._shard = (rank, world)
 
     def _node_keys(self, x_node: torch.Tensor, w) -> torch.Tensor:
         """Z = X_node W_rx^T + b_r, once per encoder output (cached on the tensor's identity and version)."""
         key = (x_node.data_ptr(), x_node._version, tuple(x_node.shape))
         if self._z_cache is None or self._z_cache[0] != key:
-            self._z_cache = (key, gemm(_as_f32_rows(x_node), w["w_rx"], w["b_r"]))
+            self._z_cache = (key, gemm(_as_f32_rows(x_node), w["w_rx"], w["b_r"], tag="gemm_node_keys"))
         return self._z_cache[1]
 
     # ---------------------------------------------------------------------------------- selection
@@ -459,32 +478,36 @@ class LinkTransformer(nn.Module):
         t0 = self._device_graph("t0", self._data_obj("ppr", test_set)) if want_t0 else None
 
         stage_off = self._workspace("stage_off", bs + 1, torch.int64)
-        check(lib.lpf_select_bound(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr),
-                                   ptr(t0.rowptr) if want_t0 else None, ptr(stage_off), st), "lpf_select_bound")
+        with KernelTimer.span("select_bound"):
+            check(lib.lpf_select_bound(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr),
+                                       ptr(t0.rowptr) if want_t0 else None, ptr(stage_off), st), "lpf_select_bound")
         cap = int(stage_off[bs].item())  # one 8-byte read-back sizes the staging area
         stage_node = self._workspace("stage_node", cap, torch.int32)
         stage_pa = self._workspace("stage_pa", cap, torch.float32)
         stage_pb = self._workspace("stage_pb", cap, torch.float32)
         stage_cnt = self._workspace("stage_cnt", 4 * bs, torch.int32)
-        check(lib.lpf_select_nodes(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(adj.col), ptr(adjx.rowptr),
-                                   ptr(adjx.col), ptr(ppr.rowptr), ptr(ppr.col), ptr(ppr.val),
-                                   ptr(t0.rowptr) if want_t0 else None, ptr(t0.col) if want_t0 else None,
-                                   ptr(t0.val) if want_t0 else None, float(self.thresh_cn), float(self.thresh_1hop),
-                                   float(self.thresh_non1hop), ptr(stage_off), ptr(stage_node), ptr(stage_pa),
-                                   ptr(stage_pb), ptr(stage_cnt), st), "lpf_select_nodes")
+        with KernelTimer.span("select_nodes"):
+            check(lib.lpf_select_nodes(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(adj.col), ptr(adjx.rowptr),
+                                       ptr(adjx.col), ptr(ppr.rowptr), ptr(ppr.col), ptr(ppr.val),
+                                       ptr(t0.rowptr) if want_t0 else None, ptr(t0.col) if want_t0 else None,
+                                       ptr(t0.val) if want_t0 else None, float(self.thresh_cn), float(self.thresh_1hop),
+                                       float(self.thresh_non1hop), ptr(stage_off), ptr(stage_node), ptr(stage_pa),
+                                       ptr(stage_pb), ptr(stage_cnt), st), "lpf_select_nodes")
         ldf = _pad4(self.dim + self.count_dim)
         feats = torch.zeros(bs, ldf, dtype=torch.float32, device=self.device)  # [att out | counts | pad]
         type_ptr = self._workspace("type_ptr", 3 * (bs + 1), torch.int64)
-        check(lib.lpf_select_scan(bs, ptr(stage_cnt), ptr(type_ptr), feats.data_ptr() + 4 * self.dim, ldf,
-                                  1 if want_t0 else 0, st), "lpf_select_scan")
+        with KernelTimer.span("select_scan"):
+            check(lib.lpf_select_scan(bs, ptr(stage_cnt), ptr(type_ptr), feats.data_ptr() + 4 * self.dim, ldf,
+                                      1 if want_t0 else 0, st), "lpf_select_scan")
         sel_pair = self._workspace("sel_pair", cap, torch.int32)
         sel_node = self._workspace("sel_node", cap, torch.int32)
         sel_pa = self._workspace("sel_pa", cap, torch.float32)
         sel_pb = self._workspace("sel_pb", cap, torch.float32)
-        check(lib.lpf_select_compact(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(stage_off),
-                                     ptr(stage_node), ptr(stage_pa), ptr(stage_pb), ptr(stage_cnt), ptr(type_ptr),
-                                     ptr(sel_pair), ptr(sel_node), ptr(sel_pa), ptr(sel_pb), st),
-              "lpf_select_compact")
+        with KernelTimer.span("select_compact"):
+            check(lib.lpf_select_compact(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(stage_off),
+                                         ptr(stage_node), ptr(stage_pa), ptr(stage_pb), ptr(stage_cnt), ptr(type_ptr),
+                                         ptr(sel_pair), ptr(sel_node), ptr(sel_pa), ptr(sel_pb), st),
+                  "lpf_select_compact")
         return {"bs": bs, "cap": cap, "type_ptr": type_ptr, "sel_pair": sel_pair, "sel_node": sel_node,
                 "sel_pa": sel_pa, "sel_pb": sel_pb, "feats": feats, "ldf": ldf}
 
@@ -534,27 +557,30 @@ class LinkTransformer(nn.Module):
             z = self._node_keys(x_node, w)
 
             qin = torch.empty(bs, d, dtype=torch.float32, device=self.device)
-            check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0), None, 0,
-                                          ptr(qin), d, st), "lpf_pair_gather_f32")
-            q = gemm(qin, w["w_l"], w["b_l2"])
+            with KernelTimer.span("pair_gather"):
+                check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0), None, 0,
+                                              ptr(qin), d, st), "lpf_pair_gather_f32")
+            q = gemm(qin, w["w_l"], w["b_l2"], tag="gemm_q")
 
             s = self._select(batch, test_set, adj_mask)
             score = self._workspace("score", s["cap"], torch.float32)
-            check(lib.lpf_pair_scores_f32(d, ptr(s["type_ptr"]), bs, ptr(s["sel_pair"]), ptr(s["sel_node"]),
-                                          ptr(s["sel_pa"]), ptr(s["sel_pb"]), ptr(z), z.stride(0), ptr(q),
-                                          q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]),
-                                          ptr(w["bfold"]), ptr(w["att"]), ptr(score), s["cap"], st),
-                  "lpf_pair_scores_f32")
+            with KernelTimer.span("pair_scores"):
+                check(lib.lpf_pair_scores_f32(d, ptr(s["type_ptr"]), bs, ptr(s["sel_pair"]), ptr(s["sel_node"]),
+                                              ptr(s["sel_pa"]), ptr(s["sel_pb"]), ptr(z), z.stride(0), ptr(q),
+                                              q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]),
+                                              ptr(w["bfold"]), ptr(w["att"]), ptr(score), s["cap"], st),
+                      "lpf_pair_scores_f32")
             ldg = 4 * d + 4
             g = torch.empty(bs, ldg, dtype=torch.float32, device=self.device)
             alpha = torch.empty(s["cap"], dtype=torch.float32, device=self.device) if return_weights else None
-            check(lib.lpf_pair_softmax_gather_f32(d, bs, ptr(s["type_ptr"]), ptr(s["sel_node"]), ptr(s["sel_pa"]),
-                                                  ptr(s["sel_pb"]), ptr(score), ptr(z), z.stride(0),
-                                                  ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(g), ldg, ptr(alpha), st),
-                  "lpf_pair_softmax_gather_f32")
+            with KernelTimer.span("pair_softmax_gather"):
+                check(lib.lpf_pair_softmax_gather_f32(d, bs, ptr(s["type_ptr"]), ptr(s["sel_node"]), ptr(s["sel_pa"]),
+                                                      ptr(s["sel_pb"]), ptr(score), ptr(z), z.stride(0),
+                                                      ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(g), ldg, ptr(alpha), st),
+                      "lpf_pair_softmax_gather_f32")
             feats = s["feats"]
             att_view = feats[:, :d]
-            gemm(g[:, d:], w["wcat"], None, addend=g[:, :d], out=att_view)      # sum_e alpha_e k_e + bias
+            gemm(g[:, d:], w["wcat"], None, addend=g[:, :d], out=att_view, tag="gemm_attn_out")      # sum_e alpha_e k_e + bias
             layer = self.att_layers[0]
             layernorm_(att_view, layer.post_att_norm.weight, layer.post_att_norm.bias)
             self._last_att = att_view
@@ -589,8 +615,9 @@ class LinkTransformer(nn.Module):
             x_node = _as_f32_rows(X_node)
             comb = torch.empty(bs, 2 * d, dtype=torch.float32, device=self.device)
             prod = torch.empty(bs, d, dtype=torch.float32, device=self.device)
-            check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0),
-                                          ptr(prod), d, None, 0, st), "lpf_pair_gather_f32")
+            with KernelTimer.span("pair_gather"):
+                check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0),
+                                              ptr(prod), d, None, 0, st), "lpf_pair_gather_f32")
             self.elementwise_lin.run(prod, out=comb[:, :d])
             _, attw = self.calc_pairwise(batch, x_node, test_set, adj_mask, return_weights, _out=comb[:, d:])
             return (comb, attw) if return_weights else comb
