@@ -93,9 +93,11 @@ int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t bat
 
 /* Per-pair upper bound on staged entries and its exclusive scan (feeds lpf_select_nodes).
  *   ub_k = 2*deg(a) + deg(b) + min(len T0[a], len T0[b])      (T0 = the CSR scanned for >1-hop nodes)
- * stage_off: int64[bs+1] (stage_off[bs] = total).  t0_rowptr may be NULL (mode "1-hop": no >1-hop part). */
+ * stage_off: int64[bs+1] (stage_off[bs] = total).  t0_rowptr may be NULL (mode "1-hop": no >1-hop part).
+ * scratch: int64[LPF_SELECT_SCRATCH_ELEMS(bs)] (block sums of the two-kernel scan). */
+#define LPF_SELECT_SCRATCH_ELEMS(bs) (3 * (((bs) + 255) / 256) + 3)
 int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
-                     const int64_t *t0_rowptr, int64_t *stage_off, void *stream);
+                     const int64_t *t0_rowptr, int64_t *stage_off, int64_t *scratch, void *stream);
 
 /* Node selection for a batch of pairs: compute_node_mask + get_ppr_vals + get_non_1hop_ppr
  * (link_transformer.py:214-319,434-481), eval mode.  One wavefront per pair; integer/bit-exact.
@@ -123,9 +125,10 @@ int lpf_select_nodes(int64_t bs, const int64_t *batch, int64_t batch_ld,
 /* Exclusive scans of the per-pair counts per type + totals:
  *   type_ptr: int64[3*(bs+1)]  rows = (cn, 1-hop, >1-hop) ; type_ptr[t*(bs+1)+bs] = total of type t
  *   counts_f: float[bs, ldc] receives the structural count features of get_structure_cnts
- *             (link_transformer.py:340-356): n_cn, n_1hop, [n_non1hop if want_t0], n_cn+n_1hop */
+ *             (link_transformer.py:340-356): n_cn, n_1hop, [n_non1hop if want_t0], n_cn+n_1hop
+ *   scratch:  int64[LPF_SELECT_SCRATCH_ELEMS(bs)] */
 int lpf_select_scan(int64_t bs, const int32_t *stage_cnt, int64_t *type_ptr, float *counts_f, int64_t ldc,
-                    int32_t want_t0, void *stream);
+                    int32_t want_t0, int64_t *scratch, void *stream);
 
 /* Compaction into the reference's layout: all CN entries sorted by (pair, node), then all 1-hop, then all
  * >1-hop (link_transformer.py:161-162).  Entry e of type t lives at  type_base(t) + type_ptr[t][k] + j  with

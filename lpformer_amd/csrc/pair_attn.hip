@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
     float *__restrict__ Gout, int64_t ldg, float *__restrict__ alpha_out) {
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
-    const int grp = lane / G, lig = lane % G;
+    const int grp = lane / G, lig = lane % G, gbase = grp * G;
     const int off = 4 * lig;
     const bool act = off < D;
     const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -178,23 +178,47 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 k[u] = act ? reinterpret_cast<const float4 *>(pe_tab)[t * D + off + u] : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = 0; i < cnt[t]; ++i) {
+            // chunks of G entries: lane i fetches the metadata of entry i (coalesced) and does the per-entry scalar
+            // math once; the inner loop broadcasts entry by entry while every lane gathers its 16 bytes of the Z row
+            for (int base = 0; base < cnt[t]; base += G) {
+                const int i = base + lig;
+                const bool valid = i < cnt[t];
                 const int64_t e = beg[t] + i;
-                const float alpha = expf(score[e] - m) / den;
-                const float pa = sel_pa[e], pb = sel_pb[e];
-                const int32_t node = sel_node[e];
-                const float r_ab = pe_rstd(st, pa, pb), r_ba = pe_rstd(st, pb, pa);
-                if (act) {
-                    const float4 z = *reinterpret_cast<const float4 *>(Z + (int64_t)node * ldz + off);
-                    accz.x = fmaf(alpha, z.x, accz.x); accz.y = fmaf(alpha, z.y, accz.y);
-                    accz.z = fmaf(alpha, z.z, accz.z); accz.w = fmaf(alpha, z.w, accz.w);
-                    acch[t].x = fmaf(alpha, pe_hidden(k[0], pa, pb, r_ab, r_ba), acch[t].x);
-                    acch[t].y = fmaf(alpha, pe_hidden(k[1], pa, pb, r_ab, r_ba), acch[t].y);
-                    acch[t].z = fmaf(alpha, pe_hidden(k[2], pa, pb, r_ab, r_ba), acch[t].z);
-                    acch[t].w = fmaf(alpha, pe_hidden(k[3], pa, pb, r_ab, r_ba), acch[t].w);
+                const float my_alpha = valid ? expf(score[e] - m) / den : 0.f;
+                const float my_pa = valid ? sel_pa[e] : 0.f, my_pb = valid ? sel_pb[e] : 0.f;
+                const int32_t my_node = valid ? sel_node[e] : 0;
+                const float my_rab = pe_rstd(st, my_pa, my_pb), my_rba = pe_rstd(st, my_pb, my_pa);
+                if (alpha_out && valid) alpha_out[e] = my_alpha;
+                const int n_here = (cnt[t] - base) < G ? (cnt[t] - base) : G;
+                for (int j = 0; j < n_here; j += 2) {  // lanes past n_here carry alpha = 0, node = 0: harmless
+                    float al[2], pa[2], pb[2], rab[2], rba[2];
+                    int32_t nd[2];
+                    float4 z[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int src = gbase + ((j + u) & (G - 1));
+                        al[u] = __shfl(my_alpha, src, 64);
+                        nd[u] = __shfl(my_node, src, 64);
+                        pa[u] = __shfl(my_pa, src, 64);
+                        pb[u] = __shfl(my_pb, src, 64);
+                        rab[u] = __shfl(my_rab, src, 64);
+                        rba[u] = __shfl(my_rba, src, 64);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        z[u] = act ? *reinterpret_cast<const float4 *>(Z + (int64_t)nd[u] * ldz + off)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        accz.x = fmaf(al[u], z[u].x, accz.x); accz.y = fmaf(al[u], z[u].y, accz.y);
+                        accz.z = fmaf(al[u], z[u].z, accz.z); accz.w = fmaf(al[u], z[u].w, accz.w);
+                        acch[t].x = fmaf(al[u], pe_hidden(k[0], pa[u], pb[u], rab[u], rba[u]), acch[t].x);
+                        acch[t].y = fmaf(al[u], pe_hidden(k[1], pa[u], pb[u], rab[u], rba[u]), acch[t].y);
+                        acch[t].z = fmaf(al[u], pe_hidden(k[2], pa[u], pb[u], rab[u], rba[u]), acch[t].z);
+                        acch[t].w = fmaf(al[u], pe_hidden(k[3], pa[u], pb[u], rab[u], rba[u]), acch[t].w);
+                        asum[t] += al[u];
+                    }
                 }
-                asum[t] += alpha;
-                if (alpha_out && lig == 0) alpha_out[e] = alpha;
             }
         }
         if (live) {

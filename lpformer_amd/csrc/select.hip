@@ -43,69 +43,109 @@ __device__ __forceinline__ int lanes_below(uint64_t mask, int lane) {
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Block-wide sum of one int64 per thread (256 threads); result valid in every thread.
+__device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *lds4) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
 __global__ __launch_bounds__(256) void select_bound_kernel(int64_t bs, const int64_t *__restrict__ batch,
                                                            int64_t batch_ld, const int64_t *__restrict__ adj_rowptr,
                                                            const int64_t *__restrict__ t0_rowptr,
-                                                           int64_t *__restrict__ stage_off) {
+                                                           int64_t *__restrict__ stage_off,
+                                                           int64_t *__restrict__ blk) {
+    __shared__ int64_t red[4];
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) stage_off[0] = 0;
-    if (k >= bs) return;
-    const int64_t a = batch[k], b = batch[batch_ld + k];
-    const int64_t dA = adj_rowptr[a + 1] - adj_rowptr[a], dB = adj_rowptr[b + 1] - adj_rowptr[b];
-    int64_t ub = 2 * dA + dB;
-    if (t0_rowptr) {
-        const int64_t ha = t0_rowptr[a + 1] - t0_rowptr[a], hb = t0_rowptr[b + 1] - t0_rowptr[b];
-        ub += ha < hb ? ha : hb;
-    }
-    stage_off[k + 1] = ub;
-}
-
-// In-place inclusive scan of NSEQ int64 sequences of length n (sequence q lives at data + q*stride).
-// One 1024-thread block: each thread scans a contiguous chunk, the 1024 chunk sums are scanned through LDS.
-template <int NSEQ>
-__global__ __launch_bounds__(1024) void scan_i64_kernel(int64_t n, int64_t *__restrict__ data, int64_t stride) {
-    __shared__ int64_t part[NSEQ][1024];
-    const int t = threadIdx.x;
-    const int64_t chunk = (n + 1023) / 1024;
-    const int64_t lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-#pragma unroll
-    for (int q = 0; q < NSEQ; ++q) {
-        int64_t s = 0;
-        for (int64_t i = lo; i < hi; ++i) s += data[q * stride + i];
-        part[q][t] = s;
-    }
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele over the chunk sums
-        int64_t v[NSEQ];
-#pragma unroll
-        for (int q = 0; q < NSEQ; ++q) v[q] = (t >= d) ? part[q][t - d] : 0;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NSEQ; ++q) part[q][t] += v[q];
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < NSEQ; ++q) {
-        int64_t run = (t > 0) ? part[q][t - 1] : 0;
-        for (int64_t i = lo; i < hi; ++i) {
-            run += data[q * stride + i];
-            data[q * stride + i] = run;
+    int64_t ub = 0;
+    if (k < bs) {
+        const int64_t a = batch[k], b = batch[batch_ld + k];
+        const int64_t dA = adj_rowptr[a + 1] - adj_rowptr[a], dB = adj_rowptr[b + 1] - adj_rowptr[b];
+        ub = 2 * dA + dB;
+        if (t0_rowptr) {
+            const int64_t ha = t0_rowptr[a + 1] - t0_rowptr[a], hb = t0_rowptr[b + 1] - t0_rowptr[b];
+            ub += ha < hb ? ha : hb;
         }
+        stage_off[k + 1] = ub;
+    }
+    const int64_t tot = block_sum_i64(ub, red);
+    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+// Second half of a two-kernel scan.  The producer kernel (256 threads, one element per thread) has written its
+// values to data[q*stride + 1 + i] and the sum of every 256-element block to blk[q*nb + block]; here block B adds
+// the sums of the blocks before it to an in-block inclusive scan.  Fully parallel: grid = nb blocks.
+template <int NSEQ>
+__global__ __launch_bounds__(256) void scan_blocks_kernel(int64_t n, int64_t *__restrict__ data, int64_t stride,
+                                                          const int64_t *__restrict__ blk, int64_t nb) {
+    __shared__ int64_t red[4];
+    __shared__ int64_t wtot[NSEQ][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t B = blockIdx.x, i = B * 256 + t;
+#pragma unroll
+    for (int q = 0; q < NSEQ; ++q) {
+        int64_t pre = 0;
+        for (int64_t j = t; j < B; j += 256) pre += blk[q * nb + j];
+        pre = block_sum_i64(pre, red);
+        int64_t x = (i < n) ? data[q * stride + 1 + i] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wtot[q][wave] = x;
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) pre += wtot[q][w];
+        if (i < n) data[q * stride + 1 + i] = x + pre;
     }
 }
 
-__global__ __launch_bounds__(256) void select_nodes_kernel(
+// A sorted int32 row that was staged into LDS when it fits (fast probes) and is searched in global memory otherwise.
+struct SortedRow {
+    const int32_t *lds;            // nullptr when the row did not fit
+    const int32_t *__restrict__ g; // global column array
+    int64_t lo;                    // row start in g
+    int n;                         // row length
+};
+
+// index of `key` inside the row, or -1
+__device__ __forceinline__ int row_find(const SortedRow &r, int32_t key) {
+    int lo = 0, hi = r.n;
+    if (r.lds) {
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (r.lds[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return (lo < r.n && r.lds[lo] == key) ? lo : -1;
+    }
+    const int32_t *__restrict__ a = r.g + r.lo;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < r.n && a[lo] == key) ? lo : -1;
+}
+
+constexpr int SEL_CAP_PPR = 1024;  // PPR row columns staged per endpoint (4 KiB each)
+constexpr int SEL_CAP_ADJ = 512;   // adjacency row staged per endpoint (2 KiB each)
+
+// One 64-lane workgroup (= one wavefront) per pair; 12 KiB of LDS holds the four sorted rows that get probed.
+__global__ __launch_bounds__(64) void select_nodes_kernel(
     int64_t bs, const int64_t *__restrict__ batch, int64_t batch_ld, const int64_t *__restrict__ adj_rowptr,
     const int32_t *__restrict__ adj_col, const int64_t *__restrict__ adjx_rowptr, const int32_t *__restrict__ adjx_col,
     const int64_t *__restrict__ ppr_rowptr, const int32_t *__restrict__ ppr_col, const float *__restrict__ ppr_val,
     const int64_t *__restrict__ t0_rowptr, const int32_t *__restrict__ t0_col, const float *__restrict__ t0_val,
     float th_cn, float th_1, float th_n, const int64_t *__restrict__ stage_off, int32_t *__restrict__ stage_node,
     float *__restrict__ stage_pa, float *__restrict__ stage_pb, int32_t *__restrict__ stage_cnt) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    __shared__ int32_t s_pa[SEL_CAP_PPR], s_pb[SEL_CAP_PPR], s_a[SEL_CAP_ADJ], s_b[SEL_CAP_ADJ];
+    const int lane = threadIdx.x;
+    const bool same_adj = (adjx_rowptr == adj_rowptr) && (adjx_col == adj_col);
 
-    for (int64_t p = wave_id; p < bs; p += n_waves) {
+    for (int64_t p = blockIdx.x; p < bs; p += gridDim.x) {
         const int64_t a = batch[p], b = batch[batch_ld + p];
         const int64_t ra0 = adj_rowptr[a], ra1 = adj_rowptr[a + 1];
         const int64_t rb0 = adj_rowptr[b], rb1 = adj_rowptr[b + 1];
@@ -116,6 +156,16 @@ __global__ __launch_bounds__(256) void select_nodes_kernel(
         const int64_t cn_base = s, l1_base = s + dA, l2_base = s + 2 * dA, t0_base = s + 2 * dA + dB;
         int n_cn = 0, n_l1 = 0, n_l2 = 0, n_t0 = 0;
 
+        // ---- stage the probed rows (coalesced 4-byte reads, all in flight together)
+        SortedRow rowA{nullptr, adj_col, ra0, (int)dA}, rowB{nullptr, adj_col, rb0, (int)dB};
+        SortedRow rowPa{nullptr, ppr_col, pa0, (int)(pa1 - pa0)}, rowPb{nullptr, ppr_col, pb0, (int)(pb1 - pb0)};
+        __syncthreads();  // previous pair's probes are done before the rows are overwritten
+        if (rowA.n <= SEL_CAP_ADJ) { for (int i = lane; i < rowA.n; i += 64) s_a[i] = adj_col[ra0 + i]; rowA.lds = s_a; }
+        if (rowB.n <= SEL_CAP_ADJ) { for (int i = lane; i < rowB.n; i += 64) s_b[i] = adj_col[rb0 + i]; rowB.lds = s_b; }
+        if (rowPa.n <= SEL_CAP_PPR) { for (int i = lane; i < rowPa.n; i += 64) s_pa[i] = ppr_col[pa0 + i]; rowPa.lds = s_pa; }
+        if (rowPb.n <= SEL_CAP_PPR) { for (int i = lane; i < rowPb.n; i += 64) s_pb[i] = ppr_col[pb0 + i]; rowPb.lds = s_pb; }
+        __syncthreads();
+
         // ---- pass A: every neighbour of a
         for (int64_t i0 = 0; i0 < dA; i0 += 64) {
             const int64_t i = i0 + lane;
@@ -124,11 +174,11 @@ __global__ __launch_bounds__(256) void select_nodes_kernel(
             bool in_b = false, keep = false;
             float va = 0.f, vb = 0.f;
             if (valid) {
-                x = adj_col[ra0 + i];
-                in_b = csr_contains(adj_col, rb0, rb1, x);
-                bool f;
-                va = ppr_round_trip(csr_value(ppr_col, ppr_val, pa0, pa1, x, &f), in_b);
-                vb = ppr_round_trip(csr_value(ppr_col, ppr_val, pb0, pb1, x, &f), in_b);
+                x = rowA.lds ? s_a[i] : adj_col[ra0 + i];
+                in_b = row_find(rowB, x) >= 0;
+                const int ia = row_find(rowPa, x), ib = row_find(rowPb, x);
+                va = ppr_round_trip(ia >= 0 ? ppr_val[pa0 + ia] : 0.0f, in_b);
+                vb = ppr_round_trip(ib >= 0 ? ppr_val[pb0 + ib] : 0.0f, in_b);
                 const float th = in_b ? th_cn : th_1;
                 keep = (va >= th) && (vb >= th);
             }
@@ -150,11 +200,11 @@ __global__ __launch_bounds__(256) void select_nodes_kernel(
             bool keep = false;
             float va = 0.f, vb = 0.f;
             if (j < dB) {
-                y = adj_col[rb0 + j];
-                if (!csr_contains(adj_col, ra0, ra1, y)) {
-                    bool f;
-                    va = ppr_round_trip(csr_value(ppr_col, ppr_val, pa0, pa1, y, &f), false);
-                    vb = ppr_round_trip(csr_value(ppr_col, ppr_val, pb0, pb1, y, &f), false);
+                y = rowB.lds ? s_b[j] : adj_col[rb0 + j];
+                if (row_find(rowA, y) < 0) {
+                    const int ia = row_find(rowPa, y), ib = row_find(rowPb, y);
+                    va = ppr_round_trip(ia >= 0 ? ppr_val[pa0 + ia] : 0.0f, false);
+                    vb = ppr_round_trip(ib >= 0 ? ppr_val[pb0 + ib] : 0.0f, false);
                     keep = (va >= th_1) && (vb >= th_1);
                 }
             }
@@ -174,8 +224,11 @@ __global__ __launch_bounds__(256) void select_nodes_kernel(
             const bool walk_a = (ta1 - ta0) <= (tb1 - tb0);  // walk the shorter row, probe the longer
             const int64_t w0 = walk_a ? ta0 : tb0, w1 = walk_a ? ta1 : tb1;
             const int64_t o0 = walk_a ? tb0 : ta0, o1 = walk_a ? tb1 : ta1;
-            const int64_t xa0 = adjx_rowptr[a], xa1 = adjx_rowptr[a + 1];
-            const int64_t xb0 = adjx_rowptr[b], xb1 = adjx_rowptr[b + 1];
+            SortedRow rowXa = rowA, rowXb = rowB;
+            if (!same_adj) {
+                rowXa = SortedRow{nullptr, adjx_col, adjx_rowptr[a], (int)(adjx_rowptr[a + 1] - adjx_rowptr[a])};
+                rowXb = SortedRow{nullptr, adjx_col, adjx_rowptr[b], (int)(adjx_rowptr[b + 1] - adjx_rowptr[b])};
+            }
             for (int64_t i0 = w0; i0 < w1; i0 += 64) {
                 const int64_t i = i0 + lane;
                 int32_t v = 0;
@@ -189,8 +242,7 @@ __global__ __launch_bounds__(256) void select_nodes_kernel(
                         bool f;
                         const float po = csr_value(t0_col, t0_val, o0, o1, v, &f);
                         const float so = __fsub_rn(__fadd_rn(po, 1.0f), 1.0f);
-                        if (f && po > 0.f && so >= th_n && !csr_contains(adjx_col, xa0, xa1, v) &&
-                            !csr_contains(adjx_col, xb0, xb1, v)) {
+                        if (f && po > 0.f && so >= th_n && row_find(rowXa, v) < 0 && row_find(rowXb, v) < 0) {
                             keep = true;
                             sa = walk_a ? sw : so;
                             sb = walk_a ? so : sw;
@@ -216,31 +268,42 @@ __global__ __launch_bounds__(256) void select_nodes_kernel(
     }
 }
 
-// counts -> (type_ptr rows offset by one, ready for the inclusive scan) + float count features
+// counts -> type_ptr rows (offset by one, ready for scan_blocks_kernel) + block sums + float count features
 __global__ __launch_bounds__(256) void select_counts_kernel(int64_t bs, const int32_t *__restrict__ stage_cnt,
                                                             int64_t *__restrict__ type_ptr,
-                                                            float *__restrict__ counts_f, int64_t ldc, int want_t0) {
+                                                            float *__restrict__ counts_f, int64_t ldc, int want_t0,
+                                                            int64_t *__restrict__ blk, int64_t nb) {
+    __shared__ int64_t red[4];
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) {
         type_ptr[0] = 0;
         type_ptr[bs + 1] = 0;
         type_ptr[2 * (bs + 1)] = 0;
     }
-    if (k >= bs) return;
-    const int n_cn = stage_cnt[4 * k], n_1 = stage_cnt[4 * k + 1] + stage_cnt[4 * k + 2], n_0 = stage_cnt[4 * k + 3];
-    type_ptr[k + 1] = n_cn;
-    type_ptr[(bs + 1) + k + 1] = n_1;
-    type_ptr[2 * (bs + 1) + k + 1] = n_0;
-    if (counts_f) {
-        float *c = counts_f + k * ldc;
-        c[0] = (float)n_cn;
-        c[1] = (float)n_1;
-        if (want_t0) {
-            c[2] = (float)n_0;
-            c[3] = (float)(n_cn + n_1);
-        } else {
-            c[2] = (float)(n_cn + n_1);
+    int n_cn = 0, n_1 = 0, n_0 = 0;
+    if (k < bs) {
+        const int4 c4 = *reinterpret_cast<const int4 *>(stage_cnt + 4 * k);
+        n_cn = c4.x; n_1 = c4.y + c4.z; n_0 = c4.w;
+        type_ptr[k + 1] = n_cn;
+        type_ptr[(bs + 1) + k + 1] = n_1;
+        type_ptr[2 * (bs + 1) + k + 1] = n_0;
+        if (counts_f) {
+            float *c = counts_f + k * ldc;
+            c[0] = (float)n_cn;
+            c[1] = (float)n_1;
+            if (want_t0) {
+                c[2] = (float)n_0;
+                c[3] = (float)(n_cn + n_1);
+            } else {
+                c[2] = (float)(n_cn + n_1);
+            }
         }
+    }
+    const int64_t s0 = block_sum_i64(n_cn, red), s1 = block_sum_i64(n_1, red), s2 = block_sum_i64(n_0, red);
+    if (threadIdx.x == 0) {
+        blk[blockIdx.x] = s0;
+        blk[nb + blockIdx.x] = s1;
+        blk[2 * nb + blockIdx.x] = s2;
     }
 }
 
@@ -305,17 +368,19 @@ inline unsigned wave_grid(int64_t n_items) {  // 4 waves per block, grid-stride 
 }  // namespace
 
 extern "C" int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
-                                const int64_t *t0_rowptr, int64_t *stage_off, void *stream) {
-    LPF_REQUIRE(bs >= 0 && stage_off);
+                                const int64_t *t0_rowptr, int64_t *stage_off, int64_t *scratch, void *stream) {
+    LPF_REQUIRE(bs >= 0 && stage_off && scratch);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (bs == 0) {
         (void)hipMemsetAsync(stage_off, 0, sizeof(int64_t), s);
         return LPF_OK;
     }
     LPF_REQUIRE(batch && adj_rowptr && batch_ld >= bs);
-    hipLaunchKernelGGL(select_bound_kernel, dim3((unsigned)((bs + 255) / 256)), dim3(256), 0, s, bs, batch, batch_ld,
-                       adj_rowptr, t0_rowptr, stage_off);
-    hipLaunchKernelGGL(scan_i64_kernel<1>, dim3(1), dim3(1024), 0, s, bs + 1, stage_off, (int64_t)0);
+    const int64_t nb = (bs + 255) / 256;
+    hipLaunchKernelGGL(select_bound_kernel, dim3((unsigned)nb), dim3(256), 0, s, bs, batch, batch_ld, adj_rowptr,
+                       t0_rowptr, stage_off, scratch);
+    hipLaunchKernelGGL(scan_blocks_kernel<1>, dim3((unsigned)nb), dim3(256), 0, s, bs, stage_off, (int64_t)0, scratch,
+                       nb);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
@@ -330,7 +395,8 @@ extern "C" int lpf_select_nodes(int64_t bs, const int64_t *batch, int64_t batch_
     LPF_REQUIRE(bs > 0 && batch && batch_ld >= bs && adj_rowptr && adj_col && ppr_rowptr && ppr_col && ppr_val);
     LPF_REQUIRE(stage_off && stage_node && stage_pa && stage_pb && stage_cnt);
     LPF_REQUIRE(!t0_rowptr || (t0_col && t0_val && adjx_rowptr && adjx_col));
-    hipLaunchKernelGGL(select_nodes_kernel, dim3(wave_grid(bs)), dim3(256), 0, static_cast<hipStream_t>(stream), bs,
+    const unsigned sel_blocks = (unsigned)(bs < 256 * 64 ? bs : 256 * 64);  // one wave per block, grid-stride
+    hipLaunchKernelGGL(select_nodes_kernel, dim3(sel_blocks), dim3(64), 0, static_cast<hipStream_t>(stream), bs,
                        batch, batch_ld, adj_rowptr, adj_col, adjx_rowptr, adjx_col, ppr_rowptr, ppr_col, ppr_val,
                        t0_rowptr, t0_col, t0_val, th_cn, th_1hop, th_non1hop, stage_off, stage_node, stage_pa,
                        stage_pb, stage_cnt);
@@ -339,17 +405,18 @@ extern "C" int lpf_select_nodes(int64_t bs, const int64_t *batch, int64_t batch_
 }
 
 extern "C" int lpf_select_scan(int64_t bs, const int32_t *stage_cnt, int64_t *type_ptr, float *counts_f, int64_t ldc,
-                               int32_t want_t0, void *stream) {
-    LPF_REQUIRE(bs >= 0 && type_ptr);
+                               int32_t want_t0, int64_t *scratch, void *stream) {
+    LPF_REQUIRE(bs >= 0 && type_ptr && scratch);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (bs == 0) {
         (void)hipMemsetAsync(type_ptr, 0, 3 * sizeof(int64_t), s);
         return LPF_OK;
     }
     LPF_REQUIRE(stage_cnt && (!counts_f || ldc >= (want_t0 ? 4 : 3)));
-    hipLaunchKernelGGL(select_counts_kernel, dim3((unsigned)((bs + 255) / 256)), dim3(256), 0, s, bs, stage_cnt,
-                       type_ptr, counts_f, ldc, (int)want_t0);
-    hipLaunchKernelGGL(scan_i64_kernel<3>, dim3(1), dim3(1024), 0, s, bs + 1, type_ptr, bs + 1);
+    const int64_t nb = (bs + 255) / 256;
+    hipLaunchKernelGGL(select_counts_kernel, dim3((unsigned)nb), dim3(256), 0, s, bs, stage_cnt, type_ptr, counts_f,
+                       ldc, (int)want_t0, scratch, nb);
+    hipLaunchKernelGGL(scan_blocks_kernel<3>, dim3((unsigned)nb), dim3(256), 0, s, bs, type_ptr, bs + 1, scratch, nb);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

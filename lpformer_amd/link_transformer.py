@@ -184,7 +184,12 @@ class mlp_score(nn.Module):  # noqa: N801  (name kept for drop-in compatibility)
             if last.out_features == 1:
                 res = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
                 w = last.weight.detach().reshape(-1).contiguous()
-                b = float(last.bias.detach().item()) if last.bias is not None else 0.0
+                b = 0.0
+                if last.bias is not None:  # scalar kernel argument: read it back only when the parameter changes
+                    key = (last.bias.data_ptr(), last.bias._version)
+                    if getattr(self, "_bias_key", None) != key:
+                        self._bias_key, self._bias_val = key, float(last.bias.detach().item())
+                    b = self._bias_val
                 check(_lib.hip().lpf_rowdot_sigmoid_f32(h.shape[0], h.shape[1], ptr(h), h.stride(0), ptr(w), b,
                                                         None if want_prob else ptr(res),
                                                         ptr(res) if want_prob else None, _stream(h.device)),
@@ -478,9 +483,11 @@ class LinkTransformer(nn.Module):
         t0 = self._device_graph("t0", self._data_obj("ppr", test_set)) if want_t0 else None
 
         stage_off = self._workspace("stage_off", bs + 1, torch.int64)
+        scratch = self._workspace("scan_scratch", 3 * ((bs + 255) // 256) + 3, torch.int64)
         with KernelTimer.span("select_bound"):
             check(lib.lpf_select_bound(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr),
-                                       ptr(t0.rowptr) if want_t0 else None, ptr(stage_off), st), "lpf_select_bound")
+                                       ptr(t0.rowptr) if want_t0 else None, ptr(stage_off), ptr(scratch), st),
+                  "lpf_select_bound")
         cap = int(stage_off[bs].item())  # one 8-byte read-back sizes the staging area
         stage_node = self._workspace("stage_node", cap, torch.int32)
         stage_pa = self._workspace("stage_pa", cap, torch.float32)
@@ -498,7 +505,7 @@ class LinkTransformer(nn.Module):
         type_ptr = self._workspace("type_ptr", 3 * (bs + 1), torch.int64)
         with KernelTimer.span("select_scan"):
             check(lib.lpf_select_scan(bs, ptr(stage_cnt), ptr(type_ptr), feats.data_ptr() + 4 * self.dim, ldf,
-                                      1 if want_t0 else 0, st), "lpf_select_scan")
+                                      1 if want_t0 else 0, ptr(scratch), st), "lpf_select_scan")
         sel_pair = self._workspace("sel_pair", cap, torch.int32)
         sel_node = self._workspace("sel_node", cap, torch.int32)
         sel_pa = self._workspace("sel_pa", cap, torch.float32)
