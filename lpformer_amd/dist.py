@@ -61,9 +61,14 @@ def allgather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
     sizes = [row_range(n, world, r) for r in range(world)]
     if n % world == 0:
         dist.all_gather_into_tensor(full, local.contiguous(), group=group)  # one ncclAllGather
-    else:
-        parts = [full[lo:hi] for lo, hi in sizes]
-        dist.all_gather(parts, local.contiguous(), group=group)
+    else:  # ragged split: pad every block to the largest one, still a single collective
+        rows = max(hi - lo for lo, hi in sizes)
+        padded = torch.zeros(rows, d, dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+        buf = torch.empty(world * rows, d, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(buf, padded, group=group)
+        for r, (lo, hi) in enumerate(sizes):
+            full[lo:hi] = buf[r * rows:r * rows + (hi - lo)]
     return full
 
 
