@@ -1,0 +1,108 @@
+"""The other BASELINE.json configurations as parity cases (GPU box): full-size or stated reduced-size synthetic
+look-alikes, checked through (i) the CPU oracle on a sample of the pairs and (ii) size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+import lpformer_amd
+from lpformer_amd import data as D
+from oracle import lpformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(name, scale=1.0, seed=0, bs=None):
+    cfg = dict(D.CONFIGS[name])
+    n = int(cfg["n"] * scale)
+    edges = int(cfg["edges"] * scale)
+    ei, w = D.chung_lu_graph(n, edges, gamma=cfg["gamma"], seed=seed, max_weight=cfg["max_weight"])
+    x = np.random.default_rng(seed + 1).standard_normal((n, cfg["f_in"])).astype(np.float32)
+    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"])
+    args = D.train_args_for(cfg)
+    torch.manual_seed(seed)
+    model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
+    score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(DEV).eval()
+    batch = D.sample_pairs(ei, n, bs or cfg["batch"], seed=seed + 2)
+    return cfg, n, ei, w, x, data, args, model, score, batch
+
+
+def _oracle_sample(model, score, data, args, batch, x_node, k=192):
+    P = {f"model.{a}": v.detach().cpu().numpy() for a, v in model.state_dict().items()}
+    P.update({f"score.{a}": v.detach().cpu().numpy() for a, v in score.state_dict().items()})
+    mask, ppr = data["adj_mask"], data["ppr"]
+    sample = batch[:, :k]
+    return sample, O.forward(sample, None, None, (mask.rowptr, mask.col.astype(np.int64)),
+                             (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P, dict(args, pred_layers=2),
+                             x_node=x_node.cpu().numpy())
+
+
+def _check(name, scale, bs=None, k=192):
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale, bs=bs)
+    tb = torch.from_numpy(batch).to(DEV)
+    h = model.propagate()
+    assert torch.isfinite(h).all()
+    logits = score.logits(model.pair_features(tb, h))
+    assert torch.isfinite(logits).all()
+    # (i) oracle on a sample of the same pairs: index sets bit-exact, logits within 1e-4
+    sample, ref = _oracle_sample(model, score, data, args, batch, h, k)
+    sel = model.compute_node_mask(torch.from_numpy(sample))
+    for tag, info in zip(("cn", "onehop", "non1hop"), sel):
+        if info is None:
+            assert tag not in ref["sel"]
+            continue
+        np.testing.assert_array_equal(info[0].cpu().numpy(), ref["sel"][tag][0])
+        np.testing.assert_array_equal(info[1].cpu().numpy().view(np.uint32), ref["sel"][tag][1].view(np.uint32))
+    got = score.logits(model.pair_features(torch.from_numpy(sample).to(DEV), h)).cpu().numpy()
+    assert np.abs(got - ref["logit"]).max() <= 1e-4
+    # (ii) properties at the full batch size: sub-batch consistency, endpoint swap, permutation
+    assert (logits[:k].cpu().numpy() == got).all()  # scoring a prefix alone gives bitwise the same scores
+    swapped = score.logits(model.pair_features(tb.flip(0).contiguous(), h))
+    assert (logits - swapped).abs().max().item() <= 5e-5
+    perm = torch.randperm(tb.shape[1], device=DEV)
+    permuted = score.logits(model.pair_features(tb[:, perm].contiguous(), h))
+    assert (logits[perm] - permuted).abs().max().item() <= 1e-5
+    return cfg, model
+
+
+def test_collab_full_size():
+    _check("collab", 1.0)
+
+
+def test_ddi_like_dense_neighbourhoods():
+    """N=4267, ~500 neighbours per node, mode "1-hop", D=256: rows longer than the LDS staging caps."""
+    _check("ddi", 1.0, k=96)
+
+
+def test_cora_like_no_layernorm():
+    """D=256, L=1, --no-layer-norm --no-relu, F=1433 (not a multiple of 4), eps 1e-4."""
+    _check("cora", 1.0, bs=4096)
+
+
+def test_citation2_like_quarter_size():
+    """N=732k (1/4 of ogbl-citation2), residual GCN, D=64, theta=(0,1e-3,1e-2), eps 2.5e-3."""
+    _check("citation2", 0.25)
+
+
+def test_ppa_like_eighth_size():
+    """N=72k, mean degree ~74 (1/8 of ogbl-ppa's nodes and edges), F=58 (not a multiple of 4), D=64, residual."""
+    _check("ppa", 0.125)
+
+
+def test_pyg_style_facade_matches_core():
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup("tiny")
+    ppr = data["ppr"]
+    m = lpformer_amd.LPFormer(cfg["f_in"], cfg["dim"], num_gnn_layers=cfg["gnn_layers"],
+                              ppr_thresholds=list(cfg["thresholds"]), device=DEV).to(DEV).eval()
+    m.core.load_state_dict(model.state_dict())
+    m.score.load_state_dict(score.state_dict())
+    # the facade takes an unweighted edge_index: compare with a core built on the same unweighted graph
+    data2 = D.build_data(ei, x, n, ppr=ppr)
+    core2 = lpformer_amd.LinkTransformer(args, data2, device=DEV).to(DEV).eval()
+    core2.load_state_dict(model.state_dict())
+    tb = torch.from_numpy(batch).to(DEV)
+    want = score.logits(core2(tb))
+    got = m(tb, torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV), ppr)
+    assert (want - got).abs().max().item() <= 1e-6
+    sp = lpformer_amd.LPFormer.calc_sparse_ppr(torch.from_numpy(ei), n, 0.15, cfg["eps"])
+    assert sp._nnz() == ppr.nnz
