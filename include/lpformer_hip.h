@@ -91,36 +91,38 @@ int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const f
 int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, const float *X,
                         int64_t ldx, float *mul, int64_t ldm, float *sum, int64_t lds, void *stream);
 
-/* Per-pair upper bound on staged entries and its exclusive scan (feeds lpf_select_nodes).
- *   ub_k = 2*deg(a) + deg(b) + min(len T0[a], len T0[b])      (T0 = the CSR scanned for >1-hop nodes)
- * stage_off: int64[bs+1] (stage_off[bs] = total).  t0_rowptr may be NULL (mode "1-hop": no >1-hop part).
- * scratch: int64[LPF_SELECT_SCRATCH_ELEMS(bs)] (block sums of the two-kernel scan). */
+/* Selection, step 1: per-pair descriptors, staging capacities and work-item counts, with their exclusive scans.
+ *   adj_rowptr  0/1 symmetric adjacency used for CN / 1-hop typing (data['adj_mask'] or the training override)
+ *   t0_rowptr   CSR scanned for >1-hop candidates: either the PPR CSR itself or a per-theta_n prefiltered copy
+ *               (entries with fl32(fl32(p+1)-1) >= theta_n); NULL => no >1-hop part (mode "1-hop")
+ *   offs  int64[2*(bs+1)]: offs[k] = staging offset of pair k, capacity deg(a)+deg(b)+min(|T0 a|,|T0 b|) slots,
+ *         offs[bs] = total;  offs[(bs+1)+k] = first work item of pair k, offs[(bs+1)+bs] = number of items
+ *         (a pair is ONE item when deg(a)+deg(b) <= 512, else ceil(deg a/512)+ceil(deg b/512) slices)
+ *   desc  int64[16*bs]: row starts/lengths of pair k (adjacency, PPR, T0 rows of a and b), one 128-byte line
+ *   scratch int64[LPF_SELECT_SCRATCH_ELEMS(bs)] (block sums of the two-kernel scans) */
 #define LPF_SELECT_SCRATCH_ELEMS(bs) (3 * (((bs) + 255) / 256) + 3)
 int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
-                     const int64_t *t0_rowptr, int64_t *stage_off, int64_t *scratch, void *stream);
+                     const int64_t *ppr_rowptr, const int64_t *t0_rowptr, int64_t *offs, int64_t *desc,
+                     int64_t *scratch, void *stream);
 
-/* Node selection for a batch of pairs: compute_node_mask + get_ppr_vals + get_non_1hop_ppr
- * (link_transformer.py:214-319,434-481), eval mode.  One wavefront per pair; integer/bit-exact.
- *   adj_*     0/1 symmetric adjacency used for CN / 1-hop typing (data['adj_mask'] or the training override)
+/* Selection, step 2: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (link_transformer.py:214-319,434-481),
+ * eval mode; integer/bit-exact.  One wavefront per work item: candidates + hash table in LDS, PPR rows streamed
+ * through the hash (see select.hip).
+ *   item_capacity  host-side upper bound on offs[(bs+1)+bs] (sizes `items` = int32[16*item_capacity], 64-byte records, and the grid)
  *   adjx_*    UNMASKED adjacency used to exclude neighbours from the >1-hop set (link_transformer.py:443);
- *             pass the same arrays as adj_* in evaluation
- *   ppr_*     PPR CSR (cols int32, vals fp32)
- *   t0_*      CSR scanned for >1-hop candidates: either the PPR CSR itself or a per-theta_n prefiltered copy
- *             (entries with fl32(fl32(p+1)-1) >= theta_n); NULL rowptr => skip (mode "1-hop")
- * Staging layout for pair k at s = stage_off[k], dA = deg(a), dB = deg(b):
- *   [s, s+dA)            CN run            (count stage_cnt[4k+0]) sorted by node
- *   [s+dA, s+2dA)        1-hop run from N(a)\N(b) (stage_cnt[4k+1]) sorted
- *   [s+2dA, s+2dA+dB)    1-hop run from N(b)\N(a) (stage_cnt[4k+2]) sorted
- *   [s+2dA+dB, ...)      >1-hop run        (stage_cnt[4k+3]) sorted
- * stage_node int32, stage_pa/pb fp32 (values AFTER the reference's fp32 round trip). */
-int lpf_select_nodes(int64_t bs, const int64_t *batch, int64_t batch_ld,
-                     const int64_t *adj_rowptr, const int32_t *adj_col,
-                     const int64_t *adjx_rowptr, const int32_t *adjx_col,
-                     const int64_t *ppr_rowptr, const int32_t *ppr_col, const float *ppr_val,
-                     const int64_t *t0_rowptr, const int32_t *t0_col, const float *t0_val,
-                     float th_cn, float th_1hop, float th_non1hop,
-                     const int64_t *stage_off, int32_t *stage_node, float *stage_pa, float *stage_pb,
-                     int32_t *stage_cnt, void *stream);
+ *             same_adj != 0 says it is the very adjacency the descriptors were built from (evaluation)
+ *   ppr_col/val, t0_col/val   column/value arrays of the PPR CSR and of the >1-hop candidate CSR (t0_col NULL: skip)
+ * Dense staging for pair k at s = offs[k], dA = deg(a), dB = deg(b):
+ *   stage_node[s+i],        i < dA : -1 (dropped) | node | (1<<30 if common neighbour)   for the i-th node of N(a)
+ *   stage_node[s+dA+j],     j < dB : -1 | node                                           for the j-th node of N(b)
+ *   stage_node[s+dA+dB+..]  the >1-hop run, already compacted and sorted (count stage_cnt[4k+3])
+ *   stage_pa/pb fp32 at the same slots (values AFTER the reference's fp32 round trip), written for kept nodes
+ *   stage_cnt[4k+0..2] = kept CN / kept 1-hop from N(a) / kept 1-hop from N(b) */
+int lpf_select_nodes(int64_t bs, int64_t item_capacity, const int64_t *offs, const int64_t *desc, int32_t *items,
+                     const int32_t *adj_col, const int64_t *adjx_rowptr, const int32_t *adjx_col, int32_t same_adj,
+                     const int32_t *ppr_col, const float *ppr_val, const int32_t *t0_col, const float *t0_val,
+                     float th_cn, float th_1hop, float th_non1hop, int32_t *stage_node, float *stage_pa,
+                     float *stage_pb, int32_t *stage_cnt, void *stream);
 
 /* Exclusive scans of the per-pair counts per type + totals:
  *   type_ptr: int64[3*(bs+1)]  rows = (cn, 1-hop, >1-hop) ; type_ptr[t*(bs+1)+bs] = total of type t
@@ -132,10 +134,10 @@ int lpf_select_scan(int64_t bs, const int32_t *stage_cnt, int64_t *type_ptr, flo
 
 /* Compaction into the reference's layout: all CN entries sorted by (pair, node), then all 1-hop, then all
  * >1-hop (link_transformer.py:161-162).  Entry e of type t lives at  type_base(t) + type_ptr[t][k] + j  with
- * type_base = (0, total_cn, total_cn+total_1hop).  The two 1-hop runs are merged here. */
-int lpf_select_compact(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
-                       const int64_t *stage_off, const int32_t *stage_node, const float *stage_pa,
-                       const float *stage_pb, const int32_t *stage_cnt, const int64_t *type_ptr,
+ * type_base = (0, total_cn, total_cn+total_1hop).  The dense runs are compacted (in place, staging is clobbered)
+ * and the two 1-hop runs merged here. */
+int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t *offs, int32_t *stage_node, float *stage_pa,
+                       float *stage_pb, const int32_t *stage_cnt, const int64_t *type_ptr,
                        int32_t *sel_pair, int32_t *sel_node, float *sel_pa, float *sel_pb, void *stream);
 
 /* Attention scores for every selected entry (layers.py:206-218 with get_pos_encodings

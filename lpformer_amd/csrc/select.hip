@@ -1,22 +1,34 @@
 // PPR-thresholded node selection for a batch of candidate pairs (integer / bit-exact part of the pair stage).
 //
 // The reference builds BS x N sparse COO temporaries and coalesces (sorts) them seven times per batch
-// (src/models/link_transformer.py:214-319,434-481).  Here every pair is handled by one wavefront working directly
-// on CSR rows with sorted columns:
-//   pass A  lanes walk N(a) (coalesced), each lane binary-searches its node in N(b) (type 2 = CN, else 1-hop) and in
-//           the PPR rows of a and b, applies the reference's fp32 round trip and threshold, and the survivors are
-//           ballot-compacted -- in ascending node order -- into the CN run and the first 1-hop run;
-//   pass B  the same for N(b) \ N(a) (second 1-hop run; the two runs are merged by lpf_select_compact);
-//   pass T  lanes walk the shorter of the two >1-hop candidate rows (the PPR row, or a per-threshold prefiltered
-//           copy of it), look the node up in the other row and in both adjacency rows, and emit the >1-hop run.
-// No LDS, no atomics, no sorting: order comes from the CSR order.  Traffic is row reads (coalesced) plus binary-search
-// probes that hit L2 -- the kernel is bound by memory latency/bandwidth, not arithmetic.
+// (src/models/link_transformer.py:214-319,434-481).  Here the work is cut into ITEMS of at most SEL_CAP candidate
+// nodes (a whole pair when deg(a)+deg(b) <= SEL_CAP, otherwise slices of N(a) and of N(b)); one wavefront handles
+// one item and the kernel is a pure streaming kernel:
+//   1. the item's candidates (coalesced reads of the adjacency rows) go into LDS together with an open-addressing
+//      hash table keyed by node id (ds_cmpswap inserts);
+//   2. the PPR rows of a and b are STREAMED once from HBM (col, val pairs, fully coalesced, several loads in flight),
+//      every entry probes the hash and drops its value into the candidate's slot -- no binary search, no dependent
+//      global loads; for sliced pairs the other endpoint's adjacency row is streamed the same way to type the nodes;
+//   3. candidates are typed (2 = common neighbour, 1 = one-hop), the reference's fp32 round trip and thresholds are
+//      applied op for op, and a code per candidate (node id, CN bit, or -1) is written to a DENSE staging slot; kept
+//      counts are accumulated per pair with integer atomics (order independent);
+//   4. the >1-hop candidates (per-threshold prefiltered PPR rows) are walked by the first item of each pair and
+//      probed against the other row and the hash.
+// lpf_select_compact then turns the dense runs into the reference's layout (all CN entries sorted by (pair, node),
+// then 1-hop, then >1-hop).  Order comes from the CSR order: no sort anywhere.  Bound: HBM bandwidth on the row bytes
+// 4(deg a + deg b) + 8(|P_a| + |P_b|) per pair.
 #include "lpf_common.h"
 
 // the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
 #pragma clang fp contract(off)
 
 namespace {
+
+constexpr int SEL_CAP = 512;           // candidates per item
+constexpr int SEL_TBL = 1024;          // hash slots (load factor <= 0.5)
+constexpr int32_t CN_BIT = 1 << 30;    // marks a kept common neighbour in the dense staging code
+constexpr int DESC_I64 = 16;           // int64 words per pair descriptor (128 B)
+constexpr uint8_t F_INB = 1, F_INA = 2;
 
 // fl32((fl32(fl32(p*t)+t)-t)/t) for t in {1,2}, without letting the compiler contract or re-associate anything.
 // p*1, p*2, x/1 and x/2 are exact in binary fp32, so only the add and the subtract round.
@@ -43,6 +55,8 @@ __device__ __forceinline__ int lanes_below(uint64_t mask, int lane) {
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
 
+__device__ __forceinline__ uint32_t sel_hash(int32_t key) { return ((uint32_t)key * 2654435761u) >> 22; }  // 10 bits
+
 // Block-wide sum of one int64 per thread (256 threads); result valid in every thread.
 __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *lds4) {
 #pragma unroll
@@ -53,27 +67,47 @@ __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *lds4) {
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
-__global__ __launch_bounds__(256) void select_bound_kernel(int64_t bs, const int64_t *__restrict__ batch,
-                                                           int64_t batch_ld, const int64_t *__restrict__ adj_rowptr,
-                                                           const int64_t *__restrict__ t0_rowptr,
-                                                           int64_t *__restrict__ stage_off,
-                                                           int64_t *__restrict__ blk) {
+__device__ __forceinline__ int items_of(int64_t dA, int64_t dB) {
+    if (dA + dB <= SEL_CAP) return 1;
+    return (int)((dA + SEL_CAP - 1) / SEL_CAP + (dB + SEL_CAP - 1) / SEL_CAP);
+}
+
+// Per pair: descriptor (every row start/length the later kernels need, one 128-byte line), staging capacity and item
+// count; also the 256-pair block sums for the two scans.
+__global__ __launch_bounds__(256) void select_bound_kernel(
+    int64_t bs, const int64_t *__restrict__ batch, int64_t batch_ld, const int64_t *__restrict__ adj_rowptr,
+    const int64_t *__restrict__ ppr_rowptr, const int64_t *__restrict__ t0_rowptr, int64_t *__restrict__ offs,
+    int64_t *__restrict__ desc, int64_t *__restrict__ blk, int64_t nb) {
     __shared__ int64_t red[4];
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) stage_off[0] = 0;
-    int64_t ub = 0;
+    if (k == 0) {
+        offs[0] = 0;
+        offs[bs + 1] = 0;
+    }
+    int64_t ub = 0, ni = 0;
     if (k < bs) {
         const int64_t a = batch[k], b = batch[batch_ld + k];
-        const int64_t dA = adj_rowptr[a + 1] - adj_rowptr[a], dB = adj_rowptr[b + 1] - adj_rowptr[b];
-        ub = 2 * dA + dB;
+        const int64_t ra0 = adj_rowptr[a], ra1 = adj_rowptr[a + 1], rb0 = adj_rowptr[b], rb1 = adj_rowptr[b + 1];
+        const int64_t pa0 = ppr_rowptr[a], pa1 = ppr_rowptr[a + 1], pb0 = ppr_rowptr[b], pb1 = ppr_rowptr[b + 1];
+        int64_t ta0 = 0, ta1 = 0, tb0 = 0, tb1 = 0;
         if (t0_rowptr) {
-            const int64_t ha = t0_rowptr[a + 1] - t0_rowptr[a], hb = t0_rowptr[b + 1] - t0_rowptr[b];
-            ub += ha < hb ? ha : hb;
+            ta0 = t0_rowptr[a]; ta1 = t0_rowptr[a + 1]; tb0 = t0_rowptr[b]; tb1 = t0_rowptr[b + 1];
         }
-        stage_off[k + 1] = ub;
+        const int64_t dA = ra1 - ra0, dB = rb1 - rb0, ha = ta1 - ta0, hb = tb1 - tb0;
+        ub = dA + dB + (ha < hb ? ha : hb);
+        ni = items_of(dA, dB);
+        offs[k + 1] = ub;
+        offs[(bs + 1) + k + 1] = ni;
+        int64_t *d = desc + k * DESC_I64;
+        d[0] = ra0; d[1] = rb0; d[2] = pa0; d[3] = pb0; d[4] = ta0; d[5] = tb0;
+        d[6] = dA; d[7] = dB; d[8] = pa1 - pa0; d[9] = pb1 - pb0; d[10] = ha; d[11] = hb;
+        d[12] = a; d[13] = b; d[14] = 0; d[15] = 0;
     }
-    const int64_t tot = block_sum_i64(ub, red);
-    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+    const int64_t s0 = block_sum_i64(ub, red), s1 = block_sum_i64(ni, red);
+    if (threadIdx.x == 0) {
+        blk[blockIdx.x] = s0;
+        blk[nb + blockIdx.x] = s1;
+    }
 }
 
 // Second half of a two-kernel scan.  The producer kernel (256 threads, one element per thread) has written its
@@ -104,148 +138,304 @@ __global__ __launch_bounds__(256) void scan_blocks_kernel(int64_t n, int64_t *__
     }
 }
 
-// A sorted int32 row that was staged into LDS when it fits (fast probes) and is searched in global memory otherwise.
-struct SortedRow {
-    const int32_t *lds;            // nullptr when the row did not fit
-    const int32_t *__restrict__ g; // global column array
-    int64_t lo;                    // row start in g
-    int n;                         // row length
+// Work-item record, 64 bytes = one coalesced 16-lane read: everything the item kernel needs to start loading rows.
+// kind 0 = whole pair, 1 = slice of N(a), 2 = slice of N(b)
+struct ItemRec {
+    int32_t p, kind, start, len, dA, dB, nPa, nPb;
+    int64_t ra0, rb0, pa0, pb0;
 };
+static_assert(sizeof(ItemRec) == 64, "ItemRec must be 64 bytes");
 
-// index of `key` inside the row, or -1
-__device__ __forceinline__ int row_find(const SortedRow &r, int32_t key) {
-    int lo = 0, hi = r.n;
-    if (r.lds) {
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (r.lds[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        return (lo < r.n && r.lds[lo] == key) ? lo : -1;
+__global__ __launch_bounds__(256) void select_items_kernel(int64_t bs, const int64_t *__restrict__ desc,
+                                                           const int64_t *__restrict__ item_off,
+                                                           ItemRec *__restrict__ items,
+                                                           int32_t *__restrict__ stage_cnt) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= bs) return;
+    *reinterpret_cast<int4 *>(stage_cnt + 4 * k) = make_int4(0, 0, 0, 0);  // the item kernel accumulates into these
+    const int64_t *d = desc + k * DESC_I64;
+    const int64_t dA = d[6], dB = d[7];
+    ItemRec r;
+    r.p = (int32_t)k; r.dA = (int32_t)dA; r.dB = (int32_t)dB; r.nPa = (int32_t)d[8]; r.nPb = (int32_t)d[9];
+    r.ra0 = d[0]; r.rb0 = d[1]; r.pa0 = d[2]; r.pb0 = d[3];
+    int64_t o = item_off[k];
+    if (dA + dB <= SEL_CAP) {
+        r.kind = 0; r.start = 0; r.len = (int32_t)(dA + dB);
+        items[o] = r;
+        return;
     }
-    const int32_t *__restrict__ a = r.g + r.lo;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    for (int64_t s = 0; s < dA; s += SEL_CAP) {
+        r.kind = 1; r.start = (int32_t)s; r.len = (int32_t)((dA - s) < SEL_CAP ? (dA - s) : SEL_CAP);
+        items[o++] = r;
     }
-    return (lo < r.n && a[lo] == key) ? lo : -1;
+    for (int64_t s = 0; s < dB; s += SEL_CAP) {
+        r.kind = 2; r.start = (int32_t)s; r.len = (int32_t)((dB - s) < SEL_CAP ? (dB - s) : SEL_CAP);
+        items[o++] = r;
+    }
 }
 
-constexpr int SEL_CAP_PPR = 1024;  // PPR row columns staged per endpoint (4 KiB each)
-constexpr int SEL_CAP_ADJ = 512;   // adjacency row staged per endpoint (2 KiB each)
+struct alignas(16) SelLds {
+    int32_t cand[SEL_CAP];
+    float pa[SEL_CAP];
+    float pb[SEL_CAP];
+    int32_t table[SEL_TBL];
+    uint8_t flag[SEL_CAP];
+};
 
-// One 64-lane workgroup (= one wavefront) per pair; 12 KiB of LDS holds the four sorted rows that get probed.
-__global__ __launch_bounds__(64) void select_nodes_kernel(
-    int64_t bs, const int64_t *__restrict__ batch, int64_t batch_ld, const int64_t *__restrict__ adj_rowptr,
-    const int32_t *__restrict__ adj_col, const int64_t *__restrict__ adjx_rowptr, const int32_t *__restrict__ adjx_col,
-    const int64_t *__restrict__ ppr_rowptr, const int32_t *__restrict__ ppr_col, const float *__restrict__ ppr_val,
-    const int64_t *__restrict__ t0_rowptr, const int32_t *__restrict__ t0_col, const float *__restrict__ t0_val,
-    float th_cn, float th_1, float th_n, const int64_t *__restrict__ stage_off, int32_t *__restrict__ stage_node,
-    float *__restrict__ stage_pa, float *__restrict__ stage_pb, int32_t *__restrict__ stage_cnt) {
-    __shared__ int32_t s_pa[SEL_CAP_PPR], s_pb[SEL_CAP_PPR], s_a[SEL_CAP_ADJ], s_b[SEL_CAP_ADJ];
-    const int lane = threadIdx.x;
-    const bool same_adj = (adjx_rowptr == adj_rowptr) && (adjx_col == adj_col);
+// slot of `key` in the item's hash, or -1
+__device__ __forceinline__ int sel_probe(const SelLds &L, int32_t key) {
+    uint32_t h = sel_hash(key);
+    while (true) {
+        const int s = L.table[h];
+        if (s < 0) return -1;
+        if (L.cand[s] == key) return s;
+        h = (h + 1) & (SEL_TBL - 1);
+    }
+}
 
-    for (int64_t p = blockIdx.x; p < bs; p += gridDim.x) {
-        const int64_t a = batch[p], b = batch[batch_ld + p];
-        const int64_t ra0 = adj_rowptr[a], ra1 = adj_rowptr[a + 1];
-        const int64_t rb0 = adj_rowptr[b], rb1 = adj_rowptr[b + 1];
-        const int64_t pa0 = ppr_rowptr[a], pa1 = ppr_rowptr[a + 1];
-        const int64_t pb0 = ppr_rowptr[b], pb1 = ppr_rowptr[b + 1];
-        const int64_t dA = ra1 - ra0, dB = rb1 - rb0;
-        const int64_t s = stage_off[p];
-        const int64_t cn_base = s, l1_base = s + dA, l2_base = s + 2 * dA, t0_base = s + 2 * dA + dB;
-        int n_cn = 0, n_l1 = 0, n_l2 = 0, n_t0 = 0;
-
-        // ---- stage the probed rows (coalesced 4-byte reads, all in flight together)
-        SortedRow rowA{nullptr, adj_col, ra0, (int)dA}, rowB{nullptr, adj_col, rb0, (int)dB};
-        SortedRow rowPa{nullptr, ppr_col, pa0, (int)(pa1 - pa0)}, rowPb{nullptr, ppr_col, pb0, (int)(pb1 - pb0)};
-        __syncthreads();  // previous pair's probes are done before the rows are overwritten
-        if (rowA.n <= SEL_CAP_ADJ) { for (int i = lane; i < rowA.n; i += 64) s_a[i] = adj_col[ra0 + i]; rowA.lds = s_a; }
-        if (rowB.n <= SEL_CAP_ADJ) { for (int i = lane; i < rowB.n; i += 64) s_b[i] = adj_col[rb0 + i]; rowB.lds = s_b; }
-        if (rowPa.n <= SEL_CAP_PPR) { for (int i = lane; i < rowPa.n; i += 64) s_pa[i] = ppr_col[pa0 + i]; rowPa.lds = s_pa; }
-        if (rowPb.n <= SEL_CAP_PPR) { for (int i = lane; i < rowPb.n; i += 64) s_pb[i] = ppr_col[pb0 + i]; rowPb.lds = s_pb; }
-        __syncthreads();
-
-        // ---- pass A: every neighbour of a
-        for (int64_t i0 = 0; i0 < dA; i0 += 64) {
-            const int64_t i = i0 + lane;
-            const bool valid = i < dA;
-            int32_t x = 0;
-            bool in_b = false, keep = false;
-            float va = 0.f, vb = 0.f;
-            if (valid) {
-                x = rowA.lds ? s_a[i] : adj_col[ra0 + i];
-                in_b = row_find(rowB, x) >= 0;
-                const int ia = row_find(rowPa, x), ib = row_find(rowPb, x);
-                va = ppr_round_trip(ia >= 0 ? ppr_val[pa0 + ia] : 0.0f, in_b);
-                vb = ppr_round_trip(ib >= 0 ? ppr_val[pb0 + ib] : 0.0f, in_b);
-                const float th = in_b ? th_cn : th_1;
-                keep = (va >= th) && (vb >= th);
-            }
-            const uint64_t m_cn = __ballot(keep && in_b), m_l1 = __ballot(keep && !in_b);
-            if (keep) {
-                const int64_t dst = in_b ? cn_base + n_cn + lanes_below(m_cn, lane)
-                                         : l1_base + n_l1 + lanes_below(m_l1, lane);
-                stage_node[dst] = x;
-                stage_pa[dst] = va;
-                stage_pb[dst] = vb;
-            }
-            n_cn += __popcll(m_cn);
-            n_l1 += __popcll(m_l1);
-        }
-        // ---- pass B: neighbours of b that are not neighbours of a (always type 1)
-        for (int64_t j0 = 0; j0 < dB; j0 += 64) {
-            const int64_t j = j0 + lane;
-            int32_t y = 0;
-            bool keep = false;
-            float va = 0.f, vb = 0.f;
-            if (j < dB) {
-                y = rowB.lds ? s_b[j] : adj_col[rb0 + j];
-                if (row_find(rowA, y) < 0) {
-                    const int ia = row_find(rowPa, y), ib = row_find(rowPb, y);
-                    va = ppr_round_trip(ia >= 0 ? ppr_val[pa0 + ia] : 0.0f, false);
-                    vb = ppr_round_trip(ib >= 0 ? ppr_val[pb0 + ib] : 0.0f, false);
-                    keep = (va >= th_1) && (vb >= th_1);
+// Probe U keys per lane in lock step: the U table reads (and then the U key compares) of a round are independent, so
+// their LDS latencies overlap; with a load factor <= 0.5 almost every key is settled in the first round.
+template <int U>
+__device__ __forceinline__ void sel_probe_values(SelLds &L, float *dst, const int32_t (&c)[U], const float (&v)[U]) {
+    uint32_t h[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        h[u] = sel_hash(c[u]);
+        act[u] = c[u] >= 0;
+    }
+    while (true) {
+        int s[U];
+        int32_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = act[u] ? L.table[h[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) k[u] = (s[u] >= 0) ? L.cand[s[u]] : -1;
+        bool again = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (act[u]) {
+                if (s[u] < 0) {
+                    act[u] = false;  // empty slot: the node is not a candidate
+                } else if (k[u] == c[u]) {
+                    dst[s[u]] = v[u];
+                    act[u] = false;
+                } else {
+                    h[u] = (h[u] + 1) & (SEL_TBL - 1);
+                    again = true;
                 }
             }
-            const uint64_t m = __ballot(keep);
-            if (keep) {
-                const int64_t dst = l2_base + n_l2 + lanes_below(m, lane);
-                stage_node[dst] = y;
-                stage_pa[dst] = va;
-                stage_pb[dst] = vb;
-            }
-            n_l2 += __popcll(m);
         }
-        // ---- pass T: >1-hop nodes = stored in both PPR rows, adjacent to neither endpoint (unmasked adjacency)
-        if (t0_rowptr) {
-            const int64_t ta0 = t0_rowptr[a], ta1 = t0_rowptr[a + 1];
-            const int64_t tb0 = t0_rowptr[b], tb1 = t0_rowptr[b + 1];
-            const bool walk_a = (ta1 - ta0) <= (tb1 - tb0);  // walk the shorter row, probe the longer
-            const int64_t w0 = walk_a ? ta0 : tb0, w1 = walk_a ? ta1 : tb1;
-            const int64_t o0 = walk_a ? tb0 : ta0, o1 = walk_a ? tb1 : ta1;
-            SortedRow rowXa = rowA, rowXb = rowB;
-            if (!same_adj) {
-                rowXa = SortedRow{nullptr, adjx_col, adjx_rowptr[a], (int)(adjx_rowptr[a + 1] - adjx_rowptr[a])};
-                rowXb = SortedRow{nullptr, adjx_col, adjx_rowptr[b], (int)(adjx_rowptr[b + 1] - adjx_rowptr[b])};
+        if (__ballot(again) == 0) break;
+    }
+}
+
+// stream the tail of a (col, val) CSR row (entries from `from` on) through the hash
+__device__ __forceinline__ void sel_stream_values(SelLds &L, float *dst, const int32_t *__restrict__ col,
+                                                  const float *__restrict__ val, int64_t lo, int from, int n,
+                                                  int lane) {
+    for (int i0 = from; i0 < n; i0 += 256) {  // four independent 64-entry loads in flight
+        int32_t c[4];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u + lane;
+            c[u] = (i < n) ? col[lo + i] : -1;
+            v[u] = (i < n) ? val[lo + i] : 0.f;
+        }
+        sel_probe_values<4>(L, dst, c, v);
+    }
+}
+
+// stream a sorted adjacency row through the hash: hits set `bit` as the candidate's flag
+__device__ __forceinline__ void sel_stream_flags(SelLds &L, uint8_t bit, const int32_t *__restrict__ col, int64_t lo,
+                                                 int64_t n, int lane) {
+    for (int64_t i0 = 0; i0 < n; i0 += 256) {
+        int32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + 64 * u + lane;
+            c[u] = (i < n) ? col[lo + i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c[u] >= 0) {
+                const int s = sel_probe(L, c[u]);
+                if (s >= 0) L.flag[s] = bit;  // one writer per slot (row entries are distinct)
             }
-            for (int64_t i0 = w0; i0 < w1; i0 += 64) {
+        }
+    }
+}
+
+constexpr int SEL_PRE = 6;  // 64-entry chunks of each PPR row fetched up front (384 entries)
+
+__global__ __launch_bounds__(64) void select_nodes_kernel(
+    const int64_t *__restrict__ item_total, const ItemRec *__restrict__ items, const int64_t *__restrict__ desc,
+    const int32_t *__restrict__ adj_col, const int64_t *__restrict__ adjx_rowptr, const int32_t *__restrict__ adjx_col,
+    int same_adj, const int32_t *__restrict__ ppr_col, const float *__restrict__ ppr_val,
+    const int32_t *__restrict__ t0_col, const float *__restrict__ t0_val, int want_t0, float th_cn, float th_1,
+    float th_n, const int64_t *__restrict__ stage_off, int32_t *__restrict__ stage_node, float *__restrict__ stage_pa,
+    float *__restrict__ stage_pb, int32_t *__restrict__ stage_cnt) {
+    __shared__ SelLds L;
+    const int lane = threadIdx.x;
+    const int64_t n_items = *item_total;
+
+    // one item per block: the hardware dispatcher balances the (very uneven) items; the record address is
+    // wave-uniform, so its fields arrive through scalar loads and every row base / bound below is scalar
+    for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const ItemRec r = items[it];
+        const int64_t p = r.p;
+        const int kind = r.kind, start = r.start, len = r.len;
+        const int64_t dA = r.dA, dB = r.dB;
+        const int nPa = r.nPa, nPb = r.nPb;
+        const int64_t ra0 = r.ra0, rb0 = r.rb0, pa0 = r.pa0, pb0 = r.pb0;
+        const int64_t s = stage_off[p];
+
+        // ---- 1. every global read of the item is issued up front: candidates and the head of both PPR rows
+        //         (chunks past the end of a row are skipped by scalar branches)
+        int32_t cnd[SEL_CAP / 64];
+        const int32_t *rowA = adj_col + ra0, *rowB = adj_col + rb0;
+        const int32_t *rowS = adj_col + (kind == 1 ? ra0 : rb0) + start;
+#pragma unroll
+        for (int u = 0; u < SEL_CAP / 64; ++u) {
+            cnd[u] = -1;
+            if (64 * u < len) {
+                const int i = lane + 64 * u;
+                if (i < len) {
+                    if (kind == 0) cnd[u] = (i < dA) ? rowA[i] : rowB[i - dA];
+                    else cnd[u] = rowS[i];
+                }
+            }
+        }
+        int32_t ca[SEL_PRE], cb[SEL_PRE];
+        float wa[SEL_PRE], wb[SEL_PRE];
+        const int32_t *pca = ppr_col + pa0, *pcb = ppr_col + pb0;
+        const float *pva = ppr_val + pa0, *pvb = ppr_val + pb0;
+#pragma unroll
+        for (int u = 0; u < SEL_PRE; ++u) {
+            const int i = lane + 64 * u;
+            ca[u] = -1; wa[u] = 0.f; cb[u] = -1; wb[u] = 0.f;
+            if (64 * u < nPa && i < nPa) { ca[u] = pca[i]; wa[u] = pva[i]; }
+            if (64 * u < nPb && i < nPb) { cb[u] = pcb[i]; wb[u] = pvb[i]; }
+        }
+        __syncthreads();  // the previous item's LDS image is no longer needed
+        // empty table and value slots while the loads are in flight
+        for (int i = lane; i < SEL_TBL / 4; i += 64)
+            reinterpret_cast<int4 *>(L.table)[i] = make_int4(-1, -1, -1, -1);
+        for (int i = lane; i < (len + 3) / 4; i += 64) {
+            reinterpret_cast<float4 *>(L.pa)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4 *>(L.pb)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int i = lane; i < (len + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(L.flag)[i] = 0u;
+#pragma unroll
+        for (int u = 0; u < SEL_CAP / 64; ++u)
+            if (lane + 64 * u < len) L.cand[lane + 64 * u] = cnd[u];
+        __syncthreads();
+        // ---- 2. hash inserts (whole pair: N(a) first, then N(b); a node found again is a common neighbour)
+        const int n_first = (kind == 0) ? (int)dA : len;
+        for (int i = lane; i < n_first; i += 64) {
+            uint32_t h = sel_hash(L.cand[i]);
+            while (atomicCAS(&L.table[h], -1, i) != -1) h = (h + 1) & (SEL_TBL - 1);
+        }
+        if (kind == 0) {
+            __syncthreads();
+            for (int i = (int)dA + lane; i < len; i += 64) {
+                const int32_t key = L.cand[i];
+                uint32_t h = sel_hash(key);
+                while (true) {
+                    const int prev = atomicCAS(&L.table[h], -1, i);
+                    if (prev == -1) break;
+                    if (L.cand[prev] == key) {  // prev is the copy from N(a)
+                        L.flag[prev] = F_INB;
+                        L.flag[i] = F_INA;
+                        break;
+                    }
+                    h = (h + 1) & (SEL_TBL - 1);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. stream the rows that carry information about the candidates
+        if (kind == 1) sel_stream_flags(L, F_INB, adj_col, rb0, dB, lane);
+        if (kind == 2) sel_stream_flags(L, F_INA, adj_col, ra0, dA, lane);
+        sel_probe_values<SEL_PRE>(L, L.pa, ca, wa);
+        sel_probe_values<SEL_PRE>(L, L.pb, cb, wb);
+        if (nPa > 64 * SEL_PRE) sel_stream_values(L, L.pa, ppr_col, ppr_val, pa0, 64 * SEL_PRE, nPa, lane);
+        if (nPb > 64 * SEL_PRE) sel_stream_values(L, L.pb, ppr_col, ppr_val, pb0, 64 * SEL_PRE, nPb, lane);
+        __syncthreads();
+        // ---- 4. type, round trip, threshold; dense code per candidate; counts
+        int n_cn = 0, n_l1 = 0, n_l2 = 0;
+        const int64_t slot0 = s + (kind == 2 ? dA : 0) + start;  // kind 0: candidate i <-> staging slot s + i
+        for (int i0 = 0; i0 < len; i0 += 64) {
+            const int i = i0 + lane;
+            int32_t code = -1;
+            bool from_a = false, cn = false, keep = false;
+            float va = 0.f, vb = 0.f;
+            if (i < len) {
+                from_a = (kind == 1) || (kind == 0 && i < dA);
+                const uint8_t f = L.flag[i];
+                if (from_a || !(f & F_INA)) {  // a node of N(b) that is also in N(a) is emitted through N(a)
+                    cn = from_a && (f & F_INB);
+                    va = ppr_round_trip(L.pa[i], cn);
+                    vb = ppr_round_trip(L.pb[i], cn);
+                    const float th = cn ? th_cn : th_1;
+                    keep = (va >= th) && (vb >= th);
+                    if (keep) code = L.cand[i] | (cn ? CN_BIT : 0);
+                }
+                stage_node[slot0 + i] = code;
+                if (keep) {
+                    stage_pa[slot0 + i] = va;
+                    stage_pb[slot0 + i] = vb;
+                }
+            }
+            n_cn += __popcll(__ballot(keep && cn));
+            n_l1 += __popcll(__ballot(keep && !cn && from_a));
+            n_l2 += __popcll(__ballot(keep && !from_a));
+        }
+        if (lane == 0) {
+            if (n_cn) atomicAdd(&stage_cnt[4 * p + 0], n_cn);
+            if (n_l1) atomicAdd(&stage_cnt[4 * p + 1], n_l1);
+            if (n_l2) atomicAdd(&stage_cnt[4 * p + 2], n_l2);
+        }
+        // ---- 5. >1-hop nodes: stored in both T0 rows, adjacent to neither endpoint (UNMASKED adjacency); done once
+        //         per pair, by its first item
+        if (want_t0 && (kind == 0 || (kind == 1 && start == 0) || (kind == 2 && start == 0 && dA == 0))) {
+            const int64_t *d = desc + p * DESC_I64;
+            const int64_t ta0 = d[4], tb0 = d[5], nTa = d[10], nTb = d[11], a = d[12], b = d[13];
+            const bool walk_a = nTa <= nTb;  // walk the shorter row, probe the longer
+            const int64_t w0 = walk_a ? ta0 : tb0, wn = walk_a ? nTa : nTb;
+            const int64_t o0 = walk_a ? tb0 : ta0, o1 = o0 + (walk_a ? nTb : nTa);
+            const bool use_hash = (kind == 0) && same_adj;  // the hash holds all of N(a) u N(b)
+            int64_t xa0 = ra0, xa1 = ra0 + dA, xb0 = rb0, xb1 = rb0 + dB;
+            const int32_t *xcol = adj_col;
+            if (!same_adj) {
+                xa0 = adjx_rowptr[a]; xa1 = adjx_rowptr[a + 1]; xb0 = adjx_rowptr[b]; xb1 = adjx_rowptr[b + 1];
+                xcol = adjx_col;
+            }
+            const int64_t t0_base = s + dA + dB;
+            int n_t0 = 0;
+            for (int64_t i0 = 0; i0 < wn; i0 += 64) {
                 const int64_t i = i0 + lane;
                 int32_t v = 0;
                 bool keep = false;
                 float sa = 0.f, sb = 0.f;
-                if (i < w1) {
-                    v = t0_col[i];
-                    const float pw = t0_val[i];
+                if (i < wn) {
+                    v = t0_col[w0 + i];
+                    const float pw = t0_val[w0 + i];
                     const float sw = __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f);
                     if (pw > 0.f && sw >= th_n) {
                         bool f;
                         const float po = csr_value(t0_col, t0_val, o0, o1, v, &f);
                         const float so = __fsub_rn(__fadd_rn(po, 1.0f), 1.0f);
-                        if (f && po > 0.f && so >= th_n && row_find(rowXa, v) < 0 && row_find(rowXb, v) < 0) {
-                            keep = true;
-                            sa = walk_a ? sw : so;
-                            sb = walk_a ? so : sw;
+                        if (f && po > 0.f && so >= th_n) {
+                            const bool adjacent = use_hash ? (sel_probe(L, v) >= 0)
+                                                           : (csr_contains(xcol, xa0, xa1, v) ||
+                                                              csr_contains(xcol, xb0, xb1, v));
+                            if (!adjacent) {
+                                keep = true;
+                                sa = walk_a ? sw : so;
+                                sb = walk_a ? so : sw;
+                            }
                         }
                     }
                 }
@@ -258,12 +448,7 @@ __global__ __launch_bounds__(64) void select_nodes_kernel(
                 }
                 n_t0 += __popcll(m);
             }
-        }
-        if (lane == 0) {
-            stage_cnt[4 * p + 0] = n_cn;
-            stage_cnt[4 * p + 1] = n_l1;
-            stage_cnt[4 * p + 2] = n_l2;
-            stage_cnt[4 * p + 3] = n_t0;
+            if (lane == 0) stage_cnt[4 * p + 3] = n_t0;
         }
     }
 }
@@ -307,32 +492,74 @@ __global__ __launch_bounds__(256) void select_counts_kernel(int64_t bs, const in
     }
 }
 
-__global__ __launch_bounds__(256) void select_compact_kernel(
-    int64_t bs, const int64_t *__restrict__ batch, int64_t batch_ld, const int64_t *__restrict__ adj_rowptr,
-    const int64_t *__restrict__ stage_off, const int32_t *__restrict__ stage_node, const float *__restrict__ stage_pa,
-    const float *__restrict__ stage_pb, const int32_t *__restrict__ stage_cnt, const int64_t *__restrict__ type_ptr,
-    int32_t *__restrict__ sel_pair, int32_t *__restrict__ sel_node, float *__restrict__ sel_pa,
-    float *__restrict__ sel_pb) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+// One wavefront per pair: dense runs -> reference layout.  CN entries go straight to their final place; the kept
+// one-hop nodes of the N(a) run and of the N(b) run are first compacted IN PLACE (writes never pass the read
+// cursor), then merged: two sorted, disjoint runs, final rank = own index + lower_bound in the other run.
+__global__ __launch_bounds__(64) void select_compact_kernel(
+    int64_t bs, const int64_t *__restrict__ desc, const int64_t *__restrict__ stage_off,
+    int32_t *__restrict__ stage_node, float *__restrict__ stage_pa, float *__restrict__ stage_pb,
+    const int32_t *__restrict__ stage_cnt, const int64_t *__restrict__ type_ptr, int32_t *__restrict__ sel_pair,
+    int32_t *__restrict__ sel_node, float *__restrict__ sel_pa, float *__restrict__ sel_pb) {
+    const int lane = threadIdx.x;
     const int64_t tot_cn = type_ptr[bs], tot_1 = type_ptr[(bs + 1) + bs];
-    for (int64_t p = wave_id; p < bs; p += n_waves) {
-        const int64_t a = batch[p], b = batch[batch_ld + p];
-        const int64_t dA = adj_rowptr[a + 1] - adj_rowptr[a], dB = adj_rowptr[b + 1] - adj_rowptr[b];
+    for (int64_t p = blockIdx.x; p < bs; p += gridDim.x) {
+        const int64_t dA = desc[p * DESC_I64 + 6], dB = desc[p * DESC_I64 + 7];
         const int64_t s = stage_off[p];
-        const int n_cn = stage_cnt[4 * p], n_l1 = stage_cnt[4 * p + 1], n_l2 = stage_cnt[4 * p + 2],
-                  n_t0 = stage_cnt[4 * p + 3];
+        const int n_l1 = stage_cnt[4 * p + 1], n_l2 = stage_cnt[4 * p + 2], n_t0 = stage_cnt[4 * p + 3];
         const int64_t d_cn = type_ptr[p], d_1 = tot_cn + type_ptr[(bs + 1) + p],
                       d_0 = tot_cn + tot_1 + type_ptr[2 * (bs + 1) + p];
-        const int64_t l1 = s + dA, l2 = s + 2 * dA, t0 = s + 2 * dA + dB;
-        for (int i = lane; i < n_cn; i += 64) {
-            sel_pair[d_cn + i] = (int32_t)p;
-            sel_node[d_cn + i] = stage_node[s + i];
-            sel_pa[d_cn + i] = stage_pa[s + i];
-            sel_pb[d_cn + i] = stage_pb[s + i];
+        const int64_t l1 = s, l2 = s + dA, t0 = s + dA + dB;
+        int c_cn = 0, c_l1 = 0, c_l2 = 0;
+        for (int64_t i0 = 0; i0 < dA; i0 += 64) {  // N(a) run: CN -> final, one-hop -> in place
+            const int64_t i = i0 + lane;
+            int32_t code = -1;
+            float va = 0.f, vb = 0.f;
+            if (i < dA) {
+                code = stage_node[s + i];
+                if (code >= 0) {
+                    va = stage_pa[s + i];
+                    vb = stage_pb[s + i];
+                }
+            }
+            const bool is_cn = code >= 0 && (code & CN_BIT), is_l1 = code >= 0 && !(code & CN_BIT);
+            const uint64_t m_cn = __ballot(is_cn), m_l1 = __ballot(is_l1);
+            if (is_cn) {
+                const int64_t dst = d_cn + c_cn + lanes_below(m_cn, lane);
+                sel_pair[dst] = (int32_t)p;
+                sel_node[dst] = code & ~CN_BIT;
+                sel_pa[dst] = va;
+                sel_pb[dst] = vb;
+            }
+            if (is_l1) {
+                const int64_t dst = l1 + c_l1 + lanes_below(m_l1, lane);
+                stage_node[dst] = code;
+                stage_pa[dst] = va;
+                stage_pb[dst] = vb;
+            }
+            c_cn += __popcll(m_cn);
+            c_l1 += __popcll(m_l1);
         }
-        // merge the two sorted, disjoint 1-hop runs: final rank = own index + rank in the other run
+        for (int64_t j0 = 0; j0 < dB; j0 += 64) {  // N(b) run: one-hop -> in place
+            const int64_t j = j0 + lane;
+            int32_t code = -1;
+            float va = 0.f, vb = 0.f;
+            if (j < dB) {
+                code = stage_node[l2 + j];
+                if (code >= 0) {
+                    va = stage_pa[l2 + j];
+                    vb = stage_pb[l2 + j];
+                }
+            }
+            const uint64_t m = __ballot(code >= 0);
+            if (code >= 0) {
+                const int64_t dst = l2 + c_l2 + lanes_below(m, lane);
+                stage_node[dst] = code;
+                stage_pa[dst] = va;
+                stage_pb[dst] = vb;
+            }
+            c_l2 += __popcll(m);
+        }
+        __syncthreads();  // the compacted runs (global memory) are read back by other lanes below
         for (int i = lane; i < n_l1; i += 64) {
             const int32_t x = stage_node[l1 + i];
             const int64_t dst = d_1 + i + (lpf_lower_bound(stage_node, l2, l2 + n_l2, x) - l2);
@@ -355,51 +582,53 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
             sel_pa[d_0 + i] = stage_pa[t0 + i];
             sel_pb[d_0 + i] = stage_pb[t0 + i];
         }
+        __syncthreads();
     }
-}
-
-inline unsigned wave_grid(int64_t n_items) {  // 4 waves per block, grid-stride past ~32 blocks per CU
-    int64_t blocks = (n_items + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    if (blocks < 1) blocks = 1;
-    return (unsigned)blocks;
 }
 
 }  // namespace
 
 extern "C" int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
-                                const int64_t *t0_rowptr, int64_t *stage_off, int64_t *scratch, void *stream) {
-    LPF_REQUIRE(bs >= 0 && stage_off && scratch);
+                                const int64_t *ppr_rowptr, const int64_t *t0_rowptr, int64_t *offs, int64_t *desc,
+                                int64_t *scratch, void *stream) {
+    LPF_REQUIRE(bs >= 0 && offs && scratch);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (bs == 0) {
-        (void)hipMemsetAsync(stage_off, 0, sizeof(int64_t), s);
+        (void)hipMemsetAsync(offs, 0, 2 * sizeof(int64_t), s);
         return LPF_OK;
     }
-    LPF_REQUIRE(batch && adj_rowptr && batch_ld >= bs);
+    LPF_REQUIRE(batch && adj_rowptr && ppr_rowptr && desc && batch_ld >= bs);
     const int64_t nb = (bs + 255) / 256;
     hipLaunchKernelGGL(select_bound_kernel, dim3((unsigned)nb), dim3(256), 0, s, bs, batch, batch_ld, adj_rowptr,
-                       t0_rowptr, stage_off, scratch);
-    hipLaunchKernelGGL(scan_blocks_kernel<1>, dim3((unsigned)nb), dim3(256), 0, s, bs, stage_off, (int64_t)0, scratch,
-                       nb);
+                       ppr_rowptr, t0_rowptr, offs, desc, scratch, nb);
+    hipLaunchKernelGGL(scan_blocks_kernel<2>, dim3((unsigned)nb), dim3(256), 0, s, bs, offs, bs + 1, scratch, nb);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
 
-extern "C" int lpf_select_nodes(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
-                                const int32_t *adj_col, const int64_t *adjx_rowptr, const int32_t *adjx_col,
-                                const int64_t *ppr_rowptr, const int32_t *ppr_col, const float *ppr_val,
-                                const int64_t *t0_rowptr, const int32_t *t0_col, const float *t0_val, float th_cn,
-                                float th_1hop, float th_non1hop, const int64_t *stage_off, int32_t *stage_node,
-                                float *stage_pa, float *stage_pb, int32_t *stage_cnt, void *stream) {
+extern "C" int lpf_select_nodes(int64_t bs, int64_t item_capacity, const int64_t *offs, const int64_t *desc,
+                                int32_t *items, const int32_t *adj_col, const int64_t *adjx_rowptr,
+                                const int32_t *adjx_col, int32_t same_adj, const int32_t *ppr_col,
+                                const float *ppr_val, const int32_t *t0_col, const float *t0_val, float th_cn,
+                                float th_1hop, float th_non1hop, int32_t *stage_node, float *stage_pa, float *stage_pb,
+                                int32_t *stage_cnt, void *stream) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && batch && batch_ld >= bs && adj_rowptr && adj_col && ppr_rowptr && ppr_col && ppr_val);
-    LPF_REQUIRE(stage_off && stage_node && stage_pa && stage_pb && stage_cnt);
-    LPF_REQUIRE(!t0_rowptr || (t0_col && t0_val && adjx_rowptr && adjx_col));
-    const unsigned sel_blocks = (unsigned)(bs < 256 * 64 ? bs : 256 * 64);  // one wave per block, grid-stride
-    hipLaunchKernelGGL(select_nodes_kernel, dim3(sel_blocks), dim3(64), 0, static_cast<hipStream_t>(stream), bs,
-                       batch, batch_ld, adj_rowptr, adj_col, adjx_rowptr, adjx_col, ppr_rowptr, ppr_col, ppr_val,
-                       t0_rowptr, t0_col, t0_val, th_cn, th_1hop, th_non1hop, stage_off, stage_node, stage_pa,
-                       stage_pb, stage_cnt);
+    LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && item_capacity >= bs && offs && desc && items && adj_col && ppr_col &&
+                ppr_val && stage_node && stage_pa && stage_pb && stage_cnt && lpf_aligned16(items) &&
+                lpf_aligned16(stage_cnt));
+    LPF_REQUIRE(same_adj || (adjx_rowptr && adjx_col));
+    const int want_t0 = t0_col != nullptr;
+    LPF_REQUIRE(!want_t0 || t0_val);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t *item_off = offs + (bs + 1);
+    hipLaunchKernelGGL(select_items_kernel, dim3((unsigned)((bs + 255) / 256)), dim3(256), 0, s, bs, desc, item_off,
+                       reinterpret_cast<ItemRec *>(items), stage_cnt);
+    // one wavefront per block and (up to a cap) one item per block: uneven items are balanced by the dispatcher
+    const int64_t blocks = item_capacity < (1 << 20) ? item_capacity : (1 << 20);
+    hipLaunchKernelGGL(select_nodes_kernel, dim3((unsigned)blocks), dim3(64), 0, s, item_off + bs,
+                       reinterpret_cast<const ItemRec *>(items), desc, adj_col, adjx_rowptr, adjx_col, (int)same_adj,
+                       ppr_col, ppr_val, t0_col, t0_val, want_t0, th_cn, th_1hop, th_non1hop, offs, stage_node,
+                       stage_pa, stage_pb, stage_cnt);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
@@ -412,7 +641,7 @@ extern "C" int lpf_select_scan(int64_t bs, const int32_t *stage_cnt, int64_t *ty
         (void)hipMemsetAsync(type_ptr, 0, 3 * sizeof(int64_t), s);
         return LPF_OK;
     }
-    LPF_REQUIRE(stage_cnt && (!counts_f || ldc >= (want_t0 ? 4 : 3)));
+    LPF_REQUIRE(stage_cnt && lpf_aligned16(stage_cnt) && (!counts_f || ldc >= (want_t0 ? 4 : 3)));
     const int64_t nb = (bs + 255) / 256;
     hipLaunchKernelGGL(select_counts_kernel, dim3((unsigned)nb), dim3(256), 0, s, bs, stage_cnt, type_ptr, counts_f,
                        ldc, (int)want_t0, scratch, nb);
@@ -421,16 +650,16 @@ extern "C" int lpf_select_scan(int64_t bs, const int32_t *stage_cnt, int64_t *ty
     return LPF_OK;
 }
 
-extern "C" int lpf_select_compact(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
-                                  const int64_t *stage_off, const int32_t *stage_node, const float *stage_pa,
-                                  const float *stage_pb, const int32_t *stage_cnt, const int64_t *type_ptr,
+extern "C" int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t *offs, int32_t *stage_node,
+                                  float *stage_pa, float *stage_pb, const int32_t *stage_cnt, const int64_t *type_ptr,
                                   int32_t *sel_pair, int32_t *sel_node, float *sel_pa, float *sel_pb, void *stream) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && batch && batch_ld >= bs && adj_rowptr && stage_off && stage_node &&
-                stage_pa && stage_pb && stage_cnt && type_ptr && sel_pair && sel_node && sel_pa && sel_pb);
-    hipLaunchKernelGGL(select_compact_kernel, dim3(wave_grid(bs)), dim3(256), 0, static_cast<hipStream_t>(stream), bs,
-                       batch, batch_ld, adj_rowptr, stage_off, stage_node, stage_pa, stage_pb, stage_cnt, type_ptr,
-                       sel_pair, sel_node, sel_pa, sel_pb);
+    LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && desc && offs && stage_node && stage_pa && stage_pb && stage_cnt &&
+                type_ptr && sel_pair && sel_node && sel_pa && sel_pb);
+    const int64_t blocks = bs < 256 * 64 ? bs : 256 * 64;
+    hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream), bs,
+                       desc, offs, stage_node, stage_pa, stage_pb, stage_cnt, type_ptr, sel_pair, sel_node, sel_pa,
+                       sel_pb);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

@@ -482,24 +482,27 @@ class LinkTransformer(nn.Module):
         want_t0 = self.mask == "all"
         t0 = self._device_graph("t0", self._data_obj("ppr", test_set)) if want_t0 else None
 
-        stage_off = self._workspace("stage_off", bs + 1, torch.int64)
+        offs = self._workspace("select_offs", 2 * (bs + 1), torch.int64)
+        desc = self._workspace("select_desc", 16 * bs, torch.int64)
         scratch = self._workspace("scan_scratch", 3 * ((bs + 255) // 256) + 3, torch.int64)
         with KernelTimer.span("select_bound"):
-            check(lib.lpf_select_bound(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr),
-                                       ptr(t0.rowptr) if want_t0 else None, ptr(stage_off), ptr(scratch), st),
+            check(lib.lpf_select_bound(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(ppr.rowptr),
+                                       ptr(t0.rowptr) if want_t0 else None, ptr(offs), ptr(desc), ptr(scratch), st),
                   "lpf_select_bound")
-        cap = int(stage_off[bs].item())  # one 8-byte read-back sizes the staging area
+        # one 16-byte read-back sizes the staging area and the work-item table
+        cap, n_items = (int(v) for v in offs[bs:2 * bs + 2:bs + 1].tolist())
         stage_node = self._workspace("stage_node", cap, torch.int32)
         stage_pa = self._workspace("stage_pa", cap, torch.float32)
         stage_pb = self._workspace("stage_pb", cap, torch.float32)
         stage_cnt = self._workspace("stage_cnt", 4 * bs, torch.int32)
+        items = self._workspace("select_items", 16 * n_items, torch.int32)
         with KernelTimer.span("select_nodes"):
-            check(lib.lpf_select_nodes(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(adj.col), ptr(adjx.rowptr),
-                                       ptr(adjx.col), ptr(ppr.rowptr), ptr(ppr.col), ptr(ppr.val),
-                                       ptr(t0.rowptr) if want_t0 else None, ptr(t0.col) if want_t0 else None,
-                                       ptr(t0.val) if want_t0 else None, float(self.thresh_cn), float(self.thresh_1hop),
-                                       float(self.thresh_non1hop), ptr(stage_off), ptr(stage_node), ptr(stage_pa),
-                                       ptr(stage_pb), ptr(stage_cnt), st), "lpf_select_nodes")
+            check(lib.lpf_select_nodes(bs, n_items, ptr(offs), ptr(desc), ptr(items), ptr(adj.col), ptr(adjx.rowptr),
+                                       ptr(adjx.col), 1 if adj is adjx else 0, ptr(ppr.col), ptr(ppr.val),
+                                       ptr(t0.col) if want_t0 else None, ptr(t0.val) if want_t0 else None,
+                                       float(self.thresh_cn), float(self.thresh_1hop), float(self.thresh_non1hop),
+                                       ptr(stage_node), ptr(stage_pa), ptr(stage_pb), ptr(stage_cnt), st),
+                  "lpf_select_nodes")
         ldf = _pad4(self.dim + self.count_dim)
         feats = torch.zeros(bs, ldf, dtype=torch.float32, device=self.device)  # [att out | counts | pad]
         type_ptr = self._workspace("type_ptr", 3 * (bs + 1), torch.int64)
@@ -511,10 +514,9 @@ class LinkTransformer(nn.Module):
         sel_pa = self._workspace("sel_pa", cap, torch.float32)
         sel_pb = self._workspace("sel_pb", cap, torch.float32)
         with KernelTimer.span("select_compact"):
-            check(lib.lpf_select_compact(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(stage_off),
-                                         ptr(stage_node), ptr(stage_pa), ptr(stage_pb), ptr(stage_cnt), ptr(type_ptr),
-                                         ptr(sel_pair), ptr(sel_node), ptr(sel_pa), ptr(sel_pb), st),
-                  "lpf_select_compact")
+            check(lib.lpf_select_compact(bs, ptr(desc), ptr(offs), ptr(stage_node), ptr(stage_pa), ptr(stage_pb),
+                                         ptr(stage_cnt), ptr(type_ptr), ptr(sel_pair), ptr(sel_node), ptr(sel_pa),
+                                         ptr(sel_pb), st), "lpf_select_compact")
         return {"bs": bs, "cap": cap, "type_ptr": type_ptr, "sel_pair": sel_pair, "sel_node": sel_node,
                 "sel_pa": sel_pa, "sel_pb": sel_pb, "feats": feats, "ldf": ldf}
 
