@@ -112,6 +112,11 @@ int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const i
  *   adjx_*    UNMASKED adjacency used to exclude neighbours from the >1-hop set (link_transformer.py:443);
  *             same_adj != 0 says it is the very adjacency the descriptors were built from (evaluation)
  *   ppr_col/val, t0_col/val   column/value arrays of the PPR CSR and of the >1-hop candidate CSR (t0_col NULL: skip)
+ *   adj_selfp  optional index (NULL = general path): adj_selfp[e] = P[i, j] for adjacency entry e = (i, j), 0 when
+ *             not stored.  When given, ppr_col/ppr_val and the ppr_rowptr handed to lpf_select_bound may be any
+ *             subset of the PPR rows that keeps every entry with fl32(fl32(p+1)-1) >= theta_1 (the "P1" index):
+ *             PPR values of a node's own neighbours then come from adj_selfp and no PPR row is streamed.
+ *             Results are identical with and without the indexes.
  * Dense staging for pair k at s = offs[k], dA = deg(a), dB = deg(b):
  *   stage_node[s+i],        i < dA : -1 (dropped) | node | (1<<30 if common neighbour)   for the i-th node of N(a)
  *   stage_node[s+dA+j],     j < dB : -1 | node                                           for the j-th node of N(b)
@@ -119,7 +124,8 @@ int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const i
  *   stage_pa/pb fp32 at the same slots (values AFTER the reference's fp32 round trip), written for kept nodes
  *   stage_cnt[4k+0..2] = kept CN / kept 1-hop from N(a) / kept 1-hop from N(b) */
 int lpf_select_nodes(int64_t bs, int64_t item_capacity, const int64_t *offs, const int64_t *desc, int32_t *items,
-                     const int32_t *adj_col, const int64_t *adjx_rowptr, const int32_t *adjx_col, int32_t same_adj,
+                     const int32_t *adj_col, const float *adj_selfp, const int64_t *adjx_rowptr,
+                     const int32_t *adjx_col, int32_t same_adj,
                      const int32_t *ppr_col, const float *ppr_val, const int32_t *t0_col, const float *t0_val,
                      float th_cn, float th_1hop, float th_non1hop, int32_t *stage_node, float *stage_pa,
                      float *stage_pb, int32_t *stage_cnt, void *stream);

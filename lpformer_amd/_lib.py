@@ -28,7 +28,7 @@ HIP_PROTOTYPES = {
     "lpf_layernorm_f32": [i64, i32, vp, i64, vp, vp, vp, i64, u32, vp],
     "lpf_pair_gather_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lpf_select_bound": [i64, vp, i64, vp, vp, vp, vp, vp, vp, vp],
-    "lpf_select_nodes": [i64, i64, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp],
+    "lpf_select_nodes": [i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp],
     "lpf_select_scan": [i64, vp, vp, vp, i64, i32, vp, vp],
     "lpf_select_compact": [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],

@@ -18,6 +18,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+constexpr int SG_HEAVY = 32;  // pairs with more selected nodes than this get a whole workgroup in phase B
+
 struct PeStat {
     float c00, c11, cbb, c01, c0b, c1b;
 };
@@ -80,10 +82,14 @@ __global__ __launch_bounds__(256) void pair_scores_kernel(
 
         const float4 *wp = reinterpret_cast<const float4 *>(wpk) + (int64_t)t * NT * NSQ * 64 + lane;
         const float4 *tb = tab + t * D + lh * (D / 2);
-        for (int sq = 0; sq < NSQ; ++sq) {
-            float4 wa[NT];
+        float4 wa[NT];
 #pragma unroll
-            for (int c = 0; c < NT; ++c) wa[c] = wp[(c * NSQ + sq) * 64];
+        for (int c = 0; c < NT; ++c) wa[c] = wp[(c * NSQ) * 64];
+        for (int sq = 0; sq < NSQ; ++sq) {
+            float4 wn[NT];  // next step group's A operands: in flight while this group's MFMAs issue
+            const int sqn = (sq + 1 < NSQ) ? sq + 1 : sq;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) wn[c] = wp[(c * NSQ + sqn) * 64];
             float h[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) h[u] = pe_hidden(tb[4 * sq + u], pa, pb, r_ab, r_ba);
@@ -94,6 +100,8 @@ __global__ __launch_bounds__(256) void pair_scores_kernel(
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].z, h[2], acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].w, h[3], acc[c], 0, 0, 0);
             }
+#pragma unroll
+            for (int c = 0; c < NT; ++c) wa[c] = wn[c];
         }
         // acc[c][4g+u] = (Wfold_t h_e)[feature 32c + 8g + 4*lh + u] for entry lj
         const float *zrow = Z + (int64_t)node * ldz;
@@ -124,6 +132,55 @@ __global__ __launch_bounds__(256) void pair_scores_kernel(
     }
 }
 
+// One chunk of up to G consecutive entries (same pair, same type) handled by one lane group: lane i fetches the
+// metadata of entry i (coalesced) and does the per-entry scalar math once (alpha, LayerNorm 1/std); then the entries
+// are broadcast one by one while every lane gathers its 16 bytes of the Z row, four rows in flight.
+template <int G>
+__device__ __forceinline__ void sg_chunk(const PeStat &st, const float4 (&k)[4], bool act, int off, int gbase, int lig,
+                                         int remaining, int64_t e0, float m, float den,
+                                         const int32_t *__restrict__ sel_node, const float *__restrict__ sel_pa,
+                                         const float *__restrict__ sel_pb, const float *__restrict__ score,
+                                         const float *__restrict__ Z, int64_t ldz, float *__restrict__ alpha_out,
+                                         float4 &accz, float4 &acch, float &asum) {
+    const bool valid = lig < remaining;
+    const int64_t e = e0 + lig;
+    const float my_alpha = valid ? expf(score[e] - m) / den : 0.f;
+    const float my_pa = valid ? sel_pa[e] : 0.f, my_pb = valid ? sel_pb[e] : 0.f;
+    const int32_t my_node = valid ? sel_node[e] : 0;
+    const float my_rab = pe_rstd(st, my_pa, my_pb), my_rba = pe_rstd(st, my_pb, my_pa);
+    if (alpha_out && valid) alpha_out[e] = my_alpha;
+    const int n_here = remaining < G ? remaining : G;
+    for (int j = 0; j < n_here; j += 4) {  // lanes past n_here carry alpha = 0, node = 0: harmless gathers
+        float al[4], pa[4], pb[4], rab[4], rba[4];
+        int32_t nd[4];
+        float4 z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int src = gbase + ((j + u) & (G - 1));
+            al[u] = __shfl(my_alpha, src, 64);
+            nd[u] = __shfl(my_node, src, 64);
+            pa[u] = __shfl(my_pa, src, 64);
+            pb[u] = __shfl(my_pb, src, 64);
+            rab[u] = __shfl(my_rab, src, 64);
+            rba[u] = __shfl(my_rba, src, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            z[u] = act ? *reinterpret_cast<const float4 *>(Z + (int64_t)nd[u] * ldz + off)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            accz.x = fmaf(al[u], z[u].x, accz.x); accz.y = fmaf(al[u], z[u].y, accz.y);
+            accz.z = fmaf(al[u], z[u].z, accz.z); accz.w = fmaf(al[u], z[u].w, accz.w);
+            acch.x = fmaf(al[u], pe_hidden(k[0], pa[u], pb[u], rab[u], rba[u]), acch.x);
+            acch.y = fmaf(al[u], pe_hidden(k[1], pa[u], pb[u], rab[u], rba[u]), acch.y);
+            acch.z = fmaf(al[u], pe_hidden(k[2], pa[u], pb[u], rab[u], rba[u]), acch.z);
+            acch.w = fmaf(al[u], pe_hidden(k[3], pa[u], pb[u], rab[u], rba[u]), acch.w);
+            asum += al[u];
+        }
+    }
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
     int D, int64_t bs, const int64_t *__restrict__ type_ptr, const int32_t *__restrict__ sel_node,
@@ -151,6 +208,10 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
             beg[t] = tbase[t] + lo;
             cnt[t] = (int)(hi - lo);
         }
+        // pairs with many selected nodes would serialise one lane group for a long time: they are left to
+        // pair_softmax_gather_heavy_kernel (a whole workgroup per pair)
+        const bool heavy = cnt[0] + cnt[1] + cnt[2] > SG_HEAVY;
+        if (heavy) cnt[0] = cnt[1] = cnt[2] = 0;
         // segment softmax statistics over all of the pair's entries (PyG softmax: shift by max, denom + 1e-16)
         float m = -INFINITY;
 #pragma unroll
@@ -180,48 +241,11 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
                 k[u] = act ? reinterpret_cast<const float4 *>(pe_tab)[t * D + off + u] : make_float4(0.f, 0.f, 0.f, 0.f);
             // chunks of G entries: lane i fetches the metadata of entry i (coalesced) and does the per-entry scalar
             // math once; the inner loop broadcasts entry by entry while every lane gathers its 16 bytes of the Z row
-            for (int base = 0; base < cnt[t]; base += G) {
-                const int i = base + lig;
-                const bool valid = i < cnt[t];
-                const int64_t e = beg[t] + i;
-                const float my_alpha = valid ? expf(score[e] - m) / den : 0.f;
-                const float my_pa = valid ? sel_pa[e] : 0.f, my_pb = valid ? sel_pb[e] : 0.f;
-                const int32_t my_node = valid ? sel_node[e] : 0;
-                const float my_rab = pe_rstd(st, my_pa, my_pb), my_rba = pe_rstd(st, my_pb, my_pa);
-                if (alpha_out && valid) alpha_out[e] = my_alpha;
-                const int n_here = (cnt[t] - base) < G ? (cnt[t] - base) : G;
-                for (int j = 0; j < n_here; j += 2) {  // lanes past n_here carry alpha = 0, node = 0: harmless
-                    float al[2], pa[2], pb[2], rab[2], rba[2];
-                    int32_t nd[2];
-                    float4 z[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int src = gbase + ((j + u) & (G - 1));
-                        al[u] = __shfl(my_alpha, src, 64);
-                        nd[u] = __shfl(my_node, src, 64);
-                        pa[u] = __shfl(my_pa, src, 64);
-                        pb[u] = __shfl(my_pb, src, 64);
-                        rab[u] = __shfl(my_rab, src, 64);
-                        rba[u] = __shfl(my_rba, src, 64);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        z[u] = act ? *reinterpret_cast<const float4 *>(Z + (int64_t)nd[u] * ldz + off)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        accz.x = fmaf(al[u], z[u].x, accz.x); accz.y = fmaf(al[u], z[u].y, accz.y);
-                        accz.z = fmaf(al[u], z[u].z, accz.z); accz.w = fmaf(al[u], z[u].w, accz.w);
-                        acch[t].x = fmaf(al[u], pe_hidden(k[0], pa[u], pb[u], rab[u], rba[u]), acch[t].x);
-                        acch[t].y = fmaf(al[u], pe_hidden(k[1], pa[u], pb[u], rab[u], rba[u]), acch[t].y);
-                        acch[t].z = fmaf(al[u], pe_hidden(k[2], pa[u], pb[u], rab[u], rba[u]), acch[t].z);
-                        acch[t].w = fmaf(al[u], pe_hidden(k[3], pa[u], pb[u], rab[u], rba[u]), acch[t].w);
-                        asum[t] += al[u];
-                    }
-                }
-            }
+            for (int base = 0; base < cnt[t]; base += G)
+                sg_chunk<G>(st, k, act, off, gbase, lig, cnt[t] - base, beg[t] + base, m, den, sel_node, sel_pa, sel_pb,
+                            score, Z, ldz, alpha_out, accz, acch[t], asum[t]);
         }
-        if (live) {
+        if (live && !heavy) {
             float *g = Gout + p * ldg;
             if (act) {
                 *reinterpret_cast<float4 *>(g + off) = accz;
@@ -230,6 +254,114 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
                 *reinterpret_cast<float4 *>(g + 3 * D + off) = acch[2];
             }
             if (lig == 0) *reinterpret_cast<float4 *>(g + 4 * D) = make_float4(asum[0], asum[1], asum[2], 1.0f);
+        }
+    }
+}
+
+// Pairs with more than SG_HEAVY selected nodes: one 256-thread workgroup per pair (every other block exits at once).
+// The NG = 256/G lane groups take entries round-robin, partial sums meet in LDS and are added in group order, so the
+// result does not depend on scheduling.
+template <int G>
+__global__ __launch_bounds__(256) void pair_softmax_gather_heavy_kernel(
+    int D, int64_t bs, const int64_t *__restrict__ type_ptr, const int32_t *__restrict__ sel_node,
+    const float *__restrict__ sel_pa, const float *__restrict__ sel_pb, const float *__restrict__ score,
+    const float *__restrict__ Z, int64_t ldz, const float *__restrict__ pe_tab, const float *__restrict__ pe_stat,
+    float *__restrict__ Gout, int64_t ldg, float *__restrict__ alpha_out) {
+    constexpr int NG = 256 / G;
+    __shared__ float red[256];
+    __shared__ float part[NG][4 * 4 * G + 4];  // per group: accz | acch[0..2] (4G floats each) | asum[0..2]
+    const int64_t p = blockIdx.x;
+    const int64_t tot0 = type_ptr[bs], tot1 = type_ptr[(bs + 1) + bs];
+    const int64_t tbase[3] = {0, tot0, tot0 + tot1};
+    int64_t beg[3];
+    int cnt[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int64_t lo = type_ptr[t * (bs + 1) + p], hi = type_ptr[t * (bs + 1) + p + 1];
+        beg[t] = tbase[t] + lo;
+        cnt[t] = (int)(hi - lo);
+    }
+    if (cnt[0] + cnt[1] + cnt[2] <= SG_HEAVY) return;
+    const int tid = threadIdx.x, grp = tid / G, lig = tid % G, off = 4 * lig;
+    const int gbase = ((tid & 63) / G) * G;  // first lane of this group inside its wavefront
+    const bool act = off < D;
+
+    auto block_reduce = [&](float v, bool take_max) {
+        red[tid] = v;
+        __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) {
+            if (tid < sft) red[tid] = take_max ? fmaxf(red[tid], red[tid + sft]) : red[tid] + red[tid + sft];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        for (int i = tid; i < cnt[t]; i += 256) m = fmaxf(m, score[beg[t] + i]);
+    m = block_reduce(m, true);
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        for (int i = tid; i < cnt[t]; i += 256) den += expf(score[beg[t] + i] - m);
+    den = block_reduce(den, false) + 1e-16f;
+
+    float4 accz = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acch[3];
+    float asum[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        acch[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        asum[t] = 0.f;
+        if (cnt[t] == 0) continue;
+        PeStat st;
+        st.c00 = pe_stat[8 * t + 0]; st.c11 = pe_stat[8 * t + 1]; st.cbb = pe_stat[8 * t + 2];
+        st.c01 = pe_stat[8 * t + 3]; st.c0b = pe_stat[8 * t + 4]; st.c1b = pe_stat[8 * t + 5];
+        float4 k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            k[u] = act ? reinterpret_cast<const float4 *>(pe_tab)[t * D + off + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // lane groups take chunks of G consecutive entries round-robin
+        for (int base = grp * G; base < cnt[t]; base += NG * G)
+            sg_chunk<G>(st, k, act, off, gbase, lig, cnt[t] - base, beg[t] + base, m, den, sel_node, sel_pa, sel_pb,
+                        score, Z, ldz, alpha_out, accz, acch[t], asum[t]);
+    }
+    float *mine = part[grp];
+    *reinterpret_cast<float4 *>(mine + off) = accz;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<float4 *>(mine + (1 + t) * 4 * G + off) = acch[t];
+    if (lig == 0) {
+        mine[16 * G + 0] = asum[0];
+        mine[16 * G + 1] = asum[1];
+        mine[16 * G + 2] = asum[2];
+    }
+    __syncthreads();
+    if (grp == 0) {
+        float *g = Gout + p * ldg;
+        float4 s4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int gq = 0; gq < NG; ++gq) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(part[gq] + q * 4 * G + off);
+                s4[q].x += v.x; s4[q].y += v.y; s4[q].z += v.z; s4[q].w += v.w;
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(g + q * D + off) = s4[q];
+        }
+        if (lig == 0) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int gq = 0; gq < NG; ++gq) {
+                a0 += part[gq][16 * G + 0];
+                a1 += part[gq][16 * G + 1];
+                a2 += part[gq][16 * G + 2];
+            }
+            *reinterpret_cast<float4 *>(g + 4 * D) = make_float4(a0, a1, a2, 1.0f);
         }
     }
 }
@@ -286,6 +418,13 @@ extern "C" int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t 
     else if (GG == 32) LPF_SG_LAUNCH(32);
     else LPF_SG_LAUNCH(64);
 #undef LPF_SG_LAUNCH
+#define LPF_SGH_LAUNCH(GV)                                                                                          \
+    hipLaunchKernelGGL(pair_softmax_gather_heavy_kernel<GV>, dim3((unsigned)bs), dim3(256), 0, s, D, bs, type_ptr, \
+                       sel_node, sel_pa, sel_pb, score, Z, ldz, pe_tab, pe_stat, G, ldg, alpha_out)
+    if (GG == 16) LPF_SGH_LAUNCH(16);
+    else if (GG == 32) LPF_SGH_LAUNCH(32);
+    else LPF_SGH_LAUNCH(64);
+#undef LPF_SGH_LAUNCH
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

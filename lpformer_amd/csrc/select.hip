@@ -22,6 +22,15 @@
 // the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
 #pragma clang fp contract(off)
 
+// Orders the calling wavefront's own LDS traffic (a wave's DS instructions execute in issue order; this only stops the
+// compiler from moving LDS accesses across the point).  Not a barrier between wavefronts.
+#define LPF_WAVE_SYNC()                                         \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
 namespace {
 
 constexpr int SEL_CAP = 512;           // candidates per item
@@ -269,20 +278,25 @@ __device__ __forceinline__ void sel_stream_flags(SelLds &L, uint8_t bit, const i
 
 constexpr int SEL_PRE = 6;  // 64-entry chunks of each PPR row fetched up front (384 entries)
 
-__global__ __launch_bounds__(64) void select_nodes_kernel(
+__global__ __launch_bounds__(256) void select_nodes_kernel(
     const int64_t *__restrict__ item_total, const ItemRec *__restrict__ items, const int64_t *__restrict__ desc,
     const int32_t *__restrict__ adj_col, const int64_t *__restrict__ adjx_rowptr, const int32_t *__restrict__ adjx_col,
     int same_adj, const int32_t *__restrict__ ppr_col, const float *__restrict__ ppr_val,
     const int32_t *__restrict__ t0_col, const float *__restrict__ t0_val, int want_t0, float th_cn, float th_1,
     float th_n, const int64_t *__restrict__ stage_off, int32_t *__restrict__ stage_node, float *__restrict__ stage_pa,
     float *__restrict__ stage_pb, int32_t *__restrict__ stage_cnt) {
-    __shared__ SelLds L;
-    const int lane = threadIdx.x;
+    // Four independent wavefronts per workgroup, one item each, private LDS images (workgroup dispatch rate, not
+    // wave count, limits how fast tiny work items can be started).  The waves never synchronise with each other:
+    // LPF_WAVE_SYNC orders a wave's own LDS traffic only (its DS instructions execute in issue order).
+    __shared__ SelLds Ls[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SelLds &L = Ls[wave];
     const int64_t n_items = *item_total;
 
-    // one item per block: the hardware dispatcher balances the (very uneven) items; the record address is
-    // wave-uniform, so its fields arrive through scalar loads and every row base / bound below is scalar
-    for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    // the record address is wave-uniform, so its fields arrive through scalar loads and every row base / bound
+    // below is scalar; uneven items are balanced by the hardware dispatcher (about one item per wavefront)
+    for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < n_items; it += (int64_t)gridDim.x * 4) {
         const ItemRec r = items[it];
         const int64_t p = r.p;
         const int kind = r.kind, start = r.start, len = r.len;
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(64) void select_nodes_kernel(
             if (64 * u < nPa && i < nPa) { ca[u] = pca[i]; wa[u] = pva[i]; }
             if (64 * u < nPb && i < nPb) { cb[u] = pcb[i]; wb[u] = pvb[i]; }
         }
-        __syncthreads();  // the previous item's LDS image is no longer needed
+        LPF_WAVE_SYNC();  // the previous item's LDS image is no longer needed
         // empty table and value slots while the loads are in flight
         for (int i = lane; i < SEL_TBL / 4; i += 64)
             reinterpret_cast<int4 *>(L.table)[i] = make_int4(-1, -1, -1, -1);
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(64) void select_nodes_kernel(
 #pragma unroll
         for (int u = 0; u < SEL_CAP / 64; ++u)
             if (lane + 64 * u < len) L.cand[lane + 64 * u] = cnd[u];
-        __syncthreads();
+        LPF_WAVE_SYNC();
         // ---- 2. hash inserts (whole pair: N(a) first, then N(b); a node found again is a common neighbour)
         const int n_first = (kind == 0) ? (int)dA : len;
         for (int i = lane; i < n_first; i += 64) {
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(64) void select_nodes_kernel(
             while (atomicCAS(&L.table[h], -1, i) != -1) h = (h + 1) & (SEL_TBL - 1);
         }
         if (kind == 0) {
-            __syncthreads();
+            LPF_WAVE_SYNC();
             for (int i = (int)dA + lane; i < len; i += 64) {
                 const int32_t key = L.cand[i];
                 uint32_t h = sel_hash(key);
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(64) void select_nodes_kernel(
                 }
             }
         }
-        __syncthreads();
+        LPF_WAVE_SYNC();
         // ---- 3. stream the rows that carry information about the candidates
         if (kind == 1) sel_stream_flags(L, F_INB, adj_col, rb0, dB, lane);
         if (kind == 2) sel_stream_flags(L, F_INA, adj_col, ra0, dA, lane);
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(64) void select_nodes_kernel(
         sel_probe_values<SEL_PRE>(L, L.pb, cb, wb);
         if (nPa > 64 * SEL_PRE) sel_stream_values(L, L.pa, ppr_col, ppr_val, pa0, 64 * SEL_PRE, nPa, lane);
         if (nPb > 64 * SEL_PRE) sel_stream_values(L, L.pb, ppr_col, ppr_val, pb0, 64 * SEL_PRE, nPb, lane);
-        __syncthreads();
+        LPF_WAVE_SYNC();
         // ---- 4. type, round trip, threshold; dense code per candidate; counts
         int n_cn = 0, n_l1 = 0, n_l2 = 0;
         const int64_t slot0 = s + (kind == 2 ? dA : 0) + start;  // kind 0: candidate i <-> staging slot s + i
@@ -495,20 +509,76 @@ __global__ __launch_bounds__(256) void select_counts_kernel(int64_t bs, const in
 // One wavefront per pair: dense runs -> reference layout.  CN entries go straight to their final place; the kept
 // one-hop nodes of the N(a) run and of the N(b) run are first compacted IN PLACE (writes never pass the read
 // cursor), then merged: two sorted, disjoint runs, final rank = own index + lower_bound in the other run.
-__global__ __launch_bounds__(64) void select_compact_kernel(
+__global__ __launch_bounds__(256) void select_compact_kernel(
     int64_t bs, const int64_t *__restrict__ desc, const int64_t *__restrict__ stage_off,
     int32_t *__restrict__ stage_node, float *__restrict__ stage_pa, float *__restrict__ stage_pb,
     const int32_t *__restrict__ stage_cnt, const int64_t *__restrict__ type_ptr, int32_t *__restrict__ sel_pair,
     int32_t *__restrict__ sel_node, float *__restrict__ sel_pa, float *__restrict__ sel_pb) {
-    const int lane = threadIdx.x;
+    // four independent wavefronts per workgroup (workgroup dispatch, not wave count, limits tiny-kernel launch rate);
+    // the waves never synchronise with each other
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     const int64_t tot_cn = type_ptr[bs], tot_1 = type_ptr[(bs + 1) + bs];
-    for (int64_t p = blockIdx.x; p < bs; p += gridDim.x) {
+    for (int64_t p = wave_id; p < bs; p += n_waves) {
         const int64_t dA = desc[p * DESC_I64 + 6], dB = desc[p * DESC_I64 + 7];
         const int64_t s = stage_off[p];
         const int n_l1 = stage_cnt[4 * p + 1], n_l2 = stage_cnt[4 * p + 2], n_t0 = stage_cnt[4 * p + 3];
         const int64_t d_cn = type_ptr[p], d_1 = tot_cn + type_ptr[(bs + 1) + p],
                       d_0 = tot_cn + tot_1 + type_ptr[2 * (bs + 1) + p];
         const int64_t l1 = s, l2 = s + dA, t0 = s + dA + dB;
+        if (dA <= 64 && dB <= 64) {
+            // fast path (almost every pair): both runs fit one wavefront, so compaction and the merge of the two
+            // one-hop runs happen in registers -- one round of loads, no staging round trip
+            const bool ina = lane < dA, inb = lane < dB;
+            const int32_t ca = ina ? stage_node[l1 + lane] : -1, cb = inb ? stage_node[l2 + lane] : -1;
+            const float paa = ina ? stage_pa[l1 + lane] : 0.f, pba = ina ? stage_pb[l1 + lane] : 0.f;
+            const float pab = inb ? stage_pa[l2 + lane] : 0.f, pbb = inb ? stage_pb[l2 + lane] : 0.f;
+            float t_pa = 0.f, t_pb = 0.f;
+            int32_t t_nd = 0;
+            if (lane < n_t0) {
+                t_nd = stage_node[t0 + lane];
+                t_pa = stage_pa[t0 + lane];
+                t_pb = stage_pb[t0 + lane];
+            }
+            const bool is_cn = ca >= 0 && (ca & CN_BIT), is_l1 = ca >= 0 && !(ca & CN_BIT), is_l2 = cb >= 0;
+            const uint64_t m_cn = __ballot(is_cn), m_l1 = __ballot(is_l1), m_l2 = __ballot(is_l2);
+            if (is_cn) {
+                const int64_t dst = d_cn + lanes_below(m_cn, lane);
+                sel_pair[dst] = (int32_t)p;
+                sel_node[dst] = ca & ~CN_BIT;
+                sel_pa[dst] = paa;
+                sel_pb[dst] = pba;
+            }
+            int r1 = lanes_below(m_l1, lane), r2 = lanes_below(m_l2, lane);
+            for (uint64_t mm = m_l2; mm; mm &= mm - 1) {  // kept N(b)-run nodes smaller than my N(a)-run node
+                const int32_t y = __shfl(cb, __ffsll((unsigned long long)mm) - 1, 64);
+                r1 += (is_l1 && y < ca) ? 1 : 0;
+            }
+            for (uint64_t mm = m_l1; mm; mm &= mm - 1) {
+                const int32_t x = __shfl(ca, __ffsll((unsigned long long)mm) - 1, 64);
+                r2 += (is_l2 && x < cb) ? 1 : 0;
+            }
+            if (is_l1) {
+                sel_pair[d_1 + r1] = (int32_t)p;
+                sel_node[d_1 + r1] = ca;
+                sel_pa[d_1 + r1] = paa;
+                sel_pb[d_1 + r1] = pba;
+            }
+            if (is_l2) {
+                sel_pair[d_1 + r2] = (int32_t)p;
+                sel_node[d_1 + r2] = cb;
+                sel_pa[d_1 + r2] = pab;
+                sel_pb[d_1 + r2] = pbb;
+            }
+            for (int i = lane; i < n_t0; i += 64) {
+                const bool first = i < 64;
+                sel_pair[d_0 + i] = (int32_t)p;
+                sel_node[d_0 + i] = first ? t_nd : stage_node[t0 + i];
+                sel_pa[d_0 + i] = first ? t_pa : stage_pa[t0 + i];
+                sel_pb[d_0 + i] = first ? t_pb : stage_pb[t0 + i];
+            }
+            continue;
+        }
         int c_cn = 0, c_l1 = 0, c_l2 = 0;
         for (int64_t i0 = 0; i0 < dA; i0 += 64) {  // N(a) run: CN -> final, one-hop -> in place
             const int64_t i = i0 + lane;
@@ -559,7 +629,9 @@ __global__ __launch_bounds__(64) void select_compact_kernel(
             }
             c_l2 += __popcll(m);
         }
-        __syncthreads();  // the compacted runs (global memory) are read back by other lanes below
+        // the compacted runs (global memory) are read back by other lanes of this wavefront below
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < n_l1; i += 64) {
             const int32_t x = stage_node[l1 + i];
             const int64_t dst = d_1 + i + (lpf_lower_bound(stage_node, l2, l2 + n_l2, x) - l2);
@@ -582,7 +654,191 @@ __global__ __launch_bounds__(64) void select_compact_kernel(
             sel_pa[d_0 + i] = stage_pa[t0 + i];
             sel_pb[d_0 + i] = stage_pb[t0 + i];
         }
-        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Indexed variant (evaluation fast path).  Two per-model indexes over the PPR matrix remove the row streaming:
+//   selfp[e] = P[i, j] for adjacency entry e = (i, j) (0 when not stored): the PPR of a node to its own neighbours,
+//              aligned with the adjacency CSR, so "P[a, x] for x in N(a)" is a coalesced read;
+//   P1       = the PPR rows restricted to entries that can pass the one-hop test (fl32(fl32(p+1)-1) >= theta_1).
+// For a candidate x of N(a): if x is in N(b) (binary search in LDS) it is a common neighbour and P[b, x] is the self
+// value of b at the position just found; otherwise P[b, x] is looked up in P1[b] -- and only when x's own value
+// passes theta_1.  Each lane owns one candidate: no hash table, no cross-lane traffic, ~4x fewer instructions.
+// Results are identical to select_nodes_kernel (tests compare both against the reference's golden vectors).
+struct alignas(16) IdxLds {
+    int32_t cand[SEL_CAP];  // kind 0: N(a) then N(b); otherwise the slice
+    int32_t p1a[SEL_CAP];   // columns of P1[a] / P1[b] when they fit (searched by the other endpoint's nodes)
+    int32_t p1b[SEL_CAP];
+};
+
+__device__ __forceinline__ int find_lds(const int32_t *a, int n, int32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && a[lo] == key) ? lo : -1;
+}
+
+__device__ __forceinline__ int find_glb(const int32_t *__restrict__ a, int n, int32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && a[lo] == key) ? lo : -1;
+}
+
+__global__ __launch_bounds__(256) void select_nodes_indexed_kernel(
+    const int64_t *__restrict__ item_total, const ItemRec *__restrict__ items, const int64_t *__restrict__ desc,
+    const int32_t *__restrict__ adj_col, const float *__restrict__ selfp, const int64_t *__restrict__ adjx_rowptr,
+    const int32_t *__restrict__ adjx_col, int same_adj, const int32_t *__restrict__ p1_col,
+    const float *__restrict__ p1_val, const int32_t *__restrict__ t0_col, const float *__restrict__ t0_val,
+    int want_t0, float th_cn, float th_1, float th_n, const int64_t *__restrict__ stage_off,
+    int32_t *__restrict__ stage_node, float *__restrict__ stage_pa, float *__restrict__ stage_pb,
+    int32_t *__restrict__ stage_cnt) {
+    __shared__ IdxLds Ls[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    IdxLds &L = Ls[wave];
+    const int64_t n_items = *item_total;
+
+    for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < n_items; it += (int64_t)gridDim.x * 4) {
+        const ItemRec r = items[it];
+        const int64_t p = r.p;
+        const int kind = r.kind, start = r.start, len = r.len;
+        const int dA = r.dA, dB = r.dB, nPa = r.nPa, nPb = r.nPb;  // nPa/nPb, pa0/pb0: the P1 rows
+        const int64_t ra0 = r.ra0, rb0 = r.rb0, pa0 = r.pa0, pb0 = r.pb0;
+        const int64_t s = stage_off[p];
+        const bool p1a_lds = nPa <= SEL_CAP, p1b_lds = nPb <= SEL_CAP;
+
+        // ---- 1. all global reads up front: candidates with their self PPR, and the P1 columns
+        int32_t cnd[SEL_CAP / 64], ta[SEL_CAP / 64], tb[SEL_CAP / 64];
+        float sp[SEL_CAP / 64];
+        const int64_t base_s = (kind == 1 ? ra0 : rb0) + start;
+#pragma unroll
+        for (int u = 0; u < SEL_CAP / 64; ++u) {
+            cnd[u] = -1; sp[u] = 0.f; ta[u] = 0; tb[u] = 0;
+            const int i = lane + 64 * u;
+            if (64 * u < len && i < len) {
+                const int64_t e = (kind == 0) ? ((i < dA) ? ra0 + i : rb0 + (i - dA)) : base_s + i;
+                cnd[u] = adj_col[e];
+                sp[u] = selfp[e];
+            }
+            if (p1a_lds && 64 * u < nPa && i < nPa) ta[u] = p1_col[pa0 + i];
+            if (p1b_lds && 64 * u < nPb && i < nPb) tb[u] = p1_col[pb0 + i];
+        }
+        LPF_WAVE_SYNC();  // the previous item's LDS image is no longer needed
+#pragma unroll
+        for (int u = 0; u < SEL_CAP / 64; ++u) {
+            const int i = lane + 64 * u;
+            if (64 * u < len && i < len) L.cand[i] = cnd[u];
+            if (p1a_lds && 64 * u < nPa && i < nPa) L.p1a[i] = ta[u];
+            if (p1b_lds && 64 * u < nPb && i < nPb) L.p1b[i] = tb[u];
+        }
+        LPF_WAVE_SYNC();
+
+        // ---- 2. one lane per candidate: membership in the other adjacency row, then (maybe) one P1 lookup
+        int n_cn = 0, n_l1 = 0, n_l2 = 0;
+        const int64_t slot0 = s + (kind == 2 ? dA : 0) + start;
+#pragma unroll
+        for (int u = 0; u < SEL_CAP / 64; ++u) {
+            if (64 * u >= len) break;
+            const int i = lane + 64 * u;
+            int32_t code = -1;
+            bool from_a = false, cn = false, keep = false;
+            float va = 0.f, vb = 0.f;
+            if (i < len) {
+                const int32_t x = cnd[u];
+                from_a = (kind == 1) || (kind == 0 && i < dA);
+                int j;  // position of x in the other endpoint's adjacency row
+                if (kind == 0) j = from_a ? find_lds(L.cand + dA, dB, x) : find_lds(L.cand, dA, x);
+                else j = from_a ? find_glb(adj_col + rb0, dB, x) : find_glb(adj_col + ra0, dA, x);
+                if (from_a || j < 0) {  // a node of N(b) that is also in N(a) is emitted through N(a)
+                    cn = from_a && j >= 0;
+                    float other = 0.f;
+                    if (cn) {
+                        other = selfp[rb0 + j];
+                    } else if (ppr_round_trip(sp[u], false) >= th_1) {  // otherwise it is dropped anyway
+                        int idx;
+                        if (from_a) idx = p1b_lds ? find_lds(L.p1b, nPb, x) : find_glb(p1_col + pb0, nPb, x);
+                        else idx = p1a_lds ? find_lds(L.p1a, nPa, x) : find_glb(p1_col + pa0, nPa, x);
+                        if (idx >= 0) other = p1_val[(from_a ? pb0 : pa0) + idx];
+                    }
+                    va = ppr_round_trip(from_a ? sp[u] : other, cn);
+                    vb = ppr_round_trip(from_a ? other : sp[u], cn);
+                    const float th = cn ? th_cn : th_1;
+                    keep = (va >= th) && (vb >= th);
+                    if (keep) code = x | (cn ? CN_BIT : 0);
+                }
+                stage_node[slot0 + i] = code;
+                if (keep) {
+                    stage_pa[slot0 + i] = va;
+                    stage_pb[slot0 + i] = vb;
+                }
+            }
+            n_cn += __popcll(__ballot(keep && cn));
+            n_l1 += __popcll(__ballot(keep && !cn && from_a));
+            n_l2 += __popcll(__ballot(keep && !from_a));
+        }
+        if (lane == 0) {
+            if (n_cn) atomicAdd(&stage_cnt[4 * p + 0], n_cn);
+            if (n_l1) atomicAdd(&stage_cnt[4 * p + 1], n_l1);
+            if (n_l2) atomicAdd(&stage_cnt[4 * p + 2], n_l2);
+        }
+        // ---- 3. >1-hop nodes, once per pair (first item): same as select_nodes_kernel, adjacency test in LDS
+        if (want_t0 && (kind == 0 || (kind == 1 && start == 0) || (kind == 2 && start == 0 && dA == 0))) {
+            const int64_t *d = desc + p * DESC_I64;
+            const int64_t ta0 = d[4], tb0 = d[5], nTa = d[10], nTb = d[11], a = d[12], b = d[13];
+            const bool walk_a = nTa <= nTb;
+            const int64_t w0 = walk_a ? ta0 : tb0, wn = walk_a ? nTa : nTb;
+            const int64_t o0 = walk_a ? tb0 : ta0, o1 = o0 + (walk_a ? nTb : nTa);
+            const bool use_lds = (kind == 0) && same_adj;
+            int64_t xa0 = ra0, xa1 = ra0 + dA, xb0 = rb0, xb1 = rb0 + dB;
+            const int32_t *xcol = adj_col;
+            if (!same_adj) {
+                xa0 = adjx_rowptr[a]; xa1 = adjx_rowptr[a + 1]; xb0 = adjx_rowptr[b]; xb1 = adjx_rowptr[b + 1];
+                xcol = adjx_col;
+            }
+            const int64_t t0_base = s + dA + dB;
+            int n_t0 = 0;
+            for (int64_t i0 = 0; i0 < wn; i0 += 64) {
+                const int64_t i = i0 + lane;
+                int32_t v = 0;
+                bool keep = false;
+                float sa = 0.f, sb = 0.f;
+                if (i < wn) {
+                    v = t0_col[w0 + i];
+                    const float pw = t0_val[w0 + i];
+                    const float sw = __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f);
+                    if (pw > 0.f && sw >= th_n) {
+                        bool f;
+                        const float po = csr_value(t0_col, t0_val, o0, o1, v, &f);
+                        const float so = __fsub_rn(__fadd_rn(po, 1.0f), 1.0f);
+                        if (f && po > 0.f && so >= th_n) {
+                            const bool adjacent =
+                                use_lds ? (find_lds(L.cand, dA, v) >= 0 || find_lds(L.cand + dA, dB, v) >= 0)
+                                        : (csr_contains(xcol, xa0, xa1, v) || csr_contains(xcol, xb0, xb1, v));
+                            if (!adjacent) {
+                                keep = true;
+                                sa = walk_a ? sw : so;
+                                sb = walk_a ? so : sw;
+                            }
+                        }
+                    }
+                }
+                const uint64_t m = __ballot(keep);
+                if (keep) {
+                    const int64_t dst = t0_base + n_t0 + lanes_below(m, lane);
+                    stage_node[dst] = v;
+                    stage_pa[dst] = sa;
+                    stage_pb[dst] = sb;
+                }
+                n_t0 += __popcll(m);
+            }
+            if (lane == 0) stage_cnt[4 * p + 3] = n_t0;
+        }
     }
 }
 
@@ -607,8 +863,9 @@ extern "C" int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_
 }
 
 extern "C" int lpf_select_nodes(int64_t bs, int64_t item_capacity, const int64_t *offs, const int64_t *desc,
-                                int32_t *items, const int32_t *adj_col, const int64_t *adjx_rowptr,
-                                const int32_t *adjx_col, int32_t same_adj, const int32_t *ppr_col,
+                                int32_t *items, const int32_t *adj_col, const float *adj_selfp,
+                                const int64_t *adjx_rowptr, const int32_t *adjx_col, int32_t same_adj,
+                                const int32_t *ppr_col,
                                 const float *ppr_val, const int32_t *t0_col, const float *t0_val, float th_cn,
                                 float th_1hop, float th_non1hop, int32_t *stage_node, float *stage_pa, float *stage_pb,
                                 int32_t *stage_cnt, void *stream) {
@@ -623,12 +880,19 @@ extern "C" int lpf_select_nodes(int64_t bs, int64_t item_capacity, const int64_t
     const int64_t *item_off = offs + (bs + 1);
     hipLaunchKernelGGL(select_items_kernel, dim3((unsigned)((bs + 255) / 256)), dim3(256), 0, s, bs, desc, item_off,
                        reinterpret_cast<ItemRec *>(items), stage_cnt);
-    // one wavefront per block and (up to a cap) one item per block: uneven items are balanced by the dispatcher
-    const int64_t blocks = item_capacity < (1 << 20) ? item_capacity : (1 << 20);
-    hipLaunchKernelGGL(select_nodes_kernel, dim3((unsigned)blocks), dim3(64), 0, s, item_off + bs,
-                       reinterpret_cast<const ItemRec *>(items), desc, adj_col, adjx_rowptr, adjx_col, (int)same_adj,
-                       ppr_col, ppr_val, t0_col, t0_val, want_t0, th_cn, th_1hop, th_non1hop, offs, stage_node,
-                       stage_pa, stage_pb, stage_cnt);
+    // four wavefronts (= four items) per block, about one item per wavefront: uneven items are balanced by the dispatcher
+    int64_t blocks = (item_capacity + 3) / 4;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    if (adj_selfp)  // indexed fast path: ppr_col / ppr_val (and the descriptors) describe the P1 rows
+        hipLaunchKernelGGL(select_nodes_indexed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, item_off + bs,
+                           reinterpret_cast<const ItemRec *>(items), desc, adj_col, adj_selfp, adjx_rowptr, adjx_col,
+                           (int)same_adj, ppr_col, ppr_val, t0_col, t0_val, want_t0, th_cn, th_1hop, th_non1hop, offs,
+                           stage_node, stage_pa, stage_pb, stage_cnt);
+    else
+        hipLaunchKernelGGL(select_nodes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, item_off + bs,
+                           reinterpret_cast<const ItemRec *>(items), desc, adj_col, adjx_rowptr, adjx_col,
+                           (int)same_adj, ppr_col, ppr_val, t0_col, t0_val, want_t0, th_cn, th_1hop, th_non1hop, offs,
+                           stage_node, stage_pa, stage_pb, stage_cnt);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
@@ -656,8 +920,9 @@ extern "C" int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && desc && offs && stage_node && stage_pa && stage_pb && stage_cnt &&
                 type_ptr && sel_pair && sel_node && sel_pa && sel_pb);
-    const int64_t blocks = bs < 256 * 64 ? bs : 256 * 64;
-    hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream), bs,
+    int64_t blocks = (bs + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), bs,
                        desc, offs, stage_node, stage_pa, stage_pb, stage_cnt, type_ptr, sel_pair, sel_node, sel_pa,
                        sel_pb);
     LPF_CHECK_LAUNCH();

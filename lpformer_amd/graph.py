@@ -110,6 +110,36 @@ def prefilter_nonhop(ppr: CSR, thresh_non1hop: float) -> CSR:
     return CSR(rowptr, ppr.col[keep].copy(), v[keep].copy(), ppr.n)
 
 
+def prefilter_onehop(ppr: CSR, thresh_1hop: float) -> CSR:
+    """The "P1" index: PPR entries that can pass the one-hop test, fl32(fl32(p+1)-1) >= f32(theta_1)
+    (src/models/link_transformer.py:241-250 with the round trip of :290-317 for t = 1).  For theta_1 <= 0 this is the
+    whole matrix.  Selection results are identical with or without it."""
+    v = ppr.val.astype(np.float32)
+    keep = ((v + np.float32(1)) - np.float32(1)) >= np.float32(thresh_1hop)
+    rows = np.repeat(np.arange(ppr.n, dtype=np.int64), np.diff(ppr.rowptr))[keep]
+    rowptr = np.zeros(ppr.n + 1, np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    np.cumsum(rowptr, out=rowptr)
+    return CSR(rowptr, ppr.col[keep].copy(), v[keep].copy(), ppr.n)
+
+
+def self_ppr(adj: CSR, ppr: CSR) -> np.ndarray:
+    """selfp[e] = P[i, j] for every adjacency entry e = (i, j), 0 where the PPR matrix stores nothing: the PPR of a
+    node to its own neighbours, aligned with the adjacency CSR."""
+    n = adj.n
+    a_rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(adj.rowptr))
+    p_rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ppr.rowptr))
+    a_key = a_rows * n + adj.col.astype(np.int64)
+    p_key = p_rows * n + ppr.col.astype(np.int64)  # sorted: rows ascending, columns ascending inside rows
+    out = np.zeros(adj.nnz, np.float32)
+    if p_key.size:
+        idx = np.searchsorted(p_key, a_key)
+        idx[idx >= p_key.size] = p_key.size - 1
+        hit = p_key[idx] == a_key
+        out[hit] = ppr.val[idx[hit]]
+    return out
+
+
 def as_coo_numpy(obj):
     """(row, col, val|None, n) from the graph objects the reference's data dict may hold:
     torch sparse COO/CSR tensors, scipy matrices, torch_sparse.SparseTensor-like objects (``.coo()``), or CSR."""

@@ -348,6 +348,7 @@ class LinkTransformer(nn.Module):
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
         self.last_stats = {}
         self._shard = (0, 1)   # (rank, world) for the row-sharded encoder
+        self.use_select_index = True  # False: always run the general (PPR-streaming) selection kernel
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self):
@@ -382,6 +383,9 @@ class LinkTransformer(nn.Module):
         if kind == "t0":
             host = self._device_graph("ppr", obj).host
             g = graph.prefilter_nonhop(host, self.thresh_non1hop).to_device(dev)
+        elif kind == "p1":
+            host = self._device_graph("ppr", obj).host
+            g = graph.prefilter_onehop(host, self.thresh_1hop).to_device(dev)
         else:
             row, col, val, n = graph.as_coo_numpy(obj)
             if kind == "prop":
@@ -394,6 +398,15 @@ class LinkTransformer(nn.Module):
                 g = graph.csr_from_coo(row, col, val, n).to_device(dev)
         self._graphs[key] = (obj, g)
         return g
+
+    def _self_ppr(self, mask_obj, ppr_obj, adj: graph.DeviceCSR, ppr: graph.DeviceCSR) -> torch.Tensor:
+        key = ("selfp", id(mask_obj), id(ppr_obj))
+        hit = self._graphs.get(key)
+        if hit is None or hit[0] is not mask_obj:
+            t = torch.from_numpy(graph.self_ppr(adj.host, ppr.host)).to(self.device)
+            self._graphs[key] = (mask_obj, t)
+            return t
+        return hit[1]
 
     def _features(self) -> torch.Tensor:
         x = self.data["x"]
@@ -476,11 +489,18 @@ class LinkTransformer(nn.Module):
         """Runs the selection kernels; returns a dict of device arrays (type-major entries, reference order)."""
         lib, st = _lib.hip(), _stream(self.device)
         bs = batch.shape[1]
-        ppr = self._device_graph("ppr", self._data_obj("ppr", test_set))
-        adjx = self._device_graph("mask", self._data_obj("mask", test_set))
+        ppr_obj, mask_obj = self._data_obj("ppr", test_set), self._data_obj("mask", test_set)
+        ppr = self._device_graph("ppr", ppr_obj)
+        adjx = self._device_graph("mask", mask_obj)
         adj = adjx if adj_mask is None else self._device_graph("mask", adj_mask)
         want_t0 = self.mask == "all"
-        t0 = self._device_graph("t0", self._data_obj("ppr", test_set)) if want_t0 else None
+        t0 = self._device_graph("t0", ppr_obj) if want_t0 else None
+        # Evaluation fast path: per-model indexes over the PPR matrix (self PPR aligned with the adjacency, one-hop
+        # prefiltered rows).  A caller-supplied adjacency override (training) takes the general kernel instead.
+        selfp = None
+        if adj is adjx and self.use_select_index:
+            selfp = self._self_ppr(mask_obj, ppr_obj, adjx, ppr)
+            ppr = self._device_graph("p1", ppr_obj)
 
         offs = self._workspace("select_offs", 2 * (bs + 1), torch.int64)
         desc = self._workspace("select_desc", 16 * bs, torch.int64)
@@ -497,8 +517,9 @@ class LinkTransformer(nn.Module):
         stage_cnt = self._workspace("stage_cnt", 4 * bs, torch.int32)
         items = self._workspace("select_items", 16 * n_items, torch.int32)
         with KernelTimer.span("select_nodes"):
-            check(lib.lpf_select_nodes(bs, n_items, ptr(offs), ptr(desc), ptr(items), ptr(adj.col), ptr(adjx.rowptr),
-                                       ptr(adjx.col), 1 if adj is adjx else 0, ptr(ppr.col), ptr(ppr.val),
+            check(lib.lpf_select_nodes(bs, n_items, ptr(offs), ptr(desc), ptr(items), ptr(adj.col), ptr(selfp),
+                                       ptr(adjx.rowptr), ptr(adjx.col), 1 if adj is adjx else 0, ptr(ppr.col),
+                                       ptr(ppr.val),
                                        ptr(t0.col) if want_t0 else None, ptr(t0.val) if want_t0 else None,
                                        float(self.thresh_cn), float(self.thresh_1hop), float(self.thresh_non1hop),
                                        ptr(stage_node), ptr(stage_pa), ptr(stage_pb), ptr(stage_cnt), st),

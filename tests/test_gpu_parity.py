@@ -51,9 +51,11 @@ def _err(a, b):
 
 
 @pytest.mark.parametrize("case", LP_CASES)
-def test_selection_bit_exact_vs_reference(case):
+@pytest.mark.parametrize("indexed", [True, False])  # indexed fast path and general PPR-streaming kernel
+def test_selection_bit_exact_vs_reference(case, indexed):
     fx = Fixture(case)
     model, _ = _build(fx)
+    model.use_select_index = indexed
     infos = model.compute_node_mask(torch.from_numpy(fx["batch"]), test_set=fx.test_set)
     for tag, info in zip(("cn", "onehop", "non1hop"), infos):
         if f"sel_{tag}_ix" not in fx:
@@ -117,11 +119,16 @@ def test_vs_oracle_on_fresh_inputs():
     feats = model(torch.from_numpy(batch))
     assert _err(feats.cpu(), ref["combined_feats"]) <= TOL
     assert _err(score.logits(feats).cpu(), ref["logit"]) <= TOL
-    infos = model.compute_node_mask(torch.from_numpy(batch))
-    for tag, info in zip(("cn", "onehop", "non1hop"), infos):
-        np.testing.assert_array_equal(info[0].cpu().numpy(), ref["sel"][tag][0])
-        np.testing.assert_array_equal(info[1].cpu().numpy().view(np.uint32), ref["sel"][tag][1].view(np.uint32))
-        np.testing.assert_array_equal(info[2].cpu().numpy().view(np.uint32), ref["sel"][tag][2].view(np.uint32))
+    for indexed in (True, False):
+        model.use_select_index = indexed
+        infos = model.compute_node_mask(torch.from_numpy(batch))
+        for tag, info in zip(("cn", "onehop", "non1hop"), infos):
+            np.testing.assert_array_equal(info[0].cpu().numpy(), ref["sel"][tag][0])
+            np.testing.assert_array_equal(info[1].cpu().numpy().view(np.uint32), ref["sel"][tag][1].view(np.uint32))
+            np.testing.assert_array_equal(info[2].cpu().numpy().view(np.uint32), ref["sel"][tag][2].view(np.uint32))
+    # a caller-supplied adjacency override (the training loop's masked adjacency) takes the general kernel
+    infos = model.compute_node_mask(torch.from_numpy(batch), adj=d["adj_mask"].to_torch_sparse_coo())
+    np.testing.assert_array_equal(infos[1][0].cpu().numpy(), ref["sel"]["onehop"][0])
     # size-independent properties: permuting the batch permutes the scores; swapping (a,b) leaves them unchanged
     perm = torch.randperm(batch.shape[1])
     s0 = score.logits(feats)
