@@ -157,9 +157,11 @@ extern "C" int lpf_gemm_f32(int64_t M, int32_t N, int32_t K, const float *A, int
     LPF_REQUIRE(!addend || ldadd >= N);
     LPF_REQUIRE((M + BM - 1) / BM < (1ll << 31));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // pick the column tile that wastes fewer padded columns
+    // Column tile: the one that wastes fewer padded columns; and for small problems the narrow tile, so that the grid
+    // has at least two workgroups per CU -- one wavefront per SIMD issues this MFMA at half rate.
     const int pad128 = ((N + 127) / 128) * 128 - N, pad64 = ((N + 63) / 64) * 64 - N;
-    if (pad64 < pad128) {
+    const int64_t blocks128 = ((M + BM - 1) / BM) * ((N + 127) / 128);
+    if (pad64 < pad128 || blocks128 < 2 * 256) {
         dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + 63) / 64));
         hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, s, M, N, K, A, lda, W, ldw, bias, addend, ldadd,
                            C, ldc, flags);

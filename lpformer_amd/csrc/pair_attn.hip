@@ -37,15 +37,92 @@ __device__ __forceinline__ float pe_hidden(const float4 k, float pa, float pb, f
     return fmaxf(fmaf(r_ab, u_ab, k.w), 0.0f) + fmaxf(fmaf(r_ba, u_ba, k.w), 0.0f);
 }
 
+// One tile of 32 same-type entries handled by one wavefront.  `wp` points at this lane's slice of the packed
+// Wfold_t image (global memory or the workgroup's LDS copy): wp[(c*NSQ + sq)*64] is the A operand of step group sq for
+// output-feature tile c.
 template <int NT>
-__global__ __launch_bounds__(256) void pair_scores_kernel(
+__device__ __forceinline__ void pair_scores_tile(
+    int t, int64_t e, bool valid, int lh, const float4 *wp, const float4 *tab, const int32_t *__restrict__ sel_pair,
+    const int32_t *__restrict__ sel_node, const float *__restrict__ sel_pa, const float *__restrict__ sel_pb,
+    const float *__restrict__ Z, int64_t ldz, const float *__restrict__ q, int64_t ldq,
+    const float *__restrict__ pe_stat, const float *__restrict__ bfold, const float *__restrict__ att,
+    float *__restrict__ score) {
+    constexpr int D = 32 * NT;
+    constexpr int NSQ = D / 8;  // groups of 4 MFMA steps (each step consumes 2 values of k)
+    const float pa = valid ? sel_pa[e] : 0.f, pb = valid ? sel_pb[e] : 0.f;
+    const int32_t node = valid ? sel_node[e] : 0, pr = valid ? sel_pair[e] : 0;
+
+    PeStat st;
+    st.c00 = pe_stat[8 * t + 0]; st.c11 = pe_stat[8 * t + 1]; st.cbb = pe_stat[8 * t + 2];
+    st.c01 = pe_stat[8 * t + 3]; st.c0b = pe_stat[8 * t + 4]; st.c1b = pe_stat[8 * t + 5];
+    const float r_ab = pe_rstd(st, pa, pb), r_ba = pe_rstd(st, pb, pa);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    const float4 *tb = tab + t * D + lh * (D / 2);
+    // No software prefetch of the A operands: one wavefront alone issues this MFMA at half rate (measured: 130
+    // cycles per v_mfma_f32_32x32x2_f32 from one wave, 67 from two), so the kernel is built for >= 3 resident waves per
+    // SIMD and lets the other waves cover the operand latency; registers are spent on occupancy instead.
+#pragma unroll 1
+    for (int sq = 0; sq < NSQ; ++sq) {
+        float4 wa[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) wa[c] = wp[(c * NSQ + sq) * 64];
+        float h[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h[u] = pe_hidden(tb[4 * sq + u], pa, pb, r_ab, r_ba);
+        // consecutive MFMAs go to different accumulators (no back-to-back dependency on one accumulator)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].x, h[0], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].y, h[1], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].z, h[2], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].w, h[3], acc[c], 0, 0, 0);
+    }
+    // acc[c][4g+u] = (Wfold_t h_e)[feature 32c + 8g + 4*lh + u] for entry lj
+    const float *zrow = Z + (int64_t)node * ldz;
+    const float *qrow = q + (int64_t)pr * ldq;
+    const float *bf = bfold + t * D;
+    float part = 0.f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 32 * c + 8 * g + 4 * lh;
+            const float4 z4 = *reinterpret_cast<const float4 *>(zrow + f0);
+            const float4 q4 = *reinterpret_cast<const float4 *>(qrow + f0);
+            const float4 b4 = *reinterpret_cast<const float4 *>(bf + f0);
+            const float4 a4 = *reinterpret_cast<const float4 *>(att + f0);
+            const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float x = (acc[c][4 * g + u] + zz[u] + bb[u]) * qq[u];
+                x = x > 0.f ? x : 0.2f * x;
+                part = fmaf(x, aa[u], part);
+            }
+        }
+    }
+    part += __shfl_xor(part, 32, 64);
+    if (valid && lh == 0) score[e] = part;
+}
+
+// Wfold streamed from global memory / L2 (used when the packed image of one type does not fit LDS: D = 256).
+template <int NT>
+__global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void pair_scores_kernel(
     const int64_t *__restrict__ type_ptr, int64_t bs, const int32_t *__restrict__ sel_pair,
     const int32_t *__restrict__ sel_node, const float *__restrict__ sel_pa, const float *__restrict__ sel_pb,
     const float *__restrict__ Z, int64_t ldz, const float *__restrict__ q, int64_t ldq,
     const float *__restrict__ pe_tab, const float *__restrict__ pe_stat, const float *__restrict__ wpk,
     const float *__restrict__ bfold, const float *__restrict__ att, float *__restrict__ score) {
     constexpr int D = 32 * NT;
-    constexpr int NSQ = D / 8;  // groups of 4 MFMA steps (each step consumes 2 values of k)
+    constexpr int NSQ = D / 8;
     __shared__ float4 tab[3 * D];
     for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) tab[i] = reinterpret_cast<const float4 *>(pe_tab)[i];
     __syncthreads();
@@ -64,71 +141,9 @@ __global__ __launch_bounds__(256) void pair_scores_kernel(
         else if (tile < t0 + t1) { t = 1; idx = tile - t0; base = n0; cnt = n1; }
         else { t = 2; idx = tile - t0 - t1; base = n0 + n1; cnt = n2; }
         const int64_t within = idx * 32 + lj;
-        const bool valid = within < cnt;
-        const int64_t e = base + within;
-        const float pa = valid ? sel_pa[e] : 0.f, pb = valid ? sel_pb[e] : 0.f;
-        const int32_t node = valid ? sel_node[e] : 0, pr = valid ? sel_pair[e] : 0;
-
-        PeStat st;
-        st.c00 = pe_stat[8 * t + 0]; st.c11 = pe_stat[8 * t + 1]; st.cbb = pe_stat[8 * t + 2];
-        st.c01 = pe_stat[8 * t + 3]; st.c0b = pe_stat[8 * t + 4]; st.c1b = pe_stat[8 * t + 5];
-        const float r_ab = pe_rstd(st, pa, pb), r_ba = pe_rstd(st, pb, pa);
-
-        f32x16 acc[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-
         const float4 *wp = reinterpret_cast<const float4 *>(wpk) + (int64_t)t * NT * NSQ * 64 + lane;
-        const float4 *tb = tab + t * D + lh * (D / 2);
-        float4 wa[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) wa[c] = wp[(c * NSQ) * 64];
-        for (int sq = 0; sq < NSQ; ++sq) {
-            float4 wn[NT];  // next step group's A operands: in flight while this group's MFMAs issue
-            const int sqn = (sq + 1 < NSQ) ? sq + 1 : sq;
-#pragma unroll
-            for (int c = 0; c < NT; ++c) wn[c] = wp[(c * NSQ + sqn) * 64];
-            float h[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) h[u] = pe_hidden(tb[4 * sq + u], pa, pb, r_ab, r_ba);
-#pragma unroll
-            for (int c = 0; c < NT; ++c) {
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].x, h[0], acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].y, h[1], acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].z, h[2], acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].w, h[3], acc[c], 0, 0, 0);
-            }
-#pragma unroll
-            for (int c = 0; c < NT; ++c) wa[c] = wn[c];
-        }
-        // acc[c][4g+u] = (Wfold_t h_e)[feature 32c + 8g + 4*lh + u] for entry lj
-        const float *zrow = Z + (int64_t)node * ldz;
-        const float *qrow = q + (int64_t)pr * ldq;
-        const float *bf = bfold + t * D;
-        float part = 0.f;
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f0 = 32 * c + 8 * g + 4 * lh;
-                const float4 z4 = *reinterpret_cast<const float4 *>(zrow + f0);
-                const float4 q4 = *reinterpret_cast<const float4 *>(qrow + f0);
-                const float4 b4 = *reinterpret_cast<const float4 *>(bf + f0);
-                const float4 a4 = *reinterpret_cast<const float4 *>(att + f0);
-                const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
-                const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float x = (acc[c][4 * g + u] + zz[u] + bb[u]) * qq[u];
-                    x = x > 0.f ? x : 0.2f * x;
-                    part = fmaf(x, aa[u], part);
-                }
-            }
-        }
-        part += __shfl_xor(part, 32, 64);
-        if (valid && lh == 0) score[e] = part;
+        pair_scores_tile<NT>(t, base + within, within < cnt, lh, wp, tab, sel_pair, sel_node, sel_pa, sel_pb, Z, ldz, q,
+                             ldq, pe_stat, bfold, att, score);
     }
 }
 
@@ -382,7 +397,7 @@ extern "C" int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t b
     // the entry count lives on the device; size the grid from the host-side capacity and let waves stride over tiles
     int64_t tiles = (max_entries + 31) / 32 + 3;
     int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks > 256 * 16) blocks = 256 * 16;
 #define LPF_SCORES_LAUNCH(NT)                                                                                      \
     hipLaunchKernelGGL(pair_scores_kernel<NT>, dim3((unsigned)blocks), dim3(256), 0, s, type_ptr, bs, sel_pair,    \
                        sel_node, sel_pa, sel_pb, Z, ldz, q, ldq, pe_tab, pe_stat, wfold_packed, bfold, att, score)
