@@ -62,11 +62,15 @@ int lpf_gcn_norm_csr(int64_t n, const int64_t *rowptr, const int32_t *col, const
  * (other_models.py:66-74 and, for the last layer, link_transformer.py:127):
  *   y = acc + bias;  if ln_g: y = LN(y; ln_g, ln_b);  if RELU: y = max(y,0);
  *   if residual: y = residual[i,:] + y;  if ln2_g: y = LN(y; ln2_g, ln2_b)
- * D % 4 == 0, D <= 256.  bias, ln_g, ln_b, residual, ln2_g, ln2_b may each be NULL. */
+ * D % 4 == 0, D <= 256.  bias, ln_g, ln_b, residual, ln2_g, ln2_b may each be NULL.
+ * long_rows (optional, NULL/0 = none): int32[n_long] list of EVERY row with more than LPF_SPMM_LONG_ROW stored entries
+ * (row ids relative to `rowptr`); those hub rows get a whole workgroup each instead of one lane group. */
+#define LPF_SPMM_LONG_ROW 128
 int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
                      const float *H, int64_t ldh, float *out, int64_t ldo, const float *bias,
                      const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
-                     const float *ln2_g, const float *ln2_b, uint32_t flags, void *stream);
+                     const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *long_rows,
+                     int64_t n_long, void *stream);
 
 /* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ addend[M,N]) (ReLU)   -- nn.Linear / PyG Linear:
  * GCNConv.lin (other_models.py:66), lin_l / node half of lin_r (src/modules/layers.py:206-214),

@@ -23,7 +23,7 @@ HIP_PROTOTYPES = {
     "lpf_last_hip_error": [],
     "lpf_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "lpf_gcn_norm_csr": [i64, vp, vp, vp, vp, vp, vp],
-    "lpf_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp],
+    "lpf_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],
     "lpf_gemm_f32": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
     "lpf_layernorm_f32": [i64, i32, vp, i64, vp, vp, vp, i64, u32, vp],
     "lpf_pair_gather_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp],

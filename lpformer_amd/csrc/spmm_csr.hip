@@ -30,6 +30,73 @@ __device__ __forceinline__ float4 group_layernorm(float4 y, bool act, int D, con
     return y;
 }
 
+constexpr int SPMM_LONG = 128;  // rows with more stored entries than this are left to spmm_long_rows_kernel
+
+// acc += sum over edges [e0, e1) taken in chunks of G starting at e0 + first_chunk*G with stride chunk_stride*G:
+// a chunk is one coalesced (col, weight) read by the group, then lane-by-lane broadcasts with four 16-byte neighbour
+// gathers in flight.
+template <int G>
+__device__ __forceinline__ void spmm_accumulate(float4 &acc, int64_t e0, int64_t e1, int first_chunk, int chunk_stride,
+                                                const int32_t *__restrict__ col, const float *__restrict__ w,
+                                                const float *__restrict__ H, int64_t ldh, int off, bool act, int gbase,
+                                                int lig) {
+    for (int64_t e = e0 + (int64_t)first_chunk * G; e < e1; e += (int64_t)chunk_stride * G) {
+        const int64_t mine = e + lig;
+        int32_t c = 0;
+        float wv = 0.f;
+        if (mine < e1) {
+            c = col[mine];
+            wv = w[mine];
+        }
+        const int cnt = (int)((e1 - e) < G ? (e1 - e) : G);
+        for (int t = 0; t < cnt; t += 4) {  // lanes past `cnt` carry (col 0, weight 0): harmless gathers
+            int32_t cc[4];
+            float ww[4];
+            float4 h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cc[u] = __shfl(c, gbase + ((t + u) & (G - 1)), 64);
+                ww[u] = __shfl(wv, gbase + ((t + u) & (G - 1)), 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                h[u] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x = fmaf(ww[u], h[u].x, acc.x);
+                acc.y = fmaf(ww[u], h[u].y, acc.y);
+                acc.z = fmaf(ww[u], h[u].z, acc.z);
+                acc.w = fmaf(ww[u], h[u].w, acc.w);
+            }
+        }
+    }
+}
+
+// fused epilogue (GCN.forward lines after conv(); propagate's gnn_norm for the last layer); result stored by the group
+template <int G>
+__device__ __forceinline__ void spmm_epilogue(float4 y, int64_t row, bool live, bool act, int D, int off,
+                                              float *__restrict__ out, int64_t ldo, const float *__restrict__ bias,
+                                              const float *__restrict__ ln_g, const float *__restrict__ ln_b,
+                                              const float *__restrict__ residual, int64_t ldr,
+                                              const float *__restrict__ ln2_g, const float *__restrict__ ln2_b,
+                                              uint32_t flags) {
+    if (bias && act) {
+        const float4 bv = *reinterpret_cast<const float4 *>(bias + off);
+        y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+    }
+    if (ln_g) y = group_layernorm<G>(y, act, D, ln_g, ln_b, off);
+    if (flags & LPF_FLAG_RELU) {
+        y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+    }
+    if (residual && act && live) {
+        const float4 rv = *reinterpret_cast<const float4 *>(residual + row * ldr + off);
+        y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
+    }
+    if (ln2_g) y = group_layernorm<G>(y, act, D, ln2_g, ln2_b, off);
+    if (act && live) *reinterpret_cast<float4 *>(out + row * ldo + off) = y;
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const int64_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ col, const float *__restrict__ w,
@@ -39,7 +106,8 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const i
                                                        const float *__restrict__ ln_b,
                                                        const float *__restrict__ residual, int64_t ldr,
                                                        const float *__restrict__ ln2_g,
-                                                       const float *__restrict__ ln2_b, uint32_t flags) {
+                                                       const float *__restrict__ ln2_b, uint32_t flags,
+                                                       int skip_long) {
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int grp = lane / G, lig = lane % G;
@@ -51,60 +119,51 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const i
 
     for (int64_t row0 = wave_id * RPW; row0 < n; row0 += n_waves * RPW) {
         const int64_t row = row0 + grp;
-        const bool live = row < n;
+        bool live = row < n;
         int64_t e0 = 0, e1 = 0;
         if (live) {
             e0 = rowptr[row];
             e1 = rowptr[row + 1];
         }
+        if (skip_long && e1 - e0 > SPMM_LONG) {  // a hub row would hold this group for a long time
+            live = false;
+            e1 = e0;
+        }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t e = e0; e < e1; e += G) {
-            const int64_t mine = e + lig;
-            int32_t c = 0;
-            float wv = 0.f;
-            if (mine < e1) {
-                c = col[mine];
-                wv = w[mine];
-            }
-            const int cnt = (int)((e1 - e) < G ? (e1 - e) : G);
-            for (int t = 0; t < cnt; t += 4) {  // lanes past `cnt` carry (col 0, weight 0): harmless gathers
-                int32_t cc[4];
-                float ww[4];
-                float4 h[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    cc[u] = __shfl(c, gbase + ((t + u) & (G - 1)), 64);
-                    ww[u] = (t + u < G) ? __shfl(wv, gbase + ((t + u) & (G - 1)), 64) : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    h[u] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc.x = fmaf(ww[u], h[u].x, acc.x);
-                    acc.y = fmaf(ww[u], h[u].y, acc.y);
-                    acc.z = fmaf(ww[u], h[u].z, acc.z);
-                    acc.w = fmaf(ww[u], h[u].w, acc.w);
-                }
-            }
+        spmm_accumulate<G>(acc, e0, e1, 0, 1, col, w, H, ldh, off, act, gbase, lig);
+        spmm_epilogue<G>(acc, row, live, act, D, off, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags);
+    }
+}
+
+// Hub rows (more than SPMM_LONG entries): one 256-thread workgroup per row.  The NG = 256/G lane groups take chunks of
+// G edges round-robin, their partial sums meet in LDS and are added in group order (deterministic), then group 0 runs
+// the same fused epilogue.
+template <int G>
+__global__ __launch_bounds__(256) void spmm_long_rows_kernel(
+    const int32_t *__restrict__ long_rows, int D, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ w, const float *__restrict__ H, int64_t ldh, float *__restrict__ out, int64_t ldo,
+    const float *__restrict__ bias, const float *__restrict__ ln_g, const float *__restrict__ ln_b,
+    const float *__restrict__ residual, int64_t ldr, const float *__restrict__ ln2_g, const float *__restrict__ ln2_b,
+    uint32_t flags) {
+    constexpr int NG = 256 / G;
+    __shared__ float4 part[NG][G];
+    const int tid = threadIdx.x, grp = tid / G, lig = tid % G;
+    const int gbase = ((tid & 63) / G) * G;
+    const int off = 4 * lig;
+    const bool act = off < D;
+    const int64_t row = long_rows[blockIdx.x];
+    const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    spmm_accumulate<G>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
+    part[grp][lig] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float4 y = part[0][lig];
+        for (int g = 1; g < NG; ++g) {
+            const float4 v = part[g][lig];
+            y.x += v.x; y.y += v.y; y.z += v.z; y.w += v.w;
         }
-        // ---- fused epilogue (GCN.forward lines after conv(); propagate's gnn_norm for the last layer)
-        float4 y = acc;
-        if (bias && act) {
-            const float4 bv = *reinterpret_cast<const float4 *>(bias + off);
-            y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
-        }
-        if (ln_g) y = group_layernorm<G>(y, act, D, ln_g, ln_b, off);
-        if (flags & LPF_FLAG_RELU) {
-            y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
-        }
-        if (residual && act && live) {
-            const float4 rv = *reinterpret_cast<const float4 *>(residual + row * ldr + off);
-            y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
-        }
-        if (ln2_g) y = group_layernorm<G>(y, act, D, ln2_g, ln2_b, off);
-        if (act && live) *reinterpret_cast<float4 *>(out + row * ldo + off) = y;
+        spmm_epilogue<G>(y, row, true, act, D, off, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags);
     }
 }
 
@@ -149,8 +208,10 @@ extern "C" int lpf_gcn_norm_csr(int64_t n, const int64_t *rowptr, const int32_t 
 extern "C" int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
                                 const float *H, int64_t ldh, float *out, int64_t ldo, const float *bias,
                                 const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
-                                const float *ln2_g, const float *ln2_b, uint32_t flags, void *stream) {
+                                const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *long_rows,
+                                int64_t n_long, void *stream) {
     if (n == 0) return LPF_OK;
+    LPF_REQUIRE(n_long >= 0 && (n_long == 0 || long_rows) && n_long < (1ll << 31));
     LPF_REQUIRE(n > 0 && rowptr && col && w && H && out);
     if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
     LPF_REQUIRE(ldh >= D && ldo >= D && (ldh & 3) == 0 && (ldo & 3) == 0 && lpf_aligned16(H) && lpf_aligned16(out));
@@ -163,8 +224,14 @@ extern "C" int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, con
     int64_t blocks = (n + 4 * rpw - 1) / (4 * rpw);
     if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond ~32 blocks per CU
 #define LPF_SPMM_LAUNCH(GG)                                                                                        \
-    hipLaunchKernelGGL(spmm_csr_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr, col, w, H, ldh, \
-                       out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags)
+    do {                                                                                                           \
+        hipLaunchKernelGGL(spmm_csr_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr, col, w, H,  \
+                           ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags, long_rows ? 1 : 0); \
+        if (n_long > 0)                                                                                            \
+            hipLaunchKernelGGL(spmm_long_rows_kernel<GG>, dim3((unsigned)n_long), dim3(256), 0, s, long_rows, D,   \
+                               rowptr, col, w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b,    \
+                               flags);                                                                             \
+    } while (0)
     if (G == 16) LPF_SPMM_LAUNCH(16);
     else if (G == 32) LPF_SPMM_LAUNCH(32);
     else LPF_SPMM_LAUNCH(64);

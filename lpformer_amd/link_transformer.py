@@ -450,6 +450,7 @@ class LinkTransformer(nn.Module):
             n_layers = len(enc.convs)
             rank, world = self._shard
             lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
+            long_rows = self._long_rows(a_hat, lo, hi)
             for i, conv in enumerate(enc.convs):
                 # dense transform of ALL rows (cheap, replicated), aggregation of the local row block only
                 t = gemm(x, self._conv_pads[i].get(conv.lin.weight), tag="gemm_encoder")
@@ -465,11 +466,23 @@ class LinkTransformer(nn.Module):
                         ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
                         ptr(res), 0 if res is None else res.stride(0),
                         ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
-                        FLAG_RELU if enc.relu else 0, st), "lpf_spmm_csr_f32")
+                        FLAG_RELU if enc.relu else 0, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
+                        st), "lpf_spmm_csr_f32")
                 # every rank needs the full layer output for the next neighbour gather; the last of these
                 # collectives is the all-gather of node embeddings (RCCL over xGMI)
                 x = lpf_dist.allgather_rows(out, self.num_nodes) if world > 1 else out
             return x
+
+    def _long_rows(self, a_hat: graph.DeviceCSR, lo: int, hi: int):
+        """Hub rows (> LPF_SPMM_LONG_ROW entries) of the local row block, as row ids relative to `lo` (cached)."""
+        key = ("long_rows", id(a_hat), lo, hi)
+        hit = self._graphs.get(key)
+        if hit is None:
+            deg = (a_hat.rowptr[lo + 1:hi + 1] - a_hat.rowptr[lo:hi])
+            rows = torch.nonzero(deg > 128).flatten().to(torch.int32)
+            hit = (a_hat, rows if rows.numel() else None)
+            self._graphs[key] = hit
+        return hit[1]
 
     def set_row_shard(self, rank: int, world: int):
         """Row-shard the encoder across `world` ranks of the default process group (see lpformer_amd/dist.py)."""

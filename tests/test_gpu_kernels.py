@@ -56,26 +56,31 @@ def test_spmm_fused_epilogue(d):
     res = rng.standard_normal((n, d)).astype(np.float32)
     bias, g1, b1, g2, b2 = (rng.standard_normal(d).astype(np.float32) for _ in range(5))
     t = lambda v: torch.from_numpy(v).to(DEV)  # noqa: E731
+    deg = a_hat.rowptr[1:] - a_hat.rowptr[:-1]
+    hubs = torch.nonzero(deg > 128).flatten().to(torch.int32)
+    assert hubs.numel() >= 1
     for use_ln, relu, use_res, use_ln2 in [(True, True, True, True), (False, False, False, False),
                                            (True, False, False, True), (False, True, True, False)]:
-        out = torch.empty(n, d, device=DEV)
-        th, tr = t(h), t(res)
-        args = [t(bias), t(g1) if use_ln else None, t(b1) if use_ln else None, tr if use_res else None,
-                t(g2) if use_ln2 else None, t(b2) if use_ln2 else None]
-        _lib.check(_lib.hip().lpf_spmm_csr_f32(
-            n, d, a_hat.rowptr.data_ptr(), a_hat.col.data_ptr(), a_hat.val.data_ptr(), th.data_ptr(), d,
-            out.data_ptr(), d, args[0].data_ptr(), _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(args[3]), d,
-            _lib.ptr(args[4]), _lib.ptr(args[5]), 1 if relu else 0, torch.cuda.current_stream().cuda_stream))
-        y = O.spmm(ref_rp, ref_col, ref_val, h) + bias
-        if use_ln:
-            y = O.layer_norm(y, g1, b1)
-        if relu:
-            y = np.maximum(y, 0)
-        if use_res:
-            y = res + y
-        if use_ln2:
-            y = O.layer_norm(y, g2, b2)
-        assert np.abs(out.cpu().numpy() - y).max() <= 5e-5
+      for long_rows in (None, hubs):  # without and with the hub-row kernel
+          out = torch.empty(n, d, device=DEV)
+          th, tr = t(h), t(res)
+          args = [t(bias), t(g1) if use_ln else None, t(b1) if use_ln else None, tr if use_res else None,
+                  t(g2) if use_ln2 else None, t(b2) if use_ln2 else None]
+          _lib.check(_lib.hip().lpf_spmm_csr_f32(
+              n, d, a_hat.rowptr.data_ptr(), a_hat.col.data_ptr(), a_hat.val.data_ptr(), th.data_ptr(), d,
+              out.data_ptr(), d, args[0].data_ptr(), _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(args[3]), d,
+              _lib.ptr(args[4]), _lib.ptr(args[5]), 1 if relu else 0, _lib.ptr(long_rows),
+              0 if long_rows is None else long_rows.numel(), torch.cuda.current_stream().cuda_stream))
+          y = O.spmm(ref_rp, ref_col, ref_val, h) + bias
+          if use_ln:
+              y = O.layer_norm(y, g1, b1)
+          if relu:
+              y = np.maximum(y, 0)
+          if use_res:
+              y = res + y
+          if use_ln2:
+              y = O.layer_norm(y, g2, b2)
+          assert np.abs(out.cpu().numpy() - y).max() <= 5e-5
 
 
 @pytest.mark.parametrize("d", [3, 64, 132, 260, 1000])
