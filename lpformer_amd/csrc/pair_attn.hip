@@ -113,9 +113,10 @@ __device__ __forceinline__ void pair_scores_tile(
     if (valid && lh == 0) score[e] = part;
 }
 
-// Wfold streamed from global memory / L2 (used when the packed image of one type does not fit LDS: D = 256).
+// Wfold streamed from global memory / L2 (packed image, L2-resident).  Register budget: 3 waves per SIMD without
+// spilling for D <= 128 (a 4-wave budget spills ~150 MB per launch to scratch: measured slower).
 template <int NT>
-__global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void pair_scores_kernel(
+__global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void pair_scores_kernel(
     const int64_t *__restrict__ type_ptr, int64_t bs, const int32_t *__restrict__ sel_pair,
     const int32_t *__restrict__ sel_node, const float *__restrict__ sel_pa, const float *__restrict__ sel_pb,
     const float *__restrict__ Z, int64_t ldz, const float *__restrict__ q, int64_t ldq,
