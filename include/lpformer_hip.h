@@ -175,11 +175,12 @@ int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t bs, const in
  *   G[k, 0:D]   = sum_e alpha_e Z[node_e]
  *   G[k, (1+t)D : (2+t)D] = sum_{e of type t} alpha_e h_e          t = 0,1,2
  *   G[k, 4D + t] = sum_{e of type t} alpha_e ;  G[k, 4D+3] = 1
- * alpha_out (optional, NULL to skip): alpha per entry in the sel_* order (return_weights path, layers.py:73-75). */
+ * alpha_out (optional, NULL to skip): alpha per entry in the sel_* order (return_weights path, layers.py:73-75).
+ * heavy_scratch: int32[bs+1] scratch (list of the pairs with many selected nodes, handled by a second kernel). */
 int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, const int32_t *sel_node,
                                 const float *sel_pa, const float *sel_pb, const float *score,
                                 const float *Z, int64_t ldz, const float *pe_tab, const float *pe_stat,
-                                float *G, int64_t ldg, float *alpha_out, void *stream);
+                                float *G, int64_t ldg, float *alpha_out, int32_t *heavy_scratch, void *stream);
 
 /* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
  * logit or prob may be NULL. */

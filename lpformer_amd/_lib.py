@@ -32,7 +32,7 @@ HIP_PROTOTYPES = {
     "lpf_select_scan": [i64, vp, vp, vp, i64, i32, vp, vp],
     "lpf_select_compact": [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
-    "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp],
+    "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp],
     "lpf_rowdot_sigmoid_f32": [i64, i32, vp, i64, vp, f32, vp, vp, vp],
 }
 HOST_PROTOTYPES = {

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
     int D, int64_t bs, const int64_t *__restrict__ type_ptr, const int32_t *__restrict__ sel_node,
     const float *__restrict__ sel_pa, const float *__restrict__ sel_pb, const float *__restrict__ score,
     const float *__restrict__ Z, int64_t ldz, const float *__restrict__ pe_tab, const float *__restrict__ pe_stat,
-    float *__restrict__ Gout, int64_t ldg, float *__restrict__ alpha_out) {
+    float *__restrict__ Gout, int64_t ldg, float *__restrict__ alpha_out, int32_t *__restrict__ heavy) {
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int grp = lane / G, lig = lane % G, gbase = grp * G;
@@ -226,8 +226,11 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
         }
         // pairs with many selected nodes would serialise one lane group for a long time: they are left to
         // pair_softmax_gather_heavy_kernel (a whole workgroup per pair)
-        const bool heavy = cnt[0] + cnt[1] + cnt[2] > SG_HEAVY;
-        if (heavy) cnt[0] = cnt[1] = cnt[2] = 0;
+        const bool is_heavy = cnt[0] + cnt[1] + cnt[2] > SG_HEAVY;
+        if (is_heavy) {
+            if (lig == 0) heavy[1 + atomicAdd(&heavy[0], 1)] = (int32_t)p;  // any order: pairs are independent
+            cnt[0] = cnt[1] = cnt[2] = 0;
+        }
         // segment softmax statistics over all of the pair's entries (PyG softmax: shift by max, denom + 1e-16)
         float m = -INFINITY;
 #pragma unroll
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_kernel(
                 sg_chunk<G>(st, k, act, off, gbase, lig, cnt[t] - base, beg[t] + base, m, den, sel_node, sel_pa, sel_pb,
                             score, Z, ldz, alpha_out, accz, acch[t], asum[t]);
         }
-        if (live && !heavy) {
+        if (live && !is_heavy) {
             float *g = Gout + p * ldg;
             if (act) {
                 *reinterpret_cast<float4 *>(g + off) = accz;
@@ -282,13 +285,15 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_heavy_kernel(
     int D, int64_t bs, const int64_t *__restrict__ type_ptr, const int32_t *__restrict__ sel_node,
     const float *__restrict__ sel_pa, const float *__restrict__ sel_pb, const float *__restrict__ score,
     const float *__restrict__ Z, int64_t ldz, const float *__restrict__ pe_tab, const float *__restrict__ pe_stat,
-    float *__restrict__ Gout, int64_t ldg, float *__restrict__ alpha_out) {
+    float *__restrict__ Gout, int64_t ldg, float *__restrict__ alpha_out, const int32_t *__restrict__ heavy) {
     constexpr int NG = 256 / G;
     __shared__ float red[256];
     __shared__ float part[NG][4 * 4 * G + 4];  // per group: accz | acch[0..2] (4G floats each) | asum[0..2]
-    const int64_t p = blockIdx.x;
     const int64_t tot0 = type_ptr[bs], tot1 = type_ptr[(bs + 1) + bs];
     const int64_t tbase[3] = {0, tot0, tot0 + tot1};
+    const int n_heavy = heavy[0];
+  for (int hidx = blockIdx.x; hidx < n_heavy; hidx += gridDim.x) {  // list written by the light kernel
+    const int64_t p = heavy[1 + hidx];
     int64_t beg[3];
     int cnt[3];
 #pragma unroll
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_heavy_kernel(
         beg[t] = tbase[t] + lo;
         cnt[t] = (int)(hi - lo);
     }
-    if (cnt[0] + cnt[1] + cnt[2] <= SG_HEAVY) return;
+    __syncthreads();  // LDS reuse across list entries
     const int tid = threadIdx.x, grp = tid / G, lig = tid % G, off = 4 * lig;
     const int gbase = ((tid & 63) / G) * G;  // first lane of this group inside its wavefront
     const bool act = off < D;
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_heavy_kernel(
             *reinterpret_cast<float4 *>(g + 4 * D) = make_float4(a0, a1, a2, 1.0f);
         }
     }
+  }
 }
 
 }  // namespace
@@ -417,26 +423,29 @@ extern "C" int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t b
 extern "C" int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, const int32_t *sel_node,
                                            const float *sel_pa, const float *sel_pb, const float *score,
                                            const float *Z, int64_t ldz, const float *pe_tab, const float *pe_stat,
-                                           float *G, int64_t ldg, float *alpha_out, void *stream) {
+                                           float *G, int64_t ldg, float *alpha_out, int32_t *heavy_scratch,
+                                           void *stream) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && type_ptr && sel_node && sel_pa && sel_pb && score && Z && pe_tab && pe_stat && G);
+    LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && type_ptr && sel_node && sel_pa && sel_pb && score && Z && pe_tab &&
+                pe_stat && G && heavy_scratch);
     if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
     LPF_REQUIRE((ldz & 3) == 0 && ldz >= D && (ldg & 3) == 0 && ldg >= 4 * D + 4 && lpf_aligned16(Z) &&
                 lpf_aligned16(G) && lpf_aligned16(pe_tab));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipMemsetAsync(heavy_scratch, 0, sizeof(int32_t), s);  // heavy-pair counter
     const int GG = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
     int64_t blocks = (bs + 4 * (64 / GG) - 1) / (4 * (64 / GG));
     if (blocks > 256 * 32) blocks = 256 * 32;
 #define LPF_SG_LAUNCH(GV)                                                                                       \
     hipLaunchKernelGGL(pair_softmax_gather_kernel<GV>, dim3((unsigned)blocks), dim3(256), 0, s, D, bs, type_ptr, \
-                       sel_node, sel_pa, sel_pb, score, Z, ldz, pe_tab, pe_stat, G, ldg, alpha_out)
+                       sel_node, sel_pa, sel_pb, score, Z, ldz, pe_tab, pe_stat, G, ldg, alpha_out, heavy_scratch)
     if (GG == 16) LPF_SG_LAUNCH(16);
     else if (GG == 32) LPF_SG_LAUNCH(32);
     else LPF_SG_LAUNCH(64);
 #undef LPF_SG_LAUNCH
 #define LPF_SGH_LAUNCH(GV)                                                                                          \
-    hipLaunchKernelGGL(pair_softmax_gather_heavy_kernel<GV>, dim3((unsigned)bs), dim3(256), 0, s, D, bs, type_ptr, \
-                       sel_node, sel_pa, sel_pb, score, Z, ldz, pe_tab, pe_stat, G, ldg, alpha_out)
+    hipLaunchKernelGGL(pair_softmax_gather_heavy_kernel<GV>, dim3(2048), dim3(256), 0, s, D, bs, type_ptr,         \
+                       sel_node, sel_pa, sel_pb, score, Z, ldz, pe_tab, pe_stat, G, ldg, alpha_out, heavy_scratch)
     if (GG == 16) LPF_SGH_LAUNCH(16);
     else if (GG == 32) LPF_SGH_LAUNCH(32);
     else LPF_SGH_LAUNCH(64);

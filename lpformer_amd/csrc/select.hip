@@ -183,6 +183,39 @@ __global__ __launch_bounds__(256) void select_items_kernel(int64_t bs, const int
     }
 }
 
+// Stores one chunk of typed candidates and updates the per-item counters.
+//   kind 0 (the item is the whole pair): COMPACTED runs, written as they are found -- common neighbours upwards from
+//     s, kept one-hop nodes of N(a) DOWNWARDS from s+dA-1 (both fit the dA slots of the N(a) run), kept one-hop nodes
+//     of N(b) upwards from s+dA.  Node order inside a run follows the CSR order (ascending; descending for the
+//     reversed run).
+//   slices of a hub pair: DENSE, one code per candidate (node | CN bit, or -1), compacted later per pair.
+__device__ __forceinline__ void sel_emit(int kind, int lane, bool in_range, bool keep, bool cn, bool from_a,
+                                         int32_t node, float va, float vb, int64_t s, int64_t dA, int64_t dense_slot,
+                                         int &n_cn, int &n_l1, int &n_l2, int32_t *__restrict__ stage_node,
+                                         float *__restrict__ stage_pa, float *__restrict__ stage_pb) {
+    const uint64_t m_cn = __ballot(keep && cn), m_l1 = __ballot(keep && !cn && from_a),
+                   m_l2 = __ballot(keep && !from_a);
+    if (kind == 0) {
+        if (keep) {
+            const int64_t dst = cn ? s + n_cn + lanes_below(m_cn, lane)
+                                   : (from_a ? s + dA - 1 - (n_l1 + lanes_below(m_l1, lane))
+                                             : s + dA + n_l2 + lanes_below(m_l2, lane));
+            stage_node[dst] = node;
+            stage_pa[dst] = va;
+            stage_pb[dst] = vb;
+        }
+    } else if (in_range) {
+        stage_node[dense_slot] = keep ? (node | (cn ? CN_BIT : 0)) : -1;
+        if (keep) {
+            stage_pa[dense_slot] = va;
+            stage_pb[dense_slot] = vb;
+        }
+    }
+    n_cn += __popcll(m_cn);
+    n_l1 += __popcll(m_l1);
+    n_l2 += __popcll(m_l2);
+}
+
 struct alignas(16) SelLds {
     int32_t cand[SEL_CAP];
     float pa[SEL_CAP];
@@ -382,29 +415,23 @@ __global__ __launch_bounds__(256) void select_nodes_kernel(
         const int64_t slot0 = s + (kind == 2 ? dA : 0) + start;  // kind 0: candidate i <-> staging slot s + i
         for (int i0 = 0; i0 < len; i0 += 64) {
             const int i = i0 + lane;
-            int32_t code = -1;
+            int32_t node = 0;
             bool from_a = false, cn = false, keep = false;
             float va = 0.f, vb = 0.f;
             if (i < len) {
                 from_a = (kind == 1) || (kind == 0 && i < dA);
                 const uint8_t f = L.flag[i];
+                node = L.cand[i];
                 if (from_a || !(f & F_INA)) {  // a node of N(b) that is also in N(a) is emitted through N(a)
                     cn = from_a && (f & F_INB);
                     va = ppr_round_trip(L.pa[i], cn);
                     vb = ppr_round_trip(L.pb[i], cn);
                     const float th = cn ? th_cn : th_1;
                     keep = (va >= th) && (vb >= th);
-                    if (keep) code = L.cand[i] | (cn ? CN_BIT : 0);
-                }
-                stage_node[slot0 + i] = code;
-                if (keep) {
-                    stage_pa[slot0 + i] = va;
-                    stage_pb[slot0 + i] = vb;
                 }
             }
-            n_cn += __popcll(__ballot(keep && cn));
-            n_l1 += __popcll(__ballot(keep && !cn && from_a));
-            n_l2 += __popcll(__ballot(keep && !from_a));
+            sel_emit(kind, lane, i < len, keep, cn, from_a, node, va, vb, s, dA, slot0 + i, n_cn, n_l1, n_l2,
+                     stage_node, stage_pa, stage_pb);
         }
         if (lane == 0) {
             if (n_cn) atomicAdd(&stage_cnt[4 * p + 0], n_cn);
@@ -506,6 +533,11 @@ __global__ __launch_bounds__(256) void select_counts_kernel(int64_t bs, const in
     }
 }
 
+constexpr int CMP_CAP = 128;  // kept one-hop nodes per run that the compaction kernel merges through LDS
+struct CmpLds {
+    int32_t n1[CMP_CAP], s1[CMP_CAP], n2[CMP_CAP], s2[CMP_CAP];  // node ids and staging slots of the two runs
+};
+
 // One wavefront per pair: dense runs -> reference layout.  CN entries go straight to their final place; the kept
 // one-hop nodes of the N(a) run and of the N(b) run are first compacted IN PLACE (writes never pass the read
 // cursor), then merged: two sorted, disjoint runs, final rank = own index + lower_bound in the other run.
@@ -514,8 +546,8 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
     int32_t *__restrict__ stage_node, float *__restrict__ stage_pa, float *__restrict__ stage_pb,
     const int32_t *__restrict__ stage_cnt, const int64_t *__restrict__ type_ptr, int32_t *__restrict__ sel_pair,
     int32_t *__restrict__ sel_node, float *__restrict__ sel_pa, float *__restrict__ sel_pb) {
-    // four independent wavefronts per workgroup (workgroup dispatch, not wave count, limits tiny-kernel launch rate);
-    // the waves never synchronise with each other
+    // four independent wavefronts per workgroup; the waves never synchronise with each other
+    __shared__ CmpLds cmp_lds[4];
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     const int64_t tot_cn = type_ptr[bs], tot_1 = type_ptr[(bs + 1) + bs];
@@ -526,56 +558,116 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
         const int64_t d_cn = type_ptr[p], d_1 = tot_cn + type_ptr[(bs + 1) + p],
                       d_0 = tot_cn + tot_1 + type_ptr[2 * (bs + 1) + p];
         const int64_t l1 = s, l2 = s + dA, t0 = s + dA + dB;
-        if (dA <= 64 && dB <= 64) {
-            // fast path (almost every pair): both runs fit one wavefront, so compaction and the merge of the two
-            // one-hop runs happen in registers -- one round of loads, no staging round trip
-            const bool ina = lane < dA, inb = lane < dB;
-            const int32_t ca = ina ? stage_node[l1 + lane] : -1, cb = inb ? stage_node[l2 + lane] : -1;
-            const float paa = ina ? stage_pa[l1 + lane] : 0.f, pba = ina ? stage_pb[l1 + lane] : 0.f;
-            const float pab = inb ? stage_pa[l2 + lane] : 0.f, pbb = inb ? stage_pb[l2 + lane] : 0.f;
-            float t_pa = 0.f, t_pb = 0.f;
-            int32_t t_nd = 0;
-            if (lane < n_t0) {
-                t_nd = stage_node[t0 + lane];
-                t_pa = stage_pa[t0 + lane];
-                t_pb = stage_pb[t0 + lane];
+        if (dA + dB <= SEL_CAP) {
+            // the pair was a single work item: its runs are already compacted (the N(a) one-hop run stored downwards
+            // from s+dA-1).  Copy CN, merge the two one-hop runs by rank = own index + lower_bound in the other run
+            // (they were written by the previous kernel: plain global reads), copy the >1-hop run.
+            const int n_cn = stage_cnt[4 * p];
+            for (int i = lane; i < n_cn; i += 64) {
+                sel_pair[d_cn + i] = (int32_t)p;
+                sel_node[d_cn + i] = stage_node[s + i];
+                sel_pa[d_cn + i] = stage_pa[s + i];
+                sel_pb[d_cn + i] = stage_pb[s + i];
             }
-            const bool is_cn = ca >= 0 && (ca & CN_BIT), is_l1 = ca >= 0 && !(ca & CN_BIT), is_l2 = cb >= 0;
-            const uint64_t m_cn = __ballot(is_cn), m_l1 = __ballot(is_l1), m_l2 = __ballot(is_l2);
-            if (is_cn) {
-                const int64_t dst = d_cn + lanes_below(m_cn, lane);
+            const int64_t top = s + dA - 1;  // element k of the N(a) one-hop run lives at top - k
+            for (int i = lane; i < n_l1; i += 64) {
+                const int32_t x = stage_node[top - i];
+                const int64_t dst = d_1 + i + (lpf_lower_bound(stage_node, l2, l2 + n_l2, x) - l2);
                 sel_pair[dst] = (int32_t)p;
-                sel_node[dst] = ca & ~CN_BIT;
-                sel_pa[dst] = paa;
-                sel_pb[dst] = pba;
+                sel_node[dst] = x;
+                sel_pa[dst] = stage_pa[top - i];
+                sel_pb[dst] = stage_pb[top - i];
             }
-            int r1 = lanes_below(m_l1, lane), r2 = lanes_below(m_l2, lane);
-            for (uint64_t mm = m_l2; mm; mm &= mm - 1) {  // kept N(b)-run nodes smaller than my N(a)-run node
-                const int32_t y = __shfl(cb, __ffsll((unsigned long long)mm) - 1, 64);
-                r1 += (is_l1 && y < ca) ? 1 : 0;
-            }
-            for (uint64_t mm = m_l1; mm; mm &= mm - 1) {
-                const int32_t x = __shfl(ca, __ffsll((unsigned long long)mm) - 1, 64);
-                r2 += (is_l2 && x < cb) ? 1 : 0;
-            }
-            if (is_l1) {
-                sel_pair[d_1 + r1] = (int32_t)p;
-                sel_node[d_1 + r1] = ca;
-                sel_pa[d_1 + r1] = paa;
-                sel_pb[d_1 + r1] = pba;
-            }
-            if (is_l2) {
-                sel_pair[d_1 + r2] = (int32_t)p;
-                sel_node[d_1 + r2] = cb;
-                sel_pa[d_1 + r2] = pab;
-                sel_pb[d_1 + r2] = pbb;
+            for (int j = lane; j < n_l2; j += 64) {
+                const int32_t y = stage_node[l2 + j];
+                int lo = 0, hi = n_l1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (stage_node[top - mid] < y) lo = mid + 1; else hi = mid;
+                }
+                const int64_t dst = d_1 + j + lo;
+                sel_pair[dst] = (int32_t)p;
+                sel_node[dst] = y;
+                sel_pa[dst] = stage_pa[l2 + j];
+                sel_pb[dst] = stage_pb[l2 + j];
             }
             for (int i = lane; i < n_t0; i += 64) {
-                const bool first = i < 64;
                 sel_pair[d_0 + i] = (int32_t)p;
-                sel_node[d_0 + i] = first ? t_nd : stage_node[t0 + i];
-                sel_pa[d_0 + i] = first ? t_pa : stage_pa[t0 + i];
-                sel_pb[d_0 + i] = first ? t_pb : stage_pb[t0 + i];
+                sel_node[d_0 + i] = stage_node[t0 + i];
+                sel_pa[d_0 + i] = stage_pa[t0 + i];
+                sel_pb[d_0 + i] = stage_pb[t0 + i];
+            }
+            continue;
+        }
+        if (n_l1 <= CMP_CAP && n_l2 <= CMP_CAP) {
+            // medium path: the kept one-hop nodes of both runs (with the staging slot they came from) go to this
+            // wave's LDS lists; ranks come from binary searches in LDS, values are fetched from the original slots
+            CmpLds &W = cmp_lds[threadIdx.x >> 6];
+            int c_cn = 0, c_l1 = 0, c_l2 = 0;
+            LPF_WAVE_SYNC();
+            for (int64_t i0 = 0; i0 < dA; i0 += 64) {
+                const int64_t i = i0 + lane;
+                const int32_t code = (i < dA) ? stage_node[s + i] : -1;
+                const bool is_cn = code >= 0 && (code & CN_BIT), is_l1 = code >= 0 && !(code & CN_BIT);
+                const uint64_t m_cn = __ballot(is_cn), m_l1 = __ballot(is_l1);
+                if (is_cn) {
+                    const int64_t dst = d_cn + c_cn + lanes_below(m_cn, lane);
+                    sel_pair[dst] = (int32_t)p;
+                    sel_node[dst] = code & ~CN_BIT;
+                    sel_pa[dst] = stage_pa[s + i];
+                    sel_pb[dst] = stage_pb[s + i];
+                }
+                if (is_l1) {
+                    const int k = c_l1 + lanes_below(m_l1, lane);
+                    W.n1[k] = code;
+                    W.s1[k] = (int32_t)i;
+                }
+                c_cn += __popcll(m_cn);
+                c_l1 += __popcll(m_l1);
+            }
+            for (int64_t j0 = 0; j0 < dB; j0 += 64) {
+                const int64_t j = j0 + lane;
+                const int32_t code = (j < dB) ? stage_node[l2 + j] : -1;
+                const uint64_t m = __ballot(code >= 0);
+                if (code >= 0) {
+                    const int k = c_l2 + lanes_below(m, lane);
+                    W.n2[k] = code;
+                    W.s2[k] = (int32_t)j;
+                }
+                c_l2 += __popcll(m);
+            }
+            LPF_WAVE_SYNC();
+            for (int i = lane; i < n_l1; i += 64) {
+                const int32_t x = W.n1[i];
+                int lo = 0, hi = n_l2;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (W.n2[mid] < x) lo = mid + 1; else hi = mid;
+                }
+                const int64_t dst = d_1 + i + lo, src = l1 + W.s1[i];
+                sel_pair[dst] = (int32_t)p;
+                sel_node[dst] = x;
+                sel_pa[dst] = stage_pa[src];
+                sel_pb[dst] = stage_pb[src];
+            }
+            for (int j = lane; j < n_l2; j += 64) {
+                const int32_t y = W.n2[j];
+                int lo = 0, hi = n_l1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (W.n1[mid] < y) lo = mid + 1; else hi = mid;
+                }
+                const int64_t dst = d_1 + j + lo, src = l2 + W.s2[j];
+                sel_pair[dst] = (int32_t)p;
+                sel_node[dst] = y;
+                sel_pa[dst] = stage_pa[src];
+                sel_pb[dst] = stage_pb[src];
+            }
+            for (int i = lane; i < n_t0; i += 64) {
+                sel_pair[d_0 + i] = (int32_t)p;
+                sel_node[d_0 + i] = stage_node[t0 + i];
+                sel_pa[d_0 + i] = stage_pa[t0 + i];
+                sel_pb[d_0 + i] = stage_pb[t0 + i];
             }
             continue;
         }
@@ -746,11 +838,10 @@ __global__ __launch_bounds__(256) void select_nodes_indexed_kernel(
         for (int u = 0; u < SEL_CAP / 64; ++u) {
             if (64 * u >= len) break;
             const int i = lane + 64 * u;
-            int32_t code = -1;
             bool from_a = false, cn = false, keep = false;
             float va = 0.f, vb = 0.f;
+            const int32_t x = cnd[u];
             if (i < len) {
-                const int32_t x = cnd[u];
                 from_a = (kind == 1) || (kind == 0 && i < dA);
                 int j;  // position of x in the other endpoint's adjacency row
                 if (kind == 0) j = from_a ? find_lds(L.cand + dA, dB, x) : find_lds(L.cand, dA, x);
@@ -770,17 +861,10 @@ __global__ __launch_bounds__(256) void select_nodes_indexed_kernel(
                     vb = ppr_round_trip(from_a ? other : sp[u], cn);
                     const float th = cn ? th_cn : th_1;
                     keep = (va >= th) && (vb >= th);
-                    if (keep) code = x | (cn ? CN_BIT : 0);
-                }
-                stage_node[slot0 + i] = code;
-                if (keep) {
-                    stage_pa[slot0 + i] = va;
-                    stage_pb[slot0 + i] = vb;
                 }
             }
-            n_cn += __popcll(__ballot(keep && cn));
-            n_l1 += __popcll(__ballot(keep && !cn && from_a));
-            n_l2 += __popcll(__ballot(keep && !from_a));
+            sel_emit(kind, lane, i < len, keep, cn, from_a, x, va, vb, s, dA, slot0 + i, n_cn, n_l1, n_l2, stage_node,
+                     stage_pa, stage_pb);
         }
         if (lane == 0) {
             if (n_cn) atomicAdd(&stage_cnt[4 * p + 0], n_cn);

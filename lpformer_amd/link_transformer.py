@@ -619,7 +619,8 @@ class LinkTransformer(nn.Module):
             with KernelTimer.span("pair_softmax_gather"):
                 check(lib.lpf_pair_softmax_gather_f32(d, bs, ptr(s["type_ptr"]), ptr(s["sel_node"]), ptr(s["sel_pa"]),
                                                       ptr(s["sel_pb"]), ptr(score), ptr(z), z.stride(0),
-                                                      ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(g), ldg, ptr(alpha), st),
+                                                      ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(g), ldg, ptr(alpha),
+                                                      ptr(self._workspace("sg_heavy", bs + 1, torch.int32)), st),
                       "lpf_pair_softmax_gather_f32")
             feats = s["feats"]
             att_view = feats[:, :d]
