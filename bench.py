@@ -183,6 +183,12 @@ def main():
                 "select_compact": ("hbm", 12.0 * sum_deg + 16.0 * n_sel + 64.0 * bs),
                 "gemm_attn_out": ("mfma", 2.0 * bs * d * (3 * d + 4)),
                 "gemm_q": ("mfma", 2.0 * bs * d * d),
+                # fused dense chains (lpf_dense_chain_f32): FLOPs of the Linear layers they contain
+                "dense_chain_attn_out": ("mfma", 2.0 * bs * d * (3 * d + 4)),
+                "dense_chain_q": ("mfma", 2.0 * bs * d * d),
+                "dense_chain_score": ("mfma", 2.0 * bs * (2 * d) * (2 * d + 1)),
+                "dense_chain_mlp": ("mfma", (2.0 * bs * (2 * d * d) + 2.0 * bs * (d + model.count_dim)
+                                             * (2 * d + model.count_dim)) / 2.0),  # 2 launches/step, mean per launch
             }
             for name, (bound, units) in work.items():
                 if name not in kt:

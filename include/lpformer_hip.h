@@ -182,6 +182,27 @@ int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, 
                                 const float *Z, int64_t ldz, const float *pe_tab, const float *pe_stat,
                                 float *G, int64_t ldg, float *alpha_out, int32_t *heavy_scratch, void *stream);
 
+/* Fused dense chain (one launch):  y = L2( act( LN( L1(x) + addend ) ) )  on the fp32 matrix cores, hidden activations
+ * never leaving registers.  Replaces Linear -> LayerNorm -> ReLU -> Linear chains of other_models.py:125-138 (MLP),
+ * :173-179 (mlp_score, N2 == 1 "dot mode": logit/prob out), the hoisted lin_l of layers.py:212-215 (in_mode 2) and the
+ * attention-output projection + post_att_norm (layers.py:78; single layer with addend + LN).
+ *   in_mode 0: x = X[m, :K1]; 1: x = X[a_m] * X[b_m]; 2: x = X[a_m] + X[b_m]  (batch: int64 [2, M], row stride batch_ld)
+ *   w1_packed: layer-1 weights [N1, K1] in MFMA A-operand order, chunks of 64 input features: float index
+ *              ((((kc*nt1 + c)*4 + sq)*64 + 16q + i)*4 + u) = W1[16c + i][64kc + 16sq + 4q + u], zero padded
+ *              (nt1 = ceil(N1/16)); b1, ln_g, ln_b: nt1*16 floats, zero padded; ln_g NULL = no LayerNorm;
+ *              flags & LPF_FLAG_RELU: ReLU after (the LayerNorm of) layer 1; addend [M, N1] optional (N1 % 4 == 0)
+ *   w2_packed: NULL = single layer (out [M, N1]); N2 == 1: plain zero-padded vector of nt1*16 floats, b2[0] the bias,
+ *              out = logits [M] and/or prob = sigmoid [M]; otherwise [N2, N1] packed like w1 over the hidden features
+ *              (nt2 = ceil(N2/16) tiles); b2: nt2*16 floats
+ *   K1 % 4 == 0.  Built tile shapes (nt1, nt2): (2|4|8|16|32, 0), (2,2) (4,4) (8,8) (16,16), (3,2) (5,4) (9,8) (17,16);
+ *   anything else returns LPF_ERR_UNSUPPORTED (callers then use lpf_gemm_f32 + lpf_layernorm_f32).
+ *   lpformer_amd/fold.py builds the packed images. */
+int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch,
+                        int64_t batch_ld, int32_t K1, const float *w1_packed, int32_t N1, const float *b1,
+                        const float *addend, int64_t ldadd, const float *ln_g, const float *ln_b, uint32_t flags,
+                        const float *w2_packed, int32_t N2, const float *b2, float *out, int64_t ldo, float *prob,
+                        void *stream);
+
 /* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
  * logit or prob may be NULL. */
 int lpf_rowdot_sigmoid_f32(int64_t M, int32_t K, const float *A, int64_t lda, const float *w, float b,

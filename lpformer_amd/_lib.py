@@ -34,6 +34,8 @@ HIP_PROTOTYPES = {
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp],
     "lpf_rowdot_sigmoid_f32": [i64, i32, vp, i64, vp, f32, vp, vp, vp],
+    "lpf_dense_chain_f32": [i64, i32, vp, i64, vp, i64, i32, vp, i32, vp, vp, i64, vp, vp, u32, vp, i32, vp, vp, i64, vp,
+                            vp],
 }
 HOST_PROTOTYPES = {
     "lpf_ppr_push_cpu": [i64, vp, vp, f64, f64, vp, C.POINTER(vp), C.POINTER(vp), i32],

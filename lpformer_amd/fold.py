@@ -75,3 +75,38 @@ def pack_wfold(wfold: np.ndarray) -> np.ndarray:
     w = wfold.reshape(3, nt, 32, 2, nsq, 4)          # t, c, row, half, sq, u
     w = w.transpose(0, 1, 4, 3, 2, 5)                 # t, c, sq, half, row, u
     return np.ascontiguousarray(w.reshape(3, nt, nsq, 64, 4))
+
+
+def _pad_to(a: np.ndarray, n: int) -> np.ndarray:
+    out = np.zeros(n, np.float32)
+    out[:a.size] = a.reshape(-1)
+    return out
+
+
+def pack_dense(w: np.ndarray) -> np.ndarray:
+    """[N, K] -> lpf_dense_chain_f32 weight image (either layer): float4 (kc, c, sq, lane = 16q + i) holds
+    W[16c + i][64kc + 16sq + 4q + 0..3], zero padded to 16-row tiles and 64-column chunks."""
+    n, k = w.shape
+    nt, nkc = (n + 15) // 16, (k + 63) // 64
+    wp = np.zeros((nt * 16, nkc * 64), np.float32)
+    wp[:n, :k] = w
+    r = wp.reshape(nt, 16, nkc, 4, 4, 4)          # c, i, kc, sq, q, u
+    return np.ascontiguousarray(r.transpose(2, 0, 3, 4, 1, 5)).reshape(-1)
+
+
+def dense_chain_tables(w1, b1, ln_g=None, ln_b=None, w2=None, b2=None) -> dict:
+    """fp32 arrays for one lpf_dense_chain_f32 call (all zero padded to 16-feature tiles)."""
+    w1 = np.asarray(w1, np.float32)
+    n1 = w1.shape[0]
+    p1 = ((n1 + 15) // 16) * 16
+    out = {"w1p": pack_dense(w1), "b1": _pad_to(np.asarray(b1, np.float32), p1)}
+    if ln_g is not None:
+        out["ln_g"], out["ln_b"] = _pad_to(np.asarray(ln_g, np.float32), p1), _pad_to(np.asarray(ln_b, np.float32), p1)
+    if w2 is not None:
+        w2 = np.asarray(w2, np.float32)
+        if w2.shape[0] == 1:
+            out["w2p"], out["b2"] = _pad_to(w2, p1), np.asarray(b2, np.float32).reshape(-1)[:1].copy()
+        else:
+            p2 = ((w2.shape[0] + 15) // 16) * 16
+            out["w2p"], out["b2"] = pack_dense(w2), _pad_to(np.asarray(b2, np.float32), p2)
+    return out

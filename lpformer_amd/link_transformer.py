@@ -105,6 +105,66 @@ class _PaddedLinear:
         return self._w
 
 
+class DenseChain:
+    """Cached device tables + launcher for ``lpf_dense_chain_f32``: Linear (+addend) (+LayerNorm) (+ReLU) (+Linear),
+    refreshed when a parameter changes.  ``run`` returns None when the shape has no fused instantiation (the caller
+    then takes the unfused HIP kernels)."""
+
+    BUILT = {(2, 0), (4, 0), (8, 0), (16, 0), (32, 0), (2, 2), (4, 4), (8, 8), (16, 16), (3, 2), (5, 4), (9, 8),
+             (17, 16)}
+
+    def __init__(self, tag: str):
+        self.tag = tag
+        self._key = None
+        self._t = None
+
+    @staticmethod
+    def _vkey(t):
+        return None if t is None else (t.data_ptr(), t._version, str(t.device))
+
+    def tables(self, w1, b1, ln_g=None, ln_b=None, w2=None, b2=None):
+        key = tuple(self._vkey(t) for t in (w1, b1, ln_g, ln_b, w2, b2))
+        if key != self._key:
+            npy = lambda t: None if t is None else t.detach().float().cpu().numpy()  # noqa: E731
+            n1 = w1.shape[0]
+            tabs = fold.dense_chain_tables(npy(w1), npy(b1) if b1 is not None else np.zeros(n1, np.float32),
+                                           npy(ln_g), npy(ln_b), npy(w2),
+                                           None if w2 is None else (npy(b2) if b2 is not None
+                                                                    else np.zeros(w2.shape[0], np.float32)))
+            dev = w1.device
+            self._t = {k: torch.from_numpy(v).to(dev) for k, v in tabs.items()}
+            self._t["shape"] = (w1.shape[1], n1, 0 if w2 is None else w2.shape[0])
+            self._key = key
+        return self._t
+
+    def run(self, t: dict, x: torch.Tensor, relu: bool, batch=None, in_mode=0, addend=None, out=None, prob=None,
+            want_logit=True):
+        """x: [M, K1] rows (in_mode 0) or the node-feature matrix gathered through ``batch`` ([2, M] int64)."""
+        k1, n1, n2 = t["shape"]
+        nt1, dot = (n1 + 15) // 16, n2 == 1
+        nt2 = 0 if (n2 == 0 or dot) else (n2 + 15) // 16
+        if (nt1, nt2) not in self.BUILT or k1 % 4 or x.stride(0) % 4 or x.data_ptr() % 16 or x.stride(1) != 1:
+            return None
+        m = x.shape[0] if in_mode == 0 else batch.shape[1]
+        dev = x.device
+        if dot:
+            res = torch.empty(m, dtype=torch.float32, device=dev)
+            o, pr, ldo = (ptr(res), None, 0) if want_logit else (None, ptr(res), 0)
+        else:
+            width = n2 if n2 else n1
+            if width % 4:
+                return None
+            res = out if out is not None else torch.empty(m, width, dtype=torch.float32, device=dev)
+            o, pr, ldo = ptr(res), None, res.stride(0)
+        with KernelTimer.span(self.tag):
+            check(_lib.hip().lpf_dense_chain_f32(
+                m, in_mode, ptr(x), x.stride(0), ptr(batch), 0 if batch is None else batch.stride(0), k1,
+                ptr(t["w1p"]), n1, ptr(t["b1"]), ptr(addend), 0 if addend is None else addend.stride(0),
+                ptr(t.get("ln_g")), ptr(t.get("ln_b")), FLAG_RELU if relu else 0, ptr(t.get("w2p")), n2,
+                ptr(t.get("b2")), o, ldo, pr, _stream(dev)), "lpf_dense_chain_f32")
+        return res
+
+
 # ------------------------------------------------------------------------------------------ parameter modules
 class MLP(nn.Module):
     """Same parameters and semantics as the reference's ``MLP`` (src/models/other_models.py:80-138):
@@ -126,11 +186,27 @@ class MLP(nn.Module):
                 self.linears.append(nn.Linear(hid_channels, hid_channels, bias=bias))
             self.linears.append(nn.Linear(hid_channels, out_channels, bias=bias))
         self._pads = [_PaddedLinear() for _ in self.linears]
+        self._chain = DenseChain("dense_chain_mlp")
 
-    def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x: [M, K] fp32 device rows (16-byte aligned).  Optionally writes the result into ``out`` (a strided view)."""
+    def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, batch=None, in_mode=0) -> torch.Tensor:
+        """x: [M, K] fp32 device rows (16-byte aligned).  Optionally writes the result into ``out`` (a strided view).
+        ``in_mode`` 1/2 with ``batch`` [2, M]: the input rows are x[a]*x[b] / x[a]+x[b], gathered inside the kernel."""
         if self.training and self.dropout > 0:
             raise NotImplementedError("training-mode dropout is not part of the HIP inference path")
+        if len(self.linears) == 2 and self.norm is not None:  # one launch: Linear -> LayerNorm -> ReLU -> Linear
+            l1, l2 = self.linears
+            t = self._chain.tables(l1.weight, l1.bias, self.norm.weight, self.norm.bias, l2.weight, l2.bias)
+            y = self._chain.run(t, x, relu=True, batch=batch, in_mode=in_mode, out=out)
+            if y is not None:
+                return y
+        if in_mode:
+            d = x.shape[1]
+            gathered = torch.empty(batch.shape[1], d, dtype=torch.float32, device=x.device)
+            args = (ptr(gathered), d, None, 0) if in_mode == 1 else (None, 0, ptr(gathered), d)
+            with KernelTimer.span("pair_gather"):
+                check(_lib.hip().lpf_pair_gather_f32(batch.shape[1], d, ptr(batch), batch.stride(0), ptr(x),
+                                                     x.stride(0), *args, _stream(x.device)), "lpf_pair_gather_f32")
+            x = gathered
         h = x
         for i, lin in enumerate(self.linears[:-1]):
             w = self._pads[i].get(lin.weight)
@@ -171,6 +247,7 @@ class mlp_score(nn.Module):  # noqa: N801  (name kept for drop-in compatibility)
             self.lins.append(nn.Linear(hidden_channels, out_channels))
         self.dropout = dropout
         self._pads = [_PaddedLinear() for _ in self.lins]
+        self._chain = DenseChain("dense_chain_score")
 
     def _run(self, x: torch.Tensor, want_prob: bool) -> torch.Tensor:
         _require_gpu(x, "mlp_score.forward")
@@ -178,6 +255,12 @@ class mlp_score(nn.Module):  # noqa: N801  (name kept for drop-in compatibility)
             raise NotImplementedError("training-mode dropout is not part of the HIP inference path")
         with torch.no_grad():
             h = _as_f32_rows(x)
+            if len(self.lins) == 2 and self.lins[1].out_features == 1:  # Linear -> ReLU -> dot -> sigmoid, one launch
+                l1, l2 = self.lins
+                t = self._chain.tables(l1.weight, l1.bias, None, None, l2.weight, l2.bias)
+                res = self._chain.run(t, h, relu=True, want_logit=not want_prob)
+                if res is not None:
+                    return res
             for i, lin in enumerate(self.lins[:-1]):
                 h = gemm(h, self._pads[i].get(lin.weight), lin.bias, relu=True)
             last = self.lins[-1]
@@ -345,6 +428,8 @@ class LinkTransformer(nn.Module):
         self._z_cache = None   # (key, Z)
         self._x_cache = None   # (key, padded features)
         self._ws = {}          # named workspaces
+        self._chain_q = DenseChain("dense_chain_q")            # lin_l(x_a + x_b)
+        self._chain_att = DenseChain("dense_chain_attn_out")   # attention output projection + post_att_norm
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
         self.last_stats = {}
         self._shard = (0, 1)   # (rank, world) for the row-sharded encoder
@@ -436,6 +521,7 @@ class LinkTransformer(nn.Module):
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
         self._folded = (key, dev)
         self._z_cache = None
+        self._chain_q._key = self._chain_att._key = None
         return dev
 
     # ---------------------------------------------------------------------------------- encoder
@@ -599,11 +685,13 @@ class LinkTransformer(nn.Module):
             x_node = _as_f32_rows(X_node)
             z = self._node_keys(x_node, w)
 
-            qin = torch.empty(bs, d, dtype=torch.float32, device=self.device)
-            with KernelTimer.span("pair_gather"):
-                check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0), None, 0,
-                                              ptr(qin), d, st), "lpf_pair_gather_f32")
-            q = gemm(qin, w["w_l"], w["b_l2"], tag="gemm_q")
+            q = self._chain_q.run(self._chain_q.tables(w["w_l"], w["b_l2"]), x_node, relu=False, batch=batch, in_mode=2)
+            if q is None:
+                qin = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+                with KernelTimer.span("pair_gather"):
+                    check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0),
+                                                  None, 0, ptr(qin), d, st), "lpf_pair_gather_f32")
+                q = gemm(qin, w["w_l"], w["b_l2"], tag="gemm_q")
 
             s = self._select(batch, test_set, adj_mask)
             score = self._workspace("score", s["cap"], torch.float32)
@@ -624,9 +712,12 @@ class LinkTransformer(nn.Module):
                       "lpf_pair_softmax_gather_f32")
             feats = s["feats"]
             att_view = feats[:, :d]
-            gemm(g[:, d:], w["wcat"], None, addend=g[:, :d], out=att_view, tag="gemm_attn_out")      # sum_e alpha_e k_e + bias
             layer = self.att_layers[0]
-            layernorm_(att_view, layer.post_att_norm.weight, layer.post_att_norm.bias)
+            # sum_e alpha_e k_e + bias, then post_att_norm: one launch (or GEMM + LayerNorm for unbuilt shapes)
+            t = self._chain_att.tables(w["wcat"], None, layer.post_att_norm.weight, layer.post_att_norm.bias)
+            if self._chain_att.run(t, g[:, d:], relu=False, addend=g[:, :d], out=att_view) is None:
+                gemm(g[:, d:], w["wcat"], None, addend=g[:, :d], out=att_view, tag="gemm_attn_out")
+                layernorm_(att_view, layer.post_att_norm.weight, layer.post_att_norm.bias)
             self._last_att = att_view
             out = self.pairwise_lin.run(feats[:, :d + self.count_dim], out=_out)
 
@@ -658,10 +749,6 @@ class LinkTransformer(nn.Module):
             bs = batch.shape[1]
             x_node = _as_f32_rows(X_node)
             comb = torch.empty(bs, 2 * d, dtype=torch.float32, device=self.device)
-            prod = torch.empty(bs, d, dtype=torch.float32, device=self.device)
-            with KernelTimer.span("pair_gather"):
-                check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0),
-                                              ptr(prod), d, None, 0, st), "lpf_pair_gather_f32")
-            self.elementwise_lin.run(prod, out=comb[:, :d])
+            self.elementwise_lin.run(x_node, out=comb[:, :d], batch=batch, in_mode=1)
             _, attw = self.calc_pairwise(batch, x_node, test_set, adj_mask, return_weights, _out=comb[:, d:])
             return (comb, attw) if return_weights else comb

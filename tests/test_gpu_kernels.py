@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from lpformer_amd import _lib, graph
-from lpformer_amd.link_transformer import gemm, layernorm_
+from lpformer_amd.link_transformer import DenseChain, gemm, layernorm_
 from oracle import lpformer_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -91,3 +91,89 @@ def test_layernorm(d):
     ref = torch.relu(torch.nn.functional.layer_norm(x, (d,), w, b))
     out = layernorm_(x.clone(), w, b, relu=True)
     assert (out - ref).abs().max().item() <= 2e-5
+
+
+def _chain_ref(x, w1, b1, add, g, be, relu, w2, b2):
+    h = x.double() @ w1.double().T + b1.double()
+    if add is not None:
+        h = h + add.double()
+    if g is not None:
+        mu = h.mean(1, keepdim=True)
+        var = ((h - mu) ** 2).mean(1, keepdim=True)
+        h = (h - mu) / torch.sqrt(var + 1e-5) * g.double() + be.double()
+    if relu:
+        h = h.clamp_min(0)
+    if w2 is not None:
+        h = h @ w2.double().T + b2.double()
+    return h
+
+
+@pytest.mark.parametrize("m,k1,n1,n2", [(1, 64, 64, 64), (300, 128, 128, 128), (1000, 132, 132, 128), (77, 68, 68, 64),
+                                        (513, 256, 256, 256), (200, 260, 260, 256), (129, 32, 32, 32),
+                                        (90, 36, 36, 32), (4096, 128, 128, 128)])
+def test_dense_chain_two_layers(m, k1, n1, n2):
+    g_ = torch.Generator().manual_seed(m + k1)
+    r = lambda *s: torch.randn(*s, generator=g_).to(DEV)  # noqa: E731
+    x, w1, b1, lg, lb, w2, b2 = r(m, k1), r(n1, k1) / k1 ** 0.5, r(n1), r(n1), r(n1), r(n2, n1) / n1 ** 0.5, r(n2)
+    dc = DenseChain("t")
+    out = dc.run(dc.tables(w1, b1, lg, lb, w2, b2), x, relu=True)
+    assert out is not None
+    ref = _chain_ref(x, w1, b1, None, lg, lb, True, w2, b2)
+    assert (out.double() - ref).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize("m,k1,n1", [(5, 64, 64), (700, 128, 128), (333, 388, 128), (257, 196, 64), (100, 256, 256),
+                                     (64, 512, 512), (31, 772, 256)])
+@pytest.mark.parametrize("mode", ["plain", "addend_ln", "relu", "dot"])
+def test_dense_chain_single_layer_variants(m, k1, n1, mode):
+    g_ = torch.Generator().manual_seed(m * 3 + k1)
+    r = lambda *s: torch.randn(*s, generator=g_).to(DEV)  # noqa: E731
+    x, w1, b1 = r(m, k1), r(n1, k1) / k1 ** 0.5, r(n1)
+    dc = DenseChain("t")
+    if mode == "plain":
+        out = dc.run(dc.tables(w1, b1), x, relu=False)
+        ref = _chain_ref(x, w1, b1, None, None, None, False, None, None)
+    elif mode == "relu":
+        out = dc.run(dc.tables(w1, b1), x, relu=True)
+        ref = _chain_ref(x, w1, b1, None, None, None, True, None, None)
+    elif mode == "addend_ln":
+        add, lg, lb = r(m, n1 + 4)[:, :n1], r(n1), r(n1)
+        buf = torch.full((m, n1 + 8), 7.0, device=DEV)
+        out = dc.run(dc.tables(w1, b1, lg, lb), x, relu=False, addend=add, out=buf[:, :n1])
+        ref = _chain_ref(x, w1, b1, add, lg, lb, False, None, None)
+        assert (buf[:, n1:] == 7.0).all()  # strided output view: nothing written past the logical width
+    else:
+        w2, b2 = r(1, n1) / n1 ** 0.5, r(1)
+        t = dc.tables(w1, b1, None, None, w2, b2)
+        out = dc.run(t, x, relu=True)
+        ref = _chain_ref(x, w1, b1, None, None, None, True, w2, b2).squeeze(1)
+        prob = dc.run(t, x, relu=True, want_logit=False)
+        assert (prob.double() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
+    assert out is not None
+    assert (out.double() - ref).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize("in_mode", [1, 2])
+def test_dense_chain_gathered_inputs(in_mode):
+    g_ = torch.Generator().manual_seed(in_mode)
+    r = lambda *s: torch.randn(*s, generator=g_).to(DEV)  # noqa: E731
+    n, d, m = 500, 128, 1111
+    xn = r(n, d)
+    batch = torch.randint(0, n, (2, m), generator=g_).to(DEV)
+    w1, b1, lg, lb, w2, b2 = r(d, d) / d ** 0.5, r(d), r(d), r(d), r(d, d) / d ** 0.5, r(d)
+    dc = DenseChain("t")
+    xin = xn[batch[0]] * xn[batch[1]] if in_mode == 1 else xn[batch[0]] + xn[batch[1]]
+    out = dc.run(dc.tables(w1, b1, lg, lb, w2, b2), xn, relu=True, batch=batch, in_mode=in_mode)
+    ref = _chain_ref(xin, w1, b1, None, lg, lb, True, w2, b2)
+    assert (out.double() - ref).abs().max().item() <= 3e-5
+
+
+def test_dense_chain_unsupported_shape_is_reported():
+    x, w1, b1 = torch.randn(8, 80, device=DEV), torch.randn(80, 80, device=DEV), torch.randn(80, device=DEV)
+    dc = DenseChain("t")
+    assert dc.run(dc.tables(w1, b1), x, relu=False) is None  # nt1 = 5 single layer is not built
+    t = dc.tables(w1, b1)
+    rc = _lib.hip().lpf_dense_chain_f32(8, 0, _lib.ptr(x), 80, None, 0, 80, _lib.ptr(t["w1p"]), 80, _lib.ptr(t["b1"]),
+                                        None, 0, None, None, 0, None, 0, None, _lib.ptr(torch.empty(8, 80, device=DEV)),
+                                        80, None, None)
+    assert rc == -2
