@@ -83,15 +83,24 @@ def _pad_to(a: np.ndarray, n: int) -> np.ndarray:
     return out
 
 
-def pack_dense(w: np.ndarray) -> np.ndarray:
-    """[N, K] -> lpf_dense_chain_f32 weight image (either layer): float4 (kc, c, sq, lane = 16q + i) holds
-    W[16c + i][64kc + 16sq + 4q + 0..3], zero padded to 16-row tiles and 64-column chunks."""
+def dense_stage_groups(nt1: int, nt2: int) -> int:
+    """k-groups (16 input features each) per pipeline stage of lpf_dense_chain_f32 for a (nt1, nt2)-tile chain."""
+    return 4 if max(nt1, nt2) <= 9 else 2
+
+
+def pack_dense(w: np.ndarray, g: int) -> np.ndarray:
+    """[N, K] -> lpf_dense_chain_f32 weight image (either layer).  k-group ks: float4 (c, lane = 16q + i) =
+    W[16c + i][16ks + 4q + 0..3]; a stage = ``g`` consecutive k-groups, zero padded to a multiple of 256 float4."""
     n, k = w.shape
-    nt, nkc = (n + 15) // 16, (k + 63) // 64
-    wp = np.zeros((nt * 16, nkc * 64), np.float32)
+    nt, ns = (n + 15) // 16, (k + 16 * g - 1) // (16 * g)
+    wp = np.zeros((nt * 16, ns * g * 16), np.float32)
     wp[:n, :k] = w
-    r = wp.reshape(nt, 16, nkc, 4, 4, 4)          # c, i, kc, sq, q, u
-    return np.ascontiguousarray(r.transpose(2, 0, 3, 4, 1, 5)).reshape(-1)
+    r = wp.reshape(nt, 16, ns, g, 4, 4)           # c, i, stage, sq, q, u
+    r = np.ascontiguousarray(r.transpose(2, 3, 0, 4, 1, 5)).reshape(ns, g * nt * 64 * 4)
+    per_stage = -(-(g * nt * 64) // 256) * 256 * 4
+    out = np.zeros((ns, per_stage), np.float32)
+    out[:, :r.shape[1]] = r
+    return out.reshape(-1)
 
 
 def dense_chain_tables(w1, b1, ln_g=None, ln_b=None, w2=None, b2=None) -> dict:
@@ -99,14 +108,16 @@ def dense_chain_tables(w1, b1, ln_g=None, ln_b=None, w2=None, b2=None) -> dict:
     w1 = np.asarray(w1, np.float32)
     n1 = w1.shape[0]
     p1 = ((n1 + 15) // 16) * 16
-    out = {"w1p": pack_dense(w1), "b1": _pad_to(np.asarray(b1, np.float32), p1)}
+    dot = w2 is not None and np.asarray(w2).shape[0] == 1
+    nt2 = 0 if (w2 is None or dot) else (np.asarray(w2).shape[0] + 15) // 16
+    g = dense_stage_groups(p1 // 16, nt2)
+    out = {"w1p": pack_dense(w1, g), "b1": _pad_to(np.asarray(b1, np.float32), p1)}
     if ln_g is not None:
         out["ln_g"], out["ln_b"] = _pad_to(np.asarray(ln_g, np.float32), p1), _pad_to(np.asarray(ln_b, np.float32), p1)
     if w2 is not None:
         w2 = np.asarray(w2, np.float32)
-        if w2.shape[0] == 1:
+        if dot:
             out["w2p"], out["b2"] = _pad_to(w2, p1), np.asarray(b2, np.float32).reshape(-1)[:1].copy()
         else:
-            p2 = ((w2.shape[0] + 15) // 16) * 16
-            out["w2p"], out["b2"] = pack_dense(w2), _pad_to(np.asarray(b2, np.float32), p2)
+            out["w2p"], out["b2"] = pack_dense(w2, g), _pad_to(np.asarray(b2, np.float32), nt2 * 16)
     return out

@@ -434,6 +434,10 @@ class LinkTransformer(nn.Module):
         self.last_stats = {}
         self._shard = (0, 1)   # (rank, world) for the row-sharded encoder
         self.use_select_index = True  # False: always run the general (PPR-streaming) selection kernel
+        # the elementwise branch and the q projection only need X and the batch: they run on a second HIP stream
+        # underneath the (latency/issue-bound) selection kernels.  False: everything on the caller's stream.
+        self.use_side_stream = True
+        self._side = None
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self):
@@ -672,6 +676,15 @@ class LinkTransformer(nn.Module):
             return tuple(out)
 
     # ---------------------------------------------------------------------------------- pair stage
+    def _fork(self):
+        """Side stream ordered after everything already queued on the caller's stream (None when disabled)."""
+        if not self.use_side_stream or KernelTimer.enabled:  # per-kernel timing wants serial launches
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        return self._side
+
     def calc_pairwise(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False, _out=None):
         """Pairwise branch (:132-178): selection -> PE + attention -> counts -> ``pairwise_lin``.
         Returns ([BS, D], att_weights or None)."""
@@ -685,15 +698,21 @@ class LinkTransformer(nn.Module):
             x_node = _as_f32_rows(X_node)
             z = self._node_keys(x_node, w)
 
-            q = self._chain_q.run(self._chain_q.tables(w["w_l"], w["b_l2"]), x_node, relu=False, batch=batch, in_mode=2)
-            if q is None:
-                qin = torch.empty(bs, d, dtype=torch.float32, device=self.device)
-                with KernelTimer.span("pair_gather"):
-                    check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node), x_node.stride(0),
-                                                  None, 0, ptr(qin), d, st), "lpf_pair_gather_f32")
-                q = gemm(qin, w["w_l"], w["b_l2"], tag="gemm_q")
+            q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+            side = self._fork()
+            with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+                if self._chain_q.run(self._chain_q.tables(w["w_l"], w["b_l2"]), x_node, relu=False, batch=batch,
+                                     in_mode=2, out=q) is None:
+                    qin = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+                    with KernelTimer.span("pair_gather"):
+                        check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node),
+                                                      x_node.stride(0), None, 0, ptr(qin), d,
+                                                      _stream(self.device)), "lpf_pair_gather_f32")
+                    gemm(qin, w["w_l"], w["b_l2"], out=q, tag="gemm_q")
 
             s = self._select(batch, test_set, adj_mask)
+            if side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(side)  # q (and the elementwise branch) are done
             score = self._workspace("score", s["cap"], torch.float32)
             with KernelTimer.span("pair_scores"):
                 check(lib.lpf_pair_scores_f32(d, ptr(s["type_ptr"]), bs, ptr(s["sel_pair"]), ptr(s["sel_node"]),
@@ -744,11 +763,13 @@ class LinkTransformer(nn.Module):
         """[elementwise_lin(X[a]*X[b]) | calc_pairwise(...)] written straight into one [BS, 2D] buffer."""
         self._check_supported()
         with torch.no_grad():
-            lib, st, d = _lib.hip(), _stream(self.device), self.dim
+            d = self.dim
             batch = self._prep_batch(batch)
             bs = batch.shape[1]
             x_node = _as_f32_rows(X_node)
             comb = torch.empty(bs, 2 * d, dtype=torch.float32, device=self.device)
-            self.elementwise_lin.run(x_node, out=comb[:, :d], batch=batch, in_mode=1)
+            side = self._fork()
+            with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+                self.elementwise_lin.run(x_node, out=comb[:, :d], batch=batch, in_mode=1)
             _, attw = self.calc_pairwise(batch, x_node, test_set, adj_mask, return_weights, _out=comb[:, d:])
             return (comb, attw) if return_weights else comb

@@ -154,17 +154,23 @@ def test_dense_chain_single_layer_variants(m, k1, n1, mode):
 
 
 @pytest.mark.parametrize("in_mode", [1, 2])
-def test_dense_chain_gathered_inputs(in_mode):
-    g_ = torch.Generator().manual_seed(in_mode)
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_dense_chain_gathered_inputs(in_mode, d):
+    """in_mode 1 (X[a]*X[b], two square layers = elementwise_lin) and 2 (X[a]+X[b], one layer = the q projection)."""
+    g_ = torch.Generator().manual_seed(in_mode + d)
     r = lambda *s: torch.randn(*s, generator=g_).to(DEV)  # noqa: E731
-    n, d, m = 500, 128, 1111
+    n, m = 500, 1111
     xn = r(n, d)
     batch = torch.randint(0, n, (2, m), generator=g_).to(DEV)
     w1, b1, lg, lb, w2, b2 = r(d, d) / d ** 0.5, r(d), r(d), r(d), r(d, d) / d ** 0.5, r(d)
     dc = DenseChain("t")
-    xin = xn[batch[0]] * xn[batch[1]] if in_mode == 1 else xn[batch[0]] + xn[batch[1]]
-    out = dc.run(dc.tables(w1, b1, lg, lb, w2, b2), xn, relu=True, batch=batch, in_mode=in_mode)
-    ref = _chain_ref(xin, w1, b1, None, lg, lb, True, w2, b2)
+    if in_mode == 1:
+        out = dc.run(dc.tables(w1, b1, lg, lb, w2, b2), xn, relu=True, batch=batch, in_mode=1)
+        ref = _chain_ref(xn[batch[0]] * xn[batch[1]], w1, b1, None, lg, lb, True, w2, b2)
+    else:
+        out = dc.run(dc.tables(w1, b1), xn, relu=False, batch=batch, in_mode=2)
+        ref = _chain_ref(xn[batch[0]] + xn[batch[1]], w1, b1, None, None, None, False, None, None)
+    assert out is not None
     assert (out.double() - ref).abs().max().item() <= 3e-5
 
 
