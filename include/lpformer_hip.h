@@ -187,15 +187,17 @@ int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, 
  * :173-179 (mlp_score, N2 == 1 "dot mode": logit/prob out), the hoisted lin_l of layers.py:212-215 (in_mode 2) and the
  * attention-output projection + post_att_norm (layers.py:78; single layer with addend + LN).
  *   in_mode 0: x = X[m, :K1]; 1: x = X[a_m] * X[b_m]; 2: x = X[a_m] + X[b_m]  (batch: int64 [2, M], row stride batch_ld)
- *   w1_packed: layer-1 weights [N1, K1] in MFMA A-operand order.  k-group ks (16 input features) is nt1*64 float4:
- *              float4 (c, lane = 16q + i) = W1[16c + i][16ks + 4q + 0..3].  A stage is g consecutive k-groups
- *              (g = 4 if max(nt1, nt2) <= 9 else 2), zero padded to a multiple of 256 float4; missing k-groups of the
- *              last stage are zeros.  The image is the concatenation of ceil(K1 / (16 g)) stages.
- *              (nt1 = ceil(N1/16)); b1, ln_g, ln_b: nt1*16 floats, zero padded; ln_g NULL = no LayerNorm;
+ *   w1_packed: layer-1 weights [N1, K1] in MFMA A-operand order, output tiles padded to an even count
+ *              ntp1 = 2*ceil(N1/32).  k-group ks (16 input features) is ntp1*64 float4: float4 (c, lane = 16q + i) =
+ *              W1[16c + i][16ks + 4q + 0..3].  A stage is g consecutive k-groups (two layers: g = 2 if
+ *              max(ntp1, ntp2) <= 8 else 1; one layer: g = 4 if ntp1 <= 8, 2 if ntp1 <= 16, else 1), zero padded to a
+ *              multiple of 512 float4; missing k-groups of the last stage are zeros.  The image is the concatenation
+ *              of ceil(K1 / (16 g)) stages.
+ *              b1, ln_g, ln_b: ntp1*16 floats, zero padded; ln_g NULL = no LayerNorm;
  *              flags & LPF_FLAG_RELU: ReLU after (the LayerNorm of) layer 1; addend [M, N1] optional (N1 % 4 == 0)
- *   w2_packed: NULL = single layer (out [M, N1]); N2 == 1: plain zero-padded vector of nt1*16 floats, b2[0] the bias,
- *              out = logits [M] and/or prob = sigmoid [M]; otherwise [N2, N1] packed like w1 over the hidden features
- *              (nt2 = ceil(N2/16) tiles); b2: nt2*16 floats
+ *   w2_packed: NULL = single layer (out [M, N1]); N2 == 1: plain zero-padded vector of ntp1*16 floats, b2[0] the bias,
+ *              out = logits [M] and/or prob = sigmoid [M]; otherwise [N2, N1] packed like w1 over the ntp1 hidden
+ *              tiles as k-groups (ntp2 = 2*ceil(N2/32) output tiles); b2: ntp2*16 floats
  *   K1 % 4 == 0.  Built tile shapes (nt1, nt2): (2|4|8|16|32, 0), (2,2) (4,4) (8,8) (16,16), (3,2) (5,4) (9,8) (17,16);
  *   anything else returns LPF_ERR_UNSUPPORTED (callers then use lpf_gemm_f32 + lpf_layernorm_f32).
  *   lpformer_amd/fold.py builds the packed images. */

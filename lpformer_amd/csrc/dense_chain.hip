@@ -5,17 +5,19 @@
 //
 // Orientation: SAMPLES ON LANES.  v_mfma_f32_16x16x4_f32 computes D[i][j] += sum_k A[i][k] B[k][j] with lane
 // l = (q = l>>4, j = l&15) holding B[k=q][j] and, in the accumulator, D[4q + r][j] (r = register 0..3).  Here i is an
-// output feature, j one of 16 samples, so a wavefront owns 16 samples and
-//   * layer 1's B operand is the sample's own input row (the four lanes of a sample read 64 contiguous bytes per step
-//     group; or the product / sum of two gathered rows),
-//   * LayerNorm over features is an in-lane reduction plus two cross-lane steps,
-//   * layer 2's B operand for step (feature tile c, register r) IS accumulator register acc1[c][r] of the same lane:
-//     the hidden activations never leave the registers,
-//   * a 1-wide second layer (the score head) is an in-lane dot product.
+// output feature, j one of 16 samples.  A group of 16 samples is owned by a PAIR of wavefronts, each computing half of
+// the output-feature tiles of both layers (a batch of 32,768 samples is only 2,048 sample groups = 2 per SIMD, and a
+// SIMD needs >= 2 wavefronts *issuing* fp32 MFMAs to reach full rate; the pair doubles the wavefronts
+// and halves their registers, so 4 per SIMD are resident and barrier / load stalls of one are covered by the others):
+//   * layer 1's B operand is the sample's own input row (the four lanes of a sample read 64 contiguous bytes per
+//     k-group; or the product / sum of two gathered rows),
+//   * LayerNorm over features is an in-lane reduction, two cross-lane steps and one exchange with the partner wave,
+//   * the hidden activations go to LDS in exactly the accumulator layout, which IS the B-operand layout of layer 2
+//     (k-group t of layer 2 = hidden tile t), so layer 2 reads them back with one 16-byte LDS load per k-group,
+//   * a 1-wide second layer (the score head) is an in-lane dot product plus the same partner exchange.
 // Weights are the A operand: host-packed in MFMA order (layout below), staged global -> registers -> LDS one stage
-// ahead of the MFMAs that consume them (double-buffered LDS, one barrier per stage) and shared by the 4 wavefronts of
-// a workgroup; two workgroups per CU keep two waves per SIMD resident (one wave alone issues fp32 MFMAs at half rate,
-// DESIGN.md 5.1).  Tile counts are template constants (exact, no guards inside the MFMA streams); shapes without an
+// ahead of the MFMAs that consume them (double-buffered LDS, one barrier per stage) and shared by the 8 wavefronts of
+// a workgroup.  Tile counts are template constants (no guards inside the MFMA streams); shapes without an
 // instantiation return LPF_ERR_UNSUPPORTED and the host uses the unfused kernels.
 #include "lpf_common.h"
 
@@ -23,7 +25,9 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DC_WAVES = 4;      // wavefronts per workgroup
+constexpr int DC_GROUPS = 4;                 // 16-sample groups per workgroup
+constexpr int DC_WAVES = 2 * DC_GROUPS;      // wavefronts per workgroup (a pair per group)
+constexpr int DC_THREADS = 64 * DC_WAVES;
 
 struct DenseChainArgs {
     int64_t M;
@@ -41,44 +45,52 @@ struct DenseChainArgs {
     float *prob;                 // dot mode: sigmoid(logit) (may be NULL)
 };
 
-// Weight image (either layer): "k-group" ks holds the A operands of the four MFMA steps that consume input features
-// 16 ks .. 16 ks + 15 (lane q supplying B values 16 ks + 4 q + u): float4 (c, lane = 16q + i) of the group =
-// W[16c + i][16 ks + 4q + 0..3].  A stage = G consecutive k-groups (sq, c, lane), zero padded to a whole number of
-// float4 per thread (P * 256), so staging is branch-free; missing k-groups of the last stage are zeros.
+// k-groups (16 input features) per pipeline stage; fold.py::dense_stage_groups mirrors this.  Chosen so that the two
+// weight buffers plus the hidden exchange stay within ~80 KiB (two workgroups per CU).
+constexpr int dc_groups(int ntp1, int ntp2) {
+    if (ntp2 > 0) return (ntp1 > ntp2 ? ntp1 : ntp2) <= 8 ? 2 : 1;
+    return ntp1 <= 8 ? 4 : (ntp1 <= 16 ? 2 : 1);
+}
+
+// Weight image (either layer), tiles padded to an even count NTP: "k-group" ks holds the A operands of the four MFMA
+// steps that consume input features 16 ks .. 16 ks + 15 (lane q supplying B values 16 ks + 4 q + u): float4
+// (c, lane = 16q + i) of the group = W[16c + i][16 ks + 4q + 0..3].  A stage = G consecutive k-groups (sq, c, lane),
+// zero padded to a whole number of float4 per thread (P * 512), so staging is branch-free; missing k-groups of the
+// last stage and the padding tile are zeros.
 //
 // Pipeline per stage: [regs -> LDS buffer b] barrier [issue global loads of stage s+1 into regs] [MFMAs of stage s
 // from buffer b]; buffers alternate, so one barrier per stage is enough (a wave can only reach the write of buffer b
 // for stage s+2 after every wave has passed the barrier of stage s+1, i.e. finished reading b for stage s).
-template <int NT, int G>
-constexpr int dc_per_thread() { return (NT * G * 64 + 64 * DC_WAVES - 1) / (64 * DC_WAVES); }
+constexpr int dc_per_thread(int ntp, int g) { return (ntp * g * 64 + DC_THREADS - 1) / DC_THREADS; }
 
-template <int NT, int G, int P>
+template <int P>
 __device__ __forceinline__ void dc_stage_load(f32x4 (&r)[P], const float *packed, int stage, int tid) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(packed) + (int64_t)stage * (P * 64 * DC_WAVES);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(packed) + (int64_t)stage * (P * DC_THREADS);
 #pragma unroll
-    for (int e = 0; e < P; ++e) r[e] = src[e * 64 * DC_WAVES + tid];
+    for (int e = 0; e < P; ++e) r[e] = src[e * DC_THREADS + tid];
 }
 
-template <int NT, int G, int P>
+template <int P>
 __device__ __forceinline__ void dc_stage_store(const f32x4 (&r)[P], f32x4 *slab, int tid) {
 #pragma unroll
-    for (int e = 0; e < P; ++e) slab[e * 64 * DC_WAVES + tid] = r[e];
+    for (int e = 0; e < P; ++e) slab[e * DC_THREADS + tid] = r[e];
 }
 
-// acc[c] += sum over GG k-groups of W[16c+i][k] * B[k][j]; bv[sq]: the lane's four B values of k-group sq.
-// The (k-group, tile) operand blocks are walked in pairs with the next pair's LDS reads issued before the current
-// pair's eight MFMAs, and the two accumulators of a pair alternate so consecutive MFMAs are independent.
-template <int NT, int G, int GG>
-__device__ __forceinline__ void dc_mfma_n(f32x4 (&acc)[NT], const f32x4 *lw, int lane, const f32x4 (&bv)[G]) {
-    constexpr int T = GG * NT;  // operand blocks, block t = (sq = t / NT, c = t % NT)
-    const f32x4 *p = lw + lane;
-    f32x4 n0 = p[0], n1 = T > 1 ? p[64] : p[0];
+// acc[cc] += sum over GG k-groups of W[16 (c0 + cc) + i][k] * B[k][j] for this wave's TPW tiles; lw points at the
+// wave's first tile of k-group 0 (+ lane); consecutive k-groups are NTP tiles apart.  The operand blocks are walked in
+// pairs with the next pair's LDS reads issued before the current pair's eight MFMAs, and the two accumulators of a
+// pair alternate so consecutive MFMAs are independent.
+template <int TPW, int NTP, int G, int GG>
+__device__ __forceinline__ void dc_mfma_n(f32x4 (&acc)[TPW], const f32x4 *lw, const f32x4 (&bv)[G]) {
+    constexpr int T = GG * TPW;  // operand blocks, block t = (sq = t / TPW, cc = t % TPW)
+    auto at = [&](int t) -> const f32x4 & { return lw[((t / TPW) * NTP + (t % TPW)) * 64]; };
+    f32x4 n0 = at(0), n1 = T > 1 ? at(1) : at(0);
 #pragma unroll
     for (int t = 0; t < T; t += 2) {
         const f32x4 a0 = n0, a1 = n1;
-        if (t + 2 < T) n0 = p[(t + 2) * 64];
-        if (t + 3 < T) n1 = p[(t + 3) * 64];
-        const int s0 = t / NT, c0 = t % NT, s1 = (t + 1) / NT, c1 = (t + 1) % NT;
+        if (t + 2 < T) n0 = at(t + 2);
+        if (t + 3 < T) n1 = at(t + 3);
+        const int s0 = t / TPW, c0 = t % TPW, s1 = (t + 1) / TPW, c1 = (t + 1) % TPW;
         if (t + 1 < T) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -90,20 +102,21 @@ __device__ __forceinline__ void dc_mfma_n(f32x4 (&acc)[NT], const f32x4 *lw, int
             for (int u = 0; u < 4; ++u)
                 acc[c0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[s0][u], acc[c0], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at one pair (register budget: 128)
     }
 }
 
-template <int NT, int G>
-__device__ __forceinline__ void dc_mfma(f32x4 (&acc)[NT], const f32x4 *lw, int lane, const f32x4 (&bv)[G], int cnt) {
+template <int TPW, int NTP, int G>
+__device__ __forceinline__ void dc_mfma(f32x4 (&acc)[TPW], const f32x4 *lw, const f32x4 (&bv)[G], int cnt) {
     if (cnt == G) {
-        dc_mfma_n<NT, G, G>(acc, lw, lane, bv);
+        dc_mfma_n<TPW, NTP, G, G>(acc, lw, bv);
     } else {  // ragged last stage
         if constexpr (G == 4) {
-            if (cnt == 3) dc_mfma_n<NT, G, 3>(acc, lw, lane, bv);
-            else if (cnt == 2) dc_mfma_n<NT, G, 2>(acc, lw, lane, bv);
-            else dc_mfma_n<NT, G, 1>(acc, lw, lane, bv);
-        } else {
-            dc_mfma_n<NT, G, 1>(acc, lw, lane, bv);
+            if (cnt == 3) dc_mfma_n<TPW, NTP, G, 3>(acc, lw, bv);
+            else if (cnt == 2) dc_mfma_n<TPW, NTP, G, 2>(acc, lw, bv);
+            else dc_mfma_n<TPW, NTP, G, 1>(acc, lw, bv);
+        } else if constexpr (G == 2) {
+            dc_mfma_n<TPW, NTP, G, 1>(acc, lw, bv);
         }
     }
 }
@@ -140,20 +153,42 @@ __device__ __forceinline__ void dc_input_combine(const f32x4 (&a)[G], const f32x
     }
 }
 
-template <int NT1, int NT2, int G, int MODE>
-__global__ __launch_bounds__(64 * DC_WAVES) void dense_chain_kernel(const DenseChainArgs A) {
-    constexpr int P1 = dc_per_thread<NT1, G>(), P2 = dc_per_thread<(NT2 ? NT2 : 1), G>();
-    constexpr int SLAB = (P1 > P2 ? P1 : P2) * 64 * DC_WAVES;         // float4 per LDS buffer
-    extern __shared__ __attribute__((aligned(16))) f32x4 slab[];     // 2 buffers
+// LDS carve-up (float4 units): [2 weight buffers][hidden exchange: DC_GROUPS * NTP1 * 64][partner scalars]
+template <int NT1, int NT2, int G>
+struct DcLds {
+    static constexpr int NTP1 = (NT1 + 1) & ~1, NTP2 = (NT2 + 1) & ~1;
+    static constexpr int P1 = dc_per_thread(NTP1, G), P2 = dc_per_thread(NTP2 ? NTP2 : 2, G);
+    static constexpr int SLAB = (P1 > P2 ? P1 : P2) * DC_THREADS;
+    static constexpr int HID = NT2 > 0 ? DC_GROUPS * NTP1 * 64 : 0;
+    static constexpr int XCH = DC_WAVES * 16 / 4;  // one float per (wave, sample)
+    static constexpr size_t BYTES = (size_t)(2 * SLAB + HID + XCH) * sizeof(f32x4);
+};
+
+// two workgroups per CU (4 wavefronts per SIMD, <= 128 VGPRs) whenever their LDS fits twice
+template <int NT1, int NT2, int G>
+constexpr int dc_min_waves() { return 2 * DcLds<NT1, NT2, G>::BYTES <= 160 * 1024 ? 4 : 2; }
+
+template <int NT1, int NT2, int G, int MODE, int MINW>
+__global__ __launch_bounds__(DC_THREADS, MINW) void dense_chain_kernel(const DenseChainArgs A) {
+    using L = DcLds<NT1, NT2, G>;
+    constexpr int NTP1 = L::NTP1, NTP2 = L::NTP2, TPW1 = NTP1 / 2, TPW2 = NTP2 / 2;
+    constexpr int P1 = L::P1, P2 = L::P2, SLAB = L::SLAB;
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    f32x4 *hid = lds + 2 * SLAB;
+    float *xch = reinterpret_cast<float *>(lds + 2 * SLAB + L::HID);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 1, half = wave & 1;   // sample group of the workgroup; which half of the feature tiles
     const int q = lane >> 4, j = lane & 15;
     const int ng1 = (A.K1 + 15) >> 4;             // k-groups of layer 1
-    constexpr int NS2 = (NT1 + G - 1) / G;        // stages of layer 2 (k-groups = hidden tiles)
+    constexpr int NS2 = (NTP1 + G - 1) / G;       // stages of layer 2 (k-groups = hidden tiles)
+    float *my_x = xch + wave * 16 + j;            // partner exchange slots (one float per sample)
+    const float *peer_x = xch + (wave ^ 1) * 16 + j;
     int buf = 0;
 
-#pragma unroll 1
-    for (int64_t m0 = (int64_t)blockIdx.x * (16 * DC_WAVES); m0 < A.M; m0 += (int64_t)gridDim.x * (16 * DC_WAVES)) {
-        const int64_t m = m0 + wave * 16 + j;
+    {   // one block of 64 samples per workgroup (no persistent loop: loop-invariant operand addresses hoisted out of
+        // it cost ~60 registers, and the weight staging is per 64 samples either way)
+        const int64_t m0 = (int64_t)blockIdx.x * (16 * DC_GROUPS);
+        const int64_t m = m0 + grp * 16 + j;
         const bool live = m < A.M;
         const int64_t mm = live ? m : A.M - 1;  // clamp: dead lanes compute on a valid row and store nothing
         int64_t ra = mm, rb = 0;
@@ -163,81 +198,82 @@ __global__ __launch_bounds__(64 * DC_WAVES) void dense_chain_kernel(const DenseC
         }
         const float *xa = A.X + ra * A.ldx, *xb = A.X + rb * A.ldx;
 
-        // ---------------- layer 1
-        f32x4 acc1[NT1];
+        // ---------------- layer 1: this wave's tiles half*TPW1 .. half*TPW1 + TPW1 - 1
+        f32x4 acc1[TPW1];
 #pragma unroll
-        for (int c = 0; c < NT1; ++c) acc1[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < TPW1; ++c) acc1[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         {
             f32x4 wr[P1], xra[G], xrb[G];
-            dc_stage_load<NT1, G>(wr, A.w1p, 0, tid);
+            dc_stage_load<P1>(wr, A.w1p, 0, tid);
             dc_input_load<G, MODE>(xra, xrb, A, xa, xb, 0, q);
 #pragma unroll 1
             for (int g0 = 0; g0 < ng1; g0 += G) {
                 const int cnt = ng1 - g0 < G ? ng1 - g0 : G;
                 f32x4 bv[G];
                 dc_input_combine<G, MODE>(xra, xrb, A, g0, q, bv);
-                f32x4 *lw = slab + buf * SLAB;
-                dc_stage_store<NT1, G>(wr, lw, tid);
+                f32x4 *lw = lds + buf * SLAB;
+                dc_stage_store<P1>(wr, lw, tid);
                 __syncthreads();
                 if (g0 + G < ng1) {  // next stage's operands fly while this stage's MFMAs run
-                    dc_stage_load<NT1, G>(wr, A.w1p, g0 / G + 1, tid);
+                    dc_stage_load<P1>(wr, A.w1p, g0 / G + 1, tid);
                     dc_input_load<G, MODE>(xra, xrb, A, xa, xb, g0 + G, q);
                 }
-                dc_mfma<NT1, G>(acc1, lw, lane, bv, cnt);
+                dc_mfma<TPW1, NTP1, G>(acc1, lw + (half * TPW1) * 64 + lane, bv, cnt);
                 buf ^= 1;
             }
         }
         // layer 2's first weight stage flies during the epilogue
         f32x4 w2r[P2];
-        if constexpr (NT2 > 0) dc_stage_load<NT2, G>(w2r, A.w2p, 0, tid);
+        if constexpr (NT2 > 0) dc_stage_load<P2>(w2r, A.w2p, 0, tid);
 
         // epilogue 1: bias (+ addend) -> LayerNorm over the N1 real features -> ReLU
-        float s1 = 0.f;
+        const int fbase = 16 * half * TPW1 + 4 * q;  // first feature of this lane's register quad in tile 0
 #pragma unroll
-        for (int c = 0; c < NT1; ++c) {
-            const int f0 = 16 * c + 4 * q;
-            const float4 b = *reinterpret_cast<const float4 *>(A.b1 + f0);  // padded with zeros by the host
-            acc1[c][0] += b.x; acc1[c][1] += b.y; acc1[c][2] += b.z; acc1[c][3] += b.w;
-        }
-        if (A.addend) {  // all rows' pieces in flight together; columns clamped into the row, pads add nothing
-            f32x4 ad[NT1];
+        for (int c = 0; c < TPW1; ++c)
+            acc1[c] += *reinterpret_cast<const f32x4 *>(A.b1 + fbase + 16 * c);  // padded with zeros by the host
+        if (A.addend) {  // all pieces in flight together; columns clamped into the row, pads add nothing
+            f32x4 ad[TPW1];
 #pragma unroll
-            for (int c = 0; c < NT1; ++c) {
-                const int f0 = 16 * c + 4 * q;
+            for (int c = 0; c < TPW1; ++c) {
+                const int f0 = fbase + 16 * c;
                 ad[c] = *reinterpret_cast<const f32x4 *>(A.addend + mm * A.ldadd + (f0 < A.N1 ? f0 : 0));
             }
 #pragma unroll
-            for (int c = 0; c < NT1; ++c)
-                acc1[c] += (16 * c + 4 * q < A.N1) ? ad[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < TPW1; ++c)
+                acc1[c] += (fbase + 16 * c < A.N1) ? ad[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-#pragma unroll
-        for (int c = 0; c < NT1; ++c) s1 += acc1[c][0] + acc1[c][1] + acc1[c][2] + acc1[c][3];
         if (A.ln_g) {
-            const float mean = dc_quad_sum(s1) / (float)A.N1;  // padded features are exactly 0 and add nothing
+            float s1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < TPW1; ++c) s1 += acc1[c][0] + acc1[c][1] + acc1[c][2] + acc1[c][3];
+            s1 = dc_quad_sum(s1);  // padded features are exactly 0 and add nothing
+            if (q == 0) *my_x = s1;
+            __syncthreads();
+            const float mean = (half == 0 ? s1 + *peer_x : *peer_x + s1) / (float)A.N1;  // same order in both waves
+            __syncthreads();       // slots free for the second exchange
             float s2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < NT1; ++c) {
+            for (int c = 0; c < TPW1; ++c) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float d = (16 * c + 4 * q + r < A.N1) ? acc1[c][r] - mean : 0.f;
+                    const float d = (fbase + 16 * c + r < A.N1) ? acc1[c][r] - mean : 0.f;
                     s2 += d * d;
                 }
             }
-            const float rstd = 1.0f / sqrtf(dc_quad_sum(s2) / (float)A.N1 + 1e-5f);
+            s2 = dc_quad_sum(s2);
+            if (q == 0) *my_x = s2;
+            __syncthreads();
+            const float rstd = 1.0f / sqrtf((half == 0 ? s2 + *peer_x : *peer_x + s2) / (float)A.N1 + 1e-5f);
 #pragma unroll
-            for (int c = 0; c < NT1; ++c) {
-                const int f0 = 16 * c + 4 * q;
-                const float4 g = *reinterpret_cast<const float4 *>(A.ln_g + f0);  // zero-padded: pads come out 0
-                const float4 be = *reinterpret_cast<const float4 *>(A.ln_b + f0);
-                acc1[c][0] = (acc1[c][0] - mean) * rstd * g.x + be.x;
-                acc1[c][1] = (acc1[c][1] - mean) * rstd * g.y + be.y;
-                acc1[c][2] = (acc1[c][2] - mean) * rstd * g.z + be.z;
-                acc1[c][3] = (acc1[c][3] - mean) * rstd * g.w + be.w;
+            for (int c = 0; c < TPW1; ++c) {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(A.ln_g + fbase + 16 * c);  // zero-padded: pads -> 0
+                const f32x4 be = *reinterpret_cast<const f32x4 *>(A.ln_b + fbase + 16 * c);
+                acc1[c] = (acc1[c] - mean) * rstd * g + be;
             }
         }
         if (A.flags & LPF_FLAG_RELU) {
 #pragma unroll
-            for (int c = 0; c < NT1; ++c)
+            for (int c = 0; c < TPW1; ++c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc1[c][r] = fmaxf(acc1[c][r], 0.f);
         }
@@ -245,54 +281,58 @@ __global__ __launch_bounds__(64 * DC_WAVES) void dense_chain_kernel(const DenseC
         if constexpr (NT2 == 0) {
             if (!A.w2p) {  // single layer: store [M, N1]
 #pragma unroll
-                for (int c = 0; c < NT1; ++c) {
-                    const int f0 = 16 * c + 4 * q;
-                    if (live && f0 < A.N1)
-                        *reinterpret_cast<float4 *>(A.out + m * A.ldo + f0) =
-                            make_float4(acc1[c][0], acc1[c][1], acc1[c][2], acc1[c][3]);
+                for (int c = 0; c < TPW1; ++c) {
+                    const int f0 = fbase + 16 * c;
+                    if (live && f0 < A.N1) *reinterpret_cast<f32x4 *>(A.out + m * A.ldo + f0) = acc1[c];
                 }
             } else {  // 1-wide second layer: logit = w2 . hidden + b2
                 float d = 0.f;
 #pragma unroll
-                for (int c = 0; c < NT1; ++c) {
-                    const float4 w = *reinterpret_cast<const float4 *>(A.w2p + 16 * c + 4 * q);  // zero-padded
-                    d = fmaf(acc1[c][0], w.x, fmaf(acc1[c][1], w.y, fmaf(acc1[c][2], w.z, fmaf(acc1[c][3], w.w, d))));
+                for (int c = 0; c < TPW1; ++c) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(A.w2p + fbase + 16 * c);  // zero-padded
+                    d = fmaf(acc1[c][0], w[0], fmaf(acc1[c][1], w[1], fmaf(acc1[c][2], w[2], fmaf(acc1[c][3], w[3], d))));
                 }
-                d = dc_quad_sum(d) + A.b2[0];
-                if (live && q == 0) {
+                d = dc_quad_sum(d);
+                __syncthreads();  // (the LayerNorm exchange, if any, has been read by everyone)
+                if (q == 0) *my_x = d;
+                __syncthreads();
+                if (live && q == 0 && half == 0) {
+                    d = d + *peer_x + A.b2[0];
                     if (A.out) A.out[m] = d;
                     if (A.prob) A.prob[m] = 1.0f / (1.0f + expf(-d));
                 }
             }
         } else {
-            // ---------------- layer 2: the B operand of k-group t (hidden tile t) is acc1[t] itself
-            f32x4 acc2[NT2];
+            // ---------------- layer 2: hidden tile t (all NTP1 of the group) is k-group t, read back from LDS in the
+            // accumulator layout, which is the B-operand layout
+            f32x4 *my_hid = hid + (grp * NTP1) * 64 + lane;
 #pragma unroll
-            for (int c = 0; c < NT2; ++c) acc2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < TPW1; ++c) my_hid[(half * TPW1 + c) * 64] = acc1[c];
+            f32x4 acc2[TPW2];
+#pragma unroll
+            for (int c = 0; c < TPW2; ++c) acc2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < NS2; ++st) {
-                const int cnt = NT1 - st * G < G ? NT1 - st * G : G;
+                const int cnt = NTP1 - st * G < G ? NTP1 - st * G : G;
+                f32x4 *lw = lds + buf * SLAB;
+                dc_stage_store<P2>(w2r, lw, tid);
+                __syncthreads();  // (stage 0: also publishes the hidden tiles)
+                if (st + 1 < NS2) dc_stage_load<P2>(w2r, A.w2p, st + 1, tid);
                 f32x4 bv[G];
 #pragma unroll
-                for (int sq = 0; sq < G; ++sq) {
-                    const int t = st * G + sq;
-                    bv[sq] = t < NT1 ? acc1[t < NT1 ? t : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                f32x4 *lw = slab + buf * SLAB;
-                dc_stage_store<NT2, G>(w2r, lw, tid);
-                __syncthreads();
-                if (st + 1 < NS2) dc_stage_load<NT2, G>(w2r, A.w2p, st + 1, tid);
-                dc_mfma<NT2, G>(acc2, lw, lane, bv, cnt);
+                for (int sq = 0; sq < G; ++sq)
+                    bv[sq] = st * G + sq < NTP1 ? my_hid[(st * G + sq < NTP1 ? st * G + sq : 0) * 64]
+                                                : (f32x4){0.f, 0.f, 0.f, 0.f};
+                dc_mfma<TPW2, NTP2, G>(acc2, lw + (half * TPW2) * 64 + lane, bv, cnt);
                 buf ^= 1;
             }
+            const int fb2 = 16 * half * TPW2 + 4 * q;
 #pragma unroll
-            for (int c = 0; c < NT2; ++c) {
-                const int f0 = 16 * c + 4 * q;
-                if (live && f0 < A.N2) {
-                    const float4 b = *reinterpret_cast<const float4 *>(A.b2 + f0);
-                    *reinterpret_cast<float4 *>(A.out + m * A.ldo + f0) =
-                        make_float4(acc2[c][0] + b.x, acc2[c][1] + b.y, acc2[c][2] + b.z, acc2[c][3] + b.w);
-                }
+            for (int c = 0; c < TPW2; ++c) {
+                const int f0 = fb2 + 16 * c;
+                if (live && f0 < A.N2)
+                    *reinterpret_cast<f32x4 *>(A.out + m * A.ldo + f0) =
+                        acc2[c] + *reinterpret_cast<const f32x4 *>(A.b2 + f0);
             }
         }
     }
@@ -300,11 +340,10 @@ __global__ __launch_bounds__(64 * DC_WAVES) void dense_chain_kernel(const DenseC
 
 template <int NT1, int NT2, int MODE>
 int dc_launch(const DenseChainArgs &a, hipStream_t s) {
-    constexpr int slab_tiles = NT1 > NT2 ? NT1 : NT2;
-    constexpr int G = slab_tiles <= 9 ? 4 : 2;  // k-groups per stage: 64 (narrow layers) or 32 input features
-    constexpr int P1 = dc_per_thread<NT1, G>(), P2 = dc_per_thread<(NT2 ? NT2 : 1), G>();
-    constexpr size_t lds = 2 * (size_t)(P1 > P2 ? P1 : P2) * 64 * DC_WAVES * sizeof(float4);
-    auto kern = dense_chain_kernel<NT1, NT2, G, MODE>;
+    constexpr int NTP1 = (NT1 + 1) & ~1, NTP2 = (NT2 + 1) & ~1;
+    constexpr int G = dc_groups(NTP1, NTP2);
+    constexpr size_t lds = DcLds<NT1, NT2, G>::BYTES;
+    auto kern = dense_chain_kernel<NT1, NT2, G, MODE, dc_min_waves<NT1, NT2, G>()>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -313,9 +352,9 @@ int dc_launch(const DenseChainArgs &a, hipStream_t s) {
             return LPF_ERR_LAUNCH;
         }
     }
-    int64_t blocks = (a.M + 16 * DC_WAVES - 1) / (16 * DC_WAVES);
-    if (blocks > 2048) blocks = 2048;  // persistent beyond eight workgroups per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * DC_WAVES), lds, s, a);
+    const int64_t blocks = (a.M + 16 * DC_GROUPS - 1) / (16 * DC_GROUPS);
+    if (blocks > 0x7fffffff) return LPF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(DC_THREADS), lds, s, a);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
@@ -340,6 +379,7 @@ extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, i
     LPF_REQUIRE(dot ? (out || prob) : (out && (ldo & 3) == 0 && lpf_aligned16(out)));
     LPF_REQUIRE(dot || ((two ? N2 : N1) & 3) == 0);
     LPF_REQUIRE(dot || ldo >= (two ? N2 : N1));
+    LPF_REQUIRE(dot || !two || lpf_aligned16(b2));
     const int nt1 = (N1 + 15) / 16, nt2 = (two && !dot) ? (N2 + 15) / 16 : 0;
     DenseChainArgs a{M, in_mode, X, ldx, batch, batch_ld, K1, w1_packed, N1, b1, addend, ldadd, ln_g, ln_b, flags,
                      w2_packed, N2, b2, out, ldo, prob};

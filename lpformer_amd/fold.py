@@ -84,33 +84,42 @@ def _pad_to(a: np.ndarray, n: int) -> np.ndarray:
 
 
 def dense_stage_groups(nt1: int, nt2: int) -> int:
-    """k-groups (16 input features each) per pipeline stage of lpf_dense_chain_f32 for a (nt1, nt2)-tile chain."""
-    return 4 if max(nt1, nt2) <= 9 else 2
+    """k-groups (16 input features each) per pipeline stage of lpf_dense_chain_f32 for a (nt1, nt2)-tile chain
+    (mirrors dc_groups in csrc/dense_chain.hip; tile counts are padded to even there)."""
+    p1, p2 = (nt1 + 1) & ~1, (nt2 + 1) & ~1
+    if p2 > 0:
+        return 2 if max(p1, p2) <= 8 else 1
+    return 4 if p1 <= 8 else (2 if p1 <= 16 else 1)
 
 
-def pack_dense(w: np.ndarray, g: int) -> np.ndarray:
-    """[N, K] -> lpf_dense_chain_f32 weight image (either layer).  k-group ks: float4 (c, lane = 16q + i) =
-    W[16c + i][16ks + 4q + 0..3]; a stage = ``g`` consecutive k-groups, zero padded to a multiple of 256 float4."""
+def pack_dense(w: np.ndarray, g: int, k_groups: int = 0) -> np.ndarray:
+    """[N, K] -> lpf_dense_chain_f32 weight image (either layer).  Output tiles are padded to an even count; k-group
+    ks: float4 (c, lane = 16q + i) = W[16c + i][16ks + 4q + 0..3]; a stage = ``g`` consecutive k-groups, zero padded
+    to a multiple of 512 float4.  ``k_groups``: number of k-groups to lay out when larger than ceil(K / 16) (layer 2
+    runs over the padded hidden tiles of layer 1)."""
     n, k = w.shape
-    nt, ns = (n + 15) // 16, (k + 16 * g - 1) // (16 * g)
+    nt = ((n + 15) // 16 + 1) & ~1
+    ng = max((k + 15) // 16, k_groups)
+    ns = (ng + g - 1) // g
     wp = np.zeros((nt * 16, ns * g * 16), np.float32)
     wp[:n, :k] = w
     r = wp.reshape(nt, 16, ns, g, 4, 4)           # c, i, stage, sq, q, u
     r = np.ascontiguousarray(r.transpose(2, 3, 0, 4, 1, 5)).reshape(ns, g * nt * 64 * 4)
-    per_stage = -(-(g * nt * 64) // 256) * 256 * 4
+    per_stage = -(-(g * nt * 64) // 512) * 512 * 4
     out = np.zeros((ns, per_stage), np.float32)
     out[:, :r.shape[1]] = r
     return out.reshape(-1)
 
 
 def dense_chain_tables(w1, b1, ln_g=None, ln_b=None, w2=None, b2=None) -> dict:
-    """fp32 arrays for one lpf_dense_chain_f32 call (all zero padded to 16-feature tiles)."""
+    """fp32 arrays for one lpf_dense_chain_f32 call (vectors zero padded to an even number of 16-feature tiles)."""
     w1 = np.asarray(w1, np.float32)
     n1 = w1.shape[0]
-    p1 = ((n1 + 15) // 16) * 16
+    nt1 = (n1 + 15) // 16
+    p1 = ((nt1 + 1) & ~1) * 16
     dot = w2 is not None and np.asarray(w2).shape[0] == 1
     nt2 = 0 if (w2 is None or dot) else (np.asarray(w2).shape[0] + 15) // 16
-    g = dense_stage_groups(p1 // 16, nt2)
+    g = dense_stage_groups(nt1, nt2)
     out = {"w1p": pack_dense(w1, g), "b1": _pad_to(np.asarray(b1, np.float32), p1)}
     if ln_g is not None:
         out["ln_g"], out["ln_b"] = _pad_to(np.asarray(ln_g, np.float32), p1), _pad_to(np.asarray(ln_b, np.float32), p1)
@@ -119,5 +128,6 @@ def dense_chain_tables(w1, b1, ln_g=None, ln_b=None, w2=None, b2=None) -> dict:
         if dot:
             out["w2p"], out["b2"] = _pad_to(w2, p1), np.asarray(b2, np.float32).reshape(-1)[:1].copy()
         else:
-            out["w2p"], out["b2"] = pack_dense(w2, g), _pad_to(np.asarray(b2, np.float32), nt2 * 16)
+            out["w2p"] = pack_dense(w2, g, k_groups=p1 // 16)
+            out["b2"] = _pad_to(np.asarray(b2, np.float32), ((nt2 + 1) & ~1) * 16)
     return out

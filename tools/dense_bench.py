@@ -6,7 +6,8 @@ sys.path.insert(0, ".")
 from lpformer_amd.link_transformer import DenseChain, gemm, layernorm_  # noqa: E402
 
 DEV = "cuda:0"
-M, D, N = 32768, 128, 235868
+import os
+M, D, N = int(os.environ.get("DC_M", 32768)), 128, 235868
 
 
 def timeit(fn, reps=50):
