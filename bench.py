@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="pairs timed on the CPU oracle")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
 
     rank, world, local = LD.init_from_env()
@@ -119,8 +121,16 @@ def main():
         feats = model.pair_features(batches[i % len(batches)], h)
         return score(feats)
 
-    for i in range(args.warmup):
-        step(i)
+    # consecutive steps rotate over `--streams` HIP streams: the selection kernels of one batch (latency / issue
+    # bound) run under the MFMA kernels of the previous one.  Every step still does all of its work.
+    lanes = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))]
+
+    def step_on(i):
+        with torch.cuda.stream(lanes[i % len(lanes)]):
+            return step(i)
+
+    for i in range(max(args.warmup, len(lanes))):
+        step_on(i)
     torch.cuda.synchronize()
 
     # ---- timed region: EXACTLY `steps` steps, nothing but the scoring path (no event recording)
@@ -129,7 +139,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(i)
+        out = step_on(i)
     torch.cuda.synchronize()
     barrier()
     elapsed = LD.max_over_ranks(time.perf_counter() - t0, dev)
@@ -265,6 +275,7 @@ def main():
                                    f"PPR eps={cfg['eps']}), {bs} candidate pairs per GPU per step, pair stage with "
                                    "encoder output resident",
                        "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
+                       "streams": len(lanes),
                        "parallelism": f"pairs sharded x{world}, encoder row-sharded + all-gather" if world > 1
                        else "single GPU"},
             "encoder_ms": round(encoder_ms, 4), "value_incl_encoder": round(value_incl_encoder, 1),

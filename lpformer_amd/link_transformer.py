@@ -505,11 +505,14 @@ class LinkTransformer(nn.Module):
         return self._x_cache[1]
 
     def _workspace(self, name: str, numel: int, dtype) -> torch.Tensor:
-        t = self._ws.get(name)
+        """Named scratch buffer of the CURRENT stream (callers may pipeline batches on several streams; each stream
+        owns its own set, allocated under that stream so the caching allocator orders its reuse correctly)."""
+        key = (name, _stream(self.device))
+        t = self._ws.get(key)
         if t is None or t.numel() < numel or t.dtype != dtype:
             grow = int(numel * 1.25) + 64
             t = torch.empty(grow, dtype=dtype, device=self.device)
-            self._ws[name] = t
+            self._ws[key] = t
         return t
 
     # ---------------------------------------------------------------------------------- folded weights
@@ -584,7 +587,9 @@ class LinkTransformer(nn.Module):
         """Z = X_node W_rx^T + b_r, once per encoder output (cached on the tensor's identity and version)."""
         key = (x_node.data_ptr(), x_node._version, tuple(x_node.shape))
         if self._z_cache is None or self._z_cache[0] != key:
-            self._z_cache = (key, gemm(_as_f32_rows(x_node), w["w_rx"], w["b_r"], tag="gemm_node_keys"))
+            z = gemm(_as_f32_rows(x_node), w["w_rx"], w["b_r"], tag="gemm_node_keys")
+            torch.cuda.current_stream(self.device).synchronize()  # once per encoder output: other streams may read Z
+            self._z_cache = (key, z)
         return self._z_cache[1]
 
     # ---------------------------------------------------------------------------------- selection
@@ -681,9 +686,13 @@ class LinkTransformer(nn.Module):
         if not self.use_side_stream or KernelTimer.enabled:  # per-kernel timing wants serial launches
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(self.device)
-        self._side.wait_stream(torch.cuda.current_stream(self.device))
-        return self._side
+            self._side = {}
+        main = torch.cuda.current_stream(self.device)
+        side = self._side.get(main.cuda_stream)
+        if side is None:
+            side = self._side[main.cuda_stream] = torch.cuda.Stream(self.device)
+        side.wait_stream(main)
+        return side
 
     def calc_pairwise(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False, _out=None):
         """Pairwise branch (:132-178): selection -> PE + attention -> counts -> ``pairwise_lin``.

@@ -106,3 +106,25 @@ def test_pyg_style_facade_matches_core():
     assert (want - got).abs().max().item() <= 1e-6
     sp = lpformer_amd.LPFormer.calc_sparse_ppr(torch.from_numpy(ei), n, 0.15, cfg["eps"])
     assert sp._nnz() == ppr.nnz
+
+
+def test_batches_pipelined_on_two_streams_match_serial():
+    """Consecutive batches issued on alternating HIP streams (per-stream workspaces, side streams for the
+    elementwise / q branches) give bit-identical scores to the strictly serial single-stream run."""
+    cfg, n, ei, w, x, data, args, model, score, _ = _setup("cora", bs=2048)
+    h = model.propagate()
+    batches = [torch.from_numpy(D.sample_pairs(ei, n, 2048 + 100 * i, seed=50 + i)).to(DEV) for i in range(6)]
+    model.use_side_stream = False
+    serial = [score.logits(model.pair_features(b, h)).clone() for b in batches]
+    torch.cuda.synchronize()
+    model.use_side_stream = True
+    lanes = [torch.cuda.Stream(DEV) for _ in range(2)]
+    outs = []
+    for rep in range(3):  # repeated so that workspaces are reused while the other lane is still running
+        outs = []
+        for i, b in enumerate(batches):
+            with torch.cuda.stream(lanes[i % 2]):
+                outs.append(score.logits(model.pair_features(b, h)))
+    torch.cuda.synchronize()
+    for a, b in zip(serial, outs):
+        assert torch.equal(a, b)
