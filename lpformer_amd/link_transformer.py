@@ -26,7 +26,9 @@ from .profile import KernelTimer
 
 
 def _stream(device):
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw hipStream_t of torch's current stream on ``device`` (the stream every C-ABI launch goes to)."""
+    idx = device.index if isinstance(device, torch.device) and device.index is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 def _glorot(t: torch.Tensor):
@@ -428,6 +430,7 @@ class LinkTransformer(nn.Module):
         self._z_cache = None   # (key, Z)
         self._x_cache = None   # (key, padded features)
         self._ws = {}          # named workspaces
+        self._param_list = None  # cached list(self.parameters()) for the fold key
         self._chain_q = DenseChain("dense_chain_q")            # lin_l(x_a + x_b)
         self._chain_att = DenseChain("dense_chain_attn_out")   # attention output projection + post_att_norm
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
@@ -504,10 +507,10 @@ class LinkTransformer(nn.Module):
             self._x_cache = (key, _as_f32_rows(x.detach().to(self.device)))
         return self._x_cache[1]
 
-    def _workspace(self, name: str, numel: int, dtype) -> torch.Tensor:
+    def _workspace(self, name: str, numel: int, dtype, st=None) -> torch.Tensor:
         """Named scratch buffer of the CURRENT stream (callers may pipeline batches on several streams; each stream
         owns its own set, allocated under that stream so the caching allocator orders its reuse correctly)."""
-        key = (name, _stream(self.device))
+        key = (name, st if st is not None else _stream(self.device))
         t = self._ws.get(key)
         if t is None or t.numel() < numel or t.dtype != dtype:
             grow = int(numel * 1.25) + 64
@@ -517,8 +520,9 @@ class LinkTransformer(nn.Module):
 
     # ---------------------------------------------------------------------------------- folded weights
     def _fold(self):
-        params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params) + (str(self.device),)
+        if self._param_list is None:
+            self._param_list = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in self._param_list)
         if self._folded is not None and self._folded[0] == key:
             return self._folded[1]
         sd = {k: v for k, v in self.state_dict().items()}
@@ -610,20 +614,20 @@ class LinkTransformer(nn.Module):
             selfp = self._self_ppr(mask_obj, ppr_obj, adjx, ppr)
             ppr = self._device_graph("p1", ppr_obj)
 
-        offs = self._workspace("select_offs", 2 * (bs + 1), torch.int64)
-        desc = self._workspace("select_desc", 16 * bs, torch.int64)
-        scratch = self._workspace("scan_scratch", 3 * ((bs + 255) // 256) + 3, torch.int64)
+        offs = self._workspace("select_offs", 2 * (bs + 1), torch.int64, st)
+        desc = self._workspace("select_desc", 16 * bs, torch.int64, st)
+        scratch = self._workspace("scan_scratch", 3 * ((bs + 255) // 256) + 3, torch.int64, st)
         with KernelTimer.span("select_bound"):
             check(lib.lpf_select_bound(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(ppr.rowptr),
                                        ptr(t0.rowptr) if want_t0 else None, ptr(offs), ptr(desc), ptr(scratch), st),
                   "lpf_select_bound")
         # one 16-byte read-back sizes the staging area and the work-item table
         cap, n_items = (int(v) for v in offs[bs:2 * bs + 2:bs + 1].tolist())
-        stage_node = self._workspace("stage_node", cap, torch.int32)
-        stage_pa = self._workspace("stage_pa", cap, torch.float32)
-        stage_pb = self._workspace("stage_pb", cap, torch.float32)
-        stage_cnt = self._workspace("stage_cnt", 4 * bs, torch.int32)
-        items = self._workspace("select_items", 16 * n_items, torch.int32)
+        stage_node = self._workspace("stage_node", cap, torch.int32, st)
+        stage_pa = self._workspace("stage_pa", cap, torch.float32, st)
+        stage_pb = self._workspace("stage_pb", cap, torch.float32, st)
+        stage_cnt = self._workspace("stage_cnt", 4 * bs, torch.int32, st)
+        items = self._workspace("select_items", 16 * n_items, torch.int32, st)
         with KernelTimer.span("select_nodes"):
             check(lib.lpf_select_nodes(bs, n_items, ptr(offs), ptr(desc), ptr(items), ptr(adj.col), ptr(selfp),
                                        ptr(adjx.rowptr), ptr(adjx.col), 1 if adj is adjx else 0, ptr(ppr.col),
@@ -634,14 +638,14 @@ class LinkTransformer(nn.Module):
                   "lpf_select_nodes")
         ldf = _pad4(self.dim + self.count_dim)
         feats = torch.zeros(bs, ldf, dtype=torch.float32, device=self.device)  # [att out | counts | pad]
-        type_ptr = self._workspace("type_ptr", 3 * (bs + 1), torch.int64)
+        type_ptr = self._workspace("type_ptr", 3 * (bs + 1), torch.int64, st)
         with KernelTimer.span("select_scan"):
             check(lib.lpf_select_scan(bs, ptr(stage_cnt), ptr(type_ptr), feats.data_ptr() + 4 * self.dim, ldf,
                                       1 if want_t0 else 0, ptr(scratch), st), "lpf_select_scan")
-        sel_pair = self._workspace("sel_pair", cap, torch.int32)
-        sel_node = self._workspace("sel_node", cap, torch.int32)
-        sel_pa = self._workspace("sel_pa", cap, torch.float32)
-        sel_pb = self._workspace("sel_pb", cap, torch.float32)
+        sel_pair = self._workspace("sel_pair", cap, torch.int32, st)
+        sel_node = self._workspace("sel_node", cap, torch.int32, st)
+        sel_pa = self._workspace("sel_pa", cap, torch.float32, st)
+        sel_pb = self._workspace("sel_pb", cap, torch.float32, st)
         with KernelTimer.span("select_compact"):
             check(lib.lpf_select_compact(bs, ptr(desc), ptr(offs), ptr(stage_node), ptr(stage_pa), ptr(stage_pb),
                                          ptr(stage_cnt), ptr(type_ptr), ptr(sel_pair), ptr(sel_node), ptr(sel_pa),
@@ -722,7 +726,7 @@ class LinkTransformer(nn.Module):
             s = self._select(batch, test_set, adj_mask)
             if side is not None:
                 torch.cuda.current_stream(self.device).wait_stream(side)  # q (and the elementwise branch) are done
-            score = self._workspace("score", s["cap"], torch.float32)
+            score = self._workspace("score", s["cap"], torch.float32, st)
             with KernelTimer.span("pair_scores"):
                 check(lib.lpf_pair_scores_f32(d, ptr(s["type_ptr"]), bs, ptr(s["sel_pair"]), ptr(s["sel_node"]),
                                               ptr(s["sel_pa"]), ptr(s["sel_pb"]), ptr(z), z.stride(0), ptr(q),
@@ -736,7 +740,7 @@ class LinkTransformer(nn.Module):
                 check(lib.lpf_pair_softmax_gather_f32(d, bs, ptr(s["type_ptr"]), ptr(s["sel_node"]), ptr(s["sel_pa"]),
                                                       ptr(s["sel_pb"]), ptr(score), ptr(z), z.stride(0),
                                                       ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(g), ldg, ptr(alpha),
-                                                      ptr(self._workspace("sg_heavy", bs + 1, torch.int32)), st),
+                                                      ptr(self._workspace("sg_heavy", bs + 1, torch.int32, st)), st),
                       "lpf_pair_softmax_gather_f32")
             feats = s["feats"]
             att_view = feats[:, :d]
