@@ -103,7 +103,9 @@ int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t bat
  *         offs[bs] = total;  offs[(bs+1)+k] = first work item of pair k, offs[(bs+1)+bs] = number of items
  *         (a pair is ONE item when deg(a)+deg(b) <= 512, else ceil(deg a/512)+ceil(deg b/512) slices)
  *   desc  int64[16*bs]: row starts/lengths of pair k (adjacency, PPR, T0 rows of a and b), one 128-byte line
- *   scratch int64[LPF_SELECT_SCRATCH_ELEMS(bs)] (block sums of the two-kernel scans) */
+ *   scratch int64[LPF_SELECT_SCRATCH_ELEMS(bs)] (block sums of the two-kernel scans); on return its last three
+ *         words start with the two totals {offs[bs], offs[(bs+1)+bs]} side by side: with nb = ceil(bs/256),
+ *         scratch[3*nb] = staging slots, scratch[3*nb+1] = work items (one 16-byte device-to-host copy) */
 #define LPF_SELECT_SCRATCH_ELEMS(bs) (3 * (((bs) + 255) / 256) + 3)
 int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
                      const int64_t *ppr_rowptr, const int64_t *t0_rowptr, int64_t *offs, int64_t *desc,

@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256) void select_bound_kernel(
 // Second half of a two-kernel scan.  The producer kernel (256 threads, one element per thread) has written its
 // values to data[q*stride + 1 + i] and the sum of every 256-element block to blk[q*nb + block]; here block B adds
 // the sums of the blocks before it to an in-block inclusive scan.  Fully parallel: grid = nb blocks.
+// The grand totals (= last element of each scanned sequence) are also written next to each other at
+// blk[3 * nb + q], so the host can fetch them with one small contiguous copy.
 template <int NSEQ>
 __global__ __launch_bounds__(256) void scan_blocks_kernel(int64_t n, int64_t *__restrict__ data, int64_t stride,
-                                                          const int64_t *__restrict__ blk, int64_t nb) {
+                                                          int64_t *__restrict__ blk, int64_t nb) {
     __shared__ int64_t red[4];
     __shared__ int64_t wtot[NSEQ][4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256) void scan_blocks_kernel(int64_t n, int64_t *__
         __syncthreads();
         for (int w = 0; w < wave; ++w) pre += wtot[q][w];
         if (i < n) data[q * stride + 1 + i] = x + pre;
+        if (i == n - 1) blk[3 * nb + q] = x + pre;
     }
 }
 

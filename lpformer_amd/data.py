@@ -79,7 +79,7 @@ def sample_pairs(edge_index, n: int, bs: int, seed: int = 0, frac_edges: float =
     pos = np.asarray(edge_index)[:, rng.integers(0, edge_index.shape[1], size=k)]
     neg = rng.integers(0, n, size=(2, bs - k))
     b = np.concatenate([pos, neg], axis=1)
-    return b[:, rng.permutation(bs)].astype(np.int64)
+    return np.ascontiguousarray(b[:, rng.permutation(bs)].astype(np.int64))
 
 
 # name -> (N, F_in, undirected edges, D, L, residual, thresholds, eps, batch, gamma, max edge weight)

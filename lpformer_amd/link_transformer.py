@@ -622,7 +622,8 @@ class LinkTransformer(nn.Module):
                                        ptr(t0.rowptr) if want_t0 else None, ptr(offs), ptr(desc), ptr(scratch), st),
                   "lpf_select_bound")
         # one 16-byte read-back sizes the staging area and the work-item table
-        cap, n_items = (int(v) for v in offs[bs:2 * bs + 2:bs + 1].tolist())
+        nb = (bs + 255) // 256
+        cap, n_items = (int(v) for v in scratch[3 * nb:3 * nb + 2].tolist())
         stage_node = self._workspace("stage_node", cap, torch.int32, st)
         stage_pa = self._workspace("stage_pa", cap, torch.float32, st)
         stage_pb = self._workspace("stage_pb", cap, torch.float32, st)
@@ -637,7 +638,9 @@ class LinkTransformer(nn.Module):
                                        ptr(stage_node), ptr(stage_pa), ptr(stage_pb), ptr(stage_cnt), st),
                   "lpf_select_nodes")
         ldf = _pad4(self.dim + self.count_dim)
-        feats = torch.zeros(bs, ldf, dtype=torch.float32, device=self.device)  # [att out | counts | pad]
+        feats = torch.empty(bs, ldf, dtype=torch.float32, device=self.device)  # [att out | counts | pad]
+        if ldf > self.dim + self.count_dim:
+            feats[:, self.dim + self.count_dim:].zero_()  # the attention output and the counts are written below
         type_ptr = self._workspace("type_ptr", 3 * (bs + 1), torch.int64, st)
         with KernelTimer.span("select_scan"):
             check(lib.lpf_select_scan(bs, ptr(stage_cnt), ptr(type_ptr), feats.data_ptr() + 4 * self.dim, ldf,
