@@ -19,7 +19,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int SG_HEAVY = 32;  // pairs with more selected nodes than this get a whole workgroup in phase B
-constexpr int SG_INFLIGHT = 16;  // Z-row gathers in flight per lane group
 
 struct PeStat {
     float c00, c11, cbb, c01, c0b, c1b;
@@ -167,31 +166,33 @@ __device__ __forceinline__ void sg_chunk(const PeStat &st, const float4 (&k)[4],
     const float my_rab = pe_rstd(st, my_pa, my_pb), my_rba = pe_rstd(st, my_pb, my_pa);
     if (alpha_out && valid) alpha_out[e] = my_alpha;
     const int n_here = remaining < G ? remaining : G;
-    // SG_INFLIGHT row gathers are issued before the first one is consumed: the loop is bound by memory latency, and a
-    // chunk of 32 entries takes two round trips instead of eight
-    for (int j = 0; j < n_here; j += SG_INFLIGHT) {
-        float4 z[SG_INFLIGHT];
+    for (int j = 0; j < n_here; j += 4) {  // lanes past n_here carry alpha = 0, node = 0: harmless gathers
+        float al[4], pa[4], pb[4], rab[4], rba[4];
+        int32_t nd[4];
+        float4 z[4];
 #pragma unroll
-        for (int u = 0; u < SG_INFLIGHT; ++u) {
-            const int32_t nd = __shfl(my_node, gbase + ((j + u) & (G - 1)), 64);
-            z[u] = (act && j + u < n_here) ? *reinterpret_cast<const float4 *>(Z + (int64_t)nd * ldz + off)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 4; ++u) {
+            const int src = gbase + ((j + u) & (G - 1));
+            al[u] = __shfl(my_alpha, src, 64);
+            nd[u] = __shfl(my_node, src, 64);
+            pa[u] = __shfl(my_pa, src, 64);
+            pb[u] = __shfl(my_pb, src, 64);
+            rab[u] = __shfl(my_rab, src, 64);
+            rba[u] = __shfl(my_rba, src, 64);
         }
 #pragma unroll
-        for (int u = 0; u < SG_INFLIGHT; ++u) {
-            if (j + u < n_here) {  // (alpha = 0 past the end anyway; this only skips the arithmetic)
-                const int src = gbase + ((j + u) & (G - 1));
-                const float al = __shfl(my_alpha, src, 64);
-                const float pa = __shfl(my_pa, src, 64), pb = __shfl(my_pb, src, 64);
-                const float rab = __shfl(my_rab, src, 64), rba = __shfl(my_rba, src, 64);
-                accz.x = fmaf(al, z[u].x, accz.x); accz.y = fmaf(al, z[u].y, accz.y);
-                accz.z = fmaf(al, z[u].z, accz.z); accz.w = fmaf(al, z[u].w, accz.w);
-                acch.x = fmaf(al, pe_hidden(k[0], pa, pb, rab, rba), acch.x);
-                acch.y = fmaf(al, pe_hidden(k[1], pa, pb, rab, rba), acch.y);
-                acch.z = fmaf(al, pe_hidden(k[2], pa, pb, rab, rba), acch.z);
-                acch.w = fmaf(al, pe_hidden(k[3], pa, pb, rab, rba), acch.w);
-                asum += al;
-            }
+        for (int u = 0; u < 4; ++u)
+            z[u] = act ? *reinterpret_cast<const float4 *>(Z + (int64_t)nd[u] * ldz + off)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            accz.x = fmaf(al[u], z[u].x, accz.x); accz.y = fmaf(al[u], z[u].y, accz.y);
+            accz.z = fmaf(al[u], z[u].z, accz.z); accz.w = fmaf(al[u], z[u].w, accz.w);
+            acch.x = fmaf(al[u], pe_hidden(k[0], pa[u], pb[u], rab[u], rba[u]), acch.x);
+            acch.y = fmaf(al[u], pe_hidden(k[1], pa[u], pb[u], rab[u], rba[u]), acch.y);
+            acch.z = fmaf(al[u], pe_hidden(k[2], pa[u], pb[u], rab[u], rba[u]), acch.z);
+            acch.w = fmaf(al[u], pe_hidden(k[3], pa[u], pb[u], rab[u], rba[u]), acch.w);
+            asum += al[u];
         }
     }
 }

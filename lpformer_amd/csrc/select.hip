@@ -761,10 +761,11 @@ __global__ __launch_bounds__(256) void select_compact_kernel(
 // value of b at the position just found; otherwise P[b, x] is looked up in P1[b] -- and only when x's own value
 // passes theta_1.  Each lane owns one candidate: no hash table, no cross-lane traffic, ~4x fewer instructions.
 // Results are identical to select_nodes_kernel (tests compare both against the reference's golden vectors).
-struct alignas(16) IdxLds {
-    int32_t cand[SEL_CAP];  // kind 0: N(a) then N(b); otherwise the slice
-    int32_t p1a[SEL_CAP];   // columns of P1[a] / P1[b] when they fit (searched by the other endpoint's nodes)
-    int32_t p1b[SEL_CAP];
+constexpr int IDX_P1_CAP = 256;  // P1 rows up to this length are searched in LDS (they hold at most ~1/theta_1 entries)
+struct alignas(16) IdxLds {     // 4 KiB per wavefront: eight wavefronts per SIMD fit
+    int32_t cand[SEL_CAP];      // kind 0: N(a) then N(b); otherwise the slice
+    int32_t p1a[IDX_P1_CAP];    // columns of P1[a] / P1[b] when they fit (searched by the other endpoint's nodes)
+    int32_t p1b[IDX_P1_CAP];
 };
 
 __device__ __forceinline__ int find_lds(const int32_t *a, int n, int32_t key) {
@@ -785,7 +786,8 @@ __device__ __forceinline__ int find_glb(const int32_t *__restrict__ a, int n, in
     return (lo < n && a[lo] == key) ? lo : -1;
 }
 
-__global__ __launch_bounds__(256) void select_nodes_indexed_kernel(
+template <int WPB>  // wavefronts (= concurrent items) per workgroup
+__global__ __launch_bounds__(64 * WPB) void select_nodes_indexed_kernel(
     const int64_t *__restrict__ item_total, const ItemRec *__restrict__ items, const int64_t *__restrict__ desc,
     const int32_t *__restrict__ adj_col, const float *__restrict__ selfp, const int64_t *__restrict__ adjx_rowptr,
     const int32_t *__restrict__ adjx_col, int same_adj, const int32_t *__restrict__ p1_col,
@@ -793,34 +795,39 @@ __global__ __launch_bounds__(256) void select_nodes_indexed_kernel(
     int want_t0, float th_cn, float th_1, float th_n, const int64_t *__restrict__ stage_off,
     int32_t *__restrict__ stage_node, float *__restrict__ stage_pa, float *__restrict__ stage_pb,
     int32_t *__restrict__ stage_cnt) {
-    __shared__ IdxLds Ls[4];
+    __shared__ IdxLds Ls[WPB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     IdxLds &L = Ls[wave];
     const int64_t n_items = *item_total;
 
-    for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < n_items; it += (int64_t)gridDim.x * 4) {
+    for (int64_t it = (int64_t)blockIdx.x * WPB + wave; it < n_items; it += (int64_t)gridDim.x * WPB) {
         const ItemRec r = items[it];
         const int64_t p = r.p;
         const int kind = r.kind, start = r.start, len = r.len;
         const int dA = r.dA, dB = r.dB, nPa = r.nPa, nPb = r.nPb;  // nPa/nPb, pa0/pb0: the P1 rows
         const int64_t ra0 = r.ra0, rb0 = r.rb0, pa0 = r.pa0, pb0 = r.pb0;
         const int64_t s = stage_off[p];
-        const bool p1a_lds = nPa <= SEL_CAP, p1b_lds = nPb <= SEL_CAP;
+        const bool p1a_lds = nPa <= IDX_P1_CAP, p1b_lds = nPb <= IDX_P1_CAP;
 
         // ---- 1. all global reads up front: candidates with their self PPR, and the P1 columns
-        int32_t cnd[SEL_CAP / 64], ta[SEL_CAP / 64], tb[SEL_CAP / 64];
+        int32_t cnd[SEL_CAP / 64], ta[IDX_P1_CAP / 64], tb[IDX_P1_CAP / 64];
         float sp[SEL_CAP / 64];
         const int64_t base_s = (kind == 1 ? ra0 : rb0) + start;
 #pragma unroll
         for (int u = 0; u < SEL_CAP / 64; ++u) {
-            cnd[u] = -1; sp[u] = 0.f; ta[u] = 0; tb[u] = 0;
+            cnd[u] = -1; sp[u] = 0.f;
             const int i = lane + 64 * u;
             if (64 * u < len && i < len) {
                 const int64_t e = (kind == 0) ? ((i < dA) ? ra0 + i : rb0 + (i - dA)) : base_s + i;
                 cnd[u] = adj_col[e];
                 sp[u] = selfp[e];
             }
+        }
+#pragma unroll
+        for (int u = 0; u < IDX_P1_CAP / 64; ++u) {
+            ta[u] = 0; tb[u] = 0;
+            const int i = lane + 64 * u;
             if (p1a_lds && 64 * u < nPa && i < nPa) ta[u] = p1_col[pa0 + i];
             if (p1b_lds && 64 * u < nPb && i < nPb) tb[u] = p1_col[pb0 + i];
         }
@@ -829,6 +836,10 @@ __global__ __launch_bounds__(256) void select_nodes_indexed_kernel(
         for (int u = 0; u < SEL_CAP / 64; ++u) {
             const int i = lane + 64 * u;
             if (64 * u < len && i < len) L.cand[i] = cnd[u];
+        }
+#pragma unroll
+        for (int u = 0; u < IDX_P1_CAP / 64; ++u) {
+            const int i = lane + 64 * u;
             if (p1a_lds && 64 * u < nPa && i < nPa) L.p1a[i] = ta[u];
             if (p1b_lds && 64 * u < nPb && i < nPb) L.p1b[i] = tb[u];
         }
@@ -970,8 +981,11 @@ extern "C" int lpf_select_nodes(int64_t bs, int64_t item_capacity, const int64_t
     // four wavefronts (= four items) per block, about one item per wavefront: uneven items are balanced by the dispatcher
     int64_t blocks = (item_capacity + 3) / 4;
     if (blocks > (1 << 20)) blocks = 1 << 20;
-    if (adj_selfp)  // indexed fast path: ppr_col / ppr_val (and the descriptors) describe the P1 rows
-        hipLaunchKernelGGL(select_nodes_indexed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, item_off + bs,
+    if (adj_selfp)  // indexed fast path: ppr_col / ppr_val (and the descriptors) describe the P1 rows; one wavefront
+                    // per workgroup, so a long item (hub slice) does not hold the LDS of three finished neighbours
+        hipLaunchKernelGGL(select_nodes_indexed_kernel<1>, dim3((unsigned)(item_capacity < (1 << 22) ? item_capacity
+                                                                                                    : (1 << 22))),
+                           dim3(64), 0, s, item_off + bs,
                            reinterpret_cast<const ItemRec *>(items), desc, adj_col, adj_selfp, adjx_rowptr, adjx_col,
                            (int)same_adj, ppr_col, ppr_val, t0_col, t0_val, want_t0, th_cn, th_1hop, th_non1hop, offs,
                            stage_node, stage_pa, stage_pb, stage_cnt);
