@@ -63,6 +63,20 @@ __device__ __forceinline__ void pair_scores_tile(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
+    // Touch every 128-byte line of the entry's Z row and of its pair's q row now (one dword per line, the two lanes of
+    // an entry split the lines): the rows are consumed only in the epilogue, and their HBM latency then overlaps the
+    // MFMA loop instead of following it.  The values are kept (4 registers) so the loads cannot be dropped.
+    const float *zrow = Z + (int64_t)node * ldz;
+    const float *qrow = q + (int64_t)pr * ldq;
+    constexpr int PF = NT >= 2 ? NT / 2 : 1;
+    float pfz[PF], pfq[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int line = (lh * PF + i) % NT;
+        pfz[i] = zrow[32 * line];
+        pfq[i] = qrow[32 * line];
+    }
+
     const float4 *tb = tab + t * D + lh * (D / 2);
     // No software prefetch of the A operands: one wavefront alone issues this MFMA at half rate (measured: 130
     // cycles per v_mfma_f32_32x32x2_f32 from one wave, 67 from two), so the kernel is built for >= 3 resident waves per
@@ -85,9 +99,9 @@ __device__ __forceinline__ void pair_scores_tile(
 #pragma unroll
         for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c].w, h[3], acc[c], 0, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) asm volatile("" ::"v"(pfz[i]), "v"(pfq[i]));  // (the line touches end here)
     // acc[c][4g+u] = (Wfold_t h_e)[feature 32c + 8g + 4*lh + u] for entry lj
-    const float *zrow = Z + (int64_t)node * ldz;
-    const float *qrow = q + (int64_t)pr * ldq;
     const float *bf = bfold + t * D;
     float part = 0.f;
 #pragma unroll
