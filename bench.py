@@ -58,7 +58,7 @@ def pair_stats(data, batch, thresholds, p1):
     a, b = batch[0], batch[1]
     deg = np.diff(adj.rowptr)
     plen = np.diff(ppr.rowptr)
-    p1len = np.diff(p1.rowptr)
+    p1len = np.minimum(np.diff(p1.rowptr), 256)  # longer P1 rows are binary-searched in place, not streamed
     return {"sum_deg": int(deg[a].sum() + deg[b].sum()), "sum_ppr_len": int(plen[a].sum() + plen[b].sum()),
             "sum_p1_len": int(p1len[a].sum() + p1len[b].sum())}
 
@@ -71,9 +71,10 @@ def main():
     ap.add_argument("--config", default="collab", choices=sorted(D.CONFIGS))
     ap.add_argument("--batches", type=int, default=4, help="distinct candidate batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="pairs timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=98304,
+                    help="pairs timed on the CPU oracle (taken from the bench's own batches; about 10-15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
 
@@ -213,11 +214,13 @@ def main():
             # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE, gfx950-corrected)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                alias = {"pair_softmax_gather": ("pair_softmax_gather_light", "pair_softmax_gather_heavy")}
+                # bench name -> (profile names, launches of the bench name they add up to)
+                alias = {"pair_softmax_gather": (("pair_softmax_gather_light", "pair_softmax_gather_heavy"), 1),
+                         "dense_chain_mlp": (("dense_chain_elementwise", "dense_chain_pairwise"), 2)}
                 for name, r in rooflines.items():
-                    keys = alias.get(name, (name,))
+                    keys, per = alias.get(name, ((name,), 1))
                     if all(k in pmc for k in keys):
-                        r["traffic"] = sum(pmc[k]["hbm_bytes_per_launch_corrected"] for k in keys)
+                        r["traffic"] = sum(pmc[k]["hbm_bytes_per_launch_corrected"] for k in keys) // per
             except (OSError, KeyError, ValueError):
                 pass
             modelled = [k for k in sorted(kt, key=lambda k: -kt[k][1]) if k in rooflines]
@@ -248,22 +251,31 @@ def main():
             torch.set_num_threads(os.cpu_count() or 8)
             P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
             P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
-            sample = batches_np[0][:, :args.cpu_sample]
+            n_take = min(args.cpu_sample, bs * len(batches_np))
+            sample = np.ascontiguousarray(np.concatenate(batches_np, axis=1)[:, :n_take])
             hx = h.cpu().numpy()
             mask, ppr = data["adj_mask"], data["ppr"]
             okw = dict(x=None, adj_norm=None, adj_mask=(mask.rowptr, mask.col.astype(np.int64)),
                        ppr=(ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P=P, cfg=dict(targs, pred_layers=2),
                        x_node=hx)
+            try:  # threads the BLAS sections of the numpy port may use (everything else in it is one thread)
+                from threadpoolctl import threadpool_info
+                blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+            except ImportError:
+                blas_threads = 1
             t0 = time.perf_counter()
-            ref = O.forward(sample, **okw)
+            refs = [O.forward(sample[:, i:i + bs], **okw)["logit"] for i in range(0, n_take, bs)]
             cpu_s = time.perf_counter() - t0
+            ref_logit = np.concatenate(refs)
             # check the GPU scores of the same pairs against it while we are here
-            gl = score.logits(model.pair_features(batches[0][:, :args.cpu_sample], h)).cpu().numpy()
-            cpu = {"value": round(sample.shape[1] / cpu_s, 1), "unit": "pairs/s", "cores": os.cpu_count(),
+            gl = np.concatenate([score.logits(model.pair_features(torch.from_numpy(sample[:, i:i + bs]).to(dev), h))
+                                 .cpu().numpy() for i in range(0, n_take, bs)])
+            cpu = {"value": round(n_take / cpu_s, 1), "unit": "pairs/s", "cores": blas_threads,
                    "kind": "port",
-                   "sample": f"{sample.shape[1]} pairs of batch 0 (pair stage, encoder output resident), numpy oracle "
-                             f"in {cpu_s:.1f} s",
-                   "max_abs_logit_diff_vs_gpu": float(np.abs(gl - ref['logit']).max())}
+                   "sample": f"first {n_take} pairs of the bench's batches (pair stage, encoder output resident); "
+                             f"numpy restatement oracle/lpformer_oracle.py, {cpu_s:.1f} s; its matmuls run on "
+                             f"{blas_threads} BLAS threads, the rest of it on one",
+                   "max_abs_logit_diff_vs_gpu": float(np.abs(gl - ref_logit).max())}
 
         result = {
             "metric": "candidate link-pairs scored/sec (whole node)", "value": round(pairs_per_s, 1),

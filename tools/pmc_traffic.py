@@ -1,0 +1,57 @@
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command.
+
+Usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+Per kernel and launch: hbm bytes = 2 * FETCH_SIZE_KB * 1024 (gfx950 tallies 128-B read requests at 64 B, see
+MI355X_MICROARCH.md "HBM") + WRITE_SIZE_KB * 1024.  Warm-up launches (first half) are dropped."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
+    ("pair_scores_kernel", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
+    ("pair_softmax_gather_kernel", "pair_softmax_gather_light"), ("select_nodes_indexed", "select_nodes"),
+    ("select_nodes_kernel", "select_nodes_general"), ("select_compact", "select_compact"),
+    ("select_bound", "select_bound"), ("select_items", "select_items"), ("select_counts", "select_counts"),
+    ("scan_blocks", "scan_blocks"), ("spmm_csr_kernel", "spmm_csr"), ("spmm_long_rows", "spmm_long_rows"),
+    ("gemm_f32_kernel<128>", "gemm128"), ("gemm_f32_kernel<64>", "gemm64"), ("layernorm", "layernorm"),
+    ("dense_chain_kernel<8, 8", "dense_chain_elementwise"), ("dense_chain_kernel<9, 8", "dense_chain_pairwise"),
+    ("dense_chain_kernel<8, 0, 4, 2", "dense_chain_q"), ("dense_chain_kernel<8, 0, 4, 0", "dense_chain_attn_out"),
+    ("dense_chain_kernel<16, 0", "dense_chain_score"),
+]
+
+
+def collect(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            for frag, short in SHORT:
+                if frag in r["Kernel_Name"]:
+                    acc[short].append(float(r["Counter_Value"]))
+                    break
+    return {k: v[len(v) // 2:] for k, v in acc.items()}
+
+
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on the collab-like bench "
+                   "workload, serial single-stream steps; bytes = 2 x FETCH_SIZE_KB x 1024 (gfx950 correction, "
+                   "MI355X_MICROARCH.md) + WRITE_SIZE_KB x 1024, mean per launch after warm-up",
+           "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, []), write.get(k, [])
+        fk = sum(f) / len(f) if f else 0.0
+        wk = sum(w) / len(w) if w else 0.0
+        out["kernels"][k] = {"FETCH_SIZE_KB_per_launch_raw": round(fk, 1), "launches_profiled_FETCH_SIZE": len(f),
+                             "WRITE_SIZE_KB_per_launch_raw": round(wk, 1), "launches_profiled_WRITE_SIZE": len(w),
+                             "hbm_bytes_per_launch_corrected": int(2 * fk * 1024 + wk * 1024)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print(f"{k:28s} {v['hbm_bytes_per_launch_corrected'] / 1e6:10.1f} MB/launch")
+
+
+if __name__ == "__main__":
+    main()
