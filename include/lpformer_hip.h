@@ -215,6 +215,32 @@ int lpf_rowdot_sigmoid_f32(int64_t M, int32_t K, const float *A, int64_t lda, co
                            float *logit, float *prob, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Device-side PPR producer: the same Andersen push as lpf_ppr_push_cpu below, on the GPU.
+ * calc_ppr (src/util/calc_ppr_scores.py:136-192) + create_sparse_ppr_matrix (:221-241): LIFO stack and float64
+ * arithmetic per source in the reference's order, so index sets and fp32 values are bit-identical.  One wavefront
+ * per source (dynamic assignment), neighbours of a popped node across the lanes; every wavefront owns dense
+ * epoch-stamped state over all n nodes (32 n bytes) inside `workspace`.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Bytes of `workspace` for n_waves concurrent sources (n_waves: multiple of 4; 4096-8192 fills an MI355X). */
+int64_t lpf_ppr_push_workspace_bytes(int64_t n, int64_t n_waves, double alpha, double eps);
+
+/* rowptr/col: CSR of the coalesced directed edge list (get_ppr_matrix, :111-117), device memory.
+ * Row i of the result lands UNSORTED at pool_col/pool_val[row_off[i] .. row_off[i] + row_len[i]) (rows are placed in
+ * completion order).  counters int64[4] on return: [1] = total entries (if > pool_capacity nothing was written for
+ * the rows that did not fit: call again with a pool of that size), [2] = rows that overflowed their
+ * 1/(alpha*eps) list bound (must be 0). */
+int lpf_ppr_push_f64(int64_t n, const int64_t *rowptr, const int32_t *col, double alpha, double eps,
+                     int64_t n_waves, void *workspace, int64_t workspace_bytes, int32_t *pool_col, float *pool_val,
+                     int64_t pool_capacity, int64_t *row_off, int32_t *row_len, int64_t *counters, void *stream);
+
+/* Sort every row by column and pack the CSR (out_rowptr int64[n+1], out_col/out_val [nnz], nnz = counters[1] above). */
+int64_t lpf_ppr_pack_workspace_bytes(int64_t n, int64_t nnz);
+int lpf_ppr_pack_csr(int64_t n, const int64_t *row_off, const int32_t *row_len, const int32_t *pool_col,
+                     const float *pool_val, int64_t nnz, int64_t *out_rowptr, int32_t *out_col, float *out_val,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host side (liblpformer_host.so)
  * ---------------------------------------------------------------------------------------------- */
 

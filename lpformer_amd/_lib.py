@@ -34,6 +34,10 @@ HIP_PROTOTYPES = {
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp],
     "lpf_rowdot_sigmoid_f32": [i64, i32, vp, i64, vp, f32, vp, vp, vp],
+    "lpf_ppr_push_workspace_bytes": [i64, i64, C.c_double, C.c_double],
+    "lpf_ppr_push_f64": [i64, vp, vp, C.c_double, C.c_double, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp],
+    "lpf_ppr_pack_workspace_bytes": [i64, i64],
+    "lpf_ppr_pack_csr": [i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp],
     "lpf_dense_chain_f32": [i64, i32, vp, i64, vp, i64, i32, vp, i32, vp, vp, i64, vp, vp, u32, vp, i32, vp, vp, i64, vp,
                             vp],
 }
@@ -42,7 +46,8 @@ HOST_PROTOTYPES = {
     "lpf_host_free": [vp],
     "lpf_host_abi_version": [],
 }
-_RESTYPE = {"lpf_strerror": C.c_char_p, "lpf_last_hip_error": C.c_char_p, "lpf_host_free": None}
+_RESTYPE = {"lpf_strerror": C.c_char_p, "lpf_last_hip_error": C.c_char_p, "lpf_host_free": None,
+            "lpf_ppr_push_workspace_bytes": C.c_int64, "lpf_ppr_pack_workspace_bytes": C.c_int64}
 
 
 class LpfError(RuntimeError):

@@ -13,23 +13,29 @@ import numpy as np
 import torch
 
 from . import graph
-from .ppr import calc_ppr
+from .ppr import calc_ppr, calc_ppr_gpu
 
 
 def build_data(edge_index, x, num_nodes: int, *, edge_weight=None, eps: float = 5e-5, alpha: float = 0.15,
                ppr: Optional[graph.CSR] = None, val_edge_index=None, ppr_test: Optional[graph.CSR] = None,
-               ppr_threads: int = 0) -> dict:
+               ppr_threads: int = 0, ppr_device=None) -> dict:
     """Reference-schema data dict (read_data_ogb, src/util/read_datasets.py:20-148) on CSR containers.
 
     edge_index: [2, E] directed list holding both directions of every undirected edge; edge_weight optional.
-    val_edge_index: optional extra (validation) edges used when ``test_set=True`` (``--use-val-in-test``)."""
+    val_edge_index: optional extra (validation) edges used when ``test_set=True`` (``--use-val-in-test``).
+    ppr_device: None = host OpenMP producer; a device ("cuda:0") = the GPU producer (bit-identical result)."""
     ei = np.asarray(edge_index, dtype=np.int64)
     n = int(num_nodes)
     data = {"num_nodes": n, "x": torch.as_tensor(x, dtype=torch.float32)}
     w = None if edge_weight is None else np.asarray(edge_weight, np.float32)
     data["adj_t"] = graph.csr_from_coo(ei[0], ei[1], np.ones(ei.shape[1], np.float32) if w is None else w, n)
     data["adj_mask"] = graph.mask_csr(ei, n, symmetric=True)
-    data["ppr"] = ppr if ppr is not None else calc_ppr(ei, n, alpha, eps, ppr_threads)
+    def producer(edges):
+        if ppr_device is not None:
+            return calc_ppr_gpu(edges, n, alpha, eps, device=ppr_device)
+        return calc_ppr(edges, n, alpha, eps, ppr_threads)
+
+    data["ppr"] = ppr if ppr is not None else producer(ei)
     if val_edge_index is not None:
         vei = np.asarray(val_edge_index, dtype=np.int64)
         vei = np.concatenate([vei, vei[::-1]], axis=1)  # to_undirected
@@ -37,7 +43,7 @@ def build_data(edge_index, x, num_nodes: int, *, edge_weight=None, eps: float = 
         fw = np.concatenate([np.ones(ei.shape[1], np.float32) if w is None else w, np.ones(vei.shape[1], np.float32)])
         data["full_adj_t"] = graph.csr_from_coo(full[0], full[1], fw, n)
         data["full_adj_mask"] = graph.mask_csr(full, n, symmetric=False)
-        data["ppr_test"] = ppr_test if ppr_test is not None else calc_ppr(full, n, alpha, eps, ppr_threads)
+        data["ppr_test"] = ppr_test if ppr_test is not None else producer(full)
     else:
         data["full_adj_t"], data["full_adj_mask"], data["ppr_test"] = data["adj_t"], data["adj_mask"], data["ppr"]
     return data

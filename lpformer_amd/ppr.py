@@ -1,6 +1,7 @@
-"""PPR producer: host C++/OpenMP Andersen push behind ``lpf_ppr_push_cpu`` (liblpformer_host.so).
+"""PPR producer: Andersen push behind ``lpf_ppr_push_cpu`` (host C++/OpenMP, liblpformer_host.so) and
+``lpf_ppr_push_f64`` + ``lpf_ppr_pack_csr`` (MI355X, liblpformer_hip.so).
 
-Replaces the reference's numba ``calc_ppr`` + Python list packing (src/util/calc_ppr_scores.py:103-241) with the
+Both replace the reference's numba ``calc_ppr`` + Python list packing (src/util/calc_ppr_scores.py:103-241) with the
 same push order and float64 arithmetic, so the resulting sparse matrix -- index sets and fp32 values -- is
 bit-identical; it is what makes the PPR neighbour sets of the scoring path reproducible.
 """
@@ -39,6 +40,84 @@ def calc_ppr(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5,
         lib.lpf_host_free(col_p)
         lib.lpf_host_free(val_p)
     return CSR(rowptr, col, val, num_nodes)
+
+
+def calc_ppr_gpu(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5, device="cuda", n_waves: int = 0,
+                 state_budget_bytes: int = 8 << 30, to_host: bool = True, pool_capacity: int = 0,
+                 timings: dict = None):
+    """Same result as ``calc_ppr`` computed on the GPU: one wavefront per source, dense per-wavefront push state.
+
+    ``n_waves`` (0 = as many as ``state_budget_bytes`` of HBM allow, at most 8192) bounds the concurrent sources
+    (the push itself keeps getting faster up to 8192 wavefronts, but a first-time allocation of the state costs
+    about 30 ms per GB, so the default stops at 8 GB);
+    ``pool_capacity`` (0 = 384 entries per node) is the first guess of the result size (a too small guess costs one
+    exact-size rerun).  ``timings`` (optional dict) receives the seconds spent per phase (synchronising).
+    Returns a host ``CSR`` (``to_host=True``) or the device tensors ``(rowptr int64, col int32, val fp32)``."""
+    import time
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.LpfError("calc_ppr_gpu needs an MI355X device; use calc_ppr for the host producer")
+
+    def mark(name, t0):
+        if timings is not None:
+            torch.cuda.synchronize(dev)
+            timings[name] = timings.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    t = time.perf_counter()
+    ei = edge_index.detach().cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
+    g = csr_from_coo(ei[0], ei[1], None, num_nodes)
+    t = mark("host_csr_s", t)
+    n = int(num_nodes)
+    lib = _lib.hip()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rowptr = torch.from_numpy(np.ascontiguousarray(g.rowptr, dtype=np.int64)).to(dev)
+    col = torch.from_numpy(np.ascontiguousarray(g.col, dtype=np.int32)).to(dev)
+    if n == 0:
+        z = torch.zeros(1, dtype=torch.int64, device=dev)
+        return CSR(np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32), 0) if to_host else \
+            (z, col[:0], torch.zeros(0, device=dev))
+    if n_waves <= 0:
+        per_wave = max(1, lib.lpf_ppr_push_workspace_bytes(n, 4, float(alpha), float(eps)) // 4)
+        n_waves = int(min(8192, max(4, state_budget_bytes // per_wave), 4 * ((n + 3) // 4)))
+    n_waves = max(4, n_waves - n_waves % 4)
+    ws_bytes = lib.lpf_ppr_push_workspace_bytes(n, n_waves, float(alpha), float(eps))
+    if ws_bytes <= 0:
+        raise _lib.LpfError("lpf_ppr_push_workspace_bytes: invalid arguments")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    row_off = torch.empty(n, dtype=torch.int64, device=dev)
+    row_len = torch.empty(n, dtype=torch.int32, device=dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    t = mark("alloc_upload_s", t)
+    cap = int(pool_capacity) if pool_capacity > 0 else max(1 << 16, 384 * n)
+    while True:
+        pool_col = torch.empty(cap, dtype=torch.int32, device=dev)
+        pool_val = torch.empty(cap, dtype=torch.float32, device=dev)
+        _lib.check(lib.lpf_ppr_push_f64(n, _lib.ptr(rowptr), _lib.ptr(col), float(alpha), float(eps), n_waves,
+                                        _lib.ptr(ws), ws_bytes, _lib.ptr(pool_col), _lib.ptr(pool_val), cap,
+                                        _lib.ptr(row_off), _lib.ptr(row_len), _lib.ptr(counters), st),
+                   "lpf_ppr_push_f64")
+        _, nnz, bad, _ = (int(v) for v in counters.tolist())
+        if bad:
+            raise _lib.LpfError(f"lpf_ppr_push_f64: {bad} rows exceeded the 1/(alpha*eps) list bound")
+        if nnz <= cap:
+            break
+        cap = nnz  # deterministic: the second run needs exactly this many slots
+    t = mark("push_s", t)
+    del ws
+    pk_bytes = lib.lpf_ppr_pack_workspace_bytes(n, nnz)
+    pk = torch.empty(max(pk_bytes, 256), dtype=torch.uint8, device=dev)
+    out_rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    out_col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    out_val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+    _lib.check(lib.lpf_ppr_pack_csr(n, _lib.ptr(row_off), _lib.ptr(row_len), _lib.ptr(pool_col), _lib.ptr(pool_val),
+                                    nnz, _lib.ptr(out_rowptr), _lib.ptr(out_col), _lib.ptr(out_val), _lib.ptr(pk),
+                                    pk.numel(), st), "lpf_ppr_pack_csr")
+    out_col, out_val = out_col[:nnz], out_val[:nnz]
+    t = mark("sort_pack_s", t)
+    if not to_host:
+        return out_rowptr, out_col, out_val
+    return CSR(out_rowptr.cpu().numpy(), out_col.cpu().numpy(), out_val.cpu().numpy(), n)
 
 
 def get_ppr(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5) -> torch.Tensor:

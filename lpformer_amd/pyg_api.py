@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import graph
 from .link_transformer import LinkTransformer, mlp_score
-from .ppr import calc_ppr
+from .ppr import calc_ppr, calc_ppr_gpu
 
 
 class LPFormer(nn.Module):
@@ -78,5 +78,8 @@ class LPFormer(nn.Module):
 
     @staticmethod
     def calc_sparse_ppr(edge_index: torch.Tensor, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5):
-        """PPR matrix as a torch sparse COO tensor (host C++/OpenMP push, bit-identical to the reference's numba code)."""
+        """PPR matrix as a torch sparse COO tensor, bit-identical to the reference's numba code: the MI355X producer
+        when ``edge_index`` lives on the GPU, the host C++/OpenMP producer otherwise."""
+        if isinstance(edge_index, torch.Tensor) and edge_index.is_cuda:
+            return calc_ppr_gpu(edge_index, num_nodes, alpha, eps, device=edge_index.device).to_torch_sparse_coo()
         return calc_ppr(edge_index, num_nodes, alpha, eps).to_torch_sparse_coo()
