@@ -41,13 +41,13 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 
 
-def build_problem(cfg, rank, world, threads):
+def build_problem(cfg, rank, world, threads, ppr_device=None):
     n = cfg["n"]
     t0 = time.time()
     ei, w = D.chung_lu_graph(n, cfg["edges"], gamma=cfg["gamma"], seed=0, max_weight=cfg["max_weight"])
     x = np.random.default_rng(1).standard_normal((n, cfg["f_in"])).astype(np.float32)
     t1 = time.time()
-    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr_threads=threads)
+    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr_threads=threads, ppr_device=ppr_device)
     t2 = time.time()
     return ei, w, x, data, {"graph_s": t1 - t0, "ppr_s": t2 - t1}
 
@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=98304,
                     help="pairs timed on the CPU oracle (taken from the bench's own batches; about 10-15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--ppr", default="gpu", choices=("gpu", "host"),
+                    help="PPR producer for the (untimed) setup: lpf_ppr_push_f64 on the GPU or the OpenMP host push")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
@@ -89,7 +91,7 @@ def main():
     n, d, bs = cfg["n"], cfg["dim"], cfg["batch"]
     host_threads = max(1, (os.cpu_count() or 8) // world)
 
-    ei, w, x, data, setup = build_problem(cfg, rank, world, host_threads)
+    ei, w, x, data, setup = build_problem(cfg, rank, world, host_threads, dev if args.ppr == "gpu" else None)
     targs = D.train_args_for(cfg)
     torch.manual_seed(0)
     model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev).eval()
@@ -293,7 +295,7 @@ def main():
             "encoder_ms": round(encoder_ms, 4), "value_incl_encoder": round(value_incl_encoder, 1),
             "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "rooflines": rooflines,
-            "setup_s": {k: round(v, 2) for k, v in setup.items()},
+            "setup_s": dict({k: round(v, 2) for k, v in setup.items()}, ppr_producer=args.ppr),
         }
         print(json.dumps(result), flush=True)
     barrier()

@@ -112,8 +112,9 @@ int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const i
                      int64_t *scratch, void *stream);
 
 /* Selection, step 2: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (link_transformer.py:214-319,434-481),
- * eval mode; integer/bit-exact.  One wavefront per work item: candidates + hash table in LDS, PPR rows streamed
- * through the hash (see select.hip).
+ * eval mode; integer/bit-exact.  One wavefront per work item.  With adj_selfp (evaluation): each lane owns one
+ * candidate, membership by binary search in LDS, one lookup in the prefiltered one-hop rows.  Without it (adjacency
+ * override): candidates + hash table in LDS, raw PPR rows streamed through the hash (see select.hip).
  *   item_capacity  host-side upper bound on offs[(bs+1)+bs] (sizes `items` = int32[16*item_capacity], 64-byte records, and the grid)
  *   adjx_*    UNMASKED adjacency used to exclude neighbours from the >1-hop set (link_transformer.py:443);
  *             same_adj != 0 says it is the very adjacency the descriptors were built from (evaluation)
@@ -123,12 +124,16 @@ int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const i
  *             subset of the PPR rows that keeps every entry with fl32(fl32(p+1)-1) >= theta_1 (the "P1" index):
  *             PPR values of a node's own neighbours then come from adj_selfp and no PPR row is streamed.
  *             Results are identical with and without the indexes.
- * Dense staging for pair k at s = offs[k], dA = deg(a), dB = deg(b):
- *   stage_node[s+i],        i < dA : -1 (dropped) | node | (1<<30 if common neighbour)   for the i-th node of N(a)
- *   stage_node[s+dA+j],     j < dB : -1 | node                                           for the j-th node of N(b)
- *   stage_node[s+dA+dB+..]  the >1-hop run, already compacted and sorted (count stage_cnt[4k+3])
- *   stage_pa/pb fp32 at the same slots (values AFTER the reference's fp32 round trip), written for kept nodes
- *   stage_cnt[4k+0..2] = kept CN / kept 1-hop from N(a) / kept 1-hop from N(b) */
+ * Staging for pair k at s = offs[k], dA = deg(a), dB = deg(b) (capacity dA + dB + min(|T0 a|, |T0 b|) slots):
+ *   pair = ONE item (dA + dB <= 512): COMPACTED runs, written as found --
+ *     stage_node[s ..]            kept common neighbours, ascending            (count stage_cnt[4k+0])
+ *     stage_node[.. s+dA-1]       kept one-hop nodes of N(a), written DOWNWARDS from s+dA-1 (count stage_cnt[4k+1])
+ *     stage_node[s+dA ..]         kept one-hop nodes of N(b), ascending        (count stage_cnt[4k+2])
+ *   pair sliced into several items (a hub): DENSE, one code per candidate --
+ *     stage_node[s+i],    i < dA : -1 (dropped) | node | (1<<30 if common neighbour)   for the i-th node of N(a)
+ *     stage_node[s+dA+j], j < dB : -1 | node                                           for the j-th node of N(b)
+ *   stage_node[s+dA+dB ..]  the >1-hop run, compacted and sorted (count stage_cnt[4k+3])
+ *   stage_pa/pb fp32 at the same slots (values AFTER the reference's fp32 round trip), written for kept nodes */
 int lpf_select_nodes(int64_t bs, int64_t item_capacity, const int64_t *offs, const int64_t *desc, int32_t *items,
                      const int32_t *adj_col, const float *adj_selfp, const int64_t *adjx_rowptr,
                      const int32_t *adjx_col, int32_t same_adj,
@@ -146,8 +151,8 @@ int lpf_select_scan(int64_t bs, const int32_t *stage_cnt, int64_t *type_ptr, flo
 
 /* Compaction into the reference's layout: all CN entries sorted by (pair, node), then all 1-hop, then all
  * >1-hop (link_transformer.py:161-162).  Entry e of type t lives at  type_base(t) + type_ptr[t][k] + j  with
- * type_base = (0, total_cn, total_cn+total_1hop).  The dense runs are compacted (in place, staging is clobbered)
- * and the two 1-hop runs merged here. */
+ * type_base = (0, total_cn, total_cn+total_1hop).  The two 1-hop runs are merged by node id here (single-item pairs
+ * through registers / LDS; dense runs of sliced pairs are compacted in place first: staging is clobbered). */
 int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t *offs, int32_t *stage_node, float *stage_pa,
                        float *stage_pb, const int32_t *stage_cnt, const int64_t *type_ptr,
                        int32_t *sel_pair, int32_t *sel_node, float *sel_pa, float *sel_pb, void *stream);

@@ -3,20 +3,21 @@
 // The reference builds BS x N sparse COO temporaries and coalesces (sorts) them seven times per batch
 // (src/models/link_transformer.py:214-319,434-481).  Here the work is cut into ITEMS of at most SEL_CAP candidate
 // nodes (a whole pair when deg(a)+deg(b) <= SEL_CAP, otherwise slices of N(a) and of N(b)); one wavefront handles
-// one item and the kernel is a pure streaming kernel:
-//   1. the item's candidates (coalesced reads of the adjacency rows) go into LDS together with an open-addressing
-//      hash table keyed by node id (ds_cmpswap inserts);
-//   2. the PPR rows of a and b are STREAMED once from HBM (col, val pairs, fully coalesced, several loads in flight),
-//      every entry probes the hash and drops its value into the candidate's slot -- no binary search, no dependent
-//      global loads; for sliced pairs the other endpoint's adjacency row is streamed the same way to type the nodes;
-//   3. candidates are typed (2 = common neighbour, 1 = one-hop), the reference's fp32 round trip and thresholds are
-//      applied op for op, and a code per candidate (node id, CN bit, or -1) is written to a DENSE staging slot; kept
-//      counts are accumulated per pair with integer atomics (order independent);
-//   4. the >1-hop candidates (per-threshold prefiltered PPR rows) are walked by the first item of each pair and
-//      probed against the other row and the hash.
-// lpf_select_compact then turns the dense runs into the reference's layout (all CN entries sorted by (pair, node),
-// then 1-hop, then >1-hop).  Order comes from the CSR order: no sort anywhere.  Bound: HBM bandwidth on the row bytes
-// 4(deg a + deg b) + 8(|P_a| + |P_b|) per pair.
+// one item.  Two kernels share the item table, the staging layout and the emit code:
+//   * select_nodes_indexed_kernel (evaluation; needs the per-model indexes selfp / P1 of DESIGN.md section 3): the
+//     candidates and their self-PPR values arrive in one coalesced burst, each lane owns one candidate, membership
+//     in the other endpoint's row is a binary search in LDS, and at most one lookup in the prefiltered one-hop rows
+//     follows -- no PPR row is streamed.  ~1,400 instructions per item; issue bound.
+//   * select_nodes_kernel (general: a caller-supplied adjacency has no aligned self-PPR): candidates go into an
+//     LDS open-addressing hash (ds_cmpswap inserts) and the raw PPR rows of a and b are STREAMED once through it
+//     (coalesced (col, val) reads, several loads in flight, lock-step probes).  Bound: HBM bandwidth on
+//     4(deg a + deg b) + 8(|P_a| + |P_b|) bytes per pair.
+// Both type the candidates (2 = common neighbour, 1 = one-hop), apply the reference's fp32 round trip and thresholds
+// op for op, and write kept nodes to the staging area: compacted runs for single-item pairs, a dense code per
+// candidate for slices of hub pairs (lpformer_hip.h); kept counts are accumulated per pair with integer atomics
+// (order independent).  The >1-hop candidates (per-threshold prefiltered PPR rows) are walked by the first item of
+// each pair.  select_compact_kernel then produces the reference's layout (all CN entries sorted by (pair, node),
+// then 1-hop, then >1-hop).  Order comes from the CSR order: no sort anywhere.
 #include "lpf_common.h"
 
 // the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
