@@ -1,0 +1,77 @@
+"""Seeded random sweep: HIP path vs the CPU oracle over model widths, modes, thresholds, hub-heavy graphs
+(degrees above the 512-candidate item size, PPR rows above the 256-entry LDS cap), weighted / residual encoders and
+batches with a == b, duplicate and isolated pairs.  Selection must be bit-exact through both selection kernels."""
+import numpy as np
+import pytest
+import torch
+
+import lpformer_amd
+from lpformer_amd import data as D
+from oracle import lpformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+HUB_SEEDS = (1, 7)
+CASES = [
+    # seed, n, undirected edges, gamma, dim, layers, residual, thresholds (cn, 1hop, >1hop), eps, weighted
+    (0, 400, 1500, 2.5, 32, 1, False, (0.0, 1e-3, 1e-2), 1e-3, False),
+    (1, 900, 9000, 2.05, 64, 2, True, (0.0, 1e-4, 1e-2), 1e-4, True),     # hubs with degree > 512
+    (2, 1500, 6000, 2.2, 128, 3, False, (1e-3, 1e-3, 5e-3), 2e-4, True),
+    (3, 600, 20000, 3.0, 256, 2, False, (0.0, 1e-2, 1.0), 1e-4, False),   # dense, "1-hop" mode (ddi-like)
+    (4, 2500, 7000, 2.1, 64, 3, True, (0.0, 0.0, 1e-2), 1e-4, False),     # theta_1hop = 0: P1 is the whole matrix
+    (5, 1200, 15000, 2.05, 128, 1, False, (0.0, 1e-5, 1e-3), 5e-5, True),  # long PPR rows, many >1-hop nodes
+    (6, 300, 600, 2.5, 32, 2, True, (5e-2, 5e-2, 5e-2), 1e-3, False),     # high thresholds: mostly empty pairs
+    (7, 800, 12000, 2.02, 256, 2, True, (0.0, 1e-4, 1e-2), 1e-4, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"seed{c[0]}_d{c[4]}" for c in CASES])
+def test_random_config_matches_oracle(case):
+    seed, n, edges, gamma, dim, layers, residual, th, eps, weighted = case
+    rng = np.random.default_rng(100 + seed)
+    ei, w = D.chung_lu_graph(n, edges, gamma=gamma, seed=seed, max_weight=6 if weighted else 0)
+    if seed in HUB_SEEDS:  # two explicit hubs: their pair is cut into slices of N(a) and of N(b)
+        star = np.concatenate([np.stack([np.zeros(640, np.int64), rng.choice(np.arange(2, n), 640, replace=False)]),
+                               np.stack([np.ones(560, np.int64), rng.choice(np.arange(2, n), 560, replace=False)])], 1)
+        allp = np.concatenate([ei, star, star[::-1]], axis=1)
+        allw = None if w is None else np.concatenate([w, np.ones(2 * star.shape[1], np.float32)])
+        _, keep = np.unique(allp[0] * n + allp[1], return_index=True)
+        ei, w = allp[:, keep], (None if allw is None else allw[keep])
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    ppr = lpformer_amd.calc_ppr(ei, n, 0.15, eps)
+    d = D.build_data(ei, x, n, edge_weight=w, ppr=ppr)
+    cfg = D.train_args_for(dict(thresholds=th, dim=dim, gnn_layers=layers, residual=residual))
+    torch.manual_seed(seed)
+    model = lpformer_amd.LinkTransformer(cfg, d, device=DEV).to(DEV).eval()
+    score = lpformer_amd.mlp_score(2 * dim, 2 * dim, 1, 2).to(DEV).eval()
+    with torch.no_grad():
+        for p in list(model.parameters()) + list(score.parameters()):
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
+    batch = D.sample_pairs(ei, n, 700, seed=seed + 50)
+    deg = np.bincount(ei[0], minlength=n)
+    hub = int(np.argmax(deg))
+    batch[:, :6] = np.array([[0, 5, 7, 7, hub, hub], [0, 5, 9, 9, (hub + 1) % n, hub]])  # a == b, duplicates, hub pairs
+    batch[:, 7:9] = np.array([[0, 1], [1, 0]])
+    iso = np.flatnonzero(deg == 0)
+    if iso.size >= 2:
+        batch[:, 6] = iso[:2]
+    ref = O.forward(batch, x, O.gcn_norm(ei, w, n), O.symmetric_mask_csr(ei, n),
+                    (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P, dict(cfg, pred_layers=2))
+    tags = ("cn", "onehop", "non1hop") if model.mask == "all" else ("cn", "onehop")
+    for indexed in (True, False):
+        model.use_select_index = indexed
+        infos = model.compute_node_mask(torch.from_numpy(batch))
+        for tag, info in zip(tags, infos):
+            np.testing.assert_array_equal(info[0].cpu().numpy(), ref["sel"][tag][0])
+            np.testing.assert_array_equal(info[1].cpu().numpy().view(np.uint32), ref["sel"][tag][1].view(np.uint32))
+            np.testing.assert_array_equal(info[2].cpu().numpy().view(np.uint32), ref["sel"][tag][2].view(np.uint32))
+        feats = model(torch.from_numpy(batch))
+        scale = max(1.0, float(np.abs(ref["combined_feats"]).max()))
+        assert np.abs(feats.cpu().numpy() - ref["combined_feats"]).max() <= TOL * scale
+        assert np.abs(score.logits(feats).cpu().numpy() - ref["logit"]).max() <= TOL * max(1.0, float(np.abs(ref["logit"]).max()))
+    assert deg.max() > 512 or seed not in HUB_SEEDS, "hub cases must exercise sliced pairs"
