@@ -120,7 +120,40 @@ def calc_ppr_gpu(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5
     return CSR(out_rowptr.cpu().numpy(), out_col.cpu().numpy(), out_val.cpu().numpy(), n)
 
 
+def ppr_cache_path(root: str, dataset: str, alpha: float, eps: float, is_val: bool = False) -> str:
+    """The reference's cache location and name (calc_ppr_scores.py:249-257) with this repo's container suffix:
+    ``<root>/node_subsets/ppr/<dataset>/sparse_adj-015_eps-5e-05[_val].lpf.npz``.  The reference pickles a
+    ``torch_sparse.SparseTensor`` there, which only that package can read back; the CSR triplet below carries the same
+    matrix (rows sorted by column, fp32 values) without the dependency."""
+    import os
+    val_suf = "_val" if is_val else ""
+    name = f"sparse_adj-{str(alpha).replace('.', '')}_eps-{str(eps).replace('.', '')}{val_suf}.lpf.npz"
+    return os.path.join(root, "node_subsets", "ppr", dataset, name)
+
+
+def load_or_calc_ppr(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5, *, cache_root=None,
+                     dataset: str = "graph", is_val: bool = False, device=None, num_threads: int = 0) -> CSR:
+    """``get_ppr`` of the reference (calc_ppr_scores.py:245-270): load the cached matrix if present, otherwise run the
+    producer (the GPU one when ``device`` is given, else the host one) and store the result."""
+    import os
+    path = None if cache_root is None else ppr_cache_path(cache_root, dataset, alpha, eps, is_val)
+    if path is not None and os.path.isfile(path):
+        z = np.load(path)
+        if int(z["num_nodes"]) != int(num_nodes):
+            raise _lib.LpfError(f"{path}: cached PPR is for {int(z['num_nodes'])} nodes, not {num_nodes}")
+        return CSR(z["rowptr"], z["col"], z["val"], int(num_nodes))
+    csr = calc_ppr_gpu(edge_index, num_nodes, alpha, eps, device=device) if device is not None else \
+        calc_ppr(edge_index, num_nodes, alpha, eps, num_threads)
+    if path is not None:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, rowptr=csr.rowptr, col=csr.col, val=csr.val, num_nodes=np.int64(num_nodes),
+                 alpha=np.float64(alpha), eps=np.float64(eps))
+        os.replace(tmp, path)
+    return csr
+
+
 def get_ppr(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5) -> torch.Tensor:
     """torch sparse COO PPR matrix, the object the reference stores in ``data['ppr']``
-    (calc_ppr_scores.py:245-270, minus the on-disk cache)."""
+    (calc_ppr_scores.py:245-270, minus the on-disk cache -- see ``load_or_calc_ppr``)."""
     return calc_ppr(edge_index, num_nodes, alpha, eps).to_torch_sparse_coo()

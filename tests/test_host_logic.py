@@ -146,3 +146,22 @@ def test_fold_algebra_matches_oracle():
     pk = w["wfold_packed"]
     c, sq, lane, u = 1, 3, 45, 2
     assert pk[2, c, sq, lane, u] == w["wfold"][2, 32 * c + (lane & 31), (lane >> 5) * (d // 2) + 4 * sq + u]
+
+
+def test_ppr_cache_round_trip(tmp_path):
+    """load_or_calc_ppr: first call computes and stores under the reference's directory / file naming, the second
+    call reads the same matrix back; a cache for another graph size is refused."""
+    rng = np.random.default_rng(0)
+    n = 120
+    ei = rng.integers(0, n, size=(2, 500))
+    a = lpformer_amd.ppr.load_or_calc_ppr(ei, n, 0.15, 1e-3, cache_root=str(tmp_path), dataset="toy", is_val=True)
+    path = lpformer_amd.ppr.ppr_cache_path(str(tmp_path), "toy", 0.15, 1e-3, True)
+    assert path.endswith(os.path.join("node_subsets", "ppr", "toy", "sparse_adj-015_eps-0001_val.lpf.npz"))
+    assert os.path.isfile(path)
+    b = lpformer_amd.ppr.load_or_calc_ppr(np.zeros((2, 0), np.int64), n, 0.15, 1e-3, cache_root=str(tmp_path),
+                                          dataset="toy", is_val=True)  # edges ignored: served from the cache
+    np.testing.assert_array_equal(a.rowptr, b.rowptr)
+    np.testing.assert_array_equal(a.col, b.col)
+    np.testing.assert_array_equal(a.val.view(np.uint32), b.val.view(np.uint32))
+    with pytest.raises(_lib.LpfError):
+        lpformer_amd.ppr.load_or_calc_ppr(ei, n + 1, 0.15, 1e-3, cache_root=str(tmp_path), dataset="toy", is_val=True)
