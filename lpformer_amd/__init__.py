@@ -3,12 +3,14 @@
 Public surface mirrors the reference (HarryShomer/LPFormer):
     LinkTransformer, mlp_score          drop-ins for src/models/link_transformer.py / other_models.py
     LPFormer                            torch_geometric.nn.models.LPFormer-style facade (logits out)
-    calc_ppr, get_ppr                   drop-ins for src/util/calc_ppr_scores.py (host C++/OpenMP push)
+    calc_ppr, calc_ppr_gpu, get_ppr     drop-ins for src/util/calc_ppr_scores.py (host OpenMP push / MI355X push)
+    evaluate                            encoder-once, device-resident evaluation sweep + ranking metrics
     graph, data                         CSR containers and the data-dict builder
 """
-from . import graph  # noqa: F401
+from . import evaluate, graph  # noqa: F401
 from .link_transformer import MLP, LinkTransformer, mlp_score  # noqa: F401
-from .ppr import calc_ppr, get_ppr  # noqa: F401
+from .ppr import calc_ppr, calc_ppr_gpu, get_ppr, load_or_calc_ppr  # noqa: F401
 from .pyg_api import LPFormer  # noqa: F401
 
-__all__ = ["LinkTransformer", "mlp_score", "MLP", "LPFormer", "calc_ppr", "get_ppr", "graph"]
+__all__ = ["LinkTransformer", "mlp_score", "MLP", "LPFormer", "calc_ppr", "calc_ppr_gpu", "get_ppr",
+           "load_or_calc_ppr", "graph", "evaluate"]

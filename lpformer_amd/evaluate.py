@@ -1,0 +1,86 @@
+"""Evaluation sweep over many candidate pairs: the reference's ``test_edge`` /
+``test_heart_negatives`` / ``test_edge_citation2`` loops (src/train/testing.py:14-121) restructured for the device:
+
+* the encoder runs ONCE per sweep (``test_edge`` re-runs it for every batch through ``model(edge)``,
+  testing.py:87 -> link_transformer.py:100);
+* batches are issued round-robin over a few HIP streams, so the selection kernels of one batch run underneath the
+  matrix-core kernels of the previous one (per-stream workspaces in ``LinkTransformer``);
+* scores stay on the device -- no ``.cpu()`` per batch (testing.py:88,117); the ranking metrics below
+  (src/train/evaluation.py:23-50 and the OGB ``hits@K`` rule) are a few reductions over them.
+
+The metric helpers are plain tensor reductions over at most a few million scores (host-layer plumbing, any device).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+def _as_2xp(edges: torch.Tensor) -> torch.Tensor:
+    edges = torch.as_tensor(edges)
+    if edges.dim() != 2 or 2 not in edges.shape:
+        raise ValueError("edges must be [P, 2] (the reference's split layout) or [2, P]")
+    return edges.t() if edges.shape[1] == 2 and edges.shape[0] != 2 else edges
+
+
+@torch.no_grad()
+def score_edges(model, score_func, edges, batch_size: int = 32768, *, h: Optional[torch.Tensor] = None,
+                test_set: bool = False, streams: int = 3, logits: bool = False) -> torch.Tensor:
+    """Probabilities (or pre-sigmoid logits) for every pair of ``edges``, as one device tensor of shape [P].
+
+    Same arithmetic per pair as ``score_func(model(edge, test_set=test_set))`` of the reference loop; ``h`` (the encoder
+    output, ``model.propagate(test_set=...)``) is computed once if not given."""
+    dev = model.device
+    batch = _as_2xp(edges).to(dev)
+    if batch.dtype != torch.int64:
+        batch = batch.long()
+    batch = batch.contiguous()
+    total = batch.shape[1]
+    if h is None:
+        h = model.propagate(test_set=test_set)
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    if total == 0:
+        return out
+    main = torch.cuda.current_stream(dev)
+    lanes = [torch.cuda.Stream(dev) for _ in range(max(1, min(streams, (total + batch_size - 1) // batch_size)))]
+    for s in lanes:
+        s.wait_stream(main)  # h, batch and out are ready
+    for i, lo in enumerate(range(0, total, batch_size)):
+        hi = min(lo + batch_size, total)
+        with torch.cuda.stream(lanes[i % len(lanes)]):
+            feats = model.pair_features(batch[:, lo:hi], h, test_set=test_set)
+            out[lo:hi] = score_func.logits(feats) if logits else score_func(feats)
+    for s in lanes:
+        main.wait_stream(s)
+    return out
+
+
+@torch.no_grad()
+def score_negatives(model, score_func, negatives, batch_size: int = 32768, **kw) -> torch.Tensor:
+    """HeaRT-style negatives [P, K, 2] -> scores [P, K] (``test_heart_negatives``, testing.py:95-121)."""
+    negatives = torch.as_tensor(negatives)
+    p, k = negatives.shape[0], negatives.shape[1]
+    return score_edges(model, score_func, negatives.reshape(-1, 2), batch_size, **kw).view(p, k)
+
+
+def hits_at_k(pos: torch.Tensor, neg: torch.Tensor, k: int) -> float:
+    """OGB ``hits@K`` (what ``evaluate_hits`` asks the ogb Evaluator for, evaluation.py:7-18): the fraction of
+    positive scores strictly above the K-th largest negative score; 1.0 when there are fewer than K negatives."""
+    pos, neg = pos.reshape(-1), neg.reshape(-1)
+    if neg.numel() < k:
+        return 1.0
+    kth = torch.topk(neg, k).values[-1]
+    return float((pos > kth).float().mean().item()) if pos.numel() else float("nan")
+
+
+def ranking_metrics(pos: torch.Tensor, neg: torch.Tensor) -> dict:
+    """``evaluate_mrr`` (evaluation.py:23-50): per positive, rank among its own K negatives as the mean of the
+    optimistic and the pessimistic rank; MRR and Hits@{10,50,100} averaged over the positives.
+    pos [P], neg [P, K]."""
+    pos = pos.reshape(-1, 1)
+    optimistic = (neg >= pos).sum(dim=1)
+    pessimistic = (neg > pos).sum(dim=1)
+    rank = 0.5 * (optimistic + pessimistic).to(torch.float32) + 1.0
+    return {"Hits@10": float((rank <= 10).float().mean().item()), "Hits@50": float((rank <= 50).float().mean().item()),
+            "Hits@100": float((rank <= 100).float().mean().item()), "MRR": float((1.0 / rank).mean().item())}

@@ -128,3 +128,21 @@ def test_batches_pipelined_on_two_streams_match_serial():
     torch.cuda.synchronize()
     for a, b in zip(serial, outs):
         assert torch.equal(a, b)
+
+
+def test_evaluation_sweep_matches_per_batch_loop():
+    """lpformer_amd.evaluate.score_edges (encoder once, batches pipelined over streams, scores kept on the device)
+    equals the reference-style loop score_func(model(edge)) batch by batch; HeaRT negatives keep their [P, K] shape."""
+    from lpformer_amd import evaluate as E
+    cfg, n, ei, w, x, data, args, model, score, _ = _setup("cora", bs=1024)
+    rng = np.random.default_rng(4)
+    edges = torch.from_numpy(rng.integers(0, n, size=(5000, 2)))            # the reference's [P, 2] split layout
+    loop = torch.cat([score(model(edges[i:i + 1024].t())) for i in range(0, 5000, 1024)])
+    sweep = E.score_edges(model, score, edges, batch_size=1024, streams=3)
+    assert sweep.is_cuda and torch.equal(loop, sweep)
+    neg = torch.from_numpy(rng.integers(0, n, size=(40, 25, 2)))
+    sn = E.score_negatives(model, score, neg, batch_size=300)
+    assert sn.shape == (40, 25)
+    assert torch.equal(sn.reshape(-1), E.score_edges(model, score, neg.reshape(-1, 2), batch_size=1000, streams=1))
+    m = E.ranking_metrics(sweep[:40], sn)
+    assert 0.0 < m["MRR"] <= 1.0 and 0.0 <= E.hits_at_k(sweep[:40], sn, 20) <= 1.0

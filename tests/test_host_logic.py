@@ -165,3 +165,23 @@ def test_ppr_cache_round_trip(tmp_path):
     np.testing.assert_array_equal(a.val.view(np.uint32), b.val.view(np.uint32))
     with pytest.raises(_lib.LpfError):
         lpformer_amd.ppr.load_or_calc_ppr(ei, n + 1, 0.15, 1e-3, cache_root=str(tmp_path), dataset="toy", is_val=True)
+
+
+def test_ranking_metrics_match_reference_formulas():
+    """hits@K and the optimistic/pessimistic-rank MRR against plain numpy restatements of the reference's formulas
+    (src/train/evaluation.py:23-50 and the OGB hits@K rule), with ties."""
+    from lpformer_amd import evaluate as E
+    rng = np.random.default_rng(0)
+    pos = np.round(rng.random(300), 2).astype(np.float32)  # rounding creates ties
+    neg = np.round(rng.random((300, 40)), 2).astype(np.float32)
+    for k in (1, 10, 50, 100, 20000):
+        flat = np.sort(neg.reshape(-1))[::-1]
+        want = 1.0 if flat.size < k else float((pos > flat[k - 1]).mean())
+        assert abs(E.hits_at_k(torch.from_numpy(pos), torch.from_numpy(neg), k) - want) < 1e-7
+    opt = (neg >= pos[:, None]).sum(1)
+    pes = (neg > pos[:, None]).sum(1)
+    rank = 0.5 * (opt + pes) + 1
+    got = E.ranking_metrics(torch.from_numpy(pos), torch.from_numpy(neg))
+    assert abs(got["MRR"] - float((1.0 / rank).mean())) < 1e-6
+    for k in (10, 50, 100):
+        assert abs(got[f"Hits@{k}"] - float((rank <= k).mean())) < 1e-7
