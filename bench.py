@@ -215,6 +215,8 @@ def main():
                                    "launches_per_step": kt[name][0] / args.steps}
             # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE, gfx950-corrected)
             try:
+                if args.config != "collab":
+                    raise KeyError("the committed PMC passes were collected on the collab-like workload only")
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
                 # bench name -> (profile names, launches of the bench name they add up to)
                 alias = {"pair_softmax_gather": (("pair_softmax_gather_light", "pair_softmax_gather_heavy"), 1),
