@@ -126,7 +126,7 @@ def main():
 
     # consecutive steps rotate over `--streams` HIP streams: the selection kernels of one batch (latency / issue
     # bound) run under the MFMA kernels of the previous one.  Every step still does all of its work.
-    lanes = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))]
+    lanes = model.lanes(max(1, args.streams))
 
     def step_on(i):
         with torch.cuda.stream(lanes[i % len(lanes)]):

@@ -43,7 +43,7 @@ def score_edges(model, score_func, edges, batch_size: int = 32768, *, h: Optiona
     if total == 0:
         return out
     main = torch.cuda.current_stream(dev)
-    lanes = [torch.cuda.Stream(dev) for _ in range(max(1, min(streams, (total + batch_size - 1) // batch_size)))]
+    lanes = model.lanes(max(1, min(streams, (total + batch_size - 1) // batch_size)))  # persistent: workspaces are per stream
     for s in lanes:
         s.wait_stream(main)  # h, batch and out are ready
     for i, lo in enumerate(range(0, total, batch_size)):

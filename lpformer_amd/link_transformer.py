@@ -688,6 +688,15 @@ class LinkTransformer(nn.Module):
             return tuple(out)
 
     # ---------------------------------------------------------------------------------- pair stage
+    def lanes(self, k: int):
+        """``k`` persistent HIP streams for pipelining independent batches (workspaces are kept per stream, so callers
+        should reuse these instead of creating streams per sweep)."""
+        if not hasattr(self, "_lanes"):
+            self._lanes = []
+        while len(self._lanes) < k:
+            self._lanes.append(torch.cuda.Stream(self.device))
+        return self._lanes[:k]
+
     def _fork(self):
         """Side stream ordered after everything already queued on the caller's stream (None when disabled)."""
         if not self.use_side_stream or KernelTimer.enabled:  # per-kernel timing wants serial launches
