@@ -3,8 +3,9 @@
 //
 //   phase A  lpf_pair_scores_f32          score_e = att . leaky_relu((Z[v_e] + Wfold_t h_e + bfold_t) * q[pair_e])
 //            tiles of 32 same-type entries; h_e (first PE layer + LayerNorm + ReLU, both argument orders) is
-//            generated in registers as the B operand of v_mfma_f32_32x32x2_f32, Wfold_t streams in as the A operand
-//            from a pre-packed image (one contiguous 1 KiB wave read per 4 MFMA steps), accumulators hold
+//            generated in registers as the B operand of v_mfma_f32_32x32x2_f32, Wfold_t is the A operand from a
+//            pre-packed image (one contiguous 1 KiB wave read per 4 MFMA steps) -- resident in LDS and shared by the
+//            8 waves of a persistent workgroup when it fits (D <= 128), streamed from L2 otherwise; accumulators hold
 //            k_e^T = [feature][entry]; the epilogue gathers Z / q rows in 16-byte pieces and reduces over features
 //            in-lane (+ one cross-half shuffle).  Bound: fp32 MFMA (2*D*D FLOP per entry).
 //   phase B  lpf_pair_softmax_gather_f32  per-pair segment softmax, then the alpha-weighted sums of Z rows and of
@@ -159,6 +160,54 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void pair_scores_kernel(
         const float4 *wp = reinterpret_cast<const float4 *>(wpk) + (int64_t)t * NT * NSQ * 64 + lane;
         pair_scores_tile<NT>(t, base + within, within < cnt, lh, wp, tab, sel_pair, sel_node, sel_pa, sel_pb, Z, ldz, q,
                              ldq, pe_stat, bfold, att, score);
+    }
+}
+
+// Same tiles, Wfold_t RESIDENT IN LDS (D <= 128: the packed image of one type is 4*D*D <= 64 KiB).  Eight waves
+// share one copy; a workgroup walks groups of eight consecutive same-type tiles (tiles are type-major, so the groups a
+// workgroup sees come in non-decreasing type order and the image is reloaded at most three times).  The A operands
+// then arrive with LDS latency instead of L2 latency and the kernel's L2 reads drop by ~64 KiB per tile.
+constexpr int PSL_WAVES = 8;
+
+template <int NT>
+__global__ __launch_bounds__(64 * PSL_WAVES, 4) void pair_scores_lds_kernel(
+    const int64_t *__restrict__ type_ptr, int64_t bs, const int32_t *__restrict__ sel_pair,
+    const int32_t *__restrict__ sel_node, const float *__restrict__ sel_pa, const float *__restrict__ sel_pb,
+    const float *__restrict__ Z, int64_t ldz, const float *__restrict__ q, int64_t ldq,
+    const float *__restrict__ pe_tab, const float *__restrict__ pe_stat, const float *__restrict__ wpk,
+    const float *__restrict__ bfold, const float *__restrict__ att, float *__restrict__ score) {
+    constexpr int D = 32 * NT;
+    constexpr int NSQ = D / 8;
+    constexpr int IMG = NT * NSQ * 64;  // float4 per type
+    extern __shared__ __attribute__((aligned(16))) float4 psl_lds[];
+    float4 *wl = psl_lds, *tab = psl_lds + IMG;
+    for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) tab[i] = reinterpret_cast<const float4 *>(pe_tab)[i];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lj = lane & 31, lh = lane >> 5;
+    const int64_t n0 = type_ptr[bs], n1 = type_ptr[(bs + 1) + bs], n2 = type_ptr[2 * (bs + 1) + bs];
+    const int64_t t0 = (n0 + 31) >> 5, t1 = (n1 + 31) >> 5, t2 = (n2 + 31) >> 5;          // tiles per type
+    const int64_t g0 = (t0 + PSL_WAVES - 1) / PSL_WAVES, g1 = (t1 + PSL_WAVES - 1) / PSL_WAVES,
+                  g2 = (t2 + PSL_WAVES - 1) / PSL_WAVES;                                   // tile groups per type
+    int loaded = -1;
+    for (int64_t g = blockIdx.x; g < g0 + g1 + g2; g += gridDim.x) {
+        int t;
+        int64_t idx, base, cnt, tiles;
+        if (g < g0) { t = 0; idx = g * PSL_WAVES + wave; base = 0; cnt = n0; tiles = t0; }
+        else if (g < g0 + g1) { t = 1; idx = (g - g0) * PSL_WAVES + wave; base = n0; cnt = n1; tiles = t1; }
+        else { t = 2; idx = (g - g0 - g1) * PSL_WAVES + wave; base = n0 + n1; cnt = n2; tiles = t2; }
+        if (t != loaded) {  // (the first pass also publishes tab)
+            __syncthreads();
+            const float4 *src = reinterpret_cast<const float4 *>(wpk) + (int64_t)t * IMG;
+            for (int i = threadIdx.x; i < IMG; i += blockDim.x) wl[i] = src[i];
+            loaded = t;
+            __syncthreads();
+        }
+        if (idx < tiles) {
+            const int64_t within = idx * 32 + lj;
+            pair_scores_tile<NT>(t, base + within, within < cnt, lh, wl + lane, tab, sel_pair, sel_node, sel_pa, sel_pb,
+                                 Z, ldz, q, ldq, pe_stat, bfold, att, score);
+        }
     }
 }
 
@@ -419,17 +468,32 @@ extern "C" int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t b
     int64_t tiles = (max_entries + 31) / 32 + 3;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
+#define LPF_SCORES_LDS(NT)                                                                                         \
+    do {                                                                                                           \
+        auto kern = pair_scores_lds_kernel<NT>;                                                                    \
+        const size_t lds = (size_t)(NT * (32 * NT / 8) * 64 + 3 * 32 * NT) * sizeof(float4);                       \
+        if (lds > 64 * 1024 &&                                                                                     \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds) != hipSuccess)                                                           \
+            return LPF_ERR_LAUNCH;                                                                                 \
+        int64_t groups = (tiles + PSL_WAVES - 1) / PSL_WAVES + 3;                                                  \
+        if (groups > 512) groups = 512; /* two workgroups per CU */                                                \
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * PSL_WAVES), lds, s, type_ptr, bs, sel_pair,     \
+                           sel_node, sel_pa, sel_pb, Z, ldz, q, ldq, pe_tab, pe_stat, wfold_packed, bfold, att,    \
+                           score);                                                                                 \
+    } while (0)
 #define LPF_SCORES_LAUNCH(NT)                                                                                      \
     hipLaunchKernelGGL(pair_scores_kernel<NT>, dim3((unsigned)blocks), dim3(256), 0, s, type_ptr, bs, sel_pair,    \
                        sel_node, sel_pa, sel_pb, Z, ldz, q, ldq, pe_tab, pe_stat, wfold_packed, bfold, att, score)
     switch (D) {
-        case 32: LPF_SCORES_LAUNCH(1); break;
-        case 64: LPF_SCORES_LAUNCH(2); break;
-        case 128: LPF_SCORES_LAUNCH(4); break;
+        case 32: LPF_SCORES_LDS(1); break;
+        case 64: LPF_SCORES_LDS(2); break;
+        case 128: LPF_SCORES_LDS(4); break;
         case 256: LPF_SCORES_LAUNCH(8); break;
         default: return LPF_ERR_UNSUPPORTED;
     }
 #undef LPF_SCORES_LAUNCH
+#undef LPF_SCORES_LDS
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
