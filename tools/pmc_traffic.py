@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
-    ("pair_scores_kernel", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
+    ("pair_scores_", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
     ("pair_softmax_gather_kernel", "pair_softmax_gather_light"), ("select_nodes_indexed", "select_nodes"),
     ("select_nodes_kernel", "select_nodes_general"), ("select_compact", "select_compact"),
     ("select_bound", "select_bound"), ("select_items", "select_items"), ("select_counts", "select_counts"),
