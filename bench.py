@@ -178,7 +178,7 @@ def main():
             # structural totals over the batches actually timed
             tp = [model.compute_node_mask(b) for b in batches]
             nsel = [sum(int(t[0].shape[1]) for t in sel if t is not None) for sel in tp]
-            p1 = model._device_graph("p1", data["ppr"]).host
+            p1 = model._device_graph("p1", data["ppr"]).to_host()
             stats = [pair_stats(data, b, cfg["thresholds"], p1) for b in batches_np]
             used = [i % len(batches) for i in range(args.steps)]
             mean = lambda arr: float(np.mean([arr[i] for i in used]))  # noqa: E731

@@ -246,6 +246,23 @@ int lpf_ppr_pack_csr(int64_t n, const int64_t *row_off, const int32_t *row_len, 
                      void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-model indexes over the PPR matrix, built on the device.  Selection results are identical
+ * with and without them.
+ *   mode 0: the >1-hop candidates  p > 0 and fl32(fl32(p+1)-1) >= theta   (link_transformer.py:464-478)  -> "T0"
+ *   mode 1: the one-hop candidates fl32(fl32(p+1)-1) >= theta             (link_transformer.py:241-250,290-317) -> "P1"
+ * Two steps around an exclusive scan of out_len by the caller: count per row, then fill (column order preserved).
+ * ---------------------------------------------------------------------------------------------- */
+int lpf_ppr_filter_count(int64_t n, const int64_t *rowptr, const float *val, int32_t mode, float theta,
+                         int64_t *out_len, void *stream);
+int lpf_ppr_filter_fill(int64_t n, const int64_t *rowptr, const int32_t *col, const float *val, int32_t mode,
+                        float theta, const int64_t *out_rowptr, int32_t *out_col, float *out_val, void *stream);
+
+/* selfp[e] = P[i, j] for every adjacency entry e = (i, j) (0 where the PPR matrix stores nothing): the PPR of a node
+ * to its own neighbours, aligned with the adjacency CSR (the adj_selfp argument of lpf_select_nodes). */
+int lpf_self_ppr(int64_t n, const int64_t *adj_rowptr, const int32_t *adj_col, const int64_t *ppr_rowptr,
+                 const int32_t *ppr_col, const float *ppr_val, float *selfp, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host side (liblpformer_host.so)
  * ---------------------------------------------------------------------------------------------- */
 

@@ -24,7 +24,8 @@ from . import _lib
 
 @dataclass
 class CSR:
-    """Host CSR: rowptr int64[n+1], col int32[nnz] sorted inside rows, optional fp32 values."""
+    """Host CSR: rowptr int64[n+1], col int32[nnz] ascending inside rows without duplicates (the kernels binary-search
+    the rows and the model uploads these containers as they are), optional fp32 values."""
     rowptr: np.ndarray
     col: np.ndarray
     val: Optional[np.ndarray]
@@ -57,6 +58,13 @@ class DeviceCSR:
     @property
     def nnz(self) -> int:
         return int(self.col.numel())
+
+    def to_host(self) -> CSR:
+        """Host copy (cached): the arrays of indexes that were built on the device are downloaded on first use."""
+        if self.host is None:
+            self.host = CSR(self.rowptr.cpu().numpy(), self.col.cpu().numpy(),
+                            None if self.val is None else self.val.cpu().numpy(), self.n)
+        return self.host
 
 
 def _from_scipy(m: sp.spmatrix, n: int, keep_val: bool) -> CSR:
@@ -176,3 +184,34 @@ def gcn_norm_device(struct: DeviceCSR, stream=None) -> DeviceCSR:
                                             _lib.ptr(struct.val), _lib.ptr(w_out), _lib.ptr(dis), st),
                "lpf_gcn_norm_csr")
     return DeviceCSR(struct.rowptr, struct.col, w_out, struct.n, None)
+
+
+def ppr_filter_device(ppr: DeviceCSR, mode: int, theta: float) -> DeviceCSR:
+    """T0 (mode 0) / P1 (mode 1) index of a device-resident PPR matrix through ``lpf_ppr_filter_count`` / ``_fill``
+    (device twin of ``prefilter_nonhop`` / ``prefilter_onehop``)."""
+    from . import _lib
+    lib, dev, n = _lib.hip(), ppr.rowptr.device, ppr.n
+    st = torch.cuda.current_stream(dev).cuda_stream
+    lens = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    _lib.check(lib.lpf_ppr_filter_count(n, _lib.ptr(ppr.rowptr), _lib.ptr(ppr.val), mode, float(theta),
+                                        _lib.ptr(lens), st), "lpf_ppr_filter_count")
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens[:n], 0, out=rowptr[1:])
+    nnz = int(rowptr[-1].item())
+    col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+    _lib.check(lib.lpf_ppr_filter_fill(n, _lib.ptr(ppr.rowptr), _lib.ptr(ppr.col), _lib.ptr(ppr.val), mode,
+                                       float(theta), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), st),
+               "lpf_ppr_filter_fill")
+    return DeviceCSR(rowptr, col[:nnz], val[:nnz], n, None)
+
+
+def self_ppr_device(adj: DeviceCSR, ppr: DeviceCSR) -> torch.Tensor:
+    """``self_ppr`` on the device (``lpf_self_ppr``)."""
+    from . import _lib
+    dev = adj.rowptr.device
+    out = torch.empty(max(adj.nnz, 1), dtype=torch.float32, device=dev)
+    _lib.check(_lib.hip().lpf_self_ppr(adj.n, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(ppr.rowptr),
+                                       _lib.ptr(ppr.col), _lib.ptr(ppr.val), _lib.ptr(out),
+                                       torch.cuda.current_stream(dev).cuda_stream), "lpf_self_ppr")
+    return out[:adj.nnz]

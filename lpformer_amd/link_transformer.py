@@ -472,12 +472,15 @@ class LinkTransformer(nn.Module):
         if hit is not None and hit[0] is obj:
             return hit[1]
         dev = self.device
-        if kind == "t0":
-            host = self._device_graph("ppr", obj).host
-            g = graph.prefilter_nonhop(host, self.thresh_non1hop).to_device(dev)
+        if kind == "t0":    # per-model indexes: filtered on the device from the resident PPR matrix
+            g = graph.ppr_filter_device(self._device_graph("ppr", obj), 0, self.thresh_non1hop)
         elif kind == "p1":
-            host = self._device_graph("ppr", obj).host
-            g = graph.prefilter_onehop(host, self.thresh_1hop).to_device(dev)
+            g = graph.ppr_filter_device(self._device_graph("ppr", obj), 1, self.thresh_1hop)
+        elif isinstance(obj, graph.CSR) and kind in ("mask", "ppr"):
+            if kind == "ppr" and obj.val is None:
+                raise ValueError("the PPR matrix needs values")
+            # this package's own containers are sorted and coalesced already: upload as they are
+            g = (obj if kind == "ppr" else graph.CSR(obj.rowptr, obj.col, None, obj.n)).to_device(dev)
         else:
             row, col, val, n = graph.as_coo_numpy(obj)
             if kind == "prop":
@@ -495,7 +498,7 @@ class LinkTransformer(nn.Module):
         key = ("selfp", id(mask_obj), id(ppr_obj))
         hit = self._graphs.get(key)
         if hit is None or hit[0] is not mask_obj:
-            t = torch.from_numpy(graph.self_ppr(adj.host, ppr.host)).to(self.device)
+            t = graph.self_ppr_device(adj, ppr)
             self._graphs[key] = (mask_obj, t)
             return t
         return hit[1]

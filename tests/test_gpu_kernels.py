@@ -232,3 +232,30 @@ def test_gpu_ppr_push_directed_and_retry_path():
     gpu = lpformer_amd.ppr.calc_ppr_gpu(ei, n, 0.15, 1e-4, device=DEV, n_waves=8, pool_capacity=1000)
     _assert_same_csr(host, gpu)
     assert host.rowptr[-1] > 0
+
+
+# ------------------------------------------------------------------------------------------ device-built PPR indexes
+@pytest.mark.parametrize("theta", [0.0, 1e-4, 1e-2])
+def test_device_ppr_indexes_match_host_twins(theta):
+    """lpf_ppr_filter_count/_fill and lpf_self_ppr against graph.prefilter_nonhop / prefilter_onehop / self_ppr, with
+    PPR values jittered around the threshold so that the fp32 +1-1 round trip decides."""
+    import lpformer_amd
+    from lpformer_amd import data as D
+    n = 3000
+    ei, _ = D.chung_lu_graph(n, 12000, gamma=2.3, seed=9, max_weight=0)
+    ppr = lpformer_amd.calc_ppr(ei, n, 0.15, 2e-4)
+    rng = np.random.default_rng(0)
+    val = ppr.val.copy()
+    pick = rng.random(val.size) < 0.2
+    val[pick] = np.float32(max(theta, 1e-3)) * (1 + rng.integers(-6, 7, pick.sum()).astype(np.float32) * np.float32(2 ** -23))
+    ppr = graph.CSR(ppr.rowptr, ppr.col, val.astype(np.float32), n)
+    adj = graph.mask_csr(ei, n, symmetric=True)
+    dppr, dadj = ppr.to_device(DEV), adj.to_device(DEV)
+    for mode, host_fn in ((0, graph.prefilter_nonhop), (1, graph.prefilter_onehop)):
+        want = host_fn(ppr, theta)
+        got = graph.ppr_filter_device(dppr, mode, theta).to_host()
+        np.testing.assert_array_equal(got.rowptr, want.rowptr)
+        np.testing.assert_array_equal(got.col, want.col)
+        np.testing.assert_array_equal(got.val.view(np.uint32), want.val.view(np.uint32))
+    sp = graph.self_ppr_device(dadj, dppr).cpu().numpy()
+    np.testing.assert_array_equal(sp.view(np.uint32), graph.self_ppr(adj, ppr).view(np.uint32))
