@@ -19,7 +19,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int SG_HEAVY = 32;  // pairs with more selected nodes than this get a whole workgroup in phase B
+constexpr int SG_HEAVY = 64;        // pairs with more selected nodes than this get a whole workgroup in phase B
+constexpr int SG_HEAVY_CHUNK = 16;  // entries per lane-group chunk in that kernel
 
 struct PeStat {
     float c00, c11, cbb, c01, c0b, c1b;
@@ -214,21 +215,21 @@ __global__ __launch_bounds__(64 * PSL_WAVES, 4) void pair_scores_lds_kernel(
 // One chunk of up to G consecutive entries (same pair, same type) handled by one lane group: lane i fetches the
 // metadata of entry i (coalesced) and does the per-entry scalar math once (alpha, LayerNorm 1/std); then the entries
 // are broadcast one by one while every lane gathers its 16 bytes of the Z row, four rows in flight.
-template <int G>
+template <int G, int CH = G>  // CH <= G: entries per chunk (lanes past CH idle while the metadata is fetched)
 __device__ __forceinline__ void sg_chunk(const PeStat &st, const float4 (&k)[4], bool act, int off, int gbase, int lig,
                                          int remaining, int64_t e0, float m, float den,
                                          const int32_t *__restrict__ sel_node, const float *__restrict__ sel_pa,
                                          const float *__restrict__ sel_pb, const float *__restrict__ score,
                                          const float *__restrict__ Z, int64_t ldz, float *__restrict__ alpha_out,
                                          float4 &accz, float4 &acch, float &asum) {
-    const bool valid = lig < remaining;
+    const int n_here = remaining < CH ? remaining : CH;
+    const bool valid = lig < n_here;
     const int64_t e = e0 + lig;
     const float my_alpha = valid ? expf(score[e] - m) / den : 0.f;
     const float my_pa = valid ? sel_pa[e] : 0.f, my_pb = valid ? sel_pb[e] : 0.f;
     const int32_t my_node = valid ? sel_node[e] : 0;
     const float my_rab = pe_rstd(st, my_pa, my_pb), my_rba = pe_rstd(st, my_pb, my_pa);
     if (alpha_out && valid) alpha_out[e] = my_alpha;
-    const int n_here = remaining < G ? remaining : G;
     for (int j = 0; j < n_here; j += 4) {  // lanes past n_here carry alpha = 0, node = 0: harmless gathers
         float al[4], pa[4], pb[4], rab[4], rba[4];
         int32_t nd[4];
@@ -370,16 +371,17 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_heavy_kernel(
     const int gbase = ((tid & 63) / G) * G;  // first lane of this group inside its wavefront
     const bool act = off < D;
 
-    auto block_reduce = [&](float v, bool take_max) {
-        red[tid] = v;
-        __syncthreads();
-        for (int sft = 128; sft > 0; sft >>= 1) {
-            if (tid < sft) red[tid] = take_max ? fmaxf(red[tid], red[tid + sft]) : red[tid] + red[tid + sft];
-            __syncthreads();
+    auto block_reduce = [&](float v, bool take_max) {  // wave butterfly, then the four wave results through LDS
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const float o = __shfl_xor(v, sft, 64);
+            v = take_max ? fmaxf(v, o) : v + o;
         }
-        const float r = red[0];
+        __syncthreads();  // red[] free (previous use read by everyone)
+        if ((tid & 63) == 0) red[tid >> 6] = v;
         __syncthreads();
-        return r;
+        const float r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+        return take_max ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : (r0 + r1) + (r2 + r3);
     };
     float m = -INFINITY;
 #pragma unroll
@@ -407,10 +409,12 @@ __global__ __launch_bounds__(256) void pair_softmax_gather_heavy_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             k[u] = act ? reinterpret_cast<const float4 *>(pe_tab)[t * D + off + u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        // lane groups take chunks of G consecutive entries round-robin
-        for (int base = grp * G; base < cnt[t]; base += NG * G)
-            sg_chunk<G>(st, k, act, off, gbase, lig, cnt[t] - base, beg[t] + base, m, den, sel_node, sel_pa, sel_pb,
-                        score, Z, ldz, alpha_out, accz, acch[t], asum[t]);
+        // lane groups take chunks of SG_HEAVY_CHUNK consecutive entries round-robin (short chunks: a pair just above
+        // the threshold still spreads over most of the workgroup's lane groups)
+        for (int base = grp * SG_HEAVY_CHUNK; base < cnt[t]; base += NG * SG_HEAVY_CHUNK)
+            sg_chunk<G, (SG_HEAVY_CHUNK < G ? SG_HEAVY_CHUNK : G)>(st, k, act, off, gbase, lig, cnt[t] - base,
+                                                                 beg[t] + base, m, den, sel_node, sel_pa, sel_pb, score,
+                                                                 Z, ldz, alpha_out, accz, acch[t], asum[t]);
     }
     float *mine = part[grp];
     *reinterpret_cast<float4 *>(mine + off) = accz;
