@@ -545,15 +545,16 @@ struct CmpLds {
 // One wavefront per pair: dense runs -> reference layout.  CN entries go straight to their final place; the kept
 // one-hop nodes of the N(a) run and of the N(b) run are first compacted IN PLACE (writes never pass the read
 // cursor), then merged: two sorted, disjoint runs, final rank = own index + lower_bound in the other run.
-__global__ __launch_bounds__(256) void select_compact_kernel(
+template <int WPB>  // wavefronts (= concurrent pairs) per workgroup; the waves never synchronise with each other
+__global__ __launch_bounds__(64 * WPB) void select_compact_kernel(
     int64_t bs, const int64_t *__restrict__ desc, const int64_t *__restrict__ stage_off,
     int32_t *__restrict__ stage_node, float *__restrict__ stage_pa, float *__restrict__ stage_pb,
     const int32_t *__restrict__ stage_cnt, const int64_t *__restrict__ type_ptr, int32_t *__restrict__ sel_pair,
     int32_t *__restrict__ sel_node, float *__restrict__ sel_pa, float *__restrict__ sel_pb) {
     // four independent wavefronts per workgroup; the waves never synchronise with each other
-    __shared__ CmpLds cmp_lds[4];
+    __shared__ CmpLds cmp_lds[WPB];
     const int lane = threadIdx.x & 63;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const int64_t wave_id = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * WPB;
     const int64_t tot_cn = type_ptr[bs], tot_1 = type_ptr[(bs + 1) + bs];
     for (int64_t p = wave_id; p < bs; p += n_waves) {
         const int64_t dA = desc[p * DESC_I64 + 6], dB = desc[p * DESC_I64 + 7];
@@ -1022,9 +1023,9 @@ extern "C" int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && desc && offs && stage_node && stage_pa && stage_pb && stage_cnt &&
                 type_ptr && sel_pair && sel_node && sel_pa && sel_pb);
-    int64_t blocks = (bs + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(select_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), bs,
+    // one wavefront per workgroup: a pair with long runs does not hold the LDS / wave slots of three finished ones
+    const int64_t blocks = bs < (1 << 22) ? bs : (1 << 22);
+    hipLaunchKernelGGL(select_compact_kernel<1>, dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream), bs,
                        desc, offs, stage_node, stage_pa, stage_pb, stage_cnt, type_ptr, sel_pair, sel_node, sel_pa,
                        sel_pb);
     LPF_CHECK_LAUNCH();
