@@ -516,10 +516,10 @@ extern "C" int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t 
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(heavy_scratch, 0, sizeof(int32_t), s);  // heavy-pair counter
     const int GG = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
-    int64_t blocks = (bs + 4 * (64 / GG) - 1) / (4 * (64 / GG));
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    int64_t blocks = (bs + (64 / GG) - 1) / (64 / GG);
+    if (blocks > (1 << 22)) blocks = 1 << 22;
 #define LPF_SG_LAUNCH(GV)                                                                                       \
-    hipLaunchKernelGGL(pair_softmax_gather_kernel<GV>, dim3((unsigned)blocks), dim3(256), 0, s, D, bs, type_ptr, \
+    hipLaunchKernelGGL(pair_softmax_gather_kernel<GV>, dim3((unsigned)blocks), dim3(64), 0, s, D, bs, type_ptr, \
                        sel_node, sel_pa, sel_pb, score, Z, ldz, pe_tab, pe_stat, G, ldg, alpha_out, heavy_scratch)
     if (GG == 16) LPF_SG_LAUNCH(16);
     else if (GG == 32) LPF_SG_LAUNCH(32);
