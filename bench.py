@@ -69,14 +69,17 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="collab", choices=sorted(D.CONFIGS))
-    ap.add_argument("--batches", type=int, default=4, help="distinct candidate batches cycled through")
+    ap.add_argument("--batches", type=int, default=5,
+                    help="distinct candidate batches cycled through (coprime with --streams: every stream sees every batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=98304,
                     help="pairs timed on the CPU oracle (taken from the bench's own batches; about 10-15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--ppr", default="gpu", choices=("gpu", "host"),
                     help="PPR producer for the (untimed) setup: lpf_ppr_push_f64 on the GPU or the OpenMP host push")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--no-side-stream", action="store_true",
+                    help="keep the elementwise / q branches on the step's own stream (model.use_side_stream = False)")
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
 
@@ -98,6 +101,7 @@ def main():
     score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
     if world > 1:
         model.set_row_shard(rank, world)
+    model.use_side_stream = not args.no_side_stream
 
     # candidate batches resident in HBM before the timed region; distinct per rank
     batches_np = [D.sample_pairs(ei, n, bs, seed=1000 * rank + i) for i in range(args.batches)]

@@ -26,7 +26,7 @@ def _as_2xp(edges: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def score_edges(model, score_func, edges, batch_size: int = 32768, *, h: Optional[torch.Tensor] = None,
-                test_set: bool = False, streams: int = 3, logits: bool = False) -> torch.Tensor:
+                test_set: bool = False, streams: int = 4, logits: bool = False) -> torch.Tensor:
     """Probabilities (or pre-sigmoid logits) for every pair of ``edges``, as one device tensor of shape [P].
 
     Same arithmetic per pair as ``score_func(model(edge, test_set=test_set))`` of the reference loop; ``h`` (the encoder
