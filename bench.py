@@ -66,7 +66,7 @@ def pair_stats(data, batch, thresholds, p1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="collab", choices=sorted(D.CONFIGS))
     ap.add_argument("--batches", type=int, default=5,
