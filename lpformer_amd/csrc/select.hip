@@ -766,8 +766,8 @@ __global__ __launch_bounds__(64 * WPB) void select_compact_kernel(
 constexpr int IDX_P1_CAP = 256;  // P1 rows up to this length are searched in LDS (they hold at most ~1/theta_1 entries)
 struct alignas(16) IdxLds {     // 4 KiB per wavefront: eight wavefronts per SIMD fit
     int32_t cand[SEL_CAP];      // kind 0: N(a) then N(b); otherwise the slice
-    int32_t p1a[IDX_P1_CAP];    // columns of P1[a] / P1[b] when they fit (searched by the other endpoint's nodes)
-    int32_t p1b[IDX_P1_CAP];
+    int32_t p1[2 * IDX_P1_CAP];  // columns of P1[a] | P1[b] when they fit (searched by the other endpoint's nodes);
+                                 // reused as one buffer for the other endpoint's T0 row in the >1-hop pass
 };
 
 __device__ __forceinline__ int find_lds(const int32_t *a, int n, int32_t key) {
@@ -842,8 +842,8 @@ __global__ __launch_bounds__(64 * WPB) void select_nodes_indexed_kernel(
 #pragma unroll
         for (int u = 0; u < IDX_P1_CAP / 64; ++u) {
             const int i = lane + 64 * u;
-            if (p1a_lds && 64 * u < nPa && i < nPa) L.p1a[i] = ta[u];
-            if (p1b_lds && 64 * u < nPb && i < nPb) L.p1b[i] = tb[u];
+            if (p1a_lds && 64 * u < nPa && i < nPa) L.p1[i] = ta[u];
+            if (p1b_lds && 64 * u < nPb && i < nPb) L.p1[IDX_P1_CAP + i] = tb[u];
         }
         LPF_WAVE_SYNC();
 
@@ -869,8 +869,8 @@ __global__ __launch_bounds__(64 * WPB) void select_nodes_indexed_kernel(
                         other = selfp[rb0 + j];
                     } else if (ppr_round_trip(sp[u], false) >= th_1) {  // otherwise it is dropped anyway
                         int idx;
-                        if (from_a) idx = p1b_lds ? find_lds(L.p1b, nPb, x) : find_glb(p1_col + pb0, nPb, x);
-                        else idx = p1a_lds ? find_lds(L.p1a, nPa, x) : find_glb(p1_col + pa0, nPa, x);
+                        if (from_a) idx = p1b_lds ? find_lds(L.p1 + IDX_P1_CAP, nPb, x) : find_glb(p1_col + pb0, nPb, x);
+                        else idx = p1a_lds ? find_lds(L.p1, nPa, x) : find_glb(p1_col + pa0, nPa, x);
                         if (idx >= 0) other = p1_val[(from_a ? pb0 : pa0) + idx];
                     }
                     va = ppr_round_trip(from_a ? sp[u] : other, cn);
@@ -903,6 +903,15 @@ __global__ __launch_bounds__(64 * WPB) void select_nodes_indexed_kernel(
             }
             const int64_t t0_base = s + dA + dB;
             int n_t0 = 0;
+            // the other endpoint's T0 columns go to LDS in one coalesced burst (rows hold at most ~1/theta_n entries):
+            // each walked node then costs one LDS search + one value load instead of a global binary search
+            const int n_o = (int)(o1 - o0);
+            const bool o_lds = n_o <= 2 * IDX_P1_CAP;
+            if (o_lds && wn > 0) {
+                LPF_WAVE_SYNC();  // phase 2 is done with the P1 columns
+                for (int i = lane; i < n_o; i += 64) L.p1[i] = t0_col[o0 + i];
+                LPF_WAVE_SYNC();
+            }
             for (int64_t i0 = 0; i0 < wn; i0 += 64) {
                 const int64_t i = i0 + lane;
                 int32_t v = 0;
@@ -914,7 +923,14 @@ __global__ __launch_bounds__(64 * WPB) void select_nodes_indexed_kernel(
                     const float sw = __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f);
                     if (pw > 0.f && sw >= th_n) {
                         bool f;
-                        const float po = csr_value(t0_col, t0_val, o0, o1, v, &f);
+                        float po;
+                        if (o_lds) {
+                            const int idx = find_lds(L.p1, n_o, v);
+                            f = idx >= 0;
+                            po = f ? t0_val[o0 + idx] : 0.0f;
+                        } else {
+                            po = csr_value(t0_col, t0_val, o0, o1, v, &f);
+                        }
                         const float so = __fsub_rn(__fadd_rn(po, 1.0f), 1.0f);
                         if (f && po > 0.f && so >= th_n) {
                             const bool adjacent =
