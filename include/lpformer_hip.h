@@ -196,10 +196,8 @@ int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, 
  *   in_mode 0: x = X[m, :K1]; 1: x = X[a_m] * X[b_m]; 2: x = X[a_m] + X[b_m]  (batch: int64 [2, M], row stride batch_ld)
  *   w1_packed: layer-1 weights [N1, K1] in MFMA A-operand order, output tiles padded to an even count
  *              ntp1 = 2*ceil(N1/32).  k-group ks (16 input features) is ntp1*64 float4: float4 (c, lane = 16q + i) =
- *              W1[16c + i][16ks + 4q + 0..3].  A stage is g consecutive k-groups (two layers: g = 2 if
- *              max(ntp1, ntp2) <= 8 else 1; one layer: g = 4 if ntp1 <= 8, 2 if ntp1 <= 16, else 1), zero padded to a
- *              multiple of 512 float4; missing k-groups of the last stage are zeros.  The image is the concatenation
- *              of ceil(K1 / (16 g)) stages.
+ *              W1[16c + i][16ks + 4q + 0..3].  A stage is one k-group, zero padded to a multiple of 512 float4; the
+ *              image is the concatenation of ceil(K1 / 16) stages.
  *              b1, ln_g, ln_b: ntp1*16 floats, zero padded; ln_g NULL = no LayerNorm;
  *              flags & LPF_FLAG_RELU: ReLU after (the LayerNorm of) layer 1; addend [M, N1] optional (N1 % 4 == 0)
  *   w2_packed: NULL = single layer (out [M, N1]); N2 == 1: plain zero-padded vector of ntp1*16 floats, b2[0] the bias,

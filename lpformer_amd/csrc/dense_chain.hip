@@ -45,11 +45,14 @@ struct DenseChainArgs {
     float *prob;                 // dot mode: sigmoid(logit) (may be NULL)
 };
 
-// k-groups (16 input features) per pipeline stage; fold.py::dense_stage_groups mirrors this.  Chosen so that the two
-// weight buffers plus the hidden exchange stay within ~80 KiB (two workgroups per CU).
+// k-groups (16 input features) per pipeline stage; fold.py::dense_stage_groups mirrors this.  One: with batches
+// pipelined over streams the LDS a workgroup holds matters more than the barriers it saves (measured: 4 / 2 / 1
+// k-groups per stage for the single-layer chains give 72.8 / 75.7 / 76.0 M pairs/s; the q projection alone drops from
+// 0.033 to 0.020 ms).  The kernel stays templated on it.
 constexpr int dc_groups(int ntp1, int ntp2) {
-    if (ntp2 > 0) return (ntp1 > ntp2 ? ntp1 : ntp2) <= 8 ? 2 : 1;
-    return ntp1 <= 8 ? 4 : (ntp1 <= 16 ? 2 : 1);
+    (void)ntp1;
+    (void)ntp2;
+    return 1;
 }
 
 // Weight image (either layer), tiles padded to an even count NTP: "k-group" ks holds the A operands of the four MFMA

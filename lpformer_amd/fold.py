@@ -85,11 +85,8 @@ def _pad_to(a: np.ndarray, n: int) -> np.ndarray:
 
 def dense_stage_groups(nt1: int, nt2: int) -> int:
     """k-groups (16 input features each) per pipeline stage of lpf_dense_chain_f32 for a (nt1, nt2)-tile chain
-    (mirrors dc_groups in csrc/dense_chain.hip; tile counts are padded to even there)."""
-    p1, p2 = (nt1 + 1) & ~1, (nt2 + 1) & ~1
-    if p2 > 0:
-        return 2 if max(p1, p2) <= 8 else 1
-    return 4 if p1 <= 8 else (2 if p1 <= 16 else 1)
+    (mirrors dc_groups in csrc/dense_chain.hip: one, see there)."""
+    return 1
 
 
 def pack_dense(w: np.ndarray, g: int, k_groups: int = 0) -> np.ndarray:
