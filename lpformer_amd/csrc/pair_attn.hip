@@ -164,11 +164,13 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void pair_scores_kernel(
     }
 }
 
-// Same tiles, Wfold_t RESIDENT IN LDS (D <= 128: the packed image of one type is 4*D*D <= 64 KiB).  Eight waves
+// Same tiles, Wfold_t RESIDENT IN LDS (D <= 128: the packed image of one type is 4*D*D <= 64 KiB).  Sixteen waves
 // share one copy; a workgroup walks groups of eight consecutive same-type tiles (tiles are type-major, so the groups a
 // workgroup sees come in non-decreasing type order and the image is reloaded at most three times).  The A operands
-// then arrive with LDS latency instead of L2 latency and the kernel's L2 reads drop by ~64 KiB per tile.
-constexpr int PSL_WAVES = 8;
+// then arrive with LDS latency instead of L2 latency and the kernel's L2 reads drop by ~64 KiB per tile.  Sixteen
+// waves per workgroup, one workgroup per CU: the same four waves per SIMD as two 8-wave workgroups, but 70 instead of
+// 140 KiB of LDS, which the kernels of the other streams can use (76 -> 78 M pairs/s pipelined).
+constexpr int PSL_WAVES = 16;
 
 template <int NT>
 __global__ __launch_bounds__(64 * PSL_WAVES, 4) void pair_scores_lds_kernel(
@@ -481,7 +483,7 @@ extern "C" int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t b
                                 (int)lds) != hipSuccess)                                                           \
             return LPF_ERR_LAUNCH;                                                                                 \
         int64_t groups = (tiles + PSL_WAVES - 1) / PSL_WAVES + 3;                                                  \
-        if (groups > 512) groups = 512; /* two workgroups per CU */                                                \
+        if (groups > 256) groups = 256; /* one 16-wave workgroup per CU: half the LDS of two 8-wave ones */       \
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * PSL_WAVES), lds, s, type_ptr, bs, sel_pair,     \
                            sel_node, sel_pa, sel_pb, Z, ldz, q, ldq, pe_tab, pe_stat, wfold_packed, bfold, att,    \
                            score);                                                                                 \
