@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void pair_scores_kernel(
 }
 
 // Same tiles, Wfold_t RESIDENT IN LDS (D <= 128: the packed image of one type is 4*D*D <= 64 KiB).  Sixteen waves
-// share one copy; a workgroup walks groups of eight consecutive same-type tiles (tiles are type-major, so the groups a
+// share one copy; a workgroup walks groups of PSL_WAVES consecutive same-type tiles (tiles are type-major, so the groups a
 // workgroup sees come in non-decreasing type order and the image is reloaded at most three times).  The A operands
 // then arrive with LDS latency instead of L2 latency and the kernel's L2 reads drop by ~64 KiB per tile.  Sixteen
 // waves per workgroup, one workgroup per CU: the same four waves per SIMD as two 8-wave workgroups, but 70 instead of
