@@ -202,7 +202,8 @@ def main():
                 "gemm_q": ("mfma", 2.0 * bs * d * d),
                 # fused dense chains (lpf_dense_chain_f32): FLOPs of the Linear layers they contain
                 "dense_chain_attn_out": ("mfma", 2.0 * bs * d * (3 * d + 4)),
-                "dense_chain_q": ("mfma", 2.0 * bs * d * d),
+                # q = Y[a] + Y[b]: two gathered rows in, one row out per pair
+                "pair_gather_q": ("hbm", 3.0 * 4.0 * d * bs + 16.0 * bs),
                 "dense_chain_score": ("mfma", 2.0 * bs * (2 * d) * (2 * d + 1)),
                 "dense_chain_mlp": ("mfma", (2.0 * bs * (2 * d * d) + 2.0 * bs * (d + model.count_dim)
                                              * (2 * d + model.count_dim)) / 2.0),  # 2 launches/step, mean per launch

@@ -89,8 +89,9 @@ int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const f
  * Pair stage (reference: src/models/link_transformer.py:132-178 calc_pairwise and helpers)
  * ---------------------------------------------------------------------------------------------- */
 
-/* mul[k,:] = X[a_k,:] * X[b_k,:]  and  sum[k,:] = X[a_k,:] + X[b_k,:]   (link_transformer.py:101-102,143;
- * layers.py:212-215 with lin_l hoisted: lin_l(xa)+lin_l(xb) = W_l(xa+xb) + 2 b_l).
+/* mul[k,:] = X[a_k,:] * X[b_k,:]  and  sum[k,:] = X[a_k,:] + X[b_k,:]   (link_transformer.py:101-102,143).
+ * With X = Y := X_node W_l^T + b_l (one GEMM per encoder output) the sum IS the attention query of the pair,
+ * lin_l(xa) + lin_l(xb) (layers.py:212-215): no per-pair GEMM.
  * batch: int64 [2, bs] row-major (row 0 = a, row 1 = b) with row stride `batch_ld`.  mul or sum may be NULL. */
 int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, const float *X,
                         int64_t ldx, float *mul, int64_t ldm, float *sum, int64_t lds, void *stream);

@@ -60,7 +60,7 @@ def fold_attention(state: dict, dim: int, n_types: int, prefix="att_layers.0.att
     wcat = np.concatenate([wfold[0], wfold[1], wfold[2], bfold.T, bias[:, None]], axis=1)  # [D, 3D+4]
     return {
         "w_rx": w_rx.astype(np.float32), "b_r": b_r.astype(np.float32),
-        "w_l": w_l.astype(np.float32), "b_l2": (2.0 * b_l).astype(np.float32),
+        "w_l": w_l.astype(np.float32), "b_l": b_l.astype(np.float32), "b_l2": (2.0 * b_l).astype(np.float32),
         "att": att.astype(np.float32), "wfold": wfold.astype(np.float32), "bfold": bfold.astype(np.float32),
         "wfold_packed": pack_wfold(wfold.astype(np.float32)), "wcat": np.ascontiguousarray(wcat.astype(np.float32)),
     }

@@ -431,7 +431,6 @@ class LinkTransformer(nn.Module):
         self._x_cache = None   # (key, padded features)
         self._ws = {}          # named workspaces
         self._param_list = None  # cached list(self.parameters()) for the fold key
-        self._chain_q = DenseChain("dense_chain_q")            # lin_l(x_a + x_b)
         self._chain_att = DenseChain("dense_chain_attn_out")   # attention output projection + post_att_norm
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
         self.last_stats = {}
@@ -535,7 +534,7 @@ class LinkTransformer(nn.Module):
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
         self._folded = (key, dev)
         self._z_cache = None
-        self._chain_q._key = self._chain_att._key = None
+        self._chain_att._key = None
         return dev
 
     # ---------------------------------------------------------------------------------- encoder
@@ -590,14 +589,20 @@ class LinkTransformer(nn.Module):
             raise ValueError("need 0 <= rank < world")
         self._shard = (rank, world)
 
-    def _node_keys(self, x_node: torch.Tensor, w) -> torch.Tensor:
-        """Z = X_node W_rx^T + b_r, once per encoder output (cached on the tensor's identity and version)."""
+    def _node_keys(self, x_node: torch.Tensor, w):
+        """Per encoder output (cached on the tensor's identity and version), two node-level projections that the
+        reference recomputes per selected node / per pair:
+          Z = X_node W_rx^T + b_r   the node half of lin_r (k_e = Z[v] + ...),
+          Y = X_node W_l^T + b_l    lin_l per node, so that q_pair = lin_l(x_a) + lin_l(x_b) = Y[a] + Y[b] -- literally
+                                    the reference's expression (layers.py:212-215) -- is a gather-add, not a GEMM."""
         key = (x_node.data_ptr(), x_node._version, tuple(x_node.shape))
         if self._z_cache is None or self._z_cache[0] != key:
-            z = gemm(_as_f32_rows(x_node), w["w_rx"], w["b_r"], tag="gemm_node_keys")
-            torch.cuda.current_stream(self.device).synchronize()  # once per encoder output: other streams may read Z
-            self._z_cache = (key, z)
-        return self._z_cache[1]
+            xr = _as_f32_rows(x_node)
+            z = gemm(xr, w["w_rx"], w["b_r"], tag="gemm_node_keys")
+            y = gemm(xr, w["w_l"], w["b_l"], tag="gemm_node_keys")
+            torch.cuda.current_stream(self.device).synchronize()  # once per encoder output: other streams read Z, Y
+            self._z_cache = (key, z, y)
+        return self._z_cache[1], self._z_cache[2]
 
     # ---------------------------------------------------------------------------------- selection
     def _select(self, batch: torch.Tensor, test_set: bool, adj_mask=None):
@@ -724,19 +729,14 @@ class LinkTransformer(nn.Module):
             bs = batch.shape[1]
             w = self._fold()
             x_node = _as_f32_rows(X_node)
-            z = self._node_keys(x_node, w)
+            z, y = self._node_keys(x_node, w)
 
             q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
             side = self._fork()
             with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
-                if self._chain_q.run(self._chain_q.tables(w["w_l"], w["b_l2"]), x_node, relu=False, batch=batch,
-                                     in_mode=2, out=q) is None:
-                    qin = torch.empty(bs, d, dtype=torch.float32, device=self.device)
-                    with KernelTimer.span("pair_gather"):
-                        check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node),
-                                                      x_node.stride(0), None, 0, ptr(qin), d,
-                                                      _stream(self.device)), "lpf_pair_gather_f32")
-                    gemm(qin, w["w_l"], w["b_l2"], out=q, tag="gemm_q")
+                with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
+                    check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(y), y.stride(0), None, 0,
+                                                  ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
 
             s = self._select(batch, test_set, adj_mask)
             if side is not None:

@@ -17,7 +17,7 @@ SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
     ("scan_blocks", "scan_blocks"), ("spmm_csr_kernel", "spmm_csr"), ("spmm_long_rows", "spmm_long_rows"),
     ("gemm_f32_kernel<128>", "gemm128"), ("gemm_f32_kernel<64>", "gemm64"), ("layernorm", "layernorm"),
     ("dense_chain_kernel<8, 8", "dense_chain_elementwise"), ("dense_chain_kernel<9, 8", "dense_chain_pairwise"),
-    ("dense_chain_kernel<8, 0, 4, 2", "dense_chain_q"), ("dense_chain_kernel<8, 0, 4, 0", "dense_chain_attn_out"),
+    ("pair_gather_kernel", "pair_gather_q"), ("dense_chain_kernel<8, 0", "dense_chain_attn_out"),
     ("dense_chain_kernel<16, 0", "dense_chain_score"),
 ]
 
