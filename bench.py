@@ -124,9 +124,8 @@ def main():
     barrier()
     encoder_ms = LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / enc_reps, dev)
 
-    def step(i):
-        feats = model.pair_features(batches[i % len(batches)], h)
-        return score(feats)
+    def step(i):  # = score(cat(elementwise_lin(x_a * x_b), calc_pairwise(...))) with the boundary Linears folded
+        return model.score_pairs(batches[i % len(batches)], h, score)
 
     # consecutive steps rotate over `--streams` HIP streams: the selection kernels of one batch (latency / issue
     # bound) run under the MFMA kernels of the previous one.  Every step still does all of its work.
@@ -204,9 +203,11 @@ def main():
                 "dense_chain_attn_out": ("mfma", 2.0 * bs * d * (3 * d + 4)),
                 # q = Y[a] + Y[b]: two gathered rows in, one row out per pair
                 "pair_gather_q": ("hbm", 3.0 * 4.0 * d * bs + 16.0 * bs),
-                "dense_chain_score": ("mfma", 2.0 * bs * (2 * d) * (2 * d + 1)),
+                "dense_chain_score": ("mfma", 2.0 * bs * (2 * d) * (2 * d + model.count_dim + 1)),  # folded first layer
                 "dense_chain_mlp": ("mfma", (2.0 * bs * (2 * d * d) + 2.0 * bs * (d + model.count_dim)
                                              * (2 * d + model.count_dim)) / 2.0),  # 2 launches/step, mean per launch
+                # first layers alone (score_pairs): D x D and (D+c) x (D+c), mean per launch
+                "dense_chain_mlp_hidden": ("mfma", (2.0 * bs * d * d + 2.0 * bs * (d + model.count_dim) ** 2) / 2.0),
             }
             for name, (bound, units) in work.items():
                 if name not in kt:
@@ -277,7 +278,7 @@ def main():
             cpu_s = time.perf_counter() - t0
             ref_logit = np.concatenate(refs)
             # check the GPU scores of the same pairs against it while we are here
-            gl = np.concatenate([score.logits(model.pair_features(torch.from_numpy(sample[:, i:i + bs]).to(dev), h))
+            gl = np.concatenate([model.score_pairs(torch.from_numpy(sample[:, i:i + bs]).to(dev), h, score, logits=True)
                                  .cpu().numpy() for i in range(0, n_take, bs)])
             cpu = {"value": round(n_take / cpu_s, 1), "unit": "pairs/s", "cores": blas_threads,
                    "kind": "port",

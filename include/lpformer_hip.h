@@ -204,7 +204,8 @@ int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, 
  *   w2_packed: NULL = single layer (out [M, N1]); N2 == 1: plain zero-padded vector of ntp1*16 floats, b2[0] the bias,
  *              out = logits [M] and/or prob = sigmoid [M]; otherwise [N2, N1] packed like w1 over the ntp1 hidden
  *              tiles as k-groups (ntp2 = 2*ceil(N2/32) output tiles); b2: ntp2*16 floats
- *   K1 % 4 == 0.  Built tile shapes (nt1, nt2): (2|4|8|16|32, 0), (2,2) (4,4) (8,8) (16,16), (3,2) (5,4) (9,8) (17,16);
+ *   K1 % 4 == 0.  Built tile shapes (nt1, nt2): (2|3|4|5|8|9|16|17|32, 0), (2,2) (4,4) (8,8) (16,16), (3,2) (5,4) (9,8)
+ *   (17,16); in_mode 1 for the square pairs and (2|4|8|16, 0), in_mode 2 for (2|4|8|16, 0);
  *   anything else returns LPF_ERR_UNSUPPORTED (callers then use lpf_gemm_f32 + lpf_layernorm_f32).
  *   lpformer_amd/fold.py builds the packed images. */
 int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch,

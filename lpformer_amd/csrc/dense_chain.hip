@@ -387,11 +387,11 @@ extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, i
     DenseChainArgs a{M, in_mode, X, ldx, batch, batch_ld, K1, w1_packed, N1, b1, addend, ldadd, ln_g, ln_b, flags,
                      w2_packed, N2, b2, out, ldo, prob};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // in_mode 1 (gather-multiply) is built for the square two-layer chains (elementwise_lin), in_mode 2 (gather-add)
-    // for the single-layer ones (the q projection); plain rows for everything
+    // in_mode 1 (gather-multiply) is built for the square two-layer chains (elementwise_lin) and the single-layer
+    // ones (its first layer alone), in_mode 2 (gather-add) for the single-layer ones; plain rows for everything
 #define DC_CASE(T1, T2, MODE) \
     if (nt1 == T1 && nt2 == T2 && in_mode == MODE) return dc_launch<T1, T2, MODE>(a, s)
-#define DC_SINGLE(T1) DC_CASE(T1, 0, 0); DC_CASE(T1, 0, 2)
+#define DC_SINGLE(T1) DC_CASE(T1, 0, 0); DC_CASE(T1, 0, 1); DC_CASE(T1, 0, 2)
 #define DC_SQUARE(T1) DC_CASE(T1, T1, 0); DC_CASE(T1, T1, 1)
     DC_SINGLE(2);    // hidden 32
     DC_SINGLE(4);    // hidden 64: q projection, attention output, score head
@@ -402,6 +402,10 @@ extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, i
     DC_SQUARE(4);    // elementwise_lin 64 -> 64 -> 64
     DC_SQUARE(8);
     DC_SQUARE(16);
+    DC_CASE(3, 0, 0);   // first layer of pairwise_lin alone (hidden layer kept for the folded score head)
+    DC_CASE(5, 0, 0);
+    DC_CASE(9, 0, 0);
+    DC_CASE(17, 0, 0);
     DC_CASE(3, 2, 0);   // pairwise_lin: (D + counts) -> (D + counts) -> D
     DC_CASE(5, 4, 0);
     DC_CASE(9, 8, 0);

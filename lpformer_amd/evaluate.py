@@ -49,8 +49,7 @@ def score_edges(model, score_func, edges, batch_size: int = 32768, *, h: Optiona
     for i, lo in enumerate(range(0, total, batch_size)):
         hi = min(lo + batch_size, total)
         with torch.cuda.stream(lanes[i % len(lanes)]):
-            feats = model.pair_features(batch[:, lo:hi], h, test_set=test_set)
-            out[lo:hi] = score_func.logits(feats) if logits else score_func(feats)
+            out[lo:hi] = model.score_pairs(batch[:, lo:hi], h, score_func, test_set=test_set, logits=logits)
     for s in lanes:
         main.wait_stream(s)
     return out

@@ -112,8 +112,10 @@ class DenseChain:
     refreshed when a parameter changes.  ``run`` returns None when the shape has no fused instantiation (the caller
     then takes the unfused HIP kernels)."""
 
-    BUILT = {(2, 0), (4, 0), (8, 0), (16, 0), (32, 0), (2, 2), (4, 4), (8, 8), (16, 16), (3, 2), (5, 4), (9, 8),
-             (17, 16)}
+    BUILT = {(2, 0), (3, 0), (4, 0), (5, 0), (8, 0), (9, 0), (16, 0), (17, 0), (32, 0), (2, 2), (4, 4), (8, 8),
+             (16, 16), (3, 2), (5, 4), (9, 8), (17, 16)}
+    BUILT_GATHER = {1: {(2, 0), (4, 0), (8, 0), (16, 0), (2, 2), (4, 4), (8, 8), (16, 16)},
+                    2: {(2, 0), (4, 0), (8, 0), (16, 0)}}
 
     def __init__(self, tag: str):
         self.tag = tag
@@ -145,7 +147,8 @@ class DenseChain:
         k1, n1, n2 = t["shape"]
         nt1, dot = (n1 + 15) // 16, n2 == 1
         nt2 = 0 if (n2 == 0 or dot) else (n2 + 15) // 16
-        if (nt1, nt2) not in self.BUILT or k1 % 4 or x.stride(0) % 4 or x.data_ptr() % 16 or x.stride(1) != 1:
+        built = self.BUILT if in_mode == 0 else self.BUILT_GATHER[in_mode]
+        if (nt1, nt2) not in built or k1 % 4 or x.stride(0) % 4 or x.data_ptr() % 16 or x.stride(1) != 1:
             return None
         m = x.shape[0] if in_mode == 0 else batch.shape[1]
         dev = x.device
@@ -189,6 +192,7 @@ class MLP(nn.Module):
             self.linears.append(nn.Linear(hid_channels, out_channels, bias=bias))
         self._pads = [_PaddedLinear() for _ in self.linears]
         self._chain = DenseChain("dense_chain_mlp")
+        self._chain1 = DenseChain("dense_chain_mlp_hidden")  # first layer alone (LinkTransformer.score_pairs)
 
     def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, batch=None, in_mode=0) -> torch.Tensor:
         """x: [M, K] fp32 device rows (16-byte aligned).  Optionally writes the result into ``out`` (a strided view).
@@ -250,6 +254,7 @@ class mlp_score(nn.Module):  # noqa: N801  (name kept for drop-in compatibility)
         self.dropout = dropout
         self._pads = [_PaddedLinear() for _ in self.lins]
         self._chain = DenseChain("dense_chain_score")
+        self._chain_fold = DenseChain("dense_chain_score")  # folded first layer (LinkTransformer.score_pairs)
 
     def _run(self, x: torch.Tensor, want_prob: bool) -> torch.Tensor:
         _require_gpu(x, "mlp_score.forward")
@@ -265,23 +270,27 @@ class mlp_score(nn.Module):  # noqa: N801  (name kept for drop-in compatibility)
                     return res
             for i, lin in enumerate(self.lins[:-1]):
                 h = gemm(h, self._pads[i].get(lin.weight), lin.bias, relu=True)
-            last = self.lins[-1]
-            if last.out_features == 1:
-                res = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
-                w = last.weight.detach().reshape(-1).contiguous()
-                b = 0.0
-                if last.bias is not None:  # scalar kernel argument: read it back only when the parameter changes
-                    key = (last.bias.data_ptr(), last.bias._version)
-                    if getattr(self, "_bias_key", None) != key:
-                        self._bias_key, self._bias_val = key, float(last.bias.detach().item())
-                    b = self._bias_val
-                check(_lib.hip().lpf_rowdot_sigmoid_f32(h.shape[0], h.shape[1], ptr(h), h.stride(0), ptr(w), b,
-                                                        None if want_prob else ptr(res),
-                                                        ptr(res) if want_prob else None, _stream(h.device)),
-                      "lpf_rowdot_sigmoid_f32")
-                return res
-            y = gemm(h, self._pads[-1].get(last.weight), last.bias)
-            return torch.sigmoid(y).squeeze(-1) if want_prob else y.squeeze(-1)
+            return self._tail(h, want_prob)
+
+    def _tail(self, h: torch.Tensor, want_prob: bool) -> torch.Tensor:
+        """Last Linear (+ sigmoid) on the hidden activations ``h`` (unfused kernels)."""
+        last = self.lins[-1]
+        if last.out_features == 1:
+            res = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
+            w = last.weight.detach().reshape(-1).contiguous()
+            b = 0.0
+            if last.bias is not None:  # scalar kernel argument: read it back only when the parameter changes
+                key = (last.bias.data_ptr(), last.bias._version)
+                if getattr(self, "_bias_key", None) != key:
+                    self._bias_key, self._bias_val = key, float(last.bias.detach().item())
+                b = self._bias_val
+            check(_lib.hip().lpf_rowdot_sigmoid_f32(h.shape[0], h.shape[1], ptr(h), h.stride(0), ptr(w), b,
+                                                    None if want_prob else ptr(res),
+                                                    ptr(res) if want_prob else None, _stream(h.device)),
+                  "lpf_rowdot_sigmoid_f32")
+            return res
+        y = gemm(h, self._pads[-1].get(last.weight), last.bias)
+        return torch.sigmoid(y).squeeze(-1) if want_prob else y.squeeze(-1)
 
     def forward(self, x):
         return self._run(x, True)
@@ -718,17 +727,13 @@ class LinkTransformer(nn.Module):
         side.wait_stream(main)
         return side
 
-    def calc_pairwise(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False, _out=None):
-        """Pairwise branch (:132-178): selection -> PE + attention -> counts -> ``pairwise_lin``.
-        Returns ([BS, D], att_weights or None)."""
-        self._check_supported()
-        _require_gpu(X_node, "calc_pairwise")
+    def _pair_attention(self, batch, x_node, test_set, adj_mask, return_weights):
+        """Selection -> PE + attention (+ post-norm) -> count features.  Returns (feats [BS, ld] = [attention output |
+        counts | pad], att_weights or None); the caller applies ``pairwise_lin`` (or its folded first layer)."""
         with torch.no_grad():
             lib, st, d = _lib.hip(), _stream(self.device), self.dim
-            batch = self._prep_batch(batch)
             bs = batch.shape[1]
             w = self._fold()
-            x_node = _as_f32_rows(X_node)
             z, y = self._node_keys(x_node, w)
 
             q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
@@ -766,14 +771,96 @@ class LinkTransformer(nn.Module):
                 gemm(g[:, d:], w["wcat"], None, addend=g[:, :d], out=att_view, tag="gemm_attn_out")
                 layernorm_(att_view, layer.post_att_norm.weight, layer.post_att_norm.bias)
             self._last_att = att_view
-            out = self.pairwise_lin.run(feats[:, :d + self.count_dim], out=_out)
-
             att_weights = None
             if return_weights:
                 tp = s["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)
                 total = int(tp[:, bs].sum().item())
                 att_weights = torch.stack((s["sel_pair"][:total].float(), alpha[:total]))
+            return feats, att_weights
+
+    def calc_pairwise(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False, _out=None):
+        """Pairwise branch (:132-178): selection -> PE + attention -> counts -> ``pairwise_lin``.
+        Returns ([BS, D], att_weights or None)."""
+        self._check_supported()
+        _require_gpu(X_node, "calc_pairwise")
+        with torch.no_grad():
+            batch = self._prep_batch(batch)
+            feats, att_weights = self._pair_attention(batch, _as_f32_rows(X_node), test_set, adj_mask, return_weights)
+            out = self.pairwise_lin.run(feats[:, :self.dim + self.count_dim], out=_out)
             return out, att_weights
+
+    # ---------------------------------------------------------------------------------- folded score path
+    def _score_fold(self, score_func):
+        """Parameter-only fold across the module boundary: there is no non-linearity between the last Linear of
+        ``elementwise_lin`` / ``pairwise_lin`` and the first Linear of the score head, so
+            lins0([ew | pw]) = A_e r_e + A_p r_p + c,   A_e = W_s0[:, :D] W_e1,  A_p = W_s0[:, D:] W_p1,
+            c = b_s0 + W_s0[:, :D] b_e1 + W_s0[:, D:] b_p1
+        with r_e / r_p the hidden activations (after LayerNorm + ReLU) of the two MLPs.  Folded in float64."""
+        d, pd = self.dim, self.dim + self.count_dim
+        ps = [self.elementwise_lin.linears[1].weight, self.elementwise_lin.linears[1].bias,
+              self.pairwise_lin.linears[1].weight, self.pairwise_lin.linears[1].bias,
+              score_func.lins[0].weight, score_func.lins[0].bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (id(score_func),)
+        hit = getattr(self, "_score_fold_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        we1, be1, wp1, bp1, ws0, bs0 = (p.detach().double().cpu() for p in ps)
+        kpad = _pad4(d + pd)
+        a = torch.zeros(ws0.shape[0], kpad, dtype=torch.float64)
+        a[:, :d] = ws0[:, :d] @ we1
+        a[:, d:d + pd] = ws0[:, d:] @ wp1
+        c = bs0 + ws0[:, :d] @ be1 + ws0[:, d:] @ bp1
+        out = (a.float().to(self.device), c.float().to(self.device), kpad)
+        self._score_fold_cache = (key, out)
+        return out
+
+    def score_pairs(self, batch, X_node, score_func, test_set=False, adj_mask=None, logits=False):
+        """``score_func(cat(elementwise_lin(x_a * x_b), calc_pairwise(...)[0]))`` -- the reference's scoring
+        expression (src/train/testing.py:29-31,113-117) -- with the three Linear layers around the module boundary
+        folded into one (``_score_fold``): probabilities (or logits) of shape [BS].  Falls back to the unfolded
+        modules when the score head is not the two-layer MLP every script uses."""
+        self._check_supported()
+        _require_gpu(X_node, "score_pairs")
+        two_layer = (len(score_func.lins) == 2 and score_func.lins[1].out_features == 1 and
+                     len(self.elementwise_lin.linears) == 2 and len(self.pairwise_lin.linears) == 2 and
+                     not (score_func.training and score_func.dropout > 0))
+        if not two_layer:
+            feats = self.pair_features(batch, X_node, test_set=test_set, adj_mask=adj_mask)
+            return score_func.logits(feats) if logits else score_func(feats)
+        with torch.no_grad():
+            d, pd = self.dim, self.dim + self.count_dim
+            batch = self._prep_batch(batch)
+            bs = batch.shape[1]
+            x_node = _as_f32_rows(X_node)
+            a, c, kpad = self._score_fold(score_func)
+            r = torch.empty(bs, kpad, dtype=torch.float32, device=self.device)  # [r_e | r_p | pad]
+            if kpad > d + pd:
+                r[:, d + pd:].zero_()
+            ew, pw = self.elementwise_lin, self.pairwise_lin
+            side = self._fork()
+            with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+                t = ew._chain1.tables(ew.linears[0].weight, ew.linears[0].bias, ew.norm.weight, ew.norm.bias)
+                if ew._chain1.run(t, x_node, relu=True, batch=batch, in_mode=1, out=r[:, :d]) is None:
+                    prod = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+                    with KernelTimer.span("pair_gather"):
+                        check(_lib.hip().lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node),
+                                                             x_node.stride(0), ptr(prod), d, None, 0,
+                                                             _stream(self.device)), "lpf_pair_gather_f32")
+                    gemm(prod, ew._pads[0].get(ew.linears[0].weight), ew.linears[0].bias, out=r[:, :d])
+                    layernorm_(r[:, :d], ew.norm.weight, ew.norm.bias, relu=True)
+            feats, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False)  # joins the side stream
+            xin = feats[:, :pd]
+            t = pw._chain1.tables(pw.linears[0].weight, pw.linears[0].bias, pw.norm.weight, pw.norm.bias)
+            if pw._chain1.run(t, xin, relu=True, out=r[:, d:d + pd]) is None:
+                gemm(xin, pw._pads[0].get(pw.linears[0].weight), pw.linears[0].bias, out=r[:, d:d + pd])
+                layernorm_(r[:, d:d + pd], pw.norm.weight, pw.norm.bias, relu=True)
+            l2 = score_func.lins[1]
+            t = score_func._chain_fold.tables(a, c, None, None, l2.weight, l2.bias)
+            res = score_func._chain_fold.run(t, r, relu=True, want_logit=logits)
+            if res is None:
+                hid = gemm(r, a, c, relu=True)
+                res = score_func._tail(hid, not logits)
+            return res
 
     def forward(self, batch, adj_prop=None, adj_mask=None, test_set=False, return_weights=False):
         """Link representations [BS, 2D] = [elementwise branch | pairwise branch] (reference :82-107).  Like the

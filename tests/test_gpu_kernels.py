@@ -175,13 +175,13 @@ def test_dense_chain_gathered_inputs(in_mode, d):
 
 
 def test_dense_chain_unsupported_shape_is_reported():
-    x, w1, b1 = torch.randn(8, 80, device=DEV), torch.randn(80, 80, device=DEV), torch.randn(80, device=DEV)
+    x, w1, b1 = torch.randn(8, 96, device=DEV), torch.randn(96, 96, device=DEV), torch.randn(96, device=DEV)
     dc = DenseChain("t")
-    assert dc.run(dc.tables(w1, b1), x, relu=False) is None  # nt1 = 5 single layer is not built
+    assert dc.run(dc.tables(w1, b1), x, relu=False) is None  # nt1 = 6 single layer is not built
     t = dc.tables(w1, b1)
-    rc = _lib.hip().lpf_dense_chain_f32(8, 0, _lib.ptr(x), 80, None, 0, 80, _lib.ptr(t["w1p"]), 80, _lib.ptr(t["b1"]),
-                                        None, 0, None, None, 0, None, 0, None, _lib.ptr(torch.empty(8, 80, device=DEV)),
-                                        80, None, None)
+    rc = _lib.hip().lpf_dense_chain_f32(8, 0, _lib.ptr(x), 96, None, 0, 96, _lib.ptr(t["w1p"]), 96, _lib.ptr(t["b1"]),
+                                        None, 0, None, None, 0, None, 0, None, _lib.ptr(torch.empty(8, 96, device=DEV)),
+                                        96, None, None)
     assert rc == -2
 
 
