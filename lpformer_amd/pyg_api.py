@@ -65,7 +65,7 @@ class LPFormer(nn.Module):
     def forward(self, batch: torch.Tensor, x: torch.Tensor, edge_index: torch.Tensor, ppr_matrix) -> torch.Tensor:
         """Logits [BS] for the candidate pairs ``batch`` [2, BS]."""
         self._bind(x, edge_index, ppr_matrix)
-        return self.score.logits(self.core(batch))
+        return self.core.score_pairs(batch, self.core.propagate(), self.score, logits=True)
 
     def propagate(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         self._bind(x, edge_index, self.core.data.get("ppr"))
