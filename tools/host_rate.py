@@ -19,12 +19,12 @@ score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval(
 h = model.propagate()
 for bs in (256, 32768):
     batches = [torch.from_numpy(D.sample_pairs(ei, cfg["n"], bs, seed=i)).to(dev) for i in range(4)]
-    for nl in (1, 3):
+    for nl in (1, 4):
         lanes = model.lanes(nl)
 
         def step(i):
             with torch.cuda.stream(lanes[i % nl]):
-                return score(model.pair_features(batches[i % 4], h))
+                return model.score_pairs(batches[i % 4], h, score)
         for i in range(10):
             step(i)
         torch.cuda.synchronize()
