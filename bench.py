@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--ppr", default="gpu", choices=("gpu", "host"),
                     help="PPR producer for the (untimed) setup: lpf_ppr_push_f64 on the GPU or the OpenMP host push")
+    ap.add_argument("--spinup", type=float, default=1.0,
+                    help="seconds of untimed steps after the W warm-up steps, so that the device holds its clocks")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="keep the elementwise / q branches on the step's own stream (model.use_side_stream = False)")
     ap.add_argument("--streams", type=int, default=4,
@@ -138,6 +140,14 @@ def main():
     for i in range(max(args.warmup, len(lanes))):
         step_on(i)
     torch.cuda.synchronize()
+    # device spin-up (untimed): a freshly started MI355X needs ~0.5 s of sustained work before it holds its clocks --
+    # the first process on a cold box measures 55 M pairs/s in a 50 ms timed window and 82 M after this
+    t_spin, n_spin = time.perf_counter(), 0
+    while args.spinup > 0 and time.perf_counter() - t_spin < args.spinup:
+        for i in range(16):
+            step_on(i)
+        torch.cuda.synchronize()
+        n_spin += 16
 
     # ---- timed region: EXACTLY `steps` steps, nothing but the scoring path (no event recording)
     KernelTimer.enabled = False
@@ -297,7 +307,7 @@ def main():
                                    f"PPR eps={cfg['eps']}), {bs} candidate pairs per GPU per step, pair stage with "
                                    "encoder output resident",
                        "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
-                       "streams": len(lanes),
+                       "streams": len(lanes), "spinup_s": args.spinup,
                        "parallelism": f"pairs sharded x{world}, encoder row-sharded + all-gather" if world > 1
                        else "single GPU"},
             "encoder_ms": round(encoder_ms, 4), "value_incl_encoder": round(value_incl_encoder, 1),
