@@ -220,6 +220,9 @@ def main():
                 "dense_chain_score": ("mfma", 2.0 * bs * (2 * d) * (2 * d + model.count_dim + 1)),  # folded first layer
                 "dense_chain_mlp": ("mfma", (2.0 * bs * (2 * d * d) + 2.0 * bs * (d + model.count_dim)
                                              * (2 * d + model.count_dim)) / 2.0),  # 2 launches/step, mean per launch
+                # attention output + first layer of pairwise_lin + folded score head in one launch
+                "tail_chain": ("mfma", 2.0 * bs * (d * (3 * d + 4) + (d + model.count_dim) ** 2
+                                                  + 2 * d * (2 * d + model.count_dim))),
                 # first layers alone (score_pairs): D x D and (D+c) x (D+c), mean per launch
                 "dense_chain_mlp_hidden": ("mfma", (2.0 * bs * d * d + 2.0 * bs * (d + model.count_dim) ** 2) / 2.0),
             }

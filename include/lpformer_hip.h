@@ -214,6 +214,22 @@ int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx,
                         const float *w2_packed, int32_t N2, const float *b2, float *out, int64_t ldo, float *prob,
                         void *stream);
 
+/* The dense tail of the scoring path in one launch (what LinkTransformer.score_pairs runs after the softmax-gather):
+ *   o   = post_att_norm( G[:, D:] Wcat^T + G[:, :D] )                        (layers.py:78; G from
+ *                                                                              lpf_pair_softmax_gather_f32)
+ *   r_p = ReLU(LayerNorm( W_p0 [o | counts] + b_p0 ))                         first layer of pairwise_lin
+ *   s   = w_dot . ReLU( W_C [r_e | r_p] + b_C ) + b_dot ;  prob = sigmoid(s)   score head, boundary Linears folded
+ * D in {32, 64, 128} (else LPF_ERR_UNSUPPORTED: run the three lpf_dense_chain_f32 launches).  n_counts = 4 (3 in
+ * "1-hop" mode; the fourth float of `counts` must then be 0).  Weight images in the lpf_dense_chain_f32 layout (one
+ * k-group per stage): wA = Wcat [D, 3D+4]; wB = W_p0 [D+n, D+n]; wC = [A_e | A_p] laid out over D + 16*2*ceil((D+n)/32)
+ * input columns (r_e first, then the even-tile-padded r_p).  lnA_*: D floats; bB, lnB_*: padded to the even tile
+ * count of D+n; bC, w_dot: 2D floats; b_dot: 1 float.  r_e [M, D] = hidden activations of elementwise_lin. */
+int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const float *G, int64_t ldg, const float *wA_packed,
+                       const float *lnA_g, const float *lnA_b, const float *counts, int64_t ldc,
+                       const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
+                       const float *r_e, int64_t ldre, const float *wC_packed, const float *bC, const float *w_dot,
+                       const float *b_dot, float *logit, float *prob, void *stream);
+
 /* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
  * logit or prob may be NULL. */
 int lpf_rowdot_sigmoid_f32(int64_t M, int32_t K, const float *A, int64_t lda, const float *w, float b,

@@ -34,6 +34,8 @@ HIP_PROTOTYPES = {
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp],
     "lpf_rowdot_sigmoid_f32": [i64, i32, vp, i64, vp, f32, vp, vp, vp],
+    "lpf_tail_chain_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
+                           vp, vp],
     "lpf_ppr_filter_count": [i64, vp, vp, i32, f32, vp, vp],
     "lpf_ppr_filter_fill": [i64, vp, vp, vp, i32, f32, vp, vp, vp, vp],
     "lpf_self_ppr": [i64, vp, vp, vp, vp, vp, vp, vp],

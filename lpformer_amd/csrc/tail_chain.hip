@@ -1,0 +1,301 @@
+// The dense tail of the scoring path in ONE launch (LinkTransformer.score_pairs):
+//
+//   A  o   = LayerNorm_post( G[:, D:] Wcat^T + G[:, :D] )                attention output (layers.py:78)
+//   B  r_p = ReLU(LayerNorm( W_p0 [o | counts] + b_p0 ))                 first layer of pairwise_lin
+//   C  s   = w_s1 . ReLU( A_e r_e + A_p r_p + c ) + b_s1 ; sigmoid       score head with the boundary Linears folded
+//
+// Same machinery as dense_chain.hip (samples on the MFMA columns, a pair of wavefronts per 16 samples splitting the
+// feature tiles, weights host-packed in A-operand order and staged global -> registers -> LDS one k-group ahead,
+// double-buffered, one barrier per stage), with three stages chained through LDS: a stage's accumulators, written in
+// accumulator layout, are the next stage's B operands.  Stage B appends one k-group read from global memory (the
+// count features), stage C starts with k-groups read from global memory (r_e, produced on the side stream by the
+// elementwise branch).  Against three separate launches this removes two launch ramps and the round trips of the
+// attention output and of r_p through HBM.
+#include "lpf_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TC_GROUPS = 4;               // 16-sample groups per workgroup
+constexpr int TC_WAVES = 2 * TC_GROUPS;    // a wave pair per group
+constexpr int TC_THREADS = 64 * TC_WAVES;
+
+struct TailArgs {
+    int64_t M;
+    const float *x; int64_t ldx; int KA;               // stage A input rows [M, KA]
+    const float *addend; int64_t ldadd;                // [M, NA]
+    const float *wA, *lnA_g, *lnA_b; int NA;
+    const float *tail; int64_t ldtail;                 // [M, 4] appended to stage B's input (count features)
+    const float *wB, *bB, *lnB_g, *lnB_b; int NB;
+    const float *re; int64_t ldre;                     // [M, 16 * NGE] leading input of stage C
+    const float *wC, *bC; int NC;
+    const float *wdot, *bdot;
+    float *logit, *prob;
+};
+
+constexpr int tc_per_thread(int ntp) { return (ntp * 64 + TC_THREADS - 1) / TC_THREADS; }
+
+template <int P>
+__device__ __forceinline__ void tc_load(f32x4 (&r)[P], const float *packed, int stage, int tid) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(packed) + (int64_t)stage * (P * TC_THREADS);
+#pragma unroll
+    for (int e = 0; e < P; ++e) r[e] = src[e * TC_THREADS + tid];
+}
+template <int P>
+__device__ __forceinline__ void tc_store(const f32x4 (&r)[P], f32x4 *slab, int tid) {
+#pragma unroll
+    for (int e = 0; e < P; ++e) slab[e * TC_THREADS + tid] = r[e];
+}
+
+// acc[c] += W[16 (c0 + c) + i][k-group] * bv for this wave's TPW tiles; lw = slab + c0 * 64 + lane
+template <int TPW>
+__device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const f32x4 *lw, const f32x4 bv) {
+    f32x4 a[TPW];
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) a[c] = lw[c * 64];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)  // consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][u], bv[u], acc[c], 0, 0, 0);
+}
+
+__device__ __forceinline__ float tc_quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// LayerNorm over the n real features held by the wave pair (this wave: TPW tiles from feature fbase), in place
+template <int TPW>
+__device__ __forceinline__ void tc_layernorm(f32x4 (&acc)[TPW], int fbase, int n, const float *g, const float *b, int half,
+                                             int q, float *my_x, const float *peer_x, bool relu) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) s1 += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    s1 = tc_quad_sum(s1);  // padded features are exactly 0 and add nothing
+    __syncthreads();       // exchange slots free
+    if (q == 0) *my_x = s1;
+    __syncthreads();
+    const float mean = (half == 0 ? s1 + *peer_x : *peer_x + s1) / (float)n;  // same order in both waves
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < TPW; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = (fbase + 16 * c + r < n) ? acc[c][r] - mean : 0.f;
+            s2 += d * d;
+        }
+    s2 = tc_quad_sum(s2);
+    __syncthreads();
+    if (q == 0) *my_x = s2;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((half == 0 ? s2 + *peer_x : *peer_x + s2) / (float)n + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + fbase + 16 * c);  // zero-padded: pads come out 0
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(b + fbase + 16 * c);
+        acc[c] = (acc[c] - mean) * rstd * gg + bb;
+        if (relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[c][r] = fmaxf(acc[c][r], 0.f);
+        }
+    }
+}
+
+// NTA / NTB / NTC: 16-feature tiles of the three stages' outputs (NTA = NGE = D/16)
+template <int NTA, int NTB, int NTC>
+struct TcShape {
+    static constexpr int NTPA = (NTA + 1) & ~1, NTPB = (NTB + 1) & ~1, NTPC = (NTC + 1) & ~1;
+    static constexpr int PA = tc_per_thread(NTPA), PB = tc_per_thread(NTPB), PC = tc_per_thread(NTPC);
+    static constexpr int PM = PA > PB ? (PA > PC ? PA : PC) : (PB > PC ? PB : PC);
+    static constexpr int SLAB = PM * TC_THREADS;
+    static constexpr int HT = NTPA > NTPB ? NTPA : NTPB;  // hidden tiles kept per sample group
+    static constexpr int HID = TC_GROUPS * HT * 64;
+    static constexpr size_t BYTES = (size_t)(2 * SLAB + HID) * sizeof(f32x4) + TC_WAVES * 16 * sizeof(float);
+};
+
+template <int NTA, int NTB, int NTC>
+__global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArgs A) {
+    using S = TcShape<NTA, NTB, NTC>;
+    constexpr int NTPA = S::NTPA, NTPB = S::NTPB, NTPC = S::NTPC;
+    constexpr int TPWA = NTPA / 2, TPWB = NTPB / 2, TPWC = NTPC / 2;
+    constexpr int NGE = NTA;  // k-groups of r_e
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    f32x4 *hid = lds + 2 * S::SLAB;
+    float *xch = reinterpret_cast<float *>(hid + S::HID);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 1, half = wave & 1, q = lane >> 4, j = lane & 15;
+    float *my_x = xch + wave * 16 + j;
+    const float *peer_x = xch + (wave ^ 1) * 16 + j;
+    f32x4 *my_hid = hid + (grp * S::HT) * 64 + lane;
+    int buf = 0;
+
+    const int64_t m = (int64_t)blockIdx.x * (16 * TC_GROUPS) + grp * 16 + j;
+    const bool live = m < A.M;
+    const int64_t mm = live ? m : A.M - 1;  // dead lanes compute on a valid row and store nothing
+
+    // ------------------------------------------------------------------ stage A: attention output + post-norm
+    f32x4 accA[TPWA];
+#pragma unroll
+    for (int c = 0; c < TPWA; ++c) accA[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const float *xa = A.x + mm * A.ldx;
+        const int ngA = (A.KA + 15) >> 4;
+        f32x4 wr[S::PA];
+        tc_load<S::PA>(wr, A.wA, 0, tid);
+        int kk = 4 * q < A.KA ? 4 * q : A.KA - 4;  // clamped into the row; out-of-range groups are zeroed below
+        f32x4 xr = *reinterpret_cast<const f32x4 *>(xa + kk);
+#pragma unroll 1
+        for (int kg = 0; kg < ngA; ++kg) {
+            const f32x4 bv = (16 * kg + 4 * q < A.KA) ? xr : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 *lw = lds + buf * S::SLAB;
+            tc_store<S::PA>(wr, lw, tid);
+            __syncthreads();
+            if (kg + 1 < ngA) {  // next k-group's operands fly while this one's MFMAs run
+                tc_load<S::PA>(wr, A.wA, kg + 1, tid);
+                kk = 16 * (kg + 1) + 4 * q;
+                kk = kk < A.KA ? kk : A.KA - 4;
+                xr = *reinterpret_cast<const f32x4 *>(xa + kk);
+            }
+            tc_mfma<TPWA>(accA, lw + (half * TPWA) * 64 + lane, bv);
+            buf ^= 1;
+        }
+    }
+    f32x4 wrB[S::PB];
+    tc_load<S::PB>(wrB, A.wB, 0, tid);  // stage B's first weights fly during the epilogue
+    {
+        const int fbase = 16 * half * TPWA + 4 * q;
+        f32x4 ad[TPWA];
+#pragma unroll
+        for (int c = 0; c < TPWA; ++c) {
+            const int f0 = fbase + 16 * c;
+            ad[c] = *reinterpret_cast<const f32x4 *>(A.addend + mm * A.ldadd + (f0 < A.NA ? f0 : 0));
+        }
+#pragma unroll
+        for (int c = 0; c < TPWA; ++c) accA[c] += (fbase + 16 * c < A.NA) ? ad[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        tc_layernorm<TPWA>(accA, fbase, A.NA, A.lnA_g, A.lnA_b, half, q, my_x, peer_x, false);
+#pragma unroll
+        for (int c = 0; c < TPWA; ++c) my_hid[(half * TPWA + c) * 64] = accA[c];
+    }
+
+    // ------------------------------------------------------------------ stage B: first layer of pairwise_lin
+    f32x4 accB[TPWB];
+#pragma unroll
+    for (int c = 0; c < TPWB; ++c) accB[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        // the appended k-group: the count features (4 floats per sample) in lane quarter 0, zeros elsewhere
+        f32x4 tailv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (q == 0) tailv = *reinterpret_cast<const f32x4 *>(A.tail + mm * A.ldtail);
+#pragma unroll
+        for (int kg = 0; kg < NTPA + 1; ++kg) {
+            f32x4 *lw = lds + buf * S::SLAB;
+            tc_store<S::PB>(wrB, lw, tid);
+            __syncthreads();  // (kg == 0: also publishes stage A's hidden tiles)
+            if (kg + 1 < NTPA + 1) tc_load<S::PB>(wrB, A.wB, kg + 1, tid);
+            const f32x4 bv = kg < NTPA ? my_hid[(kg < NTPA ? kg : 0) * 64] : tailv;
+            tc_mfma<TPWB>(accB, lw + (half * TPWB) * 64 + lane, bv);
+            buf ^= 1;
+        }
+    }
+    f32x4 wrC[S::PC];
+    tc_load<S::PC>(wrC, A.wC, 0, tid);
+    const float *rer = A.re + mm * A.ldre + 4 * q;
+    f32x4 xr = *reinterpret_cast<const f32x4 *>(rer);  // stage C's first input group
+    {
+        const int fbase = 16 * half * TPWB + 4 * q;
+#pragma unroll
+        for (int c = 0; c < TPWB; ++c) accB[c] += *reinterpret_cast<const f32x4 *>(A.bB + fbase + 16 * c);
+        tc_layernorm<TPWB>(accB, fbase, A.NB, A.lnB_g, A.lnB_b, half, q, my_x, peer_x, true);
+        // (the barriers inside the LayerNorm exchange come after every wave's last read of stage A's tiles)
+#pragma unroll
+        for (int c = 0; c < TPWB; ++c) my_hid[(half * TPWB + c) * 64] = accB[c];
+    }
+
+    // ------------------------------------------------------------------ stage C: folded score head
+    f32x4 accC[TPWC];
+#pragma unroll
+    for (int c = 0; c < TPWC; ++c) accC[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kg = 0; kg < NGE; ++kg) {  // r_e, read from global memory
+        const f32x4 bv = xr;
+        f32x4 *lw = lds + buf * S::SLAB;
+        tc_store<S::PC>(wrC, lw, tid);
+        __syncthreads();
+        tc_load<S::PC>(wrC, A.wC, kg + 1, tid);  // (stage NGE exists: the r_p groups follow)
+        if (kg + 1 < NGE) xr = *reinterpret_cast<const f32x4 *>(rer + 16 * (kg + 1));
+        tc_mfma<TPWC>(accC, lw + (half * TPWC) * 64 + lane, bv);
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int kg = 0; kg < NTPB; ++kg) {  // r_p, straight from LDS
+        f32x4 *lw = lds + buf * S::SLAB;
+        tc_store<S::PC>(wrC, lw, tid);
+        __syncthreads();  // (kg == 0: also publishes stage B's hidden tiles)
+        if (kg + 1 < NTPB) tc_load<S::PC>(wrC, A.wC, NGE + kg + 1, tid);
+        tc_mfma<TPWC>(accC, lw + (half * TPWC) * 64 + lane, my_hid[kg * 64]);
+        buf ^= 1;
+    }
+    {
+        const int fbase = 16 * half * TPWC + 4 * q;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < TPWC; ++c) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(A.bC + fbase + 16 * c);
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(A.wdot + fbase + 16 * c);  // zero-padded
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d = fmaf(fmaxf(accC[c][r] + b[r], 0.f), w[r], d);
+        }
+        d = tc_quad_sum(d);
+        __syncthreads();  // exchange slots free (the LayerNorm exchanges have been read by everyone)
+        if (q == 0) *my_x = d;
+        __syncthreads();
+        if (live && q == 0 && half == 0) {
+            d = d + *peer_x + A.bdot[0];
+            if (A.logit) A.logit[m] = d;
+            if (A.prob) A.prob[m] = 1.0f / (1.0f + expf(-d));
+        }
+    }
+}
+
+template <int NTA, int NTB, int NTC>
+int tc_launch(const TailArgs &a, hipStream_t s) {
+    constexpr size_t lds = TcShape<NTA, NTB, NTC>::BYTES;
+    auto kern = tail_chain_kernel<NTA, NTB, NTC>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return LPF_ERR_LAUNCH;
+    const int64_t blocks = (a.M + 16 * TC_GROUPS - 1) / (16 * TC_GROUPS);
+    if (blocks > 0x7fffffff) return LPF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TC_THREADS), lds, s, a);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+}  // namespace
+
+extern "C" int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const float *G, int64_t ldg,
+                                  const float *wA_packed, const float *lnA_g, const float *lnA_b, const float *counts,
+                                  int64_t ldc, const float *wB_packed, const float *bB, const float *lnB_g,
+                                  const float *lnB_b, const float *r_e, int64_t ldre, const float *wC_packed,
+                                  const float *bC, const float *w_dot, const float *b_dot, float *logit, float *prob,
+                                  void *stream) {
+    if (M == 0) return LPF_OK;
+    LPF_REQUIRE(M > 0 && G && wA_packed && lnA_g && lnA_b && counts && wB_packed && bB && lnB_g && lnB_b && r_e &&
+                wC_packed && bC && w_dot && b_dot && (logit || prob));
+    LPF_REQUIRE(n_counts >= 1 && n_counts <= 4 && (ldg & 3) == 0 && ldg >= 4 * D + 4 && (ldc & 3) == 0 && ldc >= 4 &&
+                (ldre & 3) == 0 && ldre >= D);
+    LPF_REQUIRE(lpf_aligned16(G) && lpf_aligned16(counts) && lpf_aligned16(r_e) && lpf_aligned16(wA_packed) &&
+                lpf_aligned16(wB_packed) && lpf_aligned16(wC_packed) && lpf_aligned16(lnA_g) && lpf_aligned16(lnA_b) &&
+                lpf_aligned16(bB) && lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) &&
+                lpf_aligned16(w_dot));
+    TailArgs a{M, G + D, ldg, 3 * D + 4, G, ldg, wA_packed, lnA_g, lnA_b, D, counts, ldc, wB_packed, bB, lnB_g,
+               lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (D) {
+        case 32: return tc_launch<2, 3, 4>(a, s);
+        case 64: return tc_launch<4, 5, 8>(a, s);
+        case 128: return tc_launch<8, 9, 16>(a, s);
+        default: return LPF_ERR_UNSUPPORTED;  // D = 256: 32-tile score head, the per-layer chains are used instead
+    }
+}

@@ -128,3 +128,24 @@ def dense_chain_tables(w1, b1, ln_g=None, ln_b=None, w2=None, b2=None) -> dict:
             out["w2p"] = pack_dense(w2, g, k_groups=p1 // 16)
             out["b2"] = _pad_to(np.asarray(b2, np.float32), ((nt2 + 1) & ~1) * 16)
     return out
+
+
+def tail_chain_tables(wcat, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b, a_fold, c_fold, w_dot, b_dot, dim: int) -> dict:
+    """fp32 arrays of one lpf_tail_chain_f32 call.  ``a_fold`` [2D, D + pd] = [A_e | A_p] (LinkTransformer._score_fold);
+    its r_p columns are moved behind the D r_e columns on an even-tile boundary, as the kernel walks them."""
+    wcat, w_p0, a_fold = (np.asarray(t, np.float32) for t in (wcat, w_p0, a_fold))
+    pd = w_p0.shape[0]
+    ntpb = ((pd + 15) // 16 + 1) & ~1
+    wc = np.zeros((a_fold.shape[0], dim + 16 * ntpb), np.float32)
+    wc[:, :dim] = a_fold[:, :dim]
+    wc[:, dim:dim + pd] = a_fold[:, dim:dim + pd]
+    return {
+        "wA": pack_dense(wcat, 1), "lnA_g": _pad_to(np.asarray(lnA_g, np.float32), dim),
+        "lnA_b": _pad_to(np.asarray(lnA_b, np.float32), dim),
+        "wB": pack_dense(w_p0, 1, k_groups=dim // 16 + 1), "bB": _pad_to(np.asarray(b_p0, np.float32), 16 * ntpb),
+        "lnB_g": _pad_to(np.asarray(lnB_g, np.float32), 16 * ntpb),
+        "lnB_b": _pad_to(np.asarray(lnB_b, np.float32), 16 * ntpb),
+        "wC": pack_dense(wc, 1), "bC": np.asarray(c_fold, np.float32).reshape(-1).copy(),
+        "w_dot": np.asarray(w_dot, np.float32).reshape(-1).copy(),
+        "b_dot": np.asarray(b_dot, np.float32).reshape(-1)[:1].copy(),
+    }

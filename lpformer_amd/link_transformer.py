@@ -449,6 +449,7 @@ class LinkTransformer(nn.Module):
         # underneath the (latency/issue-bound) selection kernels.  False: everything on the caller's stream.
         self.use_side_stream = True
         self._side = None
+        self.use_tail_chain = True    # score_pairs: lpf_tail_chain_f32 instead of three dense-chain launches
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self):
@@ -727,9 +728,11 @@ class LinkTransformer(nn.Module):
         side.wait_stream(main)
         return side
 
-    def _pair_attention(self, batch, x_node, test_set, adj_mask, return_weights):
+    def _pair_attention(self, batch, x_node, test_set, adj_mask, return_weights, stop_after_gather=False):
         """Selection -> PE + attention (+ post-norm) -> count features.  Returns (feats [BS, ld] = [attention output |
-        counts | pad], att_weights or None); the caller applies ``pairwise_lin`` (or its folded first layer)."""
+        counts | pad], att_weights or None); the caller applies ``pairwise_lin`` (or its folded first layer).
+        ``stop_after_gather``: return (G [BS, 4D+4], feats) right after the softmax-gather instead (the attention
+        output projection then belongs to ``lpf_tail_chain_f32``)."""
         with torch.no_grad():
             lib, st, d = _lib.hip(), _stream(self.device), self.dim
             bs = batch.shape[1]
@@ -763,6 +766,8 @@ class LinkTransformer(nn.Module):
                                                       ptr(self._workspace("sg_heavy", bs + 1, torch.int32, st)), st),
                       "lpf_pair_softmax_gather_f32")
             feats = s["feats"]
+            if stop_after_gather:
+                return g, feats
             att_view = feats[:, :d]
             layer = self.att_layers[0]
             # sum_e alpha_e k_e + bias, then post_att_norm: one launch (or GEMM + LayerNorm for unbuilt shapes)
@@ -814,6 +819,25 @@ class LinkTransformer(nn.Module):
         self._score_fold_cache = (key, out)
         return out
 
+    def _tail_tables(self, score_func, a, c):
+        """Device tables of ``lpf_tail_chain_f32`` (refreshed with the folds they are built from)."""
+        layer, pw = self.att_layers[0], self.pairwise_lin
+        ps = [layer.post_att_norm.weight, layer.post_att_norm.bias, pw.linears[0].weight, pw.linears[0].bias,
+              pw.norm.weight, pw.norm.bias, score_func.lins[1].weight, score_func.lins[1].bias]
+        self._fold()
+        key = (tuple((p.data_ptr(), p._version) for p in ps), a.data_ptr(), self._folded[0])
+        hit = getattr(self, "_tail_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w = self._fold()
+        npy = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+        tabs = fold.tail_chain_tables(npy(w["wcat"]), npy(ps[0]), npy(ps[1]), npy(ps[2]), npy(ps[3]), npy(ps[4]),
+                                      npy(ps[5]), npy(a)[:, :self.dim + self.dim + self.count_dim], npy(c), npy(ps[6]),
+                                      npy(ps[7]), self.dim)
+        dev = {k: torch.from_numpy(v).to(self.device) for k, v in tabs.items()}
+        self._tail_cache = (key, dev)
+        return dev
+
     def score_pairs(self, batch, X_node, score_func, test_set=False, adj_mask=None, logits=False):
         """``score_func(cat(elementwise_lin(x_a * x_b), calc_pairwise(...)[0]))`` -- the reference's scoring
         expression (src/train/testing.py:29-31,113-117) -- with the three Linear layers around the module boundary
@@ -848,6 +872,18 @@ class LinkTransformer(nn.Module):
                                                              _stream(self.device)), "lpf_pair_gather_f32")
                     gemm(prod, ew._pads[0].get(ew.linears[0].weight), ew.linears[0].bias, out=r[:, :d])
                     layernorm_(r[:, :d], ew.norm.weight, ew.norm.bias, relu=True)
+            if d in (32, 64, 128) and self.use_tail_chain:  # attention output + pairwise hidden + head: one launch
+                g, feats = self._pair_attention(batch, x_node, test_set, adj_mask, False, stop_after_gather=True)
+                tt = self._tail_tables(score_func, a, c)
+                res = torch.empty(bs, dtype=torch.float32, device=self.device)
+                with KernelTimer.span("tail_chain"):
+                    check(_lib.hip().lpf_tail_chain_f32(
+                        bs, d, self.count_dim, ptr(g), g.stride(0), ptr(tt["wA"]), ptr(tt["lnA_g"]), ptr(tt["lnA_b"]),
+                        feats.data_ptr() + 4 * d, feats.stride(0), ptr(tt["wB"]), ptr(tt["bB"]), ptr(tt["lnB_g"]),
+                        ptr(tt["lnB_b"]), ptr(r), r.stride(0), ptr(tt["wC"]), ptr(tt["bC"]), ptr(tt["w_dot"]),
+                        ptr(tt["b_dot"]), ptr(res) if logits else None, None if logits else ptr(res),
+                        _stream(self.device)), "lpf_tail_chain_f32")
+                return res
             feats, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False)  # joins the side stream
             xin = feats[:, :pd]
             t = pw._chain1.tables(pw.linears[0].weight, pw.linears[0].bias, pw.norm.weight, pw.norm.bias)

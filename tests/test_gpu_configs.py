@@ -152,14 +152,17 @@ def test_folded_score_path_matches_modules_and_oracle():
     """model.score_pairs (three Linears around the module boundary folded into one) against
     score_func(model.pair_features(...)) and against the CPU oracle, for D = 64 (counts 4) and the 1-hop mode
     (counts 3: padded K)."""
-    for name, bs in (("ppa", 3000), ("ddi", 1500)):
-        scale = 0.02 if name == "ppa" else 1.0
+    for name, bs in (("ppa", 3000), ("ddi", 1500), ("collab", 4000)):
+        scale = {"ppa": 0.02, "ddi": 1.0, "collab": 0.05}[name]
         cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale=scale, bs=bs)
         h = model.propagate()
         b = torch.from_numpy(batch).to(DEV)
         ref_p = score(model.pair_features(b, h))
         ref_l = score.logits(model.pair_features(b, h))
         assert (model.score_pairs(b, h, score) - ref_p).abs().max().item() <= 2e-6
+        model.use_tail_chain = False  # per-layer chains instead of lpf_tail_chain_f32 (the only path for D = 256)
+        assert (model.score_pairs(b, h, score) - ref_p).abs().max().item() <= 2e-6
+        model.use_tail_chain = True
         got_l = model.score_pairs(b, h, score, logits=True)
         assert (got_l - ref_l).abs().max().item() <= 2e-5 * max(1.0, ref_l.abs().max().item())
         sample, ref = _oracle_sample(model, score, data, args, batch, h, k=160)
