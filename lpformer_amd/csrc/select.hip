@@ -551,15 +551,16 @@ __global__ __launch_bounds__(64 * WPB) void select_compact_kernel(
     int32_t *__restrict__ stage_node, float *__restrict__ stage_pa, float *__restrict__ stage_pb,
     const int32_t *__restrict__ stage_cnt, const int64_t *__restrict__ type_ptr, int32_t *__restrict__ sel_pair,
     int32_t *__restrict__ sel_node, float *__restrict__ sel_pa, float *__restrict__ sel_pb) {
-    // four independent wavefronts per workgroup; the waves never synchronise with each other
     __shared__ CmpLds cmp_lds[WPB];
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * WPB;
     const int64_t tot_cn = type_ptr[bs], tot_1 = type_ptr[(bs + 1) + bs];
     for (int64_t p = wave_id; p < bs; p += n_waves) {
+        const int4 kept = *reinterpret_cast<const int4 *>(stage_cnt + 4 * p);
+        if ((kept.x | kept.y | kept.z | kept.w) == 0) continue;  // nothing selected for this pair (almost half of them)
         const int64_t dA = desc[p * DESC_I64 + 6], dB = desc[p * DESC_I64 + 7];
         const int64_t s = stage_off[p];
-        const int n_l1 = stage_cnt[4 * p + 1], n_l2 = stage_cnt[4 * p + 2], n_t0 = stage_cnt[4 * p + 3];
+        const int n_l1 = kept.y, n_l2 = kept.z, n_t0 = kept.w;
         const int64_t d_cn = type_ptr[p], d_1 = tot_cn + type_ptr[(bs + 1) + p],
                       d_0 = tot_cn + tot_1 + type_ptr[2 * (bs + 1) + p];
         const int64_t l1 = s, l2 = s + dA, t0 = s + dA + dB;
