@@ -12,7 +12,9 @@ the fused kernels, random attention drop) is a later row of the plan and raises 
 """
 from __future__ import annotations
 
+import functools
 import math
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -29,6 +31,19 @@ def _stream(device):
     """Raw hipStream_t of torch's current stream on ``device`` (the stream every C-ABI launch goes to)."""
     idx = device.index if isinstance(device, torch.device) and device.index is not None else torch.cuda.current_device()
     return torch._C._cuda_getCurrentRawStream(idx)
+
+
+def _on_device(fn):
+    """Run a public entry point with the model's device current: the C-ABI launches go to that device's stream, so a
+    model on cuda:1 must not launch while cuda:0 is current."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        idx = self.device.index if self.device.type == "cuda" else None
+        if idx is None or not torch.cuda.is_available() or idx == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(idx):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 def _glorot(t: torch.Tensor):
@@ -434,7 +449,8 @@ class LinkTransformer(nn.Module):
         self.pairwise_lin = MLP(2, pairwise_dim, pairwise_dim, self.dim)
 
         # runtime state (not parameters)
-        self._graphs = {}      # (kind, id(obj)) -> DeviceCSR
+        self._graphs = {}      # (kind, id(obj)) -> (obj, DeviceCSR) for the graphs held in self.data
+        self._override = {}    # kind -> (obj, DeviceCSR): the LAST caller-supplied override only
         self._folded = None    # (param version key, dict of device tensors)
         self._z_cache = None   # (key, Z)
         self._x_cache = None   # (key, padded features)
@@ -474,10 +490,21 @@ class LinkTransformer(nn.Module):
         suffix = "mask" if kind == "mask" else "t"
         return self.data[f"full_adj_{suffix}"] if test_set else self.data[f"adj_{suffix}"]
 
+    def _in_data(self, obj) -> bool:
+        return any(obj is v for v in self.data.values())
+
     def _device_graph(self, kind: str, obj) -> graph.DeviceCSR:
-        """kind in {'prop' (GCN-normalised), 'mask', 'ppr', 't0' (prefiltered >1-hop candidates)}."""
-        key = (kind, id(obj))
-        hit = self._graphs.get(key)
+        """kind in {'prop' (GCN-normalised), 'mask', 'ppr', 't0' / 'p1' (prefiltered PPR indexes)}.
+        Graphs held in ``self.data`` are converted once and stay resident.  A caller-supplied override (the training
+        loop passes a fresh ``adj_mask`` / ``adj_prop`` per batch, src/train/train_model.py:40-59) only occupies ONE
+        slot per kind: the previous override's device copy is released when the next one arrives."""
+        persistent = self._in_data(obj)
+        if persistent:
+            key = (kind, id(obj))
+            hit = self._graphs.get(key)
+        else:
+            key = None
+            hit = self._override.get(kind)
         if hit is not None and hit[0] is obj:
             return hit[1]
         dev = self.device
@@ -500,24 +527,29 @@ class LinkTransformer(nn.Module):
                 if val is None:
                     raise ValueError("the PPR matrix needs values")
                 g = graph.csr_from_coo(row, col, val, n).to_device(dev)
-        self._graphs[key] = (obj, g)
+        if g.n != self.num_nodes:
+            raise ValueError(f"graph has {g.n} nodes, the model {self.num_nodes}")
+        if persistent:
+            self._graphs[key] = (obj, g)
+        else:
+            self._override[kind] = (obj, g)
         return g
 
     def _self_ppr(self, mask_obj, ppr_obj, adj: graph.DeviceCSR, ppr: graph.DeviceCSR) -> torch.Tensor:
         key = ("selfp", id(mask_obj), id(ppr_obj))
         hit = self._graphs.get(key)
-        if hit is None or hit[0] is not mask_obj:
+        if hit is None or hit[0] is not mask_obj or hit[1] is not ppr_obj:
             t = graph.self_ppr_device(adj, ppr)
-            self._graphs[key] = (mask_obj, t)
+            self._graphs[key] = (mask_obj, ppr_obj, t)
             return t
-        return hit[1]
+        return hit[2]
 
     def _features(self) -> torch.Tensor:
         x = self.data["x"]
-        key = (x.data_ptr(), x._version, x.device)
-        if self._x_cache is None or self._x_cache[0] != key:
-            self._x_cache = (key, _as_f32_rows(x.detach().to(self.device)))
-        return self._x_cache[1]
+        hit = self._x_cache
+        if hit is None or hit[0] is not x or hit[1] != x._version:  # identity, not address (see _node_keys)
+            hit = self._x_cache = (x, x._version, _as_f32_rows(x.detach().to(self.device)))
+        return hit[2]
 
     def _workspace(self, name: str, numel: int, dtype, st=None) -> torch.Tensor:
         """Named scratch buffer of the CURRENT stream (callers may pipeline batches on several streams; each stream
@@ -548,8 +580,10 @@ class LinkTransformer(nn.Module):
         return dev
 
     # ---------------------------------------------------------------------------------- encoder
-    def propagate(self, adj=None, test_set=False):
-        """GCN encoder + ``gnn_norm`` -> [N, D] (reference :110-129).  L x (MFMA GEMM, fused CSR SpMM)."""
+    @_on_device
+    def propagate(self, adj=None, test_set=False, _layers_out=None):
+        """GCN encoder + ``gnn_norm`` -> [N, D] (reference :110-129).  L x (MFMA GEMM, fused CSR SpMM).
+        ``_layers_out`` (tests): a list that receives every layer's input and the final output."""
         self._check_supported()
         with torch.no_grad():
             a_hat = self._device_graph("prop", self._data_obj("adj", test_set) if adj is None else adj)
@@ -561,6 +595,8 @@ class LinkTransformer(nn.Module):
             lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
             long_rows = self._long_rows(a_hat, lo, hi)
             for i, conv in enumerate(enc.convs):
+                if _layers_out is not None:
+                    _layers_out.append(x)
                 # dense transform of ALL rows (cheap, replicated), aggregation of the local row block only
                 t = gemm(x, self._conv_pads[i].get(conv.lin.weight), tag="gemm_encoder")
                 d = t.shape[1]
@@ -580,18 +616,19 @@ class LinkTransformer(nn.Module):
                 # every rank needs the full layer output for the next neighbour gather; the last of these
                 # collectives is the all-gather of node embeddings (RCCL over xGMI)
                 x = lpf_dist.allgather_rows(out, self.num_nodes) if world > 1 else out
+            if _layers_out is not None:
+                _layers_out.append(x)
             return x
 
     def _long_rows(self, a_hat: graph.DeviceCSR, lo: int, hi: int):
-        """Hub rows (> LPF_SPMM_LONG_ROW entries) of the local row block, as row ids relative to `lo` (cached)."""
-        key = ("long_rows", id(a_hat), lo, hi)
-        hit = self._graphs.get(key)
-        if hit is None:
+        """Hub rows (> LPF_SPMM_LONG_ROW entries) of the local row block, as row ids relative to `lo`; cached on the
+        device graph itself, so the list lives exactly as long as the graph it describes."""
+        cache = a_hat.__dict__.setdefault("_long_rows", {})
+        if (lo, hi) not in cache:
             deg = (a_hat.rowptr[lo + 1:hi + 1] - a_hat.rowptr[lo:hi])
             rows = torch.nonzero(deg > 128).flatten().to(torch.int32)
-            hit = (a_hat, rows if rows.numel() else None)
-            self._graphs[key] = hit
-        return hit[1]
+            cache[(lo, hi)] = rows if rows.numel() else None
+        return cache[(lo, hi)]
 
     def set_row_shard(self, rank: int, world: int):
         """Row-shard the encoder across `world` ranks of the default process group (see lpformer_amd/dist.py)."""
@@ -605,14 +642,17 @@ class LinkTransformer(nn.Module):
           Z = X_node W_rx^T + b_r   the node half of lin_r (k_e = Z[v] + ...),
           Y = X_node W_l^T + b_l    lin_l per node, so that q_pair = lin_l(x_a) + lin_l(x_b) = Y[a] + Y[b] -- literally
                                     the reference's expression (layers.py:212-215) -- is a gather-add, not a GEMM."""
-        key = (x_node.data_ptr(), x_node._version, tuple(x_node.shape))
-        if self._z_cache is None or self._z_cache[0] != key:
+        # Keyed on the IDENTITY of the encoder output (weak reference) + its version: the encoder writes its output
+        # through raw pointers (no version bump) and the caching allocator hands the same address to the next
+        # propagate(), so neither data_ptr nor _version alone can tell two encoder outputs apart; a tensor object can.
+        hit = self._z_cache
+        if hit is None or hit[0]() is not x_node or hit[1] != x_node._version:
             xr = _as_f32_rows(x_node)
             z = gemm(xr, w["w_rx"], w["b_r"], tag="gemm_node_keys")
             y = gemm(xr, w["w_l"], w["b_l"], tag="gemm_node_keys")
             torch.cuda.current_stream(self.device).synchronize()  # once per encoder output: other streams read Z, Y
-            self._z_cache = (key, z, y)
-        return self._z_cache[1], self._z_cache[2]
+            hit = self._z_cache = (weakref.ref(x_node), x_node._version, z, y)
+        return hit[2], hit[3]
 
     # ---------------------------------------------------------------------------------- selection
     def _select(self, batch: torch.Tensor, test_set: bool, adj_mask=None):
@@ -684,6 +724,7 @@ class LinkTransformer(nn.Module):
             batch = batch.contiguous()
         return batch
 
+    @_on_device
     def compute_node_mask(self, batch, test_set=False, adj=None):
         """Reference-format selection result (:214-276): three tuples (ix int64 [2,n], ppr_src, ppr_tgt) for CN,
         1-hop and >1-hop nodes (None for >1-hop in "1-hop" mode), each sorted by (pair position, node)."""
@@ -783,6 +824,7 @@ class LinkTransformer(nn.Module):
                 att_weights = torch.stack((s["sel_pair"][:total].float(), alpha[:total]))
             return feats, att_weights
 
+    @_on_device
     def calc_pairwise(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False, _out=None):
         """Pairwise branch (:132-178): selection -> PE + attention -> counts -> ``pairwise_lin``.
         Returns ([BS, D], att_weights or None)."""
@@ -838,6 +880,7 @@ class LinkTransformer(nn.Module):
         self._tail_cache = (key, dev)
         return dev
 
+    @_on_device
     def score_pairs(self, batch, X_node, score_func, test_set=False, adj_mask=None, logits=False):
         """``score_func(cat(elementwise_lin(x_a * x_b), calc_pairwise(...)[0]))`` -- the reference's scoring
         expression (src/train/testing.py:29-31,113-117) -- with the three Linear layers around the module boundary
@@ -898,6 +941,7 @@ class LinkTransformer(nn.Module):
                 res = score_func._tail(hid, not logits)
             return res
 
+    @_on_device
     def forward(self, batch, adj_prop=None, adj_mask=None, test_set=False, return_weights=False):
         """Link representations [BS, 2D] = [elementwise branch | pairwise branch] (reference :82-107).  Like the
         reference, every call re-runs the encoder; evaluation loops that propagate once should call ``propagate``
@@ -910,6 +954,7 @@ class LinkTransformer(nn.Module):
                                      return_weights=return_weights)
             return out
 
+    @_on_device
     def pair_features(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False):
         """[elementwise_lin(X[a]*X[b]) | calc_pairwise(...)] written straight into one [BS, 2D] buffer."""
         self._check_supported()

@@ -46,9 +46,12 @@ class LPFormer(nn.Module):
 
     def _bind(self, x: torch.Tensor, edge_index: torch.Tensor, ppr_matrix):
         """(Re)bind graph inputs when they change (identity + version of the tensors)."""
-        key = (x.data_ptr(), x._version, edge_index.data_ptr(), edge_index._version, id(ppr_matrix))
-        if self._bound == key:
+        # identity of the three inputs (strong references: an address can be recycled) + tensor versions
+        b = self._bound
+        if b is not None and b[0] is x and b[1] is edge_index and b[2] is ppr_matrix and \
+                b[3] == (x._version, edge_index._version):
             return
+        key = (x, edge_index, ppr_matrix, (x._version, edge_index._version))
         n = x.shape[0]
         ei = edge_index.detach().cpu().numpy()
         data = self.core.data
@@ -59,7 +62,9 @@ class LPFormer(nn.Module):
         data["ppr"] = data["ppr_test"] = ppr_matrix
         self.core.num_nodes = n
         self.core._graphs.clear()
+        self.core._override.clear()
         self.core._x_cache = None
+        self.core._z_cache = None
         self._bound = key
 
     def forward(self, batch: torch.Tensor, x: torch.Tensor, edge_index: torch.Tensor, ppr_matrix) -> torch.Tensor:

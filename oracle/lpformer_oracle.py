@@ -320,14 +320,14 @@ def mlp_score(h, P, n_layers=2):
     return (F32(1) / (F32(1) + np.exp(-logit))).astype(F32), logit.astype(F32)
 
 
-def forward(batch, x, adj_norm, adj_mask, ppr, P, cfg, *, x_node=None, want_parts=False):
+def forward(batch, x, adj_norm, adj_mask, ppr, P, cfg, *, x_node=None, want_parts=False, adj_unmasked=None):
     """``LinkTransformer.forward`` (src/models/link_transformer.py:82-107) + the caller's ``score_func``
     (src/train/testing.py:87-88).  Returns a dict of every stage's output."""
     batch = np.asarray(batch, dtype=np.int64)
     if x_node is None:
         x_node = propagate(x, adj_norm, P, cfg)
     th = (cfg["thresh_cn"], cfg["thresh_1hop"], cfg["thresh_non1hop"])
-    sel = select_nodes(batch, adj_mask, ppr, th, n=x_node.shape[0])
+    sel = select_nodes(batch, adj_mask, ppr, th, n=x_node.shape[0], adj_unmasked=adj_unmasked)
     ew = mlp2((x_node[batch[0]] * x_node[batch[1]]).astype(F32), P, "model.elementwise_lin")   # :101-102
     pw, parts = calc_pairwise(batch, x_node, sel, P, want_parts=True)
     comb = np.concatenate([ew, pw], axis=1).astype(F32)                                          # :105

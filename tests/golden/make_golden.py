@@ -103,7 +103,7 @@ def make_pairs(rng, n, edge_index, bs, isolated):
 # ----------------------------------------------------------------------------- one fixture
 def build_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, residual=False,
                layer_norm=True, relu=True, weighted=False, n_isolated=0, power=0.0, jitter=False,
-               val_in_test=False):
+               val_in_test=False, masked=False):
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     from torch_sparse import SparseTensor  # shim
@@ -190,6 +190,43 @@ def build_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, 
         out[f"sel_{tag}_ix"] = info[0].numpy().astype(np.int64)
         out[f"sel_{tag}_pa"] = info[1].numpy().astype(np.float32)
         out[f"sel_{tag}_pb"] = info[2].numpy().astype(np.float32)
+    if masked:
+        # The training loop's call pattern (src/train/train_model.py:35-59), run in eval mode so that dropout and
+        # drop_pairwise are off: the batch's positive edges are removed from the adjacency that types CN / 1-hop
+        # nodes (adj_mask override) and -- with --mask-input -- from the propagation adjacency (adj_prop override);
+        # the >1-hop pass keeps using the UNMASKED adjacency (link_transformer.py:438-443).
+        und = edge_index[:, edge_index[0] < edge_index[1]].T.copy()          # train_pos: one orientation per edge
+        perm = rng.permutation(und.shape[0])[: (2 * bs) // 3]
+        keepmask = np.ones(und.shape[0], bool)
+        keepmask[perm] = False
+        edge2keep = torch.from_numpy(und[keepmask])
+        masked_adj = SparseTensor.from_edge_index(edge2keep.t(), sparse_sizes=(n, n)).to_device("cpu")
+        masked_adj = masked_adj.to_symmetric()
+        masked_adjt = masked_adj                                               # train_model.py:49-51
+        masked_adj = masked_adj.to_torch_sparse_coo_tensor().coalesce().bool().int()
+        pos = und[perm].T
+        extra = make_pairs(rng, n, edge_index, bs - pos.shape[1], isolated)
+        flip = pos[::-1, :8]                                                  # (b, a) orientation of some positives
+        mb = np.concatenate([pos, extra, flip], axis=1).astype(np.int64)
+        mb = mb[:, rng.permutation(mb.shape[1])]
+        tmb = torch.from_numpy(mb)
+        with torch.no_grad():
+            m_infos = model.compute_node_mask(tmb, False, masked_adj)
+            m_feats = model(tmb, adj_prop=None, adj_mask=masked_adj)
+            m_xnode = model.propagate(masked_adjt)
+            m_feats_prop = model(tmb, adj_prop=masked_adjt, adj_mask=masked_adj)
+            m_logit = score.lins[1](torch.relu(score.lins[0](m_feats))).squeeze(-1)
+            m_logit_prop = score.lins[1](torch.relu(score.lins[0](m_feats_prop))).squeeze(-1)
+        out.update(masked_batch=mb, masked_keep_edges=und[keepmask].T.astype(np.int32),
+                   masked_combined_feats=m_feats.numpy(), masked_logit=m_logit.numpy(),
+                   masked_prop_x_node=m_xnode.numpy(), masked_prop_combined_feats=m_feats_prop.numpy(),
+                   masked_prop_logit=m_logit_prop.numpy())
+        for tag, info in zip(("cn", "onehop", "non1hop"), m_infos):
+            if info is None:
+                continue
+            out[f"masked_sel_{tag}_ix"] = info[0].numpy().astype(np.int64)
+            out[f"masked_sel_{tag}_pa"] = info[1].numpy().astype(np.float32)
+            out[f"masked_sel_{tag}_pb"] = info[2].numpy().astype(np.float32)
     cfg = dict(train_args)
     cfg.update(n=n, f_in=f_in, eps=eps, test_set=test_set, pred_layers=2, seed=seed, param_shapes=shapes)
     out["config_json"] = np.array(__import__("json").dumps(cfg))
@@ -214,7 +251,13 @@ def build_ppr_case(name, seed, n, m, eps_list, n_isolated=0, power=0.0):
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
 
 
-if __name__ == "__main__":
+def main(only=()):
+    """Build every fixture, or only the named ones (python make_golden.py lp_all_d64_maskedadj ...)."""
+    global build_case, build_ppr_case
+    _bc, _bp = build_case, build_ppr_case
+    if only:
+        build_case = lambda name, *a, **k: _bc(name, *a, **k) if name in only else None      # noqa: E731
+        build_ppr_case = lambda name, *a, **k: _bp(name, *a, **k) if name in only else None  # noqa: E731
     # mode "all", LN+ReLU, no residual, isolated nodes, PPR values jittered onto the thresholds
     build_case("lp_all_d64", 1, n=320, m=900, f_in=24, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
                eps=1e-3, bs=192, n_isolated=6, jitter=True)
@@ -230,5 +273,12 @@ if __name__ == "__main__":
     # Cora-HeaRT-like: L=1, no LayerNorm, no ReLU, D=256 (replicate_heart.sh:4), eps 1e-4
     build_case("lp_all_d256_noln", 5, n=260, m=520, f_in=96, dim=256, gnn_layers=1, thresholds=(0, 1e-2, 1e-2),
                eps=1e-4, bs=96, layer_norm=False, relu=False, n_isolated=4, jitter=True)
+    # the training loop's masked-adjacency overrides (train_model.py:40-59), weighted graph, jittered PPR values
+    build_case("lp_all_d64_maskedadj", 6, n=340, m=1000, f_in=32, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
+               eps=1e-3, bs=180, weighted=True, power=0.4, n_isolated=4, jitter=True, masked=True)
     build_ppr_case("ppr_push_small", 7, n=220, m=600, eps_list=[1e-3, 1e-4], n_isolated=5)
     build_ppr_case("ppr_push_powerlaw", 8, n=300, m=1500, eps_list=[1e-3], power=0.9)
+
+
+if __name__ == "__main__":
+    main(tuple(sys.argv[1:]))

@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _setup(name, scale=1.0, seed=0, bs=None):
+def _setup(name, scale=1.0, seed=0, bs=None, ppr_device=None):
     cfg = dict(D.CONFIGS[name])
     n = int(cfg["n"] * scale)
     edges = int(cfg["edges"] * scale)
     ei, w = D.chung_lu_graph(n, edges, gamma=cfg["gamma"], seed=seed, max_weight=cfg["max_weight"])
     x = np.random.default_rng(seed + 1).standard_normal((n, cfg["f_in"])).astype(np.float32)
-    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"])
+    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr_device=ppr_device)
     args = D.train_args_for(cfg)
     torch.manual_seed(seed)
     model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
@@ -37,10 +37,48 @@ def _oracle_sample(model, score, data, args, batch, x_node, k=192):
                              x_node=x_node.cpu().numpy())
 
 
-def _check(name, scale, bs=None, k=192):
-    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale, bs=bs)
+def _check_encoder_rows(model, data, args, x, n_rows=96, seed=7):
+    """Every encoder layer at full size against the oracle on a sample of rows (hub rows included): the layer's
+    INPUT is taken from the device, the oracle computes A_hat[rows, :] (X W^T) + b -> LN -> ReLU -> residual for the
+    sampled rows only (the dense transform restricted to the rows' neighbours), and the final ``gnn_norm``."""
+    layers = []
+    h = model.propagate(_layers_out=layers)
+    adj = data["adj_t"]
+    n = adj.n
+    row = np.repeat(np.arange(n, dtype=np.int64), np.diff(adj.rowptr))
+    a_rp, a_col, a_val = O.gcn_norm(np.stack([row, adj.col.astype(np.int64)]), adj.val, n)
+    deg = np.diff(a_rp)
+    rng = np.random.default_rng(seed)
+    rows = np.unique(np.concatenate([rng.integers(0, n, n_rows), np.argsort(deg)[-8:], np.argsort(deg)[:4]]))
+    P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    pre = "model.node_encoder.gnn_encoder"
+    worst = 0.0
+    for i in range(args["gnn_layers"]):
+        xin = layers[i].cpu().numpy()
+        want = np.zeros((rows.size, args["dim"]), np.float32)
+        wt = P[f"{pre}.convs.{i}.lin.weight"]
+        for j, r in enumerate(rows):
+            nb, wv = a_col[a_rp[r]:a_rp[r + 1]], a_val[a_rp[r]:a_rp[r + 1]]
+            want[j] = (O.linear(xin[nb], wt) * wv[:, None]).sum(axis=0, dtype=np.float32)
+        want = want + P[f"{pre}.convs.{i}.bias"]
+        if args["layer_norm"]:
+            want = O.layer_norm(want, P[f"{pre}.lns.{i}.weight"], P[f"{pre}.lns.{i}.bias"])
+        if args["relu"]:
+            want = np.maximum(want, 0)
+        if args["residual"] and xin.shape[1] == want.shape[1]:
+            want = xin[rows] + want
+        if i == args["gnn_layers"] - 1:
+            want = O.layer_norm(want, P["model.gnn_norm.weight"], P["model.gnn_norm.bias"])
+        got = layers[i + 1][torch.from_numpy(rows).to(DEV)].cpu().numpy()
+        worst = max(worst, float(np.abs(got - want).max()))
+    assert worst <= 1e-4, f"encoder rows differ from the oracle by {worst}"
+    return h
+
+
+def _check(name, scale, bs=None, k=192, ppr_device=None):
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale, bs=bs, ppr_device=ppr_device)
     tb = torch.from_numpy(batch).to(DEV)
-    h = model.propagate()
+    h = _check_encoder_rows(model, data, args, x)
     assert torch.isfinite(h).all()
     logits = score.logits(model.pair_features(tb, h))
     assert torch.isfinite(logits).all()
@@ -87,6 +125,19 @@ def test_citation2_like_quarter_size():
 def test_ppa_like_eighth_size():
     """N=72k, mean degree ~74 (1/8 of ogbl-ppa's nodes and edges), F=58 (not a multiple of 4), D=64, residual."""
     _check("ppa", 0.125)
+
+
+def test_citation2_like_full_size():
+    """BASELINE config 4 at its stated size: N=2,927,963, 30.4 M undirected edges, D=64, L=3 residual, full-graph
+    encoder resident in HBM; PPR (eps 2.5e-3) from the device producer.  Oracle on a pair sample + an encoder row
+    sample, properties at the full 32,768-pair batch."""
+    _check("citation2", 1.0, ppr_device=DEV)
+
+
+def test_ppa_like_full_size():
+    """BASELINE config 3's per-GPU share at its stated size: N=576,289, 21.2 M undirected edges (mean degree ~74,
+    hub pairs cut into slices), F=58, D=64, residual, 32,768 pairs per GPU."""
+    _check("ppa", 1.0, ppr_device=DEV)
 
 
 def test_pyg_style_facade_matches_core():

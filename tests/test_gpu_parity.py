@@ -148,3 +148,94 @@ def test_empty_and_tiny_batches():
     iso = torch.tensor([[fx.n - 1], [fx.n - 2]])  # two isolated nodes: no selected entries -> attention = bias
     fi = model(iso, test_set=fx.test_set)
     assert torch.isfinite(fi).all()
+
+
+def _oracle_params(fx):
+    return fx.params
+
+
+def test_alternating_test_set_on_one_model():
+    """The reference's ``test()`` (src/train/testing.py:141-156) calls the SAME model with test_set=False and
+    test_set=True in turn; with --use-val-in-test the two graphs differ (full_adj_t, ppr_test).  Each call must see
+    its own encoder output and node-level projections -- never the previous call's (cached) ones."""
+    fx = Fixture("lp_all_d64_residual_valtest")
+    model, score = _build(fx)
+    n = fx.n
+    batch = fx["batch"]
+    tb = torch.from_numpy(batch).cuda()
+    # expected outputs for the TRAIN graph (test_set=False) from the oracle; for the FULL graph from the fixture
+    ei = fx["edge_index"].astype(np.int64)
+    ppr_tr = O.csr_from_coo(fx["ppr_row"].astype(np.int64), fx["ppr_col"].astype(np.int64), fx["ppr_val"], n)
+    ref_tr = O.forward(batch, fx["x"], O.gcn_norm(ei, fx["edge_weight"], n), O.symmetric_mask_csr(ei, n), ppr_tr,
+                       fx.params, fx.cfg)
+    assert np.abs(ref_tr["logit"] - fx["logit"]).max() > 1e-3  # the two graphs do give different scores
+    for rep in range(3):
+        for test_set, want_feats, want_logit in ((False, ref_tr["combined_feats"], ref_tr["logit"]),
+                                                 (True, fx["combined_feats"], fx["logit"])):
+            feats = model(tb, test_set=test_set)                     # test_edge pattern: encoder inside forward
+            assert _err(feats.cpu(), want_feats) <= TOL, (rep, test_set)
+            assert _err(score.logits(feats).cpu(), want_logit) <= TOL
+            h = model.propagate(test_set=test_set)                   # HeaRT pattern: h computed inside a function
+            got = model.score_pairs(tb, h, score, test_set=test_set, logits=True)
+            del h
+            assert _err(got.cpu(), want_logit) <= TOL, (rep, test_set)
+    # changed node features are seen too (same tensor object, bumped version; then a new tensor at a recycled address)
+    with torch.no_grad():
+        model.data["x"].mul_(0.5)
+    f_half = model(tb, test_set=True)
+    assert _err(f_half.cpu(), fx["combined_feats"]) > 1e-3
+    model.data["x"] = torch.from_numpy(fx["x"]).cuda()
+    assert _err(model(tb, test_set=True).cpu(), fx["combined_feats"]) <= TOL
+
+
+def test_masked_adjacency_override_vs_reference():
+    """The training loop's overrides (src/train/train_model.py:40-59), pinned by reference output: CN / 1-hop typing
+    from the adjacency WITHOUT the batch's positive edges, >1-hop exclusion from the unmasked adjacency
+    (link_transformer.py:438-443), optional propagation over the masked adjacency.  Takes the general selection
+    kernel (same_adj = 0).  The overrides are passed as the reference passes them: a torch sparse COO int tensor
+    and a torch_sparse.SparseTensor (here: the stand-in class with the same ``coo()`` / ``sparse_sizes()`` surface)."""
+    from oracle.ref_shims import SparseTensor
+    fx = Fixture("lp_all_d64_maskedadj")
+    model, score = _build(fx)
+    n = fx.n
+    keep = torch.from_numpy(fx["masked_keep_edges"].astype(np.int64))
+    masked_adjt = SparseTensor.from_edge_index(keep, sparse_sizes=(n, n)).to_symmetric()
+    masked_adj = masked_adjt.to_torch_sparse_coo_tensor().coalesce().bool().int().cuda()
+    mb = torch.from_numpy(fx["masked_batch"])
+    infos = model.compute_node_mask(mb, False, masked_adj)
+    for tag, info in zip(("cn", "onehop", "non1hop"), infos):
+        ix, pa, pb = (t.cpu().numpy() for t in info)
+        np.testing.assert_array_equal(ix, fx[f"masked_sel_{tag}_ix"])
+        np.testing.assert_array_equal(pa.view(np.uint32), fx[f"masked_sel_{tag}_pa"].view(np.uint32))
+        np.testing.assert_array_equal(pb.view(np.uint32), fx[f"masked_sel_{tag}_pb"].view(np.uint32))
+    feats = model(mb, adj_mask=masked_adj)
+    assert _err(feats.cpu(), fx["masked_combined_feats"]) <= TOL
+    assert _err(score.logits(feats).cpu(), fx["masked_logit"]) <= TOL
+    h = model.propagate(masked_adjt)
+    assert _err(h.cpu(), fx["masked_prop_x_node"]) <= TOL
+    feats = model(mb, adj_prop=masked_adjt, adj_mask=masked_adj)
+    assert _err(feats.cpu(), fx["masked_prop_combined_feats"]) <= TOL
+    assert _err(score.logits(feats).cpu(), fx["masked_prop_logit"]) <= TOL
+    # without the override the same batch gives the unmasked result again (no stale override state)
+    plain = model.compute_node_mask(mb, False, None)
+    assert plain[1][0].shape[1] != fx["masked_sel_onehop_ix"].shape[1]
+    # a fresh override per batch (what the training loop does) must not accumulate device copies
+    before = len(model._graphs)
+    for i in range(4):
+        k2 = keep[:, torch.randperm(keep.shape[1])[: keep.shape[1] - 10 * (i + 1)]]
+        adj_i = SparseTensor.from_edge_index(k2, sparse_sizes=(n, n)).to_symmetric()
+        model(mb, adj_prop=adj_i, adj_mask=adj_i.to_torch_sparse_coo_tensor().coalesce().bool().int())
+    assert len(model._graphs) == before and len(model._override) <= 2
+
+
+def test_invalid_inputs_are_rejected_or_harmless():
+    fx = Fixture("lp_all_d64")
+    model, score = _build(fx)
+    empty = torch.zeros(2, 0, dtype=torch.int64)
+    assert model(empty, test_set=fx.test_set).shape == (0, 128)
+    sel = model.compute_node_mask(empty, test_set=fx.test_set)
+    assert all(t[0].shape == (2, 0) for t in sel if t is not None)
+    with pytest.raises(Exception):
+        model(torch.tensor([[0, fx.n], [1, 2]]), test_set=fx.test_set)       # node id out of range
+    with pytest.raises(Exception):
+        model(torch.tensor([[0, -1], [1, 2]]), test_set=fx.test_set)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import lpformer_oracle as O
-from tests.golden_util import LP_CASES, PPR_CASES, Fixture, GOLDEN_DIR
+from tests.golden_util import LP_CASES, MASKED_CASES, PPR_CASES, Fixture, GOLDEN_DIR
 
 FLOAT_TOL = 2e-5  # abs, fp32 re-association only; observed ~1e-6
 
@@ -45,6 +45,38 @@ def test_forward_matches_reference(case):
     aw = fx["att_weights"]
     np.testing.assert_array_equal(aw[0].astype(np.int64), res["ix"][0])
     assert np.abs(aw[1] - res["alpha"]).max() <= FLOAT_TOL
+
+
+@pytest.mark.parametrize("case", MASKED_CASES)
+def test_masked_adjacency_override_matches_reference(case):
+    """The training loop's call pattern (src/train/train_model.py:40-59): CN / 1-hop typing from the adjacency with
+    the batch's positive edges removed, >1-hop exclusion from the UNMASKED adjacency (link_transformer.py:438-443);
+    optional propagation over the masked (unweighted) adjacency."""
+    fx = Fixture(case)
+    n = fx.n
+    adj_norm, mask, ppr = _graph(fx)
+    keep = fx["masked_keep_edges"].astype(np.int64)
+    masked = O.symmetric_mask_csr(keep, n)
+    th = (fx.cfg["thresh_cn"], fx.cfg["thresh_1hop"], fx.cfg["thresh_non1hop"])
+    mb = fx["masked_batch"]
+    sel = O.select_nodes(mb, masked, ppr, th, n=n, adj_unmasked=mask)
+    for tag in ("cn", "onehop", "non1hop"):
+        ix, pa, pb = sel[tag]
+        np.testing.assert_array_equal(ix, fx[f"masked_sel_{tag}_ix"])
+        np.testing.assert_array_equal(pa.view(np.uint32), fx[f"masked_sel_{tag}_pa"].view(np.uint32))
+        np.testing.assert_array_equal(pb.view(np.uint32), fx[f"masked_sel_{tag}_pb"].view(np.uint32))
+    # the override must matter: the same batch typed with the unmasked adjacency selects a different set
+    plain = O.select_nodes(mb, mask, ppr, th, n=n)
+    assert plain["onehop"][0].shape != sel["onehop"][0].shape or not np.array_equal(plain["onehop"][0], sel["onehop"][0])
+    res = O.forward(mb, fx["x"], adj_norm, masked, ppr, fx.params, fx.cfg, adj_unmasked=mask)
+    assert np.abs(res["combined_feats"] - fx["masked_combined_feats"]).max() <= FLOAT_TOL
+    assert np.abs(res["logit"] - fx["masked_logit"]).max() <= FLOAT_TOL
+    # --mask-input: propagation over the symmetrised, unweighted kept edges
+    both = np.concatenate([keep, keep[::-1]], axis=1)
+    prop = O.gcn_norm(both, None, n)
+    res = O.forward(mb, fx["x"], prop, masked, ppr, fx.params, fx.cfg, adj_unmasked=mask)
+    assert np.abs(res["x_node"] - fx["masked_prop_x_node"]).max() <= FLOAT_TOL
+    assert np.abs(res["logit"] - fx["masked_prop_logit"]).max() <= FLOAT_TOL
 
 
 def test_naive_threshold_would_differ():
