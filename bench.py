@@ -63,6 +63,12 @@ def pair_stats(data, batch, thresholds, p1):
             "sum_p1_len": int(p1len[a].sum() + p1len[b].sum())}
 
 
+def slot_count(model, batch_t):
+    """Candidate slots of one batch (adjacency rows of both endpoints + the shorter T0 row, at least one per pair)."""
+    ws = model._select_device(batch_t, False, None)
+    return int(ws.ctl[0].item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=98304,
                     help="pairs timed on the CPU oracle (taken from the bench's own batches; about 10-15 s of CPU work)")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="host threads the CPU baseline may use")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--ppr", default="gpu", choices=("gpu", "host"),
                     help="PPR producer for the (untimed) setup: lpf_ppr_push_f64 on the GPU or the OpenMP host push")
@@ -81,6 +88,8 @@ def main():
                     help="seconds of untimed steps after the W warm-up steps, so that the device holds its clocks")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="keep the elementwise / q branches on the step's own stream (model.use_side_stream = False)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed windows of K steps in total; the FIRST is `value`, min/median/max of all are reported")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
@@ -153,6 +162,18 @@ def main():
     elapsed = LD.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(out).all()
 
+    # ---- the same window repeated (reported only: `value` is the window above); spread of the measurement
+    rep_ms = [elapsed * 1e3 / args.steps]
+    for _ in range(max(0, args.repeats - 1)):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step_on(i)
+        torch.cuda.synchronize()
+        barrier()
+        rep_ms.append(LD.max_over_ranks(time.perf_counter() - t0, dev) * 1e3 / args.steps)
+
     # ---- encoder, timed separately (same output: h stays valid)
     barrier()
     torch.cuda.synchronize()
@@ -196,35 +217,37 @@ def main():
             tp = [model.compute_node_mask(b) for b in batches]
             nsel = [sum(int(t[0].shape[1]) for t in sel if t is not None) for sel in tp]
             p1 = model._device_graph("p1", data["ppr"]).to_host()
-            stats = [pair_stats(data, b, cfg["thresholds"], p1) for b in batches_np]
+            stats = [dict(pair_stats(data, b, cfg["thresholds"], p1), slots=slot_count(model, bt))
+                     for b, bt in zip(batches_np, batches)]
             used = [i % len(batches) for i in range(args.steps)]
             mean = lambda arr: float(np.mean([arr[i] for i in used]))  # noqa: E731
             n_sel, sum_deg = mean(nsel), mean([s["sum_deg"] for s in stats])
             sum_ppr, sum_p1 = mean([s["sum_ppr_len"] for s in stats]), mean([s["sum_p1_len"] for s in stats])
             # algorithmic work per launch: bytes for the HBM-bound kernels, FLOPs for MFMA ones
+            slots = mean([s["slots"] for s in stats])
+            c = model.count_dim
             work = {
-                # n_sel * (2 D^2 + ~20 D)
+                # one-pass attention (score + segment softmax + weighted sum): SURVEY 8(d) n_sel * (2 D^2 + ~20 D)
+                "pair_attention_fused": ("mfma", n_sel * (2.0 * d * d + 20.0 * d)),
+                # legacy two-pass kernels (D = 256 and the module-by-module API)
                 "pair_scores": ("mfma", n_sel * (2.0 * d * d + 20.0 * d)),
-                # indexed selection: adjacency columns + aligned self-PPR (8 B per candidate), one-hop index columns,
-                # item record + stage offset, dense staging code per candidate
-                "select_nodes": ("hbm", 8.0 * sum_deg + 4.0 * sum_p1 + 72.0 * bs + 4.0 * sum_deg),
-                # Z row + entry metadata per selected node, G row + pointers per pair
                 "pair_softmax_gather": ("hbm", n_sel * (4.0 * d + 16.0) + bs * (4.0 * (4 * d + 4) + 48.0)),
-                "select_compact": ("hbm", 12.0 * sum_deg + 16.0 * n_sel + 64.0 * bs),
-                "gemm_attn_out": ("mfma", 2.0 * bs * d * (3 * d + 4)),
-                "gemm_q": ("mfma", 2.0 * bs * d * d),
-                # fused dense chains (lpf_dense_chain_f32): FLOPs of the Linear layers they contain
-                "dense_chain_attn_out": ("mfma", 2.0 * bs * d * (3 * d + 4)),
+                # selection, run kernel: 8 B per candidate slot (column + aligned self-PPR, or T0 column + value),
+                # one 8-byte index lookup (column + value) per adjacency candidate, 148 B per pair (descriptor, offset,
+                # three segment starts), one 16-byte record per selected entry
+                "select_run": ("hbm", 8.0 * slots + 8.0 * sum_deg + 148.0 * bs + 16.0 * n_sel),
+                # plan kernel: two node ids, twelve row pointers, descriptor + offset per pair
+                "select_plan": ("hbm", (16.0 + 12 * 8.0 + 128.0 + 8.0) * bs),
+                "select_export": ("hbm", 2 * 16.0 * n_sel + 40.0 * bs),
                 # q = Y[a] + Y[b]: two gathered rows in, one row out per pair
                 "pair_gather_q": ("hbm", 3.0 * 4.0 * d * bs + 16.0 * bs),
-                "dense_chain_score": ("mfma", 2.0 * bs * (2 * d) * (2 * d + model.count_dim + 1)),  # folded first layer
-                "dense_chain_mlp": ("mfma", (2.0 * bs * (2 * d * d) + 2.0 * bs * (d + model.count_dim)
-                                             * (2 * d + model.count_dim)) / 2.0),  # 2 launches/step, mean per launch
-                # attention output + first layer of pairwise_lin + folded score head in one launch
-                "tail_chain": ("mfma", 2.0 * bs * (d * (3 * d + 4) + (d + model.count_dim) ** 2
-                                                  + 2 * d * (2 * d + model.count_dim))),
-                # first layers alone (score_pairs): D x D and (D+c) x (D+c), mean per launch
-                "dense_chain_mlp_hidden": ("mfma", (2.0 * bs * d * d + 2.0 * bs * (d + model.count_dim) ** 2) / 2.0),
+                "dense_chain_score": ("mfma", 2.0 * bs * (2 * d) * (2 * d + c + 1)),  # folded first layer
+                "dense_chain_mlp": ("mfma", (2.0 * bs * (2 * d * d) + 2.0 * bs * (d + c) * (2 * d + c)) / 2.0),
+                "dense_chain_attn_out": ("mfma", 2.0 * bs * d * (3 * d + 4)),
+                # merged dense tail: record merge + post-norm (no GEMM), first layer of pairwise_lin, folded score head
+                "tail_chain": ("mfma", 2.0 * bs * ((d + c) ** 2 + 2 * d * (2 * d + c))),
+                # first layer of elementwise_lin alone (score_pairs): D x D
+                "dense_chain_mlp_hidden": ("mfma", 2.0 * bs * d * d),
             }
             for name, (bound, units) in work.items():
                 if name not in kt:
@@ -236,25 +259,24 @@ def main():
                                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4),
                                    "traffic": None, "launch_ms": round(kt[name][2], 4),
                                    "launches_per_step": kt[name][0] / args.steps}
-            # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE, gfx950-corrected)
+            # HBM traffic per launch: NOT measured in this run -- read from the committed rocprofv3 PMC passes
+            # (FETCH_SIZE / WRITE_SIZE, gfx950-corrected; tools/collect_profiles.sh) and tagged with that file
             try:
                 if args.config != "collab":
                     raise KeyError("the committed PMC passes were collected on the collab-like workload only")
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                # bench name -> (profile names, launches of the bench name they add up to)
-                alias = {"pair_softmax_gather": (("pair_softmax_gather_light", "pair_softmax_gather_heavy"), 1),
-                         "dense_chain_mlp": (("dense_chain_elementwise", "dense_chain_pairwise"), 2)}
+                pmc_file = os.path.join("profiles", "r02_pmc_traffic.json")
+                pmc = json.load(open(os.path.join(ROOT, pmc_file)))
                 for name, r in rooflines.items():
-                    keys, per = alias.get(name, ((name,), 1))
-                    if all(k in pmc for k in keys):
-                        r["traffic"] = sum(pmc[k]["hbm_bytes_per_launch_corrected"] for k in keys) // per
+                    if name in pmc["kernels"]:
+                        r["traffic"] = pmc["kernels"][name]["hbm_bytes_per_launch_corrected"]
+                        r["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes at {pmc.get('commit', '?')})"
             except (OSError, KeyError, ValueError):
                 pass
             modelled = [k for k in sorted(kt, key=lambda k: -kt[k][1]) if k in rooflines]
             if modelled:
                 roofline = dict(rooflines[modelled[0]])
                 roofline["batch_stats"] = {"n_sel": n_sel, "sum_deg": sum_deg, "sum_ppr_len": sum_ppr,
-                                           "sum_p1_len": sum_p1}
+                                           "sum_p1_len": sum_p1, "slots": slots}
         # encoder aggregation kernel (outside the timed pair-stage region): SURVEY 8(d) bytes per layer
         KernelTimer.reset()
         KernelTimer.enabled = True
@@ -266,10 +288,24 @@ def main():
             nnz = a_hat.nnz
             byts = nnz * 8.0 + 8.0 * (n + 1) + 4.0 * d * nnz + 4.0 * d * n
             ach = byts / (enc["spmm_csr"][2] * 1e-3) / 1e9
+            floor = nnz * 8.0 + 8.0 * (n + 1) + 2 * 4.0 * d * n   # every feature row read once + written once
+            ach_floor = floor / (enc["spmm_csr"][2] * 1e-3) / 1e9
             rooflines["spmm_csr"] = {"kernel": "spmm_csr (encoder, per layer)", "bound": "hbm",
                                      "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                     "launch_ms": round(enc["spmm_csr"][2], 4)}
+                                     "launch_ms": round(enc["spmm_csr"][2], 4),
+                                     # gathered bytes (every neighbour row counted, L2 / Infinity Cache
+                                     # serve most of them) above; the compulsory floor (each row once) here
+                                     "achieved_compulsory_floor": round(ach_floor, 1),
+                                     "frac_compulsory_floor": round(ach_floor / HBM_PEAK_GBS, 4)}
+            try:
+                pmc_file = os.path.join("profiles", "r02_pmc_traffic.json")
+                pmc = json.load(open(os.path.join(ROOT, pmc_file)))
+                if args.config == "collab" and "spmm_csr" in pmc["kernels"]:
+                    rooflines["spmm_csr"]["traffic"] = pmc["kernels"]["spmm_csr"]["hbm_bytes_per_launch_corrected"]
+                    rooflines["spmm_csr"]["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes)"
+            except (OSError, KeyError, ValueError):
+                pass
 
         # ---- CPU baseline: the oracle's pair stage on a bounded sample of the same workload
         cpu = None
@@ -285,23 +321,32 @@ def main():
             okw = dict(x=None, adj_norm=None, adj_mask=(mask.rowptr, mask.col.astype(np.int64)),
                        ppr=(ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P=P, cfg=dict(targs, pred_layers=2),
                        x_node=hx)
-            try:  # threads the BLAS sections of the numpy port may use (everything else in it is one thread)
-                from threadpoolctl import threadpool_info
-                blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+            # the numpy port is one thread per call: run it over chunks of the sample on a pool of host threads (numpy
+            # releases the GIL inside its kernels), BLAS pinned to one thread per call; `cores` = threads used
+            from concurrent.futures import ThreadPoolExecutor
+            n_thr = max(1, min(os.cpu_count() or 1, args.cpu_threads))
+            try:
+                from threadpoolctl import threadpool_limits
+                limiter = threadpool_limits(limits=1)
             except ImportError:
-                blas_threads = 1
+                limiter = None
+            chunk = max(256, n_take // (4 * n_thr))
+            spans = [(i, min(i + chunk, n_take)) for i in range(0, n_take, chunk)]
             t0 = time.perf_counter()
-            refs = [O.forward(sample[:, i:i + bs], **okw)["logit"] for i in range(0, n_take, bs)]
+            with ThreadPoolExecutor(max_workers=n_thr) as pool:
+                refs = list(pool.map(lambda se: O.forward(sample[:, se[0]:se[1]], **okw)["logit"], spans))
             cpu_s = time.perf_counter() - t0
+            if limiter is not None:
+                limiter.restore_original_limits()
             ref_logit = np.concatenate(refs)
             # check the GPU scores of the same pairs against it while we are here
             gl = np.concatenate([model.score_pairs(torch.from_numpy(sample[:, i:i + bs]).to(dev), h, score, logits=True)
                                  .cpu().numpy() for i in range(0, n_take, bs)])
-            cpu = {"value": round(n_take / cpu_s, 1), "unit": "pairs/s", "cores": blas_threads,
+            cpu = {"value": round(n_take / cpu_s, 1), "unit": "pairs/s", "cores": n_thr,
                    "kind": "port",
-                   "sample": f"first {n_take} pairs of the bench's batches (pair stage, encoder output resident); "
-                             f"numpy restatement oracle/lpformer_oracle.py, {cpu_s:.1f} s; its matmuls run on "
-                             f"{blas_threads} BLAS threads, the rest of it on one",
+                   "sample": f"first {n_take} pairs of the bench's batches (pair stage, encoder output resident) in "
+                             f"chunks of {chunk} on {n_thr} host threads of {os.cpu_count()} cores; numpy restatement "
+                             f"oracle/lpformer_oracle.py, {cpu_s:.1f} s",
                    "max_abs_logit_diff_vs_gpu": float(np.abs(gl - ref_logit).max())}
 
         result = {
@@ -319,6 +364,8 @@ def main():
                        else "single GPU"},
             "encoder_ms": round(encoder_ms, 4), "value_incl_encoder": round(value_incl_encoder, 1),
             "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),
+            "ms_per_step_repeats": {"n": len(rep_ms), "min": round(min(rep_ms), 4),
+                                    "median": round(float(np.median(rep_ms)), 4), "max": round(max(rep_ms), 4)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "rooflines": rooflines,
             "setup_s": dict({k: round(v, 2) for k, v in setup.items()}, ppr_producer=args.ppr),
         }

@@ -34,7 +34,7 @@ extern "C" {
 #define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
 #define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
 
-#define LPF_ABI_VERSION 1
+#define LPF_ABI_VERSION 2
 
 /* GEMM / row-wise epilogue flags */
 #define LPF_FLAG_RELU 1u
@@ -92,8 +92,10 @@ int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const f
 /* mul[k,:] = X[a_k,:] * X[b_k,:]  and  sum[k,:] = X[a_k,:] + X[b_k,:]   (link_transformer.py:101-102,143).
  * With X = Y := X_node W_l^T + b_l (one GEMM per encoder output) the sum IS the attention query of the pair,
  * lin_l(xa) + lin_l(xb) (layers.py:212-215): no per-pair GEMM.
- * batch: int64 [2, bs] row-major (row 0 = a, row 1 = b) with row stride `batch_ld`.  mul or sum may be NULL. */
-int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, const float *X,
+ * batch: int64 [2, bs] row-major (row 0 = a, row 1 = b) with row stride `batch_ld`.  mul or sum may be NULL.
+ * n_rows: rows of X; an id outside [0, n_rows) reads row 0 instead (lpf_select_plan raises LPF_SELECT_ERR_NODE_RANGE
+ * for such a batch; the reference raises an index error at link_transformer.py:101). */
+int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, int64_t n_rows, const float *X,
                         int64_t ldx, float *mul, int64_t ldm, float *sum, int64_t lds, void *stream);
 
 /* Selection, step 1: per-pair descriptors, staging capacities and work-item counts, with their exclusive scans.
@@ -158,6 +160,50 @@ int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t *offs, int
                        float *stage_pb, const int32_t *stage_cnt, const int64_t *type_ptr,
                        int32_t *sel_pair, int32_t *sel_node, float *sel_pa, float *sel_pb, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Selection, second generation (select2.hip): two launches, nothing read back by the host.
+ * compute_node_mask + get_ppr_vals + get_non_1hop_ppr (link_transformer.py:214-319,434-481), eval mode; bit-exact.
+ * The candidates of the batch form one flat slot space -- pair k owns N(a_k) | N(b_k) | the shorter of the two T0
+ * rows, at least one slot -- cut into work items of LPF_SELECT_ITEM slots; one thread per slot.
+ *
+ *   ctl   int64[LPF_SELECT_CTL_WORDS], zero-initialised once by the caller, then owned by the library; ONE batch size
+ *         per control block (the launch number is derived from the plan ticket):
+ *         [0] slots of the batch  [1] work items  [2] item ticket  [3] STICKY error bits (LPF_SELECT_ERR_*; the caller
+ *         clears them after handling)  [4..6] selected entries per type (cn, 1-hop, >1-hop)  [7] plan ticket
+ *         [8] launch number (tags the chained-scan words: those of earlier launches read as "not ready", nothing is
+ *         ever cleared and no per-launch value comes from the host, so the two launches replay from a captured graph)
+ *   desc  128 bytes per pair;  offs int64[bs+1];  item_pair int32[item_cap];  plan_lb uint64[lpf_select_plan_blocks(bs)]
+ *   run_lb uint64[3*item_cap];  type_ptr int32[3*(bs+1)];  entries 16 bytes x 3 x ent_cap
+ *   val_*  the rows PPR values are looked up in: with adj_selfp (evaluation) the prefiltered one-hop index P1
+ *          (lpf_ppr_filter_*, mode 1) -- the PPR of a node to its own neighbours then comes from adj_selfp --,
+ *          without it (adjacency override of the training loop) the raw PPR matrix
+ *   adjx_* UNMASKED adjacency for the >1-hop exclusion (link_transformer.py:443); NULL = the typing adjacency
+ * Result: per type t a dense region entries[t*ent_cap ..) of {pair | from_N(b) << 31, node, pa, pb} records ordered by
+ * (pair, candidate slot); segment of pair k = [type_ptr[t*(bs+1)+k], type_ptr[t*(bs+1)+k+1]); the one-hop segment
+ * lists the kept nodes of N(a), then those of N(b).  Entries past ent_cap are dropped and LPF_SELECT_ERR_ENTRY_CAP is
+ * raised; consumers clamp to ent_cap.  grid_blocks: persistent workgroups of the run kernel (0 = default). */
+#define LPF_SELECT_ITEM 1024
+#define LPF_SELECT_CTL_WORDS 16
+#define LPF_SELECT_ERR_NODE_RANGE 1 /* a node id of the batch is outside [0, n_nodes): the pair was treated as empty */
+#define LPF_SELECT_ERR_ITEM_CAP 2   /* more work items than item_cap: the batch was not processed completely      */
+#define LPF_SELECT_ERR_ENTRY_CAP 4  /* more selected entries of one type than ent_cap                              */
+int64_t lpf_select_plan_blocks(int64_t bs);
+int lpf_select_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const int64_t *adj_rowptr,
+                    const int64_t *val_rowptr, const int64_t *t0_rowptr, const int64_t *adjx_rowptr, void *desc,
+                    int64_t *offs, int32_t *item_pair, int64_t item_cap, int64_t *ctl, uint64_t *plan_lb,
+                    void *stream);
+int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair, int64_t item_cap,
+                   int64_t *ctl, uint64_t *run_lb, const int32_t *adj_col, const float *adj_selfp,
+                   const int32_t *adjx_col, const int32_t *val_col, const float *val_val, const int32_t *t0_col,
+                   const float *t0_val, float th_cn, float th_1hop, float th_non1hop, int32_t *type_ptr,
+                   void *entries, int64_t ent_cap, int32_t grid_blocks, void *stream);
+/* The reference's layout from the regions above: all CN entries sorted by (pair, node), then all 1-hop (the two runs
+ * merged by node id), then all >1-hop (link_transformer.py:161-162); type_ptr64 int64[3*(bs+1)] relative per type,
+ * counts_f the float count features of get_structure_cnts (:340-356), as lpf_select_scan wrote them. */
+int lpf_select_export(int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap, int64_t *type_ptr64,
+                      float *counts_f, int64_t ldc, int32_t want_t0, int32_t *sel_pair, int32_t *sel_node,
+                      float *sel_pa, float *sel_pb, void *stream);
+
 /* Attention scores for every selected entry (layers.py:206-218 with get_pos_encodings
  * link_transformer.py:182-211 folded in; algebra in DESIGN.md):
  *   h_e = ReLU(LN_t(W1_t [pa,pb] + b1_t)) + ReLU(LN_t(W1_t [pb,pa] + b1_t))
@@ -194,7 +240,8 @@ int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, 
  * never leaving registers.  Replaces Linear -> LayerNorm -> ReLU -> Linear chains of other_models.py:125-138 (MLP),
  * :173-179 (mlp_score, N2 == 1 "dot mode": logit/prob out), the hoisted lin_l of layers.py:212-215 (in_mode 2) and the
  * attention-output projection + post_att_norm (layers.py:78; single layer with addend + LN).
- *   in_mode 0: x = X[m, :K1]; 1: x = X[a_m] * X[b_m]; 2: x = X[a_m] + X[b_m]  (batch: int64 [2, M], row stride batch_ld)
+ *   in_mode 0: x = X[m, :K1]; 1: x = X[a_m] * X[b_m]; 2: x = X[a_m] + X[b_m]  (batch: int64 [2, M], row stride batch_ld;
+ *              n_rows = rows of X, ids outside [0, n_rows) read row 0 -- see lpf_pair_gather_f32)
  *   w1_packed: layer-1 weights [N1, K1] in MFMA A-operand order, output tiles padded to an even count
  *              ntp1 = 2*ceil(N1/32).  k-group ks (16 input features) is ntp1*64 float4: float4 (c, lane = 16q + i) =
  *              W1[16c + i][16ks + 4q + 0..3].  A stage is one k-group, zero padded to a multiple of 512 float4; the
@@ -209,7 +256,7 @@ int lpf_pair_softmax_gather_f32(int32_t D, int64_t bs, const int64_t *type_ptr, 
  *   anything else returns LPF_ERR_UNSUPPORTED (callers then use lpf_gemm_f32 + lpf_layernorm_f32).
  *   lpformer_amd/fold.py builds the packed images. */
 int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch,
-                        int64_t batch_ld, int32_t K1, const float *w1_packed, int32_t N1, const float *b1,
+                        int64_t batch_ld, int64_t n_rows, int32_t K1, const float *w1_packed, int32_t N1, const float *b1,
                         const float *addend, int64_t ldadd, const float *ln_g, const float *ln_b, uint32_t flags,
                         const float *w2_packed, int32_t N2, const float *b2, float *out, int64_t ldo, float *prob,
                         void *stream);
@@ -229,6 +276,31 @@ int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const float *G, i
                        const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
                        const float *r_e, int64_t ldre, const float *wC_packed, const float *bC, const float *w_dot,
                        const float *b_dot, float *logit, float *prob, void *stream);
+
+/* Attention in ONE pass over the regions written by lpf_select_run (pair_fused.hip): per entry
+ *   k_e = Z[node] + Wfold_t h_e + bfold_t,  s_e = att . leaky_relu(k_e * q[pair], 0.2)        (layers.py:206-218)
+ * then the segment softmax and the weighted sum (layers.py:220-224) as an online softmax per (pair, type) segment;
+ * every Z row is gathered once, k_e and s_e never reach memory.  Output: for every non-empty segment
+ *   part[(t*bs + pair)*(D+4) ..] = { sum_e exp(s_e - m) k_e [D], m = max_e s_e, l = sum_e exp(s_e - m), -, - }
+ * (segments that cross 16-entry unit boundaries go through bnd/uflag and a second, small kernel of the same call).
+ * lpf_tail_chain_merge_f32 combines a pair's up to three records.  Tables as for lpf_pair_scores_f32.
+ * bnd: float[3*units_cap*2*(D+4)], uflag: int32[3*units_cap], units_cap >= ceil(ent_cap/16).  D in {32, 64, 128}. */
+int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                 int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
+                                 const float *pe_tab, const float *pe_stat, const float *wfold_packed,
+                                 const float *bfold, const float *att, float *part, float *bnd, int32_t *uflag,
+                                 int64_t units_cap, void *stream);
+
+/* lpf_tail_chain_f32 with the attention output taken from the records of lpf_pair_attention_fused_f32 instead of a
+ * GEMM:  o = post_att_norm( sum_t e^{m_t-M} acc_t / (sum_t e^{m_t-M} l_t + 1e-16) + att_bias ), M = max_t m_t over the
+ * pair's non-empty segments (PyG softmax over ALL entries of the pair, layers.py:220; no entry => o = LN(att_bias)),
+ * and the count features n_cn, n_1hop, [n_non1hop,] n_cn+n_1hop (link_transformer.py:340-356) from type_ptr.
+ * sel_ctl (optional): the selection control block; if its error word is set every score of the batch is NaN. */
+int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, const float *part, const int32_t *type_ptr,
+                             const float *att_bias, const float *lnA_g, const float *lnA_b, const float *wB_packed,
+                             const float *bB, const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre,
+                             const float *wC_packed, const float *bC, const float *w_dot, const float *b_dot,
+                             const int64_t *sel_ctl, float *logit, float *prob, void *stream);
 
 /* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
  * logit or prob may be NULL. */

@@ -11,8 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "liblpformer_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "liblpformer_host.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 FLAG_RELU = 1
+SELECT_ERR_NODE_RANGE, SELECT_ERR_ITEM_CAP, SELECT_ERR_ENTRY_CAP = 1, 2, 4
 
 i32, i64, f32, f64, u32, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32, C.c_void_p
 
@@ -26,13 +27,20 @@ HIP_PROTOTYPES = {
     "lpf_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],
     "lpf_gemm_f32": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
     "lpf_layernorm_f32": [i64, i32, vp, i64, vp, vp, vp, i64, u32, vp],
-    "lpf_pair_gather_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp],
+    "lpf_pair_gather_f32": [i64, i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp],
     "lpf_select_bound": [i64, vp, i64, vp, vp, vp, vp, vp, vp, vp],
     "lpf_select_nodes": [i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp],
     "lpf_select_scan": [i64, vp, vp, vp, i64, i32, vp, vp],
     "lpf_select_compact": [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lpf_select_plan_blocks": [i64],
+    "lpf_select_plan": [i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
+    "lpf_select_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, i64, i32, vp],
+    "lpf_select_export": [i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp],
+    "lpf_pair_attention_fused_f32": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "lpf_tail_chain_merge_f32": [i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp,
+                                 vp],
     "lpf_rowdot_sigmoid_f32": [i64, i32, vp, i64, vp, f32, vp, vp, vp],
     "lpf_tail_chain_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
                            vp, vp],
@@ -43,8 +51,8 @@ HIP_PROTOTYPES = {
     "lpf_ppr_push_f64": [i64, vp, vp, C.c_double, C.c_double, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp],
     "lpf_ppr_pack_workspace_bytes": [i64, i64],
     "lpf_ppr_pack_csr": [i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp],
-    "lpf_dense_chain_f32": [i64, i32, vp, i64, vp, i64, i32, vp, i32, vp, vp, i64, vp, vp, u32, vp, i32, vp, vp, i64, vp,
-                            vp],
+    "lpf_dense_chain_f32": [i64, i32, vp, i64, vp, i64, i64, i32, vp, i32, vp, vp, i64, vp, vp, u32, vp, i32, vp, vp, i64,
+                            vp, vp],
 }
 HOST_PROTOTYPES = {
     "lpf_ppr_push_cpu": [i64, vp, vp, f64, f64, vp, C.POINTER(vp), C.POINTER(vp), i32],
@@ -52,7 +60,7 @@ HOST_PROTOTYPES = {
     "lpf_host_abi_version": [],
 }
 _RESTYPE = {"lpf_strerror": C.c_char_p, "lpf_last_hip_error": C.c_char_p, "lpf_host_free": None,
-            "lpf_ppr_push_workspace_bytes": C.c_int64, "lpf_ppr_pack_workspace_bytes": C.c_int64}
+            "lpf_ppr_push_workspace_bytes": C.c_int64, "lpf_select_plan_blocks": C.c_int64, "lpf_ppr_pack_workspace_bytes": C.c_int64}
 
 
 class LpfError(RuntimeError):

@@ -33,7 +33,7 @@ struct DenseChainArgs {
     int64_t M;
     int in_mode;                 // 0: rows of X; 1: X[a] * X[b]; 2: X[a] + X[b]
     const float *X; int64_t ldx;
-    const int64_t *batch; int64_t batch_ld;
+    const int64_t *batch; int64_t batch_ld; int64_t n_rows;
     int K1;                      // logical input width
     const float *w1p; int N1;    // packed layer-1 weights, logical output width
     const float *b1; const float *addend; int64_t ldadd;
@@ -198,6 +198,9 @@ __global__ __launch_bounds__(DC_THREADS, MINW) void dense_chain_kernel(const Den
         if constexpr (MODE != 0) {
             ra = A.batch[mm];
             rb = A.batch[A.batch_ld + mm];
+            // ids outside the table read row 0 (the selection kernel reports them; nothing is read out of bounds)
+            if ((uint64_t)ra >= (uint64_t)A.n_rows) ra = 0;
+            if ((uint64_t)rb >= (uint64_t)A.n_rows) rb = 0;
         }
         const float *xa = A.X + ra * A.ldx, *xb = A.X + rb * A.ldx;
 
@@ -347,13 +350,15 @@ int dc_launch(const DenseChainArgs &a, hipStream_t s) {
     constexpr int G = dc_groups(NTP1, NTP2);
     constexpr size_t lds = DcLds<NT1, NT2, G>::BYTES;
     auto kern = dense_chain_kernel<NT1, NT2, G, MODE, dc_min_waves<NT1, NT2, G>()>;
-    if (lds > 64 * 1024) {
+    static bool lds_set = false;  // (per instantiation; the attribute is sticky, one call is enough)
+    if (lds > 64 * 1024 && !lds_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             lpf_set_hip_error(e);
             return LPF_ERR_LAUNCH;
         }
+        lds_set = true;
     }
     const int64_t blocks = (a.M + 16 * DC_GROUPS - 1) / (16 * DC_GROUPS);
     if (blocks > 0x7fffffff) return LPF_ERR_UNSUPPORTED;
@@ -365,14 +370,14 @@ int dc_launch(const DenseChainArgs &a, hipStream_t s) {
 }  // namespace
 
 extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch,
-                                   int64_t batch_ld, int32_t K1, const float *w1_packed, int32_t N1, const float *b1,
+                                   int64_t batch_ld, int64_t n_rows, int32_t K1, const float *w1_packed, int32_t N1, const float *b1,
                                    const float *addend, int64_t ldadd, const float *ln_g, const float *ln_b,
                                    uint32_t flags, const float *w2_packed, int32_t N2, const float *b2, float *out,
                                    int64_t ldo, float *prob, void *stream) {
     if (M == 0) return LPF_OK;
     LPF_REQUIRE(M > 0 && X && w1_packed && b1 && K1 > 0 && N1 > 0 && (ldx & 3) == 0 && lpf_aligned16(X) &&
                 lpf_aligned16(w1_packed) && lpf_aligned16(b1));
-    LPF_REQUIRE(in_mode >= 0 && in_mode <= 2 && (in_mode == 0 || (batch && batch_ld >= M)));
+    LPF_REQUIRE(in_mode >= 0 && in_mode <= 2 && (in_mode == 0 || (batch && batch_ld >= M && n_rows > 0)));
     LPF_REQUIRE((K1 & 3) == 0 && ldx >= K1);
     LPF_REQUIRE((!ln_g) == (!ln_b) && (!ln_g || (lpf_aligned16(ln_g) && lpf_aligned16(ln_b))));
     LPF_REQUIRE(!addend || ((ldadd & 3) == 0 && lpf_aligned16(addend) && ldadd >= N1 && (N1 & 3) == 0));
@@ -384,7 +389,7 @@ extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, i
     LPF_REQUIRE(dot || ldo >= (two ? N2 : N1));
     LPF_REQUIRE(dot || !two || lpf_aligned16(b2));
     const int nt1 = (N1 + 15) / 16, nt2 = (two && !dot) ? (N2 + 15) / 16 : 0;
-    DenseChainArgs a{M, in_mode, X, ldx, batch, batch_ld, K1, w1_packed, N1, b1, addend, ldadd, ln_g, ln_b, flags,
+    DenseChainArgs a{M, in_mode, X, ldx, batch, batch_ld, n_rows, K1, w1_packed, N1, b1, addend, ldadd, ln_g, ln_b, flags,
                      w2_packed, N2, b2, out, ldo, prob};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // in_mode 1 (gather-multiply) is built for the square two-layer chains (elementwise_lin) and the single-layer

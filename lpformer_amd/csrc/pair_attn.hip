@@ -11,9 +11,7 @@
 //   phase B  lpf_pair_softmax_gather_f32  per-pair segment softmax, then the alpha-weighted sums of Z rows and of
 //            h_e per type; a group of D/4 lanes owns a pair (16-byte pieces of each row).  Bound: gather bandwidth.
 //   phase C  is a plain GEMM (lpf_gemm_f32) on [sum alpha h_e | sum alpha | 1] with [Wfold | bfold | bias].
-#include "lpf_common.h"
-
-
+#include "pe_common.h"
 
 namespace {
 
@@ -21,23 +19,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int SG_HEAVY = 64;        // pairs with more selected nodes than this get a whole workgroup in phase B
 constexpr int SG_HEAVY_CHUNK = 16;  // entries per lane-group chunk in that kernel
-
-struct PeStat {
-    float c00, c11, cbb, c01, c0b, c1b;
-};
-
-// LayerNorm statistics of u_k = w0_k*x + w1_k*y + b_k over k, from the centred second moments of (w0, w1, b):
-// mean-free by construction (pe_tab already holds centred, gamma-scaled coefficients), so only 1/std is needed.
-__device__ __forceinline__ float pe_rstd(const PeStat &s, float x, float y) {
-    const float var = s.c00 * x * x + s.c11 * y * y + s.cbb + 2.0f * (s.c01 * x * y + s.c0b * x + s.c1b * y);
-    return 1.0f / sqrtf(fmaxf(var, 0.0f) + 1e-5f);
-}
-
-__device__ __forceinline__ float pe_hidden(const float4 k, float pa, float pb, float r_ab, float r_ba) {
-    const float u_ab = fmaf(k.x, pa, fmaf(k.y, pb, k.z));
-    const float u_ba = fmaf(k.x, pb, fmaf(k.y, pa, k.z));
-    return fmaxf(fmaf(r_ab, u_ab, k.w), 0.0f) + fmaxf(fmaf(r_ba, u_ba, k.w), 0.0f);
-}
 
 // One tile of 32 same-type entries handled by one wavefront.  `wp` points at this lane's slice of the packed
 // Wfold_t image (global memory or the workgroup's LDS copy): wp[(c*NSQ + sq)*64] is the A operand of step group sq for
@@ -478,10 +459,13 @@ extern "C" int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t b
     do {                                                                                                           \
         auto kern = pair_scores_lds_kernel<NT>;                                                                    \
         const size_t lds = (size_t)(NT * (32 * NT / 8) * 64 + 3 * 32 * NT) * sizeof(float4);                       \
-        if (lds > 64 * 1024 &&                                                                                     \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)lds) != hipSuccess)                                                           \
-            return LPF_ERR_LAUNCH;                                                                                 \
+        static bool lds_set = false;                                                                               \
+        if (lds > 64 * 1024 && !lds_set) {                                                                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
+                return LPF_ERR_LAUNCH;                                                                             \
+            lds_set = true;                                                                                        \
+        }                                                                                                          \
         int64_t groups = (tiles + PSL_WAVES - 1) / PSL_WAVES + 3;                                                  \
         if (groups > 256) groups = 256; /* one 16-wave workgroup per CU: half the LDS of two 8-wave ones */       \
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * PSL_WAVES), lds, s, type_ptr, bs, sel_pair,     \

@@ -1,0 +1,342 @@
+// Pairwise PPR-positional attention in ONE pass over the selected entries: score -> segment softmax -> weighted sum,
+// every Z row gathered once, the per-entry key vector and the scores never written to memory.
+//
+// Reference: LinkAttention.message + PyG softmax + scatter-sum (src/modules/layers.py:193-224) with
+// get_pos_encodings (src/models/link_transformer.py:182-211) folded in (algebra in DESIGN.md section 4):
+//     k_e = Z[v_e] + Wfold_t h_e + bfold_t          s_e = att . leaky_relu(k_e * q[pair_e], 0.2)
+//     alpha = softmax of s over the entries of a pair (max-shifted, denominator + 1e-16)
+//     out_pair = sum_e alpha_e k_e + bias
+// The selection kernels (select2.hip) leave per type t one dense region of {pair, node, pa, pb} records in which the
+// entries of a pair are contiguous.  A wavefront takes a TILE of 32 consecutive same-type entries:
+//   * v_mfma_f32_32x32x2_f32 with the ENTRIES AS ROWS: A operand = h_e generated in registers (first PE layer +
+//     LayerNorm in closed form + ReLU, both argument orders), B operand = Wfold_t from a packed image resident in LDS
+//     (shared by the workgroup's wavefronts).  The accumulators then hold k[entry][feature] with the FEATURE ON THE
+//     LANE: Z and q rows are read as 128-byte lane-contiguous pieces, the score is one butterfly over 32 lanes, and
+//     the weighted sum over the entries of a pair is an in-lane loop over registers.
+//   * A-operand row r is fed with tile entry rho^-1(r), chosen so that lanes 0-31 own entries 0-15 and lanes 32-63
+//     own entries 16-31 of the tile in register order: each half-wave is a UNIT of 16 consecutive entries that it
+//     walks sequentially with an online softmax (running max / sum / weighted sum), flushing a record
+//     {sum_e exp(s_e - m) k_e [D], m, l} whenever the pair changes.
+//   * A pair's (type) segment that lies inside one unit is flushed straight to part[t][pair].  A segment that crosses
+//     unit boundaries leaves one boundary record per unit it touches; pair_fused_fixup_kernel merges each such chain
+//     (same rescaling as the online softmax) into part[t][pair].  The tail kernel merges a pair's up to three type
+//     records, adds the bias and applies post_att_norm (tail_chain.hip, merge mode).
+// Bound: fp32 MFMA (2 D^2 FLOP per entry); one Z row + one 16-byte record read per entry.
+#include "pe_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// wavefronts per workgroup sharing one LDS copy of Wfold_t = one workgroup per CU at the register budget of the tile
+// code (NT = 1: 103 VGPRs -> 4 waves per SIMD; NT = 2, 4: 132 / 167 VGPRs -> 3 waves per SIMD)
+template <int NT>
+constexpr int pf_waves() { return NT == 1 ? 16 : 12; }
+constexpr uint32_t PF_PAIR_MASK = 0x7fffffffu;
+
+struct FusedArgs {
+    int64_t bs;
+    const int32_t *type_ptr;   // [3][bs+1]
+    const int4 *entries;       // [3][ent_cap]
+    int64_t ent_cap;
+    const float *Z; int64_t ldz;
+    const float *q; int64_t ldq;
+    const float *pe_tab, *pe_stat, *wpk, *bfold, *att;
+    float *part;               // [3][bs][D+4]
+    float *bnd;                // [3][units_cap][2][D+4]
+    int32_t *uflag;            // [3][units_cap]
+    int64_t units_cap;
+};
+
+template <int NT>
+__device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t idx, int64_t cnt, const float4 *wl,
+                                           const float4 *tab, int lane) {
+    constexpr int D = 32 * NT, NSQ = D / 8, RS = D + 4;
+    const int col = lane & 31, lh = lane >> 5;
+    // tile entry fed to A-operand row `col`: half 0 of the accumulator rows {0-3, 8-11, ...} <- entries 0..15
+    const int ja = 16 * ((col >> 2) & 1) + 4 * (col >> 3) + (col & 3);
+    const int4 *ent = A.entries + (int64_t)t * A.ent_cap;
+    const int64_t e0 = idx * 32;
+    const int64_t ea = e0 + ja;
+    const bool valid_a = ea < cnt;
+    int4 rec = make_int4(0, 0, 0, 0);
+    int prev_pair = -1;
+    if (valid_a) {
+        rec = ent[ea];
+        if (ea > 0) prev_pair = (int)((uint32_t)ent[ea - 1].x & PF_PAIR_MASK);
+    }
+    const int pair_a = (int)((uint32_t)rec.x & PF_PAIR_MASK), node_a = rec.y;
+    const float pa = __int_as_float(rec.z), pb = __int_as_float(rec.w);
+    const uint64_t sm = __ballot(valid_a && prev_pair != pair_a);  // bit r: the entry of row r starts a segment
+    // does the segment of the tile's last entry continue in the next tile?
+    bool tile_cont = false;
+    if (e0 + 32 < cnt)
+        tile_cont = ((uint32_t)ent[e0 + 32].x & PF_PAIR_MASK) == ((uint32_t)ent[e0 + 31].x & PF_PAIR_MASK);
+
+    const PeStat st = pe_load_stat(A.pe_stat, t);
+    const float r_ab = pe_rstd(st, pa, pb), r_ba = pe_rstd(st, pb, pa);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    // Touch every 128-byte line of the entry's Z row and of its pair's q row now (the two lanes that share an A row
+    // split the lines): the rows are consumed only after the MFMA loop, their HBM latency overlaps it.
+    {
+        const float *zr = A.Z + (int64_t)node_a * A.ldz, *qr = A.q + (int64_t)pair_a * A.ldq;
+        constexpr int PFN = NT >= 2 ? NT / 2 : 1;
+        float pfz[PFN], pfq[PFN];
+#pragma unroll
+        for (int i = 0; i < PFN; ++i) {
+            const int line = (lh * PFN + i) % NT;
+            pfz[i] = zr[32 * line];
+            pfq[i] = qr[32 * line];
+        }
+#pragma unroll
+        for (int i = 0; i < PFN; ++i) asm volatile("" ::"v"(pfz[i]), "v"(pfq[i]));
+    }
+
+    const float4 *tb = tab + t * D + lh * (D / 2);
+#pragma unroll 1
+    for (int sq = 0; sq < NSQ; ++sq) {
+        float4 wb[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) wb[c] = wl[(c * NSQ + sq) * 64];
+        float h[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h[u] = pe_hidden(tb[4 * sq + u], pa, pb, r_ab, r_ba);
+        // consecutive MFMAs go to different accumulators (no back-to-back dependency on one accumulator)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[0], wb[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[1], wb[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[2], wb[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[3], wb[c].w, acc[c], 0, 0, 0);
+    }
+    // acc[c][i] = (Wfold_t h)[feature 32c + col] of unit entry i (tile entry 16 lh + i)
+
+    // ---- scores of the unit's 16 entries
+    float bf[NT], at[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        bf[c] = A.bfold[t * D + 32 * c + col];
+        at[c] = A.att[32 * c + col];
+    }
+    float sc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int src = 8 * (i >> 2) + 4 * lh + (i & 3);  // A row that carried this entry
+        const int nd = __shfl(node_a, src, 64), pr = __shfl(pair_a, src, 64);
+        const float *zr = A.Z + (int64_t)nd * A.ldz + col, *qr = A.q + (int64_t)pr * A.ldq + col;
+        float p = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const float k = acc[c][i] + zr[32 * c] + bf[c];
+            acc[c][i] = k;
+            float x = k * qr[32 * c];
+            x = fmaxf(x, 0.2f * x);  // leaky_relu(x, 0.2)
+            p = fmaf(x, at[c], p);
+        }
+        sc[i] = p;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // sum over the 32 feature lanes of the half (every lane gets the total)
+        float v = sc[i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        sc[i] = v;
+    }
+
+    // ---- online softmax over the unit's entries, one record per (pair) piece
+    int64_t left = cnt - e0 - 16 * lh;
+    const int nval = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+    if (nval == 0) return;
+    const uint32_t smh = (uint32_t)(sm >> (4 * lh));     // start bit of unit entry i at position 8 (i>>2) + (i&3)
+    const bool st0 = smh & 1u;
+    // the unit's last entry: does its segment continue in the next unit?
+    bool cont = false;
+    if (nval == 16) cont = lh == 0 ? ((cnt > e0 + 16) && !((sm >> 4) & 1ull)) : tile_cont;
+    const int64_t U = 2 * idx + lh;
+    float *const part_t = A.part + (int64_t)t * A.bs * RS;
+    float *const bnd_u = A.bnd + (((int64_t)t * A.units_cap + U) * 2) * RS;
+
+    float m = -INFINITY, l = 0.f, o[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) o[c] = 0.f;
+    bool first = true;
+    int head = 0, cur_pair = 0;
+    auto flush = [&](int pair, bool cfront, bool cback) {
+        float *dst = (cfront && cback) ? part_t + (int64_t)pair * RS : bnd_u + (cfront ? RS : 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) dst[32 * c + col] = o[c];
+        if (col == 0)
+            *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, __int_as_float(pair), cback ? 0.f : 1.f);
+        if (cfront && !cback) head = 1;
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int pair_i = __shfl(pair_a, 8 * (i >> 2) + 4 * lh + (i & 3), 64);  // (source rows are lanes 0-31)
+        if (i < nval) {
+            const bool sti = (smh >> (8 * (i >> 2) + (i & 3))) & 1u;
+            if (i > 0 && sti) {
+                flush(cur_pair, first ? st0 : true, true);
+                m = -INFINITY; l = 0.f;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) o[c] = 0.f;
+                first = false;
+            }
+            cur_pair = pair_i;
+            const float mn = fmaxf(m, sc[i]);
+            const float sca = __expf(m - mn), w = __expf(sc[i] - mn);
+            l = fmaf(l, sca, w);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) o[c] = fmaf(o[c], sca, w * acc[c][i]);
+            m = mn;
+        }
+    }
+    flush(cur_pair, first ? st0 : true, !cont);
+    if (col == 0) A.uflag[(int64_t)t * A.units_cap + U] = head;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * pf_waves<NT>()) void pair_fused_kernel(const FusedArgs A) {
+    constexpr int D = 32 * NT, NSQ = D / 8, IMG = NT * NSQ * 64;  // float4 per type
+    constexpr int PF_WAVES = pf_waves<NT>();
+    extern __shared__ __attribute__((aligned(16))) float4 pf_lds[];
+    float4 *wl = pf_lds, *tab = pf_lds + IMG;
+    for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) tab[i] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t n[3], tiles[3], groups[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        n[t] = A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs];
+        if (n[t] > A.ent_cap) n[t] = A.ent_cap;  // (overflow: flagged by the selection kernel, stay inside the region)
+        tiles[t] = (n[t] + 31) >> 5;
+        groups[t] = (tiles[t] + PF_WAVES - 1) / PF_WAVES;
+    }
+    int loaded = -1;
+    for (int64_t g = blockIdx.x; g < groups[0] + groups[1] + groups[2]; g += gridDim.x) {
+        int t;
+        int64_t idx;
+        if (g < groups[0]) { t = 0; idx = g * PF_WAVES + wave; }
+        else if (g < groups[0] + groups[1]) { t = 1; idx = (g - groups[0]) * PF_WAVES + wave; }
+        else { t = 2; idx = (g - groups[0] - groups[1]) * PF_WAVES + wave; }
+        if (t != loaded) {  // (the first pass also publishes tab)
+            __syncthreads();
+            const float4 *src = reinterpret_cast<const float4 *>(A.wpk) + (int64_t)t * IMG;
+            for (int i = threadIdx.x; i < IMG; i += blockDim.x) wl[i] = src[i];
+            loaded = t;
+            __syncthreads();
+        }
+        if (idx < tiles[t]) fused_tile<NT>(A, t, idx, n[t], wl + lane, tab, lane);
+    }
+}
+
+// Chains of boundary records -> part[t][pair].  G = D/4 lanes per unit (16 bytes of the record per lane).
+template <int G>
+__global__ __launch_bounds__(256) void pair_fused_fixup_kernel(const FusedArgs A, int D) {
+    const int RS = D + 4;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = tid / G, n_grp = (int64_t)gridDim.x * blockDim.x / G;
+    const int lig = tid % G;
+    for (int t = 0; t < 3; ++t) {
+        int64_t cnt = A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs];
+        if (cnt > A.ent_cap) cnt = A.ent_cap;
+        const int64_t n_units = (cnt + 15) >> 4;
+        for (int64_t U = grp; U < n_units; U += n_grp) {
+            if (A.uflag[(int64_t)t * A.units_cap + U] == 0) continue;
+            const float *r1 = A.bnd + ((((int64_t)t * A.units_cap + U) * 2) + 1) * RS;
+            float4 o = reinterpret_cast<const float4 *>(r1)[lig];
+            const float4 h1 = *reinterpret_cast<const float4 *>(r1 + D);
+            float m = h1.x, l = h1.y;
+            const int pair = __float_as_int(h1.z);
+            int64_t nx = U + 1;
+            float more = 1.f;
+            while (more != 0.f && nx < n_units) {
+                const float *r0 = A.bnd + (((int64_t)t * A.units_cap + nx) * 2) * RS;
+                const float4 o2 = reinterpret_cast<const float4 *>(r0)[lig];
+                const float4 h2 = *reinterpret_cast<const float4 *>(r0 + D);
+                const float mn = fmaxf(m, h2.x);
+                const float a = __expf(m - mn), b = __expf(h2.x - mn);
+                o.x = fmaf(o.x, a, o2.x * b); o.y = fmaf(o.y, a, o2.y * b);
+                o.z = fmaf(o.z, a, o2.z * b); o.w = fmaf(o.w, a, o2.w * b);
+                l = fmaf(l, a, h2.y * b);
+                m = mn;
+                more = h2.w;
+                ++nx;
+            }
+            float *dst = A.part + ((int64_t)t * A.bs + pair) * RS;
+            reinterpret_cast<float4 *>(dst)[lig] = o;
+            if (lig == 0) *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, h1.z, 0.f);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                            int64_t ent_cap, const float *Z, int64_t ldz, const float *q,
+                                            int64_t ldq, const float *pe_tab, const float *pe_stat,
+                                            const float *wfold_packed, const float *bfold, const float *att,
+                                            float *part, float *bnd, int32_t *uflag, int64_t units_cap,
+                                            void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && Z && q && pe_tab && pe_stat && wfold_packed &&
+                bfold && att && part && bnd && uflag && units_cap >= (ent_cap + 15) / 16);
+    LPF_REQUIRE(ldz >= D && ldq >= D && lpf_aligned16(entries) && lpf_aligned16(pe_tab) &&
+                lpf_aligned16(wfold_packed) && lpf_aligned16(part) && lpf_aligned16(bnd));
+    FusedArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, Z, ldz, q, ldq, pe_tab, pe_stat,
+                wfold_packed, bfold, att, part, bnd, uflag, units_cap};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
+        n_cu = prop.multiProcessorCount;
+    }
+    const int64_t tiles = (3 * ent_cap + 31) / 32 + 3;
+#define LPF_FUSED(NT)                                                                                              \
+    do {                                                                                                           \
+        auto kern = pair_fused_kernel<NT>;                                                                         \
+        constexpr int PF_WAVES = pf_waves<NT>();                                                                   \
+        const size_t lds = (size_t)(NT * (32 * NT / 8) * 64 + 3 * 32 * NT) * sizeof(float4);                       \
+        static int per_cu = 0; /* resident workgroups per CU, queried once (also sets the LDS attribute) */        \
+        if (per_cu == 0) {                                                                                         \
+            if (lds > 64 * 1024 &&                                                                                 \
+                hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
+                return LPF_ERR_LAUNCH;                                                                             \
+            int occ = 1;                                                                                           \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * PF_WAVES, lds) != hipSuccess ||      \
+                occ < 1)                                                                                           \
+                occ = 1;                                                                                           \
+            per_cu = occ;                                                                                          \
+        }                                                                                                          \
+        int64_t groups = (tiles + PF_WAVES - 1) / PF_WAVES + 3;                                                    \
+        if (groups > (int64_t)n_cu * per_cu) groups = (int64_t)n_cu * per_cu; /* persistent: one resident round */ \
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * PF_WAVES), lds, s, a);                          \
+    } while (0)
+    switch (D) {
+        case 32: LPF_FUSED(1); break;
+        case 64: LPF_FUSED(2); break;
+        case 128: LPF_FUSED(4); break;
+        default: return LPF_ERR_UNSUPPORTED;  // D = 256: the two-pass kernels (the packed image exceeds LDS)
+    }
+#undef LPF_FUSED
+    switch (D) {
+        case 32: hipLaunchKernelGGL(pair_fused_fixup_kernel<8>, dim3(512), dim3(256), 0, s, a, (int)D); break;
+        case 64: hipLaunchKernelGGL(pair_fused_fixup_kernel<16>, dim3(512), dim3(256), 0, s, a, (int)D); break;
+        default: hipLaunchKernelGGL(pair_fused_fixup_kernel<32>, dim3(512), dim3(256), 0, s, a, (int)D); break;
+    }
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(int64_t M, int D, const 
 
 template <int G>
 __global__ __launch_bounds__(256) void pair_gather_kernel(int64_t bs, int D, const int64_t *__restrict__ batch,
-                                                          int64_t batch_ld, const float *__restrict__ X, int64_t ldx,
+                                                          int64_t batch_ld, int64_t n_rows,
+                                                          const float *__restrict__ X, int64_t ldx,
                                                           float *__restrict__ mul, int64_t ldm,
                                                           float *__restrict__ sum, int64_t lds) {
     constexpr int RPW = 64 / G;
@@ -60,7 +61,10 @@ __global__ __launch_bounds__(256) void pair_gather_kernel(int64_t bs, int D, con
     for (int64_t k0 = wave_id * RPW; k0 < bs; k0 += n_waves * RPW) {
         const int64_t k = k0 + grp;
         if (k >= bs || off >= D) continue;
-        const int64_t a = batch[k], b = batch[batch_ld + k];
+        int64_t a = batch[k], b = batch[batch_ld + k];
+        // ids outside the table read row 0 (the selection kernel reports them; nothing is read out of bounds)
+        if ((uint64_t)a >= (uint64_t)n_rows) a = 0;
+        if ((uint64_t)b >= (uint64_t)n_rows) b = 0;
         const float4 xa = *reinterpret_cast<const float4 *>(X + a * ldx + off);
         const float4 xb = *reinterpret_cast<const float4 *>(X + b * ldx + off);
         if (mul)
@@ -109,10 +113,11 @@ extern "C" int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t l
     return LPF_OK;
 }
 
-extern "C" int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, const float *X,
-                                   int64_t ldx, float *mul, int64_t ldm, float *sum, int64_t lds, void *stream) {
+extern "C" int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, int64_t n_rows,
+                                   const float *X, int64_t ldx, float *mul, int64_t ldm, float *sum, int64_t lds,
+                                   void *stream) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && batch && X && batch_ld >= bs);
+    LPF_REQUIRE(bs > 0 && batch && X && batch_ld >= bs && n_rows > 0);
     if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
     LPF_REQUIRE((ldx & 3) == 0 && ldx >= D && lpf_aligned16(X));
     LPF_REQUIRE(!mul || ((ldm & 3) == 0 && ldm >= D && lpf_aligned16(mul)));
@@ -121,13 +126,13 @@ extern "C" int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, 
     const int G = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
     const unsigned grid = grid_for_rows((bs + 4 * (64 / G) - 1) / (4 * (64 / G)));
     if (G == 16)
-        hipLaunchKernelGGL(pair_gather_kernel<16>, dim3(grid), dim3(256), 0, s, bs, D, batch, batch_ld, X, ldx, mul,
+        hipLaunchKernelGGL(pair_gather_kernel<16>, dim3(grid), dim3(256), 0, s, bs, D, batch, batch_ld, n_rows, X, ldx, mul,
                            ldm, sum, lds);
     else if (G == 32)
-        hipLaunchKernelGGL(pair_gather_kernel<32>, dim3(grid), dim3(256), 0, s, bs, D, batch, batch_ld, X, ldx, mul,
+        hipLaunchKernelGGL(pair_gather_kernel<32>, dim3(grid), dim3(256), 0, s, bs, D, batch, batch_ld, n_rows, X, ldx, mul,
                            ldm, sum, lds);
     else
-        hipLaunchKernelGGL(pair_gather_kernel<64>, dim3(grid), dim3(256), 0, s, bs, D, batch, batch_ld, X, ldx, mul,
+        hipLaunchKernelGGL(pair_gather_kernel<64>, dim3(grid), dim3(256), 0, s, bs, D, batch, batch_ld, n_rows, X, ldx, mul,
                            ldm, sum, lds);
     LPF_CHECK_LAUNCH();
     return LPF_OK;

@@ -1,0 +1,638 @@
+// PPR-thresholded node selection, second generation: two launches, nothing read back by the host.
+//
+// Reference: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (src/models/link_transformer.py:214-319, 434-481),
+// eval mode.  The reference materialises BS x N sparse temporaries and coalesces them seven times; the first
+// generation of this file (select.hip, still used for nothing but kept until the next round's clean-up is done) cut a
+// batch into one-wavefront work items and needed seven launches plus a 16-byte read-back to size its staging area.
+//
+// Here the candidates of a batch form ONE flat index space: pair k owns the slots
+//     [offs[k], offs[k+1])  =  N(a_k)  |  N(b_k)  |  the shorter of T0[a_k], T0[b_k]     (at least one slot per pair)
+// and the space is cut into work items of S2_ITEM consecutive slots, whatever pairs they belong to -- a hub pair
+// simply spans many items, a run of small pairs shares one.  Each slot is owned by one thread:
+//   * plan kernel   per pair: descriptor (row starts / lengths), slot count; one chained scan (decoupled look-back
+//                   over the 256-pair blocks) gives offs[] and the first pair of every item.  Node ids are range
+//                   checked here (a bad id raises a sticky error bit instead of reading out of bounds).
+//   * run kernel    persistent workgroups draw items from a ticket counter.  A thread types its candidate (binary
+//                   search in the other endpoint's adjacency run -- in LDS when that run lies inside the item --,
+//                   then at most one lookup in the prefiltered one-hop rows / the other >1-hop row), applies the
+//                   reference's fp32 round trip and thresholds op for op, and keeps the result in registers.  Kept
+//                   entries are ranked per type inside the item (ballots), the item's three totals go through a
+//                   second chained scan ordered by ticket, and the entries land at their FINAL position: per type
+//                   one dense region ordered by (pair, candidate slot).  The thread that owns a pair's first slot also
+//                   writes the pair's three segment starts, so type_ptr[t][k+1] - type_ptr[t][k] is the count
+//                   feature of get_structure_cnts (:340-356).
+// Placement is deterministic (it follows the flat slot order, not the schedule).  Inside a pair's one-hop segment
+// the kept nodes of N(a) come before those of N(b) (flag bit 31 of the pair word); lpf_select_export merges the two
+// runs by node id when a caller wants the reference's exact layout (compute_node_mask, attention weights).
+#include "lpf_common.h"
+
+// the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int S2_ITEM = LPF_SELECT_ITEM;            // candidate slots per work item
+constexpr int S2_THREADS = 256;
+constexpr int S2_ROUNDS = S2_ITEM / S2_THREADS;     // slots per thread
+constexpr int S2_WAVES = S2_THREADS / 64;
+constexpr uint32_t S2_FROM_B = 0x80000000u;
+
+struct alignas(16) PairDesc {
+    int64_t ra0, rb0;              // adjacency rows (the typing adjacency: adj_mask or the caller's override)
+    int64_t pa0, pb0;              // value rows: P1 index rows (indexed path) or raw PPR rows (general path)
+    int64_t ta0, tb0;              // >1-hop candidate rows (T0 index)
+    int32_t dA, dB, nPa, nPb;
+    int32_t nTa, nTb, a, b;
+    int64_t xa0, xb0;              // rows of the UNMASKED adjacency (>1-hop exclusion, link_transformer.py:443)
+    int32_t dxA, dxB, pad0, pad1;
+    int64_t pad2, pad3;
+};
+static_assert(sizeof(PairDesc) == 128, "PairDesc is one 128-byte line");
+
+// ------------------------------------------------------------------------------------------- chained scan helpers
+// One 8-byte word per participant: [63:42] launch epoch, [41:40] state (1 = own total, 2 = inclusive prefix),
+// [39:0] value.  Words are written and polled as single agent-scope relaxed 8-byte accesses (value and state travel
+// together, nothing else is handed over), and a word of an older launch simply reads as "not ready": the arrays are
+// never cleared.
+constexpr uint64_t LB_VAL_MASK = (1ull << 40) - 1ull;
+
+__device__ __forceinline__ void lb_store(uint64_t *p, uint32_t epoch, uint32_t state, uint64_t value) {
+    __hip_atomic_store(p, ((uint64_t)epoch << 42) | ((uint64_t)state << 40) | (value & LB_VAL_MASK), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t lb_wait(const uint64_t *p, uint32_t epoch) {
+    while (true) {
+        const uint64_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(w >> 42) == epoch && ((w >> 40) & 3ull) != 0ull) return w;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// exclusive prefix of `own` over participants 0..k-1 (k = this participant); publishes own total, then the prefix
+__device__ __forceinline__ uint64_t lb_exclusive(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own) {
+    if (k == 0) {
+        lb_store(lb, epoch, 2, own);
+        return 0;
+    }
+    lb_store(lb + k, epoch, 1, own);
+    uint64_t excl = 0;
+    for (int64_t j = k - 1;; --j) {  // participant 0 always publishes state 2
+        const uint64_t w = lb_wait(lb + j, epoch);
+        excl += w & LB_VAL_MASK;
+        if (((w >> 40) & 3ull) == 2ull) break;
+    }
+    lb_store(lb + k, epoch, 2, excl + own);
+    return excl;
+}
+
+// fl32((fl32(fl32(p*t)+t)-t)/t) for t in {1,2}: p*1, p*2, x/1 and x/2 are exact, only the add and subtract round
+__device__ __forceinline__ float s2_round_trip(float p, bool two) {
+    if (two) return 0.5f * __fsub_rn(__fadd_rn(p * 2.0f, 2.0f), 2.0f);
+    return __fsub_rn(__fadd_rn(p, 1.0f), 1.0f);
+}
+
+// position of key in the sorted array a[0..n), or -1 (a in global memory or LDS).  Lower bound that remembers the
+// value under the final `hi`: when the loop ends lo == hi, and a[hi] was loaded the last time hi moved (or hi never
+// moved and lo == n), so no load is needed after the loop.  (hipcc 7.2 miscompiled the usual "if (lo < n &&
+// a[lo] == key)" tail of two back-to-back searches in the divergent >1-hop branch: a register pair copy on the
+// conditional-load path overwrote the result of the lanes that took it.)
+__device__ __forceinline__ int s2_find(const int32_t *a, int n, int32_t key) {
+    int lo = 0, hi = n;
+    int32_t at_hi = ~key;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int32_t v = a[mid];
+        if (v < key) {
+            lo = mid + 1;
+        } else {
+            hi = mid;
+            at_hi = v;
+        }
+    }
+    return at_hi == key ? lo : -1;
+}
+
+// ------------------------------------------------------------------------------------------- plan
+__global__ __launch_bounds__(S2_THREADS) void select_plan_kernel(
+    int64_t bs, const int64_t *__restrict__ batch, int64_t batch_ld, int64_t n_nodes,
+    const int64_t *__restrict__ adj_rowptr, const int64_t *__restrict__ val_rowptr,
+    const int64_t *__restrict__ t0_rowptr, const int64_t *__restrict__ adjx_rowptr, PairDesc *__restrict__ desc,
+    int64_t *__restrict__ offs, int32_t *__restrict__ item_pair, int64_t item_cap, int64_t *__restrict__ ctl,
+    uint64_t *__restrict__ plan_lb) {
+    __shared__ int64_t wtot[S2_WAVES];
+    __shared__ int64_t s_base, s_blk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Logical block index = order of arrival: a block then only ever waits for blocks that are already running,
+    // whatever the dispatch order.  ctl[7] only ever grows and every launch on this control block draws exactly
+    // gridDim.x tickets (one batch size per control block), so ticket / gridDim.x is the launch number: it tags the
+    // chained-scan words of this launch (plan and run kernel), nothing is reset and nothing comes from the host --
+    // the same two launches can be replayed from a captured graph.
+    if (tid == 0) s_blk = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 7), 1ull);
+    __syncthreads();
+    const int64_t blk = s_blk % (int64_t)gridDim.x;
+    const uint32_t epoch = (uint32_t)((s_blk / (int64_t)gridDim.x) & ((1 << 22) - 1));
+    const int64_t k = blk * S2_THREADS + tid;
+    int64_t ub = 0;
+    if (k < bs) {
+        const int64_t a = batch[k], b = batch[batch_ld + k];
+        PairDesc d;
+        d.pad0 = d.pad1 = 0; d.pad2 = d.pad3 = 0;
+        if ((uint64_t)a >= (uint64_t)n_nodes || (uint64_t)b >= (uint64_t)n_nodes) {
+            atomicOr(reinterpret_cast<unsigned long long *>(ctl + 3), (unsigned long long)LPF_SELECT_ERR_NODE_RANGE);
+            d.ra0 = d.rb0 = d.pa0 = d.pb0 = d.ta0 = d.tb0 = d.xa0 = d.xb0 = 0;
+            d.dA = d.dB = d.nPa = d.nPb = d.nTa = d.nTb = d.dxA = d.dxB = 0;
+            d.a = d.b = 0;
+        } else {
+            d.ra0 = adj_rowptr[a]; d.dA = (int32_t)(adj_rowptr[a + 1] - d.ra0);
+            d.rb0 = adj_rowptr[b]; d.dB = (int32_t)(adj_rowptr[b + 1] - d.rb0);
+            d.pa0 = val_rowptr[a]; d.nPa = (int32_t)(val_rowptr[a + 1] - d.pa0);
+            d.pb0 = val_rowptr[b]; d.nPb = (int32_t)(val_rowptr[b + 1] - d.pb0);
+            d.ta0 = d.tb0 = 0; d.nTa = d.nTb = 0;
+            if (t0_rowptr) {
+                d.ta0 = t0_rowptr[a]; d.nTa = (int32_t)(t0_rowptr[a + 1] - d.ta0);
+                d.tb0 = t0_rowptr[b]; d.nTb = (int32_t)(t0_rowptr[b + 1] - d.tb0);
+            }
+            d.xa0 = d.ra0; d.xb0 = d.rb0; d.dxA = d.dA; d.dxB = d.dB;
+            if (adjx_rowptr) {
+                d.xa0 = adjx_rowptr[a]; d.dxA = (int32_t)(adjx_rowptr[a + 1] - d.xa0);
+                d.xb0 = adjx_rowptr[b]; d.dxB = (int32_t)(adjx_rowptr[b + 1] - d.xb0);
+            }
+            d.a = (int32_t)a; d.b = (int32_t)b;
+        }
+        ub = (int64_t)d.dA + d.dB + (d.nTa < d.nTb ? d.nTa : d.nTb);
+        if (ub == 0) ub = 1;  // every pair owns at least one slot: its owner writes the pair's segment starts
+        __builtin_memcpy(desc + k, &d, sizeof(PairDesc));  // (no type punning of the local struct)
+    }
+    // inclusive scan of ub inside the block, then the block's base through the chained scan
+    int64_t x = ub;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int64_t y = __shfl_up(x, dlt, 64);
+        if (lane >= dlt) x += y;
+    }
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    int64_t pre = 0, btot = 0;
+#pragma unroll
+    for (int w = 0; w < S2_WAVES; ++w) {
+        if (w < wave) pre += wtot[w];
+        btot += wtot[w];
+    }
+    if (tid == 0) s_base = (int64_t)lb_exclusive(plan_lb, blk, epoch, (uint64_t)btot);
+    __syncthreads();
+    const int64_t o = s_base + pre + x - ub;  // exclusive
+    if (k < bs) {
+        offs[k] = o;
+        // first pair of every item that starts inside this pair's slots
+        for (int64_t it = (o + S2_ITEM - 1) / S2_ITEM; it * S2_ITEM < o + ub; ++it) {
+            if (it < item_cap) item_pair[it] = (int32_t)k;
+            else atomicOr(reinterpret_cast<unsigned long long *>(ctl + 3), (unsigned long long)LPF_SELECT_ERR_ITEM_CAP);
+        }
+        if (k == bs - 1) {
+            const int64_t total = o + ub;
+            offs[bs] = total;
+            ctl[0] = total;
+            ctl[1] = (total + S2_ITEM - 1) / S2_ITEM;
+            ctl[2] = 0;  // ticket counter of the run kernel (stream order: the previous run kernel has finished)
+            ctl[8] = epoch;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- run
+struct RunArgs {
+    int64_t bs;
+    const PairDesc *desc;
+    const int64_t *offs;
+    const int32_t *item_pair;
+    int64_t item_cap;
+    int64_t *ctl;
+    uint64_t *run_lb;  // [3][item_cap]
+    const int32_t *adj_col;    // typing adjacency
+    const float *selfp;        // aligned with adj_col (indexed path) or NULL (general path)
+    const int32_t *adjx_col;   // unmasked adjacency (== adj_col when the typing adjacency is the unmasked one)
+    const int32_t *val_col;    // P1 rows (indexed) or raw PPR rows (general)
+    const float *val_val;
+    const int32_t *t0_col;
+    const float *t0_val;
+    float th_cn, th_1, th_n;
+    int32_t *type_ptr;         // [3][bs+1]
+    int4 *entries;             // [3][ent_cap]
+    int64_t ent_cap;
+};
+
+struct RunLds {
+    int32_t loc[S2_ITEM + 1];   // slot (relative to the item) at which pair pf + i starts
+    int32_t cand[S2_ITEM];      // node id in every slot: the adjacency runs double as searchable rows
+    float va[S2_ITEM], vb[S2_ITEM];  // emitted values of the kept slots
+    int16_t win[S2_ITEM];       // window index of the slot's pair
+    uint8_t code[S2_ITEM];      // 0 dropped, 1 cn, 2 one-hop, 3 >1-hop; bit 2: the one-hop node comes from N(b)
+    int32_t cnt[S2_ROUNDS * S2_WAVES][4];
+    int64_t base[3];
+    int64_t ticket;
+    int32_t n_pairs;
+};
+
+// Types one candidate slot (phase B of select_run_kernel).  own: P[own endpoint, node] from the aligned self-PPR
+// array (indexed path) or the T0 value (>1-hop slots).
+template <bool INDEXED>
+__device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, int64_t pf, int64_t c0, int n_here,
+                                             int l, float own_in, int &code, float &va, float &vb, bool &fromb) {
+    const int32_t x = L.cand[l];
+    const int w = L.win[l];
+    const PairDesc *d = A.desc + (pf + w);
+    const int dA = d->dA, dB = d->dB;
+    const int i = (int)((c0 + l) - A.offs[pf + w]);
+    const int s0 = L.loc[w];  // slot of the pair's first candidate (may lie before the item)
+    if (i < dA + dB) {
+        const bool from_a = i < dA;
+        // position of x in the OTHER endpoint's adjacency run: in LDS when that run lies inside the item
+        const int o_lo = from_a ? s0 + dA : s0, o_n = from_a ? dB : dA;
+        int j;
+        if (s0 > -(1 << 30) && o_lo >= 0 && o_lo + o_n <= n_here) j = s2_find(L.cand + o_lo, o_n, x);
+        else j = s2_find(A.adj_col + (from_a ? d->rb0 : d->ra0), o_n, x);
+        if (!from_a && j >= 0) return;  // a node of N(b) that is also in N(a) is emitted through N(a)
+        const bool cn = from_a && j >= 0;
+        const int nPa = d->nPa, nPb = d->nPb;
+        float own, other = 0.f;
+        if (INDEXED) {
+            own = own_in;
+            if (cn) {
+                other = A.selfp[d->rb0 + j];
+            } else if (s2_round_trip(own, false) >= A.th_1) {  // otherwise it is dropped anyway
+                const int64_t v0 = from_a ? d->pb0 : d->pa0;
+                const int idx = s2_find(A.val_col + v0, from_a ? nPb : nPa, x);
+                if (idx >= 0) other = A.val_val[v0 + idx];
+            }
+        } else {  // general path: both values from the raw PPR rows (absent entries read as 0)
+            const int64_t m0 = from_a ? d->pa0 : d->pb0, v0 = from_a ? d->pb0 : d->pa0;
+            const int im = s2_find(A.val_col + m0, from_a ? nPa : nPb, x);
+            own = im >= 0 ? A.val_val[m0 + im] : 0.f;
+            if (cn || s2_round_trip(own, false) >= A.th_1) {
+                const int idx = s2_find(A.val_col + v0, from_a ? nPb : nPa, x);
+                if (idx >= 0) other = A.val_val[v0 + idx];
+            }
+        }
+        const float pa = s2_round_trip(from_a ? own : other, cn);
+        const float pb = s2_round_trip(from_a ? other : own, cn);
+        const float th = cn ? A.th_cn : A.th_1;
+        const bool keep = pa >= th && pb >= th;
+        code = keep ? (cn ? 1 : 2) : 0;
+        va = pa; vb = pb; fromb = !from_a;
+        return;
+    }
+    // >1-hop: stored in both T0 rows (p > 0, round trip >= theta_n), adjacent to neither endpoint in the UNMASKED
+    // adjacency; the endpoints themselves may be selected (link_transformer.py:438-443)
+    const int nTa = d->nTa, nTb = d->nTb;
+    const bool walk_a = nTa <= nTb;
+    const float pw = own_in;
+    const float sw = __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f);
+    bool ok = pw > 0.f && sw >= A.th_n;
+    float so = 0.f;
+    if (ok) {
+        const int64_t o0 = walk_a ? d->tb0 : d->ta0;
+        const int idx = s2_find(A.t0_col + o0, walk_a ? nTb : nTa, x);
+        ok = idx >= 0;
+        if (ok) {
+            const float po = A.t0_val[o0 + idx];
+            so = __fsub_rn(__fadd_rn(po, 1.0f), 1.0f);
+            ok = po > 0.f && so >= A.th_n;
+        }
+    }
+    if (ok) {
+        int ja, jb;
+        if (INDEXED && s0 >= 0 && s0 + dA + dB <= n_here) {  // both adjacency runs are in LDS
+            ja = s2_find(L.cand + s0, dA, x);
+            jb = s2_find(L.cand + s0 + dA, dB, x);
+        } else {
+            ja = s2_find(A.adjx_col + d->xa0, d->dxA, x);
+            jb = s2_find(A.adjx_col + d->xb0, d->dxB, x);
+        }
+        ok = (ja & jb) < 0;  // both searches came back -1
+    }
+    code = ok ? 3 : 0;
+    va = walk_a ? sw : so;
+    vb = walk_a ? so : sw;
+}
+
+template <bool INDEXED>
+__global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A) {
+    __shared__ RunLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const int64_t total = A.ctl[0];
+    int64_t n_items = A.ctl[1];
+    if (n_items > A.item_cap) n_items = A.item_cap;
+    const int64_t bs = A.bs;
+    const uint32_t epoch = (uint32_t)A.ctl[8];  // launch number, written by the plan kernel
+
+    while (true) {
+        __syncthreads();  // the previous item's LDS image is no longer needed
+        if (tid == 0) {
+            L.ticket = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 2), 1ull);
+            L.n_pairs = 0;
+        }
+        __syncthreads();
+        const int64_t it = L.ticket;
+        if (it >= n_items) break;
+        const int64_t c0 = it * S2_ITEM;
+        const int n_here = (int)((total - c0) < S2_ITEM ? (total - c0) : S2_ITEM);
+        const int64_t pf = A.item_pair[it];
+
+        // ---- pair window: loc[i] = offs[pf + i] - c0 clamped to [-2^30, n_here]; pairs past the item read n_here
+        {
+            int mine = 0;
+#pragma unroll
+            for (int r = 0; r < S2_ROUNDS; ++r) {
+                const int i = tid + S2_THREADS * r;
+                int64_t v = n_here;
+                if (pf + i <= bs) v = A.offs[pf + i] - c0;
+                if (v > n_here) v = n_here;
+                if (v < -(1 << 30)) v = -(1 << 30);
+                L.loc[i] = (int32_t)v;
+                mine += (v < n_here) ? 1 : 0;
+            }
+            if (tid == 0) L.loc[S2_ITEM] = n_here;
+            mine += __shfl_xor(mine, 32, 64); mine += __shfl_xor(mine, 16, 64); mine += __shfl_xor(mine, 8, 64);
+            mine += __shfl_xor(mine, 4, 64); mine += __shfl_xor(mine, 2, 64); mine += __shfl_xor(mine, 1, 64);
+            if (lane == 0 && mine) atomicAdd(&L.n_pairs, mine);
+        }
+        __syncthreads();
+        const int np = L.n_pairs;  // pairs with at least one slot in this item (>= 1)
+
+        // ---- phase A: every thread identifies its slots and loads the candidate node (+ its own PPR value)
+        // Per-slot state lives in LDS (cand / meta) and the rounds are real loops: four copies of the typing code in
+        // one kernel body are what hipcc 7.2 miscompiled (see s2_find), and the per-round register arrays cost
+        // occupancy.
+        float cown[S2_ROUNDS];     // P[own endpoint, node] (indexed path) / T0 value (>1-hop slots)
+#pragma unroll
+        for (int r = 0; r < S2_ROUNDS; ++r) {
+            const int l = tid + S2_THREADS * r;
+            cown[r] = 0.f;
+            if (l < n_here) {
+                int lo = 0, hi = np;  // last window pair with loc <= l
+                while (lo + 1 < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (L.loc[mid] <= l) lo = mid; else hi = mid;
+                }
+                const int w = lo;
+                const PairDesc *d = A.desc + (pf + w);
+                const int64_t i64 = (c0 + l) - A.offs[pf + w];
+                const int dA = d->dA, dB = d->dB;
+                int32_t x = -1;
+                if (i64 < dA) {
+                    const int64_t e = d->ra0 + i64;
+                    x = A.adj_col[e];
+                    if (INDEXED) cown[r] = A.selfp[e];
+                } else if (i64 < (int64_t)dA + dB) {
+                    const int64_t e = d->rb0 + (i64 - dA);
+                    x = A.adj_col[e];
+                    if (INDEXED) cown[r] = A.selfp[e];
+                } else {
+                    const int nTa = d->nTa, nTb = d->nTb;
+                    const int nW = nTa < nTb ? nTa : nTb;
+                    const int64_t wi = i64 - dA - dB;
+                    if (wi < nW) {
+                        const int64_t e = (nTa <= nTb ? d->ta0 : d->tb0) + wi;
+                        x = A.t0_col[e];
+                        cown[r] = A.t0_val[e];
+                    }
+                }
+                L.cand[l] = x;
+                L.win[l] = (int16_t)w;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: type, look up the other endpoint's value, round trip, thresholds
+#pragma unroll 1
+        for (int r = 0; r < S2_ROUNDS; ++r) {
+            const int l = tid + S2_THREADS * r;
+            int code = 0;  // 0 dropped, 1 common neighbour, 2 one-hop, 3 >1-hop
+            float va = 0.f, vb = 0.f;
+            bool fromb = false;
+            const float ownv = r == 0 ? cown[0] : (r == 1 ? cown[1] : (r == 2 ? cown[2] : cown[3]));
+            if (l < n_here && L.cand[l] >= 0)
+                s2_type_slot<INDEXED>(A, L, pf, c0, n_here, l, ownv, code, va, vb, fromb);
+            L.code[l] = (uint8_t)(code | (fromb ? 4 : 0));
+            L.va[l] = va;
+            L.vb[l] = vb;
+            const uint64_t b0 = __ballot(code == 1), b1 = __ballot(code == 2), b2 = __ballot(code == 3);
+            if (lane == 0) {
+                int32_t *c = L.cnt[r * S2_WAVES + wave];
+                c[0] = __popcll(b0); c[1] = __popcll(b1); c[2] = __popcll(b2);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase C: ranks inside the item, then the item's base per type through the chained scan
+        if (tid < 3) {  // exclusive scan over the (round, wave) groups in slot order, then the chained scan
+            int run = 0;
+            for (int g = 0; g < S2_ROUNDS * S2_WAVES; ++g) {
+                const int v = L.cnt[g][tid];
+                L.cnt[g][tid] = run;
+                run += v;
+            }
+            L.base[tid] = (int64_t)lb_exclusive(A.run_lb + (int64_t)tid * A.item_cap, it, epoch, (uint64_t)run);
+        }
+        __syncthreads();
+
+        // ---- phase D: entries to their final place, segment starts of the pairs that begin here, totals
+#pragma unroll 1
+        for (int r = 0; r < S2_ROUNDS; ++r) {
+            const int l = tid + S2_THREADS * r;
+            const bool live = l < n_here;
+            const int cf = live ? L.code[l] : 0;
+            const int code = cf & 3;
+            const uint64_t b0 = __ballot(code == 1), b1 = __ballot(code == 2), b2 = __ballot(code == 3);
+            if (!live) continue;
+            const int32_t *gp = L.cnt[r * S2_WAVES + wave];
+            const int64_t rank0 = L.base[0] + gp[0] + __popcll(b0 & lt_mask);
+            const int64_t rank1 = L.base[1] + gp[1] + __popcll(b1 & lt_mask);
+            const int64_t rank2 = L.base[2] + gp[2] + __popcll(b2 & lt_mask);
+            const int64_t p = pf + L.win[l];
+            if (code) {
+                const int t = code - 1;
+                const int64_t dst = t == 0 ? rank0 : (t == 1 ? rank1 : rank2);
+                if (dst < A.ent_cap) {
+                    A.entries[(int64_t)t * A.ent_cap + dst] =
+                        make_int4((int32_t)((uint32_t)p | ((cf & 4) ? S2_FROM_B : 0u)), L.cand[l],
+                                  __float_as_int(L.va[l]), __float_as_int(L.vb[l]));
+                } else {
+                    atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + 3),
+                             (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
+                }
+            }
+            if (c0 + l == A.offs[p]) {  // first slot of the pair: its three segment starts
+                A.type_ptr[p] = (int32_t)rank0;
+                A.type_ptr[(bs + 1) + p] = (int32_t)rank1;
+                A.type_ptr[2 * (bs + 1) + p] = (int32_t)rank2;
+            }
+            if (c0 + l == total - 1) {
+                const int64_t t0 = rank0 + (code == 1), t1 = rank1 + (code == 2), t2 = rank2 + (code == 3);
+                A.type_ptr[bs] = (int32_t)t0;
+                A.type_ptr[(bs + 1) + bs] = (int32_t)t1;
+                A.type_ptr[2 * (bs + 1) + bs] = (int32_t)t2;
+                A.ctl[4] = t0; A.ctl[5] = t1; A.ctl[6] = t2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- export
+// Reference layout for callers that want it (compute_node_mask, attention weights, the module-by-module path):
+// all CN entries sorted by (pair, node), then all 1-hop, then all >1-hop (link_transformer.py:161-162), separate
+// arrays, int64 segment pointers, float count features.  One wavefront per pair.
+__global__ __launch_bounds__(256) void select_export_kernel(
+    int64_t bs, const int32_t *__restrict__ type_ptr, const int4 *__restrict__ entries, int64_t ent_cap,
+    int64_t *__restrict__ type_ptr64, float *__restrict__ counts_f, int64_t ldc, int want_t0,
+    int32_t *__restrict__ sel_pair, int32_t *__restrict__ sel_node, float *__restrict__ sel_pa,
+    float *__restrict__ sel_pb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    int64_t tot[3], obase[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        tot[t] = type_ptr[(int64_t)t * (bs + 1) + bs];
+        if (tot[t] > ent_cap) tot[t] = ent_cap;  // (overflow: the sticky error bit is set; stay inside the arrays)
+    }
+    obase[0] = 0; obase[1] = tot[0]; obase[2] = tot[0] + tot[1];
+    for (int64_t p = wave_id; p <= bs; p += n_waves) {
+        if (p == bs) {
+            if (lane < 3) type_ptr64[(int64_t)lane * (bs + 1) + bs] = tot[lane];
+            continue;
+        }
+        int64_t lo[3], n[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            lo[t] = type_ptr[(int64_t)t * (bs + 1) + p];
+            int64_t hi = type_ptr[(int64_t)t * (bs + 1) + p + 1];
+            if (lo[t] > tot[t]) lo[t] = tot[t];
+            if (hi > tot[t]) hi = tot[t];
+            n[t] = hi - lo[t];
+        }
+        if (lane < 3) type_ptr64[(int64_t)lane * (bs + 1) + p] = lane == 0 ? lo[0] : (lane == 1 ? lo[1] : lo[2]);
+        if (counts_f && lane == 0) {
+            float *c = counts_f + p * ldc;
+            c[0] = (float)n[0];
+            c[1] = (float)n[1];
+            if (want_t0) {
+                c[2] = (float)n[2];
+                c[3] = (float)(n[0] + n[1]);
+            } else {
+                c[2] = (float)(n[0] + n[1]);
+            }
+        }
+        // common neighbours and >1-hop nodes are already in node order
+#pragma unroll
+        for (int t = 0; t < 3; t += 2) {
+            const int4 *src = entries + (int64_t)t * ent_cap + lo[t];
+            for (int64_t i = lane; i < n[t]; i += 64) {
+                const int4 e = src[i];
+                const int64_t dst = obase[t] + lo[t] + i;
+                sel_pair[dst] = (int32_t)p;
+                sel_node[dst] = e.y;
+                sel_pa[dst] = __int_as_float(e.z);
+                sel_pb[dst] = __int_as_float(e.w);
+            }
+        }
+        // one-hop: kept nodes of N(a) (ascending), then kept nodes of N(b) (ascending, flagged); disjoint sets:
+        // final rank = own index + number of nodes of the other run below it
+        if (n[1] > 0) {
+            const int4 *src = entries + ent_cap + lo[1];
+            int64_t na = 0;
+            for (int64_t i0 = 0; i0 < n[1]; i0 += 64) {
+                const int64_t i = i0 + lane;
+                const bool isa = i < n[1] && !((uint32_t)src[i].x & S2_FROM_B);
+                na += __popcll(__ballot(isa));
+            }
+            const int64_t nb = n[1] - na;
+            for (int64_t i = lane; i < n[1]; i += 64) {
+                const int4 e = src[i];
+                int64_t r;
+                if (i < na) {
+                    int64_t l2 = 0, h2 = nb;
+                    while (l2 < h2) {
+                        const int64_t mid = (l2 + h2) >> 1;
+                        if (src[na + mid].y < e.y) l2 = mid + 1; else h2 = mid;
+                    }
+                    r = i + l2;
+                } else {
+                    int64_t l2 = 0, h2 = na;
+                    while (l2 < h2) {
+                        const int64_t mid = (l2 + h2) >> 1;
+                        if (src[mid].y < e.y) l2 = mid + 1; else h2 = mid;
+                    }
+                    r = (i - na) + l2;
+                }
+                const int64_t dst = obase[1] + lo[1] + r;
+                sel_pair[dst] = (int32_t)p;
+                sel_node[dst] = e.y;
+                sel_pa[dst] = __int_as_float(e.z);
+                sel_pb[dst] = __int_as_float(e.w);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t lpf_select_plan_blocks(int64_t bs) { return (bs + S2_THREADS - 1) / S2_THREADS; }
+
+extern "C" int lpf_select_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes,
+                               const int64_t *adj_rowptr, const int64_t *val_rowptr, const int64_t *t0_rowptr,
+                               const int64_t *adjx_rowptr, void *desc, int64_t *offs, int32_t *item_pair,
+                               int64_t item_cap, int64_t *ctl, uint64_t *plan_lb, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && batch && batch_ld >= bs && n_nodes > 0 && adj_rowptr && val_rowptr &&
+                desc && offs && item_pair && item_cap > 0 && ctl && plan_lb && lpf_aligned16(desc));
+    const int64_t nb = (bs + S2_THREADS - 1) / S2_THREADS;
+    if (nb > 2048) return LPF_ERR_UNSUPPORTED;  // the chained scan wants every block resident: split larger batches
+    hipLaunchKernelGGL(select_plan_kernel, dim3((unsigned)nb), dim3(S2_THREADS), 0, static_cast<hipStream_t>(stream), bs,
+                       batch, batch_ld, n_nodes, adj_rowptr, val_rowptr, t0_rowptr, adjx_rowptr,
+                       static_cast<PairDesc *>(desc), offs, item_pair, item_cap, ctl, plan_lb);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair,
+                              int64_t item_cap, int64_t *ctl, uint64_t *run_lb, const int32_t *adj_col, const float *adj_selfp, const int32_t *adjx_col,
+                              const int32_t *val_col, const float *val_val, const int32_t *t0_col,
+                              const float *t0_val, float th_cn, float th_1hop, float th_non1hop, int32_t *type_ptr,
+                              void *entries, int64_t ent_cap, int32_t grid_blocks, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && adj_col && val_col &&
+                val_val && type_ptr && entries && ent_cap > 0 && lpf_aligned16(entries) && lpf_aligned16(desc));
+    LPF_REQUIRE((t0_col == nullptr) == (t0_val == nullptr));
+    RunArgs a;
+    a.bs = bs; a.desc = static_cast<const PairDesc *>(desc); a.offs = offs; a.item_pair = item_pair;
+    a.item_cap = item_cap; a.ctl = ctl; a.run_lb = run_lb;
+    a.adj_col = adj_col; a.selfp = adj_selfp; a.adjx_col = adjx_col ? adjx_col : adj_col;
+    a.val_col = val_col; a.val_val = val_val; a.t0_col = t0_col; a.t0_val = t0_val;
+    a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop;
+    a.type_ptr = type_ptr; a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
+    int64_t blocks = grid_blocks > 0 ? grid_blocks : 2048;
+    if (blocks > item_cap) blocks = item_cap;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (adj_selfp) hipLaunchKernelGGL(select_run_kernel<true>, dim3((unsigned)blocks), dim3(S2_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(select_run_kernel<false>, dim3((unsigned)blocks), dim3(S2_THREADS), 0, s, a);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+extern "C" int lpf_select_export(int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
+                                 int64_t *type_ptr64, float *counts_f, int64_t ldc, int32_t want_t0,
+                                 int32_t *sel_pair, int32_t *sel_node, float *sel_pa, float *sel_pb, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && type_ptr64 && sel_pair && sel_node && sel_pa &&
+                sel_pb && (!counts_f || ldc >= (want_t0 ? 4 : 3)));
+    int64_t blocks = (bs + 1 + 3) / 4;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(select_export_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), bs,
+                       type_ptr, static_cast<const int4 *>(entries), ent_cap, type_ptr64, counts_f, ldc, (int)want_t0,
+                       sel_pair, sel_node, sel_pa, sel_pb);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -32,6 +32,14 @@ struct TailArgs {
     const float *wC, *bC; int NC;
     const float *wdot, *bdot;
     float *logit, *prob;
+    // merge mode (part != nullptr): stage A is not a GEMM but the merge of the per-type attention records written by
+    // lpf_pair_attention_fused_f32 -- out = sum_t e^{m_t - M} acc_t / (sum_t e^{m_t - M} l_t + 1e-16) + bias -- and the
+    // count features come from the int32 segment pointers of the selection
+    const float *part;              // [3][M][NA + 4]: acc[NA], m, l, -, -
+    const int32_t *type_ptr;        // [3][M + 1]
+    const float *att_bias;          // [NA]
+    const int64_t *sel_ctl;         // selection control block: word 3 != 0 => the batch did not fit, scores = NaN
+    int n_counts;
 };
 
 constexpr int tc_per_thread(int ntp) { return (ntp * 64 + TC_THREADS - 1) / TC_THREADS; }
@@ -139,7 +147,8 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
     f32x4 accA[TPWA];
 #pragma unroll
     for (int c = 0; c < TPWA; ++c) accA[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {
+    int seg_cnt[3] = {0, 0, 0};
+    if (A.part == nullptr) {
         const float *xa = A.x + mm * A.ldx;
         const int ngA = (A.KA + 15) >> 4;
         f32x4 wr[S::PA];
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
     }
     f32x4 wrB[S::PB];
     tc_load<S::PB>(wrB, A.wB, 0, tid);  // stage B's first weights fly during the epilogue
-    {
+    if (A.part == nullptr) {
         const int fbase = 16 * half * TPWA + 4 * q;
         f32x4 ad[TPWA];
 #pragma unroll
@@ -174,6 +183,48 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
         }
 #pragma unroll
         for (int c = 0; c < TPWA; ++c) accA[c] += (fbase + 16 * c < A.NA) ? ad[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+        // merge of the (up to three) per-type records of this pair: a type takes part iff its segment is non-empty
+        const int fbase = 16 * half * TPWA + 4 * q;
+        const int64_t rs = A.NA + 4;
+        float mt[3], lt[3], wt[3];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int32_t *tp = A.type_ptr + (int64_t)t * (A.M + 1) + mm;
+            seg_cnt[t] = tp[1] - tp[0];
+            mt[t] = -INFINITY; lt[t] = 0.f;
+            if (seg_cnt[t] > 0) {
+                const f32x4 h = *reinterpret_cast<const f32x4 *>(A.part + ((int64_t)t * A.M + mm) * rs + A.NA);
+                mt[t] = h[0]; lt[t] = h[1];
+            }
+            mx = fmaxf(mx, mt[t]);
+        }
+        float den = 1e-16f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            wt[t] = seg_cnt[t] > 0 ? __expf(mt[t] - mx) : 0.f;
+            den = fmaf(wt[t], lt[t], den);
+        }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int c = 0; c < TPWA; ++c) {
+            const int f0 = fbase + 16 * c;
+            if (f0 < A.NA) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(A.att_bias + f0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    if (seg_cnt[t] > 0) {
+                        const f32x4 r = *reinterpret_cast<const f32x4 *>(A.part + ((int64_t)t * A.M + mm) * rs + f0);
+                        v += r * (wt[t] * inv);
+                    }
+                }
+                accA[c] = v;
+            }
+        }
+    }
+    {
+        const int fbase = 16 * half * TPWA + 4 * q;
         tc_layernorm<TPWA>(accA, fbase, A.NA, A.lnA_g, A.lnA_b, half, q, my_x, peer_x, false);
 #pragma unroll
         for (int c = 0; c < TPWA; ++c) my_hid[(half * TPWA + c) * 64] = accA[c];
@@ -186,7 +237,14 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
     {
         // the appended k-group: the count features (4 floats per sample) in lane quarter 0, zeros elsewhere
         f32x4 tailv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (q == 0) tailv = *reinterpret_cast<const f32x4 *>(A.tail + mm * A.ldtail);
+        if (q == 0) {
+            if (A.part == nullptr) {
+                tailv = *reinterpret_cast<const f32x4 *>(A.tail + mm * A.ldtail);
+            } else {  // get_structure_cnts (link_transformer.py:340-356): n_cn, n_1hop, [n_non1hop,] n_cn + n_1hop
+                const float n0 = (float)seg_cnt[0], n1 = (float)seg_cnt[1], n2 = (float)seg_cnt[2];
+                tailv = A.n_counts == 4 ? (f32x4){n0, n1, n2, n0 + n1} : (f32x4){n0, n1, n0 + n1, 0.f};
+            }
+        }
 #pragma unroll
         for (int kg = 0; kg < NTPA + 1; ++kg) {
             f32x4 *lw = lds + buf * S::SLAB;
@@ -252,6 +310,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
         __syncthreads();
         if (live && q == 0 && half == 0) {
             d = d + *peer_x + A.bdot[0];
+            if (A.sel_ctl && A.sel_ctl[3] != 0) d = __builtin_nanf("");  // the batch did not fit the selection workspace
             if (A.logit) A.logit[m] = d;
             if (A.prob) A.prob[m] = 1.0f / (1.0f + expf(-d));
         }
@@ -262,9 +321,13 @@ template <int NTA, int NTB, int NTC>
 int tc_launch(const TailArgs &a, hipStream_t s) {
     constexpr size_t lds = TcShape<NTA, NTB, NTC>::BYTES;
     auto kern = tail_chain_kernel<NTA, NTB, NTC>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return LPF_ERR_LAUNCH;
+    static bool lds_set = false;  // (per instantiation; the attribute is sticky, one call is enough)
+    if (lds > 64 * 1024 && !lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return LPF_ERR_LAUNCH;
+        lds_set = true;
+    }
     const int64_t blocks = (a.M + 16 * TC_GROUPS - 1) / (16 * TC_GROUPS);
     if (blocks > 0x7fffffff) return LPF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TC_THREADS), lds, s, a);
@@ -290,12 +353,38 @@ extern "C" int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const 
                 lpf_aligned16(bB) && lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) &&
                 lpf_aligned16(w_dot));
     TailArgs a{M, G + D, ldg, 3 * D + 4, G, ldg, wA_packed, lnA_g, lnA_b, D, counts, ldc, wB_packed, bB, lnB_g,
-               lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob};
+               lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
+               nullptr, nullptr, nullptr, nullptr, n_counts};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);
         case 64: return tc_launch<4, 5, 8>(a, s);
         case 128: return tc_launch<8, 9, 16>(a, s);
         default: return LPF_ERR_UNSUPPORTED;  // D = 256: 32-tile score head, the per-layer chains are used instead
+    }
+}
+
+extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, const float *part,
+                                        const int32_t *type_ptr, const float *att_bias, const float *lnA_g,
+                                        const float *lnA_b, const float *wB_packed, const float *bB, const float *lnB_g,
+                                        const float *lnB_b, const float *r_e, int64_t ldre, const float *wC_packed,
+                                        const float *bC, const float *w_dot, const float *b_dot,
+                                        const int64_t *sel_ctl, float *logit, float *prob, void *stream) {
+    if (M == 0) return LPF_OK;
+    LPF_REQUIRE(M > 0 && part && type_ptr && att_bias && lnA_g && lnA_b && wB_packed && bB && lnB_g && lnB_b && r_e &&
+                wC_packed && bC && w_dot && b_dot && (logit || prob));
+    LPF_REQUIRE((n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D);
+    LPF_REQUIRE(lpf_aligned16(part) && lpf_aligned16(att_bias) && lpf_aligned16(r_e) && lpf_aligned16(wB_packed) &&
+                lpf_aligned16(wC_packed) && lpf_aligned16(lnA_g) && lpf_aligned16(lnA_b) && lpf_aligned16(bB) &&
+                lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
+    TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0, wB_packed, bB, lnB_g,
+               lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
+               part, type_ptr, att_bias, sel_ctl, n_counts};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (D) {
+        case 32: return tc_launch<2, 3, 4>(a, s);
+        case 64: return tc_launch<4, 5, 8>(a, s);
+        case 128: return tc_launch<8, 9, 16>(a, s);
+        default: return LPF_ERR_UNSUPPORTED;
     }
 }

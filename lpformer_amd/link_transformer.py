@@ -178,7 +178,8 @@ class DenseChain:
             o, pr, ldo = ptr(res), None, res.stride(0)
         with KernelTimer.span(self.tag):
             check(_lib.hip().lpf_dense_chain_f32(
-                m, in_mode, ptr(x), x.stride(0), ptr(batch), 0 if batch is None else batch.stride(0), k1,
+                m, in_mode, ptr(x), x.stride(0), ptr(batch), 0 if batch is None else batch.stride(0),
+                x.shape[0] if in_mode else 0, k1,
                 ptr(t["w1p"]), n1, ptr(t["b1"]), ptr(addend), 0 if addend is None else addend.stride(0),
                 ptr(t.get("ln_g")), ptr(t.get("ln_b")), FLAG_RELU if relu else 0, ptr(t.get("w2p")), n2,
                 ptr(t.get("b2")), o, ldo, pr, _stream(dev)), "lpf_dense_chain_f32")
@@ -225,7 +226,7 @@ class MLP(nn.Module):
             gathered = torch.empty(batch.shape[1], d, dtype=torch.float32, device=x.device)
             args = (ptr(gathered), d, None, 0) if in_mode == 1 else (None, 0, ptr(gathered), d)
             with KernelTimer.span("pair_gather"):
-                check(_lib.hip().lpf_pair_gather_f32(batch.shape[1], d, ptr(batch), batch.stride(0), ptr(x),
+                check(_lib.hip().lpf_pair_gather_f32(batch.shape[1], d, ptr(batch), batch.stride(0), x.shape[0], ptr(x),
                                                      x.stride(0), *args, _stream(x.device)), "lpf_pair_gather_f32")
             x = gathered
         h = x
@@ -392,6 +393,41 @@ class LinkTransformerLayer(nn.Module):
         self.post_att_norm = nn.LayerNorm(out_dim * train_args["num_heads"])
 
 
+class _SelectWorkspace:
+    """Per (stream, batch size) buffers of the selection kernels (include/lpformer_hip.h, "Selection, second
+    generation").  ``ctl`` and the chained-scan words persist across launches (epoch-tagged, never cleared)."""
+
+    def __init__(self, device, bs: int):
+        self.device, self.bs = device, bs
+        self.plan_blocks = int(_lib.hip().lpf_select_plan_blocks(bs))
+        self.ctl = torch.zeros(16, dtype=torch.int64, device=device)  # LPF_SELECT_CTL_WORDS
+        self.desc = torch.empty(16 * max(bs, 1), dtype=torch.int64, device=device)
+        self.offs = torch.empty(bs + 1, dtype=torch.int64, device=device)
+        self.plan_lb = torch.zeros(self.plan_blocks + 1, dtype=torch.int64, device=device)
+        self.type_ptr = torch.zeros(3 * (bs + 1), dtype=torch.int32, device=device)
+        self.item_cap = self.ent_cap = 0
+        self.item_pair = self.run_lb = self.entries = None
+        self.calibrated = False
+
+    def ensure(self, item_cap: int, ent_cap: int, shrink: bool = False):
+        if item_cap > self.item_cap:
+            self.item_cap = int(item_cap)
+            self.item_pair = torch.empty(self.item_cap, dtype=torch.int32, device=self.device)
+            self.run_lb = torch.zeros(3 * self.item_cap, dtype=torch.int64, device=self.device)
+        if ent_cap > self.ent_cap or (shrink and ent_cap < self.ent_cap // 2):
+            self.ent_cap = int(ent_cap)
+            self.entries = None  # release before allocating the new size
+            self.entries = torch.empty(3 * self.ent_cap * 4, dtype=torch.int32, device=self.device)
+
+    def read_status(self):
+        """(error bits, [n_cn, n_1hop, n_non1hop]) of the last batch; synchronises the current stream."""
+        v = self.ctl.tolist()
+        return int(v[3]), [int(v[4]), int(v[5]), int(v[6])]
+
+    def clear_errors(self):
+        self.ctl[3] = 0
+
+
 # ------------------------------------------------------------------------------------------ the model
 class LinkTransformer(nn.Module):
     """LPFormer link-representation model on MI355X.
@@ -466,6 +502,7 @@ class LinkTransformer(nn.Module):
         self.use_side_stream = True
         self._side = None
         self.use_tail_chain = True    # score_pairs: lpf_tail_chain_f32 instead of three dense-chain launches
+        self.use_fused_attention = True  # score_pairs: one-pass attention on the selection regions (D <= 128)
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self):
@@ -655,63 +692,138 @@ class LinkTransformer(nn.Module):
         return hit[2], hit[3]
 
     # ---------------------------------------------------------------------------------- selection
-    def _select(self, batch: torch.Tensor, test_set: bool, adj_mask=None):
-        """Runs the selection kernels; returns a dict of device arrays (type-major entries, reference order)."""
+    def _sel_ws(self, st, bs: int) -> "_SelectWorkspace":
+        key = ("sel2", st, bs)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = _SelectWorkspace(self.device, bs)
+        return ws
+
+    def _select_launch(self, ws, batch, graphs):
+        """The two selection launches (lpf_select_plan, lpf_select_run) on the current stream; no host sync."""
         lib, st = _lib.hip(), _stream(self.device)
+        adj, adjx, val, t0, selfp = graphs
         bs = batch.shape[1]
+        with KernelTimer.span("select_plan"):
+            check(lib.lpf_select_plan(bs, ptr(batch), batch.stride(0), self.num_nodes, ptr(adj.rowptr),
+                                      ptr(val.rowptr), ptr(t0.rowptr) if t0 is not None else None,
+                                      ptr(adjx.rowptr) if adjx is not adj else None, ptr(ws.desc), ptr(ws.offs),
+                                      ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl), ptr(ws.plan_lb), st),
+                  "lpf_select_plan")
+        with KernelTimer.span("select_run"):
+            check(lib.lpf_select_run(bs, ptr(ws.desc), ptr(ws.offs), ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl),
+                                     ptr(ws.run_lb), ptr(adj.col), ptr(selfp),
+                                     ptr(adjx.col) if adjx is not adj else None, ptr(val.col), ptr(val.val),
+                                     ptr(t0.col) if t0 is not None else None,
+                                     ptr(t0.val) if t0 is not None else None, float(self.thresh_cn),
+                                     float(self.thresh_1hop), float(self.thresh_non1hop), ptr(ws.type_ptr),
+                                     ptr(ws.entries), ws.ent_cap, 0, st), "lpf_select_run")
+
+    def _select_graphs(self, test_set: bool, adj_mask=None):
+        """(typing adjacency, unmasked adjacency, value rows, T0 rows or None, self-PPR or None) on the device."""
         ppr_obj, mask_obj = self._data_obj("ppr", test_set), self._data_obj("mask", test_set)
         ppr = self._device_graph("ppr", ppr_obj)
         adjx = self._device_graph("mask", mask_obj)
         adj = adjx if adj_mask is None else self._device_graph("mask", adj_mask)
-        want_t0 = self.mask == "all"
-        t0 = self._device_graph("t0", ppr_obj) if want_t0 else None
+        t0 = self._device_graph("t0", ppr_obj) if self.mask == "all" else None
         # Evaluation fast path: per-model indexes over the PPR matrix (self PPR aligned with the adjacency, one-hop
-        # prefiltered rows).  A caller-supplied adjacency override (training) takes the general kernel instead.
-        selfp = None
+        # prefiltered rows).  A caller-supplied adjacency override (training) looks values up in the raw PPR rows.
+        selfp, val = None, ppr
         if adj is adjx and self.use_select_index:
             selfp = self._self_ppr(mask_obj, ppr_obj, adjx, ppr)
-            ppr = self._device_graph("p1", ppr_obj)
+            val = self._device_graph("p1", ppr_obj)
+        return adj, adjx, val, t0, selfp
 
-        offs = self._workspace("select_offs", 2 * (bs + 1), torch.int64, st)
-        desc = self._workspace("select_desc", 16 * bs, torch.int64, st)
-        scratch = self._workspace("scan_scratch", 3 * ((bs + 255) // 256) + 3, torch.int64, st)
-        with KernelTimer.span("select_bound"):
-            check(lib.lpf_select_bound(bs, ptr(batch), batch.stride(0), ptr(adj.rowptr), ptr(ppr.rowptr),
-                                       ptr(t0.rowptr) if want_t0 else None, ptr(offs), ptr(desc), ptr(scratch), st),
-                  "lpf_select_bound")
-        # one 16-byte read-back sizes the staging area and the work-item table
-        nb = (bs + 255) // 256
-        cap, n_items = (int(v) for v in scratch[3 * nb:3 * nb + 2].tolist())
-        stage_node = self._workspace("stage_node", cap, torch.int32, st)
-        stage_pa = self._workspace("stage_pa", cap, torch.float32, st)
-        stage_pb = self._workspace("stage_pb", cap, torch.float32, st)
-        stage_cnt = self._workspace("stage_cnt", 4 * bs, torch.int32, st)
-        items = self._workspace("select_items", 16 * n_items, torch.int32, st)
-        with KernelTimer.span("select_nodes"):
-            check(lib.lpf_select_nodes(bs, n_items, ptr(offs), ptr(desc), ptr(items), ptr(adj.col), ptr(selfp),
-                                       ptr(adjx.rowptr), ptr(adjx.col), 1 if adj is adjx else 0, ptr(ppr.col),
-                                       ptr(ppr.val),
-                                       ptr(t0.col) if want_t0 else None, ptr(t0.val) if want_t0 else None,
-                                       float(self.thresh_cn), float(self.thresh_1hop), float(self.thresh_non1hop),
-                                       ptr(stage_node), ptr(stage_pa), ptr(stage_pb), ptr(stage_cnt), st),
-                  "lpf_select_nodes")
+    def _select_device(self, batch: torch.Tensor, test_set: bool, adj_mask=None) -> "_SelectWorkspace":
+        """Selection for the hot path: the result stays in the stream's workspace (per-type entry regions + int32
+        segment pointers), sized from earlier batches; nothing is read back.  A batch that does not fit raises the
+        sticky error bits in ``ws.ctl`` -- consumers clamp, the scores of such a batch come out as NaN, and
+        ``check_selection()`` (called by the evaluation sweep and by every API that synchronises anyway) grows the
+        workspace.  The first batch of a (stream, batch size) is sized exactly, with one synchronisation."""
+        st = _stream(self.device)
+        bs = batch.shape[1]
+        ws = self._sel_ws(st, bs)
+        graphs = self._select_graphs(test_set, adj_mask)
+        if not ws.calibrated:
+            # exact sizing, once (synchronises): the kernels count every selected entry even when the entry regions
+            # are too small to hold them, so one pass with token regions gives the totals
+            ws.ensure(item_cap=max(bs, 4096) + 16, ent_cap=16)
+            for _attempt in range(3):
+                self._select_launch(ws, batch, graphs)
+                items = int(ws.ctl[1].item())
+                err, tot = ws.read_status()
+                ws.clear_errors()
+                if err & _lib.SELECT_ERR_NODE_RANGE:
+                    raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
+                if not (err & _lib.SELECT_ERR_ITEM_CAP):
+                    break
+                ws.ensure(item_cap=2 * items + 16, ent_cap=16)
+            else:
+                raise _lib.LpfError("selection workspace could not be sized")
+            ws.ensure(item_cap=2 * items + 16, ent_cap=2 * max(tot) + 4096, shrink=True)
+            ws.calibrated = True
+        self._select_launch(ws, batch, graphs)
+        return ws
+
+    def check_selection(self, stream=None) -> bool:
+        """Synchronising check of the sticky selection status of ``stream`` (default: the current one).  Returns True
+        when every batch since the last check fitted its workspace; otherwise clears the status, marks the workspace
+        for re-sizing and returns False (the caller re-scores those batches).  Node ids out of range raise
+        IndexError."""
+        st = _stream(self.device) if stream is None else stream.cuda_stream
+        ok = True
+        for key, ws in list(self._ws.items()):
+            if not (isinstance(key, tuple) and key[0] == "sel2" and key[1] == st):
+                continue
+            err, _ = ws.read_status()
+            if err == 0:
+                continue
+            ok = False
+            ws.clear_errors()
+            if err & _lib.SELECT_ERR_NODE_RANGE:
+                raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
+            ws.calibrated = False   # re-size on the next batch
+        return ok
+
+    def _select(self, batch: torch.Tensor, test_set: bool, adj_mask=None):
+        """Selection in the REFERENCE layout (module-by-module path, compute_node_mask, attention weights): the two
+        selection launches, a status check (this path synchronises), then lpf_select_export.  Returns a dict of device
+        arrays (type-major entries sorted by (pair, node), int64 segment pointers, float count features)."""
+        lib, st = _lib.hip(), _stream(self.device)
+        bs = batch.shape[1]
+        want_t0 = self.mask == "all"
         ldf = _pad4(self.dim + self.count_dim)
         feats = torch.empty(bs, ldf, dtype=torch.float32, device=self.device)  # [att out | counts | pad]
         if ldf > self.dim + self.count_dim:
             feats[:, self.dim + self.count_dim:].zero_()  # the attention output and the counts are written below
         type_ptr = self._workspace("type_ptr", 3 * (bs + 1), torch.int64, st)
-        with KernelTimer.span("select_scan"):
-            check(lib.lpf_select_scan(bs, ptr(stage_cnt), ptr(type_ptr), feats.data_ptr() + 4 * self.dim, ldf,
-                                      1 if want_t0 else 0, ptr(scratch), st), "lpf_select_scan")
+        if bs == 0:
+            type_ptr[:3].zero_()
+            empty_i = torch.empty(0, dtype=torch.int32, device=self.device)
+            empty_f = torch.empty(0, dtype=torch.float32, device=self.device)
+            return {"bs": 0, "cap": 0, "type_ptr": type_ptr, "sel_pair": empty_i, "sel_node": empty_i,
+                    "sel_pa": empty_f, "sel_pb": empty_f, "feats": feats, "ldf": ldf}
+        for _attempt in range(3):
+            ws = self._select_device(batch, test_set, adj_mask)
+            err, tot = ws.read_status()
+            if err == 0:
+                break
+            ws.clear_errors()
+            if err & _lib.SELECT_ERR_NODE_RANGE:
+                raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
+            ws.calibrated = False  # did not fit: size again for this batch
+        else:
+            raise _lib.LpfError("selection workspace could not be sized")
+        cap = sum(tot)
         sel_pair = self._workspace("sel_pair", cap, torch.int32, st)
         sel_node = self._workspace("sel_node", cap, torch.int32, st)
         sel_pa = self._workspace("sel_pa", cap, torch.float32, st)
         sel_pb = self._workspace("sel_pb", cap, torch.float32, st)
-        with KernelTimer.span("select_compact"):
-            check(lib.lpf_select_compact(bs, ptr(desc), ptr(offs), ptr(stage_node), ptr(stage_pa), ptr(stage_pb),
-                                         ptr(stage_cnt), ptr(type_ptr), ptr(sel_pair), ptr(sel_node), ptr(sel_pa),
-                                         ptr(sel_pb), st), "lpf_select_compact")
-        return {"bs": bs, "cap": cap, "type_ptr": type_ptr, "sel_pair": sel_pair, "sel_node": sel_node,
+        with KernelTimer.span("select_export"):
+            check(lib.lpf_select_export(bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(type_ptr),
+                                        feats.data_ptr() + 4 * self.dim, ldf, 1 if want_t0 else 0, ptr(sel_pair),
+                                        ptr(sel_node), ptr(sel_pa), ptr(sel_pb), st), "lpf_select_export")
+        return {"bs": bs, "cap": max(cap, 1), "type_ptr": type_ptr, "sel_pair": sel_pair, "sel_node": sel_node,
                 "sel_pa": sel_pa, "sel_pb": sel_pb, "feats": feats, "ldf": ldf}
 
     def _prep_batch(self, batch) -> torch.Tensor:
@@ -784,7 +896,7 @@ class LinkTransformer(nn.Module):
             side = self._fork()
             with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
                 with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
-                    check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(y), y.stride(0), None, 0,
+                    check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0), None, 0,
                                                   ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
 
             s = self._select(batch, test_set, adj_mask)
@@ -910,11 +1022,44 @@ class LinkTransformer(nn.Module):
                 if ew._chain1.run(t, x_node, relu=True, batch=batch, in_mode=1, out=r[:, :d]) is None:
                     prod = torch.empty(bs, d, dtype=torch.float32, device=self.device)
                     with KernelTimer.span("pair_gather"):
-                        check(_lib.hip().lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), ptr(x_node),
+                        check(_lib.hip().lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), x_node.shape[0], ptr(x_node),
                                                              x_node.stride(0), ptr(prod), d, None, 0,
                                                              _stream(self.device)), "lpf_pair_gather_f32")
                     gemm(prod, ew._pads[0].get(ew.linears[0].weight), ew.linears[0].bias, out=r[:, :d])
                     layernorm_(r[:, :d], ew.norm.weight, ew.norm.bias, relu=True)
+            if d in (32, 64, 128) and self.use_tail_chain and self.use_fused_attention and bs > 0:
+                # hot path: 2 selection launches (nothing read back) -> one-pass attention -> merged dense tail
+                lib, st = _lib.hip(), _stream(self.device)
+                w = self._fold()
+                z, y = self._node_keys(x_node, w)
+                q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+                with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+                    with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
+                        check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0), None, 0,
+                                                      ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
+                ws = self._select_device(batch, test_set, adj_mask)
+                if side is not None:
+                    torch.cuda.current_stream(self.device).wait_stream(side)
+                rs = d + 4
+                units_cap = (ws.ent_cap + 15) // 16 + 1
+                part = self._workspace("att_part", 3 * bs * rs, torch.float32, st)
+                bnd = self._workspace("att_bnd", 3 * units_cap * 2 * rs, torch.float32, st)
+                uflag = self._workspace("att_uflag", 3 * units_cap, torch.int32, st)
+                with KernelTimer.span("pair_attention_fused"):
+                    check(lib.lpf_pair_attention_fused_f32(
+                        d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q),
+                        q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]), ptr(w["bfold"]),
+                        ptr(w["att"]), ptr(part), ptr(bnd), ptr(uflag), units_cap, st), "lpf_pair_attention_fused_f32")
+                tt = self._tail_tables(score_func, a, c)
+                res = torch.empty(bs, dtype=torch.float32, device=self.device)
+                with KernelTimer.span("tail_chain"):
+                    check(lib.lpf_tail_chain_merge_f32(
+                        bs, d, self.count_dim, ptr(part), ptr(ws.type_ptr), ptr(self.att_layers[0].att.bias),
+                        ptr(tt["lnA_g"]), ptr(tt["lnA_b"]), ptr(tt["wB"]), ptr(tt["bB"]), ptr(tt["lnB_g"]),
+                        ptr(tt["lnB_b"]), ptr(r), r.stride(0), ptr(tt["wC"]), ptr(tt["bC"]), ptr(tt["w_dot"]),
+                        ptr(tt["b_dot"]), ptr(ws.ctl), ptr(res) if logits else None, None if logits else ptr(res),
+                        st), "lpf_tail_chain_merge_f32")
+                return res
             if d in (32, 64, 128) and self.use_tail_chain:  # attention output + pairwise hidden + head: one launch
                 g, feats = self._pair_attention(batch, x_node, test_set, adj_mask, False, stop_after_gather=True)
                 tt = self._tail_tables(score_func, a, c)

@@ -218,3 +218,40 @@ def test_folded_score_path_matches_modules_and_oracle():
         assert (got_l - ref_l).abs().max().item() <= 2e-5 * max(1.0, ref_l.abs().max().item())
         sample, ref = _oracle_sample(model, score, data, args, batch, h, k=160)
         assert np.abs(got_l[:160].cpu().numpy() - ref["logit"]).max() <= 1e-4 * max(1.0, float(np.abs(ref["logit"]).max()))
+
+
+def test_step_replays_from_a_captured_graph():
+    """A whole scoring step (selection without read-back, one-pass attention, merged tail, side-stream branches) is
+    captured in a HIP graph once; replays on other batches give bitwise the scores of the eager path."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup("collab", scale=0.1, bs=4096)
+    h = model.propagate()
+    batches = [torch.from_numpy(D.sample_pairs(ei, n, 4096, seed=70 + i)).to(DEV) for i in range(4)]
+    scorer = lpformer_amd.GraphedScorer(model, score, h, batches[0], logits=True)
+    for b in batches + batches[:2]:
+        got = scorer(b).clone()
+        torch.cuda.synchronize()
+        want = model.score_pairs(b, h, score, logits=True)
+        assert torch.equal(got, want)
+    assert model.check_selection(scorer.stream)
+
+
+def test_selection_overflow_is_flagged_and_recovered():
+    """A batch with many more selected entries than the workspace was sized for: the scores come back as NaN (never
+    silently wrong), check_selection() reports it once, and the re-scored batch is right."""
+    cfg, n, ei, w, x, data, args, model, score, _ = _setup("collab", scale=0.05, bs=2048)
+    h = model.propagate()
+    rng = np.random.default_rng(0)
+    sparse = torch.from_numpy(rng.integers(0, n, size=(2, 2048))).to(DEV)            # random pairs: few entries
+    deg = np.diff(data["adj_mask"].rowptr)
+    hubs = np.argsort(deg)[-64:]
+    dense = torch.from_numpy(np.stack([rng.choice(hubs, 2048), rng.choice(hubs, 2048)])).to(DEV)  # hub pairs
+    model.score_pairs(sparse, h, score)                     # sizes the workspace for the sparse batch
+    assert model.check_selection()
+    bad = model.score_pairs(dense, h, score, logits=True)
+    torch.cuda.synchronize()
+    assert torch.isnan(bad).all()
+    assert not model.check_selection()                      # reported once, workspace marked for re-sizing
+    good = model.score_pairs(dense, h, score, logits=True)
+    assert model.check_selection() and torch.isfinite(good).all()
+    ref = score.logits(model.pair_features(dense, h))
+    assert (good - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())

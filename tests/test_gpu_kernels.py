@@ -179,7 +179,7 @@ def test_dense_chain_unsupported_shape_is_reported():
     dc = DenseChain("t")
     assert dc.run(dc.tables(w1, b1), x, relu=False) is None  # nt1 = 6 single layer is not built
     t = dc.tables(w1, b1)
-    rc = _lib.hip().lpf_dense_chain_f32(8, 0, _lib.ptr(x), 96, None, 0, 96, _lib.ptr(t["w1p"]), 96, _lib.ptr(t["b1"]),
+    rc = _lib.hip().lpf_dense_chain_f32(8, 0, _lib.ptr(x), 96, None, 0, 0, 96, _lib.ptr(t["w1p"]), 96, _lib.ptr(t["b1"]),
                                         None, 0, None, None, 0, None, 0, None, _lib.ptr(torch.empty(8, 96, device=DEV)),
                                         96, None, None)
     assert rc == -2
