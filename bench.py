@@ -90,6 +90,10 @@ def main():
                     help="keep the elementwise / q branches on the step's own stream (model.use_side_stream = False)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of K steps in total; the FIRST is `value`, min/median/max of all are reported")
+    ap.add_argument("--encoder", default="auto", choices=("auto", "replicated", "sharded"),
+                    help="N > 1: every rank runs the whole encoder, or rows are sharded with an all-gather per layer; "
+                         "auto = the cheaper one by lpformer_amd.dist.encoder_plan (measured encoder time and "
+                         "measured all-gather rate)")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
@@ -110,9 +114,25 @@ def main():
     torch.manual_seed(0)
     model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev).eval()
     score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
-    if world > 1:
-        model.set_row_shard(rank, world)
     model.use_side_stream = not args.no_side_stream
+    enc_plan = None
+    if world > 1:
+        # encoder layout: measure the whole encoder on one GPU (replicated mode) and the all-gather of an [N, D] fp32
+        # matrix on this process group, then take the cheaper layout (or the one asked for)
+        model.set_row_shard(rank, world, "replicated")
+        for _ in range(2):
+            model.propagate()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.propagate()
+        torch.cuda.synchronize()
+        enc1 = LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / 3, dev)
+        ag = LD.measure_allgather_gbps(n, d, dev)
+        enc_plan = LD.encoder_plan(enc1, n, d, cfg["gnn_layers"], world, ag)
+        enc_plan["allgather_gbps"] = round(ag, 1)
+        enc_plan["chosen"] = enc_plan["mode"] if args.encoder == "auto" else args.encoder
+        model.set_row_shard(rank, world, enc_plan["chosen"])
 
     # candidate batches resident in HBM before the timed region; distinct per rank
     batches_np = [D.sample_pairs(ei, n, bs, seed=1000 * rank + i) for i in range(args.batches)]
@@ -216,7 +236,7 @@ def main():
             # structural totals over the batches actually timed
             tp = [model.compute_node_mask(b) for b in batches]
             nsel = [sum(int(t[0].shape[1]) for t in sel if t is not None) for sel in tp]
-            p1 = model._device_graph("p1", data["ppr"]).to_host()
+            p1 = model._device_graph("p1", data["ppr"]).to_host_compact()
             stats = [dict(pair_stats(data, b, cfg["thresholds"], p1), slots=slot_count(model, bt))
                      for b, bt in zip(batches_np, batches)]
             used = [i % len(batches) for i in range(args.steps)]
@@ -360,8 +380,10 @@ def main():
                                    "encoder output resident",
                        "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
                        "streams": len(lanes), "spinup_s": args.spinup,
-                       "parallelism": f"pairs sharded x{world}, encoder row-sharded + all-gather" if world > 1
-                       else "single GPU"},
+                       "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']}" +
+                                       (" (rows + all-gather per layer)" if enc_plan["chosen"] == "sharded" else
+                                        " (every rank runs it, no exchange)")) if world > 1 else "single GPU",
+                       "encoder_plan": enc_plan},
             "encoder_ms": round(encoder_ms, 4), "value_incl_encoder": round(value_incl_encoder, 1),
             "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),
             "ms_per_step_repeats": {"n": len(rep_ms), "min": round(min(rep_ms), 4),

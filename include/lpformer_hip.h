@@ -177,6 +177,12 @@ int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t *offs, int
  *   val_*  the rows PPR values are looked up in: with adj_selfp (evaluation) the prefiltered one-hop index P1
  *          (lpf_ppr_filter_*, mode 1) -- the PPR of a node to its own neighbours then comes from adj_selfp --,
  *          without it (adjacency override of the training loop) the raw PPR matrix
+ *   BLOCKED indexes (the P1 rows with adj_selfp, the T0 rows always): every row padded to a multiple of 16 entries
+ *          (column INT32_MAX, value 0), row pointers counting padded entries, *_len[i] = real entries of row i,
+ *          *_cv = interleaved {int32 column, float value} pairs (a 16-entry block = one aligned 128-byte line),
+ *          *_skip[b] = last column of block b (+ 4 spare entries): a lookup reads the row's skip entries, then one
+ *          block that carries the value -- two memory round trips instead of a binary search plus a value load.
+ *          Without adj_selfp (adjacency override) val_col / val_val are the raw PPR rows, plain sorted CSR.
  *   adjx_* UNMASKED adjacency for the >1-hop exclusion (link_transformer.py:443); NULL = the typing adjacency
  * Result: per type t a dense region entries[t*ent_cap ..) of {pair | from_N(b) << 31, node, pa, pb} records ordered by
  * (pair, candidate slot); segment of pair k = [type_ptr[t*(bs+1)+k], type_ptr[t*(bs+1)+k+1]); the one-hop segment
@@ -189,14 +195,15 @@ int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t *offs, int
 #define LPF_SELECT_ERR_ENTRY_CAP 4  /* more selected entries of one type than ent_cap                              */
 int64_t lpf_select_plan_blocks(int64_t bs);
 int lpf_select_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const int64_t *adj_rowptr,
-                    const int64_t *val_rowptr, const int64_t *t0_rowptr, const int64_t *adjx_rowptr, void *desc,
-                    int64_t *offs, int32_t *item_pair, int64_t item_cap, int64_t *ctl, uint64_t *plan_lb,
-                    void *stream);
+                    const int64_t *val_rowptr, const int64_t *t0_rowptr, const int64_t *adjx_rowptr,
+                    const int32_t *val_len, const int32_t *t0_len, void *desc, int64_t *offs, int32_t *item_pair,
+                    int64_t item_cap, int64_t *ctl, uint64_t *plan_lb, void *stream);
 int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair, int64_t item_cap,
                    int64_t *ctl, uint64_t *run_lb, const int32_t *adj_col, const float *adj_selfp,
-                   const int32_t *adjx_col, const int32_t *val_col, const float *val_val, const int32_t *t0_col,
-                   const float *t0_val, float th_cn, float th_1hop, float th_non1hop, int32_t *type_ptr,
-                   void *entries, int64_t ent_cap, int32_t grid_blocks, void *stream);
+                   const int32_t *adjx_col, const int32_t *val_col, const float *val_val, const void *val_cv,
+                   const int32_t *val_skip, const void *t0_cv, const int32_t *t0_skip, float th_cn, float th_1hop,
+                   float th_non1hop, int32_t *type_ptr, void *entries, int64_t ent_cap, int32_t grid_blocks,
+                   void *stream);
 /* The reference's layout from the regions above: all CN entries sorted by (pair, node), then all 1-hop (the two runs
  * merged by node id), then all >1-hop (link_transformer.py:161-162); type_ptr64 int64[3*(bs+1)] relative per type,
  * counts_f the float count features of get_structure_cnts (:340-356), as lpf_select_scan wrote them. */
@@ -290,6 +297,21 @@ int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t *type_ptr,
                                  const float *pe_tab, const float *pe_stat, const float *wfold_packed,
                                  const float *bfold, const float *att, float *part, float *bnd, int32_t *uflag,
                                  int64_t units_cap, void *stream);
+
+/* bf16 THROUGHPUT MODE of lpf_pair_attention_fused_f32 (BASELINE.json config 2 names bf16 storage): the node table
+ * Z is stored in bf16 (half the gather bytes: rows of 2 D bytes staged by LDS-DMA) and Wfold_t h_e runs on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; h_e is generated in fp32 and rounded to bf16 as the A operand.
+ * Everything else (q, bfold, att, scores, softmax, records) stays fp32, and the selection never touches bf16, so the
+ * selected index sets are unchanged.  Logits differ from the fp32 path by the bf16 rounding of Z and Wfold (tests state
+ * the tolerance).
+ *   Z_bf16            bf16 [N, ldz] (ldz in elements, rows 16-byte aligned)
+ *   wfold_packed_bf16 bf16 [3][D/32][D/16][64][8]: element (t, c, s, lane, j) =
+ *                     Wfold_t[32 c + (lane & 31)][16 s + 8 (lane >> 5) + j]   (MFMA B-operand order) */
+int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                  int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q, int64_t ldq,
+                                  const float *pe_tab, const float *pe_stat, const void *wfold_packed_bf16,
+                                  const float *bfold, const float *att, float *part, float *bnd, int32_t *uflag,
+                                  int64_t units_cap, void *stream);
 
 /* lpf_tail_chain_f32 with the attention output taken from the records of lpf_pair_attention_fused_f32 instead of a
  * GEMM:  o = post_att_norm( sum_t e^{m_t-M} acc_t / (sum_t e^{m_t-M} l_t + 1e-16) + att_bias ), M = max_t m_t over the

@@ -22,16 +22,20 @@
 //     (same rescaling as the online softmax) into part[t][pair].  The tail kernel merges a pair's up to three type
 //     records, adds the bias and applies post_att_norm (tail_chain.hip, merge mode).
 // Bound: fp32 MFMA (2 D^2 FLOP per entry); one Z row + one 16-byte record read per entry.
+#include <stdlib.h>
+
 #include "pe_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // wavefronts per workgroup sharing one LDS copy of Wfold_t = one workgroup per CU at the register budget of the tile
-// code (NT = 1: 103 VGPRs -> 4 waves per SIMD; NT = 2, 4: 132 / 167 VGPRs -> 3 waves per SIMD)
+// code (NT = 1: 88 VGPRs -> 4 waves per SIMD; NT = 2: 142 -> 3; NT = 4: ~200 -> 2 -- at 3 waves per SIMD it spills 82
+// registers to scratch, which cost more than half of the kernel's time); LDS: 16 NT KB of Z rows per wavefront
 template <int NT>
-constexpr int pf_waves() { return NT == 1 ? 16 : 12; }
+constexpr int pf_waves() { return NT == 1 ? 16 : (NT == 2 ? 12 : 8); }
 constexpr uint32_t PF_PAIR_MASK = 0x7fffffffu;
 
 struct FusedArgs {
@@ -39,19 +43,21 @@ struct FusedArgs {
     const int32_t *type_ptr;   // [3][bs+1]
     const int4 *entries;       // [3][ent_cap]
     int64_t ent_cap;
-    const float *Z; int64_t ldz;
+    const float *Z; int64_t ldz;   // BF16 kernels: Z points at bf16 rows, ldz in bf16 elements
     const float *q; int64_t ldq;
     const float *pe_tab, *pe_stat, *wpk, *bfold, *att;
     float *part;               // [3][bs][D+4]
     float *bnd;                // [3][units_cap][2][D+4]
     int32_t *uflag;            // [3][units_cap]
     int64_t units_cap;
+    int dbg;                   // tuning aid (LPF_FUSED_DBG): bit 0 no Z/q loads, 1 no softmax/flush, 2 no MFMA, 3 no butterfly
 };
 
-template <int NT>
+template <int NT, bool BF16>
 __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t idx, int64_t cnt, const float4 *wl,
-                                           const float4 *tab, int lane) {
+                                           const float4 *tab, float *zbuf, int lane) {
     constexpr int D = 32 * NT, NSQ = D / 8, RS = D + 4;
+    constexpr int ZB = BF16 ? 2 : 4;  // bytes per Z element
     const int col = lane & 31, lh = lane >> 5;
     // tile entry fed to A-operand row `col`: half 0 of the accumulator rows {0-3, 8-11, ...} <- entries 0..15
     const int ja = 16 * ((col >> 2) & 1) + 4 * (col >> 3) + (col & 3);
@@ -82,75 +88,125 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-    // Touch every 128-byte line of the entry's Z row and of its pair's q row now (the two lanes that share an A row
-    // split the lines): the rows are consumed only after the MFMA loop, their HBM latency overlaps it.
+    // The tile's 32 Z rows go straight to this wavefront's LDS buffer (LDS-DMA: no VGPR destination), in unit order
+    // (row j = tile entry j): each instruction moves 64 x 16 bytes = RPI whole rows, lane l -> row m RPI + l / LPR,
+    // 16-byte piece l % LPR.  They are issued before the MFMA loop and land while it runs (the loop's first weight
+    // load waits for them -- hipcc's vmcnt is not selective --, the SIMD's other wavefront covers that); the epilogue
+    // then reads Z from LDS.  Register staging of the same rows is what limited the first version of this kernel:
+    // two rows in flight per lane at a time, every pair of entries waiting out a trip to the Infinity Cache.
     {
-        const float *zr = A.Z + (int64_t)node_a * A.ldz, *qr = A.q + (int64_t)pair_a * A.ldq;
-        constexpr int PFN = NT >= 2 ? NT / 2 : 1;
-        float pfz[PFN], pfq[PFN];
+        constexpr int LPR = D * ZB / 16, RPI = 64 / LPR;  // lanes per row (16 bytes each), rows per instruction
+        const char *zbase = reinterpret_cast<const char *>(A.Z);
 #pragma unroll
-        for (int i = 0; i < PFN; ++i) {
-            const int line = (lh * PFN + i) % NT;
-            pfz[i] = zr[32 * line];
-            pfq[i] = qr[32 * line];
+        for (int mi = 0; mi < 32 / RPI; ++mi) {
+            const int j = mi * RPI + lane / LPR;                                   // tile entry (unit order)
+            const int src = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);          // A row that carries entry j
+            const int nd = __shfl(node_a, src, 64);
+            const char *g = zbase + ((int64_t)nd * A.ldz) * ZB + 16 * (lane % LPR);
+            __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void *)(zbuf + mi * 256), 16, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < PFN; ++i) asm volatile("" ::"v"(pfz[i]), "v"(pfq[i]));
     }
 
-    const float4 *tb = tab + t * D + lh * (D / 2);
-#pragma unroll 1
-    for (int sq = 0; sq < NSQ; ++sq) {
-        float4 wb[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) wb[c] = wl[(c * NSQ + sq) * 64];
-        float h[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) h[u] = pe_hidden(tb[4 * sq + u], pa, pb, r_ab, r_ba);
-        // consecutive MFMAs go to different accumulators (no back-to-back dependency on one accumulator)
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[0], wb[c].x, acc[c], 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[1], wb[c].y, acc[c], 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[2], wb[c].z, acc[c], 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[3], wb[c].w, acc[c], 0, 0, 0);
-    }
-    // acc[c][i] = (Wfold_t h)[feature 32c + col] of unit entry i (tile entry 16 lh + i)
-
-    // ---- scores of the unit's 16 entries
+    // per-feature constants of the epilogue: requested before the MFMA loop, in registers when it ends
     float bf[NT], at[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         bf[c] = A.bfold[t * D + 32 * c + col];
         at[c] = A.att[32 * c + col];
     }
+    const float4 *tb = tab + t * D + lh * (D / 2);
+    if constexpr (!BF16) {
+#pragma unroll 1
+        for (int sq = 0; sq < ((A.dbg & 4) ? 0 : NSQ); ++sq) {
+            float4 wb[NT];  // (an explicit one-group-ahead prefetch of these measured slower: 198 vs 173 us)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) wb[c] = wl[(c * NSQ + sq) * 64];
+            float h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h[u] = pe_hidden(tb[4 * sq + u], pa, pb, r_ab, r_ba);
+            // consecutive MFMAs go to different accumulators (no back-to-back dependency on one accumulator)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[0], wb[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[1], wb[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[2], wb[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[3], wb[c].w, acc[c], 0, 0, 0);
+        }
+    } else {
+        // bf16 throughput mode: v_mfma_f32_32x32x16_bf16, fp32 accumulate.  K-step s covers k = 16 s .. 16 s + 15;
+        // lane (row, half) holds A[row][16 s + 8 half + j] = bf16(h_e[k]) and B[k][col] = bf16(Wfold_t[col][k]) from
+        // the bf16 image (element (t, c, s, lane, j) = Wfold_t[32 c + (lane & 31)][16 s + 8 (lane >> 5) + j]).
+        const float4 *tk = tab + t * D + 8 * lh;
+#pragma unroll 1
+        for (int ks = 0; ks < ((A.dbg & 4) ? 0 : D / 16); ++ks) {
+            bf16x8 wbb[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                wbb[c] = __builtin_bit_cast(bf16x8, wl[(c * (D / 16) + ks) * 64]);
+            bf16x8 ha;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ha[j] = (__bf16)pe_hidden(tk[16 * ks + j], pa, pb, r_ab, r_ba);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, wbb[c], acc[c], 0, 0, 0);
+        }
+    }
+    // acc[c][i] = (Wfold_t h)[feature 32c + col] of unit entry i (tile entry 16 lh + i)
+
+    // ---- scores of the unit's 16 entries.  Entries are taken two at a time (16 row pieces in flight per lane) with a
+    // scheduling barrier in between: left to itself the scheduler hoists all 128 loads of the unit and spills.
     float sc[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int src = 8 * (i >> 2) + 4 * lh + (i & 3);  // A row that carried this entry
-        const int nd = __shfl(node_a, src, 64), pr = __shfl(pair_a, src, 64);
-        const float *zr = A.Z + (int64_t)nd * A.ldz + col, *qr = A.q + (int64_t)pr * A.ldq + col;
-        float p = 0.f;
+    for (int i0 = 0; i0 < 16; i0 += 2) {
+        const float *qr[2];
+        float zv[2][NT], qv[2][NT];
 #pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            const float k = acc[c][i] + zr[32 * c] + bf[c];
-            acc[c][i] = k;
-            float x = k * qr[32 * c];
-            x = fmaxf(x, 0.2f * x);  // leaky_relu(x, 0.2)
-            p = fmaf(x, at[c], p);
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u;
+            const int r0 = 8 * (i >> 2) + (i & 3);  // A row that carried unit entry i of half 0 (half 1: r0 + 4)
+            const int pr0 = __builtin_amdgcn_readlane(pair_a, r0), pr1 = __builtin_amdgcn_readlane(pair_a, r0 + 4);
+            qr[u] = A.q + (int64_t)(lh ? pr1 : pr0) * A.ldq + col;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {  // the staged row of unit entry i (LDS)
+                if constexpr (BF16) {
+                    const uint16_t zb = reinterpret_cast<const uint16_t *>(zbuf)[(16 * lh + i) * D + 32 * c + col];
+                    zv[u][c] = (A.dbg & 1) ? 0.5f : __uint_as_float((uint32_t)zb << 16);
+                } else {
+                    zv[u][c] = (A.dbg & 1) ? 0.5f : zbuf[(16 * lh + i) * D + 32 * c + col];
+                }
+            }
         }
-        sc[i] = p;
-    }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {  // sum over the 32 feature lanes of the half (every lane gets the total)
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) qv[u][c] = (A.dbg & 1) ? 0.25f : qr[u][32 * c];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u;
+            float p = 0.f;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const float k = acc[c][i] + zv[u][c] + bf[c];
+                acc[c][i] = k;
+                float x = k * qv[u][c];
+                x = fmaxf(x, 0.2f * x);  // leaky_relu(x, 0.2)
+                p = fmaf(x, at[c], p);
+            }
+            sc[i] = p;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // sum over the 32 feature lanes of the half: rotations inside each 16-lane row (DPP), then the other row
+    if (!(A.dbg & 8))
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
         float v = sc[i];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
         v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 1, 64);
         sc[i] = v;
     }
 
@@ -158,6 +214,13 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     int64_t left = cnt - e0 - 16 * lh;
     const int nval = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
     if (nval == 0) return;
+    if (A.dbg & 2) {  // (tuning aid: keep the scores alive, skip the softmax walk)
+        float t_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t_ += sc[i] + acc[0][i];
+        if (t_ == 12345.678f) A.part[0] = t_;
+        return;
+    }
     const uint32_t smh = (uint32_t)(sm >> (4 * lh));     // start bit of unit entry i at position 8 (i>>2) + (i&3)
     const bool st0 = smh & 1u;
     // the unit's last entry: does its segment continue in the next unit?
@@ -172,7 +235,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     for (int c = 0; c < NT; ++c) o[c] = 0.f;
     bool first = true;
     int head = 0, cur_pair = 0;
-    auto flush = [&](int pair, bool cfront, bool cback) {
+    auto flush = [&](int pair, bool cfront, bool cback) __attribute__((always_inline)) {
         float *dst = (cfront && cback) ? part_t + (int64_t)pair * RS : bnd_u + (cfront ? RS : 0);
 #pragma unroll
         for (int c = 0; c < NT; ++c) dst[32 * c + col] = o[c];
@@ -182,7 +245,9 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     };
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int pair_i = __shfl(pair_a, 8 * (i >> 2) + 4 * lh + (i & 3), 64);  // (source rows are lanes 0-31)
+        const int pi0 = __builtin_amdgcn_readlane(pair_a, 8 * (i >> 2) + (i & 3));
+        const int pi1 = __builtin_amdgcn_readlane(pair_a, 8 * (i >> 2) + 4 + (i & 3));
+        const int pair_i = lh ? pi1 : pi0;
         if (i < nval) {
             const bool sti = (smh >> (8 * (i >> 2) + (i & 3))) & 1u;
             if (i > 0 && sti) {
@@ -205,45 +270,53 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     if (col == 0) A.uflag[(int64_t)t * A.units_cap + U] = head;
 }
 
-template <int NT>
+template <int NT, bool BF16>
 __global__ __launch_bounds__(64 * pf_waves<NT>()) void pair_fused_kernel(const FusedArgs A) {
-    constexpr int D = 32 * NT, NSQ = D / 8, IMG = NT * NSQ * 64;  // float4 per type
+    constexpr int D = 32 * NT, NSQ = D / 8;
+    constexpr int IMG = BF16 ? NT * (D / 16) * 64 : NT * NSQ * 64;  // 16-byte groups of the weight image per type
     constexpr int PF_WAVES = pf_waves<NT>();
+    // LDS: the first PE layer's table, then one 32-row Z buffer per wavefront.  The packed Wfold_t image (B operand)
+    // is streamed from L2: LDS cannot hold both it and the row buffers, and the rows are the part that pays.
     extern __shared__ __attribute__((aligned(16))) float4 pf_lds[];
-    float4 *wl = pf_lds, *tab = pf_lds + IMG;
+    float4 *tab = pf_lds;
     for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) tab[i] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
+    __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t n[3], tiles[3], groups[3];
+    float *zbuf = reinterpret_cast<float *>(pf_lds + 3 * D) + wave * (32 * D) / (BF16 ? 2 : 1);
+    int64_t n[3], tiles[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         n[t] = A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs];
         if (n[t] > A.ent_cap) n[t] = A.ent_cap;  // (overflow: flagged by the selection kernel, stay inside the region)
         tiles[t] = (n[t] + 31) >> 5;
-        groups[t] = (tiles[t] + PF_WAVES - 1) / PF_WAVES;
     }
-    int loaded = -1;
-    for (int64_t g = blockIdx.x; g < groups[0] + groups[1] + groups[2]; g += gridDim.x) {
+    const int64_t wave_id = (int64_t)blockIdx.x * PF_WAVES + wave, n_waves = (int64_t)gridDim.x * PF_WAVES;
+    // The two wavefronts of a SIMD (waves w and w + PF_WAVES/2) run the same program: started together they do their
+    // MFMA loops together (sharing the matrix pipe) and their epilogues together (leaving it idle).  The second half
+    // starts about half a tile late.
+    if (wave >= PF_WAVES / 2 && !(A.dbg & 16)) {
+        constexpr int UNITS = 12 * NT * NT;  // s_sleep units of 64 cycles
+#pragma unroll
+        for (int i = 0; i < UNITS / 96; ++i) __builtin_amdgcn_s_sleep(96);
+        if (UNITS % 96) __builtin_amdgcn_s_sleep(UNITS % 96);
+    }
+    for (int64_t tile = wave_id; tile < tiles[0] + tiles[1] + tiles[2]; tile += n_waves) {
         int t;
         int64_t idx;
-        if (g < groups[0]) { t = 0; idx = g * PF_WAVES + wave; }
-        else if (g < groups[0] + groups[1]) { t = 1; idx = (g - groups[0]) * PF_WAVES + wave; }
-        else { t = 2; idx = (g - groups[0] - groups[1]) * PF_WAVES + wave; }
-        if (t != loaded) {  // (the first pass also publishes tab)
-            __syncthreads();
-            const float4 *src = reinterpret_cast<const float4 *>(A.wpk) + (int64_t)t * IMG;
-            for (int i = threadIdx.x; i < IMG; i += blockDim.x) wl[i] = src[i];
-            loaded = t;
-            __syncthreads();
-        }
-        if (idx < tiles[t]) fused_tile<NT>(A, t, idx, n[t], wl + lane, tab, lane);
+        if (tile < tiles[0]) { t = 0; idx = tile; }
+        else if (tile < tiles[0] + tiles[1]) { t = 1; idx = tile - tiles[0]; }
+        else { t = 2; idx = tile - tiles[0] - tiles[1]; }
+        const float4 *wp = reinterpret_cast<const float4 *>(A.wpk) + (int64_t)t * IMG + lane;
+        fused_tile<NT, BF16>(A, t, idx, n[t], wp, tab, zbuf, lane);
     }
 }
 
-// Chains of boundary records -> part[t][pair].  G = D/4 lanes per unit (16 bytes of the record per lane).
-template <int G>
-__global__ __launch_bounds__(256) void pair_fused_fixup_kernel(const FusedArgs A, int D) {
-    const int RS = D + 4;
+// Chains of boundary records -> part[t][pair].  Eight lanes per unit (NV = D/32 16-byte pieces of a record per lane):
+// the walk along a chain is a few dependent reads, so what matters is how many chains are walked at once.
+template <int NV>
+__global__ __launch_bounds__(256) void pair_fused_fixup_kernel(const FusedArgs A) {
+    constexpr int D = 32 * NV, RS = D + 4, G = 8;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = tid / G, n_grp = (int64_t)gridDim.x * blockDim.x / G;
     const int lig = tid % G;
@@ -254,7 +327,9 @@ __global__ __launch_bounds__(256) void pair_fused_fixup_kernel(const FusedArgs A
         for (int64_t U = grp; U < n_units; U += n_grp) {
             if (A.uflag[(int64_t)t * A.units_cap + U] == 0) continue;
             const float *r1 = A.bnd + ((((int64_t)t * A.units_cap + U) * 2) + 1) * RS;
-            float4 o = reinterpret_cast<const float4 *>(r1)[lig];
+            float4 o[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) o[v] = reinterpret_cast<const float4 *>(r1)[lig + G * v];
             const float4 h1 = *reinterpret_cast<const float4 *>(r1 + D);
             float m = h1.x, l = h1.y;
             const int pair = __float_as_int(h1.z);
@@ -262,19 +337,25 @@ __global__ __launch_bounds__(256) void pair_fused_fixup_kernel(const FusedArgs A
             float more = 1.f;
             while (more != 0.f && nx < n_units) {
                 const float *r0 = A.bnd + (((int64_t)t * A.units_cap + nx) * 2) * RS;
-                const float4 o2 = reinterpret_cast<const float4 *>(r0)[lig];
+                float4 o2[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) o2[v] = reinterpret_cast<const float4 *>(r0)[lig + G * v];
                 const float4 h2 = *reinterpret_cast<const float4 *>(r0 + D);
                 const float mn = fmaxf(m, h2.x);
                 const float a = __expf(m - mn), b = __expf(h2.x - mn);
-                o.x = fmaf(o.x, a, o2.x * b); o.y = fmaf(o.y, a, o2.y * b);
-                o.z = fmaf(o.z, a, o2.z * b); o.w = fmaf(o.w, a, o2.w * b);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    o[v].x = fmaf(o[v].x, a, o2[v].x * b); o[v].y = fmaf(o[v].y, a, o2[v].y * b);
+                    o[v].z = fmaf(o[v].z, a, o2[v].z * b); o[v].w = fmaf(o[v].w, a, o2[v].w * b);
+                }
                 l = fmaf(l, a, h2.y * b);
                 m = mn;
                 more = h2.w;
                 ++nx;
             }
             float *dst = A.part + ((int64_t)t * A.bs + pair) * RS;
-            reinterpret_cast<float4 *>(dst)[lig] = o;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) reinterpret_cast<float4 *>(dst)[lig + G * v] = o[v];
             if (lig == 0) *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, h1.z, 0.f);
         }
     }
@@ -282,19 +363,26 @@ __global__ __launch_bounds__(256) void pair_fused_fixup_kernel(const FusedArgs A
 
 }  // namespace
 
-extern "C" int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
-                                            int64_t ent_cap, const float *Z, int64_t ldz, const float *q,
-                                            int64_t ldq, const float *pe_tab, const float *pe_stat,
-                                            const float *wfold_packed, const float *bfold, const float *att,
-                                            float *part, float *bnd, int32_t *uflag, int64_t units_cap,
-                                            void *stream) {
+namespace {
+
+template <bool BF16>
+int fused_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap, const void *Z,
+                 int64_t ldz, const float *q, int64_t ldq, const float *pe_tab, const float *pe_stat,
+                 const void *wfold_packed, const float *bfold, const float *att, float *part, float *bnd,
+                 int32_t *uflag, int64_t units_cap, void *stream) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && Z && q && pe_tab && pe_stat && wfold_packed &&
                 bfold && att && part && bnd && uflag && units_cap >= (ent_cap + 15) / 16);
     LPF_REQUIRE(ldz >= D && ldq >= D && lpf_aligned16(entries) && lpf_aligned16(pe_tab) &&
-                lpf_aligned16(wfold_packed) && lpf_aligned16(part) && lpf_aligned16(bnd));
-    FusedArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, Z, ldz, q, ldq, pe_tab, pe_stat,
-                wfold_packed, bfold, att, part, bnd, uflag, units_cap};
+                lpf_aligned16(wfold_packed) && lpf_aligned16(part) && lpf_aligned16(bnd) && lpf_aligned16(Z) &&
+                (ldz * (BF16 ? 2 : 4)) % 16 == 0);
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char *e = getenv("LPF_FUSED_DBG");
+        dbg = e ? atoi(e) : 0;
+    }
+    FusedArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), ldz, q, ldq,
+                pe_tab, pe_stat, static_cast<const float *>(wfold_packed), bfold, att, part, bnd, uflag, units_cap, dbg};
     hipStream_t s = static_cast<hipStream_t>(stream);
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -306,9 +394,10 @@ extern "C" int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t
     const int64_t tiles = (3 * ent_cap + 31) / 32 + 3;
 #define LPF_FUSED(NT)                                                                                              \
     do {                                                                                                           \
-        auto kern = pair_fused_kernel<NT>;                                                                         \
+        auto kern = pair_fused_kernel<NT, BF16>;                                                                   \
         constexpr int PF_WAVES = pf_waves<NT>();                                                                   \
-        const size_t lds = (size_t)(NT * (32 * NT / 8) * 64 + 3 * 32 * NT) * sizeof(float4);                       \
+        const size_t lds = (size_t)(3 * 32 * NT) * sizeof(float4) +                                                \
+                           (size_t)PF_WAVES * 32 * 32 * NT * (BF16 ? 2 : 4);                                       \
         static int per_cu = 0; /* resident workgroups per CU, queried once (also sets the LDS attribute) */        \
         if (per_cu == 0) {                                                                                         \
             if (lds > 64 * 1024 &&                                                                                 \
@@ -321,7 +410,7 @@ extern "C" int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t
                 occ = 1;                                                                                           \
             per_cu = occ;                                                                                          \
         }                                                                                                          \
-        int64_t groups = (tiles + PF_WAVES - 1) / PF_WAVES + 3;                                                    \
+        int64_t groups = (tiles + PF_WAVES - 1) / PF_WAVES;                                                        \
         if (groups > (int64_t)n_cu * per_cu) groups = (int64_t)n_cu * per_cu; /* persistent: one resident round */ \
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * PF_WAVES), lds, s, a);                          \
     } while (0)
@@ -329,14 +418,36 @@ extern "C" int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t
         case 32: LPF_FUSED(1); break;
         case 64: LPF_FUSED(2); break;
         case 128: LPF_FUSED(4); break;
-        default: return LPF_ERR_UNSUPPORTED;  // D = 256: the two-pass kernels (the packed image exceeds LDS)
+        default: return LPF_ERR_UNSUPPORTED;  // D = 256: the two-pass kernels
     }
 #undef LPF_FUSED
     switch (D) {
-        case 32: hipLaunchKernelGGL(pair_fused_fixup_kernel<8>, dim3(512), dim3(256), 0, s, a, (int)D); break;
-        case 64: hipLaunchKernelGGL(pair_fused_fixup_kernel<16>, dim3(512), dim3(256), 0, s, a, (int)D); break;
-        default: hipLaunchKernelGGL(pair_fused_fixup_kernel<32>, dim3(512), dim3(256), 0, s, a, (int)D); break;
+        case 32: hipLaunchKernelGGL(pair_fused_fixup_kernel<1>, dim3(1024), dim3(256), 0, s, a); break;
+        case 64: hipLaunchKernelGGL(pair_fused_fixup_kernel<2>, dim3(1024), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(pair_fused_fixup_kernel<4>, dim3(1024), dim3(256), 0, s, a); break;
     }
     LPF_CHECK_LAUNCH();
     return LPF_OK;
+}
+
+}  // namespace
+
+extern "C" int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                            int64_t ent_cap, const float *Z, int64_t ldz, const float *q,
+                                            int64_t ldq, const float *pe_tab, const float *pe_stat,
+                                            const float *wfold_packed, const float *bfold, const float *att,
+                                            float *part, float *bnd, int32_t *uflag, int64_t units_cap,
+                                            void *stream) {
+    return fused_launch<false>(D, bs, type_ptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab, pe_stat, wfold_packed, bfold,
+                               att, part, bnd, uflag, units_cap, stream);
+}
+
+extern "C" int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                             int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q,
+                                             int64_t ldq, const float *pe_tab, const float *pe_stat,
+                                             const void *wfold_packed_bf16, const float *bfold, const float *att,
+                                             float *part, float *bnd, int32_t *uflag, int64_t units_cap,
+                                             void *stream) {
+    return fused_launch<true>(D, bs, type_ptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab, pe_stat,
+                              wfold_packed_bf16, bfold, att, part, bnd, uflag, units_cap, stream);
 }

@@ -24,10 +24,15 @@
 // Placement is deterministic (it follows the flat slot order, not the schedule).  Inside a pair's one-hop segment
 // the kept nodes of N(a) come before those of N(b) (flag bit 31 of the pair word); lpf_select_export merges the two
 // runs by node id when a caller wants the reference's exact layout (compute_node_mask, attention weights).
+#include <stdlib.h>
+
 #include "lpf_common.h"
 
 // the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
 #pragma clang fp contract(off)
+
+// tuning aid (LPF_SEL_DBG bit 1): per-item s_memtime stamps of the run kernel's phases
+__device__ long long g_sel_stamps[16384 * 8];
 
 namespace {
 
@@ -36,6 +41,8 @@ constexpr int S2_THREADS = 256;
 constexpr int S2_ROUNDS = S2_ITEM / S2_THREADS;     // slots per thread
 constexpr int S2_WAVES = S2_THREADS / 64;
 constexpr uint32_t S2_FROM_B = 0x80000000u;
+constexpr int S2_WCACHE = 48;                       // window pairs whose descriptors are cached in LDS
+constexpr int S2_MIN_SLOTS = (S2_ITEM + S2_WCACHE - 2) / (S2_WCACHE - 1);  // => at most S2_WCACHE pairs per item
 
 struct alignas(16) PairDesc {
     int64_t ra0, rb0;              // adjacency rows (the typing adjacency: adj_mask or the caller's override)
@@ -65,24 +72,41 @@ __device__ __forceinline__ uint64_t lb_wait(const uint64_t *p, uint32_t epoch) {
     while (true) {
         const uint64_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(w >> 42) == epoch && ((w >> 40) & 3ull) != 0ull) return w;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
     }
 }
 
-// exclusive prefix of `own` over participants 0..k-1 (k = this participant); publishes own total, then the prefix
-__device__ __forceinline__ uint64_t lb_exclusive(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own) {
+__device__ __forceinline__ uint64_t lb_wave_sum(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor((unsigned long long)v, d, 64);
+    return v;
+}
+
+// Exclusive prefix of `own` over participants 0..k-1 (k = this participant), computed by ONE WHOLE WAVEFRONT (every
+// lane calls it with the same k / own and gets the result): publishes own total, looks back 64 predecessors at a
+// time -- a participant that already carries an inclusive prefix ends the walk --, then publishes its own prefix.
+// (A 256-word window, four words per lane, measured slower: 326 vs 250 us -- the polling traffic grows with it.)
+__device__ __forceinline__ uint64_t lb_exclusive(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own, int lane) {
     if (k == 0) {
-        lb_store(lb, epoch, 2, own);
+        if (lane == 0) lb_store(lb, epoch, 2, own);
         return 0;
     }
-    lb_store(lb + k, epoch, 1, own);
+    if (lane == 0) lb_store(lb + k, epoch, 1, own);
     uint64_t excl = 0;
-    for (int64_t j = k - 1;; --j) {  // participant 0 always publishes state 2
-        const uint64_t w = lb_wait(lb + j, epoch);
-        excl += w & LB_VAL_MASK;
-        if (((w >> 40) & 3ull) == 2ull) break;
+    for (int64_t j = k - 1;; j -= 64) {
+        const int64_t idx = j - lane;
+        uint64_t w = 2ull << 40;  // before participant 0: an inclusive prefix of value 0
+        if (idx >= 0) w = lb_wait(lb + idx, epoch);
+        const uint64_t pm = __ballot(((w >> 40) & 3ull) == 2ull);
+        const uint64_t v = w & LB_VAL_MASK;
+        if (pm) {  // nearest predecessor with an inclusive prefix: take it and the totals of the nearer ones
+            const int p = __ffsll((unsigned long long)pm) - 1;
+            excl += lb_wave_sum(lane <= p ? v : 0ull);
+            break;
+        }
+        excl += lb_wave_sum(v);
     }
-    lb_store(lb + k, epoch, 2, excl + own);
+    if (lane == 0) lb_store(lb + k, epoch, 2, excl + own);
     return excl;
 }
 
@@ -113,11 +137,61 @@ __device__ __forceinline__ int s2_find(const int32_t *a, int n, int32_t key) {
     return at_hi == key ? lo : -1;
 }
 
+// Lookup in a row of a BLOCKED index (lpformer_amd/graph.py BlockedIndex): rows padded to multiples of 16 entries
+// (padding column INT32_MAX), entries stored as interleaved {column, value} pairs so that a 16-entry block is one
+// aligned 128-byte line carrying the values with the columns, skip[b] = last column of block b.  Two memory round
+// trips instead of a binary search's eight plus one for the value: the row's skip entries (<= 16 of them in aligned
+// groups of four; longer rows are narrowed with a few scalar probes first) give the block, the block gives the value.
+__device__ __forceinline__ bool s2_lookup_blocked(const int2 *__restrict__ cv, const int32_t *__restrict__ skip,
+                                                  int64_t row0, int n_real, int32_t key, float &val) {
+    if (n_real <= 0) return false;
+    const int nb = (n_real + 15) >> 4;
+    int j = 0;
+    if (nb > 1) {
+        const int64_t sb = row0 >> 4;
+        int lo = 0, hi = nb;  // the first block whose last column is >= key lies in [lo, hi] (hi: none below nb)
+        while (hi - lo > 16) {
+            const int mid = (lo + hi) >> 1;
+            if (skip[sb + mid] < key) lo = mid + 1; else hi = mid;
+        }
+        const int64_t first = sb + lo, g0 = first & ~3ll;
+        const int off = (int)(first - g0), n_in = hi - lo;
+        int cnt = 0;
+        // five aligned groups cover any 16 entries; all five are requested together (reads past the row's entries
+        // stay inside the array -- it ends with spare entries -- and are masked out)
+        int4 v[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v[q] = *reinterpret_cast<const int4 *>(skip + g0 + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int b = 4 * q - off;  // index of v[q].x relative to `first`
+            cnt += (b + 0 >= 0 && b + 0 < n_in && v[q].x < key) + (b + 1 >= 0 && b + 1 < n_in && v[q].y < key) +
+                   (b + 2 >= 0 && b + 2 < n_in && v[q].z < key) + (b + 3 >= 0 && b + 3 < n_in && v[q].w < key);
+        }
+        j = lo + cnt;
+        if (j >= nb) return false;
+    }
+    const int4 *blk = reinterpret_cast<const int4 *>(cv + row0 + 16 * j);  // {col, val, col, val} x 8
+    bool eq = false;
+    int bits = 0;
+    int4 bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bv[q] = blk[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (bv[q].x == key) { eq = true; bits = bv[q].y; }
+        if (bv[q].z == key) { eq = true; bits = bv[q].w; }
+    }
+    val = __int_as_float(bits);
+    return eq;
+}
+
 // ------------------------------------------------------------------------------------------- plan
 __global__ __launch_bounds__(S2_THREADS) void select_plan_kernel(
     int64_t bs, const int64_t *__restrict__ batch, int64_t batch_ld, int64_t n_nodes,
     const int64_t *__restrict__ adj_rowptr, const int64_t *__restrict__ val_rowptr,
-    const int64_t *__restrict__ t0_rowptr, const int64_t *__restrict__ adjx_rowptr, PairDesc *__restrict__ desc,
+    const int64_t *__restrict__ t0_rowptr, const int64_t *__restrict__ adjx_rowptr,
+    const int32_t *__restrict__ val_len, const int32_t *__restrict__ t0_len, PairDesc *__restrict__ desc,
     int64_t *__restrict__ offs, int32_t *__restrict__ item_pair, int64_t item_cap, int64_t *__restrict__ ctl,
     uint64_t *__restrict__ plan_lb) {
     __shared__ int64_t wtot[S2_WAVES];
@@ -146,12 +220,13 @@ __global__ __launch_bounds__(S2_THREADS) void select_plan_kernel(
         } else {
             d.ra0 = adj_rowptr[a]; d.dA = (int32_t)(adj_rowptr[a + 1] - d.ra0);
             d.rb0 = adj_rowptr[b]; d.dB = (int32_t)(adj_rowptr[b + 1] - d.rb0);
-            d.pa0 = val_rowptr[a]; d.nPa = (int32_t)(val_rowptr[a + 1] - d.pa0);
-            d.pb0 = val_rowptr[b]; d.nPb = (int32_t)(val_rowptr[b + 1] - d.pb0);
+            // (blocked indexes carry their real row lengths separately: the row pointers count padded entries)
+            d.pa0 = val_rowptr[a]; d.nPa = val_len ? val_len[a] : (int32_t)(val_rowptr[a + 1] - d.pa0);
+            d.pb0 = val_rowptr[b]; d.nPb = val_len ? val_len[b] : (int32_t)(val_rowptr[b + 1] - d.pb0);
             d.ta0 = d.tb0 = 0; d.nTa = d.nTb = 0;
             if (t0_rowptr) {
-                d.ta0 = t0_rowptr[a]; d.nTa = (int32_t)(t0_rowptr[a + 1] - d.ta0);
-                d.tb0 = t0_rowptr[b]; d.nTb = (int32_t)(t0_rowptr[b + 1] - d.tb0);
+                d.ta0 = t0_rowptr[a]; d.nTa = t0_len ? t0_len[a] : (int32_t)(t0_rowptr[a + 1] - d.ta0);
+                d.tb0 = t0_rowptr[b]; d.nTb = t0_len ? t0_len[b] : (int32_t)(t0_rowptr[b + 1] - d.tb0);
             }
             d.xa0 = d.ra0; d.xb0 = d.rb0; d.dxA = d.dA; d.dxB = d.dB;
             if (adjx_rowptr) {
@@ -161,7 +236,11 @@ __global__ __launch_bounds__(S2_THREADS) void select_plan_kernel(
             d.a = (int32_t)a; d.b = (int32_t)b;
         }
         ub = (int64_t)d.dA + d.dB + (d.nTa < d.nTb ? d.nTa : d.nTb);
-        if (ub == 0) ub = 1;  // every pair owns at least one slot: its owner writes the pair's segment starts
+        // Every pair owns at least S2_MIN_SLOTS slots (the surplus ones hold no candidate): the owner of the first
+        // writes the pair's segment starts, and an item of S2_ITEM slots then never spans more than S2_WCACHE pairs,
+        // so all its descriptors sit in LDS -- items made of hundreds of one-neighbour pairs were the slow ones, and
+        // in a chained scan everything behind a slow item waits for it.
+        if (ub < S2_MIN_SLOTS) ub = S2_MIN_SLOTS;
         __builtin_memcpy(desc + k, &d, sizeof(PairDesc));  // (no type punning of the local struct)
     }
     // inclusive scan of ub inside the block, then the block's base through the chained scan
@@ -179,7 +258,10 @@ __global__ __launch_bounds__(S2_THREADS) void select_plan_kernel(
         if (w < wave) pre += wtot[w];
         btot += wtot[w];
     }
-    if (tid == 0) s_base = (int64_t)lb_exclusive(plan_lb, blk, epoch, (uint64_t)btot);
+    if (wave == 0) {
+        const int64_t base = (int64_t)lb_exclusive(plan_lb, blk, epoch, (uint64_t)btot, lane);
+        if (lane == 0) s_base = base;
+    }
     __syncthreads();
     const int64_t o = s_base + pre + x - ub;  // exclusive
     if (k < bs) {
@@ -212,14 +294,17 @@ struct RunArgs {
     const int32_t *adj_col;    // typing adjacency
     const float *selfp;        // aligned with adj_col (indexed path) or NULL (general path)
     const int32_t *adjx_col;   // unmasked adjacency (== adj_col when the typing adjacency is the unmasked one)
-    const int32_t *val_col;    // P1 rows (indexed) or raw PPR rows (general)
+    const int32_t *val_col;    // general path: raw PPR rows (plain sorted CSR)
     const float *val_val;
-    const int32_t *t0_col;
-    const float *t0_val;
+    const int2 *val_cv;        // indexed path: P1 index, blocked {column, value} layout
+    const int32_t *val_skip;
+    const int2 *t0_cv;         // T0 index, blocked layout (both paths)
+    const int32_t *t0_skip;
     float th_cn, th_1, th_n;
     int32_t *type_ptr;         // [3][bs+1]
     int4 *entries;             // [3][ent_cap]
     int64_t ent_cap;
+    int dbg;                   // tuning aid (LPF_SEL_DBG): bit 0 = no chained scan (placement is then wrong)
 };
 
 struct RunLds {
@@ -228,11 +313,38 @@ struct RunLds {
     float va[S2_ITEM], vb[S2_ITEM];  // emitted values of the kept slots
     int16_t win[S2_ITEM];       // window index of the slot's pair
     uint8_t code[S2_ITEM];      // 0 dropped, 1 cn, 2 one-hop, 3 >1-hop; bit 2: the one-hop node comes from N(b)
+    PairDesc dsc[S2_WCACHE];    // descriptors of the first window pairs (one coalesced copy per item)
     int32_t cnt[S2_ROUNDS * S2_WAVES][4];
     int64_t base[3];
     int64_t ticket;
     int32_t n_pairs;
 };
+
+// Descriptor fields of window pair w in registers: from the LDS cache (first S2_WCACHE pairs of the window) or from
+// global memory.  Only what a caller uses is actually loaded.
+struct PairLite {
+    int64_t ra0, rb0, pa0, pb0, ta0, tb0, xa0, xb0;
+    int dA, dB, nPa, nPb, nTa, nTb, dxA, dxB;
+};
+__device__ __forceinline__ PairLite s2_pair(const RunArgs &A, const RunLds &L, int64_t pf, int w) {
+    PairLite p;
+#define S2_COPY(src)                                                                                       \
+    p.ra0 = (src).ra0; p.rb0 = (src).rb0; p.pa0 = (src).pa0; p.pb0 = (src).pb0; p.ta0 = (src).ta0;         \
+    p.tb0 = (src).tb0; p.xa0 = (src).xa0; p.xb0 = (src).xb0; p.dA = (src).dA; p.dB = (src).dB;             \
+    p.nPa = (src).nPa; p.nPb = (src).nPb; p.nTa = (src).nTa; p.nTb = (src).nTb; p.dxA = (src).dxA;         \
+    p.dxB = (src).dxB
+    if (w < S2_WCACHE) { S2_COPY(L.dsc[w]); }
+    else { const PairDesc *d = A.desc + (pf + w); S2_COPY(*d); }
+#undef S2_COPY
+    return p;
+}
+
+// slot index inside pair (window index w) of item slot l
+__device__ __forceinline__ int64_t s2_slot_in_pair(const RunArgs &A, const RunLds &L, int64_t pf, int64_t c0, int w,
+                                                   int l) {
+    const int s0 = L.loc[w];
+    return s0 > -(1 << 30) ? (int64_t)(l - s0) : (c0 + l) - A.offs[pf + w];  // (clamped only ~2^30 slots back)
+}
 
 // Types one candidate slot (phase B of select_run_kernel).  own: P[own endpoint, node] from the aligned self-PPR
 // array (indexed path) or the T0 value (>1-hop slots).
@@ -241,9 +353,9 @@ __device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, 
                                              int l, float own_in, int &code, float &va, float &vb, bool &fromb) {
     const int32_t x = L.cand[l];
     const int w = L.win[l];
-    const PairDesc *d = A.desc + (pf + w);
-    const int dA = d->dA, dB = d->dB;
-    const int i = (int)((c0 + l) - A.offs[pf + w]);
+    const PairLite d = s2_pair(A, L, pf, w);
+    const int dA = d.dA, dB = d.dB;
+    const int i = (int)s2_slot_in_pair(A, L, pf, c0, w, l);
     const int s0 = L.loc[w];  // slot of the pair's first candidate (may lie before the item)
     if (i < dA + dB) {
         const bool from_a = i < dA;
@@ -251,26 +363,25 @@ __device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, 
         const int o_lo = from_a ? s0 + dA : s0, o_n = from_a ? dB : dA;
         int j;
         if (s0 > -(1 << 30) && o_lo >= 0 && o_lo + o_n <= n_here) j = s2_find(L.cand + o_lo, o_n, x);
-        else j = s2_find(A.adj_col + (from_a ? d->rb0 : d->ra0), o_n, x);
+        else j = s2_find(A.adj_col + (from_a ? d.rb0 : d.ra0), o_n, x);
         if (!from_a && j >= 0) return;  // a node of N(b) that is also in N(a) is emitted through N(a)
         const bool cn = from_a && j >= 0;
-        const int nPa = d->nPa, nPb = d->nPb;
         float own, other = 0.f;
         if (INDEXED) {
             own = own_in;
             if (cn) {
-                other = A.selfp[d->rb0 + j];
+                other = A.selfp[d.rb0 + j];
             } else if (s2_round_trip(own, false) >= A.th_1) {  // otherwise it is dropped anyway
-                const int64_t v0 = from_a ? d->pb0 : d->pa0;
-                const int idx = s2_find(A.val_col + v0, from_a ? nPb : nPa, x);
-                if (idx >= 0) other = A.val_val[v0 + idx];
+                float v;
+                if (s2_lookup_blocked(A.val_cv, A.val_skip, from_a ? d.pb0 : d.pa0, from_a ? d.nPb : d.nPa, x, v))
+                    other = v;
             }
         } else {  // general path: both values from the raw PPR rows (absent entries read as 0)
-            const int64_t m0 = from_a ? d->pa0 : d->pb0, v0 = from_a ? d->pb0 : d->pa0;
-            const int im = s2_find(A.val_col + m0, from_a ? nPa : nPb, x);
+            const int64_t m0 = from_a ? d.pa0 : d.pb0, v0 = from_a ? d.pb0 : d.pa0;
+            const int im = s2_find(A.val_col + m0, from_a ? d.nPa : d.nPb, x);
             own = im >= 0 ? A.val_val[m0 + im] : 0.f;
             if (cn || s2_round_trip(own, false) >= A.th_1) {
-                const int idx = s2_find(A.val_col + v0, from_a ? nPb : nPa, x);
+                const int idx = s2_find(A.val_col + v0, from_a ? d.nPb : d.nPa, x);
                 if (idx >= 0) other = A.val_val[v0 + idx];
             }
         }
@@ -284,18 +395,15 @@ __device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, 
     }
     // >1-hop: stored in both T0 rows (p > 0, round trip >= theta_n), adjacent to neither endpoint in the UNMASKED
     // adjacency; the endpoints themselves may be selected (link_transformer.py:438-443)
-    const int nTa = d->nTa, nTb = d->nTb;
-    const bool walk_a = nTa <= nTb;
+    const bool walk_a = d.nTa <= d.nTb;
     const float pw = own_in;
     const float sw = __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f);
     bool ok = pw > 0.f && sw >= A.th_n;
     float so = 0.f;
     if (ok) {
-        const int64_t o0 = walk_a ? d->tb0 : d->ta0;
-        const int idx = s2_find(A.t0_col + o0, walk_a ? nTb : nTa, x);
-        ok = idx >= 0;
+        float po;
+        ok = s2_lookup_blocked(A.t0_cv, A.t0_skip, walk_a ? d.tb0 : d.ta0, walk_a ? d.nTb : d.nTa, x, po);
         if (ok) {
-            const float po = A.t0_val[o0 + idx];
             so = __fsub_rn(__fadd_rn(po, 1.0f), 1.0f);
             ok = po > 0.f && so >= A.th_n;
         }
@@ -306,8 +414,8 @@ __device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, 
             ja = s2_find(L.cand + s0, dA, x);
             jb = s2_find(L.cand + s0 + dA, dB, x);
         } else {
-            ja = s2_find(A.adjx_col + d->xa0, d->dxA, x);
-            jb = s2_find(A.adjx_col + d->xb0, d->dxB, x);
+            ja = s2_find(A.adjx_col + d.xa0, d.dxA, x);
+            jb = s2_find(A.adjx_col + d.xb0, d.dxB, x);
         }
         ok = (ja & jb) < 0;  // both searches came back -1
     }
@@ -331,36 +439,38 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
         __syncthreads();  // the previous item's LDS image is no longer needed
         if (tid == 0) {
             L.ticket = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 2), 1ull);
-            L.n_pairs = 0;
         }
         __syncthreads();
         const int64_t it = L.ticket;
         if (it >= n_items) break;
+        const bool stamp = (A.dbg & 2) && tid == 0 && it < 16384;
+        if (stamp) g_sel_stamps[it * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
         const int64_t c0 = it * S2_ITEM;
         const int n_here = (int)((total - c0) < S2_ITEM ? (total - c0) : S2_ITEM);
         const int64_t pf = A.item_pair[it];
 
-        // ---- pair window: loc[i] = offs[pf + i] - c0 clamped to [-2^30, n_here]; pairs past the item read n_here
-        {
-            int mine = 0;
-#pragma unroll
-            for (int r = 0; r < S2_ROUNDS; ++r) {
-                const int i = tid + S2_THREADS * r;
-                int64_t v = n_here;
-                if (pf + i <= bs) v = A.offs[pf + i] - c0;
-                if (v > n_here) v = n_here;
-                if (v < -(1 << 30)) v = -(1 << 30);
-                L.loc[i] = (int32_t)v;
-                mine += (v < n_here) ? 1 : 0;
-            }
-            if (tid == 0) L.loc[S2_ITEM] = n_here;
-            mine += __shfl_xor(mine, 32, 64); mine += __shfl_xor(mine, 16, 64); mine += __shfl_xor(mine, 8, 64);
-            mine += __shfl_xor(mine, 4, 64); mine += __shfl_xor(mine, 2, 64); mine += __shfl_xor(mine, 1, 64);
-            if (lane == 0 && mine) atomicAdd(&L.n_pairs, mine);
+        // ---- pair window: loc[i] = offs[pf + i] - c0 clamped to [-2^30, n_here]; pairs past the item read n_here.
+        //      (every pair owns >= S2_MIN_SLOTS slots, so the window holds at most S2_WCACHE pairs)
+        if (tid < 64) {
+            int64_t v = n_here;
+            if (pf + tid <= bs) v = A.offs[pf + tid] - c0;
+            if (v > n_here) v = n_here;
+            if (v < -(1 << 30)) v = -(1 << 30);
+            L.loc[tid] = (int32_t)v;
+            const int cntp = __popcll(__ballot(v < n_here));
+            if (tid == 0) L.n_pairs = cntp;
         }
         __syncthreads();
         const int np = L.n_pairs;  // pairs with at least one slot in this item (>= 1)
+        {   // descriptors of the first window pairs -> LDS (one coalesced copy; every slot reads them several times)
+            const int n4 = (np < S2_WCACHE ? np : S2_WCACHE) * 8;
+            const int4 *src = reinterpret_cast<const int4 *>(A.desc + pf);
+            int4 *dst = reinterpret_cast<int4 *>(L.dsc);
+            for (int i = tid; i < n4; i += S2_THREADS) dst[i] = src[i];
+        }
+        __syncthreads();
 
+        if (stamp) g_sel_stamps[it * 8 + 1] = (long long)__builtin_amdgcn_s_memtime();
         // ---- phase A: every thread identifies its slots and loads the candidate node (+ its own PPR value)
         // Per-slot state lives in LDS (cand / meta) and the rounds are real loops: four copies of the typing code in
         // one kernel body are what hipcc 7.2 miscompiled (see s2_find), and the per-round register arrays cost
@@ -377,26 +487,25 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
                     if (L.loc[mid] <= l) lo = mid; else hi = mid;
                 }
                 const int w = lo;
-                const PairDesc *d = A.desc + (pf + w);
-                const int64_t i64 = (c0 + l) - A.offs[pf + w];
-                const int dA = d->dA, dB = d->dB;
+                const PairLite d = s2_pair(A, L, pf, w);
+                const int64_t i64 = s2_slot_in_pair(A, L, pf, c0, w, l);
+                const int dA = d.dA, dB = d.dB;
                 int32_t x = -1;
                 if (i64 < dA) {
-                    const int64_t e = d->ra0 + i64;
+                    const int64_t e = d.ra0 + i64;
                     x = A.adj_col[e];
                     if (INDEXED) cown[r] = A.selfp[e];
                 } else if (i64 < (int64_t)dA + dB) {
-                    const int64_t e = d->rb0 + (i64 - dA);
+                    const int64_t e = d.rb0 + (i64 - dA);
                     x = A.adj_col[e];
                     if (INDEXED) cown[r] = A.selfp[e];
                 } else {
-                    const int nTa = d->nTa, nTb = d->nTb;
-                    const int nW = nTa < nTb ? nTa : nTb;
+                    const int nW = d.nTa < d.nTb ? d.nTa : d.nTb;
                     const int64_t wi = i64 - dA - dB;
                     if (wi < nW) {
-                        const int64_t e = (nTa <= nTb ? d->ta0 : d->tb0) + wi;
-                        x = A.t0_col[e];
-                        cown[r] = A.t0_val[e];
+                        const int2 cv = A.t0_cv[(d.nTa <= d.nTb ? d.ta0 : d.tb0) + wi];
+                        x = cv.x;
+                        cown[r] = __int_as_float(cv.y);
                     }
                 }
                 L.cand[l] = x;
@@ -405,6 +514,7 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
         }
         __syncthreads();
 
+        if (stamp) g_sel_stamps[it * 8 + 2] = (long long)__builtin_amdgcn_s_memtime();
         // ---- phase B: type, look up the other endpoint's value, round trip, thresholds
 #pragma unroll 1
         for (int r = 0; r < S2_ROUNDS; ++r) {
@@ -426,18 +536,26 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
         }
         __syncthreads();
 
+        if (stamp) g_sel_stamps[it * 8 + 3] = (long long)__builtin_amdgcn_s_memtime();
         // ---- phase C: ranks inside the item, then the item's base per type through the chained scan
-        if (tid < 3) {  // exclusive scan over the (round, wave) groups in slot order, then the chained scan
-            int run = 0;
-            for (int g = 0; g < S2_ROUNDS * S2_WAVES; ++g) {
-                const int v = L.cnt[g][tid];
-                L.cnt[g][tid] = run;
-                run += v;
+        if (wave < 3) {  // wavefront t: exclusive scan of type t over the (round, wave) groups in slot order, then the
+                         // chained scan over the items
+            constexpr int NG = S2_ROUNDS * S2_WAVES;
+            const int v = lane < NG ? L.cnt[lane][wave] : 0;
+            int x = v;
+#pragma unroll
+            for (int dlt = 1; dlt < NG; dlt <<= 1) {
+                const int y = __shfl_up(x, dlt, 64);
+                if (lane >= dlt) x += y;
             }
-            L.base[tid] = (int64_t)lb_exclusive(A.run_lb + (int64_t)tid * A.item_cap, it, epoch, (uint64_t)run);
+            if (lane < NG) L.cnt[lane][wave] = x - v;
+            const int run = __shfl(x, NG - 1, 64);
+            const int64_t base = (A.dbg & 1) ? it * 64 : (int64_t)lb_exclusive(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)run, lane);
+            if (lane == 0) L.base[wave] = base;
         }
         __syncthreads();
 
+        if (stamp) { g_sel_stamps[it * 8 + 4] = (long long)__builtin_amdgcn_s_memtime(); g_sel_stamps[it * 8 + 6] = n_here; g_sel_stamps[it * 8 + 7] = np; }
         // ---- phase D: entries to their final place, segment starts of the pairs that begin here, totals
 #pragma unroll 1
         for (int r = 0; r < S2_ROUNDS; ++r) {
@@ -464,7 +582,7 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
                              (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
                 }
             }
-            if (c0 + l == A.offs[p]) {  // first slot of the pair: its three segment starts
+            if (l == L.loc[L.win[l]]) {  // first slot of the pair: its three segment starts
                 A.type_ptr[p] = (int32_t)rank0;
                 A.type_ptr[(bs + 1) + p] = (int32_t)rank1;
                 A.type_ptr[2 * (bs + 1) + p] = (int32_t)rank2;
@@ -477,6 +595,7 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
                 A.ctl[4] = t0; A.ctl[5] = t1; A.ctl[6] = t2;
             }
         }
+        if (stamp) g_sel_stamps[it * 8 + 5] = (long long)__builtin_amdgcn_s_memtime();
     }
 }
 
@@ -583,7 +702,8 @@ extern "C" int64_t lpf_select_plan_blocks(int64_t bs) { return (bs + S2_THREADS 
 
 extern "C" int lpf_select_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes,
                                const int64_t *adj_rowptr, const int64_t *val_rowptr, const int64_t *t0_rowptr,
-                               const int64_t *adjx_rowptr, void *desc, int64_t *offs, int32_t *item_pair,
+                               const int64_t *adjx_rowptr, const int32_t *val_len, const int32_t *t0_len, void *desc,
+                               int64_t *offs, int32_t *item_pair,
                                int64_t item_cap, int64_t *ctl, uint64_t *plan_lb, void *stream) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && batch && batch_ld >= bs && n_nodes > 0 && adj_rowptr && val_rowptr &&
@@ -591,28 +711,41 @@ extern "C" int lpf_select_plan(int64_t bs, const int64_t *batch, int64_t batch_l
     const int64_t nb = (bs + S2_THREADS - 1) / S2_THREADS;
     if (nb > 2048) return LPF_ERR_UNSUPPORTED;  // the chained scan wants every block resident: split larger batches
     hipLaunchKernelGGL(select_plan_kernel, dim3((unsigned)nb), dim3(S2_THREADS), 0, static_cast<hipStream_t>(stream), bs,
-                       batch, batch_ld, n_nodes, adj_rowptr, val_rowptr, t0_rowptr, adjx_rowptr,
+                       batch, batch_ld, n_nodes, adj_rowptr, val_rowptr, t0_rowptr, adjx_rowptr, val_len, t0_len,
                        static_cast<PairDesc *>(desc), offs, item_pair, item_cap, ctl, plan_lb);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
 
 extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair,
-                              int64_t item_cap, int64_t *ctl, uint64_t *run_lb, const int32_t *adj_col, const float *adj_selfp, const int32_t *adjx_col,
-                              const int32_t *val_col, const float *val_val, const int32_t *t0_col,
-                              const float *t0_val, float th_cn, float th_1hop, float th_non1hop, int32_t *type_ptr,
-                              void *entries, int64_t ent_cap, int32_t grid_blocks, void *stream) {
+                              int64_t item_cap, int64_t *ctl, uint64_t *run_lb, const int32_t *adj_col,
+                              const float *adj_selfp, const int32_t *adjx_col, const int32_t *val_col,
+                              const float *val_val, const void *val_cv, const int32_t *val_skip, const void *t0_cv,
+                              const int32_t *t0_skip, float th_cn, float th_1hop,
+                              float th_non1hop, int32_t *type_ptr, void *entries, int64_t ent_cap,
+                              int32_t grid_blocks, void *stream) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && adj_col && val_col &&
-                val_val && type_ptr && entries && ent_cap > 0 && lpf_aligned16(entries) && lpf_aligned16(desc));
-    LPF_REQUIRE((t0_col == nullptr) == (t0_val == nullptr));
+    LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && adj_col && type_ptr &&
+                entries && ent_cap > 0 && lpf_aligned16(entries) && lpf_aligned16(desc));
+    // indexed path: self-PPR + blocked P1 index; general path: raw PPR rows
+    LPF_REQUIRE(adj_selfp ? (val_cv && val_skip && lpf_aligned16(val_cv) && lpf_aligned16(val_skip))
+                          : (val_col && val_val));
+    LPF_REQUIRE((t0_cv == nullptr) == (t0_skip == nullptr) && lpf_aligned16(t0_cv) && lpf_aligned16(t0_skip));
     RunArgs a;
     a.bs = bs; a.desc = static_cast<const PairDesc *>(desc); a.offs = offs; a.item_pair = item_pair;
     a.item_cap = item_cap; a.ctl = ctl; a.run_lb = run_lb;
     a.adj_col = adj_col; a.selfp = adj_selfp; a.adjx_col = adjx_col ? adjx_col : adj_col;
-    a.val_col = val_col; a.val_val = val_val; a.t0_col = t0_col; a.t0_val = t0_val;
+    a.val_col = val_col; a.val_val = val_val;
+    a.val_cv = static_cast<const int2 *>(val_cv); a.val_skip = val_skip;
+    a.t0_cv = static_cast<const int2 *>(t0_cv); a.t0_skip = t0_skip;
     a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop;
     a.type_ptr = type_ptr; a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char *e = getenv("LPF_SEL_DBG");
+        dbg = e ? atoi(e) : 0;
+    }
+    a.dbg = dbg;
     int64_t blocks = grid_blocks > 0 ? grid_blocks : 2048;
     if (blocks > item_cap) blocks = item_cap;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -620,6 +753,12 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     else hipLaunchKernelGGL(select_run_kernel<false>, dim3((unsigned)blocks), dim3(S2_THREADS), 0, s, a);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
+}
+
+extern "C" int lpf_select_debug_stamps(long long *dst_host, int64_t n_items) {
+    if (n_items > 16384) n_items = 16384;
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_sel_stamps), (size_t)n_items * 8 * sizeof(long long)) == hipSuccess
+               ? LPF_OK : LPF_ERR_LAUNCH;
 }
 
 extern "C" int lpf_select_export(int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,

@@ -85,3 +85,41 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def measure_allgather_gbps(n: int, d: int, device, reps: int = 3, group=None) -> float:
+    """Payload rate (GB/s of the assembled [n, d] fp32 matrix per second) of ``allgather_rows`` on this process
+    group, measured: the one number the encoder plan needs."""
+    import time
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return float("inf")
+    rank = dist.get_rank(group)
+    lo, hi = row_range(n, world, rank)
+    local = torch.zeros(hi - lo, d, dtype=torch.float32, device=device)
+    allgather_rows(local, n, group)  # warm-up (connection set-up)
+    if local.is_cuda:
+        torch.cuda.synchronize()
+    dist.barrier(group)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        allgather_rows(local, n, group)
+    if local.is_cuda:
+        torch.cuda.synchronize()
+    dt = max_over_ranks((time.perf_counter() - t0) / reps, device if local.is_cuda else None)
+    return n * d * 4 / dt / 1e9
+
+
+def encoder_plan(encoder_ms_one_gpu: float, n: int, d: int, n_layers: int, world: int, allgather_gbps: float) -> dict:
+    """Cost model for the encoder on ``world`` GPUs (all times in ms):
+         replicated: every rank runs the whole encoder            = encoder_ms_one_gpu
+         sharded:    1/world of the work + (L + 1) all-gathers of an [n, d] fp32 matrix
+                                                                   = encoder_ms_one_gpu / world + (L + 1) * bytes / rate
+    Returns both estimates and the cheaper mode.  The reference has no counterpart (single device)."""
+    if world <= 1:
+        return {"mode": "replicated", "replicated_ms": encoder_ms_one_gpu, "sharded_ms": encoder_ms_one_gpu,
+                "allgather_ms": 0.0}
+    ag_ms = n * d * 4 / (allgather_gbps * 1e9) * 1e3
+    sharded = encoder_ms_one_gpu / world + (n_layers + 1) * ag_ms
+    return {"mode": "sharded" if sharded < encoder_ms_one_gpu else "replicated",
+            "replicated_ms": encoder_ms_one_gpu, "sharded_ms": sharded, "allgather_ms": ag_ms}

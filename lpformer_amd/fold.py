@@ -62,7 +62,8 @@ def fold_attention(state: dict, dim: int, n_types: int, prefix="att_layers.0.att
         "w_rx": w_rx.astype(np.float32), "b_r": b_r.astype(np.float32),
         "w_l": w_l.astype(np.float32), "b_l": b_l.astype(np.float32), "b_l2": (2.0 * b_l).astype(np.float32),
         "att": att.astype(np.float32), "wfold": wfold.astype(np.float32), "bfold": bfold.astype(np.float32),
-        "wfold_packed": pack_wfold(wfold.astype(np.float32)), "wcat": np.ascontiguousarray(wcat.astype(np.float32)),
+        "wfold_packed": pack_wfold(wfold.astype(np.float32)),
+        "wfold_packed_bf16": pack_wfold_bf16(wfold.astype(np.float32)).view(np.int16), "wcat": np.ascontiguousarray(wcat.astype(np.float32)),
     }
 
 
@@ -75,6 +76,22 @@ def pack_wfold(wfold: np.ndarray) -> np.ndarray:
     w = wfold.reshape(3, nt, 32, 2, nsq, 4)          # t, c, row, half, sq, u
     w = w.transpose(0, 1, 4, 3, 2, 5)                 # t, c, sq, half, row, u
     return np.ascontiguousarray(w.reshape(3, nt, nsq, 64, 4))
+
+
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 bit patterns (uint16), round to nearest even."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def pack_wfold_bf16(wfold: np.ndarray) -> np.ndarray:
+    """[3, D, D] (out, in) -> uint16 [3, D/32, D/16, 64, 8]: element (t, c, s, lane, j) =
+    bf16(wfold[t, 32c + (lane & 31), 16s + 8 (lane >> 5) + j])   (B operand of v_mfma_f32_32x32x16_bf16)."""
+    _, d, _ = wfold.shape
+    nt, ns = d // 32, d // 16
+    w = wfold.reshape(3, nt, 32, ns, 2, 8)            # t, c, col, s, half, j
+    w = w.transpose(0, 1, 3, 4, 2, 5)                  # t, c, s, half, col, j
+    return to_bf16_bits(np.ascontiguousarray(w.reshape(3, nt, ns, 64, 8)))
 
 
 def _pad_to(a: np.ndarray, n: int) -> np.ndarray:

@@ -206,6 +206,61 @@ def ppr_filter_device(ppr: DeviceCSR, mode: int, theta: float) -> DeviceCSR:
     return DeviceCSR(rowptr, col[:nnz], val[:nnz], n, None)
 
 
+BLOCK = 16  # entries per block of a blocked index (one 64-byte line of columns)
+
+
+@dataclass
+class BlockedIndex:
+    """A filtered PPR index (T0 / P1) laid out for two-step lookups (csrc/select2.hip, s2_find_blocked): every row is
+    padded to a multiple of 16 entries (padding columns = INT32_MAX, values 0), so each 16-entry block is one aligned
+    64-byte line, and ``skip[b]`` = last column of block b: a lookup reads the row's skip entries (one or two lines),
+    then ONE block, instead of walking a binary search through memory.  ``len`` = real entries per row."""
+    rowptr: torch.Tensor   # int64 [n+1], padded units (multiples of 16)
+    col: torch.Tensor      # int32
+    val: torch.Tensor      # float32
+    cv: torch.Tensor       # int32 [padded entries, 2]: {column, value bits} interleaved (what the kernels read)
+    len: torch.Tensor      # int32 [n]
+    skip: torch.Tensor     # int32 [rowptr[n] / 16]
+    n: int
+
+    def to_host_compact(self) -> CSR:
+        """The index as a plain CSR without padding (tests, statistics)."""
+        ln = self.len.cpu().numpy().astype(np.int64)
+        rp = self.rowptr.cpu().numpy()
+        col, val = self.col.cpu().numpy(), self.val.cpu().numpy()
+        keep = np.zeros(col.size, bool)
+        starts = np.repeat(rp[:-1], ln)
+        within = np.arange(int(ln.sum())) - np.repeat(np.concatenate([[0], np.cumsum(ln)[:-1]]), ln)
+        keep[starts + within] = True
+        rowptr = np.zeros(self.n + 1, np.int64)
+        np.cumsum(ln, out=rowptr[1:])
+        return CSR(rowptr, col[keep].copy(), val[keep].copy(), self.n)
+
+
+def ppr_filter_device_blocked(ppr: DeviceCSR, mode: int, theta: float) -> BlockedIndex:
+    """T0 (mode 0) / P1 (mode 1) index of a device-resident PPR matrix in the blocked layout (same kept entries, same
+    order as ``ppr_filter_device``; ``lpf_ppr_filter_count`` / ``_fill`` with padded row starts)."""
+    lib, dev, n = _lib.hip(), ppr.rowptr.device, ppr.n
+    st = torch.cuda.current_stream(dev).cuda_stream
+    lens = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    _lib.check(lib.lpf_ppr_filter_count(n, _lib.ptr(ppr.rowptr), _lib.ptr(ppr.val), mode, float(theta),
+                                        _lib.ptr(lens), st), "lpf_ppr_filter_count")
+    padded = (lens[:n] + (BLOCK - 1)) // BLOCK * BLOCK
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(padded, 0, out=rowptr[1:])
+    total = int(rowptr[-1].item())
+    col = torch.full((max(total, BLOCK),), 2**31 - 1, dtype=torch.int32, device=dev)
+    val = torch.zeros(max(total, BLOCK), dtype=torch.float32, device=dev)
+    _lib.check(lib.lpf_ppr_filter_fill(n, _lib.ptr(ppr.rowptr), _lib.ptr(ppr.col), _lib.ptr(ppr.val), mode,
+                                       float(theta), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), st),
+               "lpf_ppr_filter_fill")
+    skip = col.view(-1, BLOCK)[:, BLOCK - 1].contiguous()
+    # four extra entries: the lookup reads skip entries in aligned groups of four
+    skip = torch.cat([skip, torch.full((4,), 2**31 - 1, dtype=torch.int32, device=dev)])
+    cv = torch.stack([col, val.view(torch.int32)], dim=1).contiguous()
+    return BlockedIndex(rowptr, col, val, cv, lens[:n].to(torch.int32), skip, n)
+
+
 def self_ppr_device(adj: DeviceCSR, ppr: DeviceCSR) -> torch.Tensor:
     """``self_ppr`` on the device (``lpf_self_ppr``)."""
     from . import _lib

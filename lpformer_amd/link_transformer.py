@@ -495,7 +495,8 @@ class LinkTransformer(nn.Module):
         self._chain_att = DenseChain("dense_chain_attn_out")   # attention output projection + post_att_norm
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
         self.last_stats = {}
-        self._shard = (0, 1)   # (rank, world) for the row-sharded encoder
+        self._shard = (0, 1)   # (rank, world)
+        self.encoder_mode = "sharded"  # with world > 1: "sharded" (rows + all-gather per layer) or "replicated"
         self.use_select_index = True  # False: always run the general (PPR-streaming) selection kernel
         # the elementwise branch and the q projection only need X and the batch: they run on a second HIP stream
         # underneath the (latency/issue-bound) selection kernels.  False: everything on the caller's stream.
@@ -503,6 +504,9 @@ class LinkTransformer(nn.Module):
         self._side = None
         self.use_tail_chain = True    # score_pairs: lpf_tail_chain_f32 instead of three dense-chain launches
         self.use_fused_attention = True  # score_pairs: one-pass attention on the selection regions (D <= 128)
+        # "f32" (parity mode, logits within 1e-4 of the reference) or "bf16" (throughput mode of score_pairs: the node
+        # table Z is stored in bf16 and Wfold h runs on the bf16 matrix cores; selection and everything else as in f32)
+        self.precision = "f32"
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self):
@@ -546,9 +550,9 @@ class LinkTransformer(nn.Module):
             return hit[1]
         dev = self.device
         if kind == "t0":    # per-model indexes: filtered on the device from the resident PPR matrix
-            g = graph.ppr_filter_device(self._device_graph("ppr", obj), 0, self.thresh_non1hop)
+            g = graph.ppr_filter_device_blocked(self._device_graph("ppr", obj), 0, self.thresh_non1hop)
         elif kind == "p1":
-            g = graph.ppr_filter_device(self._device_graph("ppr", obj), 1, self.thresh_1hop)
+            g = graph.ppr_filter_device_blocked(self._device_graph("ppr", obj), 1, self.thresh_1hop)
         elif isinstance(obj, graph.CSR) and kind in ("mask", "ppr"):
             if kind == "ppr" and obj.val is None:
                 raise ValueError("the PPR matrix needs values")
@@ -620,42 +624,60 @@ class LinkTransformer(nn.Module):
     @_on_device
     def propagate(self, adj=None, test_set=False, _layers_out=None):
         """GCN encoder + ``gnn_norm`` -> [N, D] (reference :110-129).  L x (MFMA GEMM, fused CSR SpMM).
+        With more than one rank (``set_row_shard``) the encoder is either REPLICATED (every rank runs all of it, no
+        exchange) or ROW-SHARDED: a rank transforms and aggregates only its block of node rows and the transformed
+        rows are all-gathered once per layer (RCCL over xGMI), plus one all-gather of the output.
         ``_layers_out`` (tests): a list that receives every layer's input and the final output."""
         self._check_supported()
         with torch.no_grad():
             a_hat = self._device_graph("prop", self._data_obj("adj", test_set) if adj is None else adj)
-            enc = self.node_encoder.gnn_encoder
-            x = self._features()
-            st = _stream(self.device)
-            n_layers = len(enc.convs)
+            n_layers = len(self.node_encoder.gnn_encoder.convs)
             rank, world = self._shard
-            lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
-            long_rows = self._long_rows(a_hat, lo, hi)
-            for i, conv in enumerate(enc.convs):
-                if _layers_out is not None:
-                    _layers_out.append(x)
-                # dense transform of ALL rows (cheap, replicated), aggregation of the local row block only
-                t = gemm(x, self._conv_pads[i].get(conv.lin.weight), tag="gemm_encoder")
-                d = t.shape[1]
-                last = i == n_layers - 1
-                res = x[lo:hi] if (enc.residual and x.shape[1] == d) else None
-                ln = enc.lns[i] if enc.lns is not None else None
-                out = torch.empty(hi - lo, d, dtype=torch.float32, device=self.device)
-                with KernelTimer.span("spmm_csr"):
-                    check(_lib.hip().lpf_spmm_csr_f32(
-                        hi - lo, d, a_hat.rowptr.data_ptr() + 8 * lo, ptr(a_hat.col), ptr(a_hat.val), ptr(t),
-                        t.stride(0), ptr(out), out.stride(0), ptr(conv.bias),
-                        ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
-                        ptr(res), 0 if res is None else res.stride(0),
-                        ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
-                        FLAG_RELU if enc.relu else 0, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
-                        st), "lpf_spmm_csr_f32")
-                # every rank needs the full layer output for the next neighbour gather; the last of these
-                # collectives is the all-gather of node embeddings (RCCL over xGMI)
-                x = lpf_dist.allgather_rows(out, self.num_nodes) if world > 1 else out
+            if world == 1 or self.encoder_mode == "replicated":
+                x = self._features()
+                for i in range(n_layers):
+                    if _layers_out is not None:
+                        _layers_out.append(x)
+                    x = self._layer_aggregate(i, a_hat, self._layer_transform(i, x), 0, self.num_nodes, x)
+            else:
+                lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
+                x = self._features()[lo:hi]                      # the rank's rows of the layer input
+                for i in range(n_layers):
+                    t = lpf_dist.allgather_rows(self._layer_transform(i, x), self.num_nodes)   # [N, D] on every rank
+                    x = self._layer_aggregate(i, a_hat, t, lo, hi, x)
+                x = lpf_dist.allgather_rows(x, self.num_nodes)  # the all-gather of node embeddings
             if _layers_out is not None:
                 _layers_out.append(x)
             return x
+
+    def _layer_transform(self, i: int, x_rows: torch.Tensor) -> torch.Tensor:
+        """GCNConv.lin of layer i on the given rows (other_models.py:66 -> PyG GCNConv: x W^T, no bias)."""
+        conv = self.node_encoder.gnn_encoder.convs[i]
+        return gemm(_as_f32_rows(x_rows), self._conv_pads[i].get(conv.lin.weight), tag="gemm_encoder")
+
+    def _layer_aggregate(self, i: int, a_hat: graph.DeviceCSR, t: torch.Tensor, lo: int, hi: int,
+                         x_rows: torch.Tensor) -> torch.Tensor:
+        """Rows [lo, hi) of layer i's output from the transformed features ``t`` of ALL nodes: A_hat t + bias ->
+        LayerNorm -> ReLU -> (+ residual: ``x_rows`` = the same rows of the layer input) and, for the last layer, the
+        model's ``gnn_norm`` (other_models.py:66-74, link_transformer.py:127), all in the SpMM epilogue."""
+        enc = self.node_encoder.gnn_encoder
+        conv = enc.convs[i]
+        d = t.shape[1]
+        last = i == len(enc.convs) - 1
+        res = x_rows if (enc.residual and x_rows.shape[1] == d) else None
+        ln = enc.lns[i] if enc.lns is not None else None
+        long_rows = self._long_rows(a_hat, lo, hi)
+        out = torch.empty(hi - lo, d, dtype=torch.float32, device=self.device)
+        with KernelTimer.span("spmm_csr"):
+            check(_lib.hip().lpf_spmm_csr_f32(
+                hi - lo, d, a_hat.rowptr.data_ptr() + 8 * lo, ptr(a_hat.col), ptr(a_hat.val), ptr(t),
+                t.stride(0), ptr(out), out.stride(0), ptr(conv.bias),
+                ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
+                ptr(res), 0 if res is None else res.stride(0),
+                ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
+                FLAG_RELU if enc.relu else 0, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
+                _stream(self.device)), "lpf_spmm_csr_f32")
+        return out
 
     def _long_rows(self, a_hat: graph.DeviceCSR, lo: int, hi: int):
         """Hub rows (> LPF_SPMM_LONG_ROW entries) of the local row block, as row ids relative to `lo`; cached on the
@@ -667,11 +689,16 @@ class LinkTransformer(nn.Module):
             cache[(lo, hi)] = rows if rows.numel() else None
         return cache[(lo, hi)]
 
-    def set_row_shard(self, rank: int, world: int):
-        """Row-shard the encoder across `world` ranks of the default process group (see lpformer_amd/dist.py)."""
+    def set_row_shard(self, rank: int, world: int, mode: str = "sharded"):
+        """This process is rank ``rank`` of ``world`` (default process group, lpformer_amd/dist.py).  ``mode``:
+        "sharded" = row-sharded encoder with an all-gather per layer, "replicated" = every rank runs the whole encoder
+        (no exchange; pays when the encoder is cheaper than L all-gathers -- ``lpformer_amd.dist.encoder_plan``)."""
         if not (0 <= rank < world):
             raise ValueError("need 0 <= rank < world")
+        if mode not in ("sharded", "replicated"):
+            raise ValueError("mode must be 'sharded' or 'replicated'")
         self._shard = (rank, world)
+        self.encoder_mode = mode
 
     def _node_keys(self, x_node: torch.Tensor, w):
         """Per encoder output (cached on the tensor's identity and version), two node-level projections that the
@@ -691,6 +718,15 @@ class LinkTransformer(nn.Module):
             hit = self._z_cache = (weakref.ref(x_node), x_node._version, z, y)
         return hit[2], hit[3]
 
+    def _z_bf16(self, z: torch.Tensor) -> torch.Tensor:
+        """bf16 copy of the node table Z (once per encoder output; the storage format of the bf16 throughput mode)."""
+        hit = getattr(self, "_zb_cache", None)
+        if hit is None or hit[0] is not z:
+            zb = z.to(torch.bfloat16).contiguous()
+            torch.cuda.current_stream(self.device).synchronize()  # other streams read it
+            hit = self._zb_cache = (z, zb)
+        return hit[1]
+
     # ---------------------------------------------------------------------------------- selection
     def _sel_ws(self, st, bs: int) -> "_SelectWorkspace":
         key = ("sel2", st, bs)
@@ -707,15 +743,21 @@ class LinkTransformer(nn.Module):
         with KernelTimer.span("select_plan"):
             check(lib.lpf_select_plan(bs, ptr(batch), batch.stride(0), self.num_nodes, ptr(adj.rowptr),
                                       ptr(val.rowptr), ptr(t0.rowptr) if t0 is not None else None,
-                                      ptr(adjx.rowptr) if adjx is not adj else None, ptr(ws.desc), ptr(ws.offs),
+                                      ptr(adjx.rowptr) if adjx is not adj else None,
+                                      ptr(getattr(val, "len", None)), ptr(getattr(t0, "len", None)),
+                                      ptr(ws.desc), ptr(ws.offs),
                                       ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl), ptr(ws.plan_lb), st),
                   "lpf_select_plan")
         with KernelTimer.span("select_run"):
             check(lib.lpf_select_run(bs, ptr(ws.desc), ptr(ws.offs), ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl),
                                      ptr(ws.run_lb), ptr(adj.col), ptr(selfp),
-                                     ptr(adjx.col) if adjx is not adj else None, ptr(val.col), ptr(val.val),
-                                     ptr(t0.col) if t0 is not None else None,
-                                     ptr(t0.val) if t0 is not None else None, float(self.thresh_cn),
+                                     ptr(adjx.col) if adjx is not adj else None,
+                                     None if selfp is not None else ptr(val.col),
+                                     None if selfp is not None else ptr(val.val),
+                                     ptr(val.cv) if selfp is not None else None,
+                                     ptr(val.skip) if selfp is not None else None,
+                                     ptr(t0.cv) if t0 is not None else None,
+                                     ptr(t0.skip) if t0 is not None else None, float(self.thresh_cn),
                                      float(self.thresh_1hop), float(self.thresh_non1hop), ptr(ws.type_ptr),
                                      ptr(ws.entries), ws.ent_cap, 0, st), "lpf_select_run")
 
@@ -1046,10 +1088,19 @@ class LinkTransformer(nn.Module):
                 bnd = self._workspace("att_bnd", 3 * units_cap * 2 * rs, torch.float32, st)
                 uflag = self._workspace("att_uflag", 3 * units_cap, torch.int32, st)
                 with KernelTimer.span("pair_attention_fused"):
-                    check(lib.lpf_pair_attention_fused_f32(
-                        d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q),
-                        q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]), ptr(w["bfold"]),
-                        ptr(w["att"]), ptr(part), ptr(bnd), ptr(uflag), units_cap, st), "lpf_pair_attention_fused_f32")
+                    if self.precision == "bf16":
+                        zb = self._z_bf16(z)
+                        check(lib.lpf_pair_attention_fused_bf16(
+                            d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zb), zb.stride(0), ptr(q),
+                            q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed_bf16"]),
+                            ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), ptr(uflag), units_cap, st),
+                            "lpf_pair_attention_fused_bf16")
+                    else:
+                        check(lib.lpf_pair_attention_fused_f32(
+                            d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q),
+                            q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]),
+                            ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), ptr(uflag), units_cap, st),
+                            "lpf_pair_attention_fused_f32")
                 tt = self._tail_tables(score_func, a, c)
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):

@@ -255,3 +255,29 @@ def test_selection_overflow_is_flagged_and_recovered():
     assert model.check_selection() and torch.isfinite(good).all()
     ref = score.logits(model.pair_features(dense, h))
     assert (good - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_encoder_matches_unsharded(world):
+    """The row-sharded encoder of every rank, emulated on one GPU (ragged N: not a multiple of the world size): per
+    layer each rank transforms and aggregates its own row block, the blocks are stitched where the RCCL all-gather
+    would assemble them; the result is bitwise the unsharded encoder output.  Residual GCN (the shard must add its own
+    rows of the layer input) with hub rows in every block."""
+    from lpformer_amd import dist as LD
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup("ppa", scale=0.03)
+    want = model.propagate()
+    a_hat = model._device_graph("prop", data["adj_t"])
+    n_layers = args["gnn_layers"]
+    spans = [LD.row_range(n, world, r) for r in range(world)]
+    xs = [model._features()[lo:hi] for lo, hi in spans]
+    for i in range(n_layers):
+        t_full = torch.cat([model._layer_transform(i, xr) for xr in xs])        # <- all-gather of the transformed rows
+        xs = [model._layer_aggregate(i, a_hat, t_full, lo, hi, xr) for (lo, hi), xr in zip(spans, xs)]
+    got = torch.cat(xs)                                                          # <- all-gather of node embeddings
+    assert torch.equal(got, want)
+    # pairs are split by index, scores need no exchange: scoring the shards separately = scoring the batch
+    tb = torch.from_numpy(batch).to(DEV)
+    whole = model.score_pairs(tb, want, score, logits=True)
+    parts = torch.cat([model.score_pairs(LD.shard_pairs(tb, world, r).contiguous(), want, score, logits=True)
+                       for r in range(world)])
+    assert (whole - parts).abs().max().item() <= 1e-5

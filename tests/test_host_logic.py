@@ -185,3 +185,14 @@ def test_ranking_metrics_match_reference_formulas():
     assert abs(got["MRR"] - float((1.0 / rank).mean())) < 1e-6
     for k in (10, 50, 100):
         assert abs(got[f"Hits@{k}"] - float((rank <= k).mean())) < 1e-7
+
+
+def test_encoder_plan_cost_model():
+    from lpformer_amd import dist as LD
+    # collab-like: the encoder is cheaper than four 121 MB all-gathers -> replicate
+    p = LD.encoder_plan(1.1, 235_868, 128, 3, 8, allgather_gbps=300.0)
+    assert p["mode"] == "replicated" and p["sharded_ms"] > p["replicated_ms"]
+    # citation2-like: 10 ms of encoder against 4 x 750 MB -> shard when the exchange is fast enough
+    assert LD.encoder_plan(10.0, 2_927_963, 64, 3, 8, allgather_gbps=1000.0)["mode"] == "sharded"
+    assert LD.encoder_plan(10.0, 2_927_963, 64, 3, 8, allgather_gbps=200.0)["mode"] == "replicated"
+    assert LD.encoder_plan(5.0, 1000, 64, 3, 1, allgather_gbps=1.0)["mode"] == "replicated"

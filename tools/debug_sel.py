@@ -29,6 +29,7 @@ for indexed in (True, False):
 adj = model._device_graph("mask", model.data["adj_mask"])
 rp, col = adj.rowptr.cpu().numpy(), adj.col.cpu().numpy()
 t0 = model._device_graph("t0", model.data["ppr"])
+t0 = t0.to_host_compact().to_device("cuda:0")
 trp, tcol = t0.rowptr.cpu().numpy(), t0.col.cpu().numpy()
 for k in (1, 4, 5):
     a, b = fx["batch"][:, k]
