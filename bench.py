@@ -82,6 +82,7 @@ def main():
                     help="pairs timed on the CPU oracle (taken from the bench's own batches; about 10-15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads the CPU baseline may use")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16 throughput-mode measurement")
     ap.add_argument("--ppr", default="gpu", choices=("gpu", "host"),
                     help="PPR producer for the (untimed) setup: lpf_ppr_push_f64 on the GPU or the OpenMP host push")
     ap.add_argument("--spinup", type=float, default=1.0,
@@ -206,6 +207,40 @@ def main():
     encoder_ms = LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / enc_reps, dev)
     del h2
 
+    # ---- bf16 throughput mode (extra keys; the headline stays fp32 = the reference's precision): same steps with
+    #      model.precision = "bf16" (bf16 storage of Z + bf16 matrix cores in the attention kernel)
+    bf16 = None
+    if not args.no_bf16 and d in (32, 64, 128):
+        model.precision = "bf16"
+        for i in range(max(args.warmup, len(lanes))):
+            step_on(i)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out16 = step_on(i)
+        torch.cuda.synchronize()
+        barrier()
+        el16 = LD.max_over_ranks(time.perf_counter() - t0, dev)
+        model.precision = "f32"
+        ref_l = model.score_pairs(batches[0], h, score, logits=True).clone()
+        model.precision = "bf16"
+        got_l = model.score_pairs(batches[0], h, score, logits=True)
+        bf16 = {"value": round(world * bs * args.steps / el16, 1), "unit": "pairs/s",
+                "ms_per_step": round(el16 * 1e3 / args.steps, 4),
+                "max_abs_logit_diff_vs_f32": float((got_l - ref_l).abs().max()),
+                "what": "bf16 storage of the node table Z + v_mfma_f32_32x32x16_bf16 for Wfold h (fp32 accumulate); "
+                        "selection, q, softmax, dense tail in fp32; selected index sets identical to fp32"}
+        KernelTimer.reset()
+        KernelTimer.enabled = True
+        for i in range(args.steps):
+            step(i)
+        kt16 = KernelTimer.summary()
+        KernelTimer.enabled = False
+        if "pair_attention_fused" in kt16:
+            bf16["pair_attention_fused_ms"] = round(kt16["pair_attention_fused"][2], 4)
+        model.precision = "f32"
+
     # ---- instrumented replay of the same steps: HIP events around every kernel launch on the launch stream
     # (recording ~50 events per step costs ~0.1 ms per step, so it is kept out of the headline timing)
     instrumented_ms = None
@@ -292,6 +327,14 @@ def main():
                         r["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes at {pmc.get('commit', '?')})"
             except (OSError, KeyError, ValueError):
                 pass
+            if bf16 is not None and "pair_attention_fused_ms" in bf16:
+                # bf16 mode: the attention kernel is HBM-bound -- one bf16 Z row + one 16-byte record per selected
+                # entry, one fp32 q row read and about one fp32 record written per pair
+                byts = n_sel * (2.0 * d + 16.0) + bs * (4.0 * d + 4.0 * d + 16.0)
+                ach = byts / (bf16["pair_attention_fused_ms"] * 1e-3) / 1e9
+                bf16["roofline"] = {"kernel": "pair_attention_fused (bf16)", "bound": "hbm", "achieved": round(ach, 1),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                    "traffic": None, "launch_ms": bf16["pair_attention_fused_ms"]}
             modelled = [k for k in sorted(kt, key=lambda k: -kt[k][1]) if k in rooflines]
             if modelled:
                 roofline = dict(rooflines[modelled[0]])
@@ -388,7 +431,7 @@ def main():
             "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),
             "ms_per_step_repeats": {"n": len(rep_ms), "min": round(min(rep_ms), 4),
                                     "median": round(float(np.median(rep_ms)), 4), "max": round(max(rep_ms), 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "rooflines": rooflines,
+            "roofline": roofline, "cpu_baseline": cpu, "bf16_mode": bf16, "kernels": kernels, "rooflines": rooflines,
             "setup_s": dict({k: round(v, 2) for k, v in setup.items()}, ppr_producer=args.ppr),
         }
         print(json.dumps(result), flush=True)

@@ -82,11 +82,6 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     const PeStat st = pe_load_stat(A.pe_stat, t);
     const float r_ab = pe_rstd(st, pa, pb), r_ba = pe_rstd(st, pb, pa);
 
-    f32x16 acc[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
     // The tile's 32 Z rows go straight to this wavefront's LDS buffer (LDS-DMA: no VGPR destination), in unit order
     // (row j = tile entry j): each instruction moves 64 x 16 bytes = RPI whole rows, lane l -> row m RPI + l / LPR,
@@ -107,12 +102,16 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         }
     }
 
-    // per-feature constants of the epilogue: requested before the MFMA loop, in registers when it ends
-    float bf[NT], at[NT];
+    // per-feature constants: bfold_t seeds the accumulators (k = Z + Wfold h + bfold comes out of the MFMA loop with
+    // the bias already in), att is needed in the epilogue
+    float at[NT];
+    f32x16 acc[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-        bf[c] = A.bfold[t * D + 32 * c + col];
+        const float bfc = A.bfold[t * D + 32 * c + col];
         at[c] = A.att[32 * c + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = bfc;
     }
     const float4 *tb = tab + t * D + lh * (D / 2);
     if constexpr (!BF16) {
@@ -152,21 +151,37 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
             for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, wbb[c], acc[c], 0, 0, 0);
         }
     }
-    // acc[c][i] = (Wfold_t h)[feature 32c + col] of unit entry i (tile entry 16 lh + i)
+    // acc[c][i] = (Wfold_t h + bfold_t)[feature 32c + col] of unit entry i (tile entry 16 lh + i)
 
     // ---- scores of the unit's 16 entries.  Entries are taken two at a time (16 row pieces in flight per lane) with a
     // scheduling barrier in between: left to itself the scheduler hoists all 128 loads of the unit and spills.
     float sc[16];
-#pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += 2) {
-        const float *qr[2];
-        float zv[2][NT], qv[2][NT];
+    // q rows (global, mostly L1/L2 hits: consecutive entries share their pair) are requested one pair of entries
+    // ahead of the arithmetic that uses them; the Z rows come from the LDS buffer
+    float qn[2][NT];
+    auto load_q = [&](int i0, float (&dst)[2][NT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = i0 + u;
             const int r0 = 8 * (i >> 2) + (i & 3);  // A row that carried unit entry i of half 0 (half 1: r0 + 4)
             const int pr0 = __builtin_amdgcn_readlane(pair_a, r0), pr1 = __builtin_amdgcn_readlane(pair_a, r0 + 4);
-            qr[u] = A.q + (int64_t)(lh ? pr1 : pr0) * A.ldq + col;
+            const float *qr = A.q + (int64_t)(lh ? pr1 : pr0) * A.ldq + col;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) dst[u][c] = (A.dbg & 1) ? 0.25f : qr[32 * c];
+        }
+    };
+    load_q(0, qn);
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 2) {
+        float zv[2][NT], qv[2][NT];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) qv[u][c] = qn[u][c];
+        if (i0 + 2 < 16) load_q(i0 + 2, qn);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u;
 #pragma unroll
             for (int c = 0; c < NT; ++c) {  // the staged row of unit entry i (LDS)
                 if constexpr (BF16) {
@@ -178,16 +193,12 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int c = 0; c < NT; ++c) qv[u][c] = (A.dbg & 1) ? 0.25f : qr[u][32 * c];
-#pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = i0 + u;
             float p = 0.f;
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
-                const float k = acc[c][i] + zv[u][c] + bf[c];
+                const float k = acc[c][i] + zv[u][c];
                 acc[c][i] = k;
                 float x = k * qv[u][c];
                 x = fmaxf(x, 0.2f * x);  // leaky_relu(x, 0.2)

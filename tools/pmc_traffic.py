@@ -10,6 +10,9 @@ import sys
 from collections import defaultdict
 
 SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
+    ("select_run_kernel", "select_run"), ("select_plan_kernel", "select_plan"), ("select_export", "select_export"),
+    ("pair_fused_kernel", "pair_attention_fused"), ("pair_fused_fixup", "pair_attention_fixup"),
+    ("tail_chain_kernel", "tail_chain"), ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"),
     ("pair_scores_", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
     ("pair_softmax_gather_kernel", "pair_softmax_gather_light"), ("select_nodes_indexed", "select_nodes"),
     ("select_nodes_kernel", "select_nodes_general"), ("select_compact", "select_compact"),
@@ -40,7 +43,7 @@ def main():
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on the collab-like bench "
                    "workload, serial single-stream steps; bytes = 2 x FETCH_SIZE_KB x 1024 (gfx950 correction, "
                    "MI355X_MICROARCH.md) + WRITE_SIZE_KB x 1024, mean per launch after warm-up",
-           "kernels": {}}
+           "commit": sys.argv[4] if len(sys.argv) > 4 else "?", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, []), write.get(k, [])
         fk = sum(f) / len(f) if f else 0.0

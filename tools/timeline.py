@@ -1,6 +1,6 @@
 """GPU timeline of the bench's steady state from a rocprofv3 --kernel-trace CSV.
 
-Window: from the start of the `lo`-th to the start of the `hi`-th select_bound launch (one per step).  Reports the
+Window: from the start of the `lo`-th to the start of the `hi`-th select_plan launch (one per step).  Reports the
 span per step, the union of kernel-busy time, the sum of kernel durations (overlap) and the largest idle gaps."""
 import csv
 import sys
@@ -10,7 +10,7 @@ path = sys.argv[1]
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (12, 42)
 rows = list(csv.DictReader(open(path)))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-marks = [s for s, e, n in ks if "select_bound_kernel" in n]
+marks = [s for s, e, n in ks if "select_plan_kernel" in n]
 w0, w1 = marks[lo], marks[hi]
 win = [(s, e, n) for s, e, n in ks if w0 <= s < w1]
 steps = hi - lo
