@@ -114,6 +114,8 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         for (int r = 0; r < 16; ++r) acc[c][r] = bfc;
     }
     const float4 *tb = tab + t * D + lh * (D / 2);
+    // (Letting the wavefronts of a SIMD take turns in the MFMA loop through an LDS token -- to keep one wave's
+    // epilogue beside another's matrix loop -- measured slower: 203 vs 194 us.)
     if constexpr (!BF16) {
 #pragma unroll 1
         for (int sq = 0; sq < ((A.dbg & 4) ? 0 : NSQ); ++sq) {
