@@ -275,7 +275,7 @@ class mlp_score(nn.Module):  # noqa: N801  (name kept for drop-in compatibility)
     def _run(self, x: torch.Tensor, want_prob: bool) -> torch.Tensor:
         _require_gpu(x, "mlp_score.forward")
         if self.training and self.dropout > 0:
-            raise NotImplementedError("training-mode dropout is not part of the HIP inference path")
+            raise NotImplementedError("training-mode dropout without autograd: use model.eval() for inference")
         with torch.no_grad():
             h = _as_f32_rows(x)
             if len(self.lins) == 2 and self.lins[1].out_features == 1:  # Linear -> ReLU -> dot -> sigmoid, one launch
@@ -309,6 +309,9 @@ class mlp_score(nn.Module):  # noqa: N801  (name kept for drop-in compatibility)
         return torch.sigmoid(y).squeeze(-1) if want_prob else y.squeeze(-1)
 
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            from . import train as lpf_train
+            return lpf_train.score_train(self, x)
         return self._run(x, True)
 
     def logits(self, x):
@@ -509,7 +512,7 @@ class LinkTransformer(nn.Module):
         self.precision = "f32"
 
     # ---------------------------------------------------------------------------------- support checks
-    def _check_supported(self):
+    def _check_supported(self, train_ok: bool = False):
         if self.mask == "cn":
             raise NotImplementedError("mask mode 'cn' (thresh_1hop == thresh_non1hop == 1) is unspecified: the "
                                       "reference itself crashes in this mode on torch >= 2.1")
@@ -518,9 +521,10 @@ class LinkTransformer(nn.Module):
                                       "reference is shape-inconsistent for heads>1 with layers>1")
         if self.dim not in (32, 64, 128, 256):
             raise NotImplementedError("dim must be one of 32, 64, 128, 256 for the gfx950 kernels")
-        if self.training:
-            raise NotImplementedError("training step (autograd through the fused kernels) is not implemented in this "
-                                      "round: call model.eval()")
+        if self.training and not train_ok:
+            raise NotImplementedError("in training mode only forward() is available (the reference's training loop calls "
+                                      "nothing else, src/train/train_model.py:59-66); the inference kernels behind "
+                                      "propagate / calc_pairwise / score_pairs need model.eval()")
         if "emb" in self.data:
             raise NotImplementedError("data['emb'] is never set by the reference's readers and is not supported")
 
@@ -1142,6 +1146,13 @@ class LinkTransformer(nn.Module):
         """Link representations [BS, 2D] = [elementwise branch | pairwise branch] (reference :82-107).  Like the
         reference, every call re-runs the encoder; evaluation loops that propagate once should call ``propagate``
         + ``elementwise_lin`` + ``calc_pairwise`` (src/train/testing.py:96-121)."""
+        if self.training:
+            # autograd graph on the device: GEMMs, aggregation and selection through the C ABI (lpformer_amd/train.py)
+            self._check_supported(train_ok=True)
+            if return_weights:
+                raise NotImplementedError("return_weights is an evaluation-time debugging aid (layers.py:69-75)")
+            from . import train as lpf_train
+            return lpf_train.forward_train(self, batch, adj_prop, adj_mask, test_set)
         self._check_supported()
         with torch.no_grad():
             batch = self._prep_batch(batch)

@@ -237,6 +237,81 @@ def build_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, 
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+
+def build_train_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, residual=False, weighted=False,
+                     power=0.0, n_isolated=0, mask_input=True, num_negative=1):
+    """One training step of the reference (src/train/train_model.py:35-66) on CPU: model.train() with every dropout
+    probability set to 0 (so the step is deterministic), positives scored with their edges removed from the typing
+    adjacency (and, with mask_input, from the propagation adjacency), negatives drawn here, loss =
+    -log(pos + 1e-6).mean() - log(1 - neg + 1e-6).mean(), loss.backward().  Recorded: inputs, loss, and the gradient
+    of every parameter of the model and of the score head."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    from torch_sparse import SparseTensor  # shim
+    edge_index, edge_w = rand_graph(rng, n, m, n_isolated, power, weighted)
+    x = rng.standard_normal((n, f_in)).astype(np.float32)
+    th_cn, th_1, th_n = thresholds
+    adj_t = SparseTensor.from_edge_index(torch.from_numpy(edge_index), torch.from_numpy(edge_w), [n, n])
+    adj_mask = adj_t.to_symmetric().to_torch_sparse_coo_tensor().coalesce().bool().int()
+    pr, pc, pv = reference_ppr(edge_index, n, eps)
+    ppr = torch.sparse_coo_tensor(torch.from_numpy(np.stack([pr, pc])), torch.from_numpy(pv), (n, n)).coalesce()
+    data = {"x": torch.from_numpy(x), "adj_t": adj_t, "adj_mask": adj_mask, "ppr": ppr, "num_nodes": n,
+            "full_adj_t": adj_t, "full_adj_mask": adj_mask, "ppr_test": ppr}
+    train_args = {"thresh_cn": th_cn, "thresh_1hop": th_1, "thresh_non1hop": th_n, "dim": dim,
+                  "trans_layers": 1, "num_heads": 1, "att_drop": 0.0, "dropout": 0.0, "gnn_drop": 0.0,
+                  "feat_drop": 0.0, "gcn_cache": False, "gnn_layers": gnn_layers, "residual": residual,
+                  "layer_norm": True, "relu": True}
+    model = LinkTransformer(train_args, data, device="cpu")
+    score = mlp_score(model.out_dim, model.out_dim, 1, 2, 0.0)
+    shapes = {}
+    with torch.no_grad():
+        for tag, mod in (("model", model), ("score", score)):
+            for pname, p in mod.state_dict().items():
+                shapes[f"{tag}.{pname}"] = list(p.shape)
+                p.copy_(torch.from_numpy(make_param(f"{tag}.{pname}", p.shape, seed)))
+    model.train()
+    score.train()
+    und = edge_index[:, edge_index[0] < edge_index[1]].T.copy()          # train_pos
+    perm = rng.permutation(und.shape[0])[:bs]
+    keepmask = np.ones(und.shape[0], bool)
+    keepmask[perm] = False
+    edge2keep = torch.from_numpy(und[keepmask])
+    masked = SparseTensor.from_edge_index(edge2keep.t(), sparse_sizes=(n, n)).to_device("cpu").to_symmetric()
+    masked_adj = masked.to_torch_sparse_coo_tensor().coalesce().bool().int()
+    masked_adjt = masked if mask_input else None
+    edges = torch.from_numpy(und[perm].T.copy())
+    neg_edges = torch.from_numpy(rng.integers(0, n, size=(2, bs * num_negative)))
+    h = model(edges, adj_prop=masked_adjt, adj_mask=masked_adj)
+    pos_out = score(h)
+    pos_loss = -torch.log(pos_out + 1e-6).mean()
+    hn = model(neg_edges)
+    neg_out = score(hn)
+    neg_loss = -torch.log(1 - neg_out + 1e-6).mean()
+    loss = pos_loss + neg_loss
+    loss.backward()
+    out = {"edge_index": edge_index.astype(np.int32), "edge_weight": edge_w, "x": x,
+           "ppr_row": pr.astype(np.int32), "ppr_col": pc.astype(np.int32), "ppr_val": pv,
+           "pos_edges": edges.numpy(), "neg_edges": neg_edges.numpy(), "keep_edges": und[keepmask].T.astype(np.int32),
+           "loss": np.float32(loss.item()), "pos_out": pos_out.detach().numpy(), "neg_out": neg_out.detach().numpy(),
+           "pos_feats": h.detach().numpy()}
+    n_none = 0
+    for tag, mod in (("model", model), ("score", score)):
+        for pname, p in mod.named_parameters():
+            if p.grad is None:
+                n_none += 1
+                continue
+            out[f"grad.{tag}.{pname}"] = p.grad.numpy().astype(np.float32)
+    cfg = dict(train_args)
+    cfg.update(n=n, f_in=f_in, eps=eps, test_set=False, pred_layers=2, seed=seed, param_shapes=shapes,
+               mask_input=bool(mask_input))
+    out["config_json"] = np.array(__import__("json").dumps(cfg))
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    gn = {k: float(np.abs(v).max()) for k, v in out.items() if k.startswith("grad.")}
+    print(f"[golden] {name}: loss={loss.item():.6f} params with grad={len(gn)} (without: {n_none}) "
+          f"max|grad|={max(gn.values()):.3e} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def build_ppr_case(name, seed, n, m, eps_list, n_isolated=0, power=0.0):
     """PPR producer golden: graph -> (row, col, fp32 val) exactly as calc_ppr_scores.py emits them."""
     rng = np.random.default_rng(seed)
@@ -253,11 +328,12 @@ def build_ppr_case(name, seed, n, m, eps_list, n_isolated=0, power=0.0):
 
 def main(only=()):
     """Build every fixture, or only the named ones (python make_golden.py lp_all_d64_maskedadj ...)."""
-    global build_case, build_ppr_case
-    _bc, _bp = build_case, build_ppr_case
+    global build_case, build_ppr_case, build_train_case
+    _bc, _bp, _bt = build_case, build_ppr_case, build_train_case
     if only:
         build_case = lambda name, *a, **k: _bc(name, *a, **k) if name in only else None      # noqa: E731
         build_ppr_case = lambda name, *a, **k: _bp(name, *a, **k) if name in only else None  # noqa: E731
+        build_train_case = lambda name, *a, **k: _bt(name, *a, **k) if name in only else None  # noqa: E731
     # mode "all", LN+ReLU, no residual, isolated nodes, PPR values jittered onto the thresholds
     build_case("lp_all_d64", 1, n=320, m=900, f_in=24, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
                eps=1e-3, bs=192, n_isolated=6, jitter=True)
@@ -276,6 +352,11 @@ def main(only=()):
     # the training loop's masked-adjacency overrides (train_model.py:40-59), weighted graph, jittered PPR values
     build_case("lp_all_d64_maskedadj", 6, n=340, m=1000, f_in=32, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
                eps=1e-3, bs=180, weighted=True, power=0.4, n_isolated=4, jitter=True, masked=True)
+    # one deterministic training step (all dropouts 0): loss + gradients of every parameter
+    build_train_case("train_step_d64", 9, n=300, m=900, f_in=32, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
+                     eps=1e-3, bs=96, weighted=True, power=0.4, n_isolated=3, mask_input=True)
+    build_train_case("train_step_d64_residual", 10, n=280, m=800, f_in=64, dim=64, gnn_layers=3,
+                     thresholds=(0, 1e-3, 1e-2), eps=1e-3, bs=80, residual=True, mask_input=False)
     build_ppr_case("ppr_push_small", 7, n=220, m=600, eps_list=[1e-3, 1e-4], n_isolated=5)
     build_ppr_case("ppr_push_powerlaw", 8, n=300, m=1500, eps_list=[1e-3], power=0.9)
 
