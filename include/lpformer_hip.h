@@ -289,13 +289,15 @@ int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const float *G, i
  * then the segment softmax and the weighted sum (layers.py:220-224) as an online softmax per (pair, type) segment;
  * every Z row is gathered once, k_e and s_e never reach memory.  Output: for every non-empty segment
  *   part[(t*bs + pair)*(D+4) ..] = { sum_e exp(s_e - m) k_e [D], m = max_e s_e, l = sum_e exp(s_e - m), -, - }
- * (segments that cross 16-entry unit boundaries go through bnd/uflag and a second, small kernel of the same call).
- * lpf_tail_chain_merge_f32 combines a pair's up to three records.  Tables as for lpf_pair_scores_f32.
- * bnd: float[3*units_cap*2*(D+4)], uflag: int32[3*units_cap], units_cap >= ceil(ent_cap/16).  D in {32, 64, 128}. */
+ * A segment that crosses 16-entry unit boundaries of its type's region leaves instead one boundary record per unit it
+ * touches: bnd[((t*units_cap + U)*2 + slot)*(D+4) ..], slot 1 of the unit it starts in, slot 0 of every following
+ * unit.  lpf_tail_chain_merge_f32 combines a pair's records (it finds the boundary records from the segment
+ * pointers).  Tables as for lpf_pair_scores_f32.
+ * bnd: float[3*units_cap*2*(D+4)], units_cap >= ceil(ent_cap/16).  D in {32, 64, 128}. */
 int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
                                  int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
                                  const float *pe_tab, const float *pe_stat, const float *wfold_packed,
-                                 const float *bfold, const float *att, float *part, float *bnd, int32_t *uflag,
+                                 const float *bfold, const float *att, float *part, float *bnd,
                                  int64_t units_cap, void *stream);
 
 /* bf16 THROUGHPUT MODE of lpf_pair_attention_fused_f32 (BASELINE.json config 2 names bf16 storage): the node table
@@ -310,7 +312,7 @@ int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t *type_ptr,
 int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
                                   int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q, int64_t ldq,
                                   const float *pe_tab, const float *pe_stat, const void *wfold_packed_bf16,
-                                  const float *bfold, const float *att, float *part, float *bnd, int32_t *uflag,
+                                  const float *bfold, const float *att, float *part, float *bnd,
                                   int64_t units_cap, void *stream);
 
 /* lpf_tail_chain_f32 with the attention output taken from the records of lpf_pair_attention_fused_f32 instead of a
@@ -318,8 +320,8 @@ int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_t *type_ptr
  * pair's non-empty segments (PyG softmax over ALL entries of the pair, layers.py:220; no entry => o = LN(att_bias)),
  * and the count features n_cn, n_1hop, [n_non1hop,] n_cn+n_1hop (link_transformer.py:340-356) from type_ptr.
  * sel_ctl (optional): the selection control block; if its error word is set every score of the batch is NaN. */
-int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, const float *part, const int32_t *type_ptr,
-                             const float *att_bias, const float *lnA_g, const float *lnA_b, const float *wB_packed,
+int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, const float *part, const float *bnd,
+                             int64_t units_cap, const int32_t *type_ptr, const float *att_bias, const float *lnA_g, const float *lnA_b, const float *wB_packed,
                              const float *bB, const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre,
                              const float *wC_packed, const float *bC, const float *w_dot, const float *b_dot,
                              const int64_t *sel_ctl, float *logit, float *prob, void *stream);

@@ -18,9 +18,9 @@
 //     walks sequentially with an online softmax (running max / sum / weighted sum), flushing a record
 //     {sum_e exp(s_e - m) k_e [D], m, l} whenever the pair changes.
 //   * A pair's (type) segment that lies inside one unit is flushed straight to part[t][pair].  A segment that crosses
-//     unit boundaries leaves one boundary record per unit it touches; pair_fused_fixup_kernel merges each such chain
-//     (same rescaling as the online softmax) into part[t][pair].  The tail kernel merges a pair's up to three type
-//     records, adds the bias and applies post_att_norm (tail_chain.hip, merge mode).
+//     unit boundaries leaves one boundary record per unit it touches: slot 1 of the unit it starts in, slot 0 of every
+//     unit after.  The tail kernel (tail_chain.hip, merge mode) finds a pair's records from its segment pointers,
+//     merges them with the same rescaling as the online softmax, adds the bias and applies post_att_norm.
 // Bound: fp32 MFMA (2 D^2 FLOP per entry); one Z row + one 16-byte record read per entry.
 #include <stdlib.h>
 
@@ -48,7 +48,6 @@ struct FusedArgs {
     const float *pe_tab, *pe_stat, *wpk, *bfold, *att;
     float *part;               // [3][bs][D+4]
     float *bnd;                // [3][units_cap][2][D+4]
-    int32_t *uflag;            // [3][units_cap]
     int64_t units_cap;
     int dbg;                   // tuning aid (LPF_FUSED_DBG): bit 0 no Z/q loads, 1 no softmax/flush, 2 no MFMA, 3 no butterfly
 };
@@ -247,14 +246,13 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
 #pragma unroll
     for (int c = 0; c < NT; ++c) o[c] = 0.f;
     bool first = true;
-    int head = 0, cur_pair = 0;
+    int cur_pair = 0;
     auto flush = [&](int pair, bool cfront, bool cback) __attribute__((always_inline)) {
         float *dst = (cfront && cback) ? part_t + (int64_t)pair * RS : bnd_u + (cfront ? RS : 0);
 #pragma unroll
         for (int c = 0; c < NT; ++c) dst[32 * c + col] = o[c];
         if (col == 0)
             *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, __int_as_float(pair), cback ? 0.f : 1.f);
-        if (cfront && !cback) head = 1;
     };
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -280,7 +278,6 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         }
     }
     flush(cur_pair, first ? st0 : true, !cont);
-    if (col == 0) A.uflag[(int64_t)t * A.units_cap + U] = head;
 }
 
 template <int NT, bool BF16>
@@ -325,55 +322,6 @@ __global__ __launch_bounds__(64 * pf_waves<NT>()) void pair_fused_kernel(const F
     }
 }
 
-// Chains of boundary records -> part[t][pair].  Eight lanes per unit (NV = D/32 16-byte pieces of a record per lane):
-// the walk along a chain is a few dependent reads, so what matters is how many chains are walked at once.
-template <int NV>
-__global__ __launch_bounds__(256) void pair_fused_fixup_kernel(const FusedArgs A) {
-    constexpr int D = 32 * NV, RS = D + 4, G = 8;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t grp = tid / G, n_grp = (int64_t)gridDim.x * blockDim.x / G;
-    const int lig = tid % G;
-    for (int t = 0; t < 3; ++t) {
-        int64_t cnt = A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs];
-        if (cnt > A.ent_cap) cnt = A.ent_cap;
-        const int64_t n_units = (cnt + 15) >> 4;
-        for (int64_t U = grp; U < n_units; U += n_grp) {
-            if (A.uflag[(int64_t)t * A.units_cap + U] == 0) continue;
-            const float *r1 = A.bnd + ((((int64_t)t * A.units_cap + U) * 2) + 1) * RS;
-            float4 o[NV];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) o[v] = reinterpret_cast<const float4 *>(r1)[lig + G * v];
-            const float4 h1 = *reinterpret_cast<const float4 *>(r1 + D);
-            float m = h1.x, l = h1.y;
-            const int pair = __float_as_int(h1.z);
-            int64_t nx = U + 1;
-            float more = 1.f;
-            while (more != 0.f && nx < n_units) {
-                const float *r0 = A.bnd + (((int64_t)t * A.units_cap + nx) * 2) * RS;
-                float4 o2[NV];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) o2[v] = reinterpret_cast<const float4 *>(r0)[lig + G * v];
-                const float4 h2 = *reinterpret_cast<const float4 *>(r0 + D);
-                const float mn = fmaxf(m, h2.x);
-                const float a = __expf(m - mn), b = __expf(h2.x - mn);
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    o[v].x = fmaf(o[v].x, a, o2[v].x * b); o[v].y = fmaf(o[v].y, a, o2[v].y * b);
-                    o[v].z = fmaf(o[v].z, a, o2[v].z * b); o[v].w = fmaf(o[v].w, a, o2[v].w * b);
-                }
-                l = fmaf(l, a, h2.y * b);
-                m = mn;
-                more = h2.w;
-                ++nx;
-            }
-            float *dst = A.part + ((int64_t)t * A.bs + pair) * RS;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) reinterpret_cast<float4 *>(dst)[lig + G * v] = o[v];
-            if (lig == 0) *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, h1.z, 0.f);
-        }
-    }
-}
-
 }  // namespace
 
 namespace {
@@ -382,10 +330,10 @@ template <bool BF16>
 int fused_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap, const void *Z,
                  int64_t ldz, const float *q, int64_t ldq, const float *pe_tab, const float *pe_stat,
                  const void *wfold_packed, const float *bfold, const float *att, float *part, float *bnd,
-                 int32_t *uflag, int64_t units_cap, void *stream) {
+                 int64_t units_cap, void *stream) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && Z && q && pe_tab && pe_stat && wfold_packed &&
-                bfold && att && part && bnd && uflag && units_cap >= (ent_cap + 15) / 16);
+                bfold && att && part && bnd && units_cap >= (ent_cap + 15) / 16);
     LPF_REQUIRE(ldz >= D && ldq >= D && lpf_aligned16(entries) && lpf_aligned16(pe_tab) &&
                 lpf_aligned16(wfold_packed) && lpf_aligned16(part) && lpf_aligned16(bnd) && lpf_aligned16(Z) &&
                 (ldz * (BF16 ? 2 : 4)) % 16 == 0);
@@ -395,7 +343,7 @@ int fused_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *ent
         dbg = e ? atoi(e) : 0;
     }
     FusedArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), ldz, q, ldq,
-                pe_tab, pe_stat, static_cast<const float *>(wfold_packed), bfold, att, part, bnd, uflag, units_cap, dbg};
+                pe_tab, pe_stat, static_cast<const float *>(wfold_packed), bfold, att, part, bnd, units_cap, dbg};
     hipStream_t s = static_cast<hipStream_t>(stream);
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -434,11 +382,8 @@ int fused_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *ent
         default: return LPF_ERR_UNSUPPORTED;  // D = 256: the two-pass kernels
     }
 #undef LPF_FUSED
-    switch (D) {
-        case 32: hipLaunchKernelGGL(pair_fused_fixup_kernel<1>, dim3(1024), dim3(256), 0, s, a); break;
-        case 64: hipLaunchKernelGGL(pair_fused_fixup_kernel<2>, dim3(1024), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(pair_fused_fixup_kernel<4>, dim3(1024), dim3(256), 0, s, a); break;
-    }
+    // (the boundary records of segments that cross units are merged by the consumer, lpf_tail_chain_merge_f32, which
+    // finds them from the segment pointers)
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
@@ -449,18 +394,18 @@ extern "C" int lpf_pair_attention_fused_f32(int32_t D, int64_t bs, const int32_t
                                             int64_t ent_cap, const float *Z, int64_t ldz, const float *q,
                                             int64_t ldq, const float *pe_tab, const float *pe_stat,
                                             const float *wfold_packed, const float *bfold, const float *att,
-                                            float *part, float *bnd, int32_t *uflag, int64_t units_cap,
+                                            float *part, float *bnd, int64_t units_cap,
                                             void *stream) {
     return fused_launch<false>(D, bs, type_ptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab, pe_stat, wfold_packed, bfold,
-                               att, part, bnd, uflag, units_cap, stream);
+                               att, part, bnd, units_cap, stream);
 }
 
 extern "C" int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
                                              int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q,
                                              int64_t ldq, const float *pe_tab, const float *pe_stat,
                                              const void *wfold_packed_bf16, const float *bfold, const float *att,
-                                             float *part, float *bnd, int32_t *uflag, int64_t units_cap,
+                                             float *part, float *bnd, int64_t units_cap,
                                              void *stream) {
     return fused_launch<true>(D, bs, type_ptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab, pe_stat,
-                              wfold_packed_bf16, bfold, att, part, bnd, uflag, units_cap, stream);
+                              wfold_packed_bf16, bfold, att, part, bnd, units_cap, stream);
 }

@@ -86,12 +86,13 @@ __device__ __forceinline__ uint64_t lb_wave_sum(uint64_t v) {
 // lane calls it with the same k / own and gets the result): publishes own total, looks back 64 predecessors at a
 // time -- a participant that already carries an inclusive prefix ends the walk --, then publishes its own prefix.
 // (A 256-word window, four words per lane, measured slower: 326 vs 250 us -- the polling traffic grows with it.)
-__device__ __forceinline__ uint64_t lb_exclusive(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own, int lane) {
-    if (k == 0) {
-        if (lane == 0) lb_store(lb, epoch, 2, own);
-        return 0;
-    }
-    if (lane == 0) lb_store(lb + k, epoch, 1, own);
+__device__ __forceinline__ void lb_publish(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own, int lane) {
+    if (lane == 0) lb_store(lb + k, epoch, k == 0 ? 2 : 1, own);
+}
+// (second half: the walk.  A participant may do other work between the two halves -- nothing a predecessor needs is
+// held back by that, its own total is already out.)
+__device__ __forceinline__ uint64_t lb_lookback(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own, int lane) {
+    if (k == 0) return 0;
     uint64_t excl = 0;
     for (int64_t j = k - 1;; j -= 64) {
         const int64_t idx = j - lane;
@@ -108,6 +109,10 @@ __device__ __forceinline__ uint64_t lb_exclusive(uint64_t *lb, int64_t k, uint32
     }
     if (lane == 0) lb_store(lb + k, epoch, 2, excl + own);
     return excl;
+}
+__device__ __forceinline__ uint64_t lb_exclusive(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own, int lane) {
+    lb_publish(lb, k, epoch, own, lane);
+    return lb_lookback(lb, k, epoch, own, lane);
 }
 
 // fl32((fl32(fl32(p*t)+t)-t)/t) for t in {1,2}: p*1, p*2, x/1 and x/2 are exact, only the add and subtract round
@@ -307,7 +312,9 @@ struct RunArgs {
     int dbg;                   // tuning aid (LPF_SEL_DBG): bit 0 = no chained scan (placement is then wrong)
 };
 
+constexpr int S2_PARK = 384;  // kept entries of one item that can wait in LDS for the item's place in the output
 struct RunLds {
+    int4 pk[S2_PARK];           // parked entries: type 0 | type 1 | type 2, each in slot order
     int32_t loc[S2_ITEM + 1];   // slot (relative to the item) at which pair pf + i starts
     int32_t cand[S2_ITEM];      // node id in every slot: the adjacency runs double as searchable rows
     float va[S2_ITEM], vb[S2_ITEM];  // emitted values of the kept slots
@@ -318,7 +325,13 @@ struct RunLds {
     int64_t base[3];
     int64_t ticket;
     int32_t n_pairs;
+    int32_t run[3];             // kept entries per type of the item being built
+    // the parked item: what its deferred write-out needs once cand / code / loc belong to the next item
+    int64_t p_item, p_pf;
+    int32_t p_run[3], p_np, p_last, p_live;
+    int16_t ps[S2_WCACHE][4];   // {rank of the pair's first slot per type, pair starts in the item}
 };
+static_assert(sizeof(RunLds) <= 32 * 1024, "five workgroups per CU");
 
 // Descriptor fields of window pair w in registers: from the LDS cache (first S2_WCACHE pairs of the window) or from
 // global memory.  Only what a caller uses is actually loaded.
@@ -424,8 +437,60 @@ __device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, 
     vb = walk_a ? so : sw;
 }
 
+// Entries [p_lo, p_lo + S2_PARK) of the item described by L.p_* (type 0 | type 1 | type 2 order) from L.pk to their
+// final place; with `heads`, also the segment starts of the pairs that begin in the item and, from the last item, the
+// totals.  L.base holds the item's place per type.
+__device__ __forceinline__ void s2_write_out(const RunArgs &A, RunLds &L, int64_t bs, int tid, int p_lo, bool heads) {
+    const int r0 = L.p_run[0], r1 = L.p_run[1], r2 = L.p_run[2];
+    const int64_t b0 = L.base[0], b1 = L.base[1], b2 = L.base[2];
+    const int n = r0 + r1 + r2 - p_lo < S2_PARK ? r0 + r1 + r2 - p_lo : S2_PARK;
+    for (int i = tid; i < n; i += S2_THREADS) {
+        const int g = p_lo + i;
+        const int t = g < r0 ? 0 : (g < r0 + r1 ? 1 : 2);
+        const int64_t dst = t == 0 ? b0 + g : (t == 1 ? b1 + (g - r0) : b2 + (g - r0 - r1));
+        if (dst < A.ent_cap) {
+            A.entries[(int64_t)t * A.ent_cap + dst] = L.pk[i];
+        } else {
+            atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + 3), (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
+        }
+    }
+    if (!heads) return;
+    if (tid < L.p_np && L.ps[tid][3]) {
+        const int64_t p = L.p_pf + tid;
+        A.type_ptr[p] = (int32_t)(b0 + L.ps[tid][0]);
+        A.type_ptr[(bs + 1) + p] = (int32_t)(b1 + L.ps[tid][1]);
+        A.type_ptr[2 * (bs + 1) + p] = (int32_t)(b2 + L.ps[tid][2]);
+    }
+    if (tid == 0 && L.p_last) {
+        const int64_t t0 = b0 + r0, t1 = b1 + r1, t2 = b2 + r2;
+        A.type_ptr[bs] = (int32_t)t0;
+        A.type_ptr[(bs + 1) + bs] = (int32_t)t1;
+        A.type_ptr[2 * (bs + 1) + bs] = (int32_t)t2;
+        A.ctl[4] = t0; A.ctl[5] = t1; A.ctl[6] = t2;
+    }
+}
+
+// Write-out of the parked item, if there is one (whole workgroup; barriers at both ends).
+__device__ __forceinline__ void s2_finish_parked(const RunArgs &A, RunLds &L, uint32_t epoch, int64_t bs, int lane,
+                                                 int wave, int tid) {
+    __syncthreads();
+    if (L.p_live) {
+        if (wave < 3) {
+            const int64_t base = (A.dbg & 1) ? L.p_item * 64
+                                             : (int64_t)lb_lookback(A.run_lb + (int64_t)wave * A.item_cap, L.p_item,
+                                                                    epoch, (uint64_t)L.p_run[wave], lane);
+            if (lane == 0) L.base[wave] = base;
+        }
+        __syncthreads();
+        s2_write_out(A, L, bs, tid, 0, true);
+    }
+    __syncthreads();
+}
+
+// (forcing six workgroups per CU -- 80 registers, 32 bytes of scratch -- measured 176 us against 171 us at the natural
+// five)
 template <bool INDEXED>
-__global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A) {
+__global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs A) {
     __shared__ RunLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -434,6 +499,7 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
     if (n_items > A.item_cap) n_items = A.item_cap;
     const int64_t bs = A.bs;
     const uint32_t epoch = (uint32_t)A.ctl[8];  // launch number, written by the plan kernel
+    if (tid == 0) L.p_live = 0;
 
     while (true) {
         __syncthreads();  // the previous item's LDS image is no longer needed
@@ -537,9 +603,8 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
         __syncthreads();
 
         if (stamp) g_sel_stamps[it * 8 + 3] = (long long)__builtin_amdgcn_s_memtime();
-        // ---- phase C: ranks inside the item, then the item's base per type through the chained scan
-        if (wave < 3) {  // wavefront t: exclusive scan of type t over the (round, wave) groups in slot order, then the
-                         // chained scan over the items
+        // ---- phase C: ranks inside the item; the item's totals go out to the chained scan at once
+        if (wave < 3) {  // wavefront t: exclusive scan of type t over the (round, wave) groups in slot order
             constexpr int NG = S2_ROUNDS * S2_WAVES;
             const int v = lane < NG ? L.cnt[lane][wave] : 0;
             int x = v;
@@ -550,53 +615,62 @@ __global__ __launch_bounds__(S2_THREADS) void select_run_kernel(const RunArgs A)
             }
             if (lane < NG) L.cnt[lane][wave] = x - v;
             const int run = __shfl(x, NG - 1, 64);
-            const int64_t base = (A.dbg & 1) ? it * 64 : (int64_t)lb_exclusive(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)run, lane);
+            if (lane == 0) L.run[wave] = run;
+            if (!(A.dbg & 1)) lb_publish(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)run, lane);
+        }
+        // ---- phase D, deferred: the item's place in the output depends on every earlier item, and the slowest of the
+        //      ~1300 in flight decides when that is known.  So the kept entries are parked in LDS, the workgroup goes
+        //      on to type the next item, and only then asks for the parked item's place (by then an answer that
+        //      needs no waiting) and writes it out.
+        s2_finish_parked(A, L, epoch, bs, lane, wave, tid);  // (starts and ends with a barrier)
+        if (stamp) { g_sel_stamps[it * 8 + 4] = (long long)__builtin_amdgcn_s_memtime(); g_sel_stamps[it * 8 + 6] = n_here; g_sel_stamps[it * 8 + 7] = np; }
+        const int run0 = L.run[0], run1 = L.run[1], run2 = L.run[2];
+        const int n_kept = run0 + run1 + run2;
+        const bool now = n_kept > S2_PARK;  // (does not fit: wait for the place here and write in several passes)
+        if (tid == 0) {
+            L.p_item = it; L.p_pf = pf; L.p_np = np; L.p_last = (c0 + n_here == total);
+            L.p_run[0] = run0; L.p_run[1] = run1; L.p_run[2] = run2;
+            L.p_live = now ? 0 : 1;
+        }
+        if (tid < S2_WCACHE) L.ps[tid][3] = 0;
+        if (now && wave < 3) {
+            const int64_t base = (A.dbg & 1) ? it * 64 : (int64_t)lb_lookback(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)L.run[wave], lane);
             if (lane == 0) L.base[wave] = base;
         }
         __syncthreads();
-
-        if (stamp) { g_sel_stamps[it * 8 + 4] = (long long)__builtin_amdgcn_s_memtime(); g_sel_stamps[it * 8 + 6] = n_here; g_sel_stamps[it * 8 + 7] = np; }
-        // ---- phase D: entries to their final place, segment starts of the pairs that begin here, totals
+        for (int pass = 0; pass * S2_PARK < (n_kept > 0 ? n_kept : 1); ++pass) {
+            const int p_lo = pass * S2_PARK;
 #pragma unroll 1
-        for (int r = 0; r < S2_ROUNDS; ++r) {
-            const int l = tid + S2_THREADS * r;
-            const bool live = l < n_here;
-            const int cf = live ? L.code[l] : 0;
-            const int code = cf & 3;
-            const uint64_t b0 = __ballot(code == 1), b1 = __ballot(code == 2), b2 = __ballot(code == 3);
-            if (!live) continue;
-            const int32_t *gp = L.cnt[r * S2_WAVES + wave];
-            const int64_t rank0 = L.base[0] + gp[0] + __popcll(b0 & lt_mask);
-            const int64_t rank1 = L.base[1] + gp[1] + __popcll(b1 & lt_mask);
-            const int64_t rank2 = L.base[2] + gp[2] + __popcll(b2 & lt_mask);
-            const int64_t p = pf + L.win[l];
-            if (code) {
-                const int t = code - 1;
-                const int64_t dst = t == 0 ? rank0 : (t == 1 ? rank1 : rank2);
-                if (dst < A.ent_cap) {
-                    A.entries[(int64_t)t * A.ent_cap + dst] =
-                        make_int4((int32_t)((uint32_t)p | ((cf & 4) ? S2_FROM_B : 0u)), L.cand[l],
-                                  __float_as_int(L.va[l]), __float_as_int(L.vb[l]));
-                } else {
-                    atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + 3),
-                             (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
+            for (int r = 0; r < S2_ROUNDS; ++r) {
+                const int l = tid + S2_THREADS * r;
+                const bool live = l < n_here;
+                const int cf = live ? L.code[l] : 0;
+                const int code = cf & 3;
+                const uint64_t b0 = __ballot(code == 1), b1 = __ballot(code == 2), b2 = __ballot(code == 3);
+                if (!live) continue;
+                const int32_t *gp = L.cnt[r * S2_WAVES + wave];
+                const int k0 = gp[0] + __popcll(b0 & lt_mask);
+                const int k1 = gp[1] + __popcll(b1 & lt_mask);
+                const int k2 = gp[2] + __popcll(b2 & lt_mask);
+                const int w = L.win[l];
+                if (code) {
+                    const int pos = (code == 1 ? k0 : (code == 2 ? run0 + k1 : run0 + run1 + k2)) - p_lo;
+                    if (pos >= 0 && pos < S2_PARK)
+                        L.pk[pos] = make_int4((int32_t)((uint32_t)(pf + w) | ((cf & 4) ? S2_FROM_B : 0u)), L.cand[l],
+                                              __float_as_int(L.va[l]), __float_as_int(L.vb[l]));
+                }
+                if (pass == 0 && l == L.loc[w]) {  // first slot of the pair: its three segment starts
+                    L.ps[w][0] = (int16_t)k0; L.ps[w][1] = (int16_t)k1; L.ps[w][2] = (int16_t)k2; L.ps[w][3] = 1;
                 }
             }
-            if (l == L.loc[L.win[l]]) {  // first slot of the pair: its three segment starts
-                A.type_ptr[p] = (int32_t)rank0;
-                A.type_ptr[(bs + 1) + p] = (int32_t)rank1;
-                A.type_ptr[2 * (bs + 1) + p] = (int32_t)rank2;
-            }
-            if (c0 + l == total - 1) {
-                const int64_t t0 = rank0 + (code == 1), t1 = rank1 + (code == 2), t2 = rank2 + (code == 3);
-                A.type_ptr[bs] = (int32_t)t0;
-                A.type_ptr[(bs + 1) + bs] = (int32_t)t1;
-                A.type_ptr[2 * (bs + 1) + bs] = (int32_t)t2;
-                A.ctl[4] = t0; A.ctl[5] = t1; A.ctl[6] = t2;
-            }
+            if (!now) break;  // parked: written out after the next item has been typed (or at the end)
+            __syncthreads();
+            s2_write_out(A, L, bs, tid, p_lo, pass == 0);
+            __syncthreads();
         }
         if (stamp) g_sel_stamps[it * 8 + 5] = (long long)__builtin_amdgcn_s_memtime();
     }
+    s2_finish_parked(A, L, epoch, bs, lane, wave, tid);
 }
 
 // ------------------------------------------------------------------------------------------- export

@@ -36,6 +36,8 @@ struct TailArgs {
     // lpf_pair_attention_fused_f32 -- out = sum_t e^{m_t - M} acc_t / (sum_t e^{m_t - M} l_t + 1e-16) + bias -- and the
     // count features come from the int32 segment pointers of the selection
     const float *part;              // [3][M][NA + 4]: acc[NA], m, l, -, -
+    const float *bnd;               // [3][units_cap][2][NA + 4]: boundary records of segments that cross 16-entry units
+    int64_t units_cap;
     const int32_t *type_ptr;        // [3][M + 1]
     const float *att_bias;          // [NA]
     const int64_t *sel_ctl;         // selection control block: word 3 != 0 => the batch did not fit, scores = NaN
@@ -184,43 +186,82 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
 #pragma unroll
         for (int c = 0; c < TPWA; ++c) accA[c] += (fbase + 16 * c < A.NA) ? ad[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
     } else {
-        // merge of the (up to three) per-type records of this pair: a type takes part iff its segment is non-empty
+        // Merge of this pair's attention records (online-softmax states {acc, m, l}).  A (pair, type) segment
+        // [lo, hi) of the type's entry region that lies inside one 16-entry unit left ONE record in part[t][pair];
+        // one that crosses units left a boundary record per unit it touches -- the head in slot 1 of its first unit,
+        // then slot 0 of every following unit (pair_fused.hip) -- whose addresses follow from lo and hi alone.
+        // All addresses are known before the first record arrives, so the reads go out in batches (the three segment
+        // pointers, the three first records, then the remaining boundary records two or four at a time): the record region is
+        // hundreds of MB touched sparsely, every read is a long-latency miss, and there are only two wavefronts per
+        // SIMD here to hide it.
         const int fbase = 16 * half * TPWA + 4 * q;
         const int64_t rs = A.NA + 4;
-        float mt[3], lt[3], wt[3];
-        float mx = -INFINITY;
+        float mx = -INFINITY, den = 0.f;
+        f32x4 v[TPWA];
+#pragma unroll
+        for (int c = 0; c < TPWA; ++c) v[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto fetch = [&](const float *rec, f32x4 &h, f32x4 *b) __attribute__((always_inline)) {
+            h = *reinterpret_cast<const f32x4 *>(rec + A.NA);
+#pragma unroll
+            for (int c = 0; c < TPWA; ++c) {
+                const int f0 = fbase + 16 * c;
+                b[c] = *reinterpret_cast<const f32x4 *>(rec + (f0 < A.NA ? f0 : 0));
+            }
+        };
+        auto merge = [&](const f32x4 &h, const f32x4 *b) __attribute__((always_inline)) {
+            const float mn = fmaxf(mx, h[0]);
+            const float sa = __expf(mx - mn), sb = __expf(h[0] - mn);
+            den = fmaf(den, sa, h[1] * sb);
+#pragma unroll
+            for (int c = 0; c < TPWA; ++c) v[c] = v[c] * sa + b[c] * sb;
+            mx = mn;
+        };
+        int lo[3], hi[3], n_p[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int32_t *tp = A.type_ptr + (int64_t)t * (A.M + 1) + mm;
-            seg_cnt[t] = tp[1] - tp[0];
-            mt[t] = -INFINITY; lt[t] = 0.f;
-            if (seg_cnt[t] > 0) {
-                const f32x4 h = *reinterpret_cast<const f32x4 *>(A.part + ((int64_t)t * A.M + mm) * rs + A.NA);
-                mt[t] = h[0]; lt[t] = h[1];
-            }
-            mx = fmaxf(mx, mt[t]);
+            lo[t] = tp[0];
+            hi[t] = tp[1];
         }
-        float den = 1e-16f;
+        {
+            f32x4 h0[3], b0[3][TPWA];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            wt[t] = seg_cnt[t] > 0 ? __expf(mt[t] - mx) : 0.f;
-            den = fmaf(wt[t], lt[t], den);
+            for (int t = 0; t < 3; ++t) {
+                seg_cnt[t] = hi[t] - lo[t];
+                // (a segment past the region: sel_ctl[3] is set and the row becomes NaN below)
+                const bool some = hi[t] > lo[t] && ((hi[t] - 1) >> 4) < A.units_cap;
+                n_p[t] = some ? ((hi[t] - 1) >> 4) - (lo[t] >> 4) + 1 : 0;
+                const float *rec = n_p[t] > 1 ? A.bnd + ((((int64_t)t * A.units_cap + (lo[t] >> 4)) * 2) + 1) * rs
+                                              : A.part + ((int64_t)t * A.M + mm) * rs;
+                fetch(rec, h0[t], b0[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (n_p[t] > 0) merge(h0[t], b0[t]);
         }
-        const float inv = 1.0f / den;
+        const int r0 = n_p[0] > 1 ? n_p[0] - 1 : 0, r1 = n_p[1] > 1 ? n_p[1] - 1 : 0, r2 = n_p[2] > 1 ? n_p[2] - 1 : 0;
+        const int n_rest = r0 + r1 + r2;
+        constexpr int NB = TPWA >= 4 ? 2 : 4;  // (registers: the kernel is held to 128)
+#pragma unroll 1
+        for (int k0 = 0; k0 < n_rest; k0 += NB) {
+            f32x4 hh[NB], bb[NB][TPWA];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = k0 + i < n_rest ? k0 + i : n_rest - 1;
+                const int t = k < r0 ? 0 : (k < r0 + r1 ? 1 : 2);
+                const int jj = k - (t == 0 ? 0 : (t == 1 ? r0 : r0 + r1));
+                const int ut = t == 0 ? lo[0] >> 4 : (t == 1 ? lo[1] >> 4 : lo[2] >> 4);
+                fetch(A.bnd + (((int64_t)t * A.units_cap + ut + 1 + jj) * 2) * rs, hh[i], bb[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (k0 + i < n_rest) merge(hh[i], bb[i]);
+        }
+        const float inv = 1.0f / (den + 1e-16f);
 #pragma unroll
         for (int c = 0; c < TPWA; ++c) {
             const int f0 = fbase + 16 * c;
-            if (f0 < A.NA) {
-                f32x4 v = *reinterpret_cast<const f32x4 *>(A.att_bias + f0);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    if (seg_cnt[t] > 0) {
-                        const f32x4 r = *reinterpret_cast<const f32x4 *>(A.part + ((int64_t)t * A.M + mm) * rs + f0);
-                        v += r * (wt[t] * inv);
-                    }
-                }
-                accA[c] = v;
-            }
+            if (f0 < A.NA) accA[c] = v[c] * inv + *reinterpret_cast<const f32x4 *>(A.att_bias + f0);
         }
     }
     {
@@ -354,7 +395,7 @@ extern "C" int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const 
                 lpf_aligned16(w_dot));
     TailArgs a{M, G + D, ldg, 3 * D + 4, G, ldg, wA_packed, lnA_g, lnA_b, D, counts, ldc, wB_packed, bB, lnB_g,
                lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
-               nullptr, nullptr, nullptr, nullptr, n_counts};
+               nullptr, nullptr, 0, nullptr, nullptr, nullptr, n_counts};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);
@@ -364,14 +405,14 @@ extern "C" int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const 
     }
 }
 
-extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, const float *part,
-                                        const int32_t *type_ptr, const float *att_bias, const float *lnA_g,
+extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, const float *part, const float *bnd,
+                                        int64_t units_cap, const int32_t *type_ptr, const float *att_bias, const float *lnA_g,
                                         const float *lnA_b, const float *wB_packed, const float *bB, const float *lnB_g,
                                         const float *lnB_b, const float *r_e, int64_t ldre, const float *wC_packed,
                                         const float *bC, const float *w_dot, const float *b_dot,
                                         const int64_t *sel_ctl, float *logit, float *prob, void *stream) {
     if (M == 0) return LPF_OK;
-    LPF_REQUIRE(M > 0 && part && type_ptr && att_bias && lnA_g && lnA_b && wB_packed && bB && lnB_g && lnB_b && r_e &&
+    LPF_REQUIRE(M > 0 && part && bnd && units_cap > 0 && lpf_aligned16(bnd) && type_ptr && att_bias && lnA_g && lnA_b && wB_packed && bB && lnB_g && lnB_b && r_e &&
                 wC_packed && bC && w_dot && b_dot && (logit || prob));
     LPF_REQUIRE((n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D);
     LPF_REQUIRE(lpf_aligned16(part) && lpf_aligned16(att_bias) && lpf_aligned16(r_e) && lpf_aligned16(wB_packed) &&
@@ -379,7 +420,7 @@ extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, 
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0, wB_packed, bB, lnB_g,
                lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
-               part, type_ptr, att_bias, sel_ctl, n_counts};
+               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);

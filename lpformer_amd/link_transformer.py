@@ -1090,26 +1090,26 @@ class LinkTransformer(nn.Module):
                 units_cap = (ws.ent_cap + 15) // 16 + 1
                 part = self._workspace("att_part", 3 * bs * rs, torch.float32, st)
                 bnd = self._workspace("att_bnd", 3 * units_cap * 2 * rs, torch.float32, st)
-                uflag = self._workspace("att_uflag", 3 * units_cap, torch.int32, st)
                 with KernelTimer.span("pair_attention_fused"):
                     if self.precision == "bf16":
                         zb = self._z_bf16(z)
                         check(lib.lpf_pair_attention_fused_bf16(
                             d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zb), zb.stride(0), ptr(q),
                             q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed_bf16"]),
-                            ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), ptr(uflag), units_cap, st),
+                            ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st),
                             "lpf_pair_attention_fused_bf16")
                     else:
                         check(lib.lpf_pair_attention_fused_f32(
                             d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q),
                             q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]),
-                            ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), ptr(uflag), units_cap, st),
+                            ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st),
                             "lpf_pair_attention_fused_f32")
                 tt = self._tail_tables(score_func, a, c)
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):
                     check(lib.lpf_tail_chain_merge_f32(
-                        bs, d, self.count_dim, ptr(part), ptr(ws.type_ptr), ptr(self.att_layers[0].att.bias),
+                        bs, d, self.count_dim, ptr(part), ptr(bnd), units_cap, ptr(ws.type_ptr),
+                        ptr(self.att_layers[0].att.bias),
                         ptr(tt["lnA_g"]), ptr(tt["lnA_b"]), ptr(tt["wB"]), ptr(tt["bB"]), ptr(tt["lnB_g"]),
                         ptr(tt["lnB_b"]), ptr(r), r.stride(0), ptr(tt["wC"]), ptr(tt["bC"]), ptr(tt["w_dot"]),
                         ptr(tt["b_dot"]), ptr(ws.ctl), ptr(res) if logits else None, None if logits else ptr(res),
