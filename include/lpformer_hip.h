@@ -177,12 +177,15 @@ int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t *offs, int
  *   val_*  the rows PPR values are looked up in: with adj_selfp (evaluation) the prefiltered one-hop index P1
  *          (lpf_ppr_filter_*, mode 1) -- the PPR of a node to its own neighbours then comes from adj_selfp --,
  *          without it (adjacency override of the training loop) the raw PPR matrix
- *   BLOCKED indexes (the P1 rows with adj_selfp, the T0 rows always): every row padded to a multiple of 16 entries
- *          (column INT32_MAX, value 0), row pointers counting padded entries, *_len[i] = real entries of row i,
- *          *_cv = interleaved {int32 column, float value} pairs (a 16-entry block = one aligned 128-byte line),
- *          *_skip[b] = last column of block b (+ 4 spare entries): a lookup reads the row's skip entries, then one
- *          block that carries the value -- two memory round trips instead of a binary search plus a value load.
- *          Without adj_selfp (adjacency override) val_col / val_val are the raw PPR rows, plain sorted CSR.
+ *   BLOCKED index (the T0 rows): every row padded to a multiple of 16 entries (column INT32_MAX, value 0), row
+ *          pointers counting padded entries, t0_len[i] = real entries of row i, t0_cv = interleaved {int32 column,
+ *          float value} pairs (a 16-entry block = one aligned 128-byte line), t0_skip[b] = last column of block b
+ *          (+ 40 spare entries): a lookup reads the row's skip entries, then one block that carries the value.
+ *   HASHED index (the P1 rows with adj_selfp): row i owns val_len[i] buckets of 16 {column, value} entries (val_cv,
+ *          one aligned 128-byte line per bucket, unused entries column INT32_MAX), val_rowptr counting entries
+ *          (16 per bucket); entry (i, c) sits in bucket  mulhi_u32(c * 2654435761 mod 2^32, val_len[i])  and no
+ *          bucket overflows (the builder grows a row's bucket count until that holds): ONE memory round trip per
+ *          lookup.  Without adj_selfp (adjacency override) val_col / val_val are the raw PPR rows, plain sorted CSR.
  *   adjx_* UNMASKED adjacency for the >1-hop exclusion (link_transformer.py:443); NULL = the typing adjacency
  * Result: per type t a dense region entries[t*ent_cap ..) of {pair | from_N(b) << 31, node, pa, pb} records ordered by
  * (pair, candidate slot); segment of pair k = [type_ptr[t*(bs+1)+k], type_ptr[t*(bs+1)+k+1]); the one-hop segment
@@ -201,7 +204,7 @@ int lpf_select_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t 
 int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair, int64_t item_cap,
                    int64_t *ctl, uint64_t *run_lb, const int32_t *adj_col, const float *adj_selfp,
                    const int32_t *adjx_col, const int32_t *val_col, const float *val_val, const void *val_cv,
-                   const int32_t *val_skip, const void *t0_cv, const int32_t *t0_skip, float th_cn, float th_1hop,
+                   const void *t0_cv, const int32_t *t0_skip, float th_cn, float th_1hop,
                    float th_non1hop, int32_t *type_ptr, void *entries, int64_t ent_cap, int32_t grid_blocks,
                    void *stream);
 /* The reference's layout from the regions above: all CN entries sorted by (pair, node), then all 1-hop (the two runs

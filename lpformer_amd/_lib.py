@@ -34,7 +34,7 @@ HIP_PROTOTYPES = {
     "lpf_select_compact": [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lpf_select_plan_blocks": [i64],
     "lpf_select_plan": [i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
-    "lpf_select_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, i64, i32,
+    "lpf_select_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, i64, i32,
                        vp],
     "lpf_select_export": [i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],

@@ -191,6 +191,29 @@ __device__ __forceinline__ bool s2_lookup_blocked(const int2 *__restrict__ cv, c
     return eq;
 }
 
+// Lookup in a row of a HASHED index (lpformer_amd/graph.py HashedIndex): the row owns n_buckets buckets of 16
+// {column, value} entries, the key's bucket follows from its hash, and the builder made sure no bucket overflows -- one
+// memory round trip and no search (the blocked layout above needs the row's skip entries first: two dependent round
+// trips and about twice the instructions, and the instruction issue is what select_run_kernel runs at).
+__device__ __forceinline__ bool s2_lookup_hashed(const int2 *__restrict__ cv, int64_t row0, int n_buckets, int32_t key,
+                                                 float &val) {
+    if (n_buckets <= 0) return false;
+    const uint32_t b = __umulhi((uint32_t)key * 2654435761u, (uint32_t)n_buckets);
+    const int4 *blk = reinterpret_cast<const int4 *>(cv + row0 + 16 * (int64_t)b);  // {col, val, col, val} x 8
+    bool eq = false;
+    int bits = 0;
+    int4 bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bv[q] = blk[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (bv[q].x == key) { eq = true; bits = bv[q].y; }
+        if (bv[q].z == key) { eq = true; bits = bv[q].w; }
+    }
+    val = __int_as_float(bits);
+    return eq;
+}
+
 // ------------------------------------------------------------------------------------------- plan
 __global__ __launch_bounds__(S2_THREADS) void select_plan_kernel(
     int64_t bs, const int64_t *__restrict__ batch, int64_t batch_ld, int64_t n_nodes,
@@ -301,8 +324,7 @@ struct RunArgs {
     const int32_t *adjx_col;   // unmasked adjacency (== adj_col when the typing adjacency is the unmasked one)
     const int32_t *val_col;    // general path: raw PPR rows (plain sorted CSR)
     const float *val_val;
-    const int2 *val_cv;        // indexed path: P1 index, blocked {column, value} layout
-    const int32_t *val_skip;
+    const int2 *val_cv;        // indexed path: P1 index, hashed buckets of 16 {column, value} entries
     const int2 *t0_cv;         // T0 index, blocked layout (both paths)
     const int32_t *t0_skip;
     float th_cn, th_1, th_n;
@@ -375,7 +397,8 @@ __device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, 
         // position of x in the OTHER endpoint's adjacency run: in LDS when that run lies inside the item
         const int o_lo = from_a ? s0 + dA : s0, o_n = from_a ? dB : dA;
         int j;
-        if (s0 > -(1 << 30) && o_lo >= 0 && o_lo + o_n <= n_here) j = s2_find(L.cand + o_lo, o_n, x);
+        if (A.dbg & 8) j = -1;
+        else if (s0 > -(1 << 30) && o_lo >= 0 && o_lo + o_n <= n_here) j = s2_find(L.cand + o_lo, o_n, x);
         else j = s2_find(A.adj_col + (from_a ? d.rb0 : d.ra0), o_n, x);
         if (!from_a && j >= 0) return;  // a node of N(b) that is also in N(a) is emitted through N(a)
         const bool cn = from_a && j >= 0;
@@ -384,9 +407,9 @@ __device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, 
             own = own_in;
             if (cn) {
                 other = A.selfp[d.rb0 + j];
-            } else if (s2_round_trip(own, false) >= A.th_1) {  // otherwise it is dropped anyway
+            } else if (s2_round_trip(own, false) >= A.th_1 && !(A.dbg & 4)) {  // otherwise it is dropped anyway
                 float v;
-                if (s2_lookup_blocked(A.val_cv, A.val_skip, from_a ? d.pb0 : d.pa0, from_a ? d.nPb : d.nPa, x, v))
+                if (s2_lookup_hashed(A.val_cv, from_a ? d.pb0 : d.pa0, from_a ? d.nPb : d.nPa, x, v))
                     other = v;
             }
         } else {  // general path: both values from the raw PPR rows (absent entries read as 0)
@@ -487,8 +510,9 @@ __device__ __forceinline__ void s2_finish_parked(const RunArgs &A, RunLds &L, ui
     __syncthreads();
 }
 
-// (forcing six workgroups per CU -- 80 registers, 32 bytes of scratch -- measured 176 us against 171 us at the natural
-// five)
+// (five workgroups per CU = 96 registers.  Forcing six -- 80 registers, 32 bytes of scratch -- measured slower, and
+// so did an index lookup shared by eight lanes per slot, one 128-byte line per instruction and group instead of one per
+// lane: 177 us against 133 us, the extra LDS traffic and lane shuffling cost more than the L1 line look-ups saved.)
 template <bool INDEXED>
 __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs A) {
     __shared__ RunLds L;
@@ -794,7 +818,7 @@ extern "C" int lpf_select_plan(int64_t bs, const int64_t *batch, int64_t batch_l
 extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair,
                               int64_t item_cap, int64_t *ctl, uint64_t *run_lb, const int32_t *adj_col,
                               const float *adj_selfp, const int32_t *adjx_col, const int32_t *val_col,
-                              const float *val_val, const void *val_cv, const int32_t *val_skip, const void *t0_cv,
+                              const float *val_val, const void *val_cv, const void *t0_cv,
                               const int32_t *t0_skip, float th_cn, float th_1hop,
                               float th_non1hop, int32_t *type_ptr, void *entries, int64_t ent_cap,
                               int32_t grid_blocks, void *stream) {
@@ -802,7 +826,7 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && adj_col && type_ptr &&
                 entries && ent_cap > 0 && lpf_aligned16(entries) && lpf_aligned16(desc));
     // indexed path: self-PPR + blocked P1 index; general path: raw PPR rows
-    LPF_REQUIRE(adj_selfp ? (val_cv && val_skip && lpf_aligned16(val_cv) && lpf_aligned16(val_skip))
+    LPF_REQUIRE(adj_selfp ? (val_cv && lpf_aligned16(val_cv))
                           : (val_col && val_val));
     LPF_REQUIRE((t0_cv == nullptr) == (t0_skip == nullptr) && lpf_aligned16(t0_cv) && lpf_aligned16(t0_skip));
     RunArgs a;
@@ -810,7 +834,7 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     a.item_cap = item_cap; a.ctl = ctl; a.run_lb = run_lb;
     a.adj_col = adj_col; a.selfp = adj_selfp; a.adjx_col = adjx_col ? adjx_col : adj_col;
     a.val_col = val_col; a.val_val = val_val;
-    a.val_cv = static_cast<const int2 *>(val_cv); a.val_skip = val_skip;
+    a.val_cv = static_cast<const int2 *>(val_cv);
     a.t0_cv = static_cast<const int2 *>(t0_cv); a.t0_skip = t0_skip;
     a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop;
     a.type_ptr = type_ptr; a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
@@ -820,7 +844,19 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
         dbg = e ? atoi(e) : 0;
     }
     a.dbg = dbg;
-    int64_t blocks = grid_blocks > 0 ? grid_blocks : 2048;
+    // one resident round of workgroups (they are persistent; more than fit only queue up behind the others:
+    // 1024 / 1280 / 2048 / 4096 workgroups measured 132 / 132 / 138 / 158 us on 256 CUs)
+    static int resident = 0;
+    if (resident == 0) {
+        int dev = 0, occ = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, select_run_kernel<true>, S2_THREADS, 0) != hipSuccess ||
+            occ < 1)
+            occ = 4;
+        resident = prop.multiProcessorCount * occ;
+    }
+    int64_t blocks = grid_blocks > 0 ? grid_blocks : resident;
     if (blocks > item_cap) blocks = item_cap;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (adj_selfp) hipLaunchKernelGGL(select_run_kernel<true>, dim3((unsigned)blocks), dim3(S2_THREADS), 0, s, a);

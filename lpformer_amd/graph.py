@@ -255,10 +255,74 @@ def ppr_filter_device_blocked(ppr: DeviceCSR, mode: int, theta: float) -> Blocke
                                        float(theta), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), st),
                "lpf_ppr_filter_fill")
     skip = col.view(-1, BLOCK)[:, BLOCK - 1].contiguous()
-    # four extra entries: the lookup reads skip entries in aligned groups of four
-    skip = torch.cat([skip, torch.full((4,), 2**31 - 1, dtype=torch.int32, device=dev)])
+    # spare entries: a lookup reads 32 skip entries from the aligned group its window starts in
+    skip = torch.cat([skip, torch.full((40,), 2**31 - 1, dtype=torch.int32, device=dev)])
     cv = torch.stack([col, val.view(torch.int32)], dim=1).contiguous()
     return BlockedIndex(rowptr, col, val, cv, lens[:n].to(torch.int32), skip, n)
+
+
+HASH_MUL = 2654435761  # Fibonacci hashing constant (2^32 / golden ratio)
+
+
+@dataclass
+class HashedIndex:
+    """A filtered PPR index (P1) laid out for ONE-step lookups (csrc/select2.hip, s2_lookup_hashed): row i owns
+    ``len[i]`` buckets of 16 {column, value bits} entries (one aligned 128-byte line each, empty entries carry column
+    INT32_MAX), entry (i, c) lives in bucket ``((c * HASH_MUL mod 2^32) * len[i]) >> 32`` of the row.  Bucket counts
+    start at one per eight entries and grow for the rows where some bucket would hold more than 16, so a lookup never
+    has to look further than its bucket.  ``rowptr`` counts ENTRIES (16 per bucket), like a blocked index."""
+    rowptr: torch.Tensor   # int64 [n+1]
+    cv: torch.Tensor       # int32 [16 * buckets, 2]
+    len: torch.Tensor      # int32 [n]: buckets per row
+    n: int
+
+    def to_host_compact(self) -> CSR:
+        """The index as a plain sorted CSR (tests, statistics)."""
+        cv = self.cv.cpu().numpy()
+        rp = self.rowptr.cpu().numpy()
+        row = np.repeat(np.arange(self.n), np.diff(rp))
+        live = cv[: row.size, 0] != 2**31 - 1
+        row, col, val = row[live], cv[: row.size][live, 0], cv[: row.size][live, 1].copy().view(np.float32)
+        order = np.lexsort((col, row))
+        rowptr = np.zeros(self.n + 1, np.int64)
+        np.cumsum(np.bincount(row, minlength=self.n), out=rowptr[1:])
+        return CSR(rowptr, col[order].copy(), val[order].copy(), self.n)
+
+
+def hash_index_device(p: DeviceCSR) -> HashedIndex:
+    """Bucketised layout of a device-resident sorted CSR (see HashedIndex).  One-time, a few torch passes."""
+    dev, n = p.rowptr.device, p.n
+    ln = p.rowptr[1:] - p.rowptr[:-1]
+    nnz = int(p.rowptr[-1].item())
+    col = p.col[:nnz].long()
+    row = torch.repeat_interleave(torch.arange(n, device=dev), ln)
+    h = (col * HASH_MUL) & 0xFFFFFFFF
+    nbk = (ln + 7) // 8
+    for _ in range(64):
+        base = torch.cumsum(nbk, 0) - nbk
+        total = int(nbk.sum().item())
+        key = base[row] + ((h * nbk[row]) >> 32)
+        cnt = torch.bincount(key, minlength=max(total, 1))
+        over = cnt > BLOCK
+        if nnz == 0 or not bool(over.any().item()):
+            break
+        bucket_row = torch.repeat_interleave(torch.arange(n, device=dev), nbk)
+        bad = torch.unique(bucket_row[over[:total]])
+        nbk[bad] = nbk[bad] * 3 // 2 + 1
+    else:
+        raise RuntimeError("hash_index_device: bucket sizes did not settle")
+    cv = torch.zeros((max(total, 1) * BLOCK, 2), dtype=torch.int32, device=dev)
+    cv[:, 0] = 2**31 - 1
+    if nnz:
+        order = torch.argsort(key, stable=True)
+        key_s = key[order]
+        start = torch.cumsum(cnt, 0) - cnt
+        pos = key_s * BLOCK + (torch.arange(nnz, device=dev) - start[key_s])
+        cv[pos, 0] = p.col[:nnz][order]
+        cv[pos, 1] = p.val[:nnz].view(torch.int32)[order]
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(nbk * BLOCK, 0, out=rowptr[1:])
+    return HashedIndex(rowptr, cv.contiguous(), nbk.to(torch.int32), n)
 
 
 def self_ppr_device(adj: DeviceCSR, ppr: DeviceCSR) -> torch.Tensor:

@@ -556,7 +556,7 @@ class LinkTransformer(nn.Module):
         if kind == "t0":    # per-model indexes: filtered on the device from the resident PPR matrix
             g = graph.ppr_filter_device_blocked(self._device_graph("ppr", obj), 0, self.thresh_non1hop)
         elif kind == "p1":
-            g = graph.ppr_filter_device_blocked(self._device_graph("ppr", obj), 1, self.thresh_1hop)
+            g = graph.hash_index_device(graph.ppr_filter_device(self._device_graph("ppr", obj), 1, self.thresh_1hop))
         elif isinstance(obj, graph.CSR) and kind in ("mask", "ppr"):
             if kind == "ppr" and obj.val is None:
                 raise ValueError("the PPR matrix needs values")
@@ -759,7 +759,6 @@ class LinkTransformer(nn.Module):
                                      None if selfp is not None else ptr(val.col),
                                      None if selfp is not None else ptr(val.val),
                                      ptr(val.cv) if selfp is not None else None,
-                                     ptr(val.skip) if selfp is not None else None,
                                      ptr(t0.cv) if t0 is not None else None,
                                      ptr(t0.skip) if t0 is not None else None, float(self.thresh_cn),
                                      float(self.thresh_1hop), float(self.thresh_non1hop), ptr(ws.type_ptr),

@@ -196,3 +196,35 @@ def test_encoder_plan_cost_model():
     assert LD.encoder_plan(10.0, 2_927_963, 64, 3, 8, allgather_gbps=1000.0)["mode"] == "sharded"
     assert LD.encoder_plan(10.0, 2_927_963, 64, 3, 8, allgather_gbps=200.0)["mode"] == "replicated"
     assert LD.encoder_plan(5.0, 1000, 64, 3, 1, allgather_gbps=1.0)["mode"] == "replicated"
+
+
+def test_hashed_index_layout():
+    """graph.hash_index_device: every entry sits in the bucket its hash names, no bucket holds more than 16, the
+    compact view gives the input back (the builder is plain torch, so it runs on the CPU too)."""
+    import torch
+    from lpformer_amd import graph
+    rng = np.random.default_rng(5)
+    n = 300
+    lens = rng.integers(0, 90, n)
+    lens[7] = 0
+    lens[11] = 2000                     # a long row
+    cols, rp = [], np.zeros(n + 1, np.int64)
+    for i in range(n):
+        # (row 12: columns that all hash into few buckets at first -- forces the bucket count of the row to grow)
+        c = np.sort(rng.choice(200_000, lens[i], replace=False)) if i != 12 else np.arange(60) * 4096
+        lens[i] = c.size
+        cols.append(c)
+        rp[i + 1] = rp[i] + c.size
+    col = np.concatenate(cols).astype(np.int32)
+    val = rng.random(col.size).astype(np.float32)
+    p = graph.DeviceCSR(torch.from_numpy(rp), torch.from_numpy(col), torch.from_numpy(val), n)
+    h = graph.hash_index_device(p)
+    back = h.to_host_compact()
+    assert np.array_equal(back.rowptr, rp) and np.array_equal(back.col, col) and np.array_equal(back.val, val)
+    cv, hrp, nbk = h.cv.numpy(), h.rowptr.numpy(), h.len.numpy().astype(np.int64)
+    assert np.array_equal(np.diff(hrp), 16 * nbk) and nbk[7] == 0
+    for i in (0, 11, 12, 299):
+        for c in cols[i][:50]:
+            b = ((int(c) * graph.HASH_MUL & 0xFFFFFFFF) * int(nbk[i])) >> 32
+            line = cv[hrp[i] + 16 * b: hrp[i] + 16 * b + 16, 0]
+            assert c in line

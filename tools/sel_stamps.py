@@ -36,3 +36,29 @@ order = np.argsort(-d[:, 1] - d[:, 2])[:8]
 print("slowest A+B items:", [(int(i), int(d[i, 1]), int(d[i, 2]), int(s[i, 6]), int(s[i, 7])) for i in order])
 print("start times (first 8, every 256th):", (s[::256, 0] - t0)[:16])
 print("end   times (first 8, every 256th):", (s[::256, 5] - t0)[:16])
+# slot population: what the slots are and how many survive
+err, kept = ws.read_status()
+adj, adjx, val, t0, selfp = model._select_graphs(False, None)[:5] if hasattr(model, "_select_graphs") else (None,) * 5
+print("slots", int(ws.ctl[0].item()), "kept [cn, 1hop, >1hop]", kept)
+try:
+    a, c = b[0], b[1]
+    rp = adj.rowptr if hasattr(adj, "rowptr") else adj[0]
+    deg = (rp[1:] - rp[:-1])
+    tl = t0.len.long()
+    print("sum dA+dB", int((deg[a] + deg[c]).sum()), "sum shorter T0", int(torch.minimum(tl[a], tl[c]).sum()),
+          "mean longer T0", float(torch.maximum(tl[a], tl[c]).float().mean()), "max T0 row", int(tl.max()))
+except Exception as e:
+    print("population stats failed:", repr(e))
+try:
+    def runs(nodes):
+        lo = rp[nodes]; cnt = deg[nodes]
+        base = torch.repeat_interleave(lo - torch.cumsum(cnt, 0) + cnt, cnt)
+        return base + torch.arange(int(cnt.sum()), device=dev)
+    for nm, nodes in (("N(a)", a), ("N(b)", c)):
+        own = selfp[runs(nodes)]
+        p1 = ((own + 1.0) - 1.0) >= model.thresh_1hop
+        pc = (0.5 * ((own * 2.0 + 2.0) - 2.0)) >= model.thresh_cn
+        print(nm, "slots", own.numel(), "own >= th_1hop", int(p1.sum()), "own >= th_cn", int(pc.sum()), "either", int((p1 | pc).sum()))
+    print("thresholds", model.thresh_cn, model.thresh_1hop, model.thresh_non1hop)
+except Exception as e:
+    print("pass-rate stats failed:", repr(e))
