@@ -233,7 +233,10 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
                 n_p[t] = some ? ((hi[t] - 1) >> 4) - (lo[t] >> 4) + 1 : 0;
                 const float *rec = n_p[t] > 1 ? A.bnd + ((((int64_t)t * A.units_cap + (lo[t] >> 4)) * 2) + 1) * rs
                                               : A.part + ((int64_t)t * A.M + mm) * rs;
-                fetch(rec, h0[t], b0[t]);
+                h0[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < TPWA; ++c) b0[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (n_p[t] > 0) fetch(rec, h0[t], b0[t]);  // (most pairs have no entry of some type: nothing to read)
             }
 #pragma unroll
             for (int t = 0; t < 3; ++t)
