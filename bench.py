@@ -205,6 +205,22 @@ def main():
     torch.cuda.synchronize()
     barrier()
     encoder_ms = LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / enc_reps, dev)
+    # the same with the gathered per-layer table stored in bf16 (lpf_gemm_f32_out_bf16 + lpf_spmm_csr_bf16)
+    encoder_bf16 = None
+    if not args.no_bf16:
+        model.encoder_precision = "bf16"
+        h16 = model.propagate()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(enc_reps):
+            h16 = model.propagate()
+        torch.cuda.synchronize()
+        barrier()
+        encoder_bf16 = {"encoder_ms": round(LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / enc_reps, dev), 4),
+                        "max_abs_diff_x_node_vs_f32": float((h16 - h).abs().max())}
+        model.encoder_precision = "f32"
+        del h16
     del h2
 
     # ---- bf16 throughput mode (extra keys; the headline stays fp32 = the reference's precision): same steps with
@@ -240,6 +256,11 @@ def main():
         if "pair_attention_fused" in kt16:
             bf16["pair_attention_fused_ms"] = round(kt16["pair_attention_fused"][2], 4)
         model.precision = "f32"
+    if bf16 is not None and encoder_bf16 is not None:
+        bf16.update(encoder_bf16)
+    elif encoder_bf16 is not None:
+        bf16 = dict(encoder_bf16, what="bf16 storage of the aggregation's gathered table only (D = 256: the pair stage "
+                                      "has no bf16 kernels)")
 
     # ---- instrumented replay of the same steps: HIP events around every kernel launch on the launch stream
     # (recording ~50 events per step costs ~0.1 ms per step, so it is kept out of the headline timing)

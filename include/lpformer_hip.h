@@ -72,6 +72,16 @@ int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t 
                      const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *long_rows,
                      int64_t n_long, void *stream);
 
+/* bf16 THROUGHPUT MODE of the aggregation (BASELINE.json config 2 names bf16 storage; SURVEY 8b lpf_spmm_csr_bf16):
+ * the gathered table H holds bf16 rows (ldh in bf16 elements, rows 16-byte aligned) -- half the gather bytes, which
+ * are what bounds this kernel --, the sum over neighbours, the epilogue and the output stay fp32.  The table comes
+ * from lpf_gemm_f32_out_bf16 (the layer's X W^T, rounded to nearest even once). */
+int lpf_spmm_csr_bf16(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
+                      const void *H_bf16, int64_t ldh, float *out, int64_t ldo, const float *bias,
+                      const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                      const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *long_rows,
+                      int64_t n_long, void *stream);
+
 /* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ addend[M,N]) (ReLU)   -- nn.Linear / PyG Linear:
  * GCNConv.lin (other_models.py:66), lin_l / node half of lin_r (src/modules/layers.py:206-214),
  * MLP linears (other_models.py:125-138), mlp_score (other_models.py:173-179).
@@ -79,6 +89,10 @@ int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t 
 int lpf_gemm_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W, int64_t ldw,
                  const float *bias, const float *addend, int64_t ldadd, float *C, int64_t ldc,
                  uint32_t flags, void *stream);
+/* Same product, C stored as bf16 (ldc in bf16 elements). */
+int lpf_gemm_f32_out_bf16(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W, int64_t ldw,
+                          const float *bias, const float *addend, int64_t ldadd, void *C_bf16, int64_t ldc,
+                          uint32_t flags, void *stream);
 
 /* y[i,:] = LN(x[i,:]; g, b) (then ReLU if flagged), in place allowed (nn.LayerNorm eps 1e-5, biased variance).
  * other_models.py:131-132, layers.py:78.  D <= 1024. g/b NULL -> plain ReLU / identity. */

@@ -26,6 +26,8 @@ HIP_PROTOTYPES = {
     "lpf_gcn_norm_csr": [i64, vp, vp, vp, vp, vp, vp],
     "lpf_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],
     "lpf_gemm_f32": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
+    "lpf_gemm_f32_out_bf16": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
+    "lpf_spmm_csr_bf16": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],
     "lpf_layernorm_f32": [i64, i32, vp, i64, vp, vp, vp, i64, u32, vp],
     "lpf_pair_gather_f32": [i64, i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp],
     "lpf_select_bound": [i64, vp, i64, vp, vp, vp, vp, vp, vp, vp],

@@ -18,7 +18,7 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // padded LDS row stride (floats)
 
-template <int BN>
+template <int BN, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int N, int K, const float *__restrict__ A,
                                                        int64_t lda, const float *__restrict__ W, int64_t ldw,
                                                        const float *__restrict__ bias,
@@ -140,16 +140,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int N, int K, 
             float v = acc[c][r] + bv;
             if (addend) v += addend[m * ldadd + n];
             if (relu) v = fmaxf(v, 0.f);
-            C[m * ldc + n] = v;
+            if constexpr (OUT_BF16) reinterpret_cast<uint16_t *>(C)[m * ldc + n] = lpf_f32_to_bf16(v);
+            else C[m * ldc + n] = v;
         }
     }
 }
 
 }  // namespace
 
-extern "C" int lpf_gemm_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W,
-                            int64_t ldw, const float *bias, const float *addend, int64_t ldadd, float *C,
-                            int64_t ldc, uint32_t flags, void *stream) {
+namespace {
+template <bool OUT_BF16>
+int gemm_launch(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W, int64_t ldw,
+                const float *bias, const float *addend, int64_t ldadd, float *C, int64_t ldc, uint32_t flags,
+                void *stream) {
     if (M == 0 || N == 0) return LPF_OK;
     LPF_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && C);
     LPF_REQUIRE(lda >= K && ldw >= K && ldc >= N && (lda & 3) == 0 && (ldw & 3) == 0);
@@ -158,18 +161,32 @@ extern "C" int lpf_gemm_f32(int64_t M, int32_t N, int32_t K, const float *A, int
     LPF_REQUIRE((M + BM - 1) / BM < (1ll << 31));
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Column tile: the one that wastes fewer padded columns; and for small problems the narrow tile, so that the grid
-    // has at least two workgroups per CU -- one wavefront per SIMD issues this MFMA at half rate.
+    // has at least two workgroups per CU.
     const int pad128 = ((N + 127) / 128) * 128 - N, pad64 = ((N + 63) / 64) * 64 - N;
     const int64_t blocks128 = ((M + BM - 1) / BM) * ((N + 127) / 128);
     if (pad64 < pad128 || blocks128 < 2 * 256) {
         dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + 63) / 64));
-        hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, s, M, N, K, A, lda, W, ldw, bias, addend, ldadd,
-                           C, ldc, flags);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, OUT_BF16>), grid, dim3(256), 0, s, M, N, K, A, lda, W, ldw, bias,
+                           addend, ldadd, C, ldc, flags);
     } else {
         dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + 127) / 128));
-        hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(256), 0, s, M, N, K, A, lda, W, ldw, bias, addend,
-                           ldadd, C, ldc, flags);
+        hipLaunchKernelGGL((gemm_f32_kernel<128, OUT_BF16>), grid, dim3(256), 0, s, M, N, K, A, lda, W, ldw, bias,
+                           addend, ldadd, C, ldc, flags);
     }
     LPF_CHECK_LAUNCH();
     return LPF_OK;
+}
+}  // namespace
+
+extern "C" int lpf_gemm_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W,
+                            int64_t ldw, const float *bias, const float *addend, int64_t ldadd, float *C,
+                            int64_t ldc, uint32_t flags, void *stream) {
+    return gemm_launch<false>(M, N, K, A, lda, W, ldw, bias, addend, ldadd, C, ldc, flags, stream);
+}
+
+extern "C" int lpf_gemm_f32_out_bf16(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W,
+                                     int64_t ldw, const float *bias, const float *addend, int64_t ldadd,
+                                     void *C_bf16, int64_t ldc, uint32_t flags, void *stream) {
+    return gemm_launch<true>(M, N, K, A, lda, W, ldw, bias, addend, ldadd, static_cast<float *>(C_bf16), ldc, flags,
+                             stream);
 }

@@ -49,3 +49,12 @@ __device__ __forceinline__ int64_t lpf_lower_bound(const int32_t *__restrict__ a
     }
     return lo;
 }
+
+// fp32 <-> bf16 bits (round to nearest even; NaN stays NaN)
+__device__ __forceinline__ uint16_t lpf_f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float lpf_bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }

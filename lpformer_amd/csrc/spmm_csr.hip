@@ -35,7 +35,8 @@ constexpr int SPMM_LONG = 128;  // rows with more stored entries than this are l
 // acc += sum over edges [e0, e1) taken in chunks of G starting at e0 + first_chunk*G with stride chunk_stride*G:
 // a chunk is one coalesced (col, weight) read by the group, then lane-by-lane broadcasts with four 16-byte neighbour
 // gathers in flight.
-template <int G>
+// (HB: the gathered table H holds bf16 rows -- half the gather bytes, the bound of this kernel; the sum stays fp32)
+template <int G, bool HB>
 __device__ __forceinline__ void spmm_accumulate(float4 &acc, int64_t e0, int64_t e1, int first_chunk, int chunk_stride,
                                                 const int32_t *__restrict__ col, const float *__restrict__ w,
                                                 const float *__restrict__ H, int64_t ldh, int off, bool act, int gbase,
@@ -60,8 +61,16 @@ __device__ __forceinline__ void spmm_accumulate(float4 &acc, int64_t e0, int64_t
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                h[u] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (HB) {
+                    uint2 b = make_uint2(0u, 0u);
+                    if (act) b = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(H) +
+                                                                  (int64_t)cc[u] * ldh + off);
+                    h[u] = make_float4(__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
+                                       __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u));
+                } else {
+                    h[u] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 acc.x = fmaf(ww[u], h[u].x, acc.x);
@@ -97,7 +106,7 @@ __device__ __forceinline__ void spmm_epilogue(float4 y, int64_t row, bool live, 
     if (act && live) *reinterpret_cast<float4 *>(out + row * ldo + off) = y;
 }
 
-template <int G>
+template <int G, bool HB>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const int64_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ col, const float *__restrict__ w,
                                                        const float *__restrict__ H, int64_t ldh,
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const i
             e1 = e0;
         }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        spmm_accumulate<G>(acc, e0, e1, 0, 1, col, w, H, ldh, off, act, gbase, lig);
+        spmm_accumulate<G, HB>(acc, e0, e1, 0, 1, col, w, H, ldh, off, act, gbase, lig);
         spmm_epilogue<G>(acc, row, live, act, D, off, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags);
     }
 }
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const i
 // Hub rows (more than SPMM_LONG entries): one 256-thread workgroup per row.  The NG = 256/G lane groups take chunks of
 // G edges round-robin, their partial sums meet in LDS and are added in group order (deterministic), then group 0 runs
 // the same fused epilogue.
-template <int G>
+template <int G, bool HB>
 __global__ __launch_bounds__(256) void spmm_long_rows_kernel(
     const int32_t *__restrict__ long_rows, int D, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ w, const float *__restrict__ H, int64_t ldh, float *__restrict__ out, int64_t ldo,
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256) void spmm_long_rows_kernel(
     const int64_t row = long_rows[blockIdx.x];
     const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    spmm_accumulate<G>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
+    spmm_accumulate<G, HB>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
     part[grp][lig] = acc;
     __syncthreads();
     if (grp == 0) {
@@ -205,11 +214,12 @@ extern "C" int lpf_gcn_norm_csr(int64_t n, const int64_t *rowptr, const int32_t 
     return LPF_OK;
 }
 
-extern "C" int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
-                                const float *H, int64_t ldh, float *out, int64_t ldo, const float *bias,
-                                const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
-                                const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *long_rows,
-                                int64_t n_long, void *stream) {
+namespace {
+template <bool HB>
+int spmm_launch(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w, const float *H,
+                int64_t ldh, float *out, int64_t ldo, const float *bias, const float *ln_g, const float *ln_b,
+                const float *residual, int64_t ldr, const float *ln2_g, const float *ln2_b, uint32_t flags,
+                const int32_t *long_rows, int64_t n_long, void *stream) {
     if (n == 0) return LPF_OK;
     LPF_REQUIRE(n_long >= 0 && (n_long == 0 || long_rows) && n_long < (1ll << 31));
     LPF_REQUIRE(n > 0 && rowptr && col && w && H && out);
@@ -225,12 +235,13 @@ extern "C" int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, con
     if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond ~32 blocks per CU
 #define LPF_SPMM_LAUNCH(GG)                                                                                        \
     do {                                                                                                           \
-        hipLaunchKernelGGL(spmm_csr_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr, col, w, H,  \
-                           ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags, long_rows ? 1 : 0); \
+        hipLaunchKernelGGL((spmm_csr_kernel<GG, HB>), dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr, col,  \
+                           w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags,              \
+                           long_rows ? 1 : 0);                                                                     \
         if (n_long > 0)                                                                                            \
-            hipLaunchKernelGGL(spmm_long_rows_kernel<GG>, dim3((unsigned)n_long), dim3(256), 0, s, long_rows, D,   \
-                               rowptr, col, w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b,    \
-                               flags);                                                                             \
+            hipLaunchKernelGGL((spmm_long_rows_kernel<GG, HB>), dim3((unsigned)n_long), dim3(256), 0, s,           \
+                               long_rows, D, rowptr, col, w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr,    \
+                               ln2_g, ln2_b, flags);                                                               \
     } while (0)
     if (G == 16) LPF_SPMM_LAUNCH(16);
     else if (G == 32) LPF_SPMM_LAUNCH(32);
@@ -238,4 +249,24 @@ extern "C" int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, con
 #undef LPF_SPMM_LAUNCH
     LPF_CHECK_LAUNCH();
     return LPF_OK;
+}
+}  // namespace
+
+extern "C" int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
+                                const float *H, int64_t ldh, float *out, int64_t ldo, const float *bias,
+                                const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                                const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *long_rows,
+                                int64_t n_long, void *stream) {
+    return spmm_launch<false>(n, D, rowptr, col, w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b,
+                              flags, long_rows, n_long, stream);
+}
+
+extern "C" int lpf_spmm_csr_bf16(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
+                                 const void *H_bf16, int64_t ldh, float *out, int64_t ldo, const float *bias,
+                                 const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                                 const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *long_rows,
+                                 int64_t n_long, void *stream) {
+    LPF_REQUIRE((ldh & 7) == 0);  // 16-byte aligned bf16 rows
+    return spmm_launch<true>(n, D, rowptr, col, w, static_cast<const float *>(H_bf16), ldh, out, ldo, bias, ln_g, ln_b,
+                             residual, ldr, ln2_g, ln2_b, flags, long_rows, n_long, stream);
 }

@@ -510,6 +510,9 @@ class LinkTransformer(nn.Module):
         # "f32" (parity mode, logits within 1e-4 of the reference) or "bf16" (throughput mode of score_pairs: the node
         # table Z is stored in bf16 and Wfold h runs on the bf16 matrix cores; selection and everything else as in f32)
         self.precision = "f32"
+        # "f32" or "bf16": in bf16 the per-layer table X W^T that the aggregation gathers (and that a row-sharded
+        # encoder all-gathers) is stored in bf16; the GEMM, the sums over neighbours and the epilogue stay fp32
+        self.encoder_precision = "f32"
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self, train_ok: bool = False):
@@ -655,9 +658,23 @@ class LinkTransformer(nn.Module):
             return x
 
     def _layer_transform(self, i: int, x_rows: torch.Tensor) -> torch.Tensor:
-        """GCNConv.lin of layer i on the given rows (other_models.py:66 -> PyG GCNConv: x W^T, no bias)."""
+        """GCNConv.lin of layer i on the given rows (other_models.py:66 -> PyG GCNConv: x W^T, no bias).  With
+        ``encoder_precision == "bf16"`` the product (fp32 MFMA) is stored as bf16: it is the table the aggregation
+        gathers -- and, row-sharded, the tensor that crosses xGMI."""
         conv = self.node_encoder.gnn_encoder.convs[i]
-        return gemm(_as_f32_rows(x_rows), self._conv_pads[i].get(conv.lin.weight), tag="gemm_encoder")
+        w = self._conv_pads[i].get(conv.lin.weight)
+        a = _as_f32_rows(x_rows)
+        if self.encoder_precision != "bf16":
+            return gemm(a, w, tag="gemm_encoder")
+        m, k = a.shape
+        n = w.shape[0]
+        ld = (n + 7) // 8 * 8
+        out = torch.empty(m, ld, dtype=torch.bfloat16, device=a.device)[:, :n]
+        with KernelTimer.span("gemm_encoder"):
+            check(_lib.hip().lpf_gemm_f32_out_bf16(m, n, k, ptr(a), a.stride(0), ptr(w), w.stride(0), None, None, 0,
+                                                   ptr(out), out.stride(0), 0, _stream(a.device)),
+                  "lpf_gemm_f32_out_bf16")
+        return out
 
     def _layer_aggregate(self, i: int, a_hat: graph.DeviceCSR, t: torch.Tensor, lo: int, hi: int,
                          x_rows: torch.Tensor) -> torch.Tensor:
@@ -672,15 +689,17 @@ class LinkTransformer(nn.Module):
         ln = enc.lns[i] if enc.lns is not None else None
         long_rows = self._long_rows(a_hat, lo, hi)
         out = torch.empty(hi - lo, d, dtype=torch.float32, device=self.device)
+        bf16 = t.dtype == torch.bfloat16
+        fn = _lib.hip().lpf_spmm_csr_bf16 if bf16 else _lib.hip().lpf_spmm_csr_f32
         with KernelTimer.span("spmm_csr"):
-            check(_lib.hip().lpf_spmm_csr_f32(
+            check(fn(
                 hi - lo, d, a_hat.rowptr.data_ptr() + 8 * lo, ptr(a_hat.col), ptr(a_hat.val), ptr(t),
                 t.stride(0), ptr(out), out.stride(0), ptr(conv.bias),
                 ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
                 ptr(res), 0 if res is None else res.stride(0),
                 ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
                 FLAG_RELU if enc.relu else 0, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
-                _stream(self.device)), "lpf_spmm_csr_f32")
+                _stream(self.device)), "lpf_spmm_csr_bf16" if bf16 else "lpf_spmm_csr_f32")
         return out
 
     def _long_rows(self, a_hat: graph.DeviceCSR, lo: int, hi: int):

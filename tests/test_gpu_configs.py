@@ -307,3 +307,71 @@ def test_bf16_throughput_mode(name, scale, bs):
     print(f"bf16 vs f32 logits on {name}: max abs diff {err:.3e} (tolerance {tol:.3e})")
     assert torch.isfinite(got).all() and err <= tol
     assert err > 0.0  # it really is a different arithmetic
+
+
+@pytest.mark.gpu
+def test_spmm_and_gemm_bf16_entry_points():
+    """lpf_gemm_f32_out_bf16 = the fp32 product rounded to nearest even once; lpf_spmm_csr_bf16 = the fp32 aggregation
+    of a bf16 table (sums, epilogue and output fp32): compared with plain torch on the same bf16-rounded table."""
+    from lpformer_amd import _lib
+    from lpformer_amd._lib import ptr, check
+    torch.manual_seed(3)
+    m, k, n = 1000, 96, 128
+    a = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    out16 = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    check(_lib.hip().lpf_gemm_f32_out_bf16(m, n, k, ptr(a), k, ptr(w), k, None, None, 0, ptr(out16), n, 0, st), "gemm")
+    ref = a.double() @ w.double().t()
+    rel = ((out16.double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+    assert rel <= 2.0 ** -8                       # one bf16 rounding of an fp32-accurate product
+    assert (out16.float() - ref.float().to(torch.bfloat16).float()).ne(0).float().mean().item() < 0.01
+
+    # aggregation: random CSR with a hub row, bias + LayerNorm + ReLU epilogue
+    rows, d = 700, 128
+    deg = torch.randint(0, 12, (rows,))
+    deg[5] = 400
+    rp = torch.zeros(rows + 1, dtype=torch.int64)
+    rp[1:] = torch.cumsum(deg, 0)
+    nnz = int(rp[-1])
+    col = torch.randint(0, m, (nnz,), dtype=torch.int32)
+    val = torch.rand(nnz)
+    bias, g, b = torch.randn(d, device=DEV), torch.rand(d, device=DEV) + 0.5, torch.randn(d, device=DEV)
+    rp_d, col_d, val_d = rp.to(DEV), col.to(DEV), val.to(DEV)
+    long_rows = torch.nonzero(deg > 128).flatten().to(torch.int32).to(DEV)
+    got = torch.empty(rows, d, device=DEV)
+    check(_lib.hip().lpf_spmm_csr_bf16(rows, d, ptr(rp_d), ptr(col_d), ptr(val_d), ptr(out16), n, ptr(got), d,
+                                       ptr(bias), ptr(g), ptr(b), None, 0, None, None, 1, ptr(long_rows),
+                                       long_rows.numel(), st), "spmm")
+    table = out16.double().cpu()
+    acc = torch.zeros(rows, d, dtype=torch.float64)
+    r_of = torch.repeat_interleave(torch.arange(rows), deg)
+    acc.index_add_(0, r_of, table[col.long()] * val.double()[:, None])
+    y = acc + bias.double().cpu()
+    y = torch.nn.functional.layer_norm(y, (d,), g.double().cpu(), b.double().cpu(), 1e-5).clamp_min(0)
+    assert (got.double().cpu() - y).abs().max().item() <= 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scale,bs", [("collab", 0.1, 4096), ("ppa", 0.02, 3000), ("citation2", 0.01, 3000),
+                                           ("ddi", 1.0, 1024), ("cora", 1.0, 2048)])
+def test_bf16_encoder_mode(name, scale, bs):
+    """encoder_precision = "bf16": the per-layer table X W^T is gathered from bf16 storage (GEMM, neighbour sums and
+    epilogue fp32).  Stated tolerance: node embeddings (LayerNorm output, magnitude ~1) within 3e-2 absolute of the
+    fp32 encoder, logits of the full bf16 mode (encoder + attention) within 5e-3 (observed <= 1.2e-3); the selected index sets do not
+    depend on the encoder at all."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale=scale, bs=bs)
+    h32 = model.propagate()
+    b = torch.from_numpy(batch).to(DEV)
+    ref = model.score_pairs(b, h32, score, logits=True).clone()
+    model.encoder_precision = "bf16"
+    h16 = model.propagate()
+    if model.dim <= 128:
+        model.precision = "bf16"
+    got = model.score_pairs(b, h16, score, logits=True)
+    model.encoder_precision = model.precision = "f32"
+    e_h = (h16 - h32).abs().max().item()
+    e_l = (got - ref).abs().max().item()
+    print(f"bf16 encoder on {name}: max |dX| {e_h:.3e}, max |dlogit| (full bf16 mode) {e_l:.3e}")
+    assert torch.isfinite(h16).all() and 0.0 < e_h <= 3e-2
+    assert torch.isfinite(got).all() and e_l <= 5e-3
