@@ -7,7 +7,7 @@ Public surface mirrors the reference (HarryShomer/LPFormer):
     evaluate                            encoder-once, device-resident evaluation sweep + ranking metrics
     graph, data                         CSR containers and the data-dict builder
 """
-from . import evaluate, graph  # noqa: F401
+from . import evaluate, graph, readers  # noqa: F401
 from .graphed import GraphedScorer  # noqa: F401
 from .link_transformer import MLP, LinkTransformer, mlp_score  # noqa: F401
 from .ppr import calc_ppr, calc_ppr_gpu, get_ppr, load_or_calc_ppr  # noqa: F401
