@@ -26,6 +26,12 @@
 
 #include "pe_common.h"
 
+// Tuning aid, compiled only with -DLPF_FUSED_STAMPS (make EXTRA=-DLPF_FUSED_STAMPS; tools/fused_stamps.py): s_memtime at the
+// phase boundaries of the first eight tiles of 512 wavefronts.
+#ifdef LPF_FUSED_STAMPS
+__device__ long long g_pf_stamps[4096 * 8];
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -54,7 +60,7 @@ struct FusedArgs {
 
 template <int NT, bool BF16>
 __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t idx, int64_t cnt, const float4 *wl,
-                                           const float4 *tab, float *zbuf, int lane) {
+                                           const float4 *tab, float *zbuf, int lane, int stamp_slot) {
     constexpr int D = 32 * NT, NSQ = D / 8, RS = D + 4;
     constexpr int ZB = BF16 ? 2 : 4;  // bytes per Z element
     const int col = lane & 31, lh = lane >> 5;
@@ -78,6 +84,14 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     if (e0 + 32 < cnt)
         tile_cont = ((uint32_t)ent[e0 + 32].x & PF_PAIR_MASK) == ((uint32_t)ent[e0 + 31].x & PF_PAIR_MASK);
 
+#ifdef LPF_FUSED_STAMPS
+    const bool stamp = (A.dbg & 32) && lane == 0 && stamp_slot >= 0;
+#define PF_STAMP(k) do { if (stamp) g_pf_stamps[stamp_slot * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+    (void)stamp_slot;
+#define PF_STAMP(k) do { } while (0)
+#endif
+    PF_STAMP(0);
     const PeStat st = pe_load_stat(A.pe_stat, t);
     const float r_ab = pe_rstd(st, pa, pb), r_ba = pe_rstd(st, pb, pa);
 
@@ -115,6 +129,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     const float4 *tb = tab + t * D + lh * (D / 2);
     // (Letting the wavefronts of a SIMD take turns in the MFMA loop through an LDS token -- to keep one wave's
     // epilogue beside another's matrix loop -- measured slower: 203 vs 194 us.)
+    PF_STAMP(1);
     if constexpr (!BF16) {
 #pragma unroll 1
         for (int sq = 0; sq < ((A.dbg & 4) ? 0 : NSQ); ++sq) {
@@ -156,6 +171,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
 
     // ---- scores of the unit's 16 entries.  Entries are taken two at a time (16 row pieces in flight per lane) with a
     // scheduling barrier in between: left to itself the scheduler hoists all 128 loads of the unit and spills.
+    PF_STAMP(2);
     float sc[16];
     // q rows (global, mostly L1/L2 hits: consecutive entries share their pair) are requested one pair of entries
     // ahead of the arithmetic that uses them; the Z rows come from the LDS buffer
@@ -209,6 +225,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    PF_STAMP(3);
     // sum over the 32 feature lanes of the half: rotations inside each 16-lane row (DPP), then the other row
     if (!(A.dbg & 8))
 #pragma unroll
@@ -222,6 +239,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         sc[i] = v;
     }
 
+    PF_STAMP(4);
     // ---- online softmax over the unit's entries, one record per (pair) piece
     int64_t left = cnt - e0 - 16 * lh;
     const int nval = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
@@ -278,6 +296,8 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         }
     }
     flush(cur_pair, first ? st0 : true, !cont);
+    PF_STAMP(5);
+#undef PF_STAMP
 }
 
 template <int NT, bool BF16>
@@ -318,7 +338,9 @@ __global__ __launch_bounds__(64 * pf_waves<NT>()) void pair_fused_kernel(const F
         else if (tile < tiles[0] + tiles[1]) { t = 1; idx = tile - tiles[0]; }
         else { t = 2; idx = tile - tiles[0] - tiles[1]; }
         const float4 *wp = reinterpret_cast<const float4 *>(A.wpk) + (int64_t)t * IMG + lane;
-        fused_tile<NT, BF16>(A, t, idx, n[t], wp, tab, zbuf, lane);
+        const int64_t k_tile = (tile - wave_id) / n_waves;
+        fused_tile<NT, BF16>(A, t, idx, n[t], wp, tab, zbuf, lane,
+                             (blockIdx.x < 64 && k_tile < 8) ? (int)((blockIdx.x * PF_WAVES + wave) * 8 + k_tile) : -1);
     }
 }
 
@@ -409,3 +431,11 @@ extern "C" int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_
     return fused_launch<true>(D, bs, type_ptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab, pe_stat,
                               wfold_packed_bf16, bfold, att, part, bnd, units_cap, stream);
 }
+
+#ifdef LPF_FUSED_STAMPS
+extern "C" int lpf_fused_debug_stamps(long long *dst_host, int64_t n) {
+    if (n > 4096 * 8) n = 4096 * 8;
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_pf_stamps), (size_t)n * sizeof(long long)) == hipSuccess ? LPF_OK
+                                                                                                                : LPF_ERR_LAUNCH;
+}
+#endif
