@@ -322,15 +322,10 @@ __global__ __launch_bounds__(64 * pf_waves<NT>()) void pair_fused_kernel(const F
         tiles[t] = (n[t] + 31) >> 5;
     }
     const int64_t wave_id = (int64_t)blockIdx.x * PF_WAVES + wave, n_waves = (int64_t)gridDim.x * PF_WAVES;
-    // The two wavefronts of a SIMD (waves w and w + PF_WAVES/2) run the same program: started together they do their
-    // MFMA loops together (sharing the matrix pipe) and their epilogues together (leaving it idle).  The second half
-    // starts about half a tile late.
-    if (wave >= PF_WAVES / 2 && !(A.dbg & 16)) {
-        constexpr int UNITS = 12 * NT * NT;  // s_sleep units of 64 cycles
-#pragma unroll
-        for (int i = 0; i < UNITS / 96; ++i) __builtin_amdgcn_s_sleep(96);
-        if (UNITS % 96) __builtin_amdgcn_s_sleep(UNITS % 96);
-    }
+    // (The two wavefronts of a SIMD -- waves w and w + PF_WAVES/2 -- run the same program and stay within a few thousand
+    // clocks of each other, tile after tile.  Starting the second one late does not help, it only costs the delay:
+    // 170 / 171 / 173 / 175 / 177 us for 0 / 6 k / 12 k / 18 k / 24 k clocks -- fp32 MFMA and vector instructions of
+    // two wavefronts share the SIMD's ALUs, so being out of phase buys nothing.)
     for (int64_t tile = wave_id; tile < tiles[0] + tiles[1] + tiles[2]; tile += n_waves) {
         int t;
         int64_t idx;
