@@ -226,17 +226,43 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         __builtin_amdgcn_sched_barrier(0);
     }
     PF_STAMP(3);
-    // sum over the 32 feature lanes of the half: rotations inside each 16-lane row (DPP), then the other row
-    if (!(A.dbg & 8))
+    // Sum over the 32 feature lanes of the half, for 16 scores at once: a butterfly that halves the number of live
+    // values at every step (a lane keeps the scores whose index bit k equals its lane bit k and hands the others to
+    // its partner), 8 + 4 + 2 + 1 adds instead of 16 x 4, then one exchange with the other 16-lane row.  Lane l of
+    // the half then holds the total of unit entry l & 15; every lane needs every total (they weight its own feature in
+    // the softmax walk), so they are read back lane by lane.
+    if (!(A.dbg & 8)) {
+        const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+        float r1[8], r2[4], r3[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float v = sc[i];
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-        v += __shfl_xor(v, 16, 64);
-        sc[i] = v;
+        for (int j = 0; j < 8; ++j) {  // partner lane ^ 1 (quad_perm [1,0,3,2])
+            const float keep = b0 ? sc[2 * j + 1] : sc[2 * j], send = b0 ? sc[2 * j] : sc[2 * j + 1];
+            r1[j] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // partner lane ^ 2 (quad_perm [2,3,0,1])
+            const float keep = b1 ? r1[2 * j + 1] : r1[2 * j], send = b1 ? r1[2 * j] : r1[2 * j + 1];
+            r2[j] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4E, 0xf, 0xf, false));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {  // partner lane ^ 4: rotate by 12 for the banks with bit 2 clear, by 4 for the others
+            const float keep = b2 ? r2[2 * j + 1] : r2[2 * j], send = b2 ? r2[2 * j] : r2[2 * j + 1];
+            int got = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x12C, 0xf, 0x5, false);
+            got = __builtin_amdgcn_update_dpp(got, __builtin_bit_cast(int, send), 0x124, 0xf, 0xa, false);
+            r3[j] = keep + __builtin_bit_cast(float, got);
+        }
+        float r4;
+        {   // partner lane ^ 8 (rotate by 8)
+            const float keep = b3 ? r3[1] : r3[0], send = b3 ? r3[0] : r3[1];
+            r4 = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xf, 0xf, false));
+        }
+        r4 += __shfl_xor(r4, 16, 64);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r4), i));
+            const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r4), 32 + i));
+            sc[i] = lh ? t1 : t0;
+        }
     }
 
     PF_STAMP(4);
