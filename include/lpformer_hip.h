@@ -112,70 +112,8 @@ int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const f
 int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, int64_t n_rows, const float *X,
                         int64_t ldx, float *mul, int64_t ldm, float *sum, int64_t lds, void *stream);
 
-/* Selection, step 1: per-pair descriptors, staging capacities and work-item counts, with their exclusive scans.
- *   adj_rowptr  0/1 symmetric adjacency used for CN / 1-hop typing (data['adj_mask'] or the training override)
- *   t0_rowptr   CSR scanned for >1-hop candidates: either the PPR CSR itself or a per-theta_n prefiltered copy
- *               (entries with fl32(fl32(p+1)-1) >= theta_n); NULL => no >1-hop part (mode "1-hop")
- *   offs  int64[2*(bs+1)]: offs[k] = staging offset of pair k, capacity deg(a)+deg(b)+min(|T0 a|,|T0 b|) slots,
- *         offs[bs] = total;  offs[(bs+1)+k] = first work item of pair k, offs[(bs+1)+bs] = number of items
- *         (a pair is ONE item when deg(a)+deg(b) <= 512, else ceil(deg a/512)+ceil(deg b/512) slices)
- *   desc  int64[16*bs]: row starts/lengths of pair k (adjacency, PPR, T0 rows of a and b), one 128-byte line
- *   scratch int64[LPF_SELECT_SCRATCH_ELEMS(bs)] (block sums of the two-kernel scans); on return its last three
- *         words start with the two totals {offs[bs], offs[(bs+1)+bs]} side by side: with nb = ceil(bs/256),
- *         scratch[3*nb] = staging slots, scratch[3*nb+1] = work items (one 16-byte device-to-host copy) */
-#define LPF_SELECT_SCRATCH_ELEMS(bs) (3 * (((bs) + 255) / 256) + 3)
-int lpf_select_bound(int64_t bs, const int64_t *batch, int64_t batch_ld, const int64_t *adj_rowptr,
-                     const int64_t *ppr_rowptr, const int64_t *t0_rowptr, int64_t *offs, int64_t *desc,
-                     int64_t *scratch, void *stream);
-
-/* Selection, step 2: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (link_transformer.py:214-319,434-481),
- * eval mode; integer/bit-exact.  One wavefront per work item.  With adj_selfp (evaluation): each lane owns one
- * candidate, membership by binary search in LDS, one lookup in the prefiltered one-hop rows.  Without it (adjacency
- * override): candidates + hash table in LDS, raw PPR rows streamed through the hash (see select.hip).
- *   item_capacity  host-side upper bound on offs[(bs+1)+bs] (sizes `items` = int32[16*item_capacity], 64-byte records, and the grid)
- *   adjx_*    UNMASKED adjacency used to exclude neighbours from the >1-hop set (link_transformer.py:443);
- *             same_adj != 0 says it is the very adjacency the descriptors were built from (evaluation)
- *   ppr_col/val, t0_col/val   column/value arrays of the PPR CSR and of the >1-hop candidate CSR (t0_col NULL: skip)
- *   adj_selfp  optional index (NULL = general path): adj_selfp[e] = P[i, j] for adjacency entry e = (i, j), 0 when
- *             not stored.  When given, ppr_col/ppr_val and the ppr_rowptr handed to lpf_select_bound may be any
- *             subset of the PPR rows that keeps every entry with fl32(fl32(p+1)-1) >= theta_1 (the "P1" index):
- *             PPR values of a node's own neighbours then come from adj_selfp and no PPR row is streamed.
- *             Results are identical with and without the indexes.
- * Staging for pair k at s = offs[k], dA = deg(a), dB = deg(b) (capacity dA + dB + min(|T0 a|, |T0 b|) slots):
- *   pair = ONE item (dA + dB <= 512): COMPACTED runs, written as found --
- *     stage_node[s ..]            kept common neighbours, ascending            (count stage_cnt[4k+0])
- *     stage_node[.. s+dA-1]       kept one-hop nodes of N(a), written DOWNWARDS from s+dA-1 (count stage_cnt[4k+1])
- *     stage_node[s+dA ..]         kept one-hop nodes of N(b), ascending        (count stage_cnt[4k+2])
- *   pair sliced into several items (a hub): DENSE, one code per candidate --
- *     stage_node[s+i],    i < dA : -1 (dropped) | node | (1<<30 if common neighbour)   for the i-th node of N(a)
- *     stage_node[s+dA+j], j < dB : -1 | node                                           for the j-th node of N(b)
- *   stage_node[s+dA+dB ..]  the >1-hop run, compacted and sorted (count stage_cnt[4k+3])
- *   stage_pa/pb fp32 at the same slots (values AFTER the reference's fp32 round trip), written for kept nodes */
-int lpf_select_nodes(int64_t bs, int64_t item_capacity, const int64_t *offs, const int64_t *desc, int32_t *items,
-                     const int32_t *adj_col, const float *adj_selfp, const int64_t *adjx_rowptr,
-                     const int32_t *adjx_col, int32_t same_adj,
-                     const int32_t *ppr_col, const float *ppr_val, const int32_t *t0_col, const float *t0_val,
-                     float th_cn, float th_1hop, float th_non1hop, int32_t *stage_node, float *stage_pa,
-                     float *stage_pb, int32_t *stage_cnt, void *stream);
-
-/* Exclusive scans of the per-pair counts per type + totals:
- *   type_ptr: int64[3*(bs+1)]  rows = (cn, 1-hop, >1-hop) ; type_ptr[t*(bs+1)+bs] = total of type t
- *   counts_f: float[bs, ldc] receives the structural count features of get_structure_cnts
- *             (link_transformer.py:340-356): n_cn, n_1hop, [n_non1hop if want_t0], n_cn+n_1hop
- *   scratch:  int64[LPF_SELECT_SCRATCH_ELEMS(bs)] */
-int lpf_select_scan(int64_t bs, const int32_t *stage_cnt, int64_t *type_ptr, float *counts_f, int64_t ldc,
-                    int32_t want_t0, int64_t *scratch, void *stream);
-
-/* Compaction into the reference's layout: all CN entries sorted by (pair, node), then all 1-hop, then all
- * >1-hop (link_transformer.py:161-162).  Entry e of type t lives at  type_base(t) + type_ptr[t][k] + j  with
- * type_base = (0, total_cn, total_cn+total_1hop).  The two 1-hop runs are merged by node id here (single-item pairs
- * through registers / LDS; dense runs of sliced pairs are compacted in place first: staging is clobbered). */
-int lpf_select_compact(int64_t bs, const int64_t *desc, const int64_t *offs, int32_t *stage_node, float *stage_pa,
-                       float *stage_pb, const int32_t *stage_cnt, const int64_t *type_ptr,
-                       int32_t *sel_pair, int32_t *sel_node, float *sel_pa, float *sel_pb, void *stream);
-
 /* ------------------------------------------------------------------------------------------------
- * Selection, second generation (select2.hip): two launches, nothing read back by the host.
+ * Selection (select2.hip): two launches, nothing read back by the host.
  * compute_node_mask + get_ppr_vals + get_non_1hop_ppr (link_transformer.py:214-319,434-481), eval mode; bit-exact.
  * The candidates of the batch form one flat slot space -- pair k owns N(a_k) | N(b_k) | the shorter of the two T0
  * rows, at least one slot -- cut into work items of LPF_SELECT_ITEM slots; one thread per slot.
@@ -223,7 +161,7 @@ int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int3
                    void *stream);
 /* The reference's layout from the regions above: all CN entries sorted by (pair, node), then all 1-hop (the two runs
  * merged by node id), then all >1-hop (link_transformer.py:161-162); type_ptr64 int64[3*(bs+1)] relative per type,
- * counts_f the float count features of get_structure_cnts (:340-356), as lpf_select_scan wrote them. */
+ * counts_f the float count features of get_structure_cnts (:340-356),  */
 int lpf_select_export(int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap, int64_t *type_ptr64,
                       float *counts_f, int64_t ldc, int32_t want_t0, int32_t *sel_pair, int32_t *sel_node,
                       float *sel_pa, float *sel_pb, void *stream);
@@ -387,7 +325,7 @@ int lpf_ppr_filter_fill(int64_t n, const int64_t *rowptr, const int32_t *col, co
                         float theta, const int64_t *out_rowptr, int32_t *out_col, float *out_val, void *stream);
 
 /* selfp[e] = P[i, j] for every adjacency entry e = (i, j) (0 where the PPR matrix stores nothing): the PPR of a node
- * to its own neighbours, aligned with the adjacency CSR (the adj_selfp argument of lpf_select_nodes). */
+ * to its own neighbours, aligned with the adjacency CSR (the adj_selfp argument of lpf_select_run). */
 int lpf_self_ppr(int64_t n, const int64_t *adj_rowptr, const int32_t *adj_col, const int64_t *ppr_rowptr,
                  const int32_t *ppr_col, const float *ppr_val, float *selfp, void *stream);
 

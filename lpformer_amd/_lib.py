@@ -30,10 +30,6 @@ HIP_PROTOTYPES = {
     "lpf_spmm_csr_bf16": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],
     "lpf_layernorm_f32": [i64, i32, vp, i64, vp, vp, vp, i64, u32, vp],
     "lpf_pair_gather_f32": [i64, i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp],
-    "lpf_select_bound": [i64, vp, i64, vp, vp, vp, vp, vp, vp, vp],
-    "lpf_select_nodes": [i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp],
-    "lpf_select_scan": [i64, vp, vp, vp, i64, i32, vp, vp],
-    "lpf_select_compact": [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lpf_select_plan_blocks": [i64],
     "lpf_select_plan": [i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
     "lpf_select_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, i64, i32,

@@ -1,9 +1,9 @@
-// PPR-thresholded node selection, second generation: two launches, nothing read back by the host.
+// PPR-thresholded node selection: two launches, nothing read back by the host.
 //
 // Reference: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (src/models/link_transformer.py:214-319, 434-481),
-// eval mode.  The reference materialises BS x N sparse temporaries and coalesces them seven times; the first
-// generation of this file (select.hip, still used for nothing but kept until the next round's clean-up is done) cut a
-// batch into one-wavefront work items and needed seven launches plus a 16-byte read-back to size its staging area.
+// eval mode.  The reference materialises BS x N sparse temporaries and coalesces them seven times; round 1 of this
+// project cut a batch into one-wavefront work items and needed seven launches plus a 16-byte read-back to size its
+// staging area (removed).
 //
 // Here the candidates of a batch form ONE flat index space: pair k owns the slots
 //     [offs[k], offs[k+1])  =  N(a_k)  |  N(b_k)  |  the shorter of T0[a_k], T0[b_k]     (at least one slot per pair)

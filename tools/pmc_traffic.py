@@ -14,10 +14,8 @@ SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
     ("pair_fused_kernel", "pair_attention_fused"),
     ("tail_chain_kernel", "tail_chain"), ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"),
     ("pair_scores_", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
-    ("pair_softmax_gather_kernel", "pair_softmax_gather_light"), ("select_nodes_indexed", "select_nodes"),
-    ("select_nodes_kernel", "select_nodes_general"), ("select_compact", "select_compact"),
-    ("select_bound", "select_bound"), ("select_items", "select_items"), ("select_counts", "select_counts"),
-    ("scan_blocks", "scan_blocks"), ("spmm_csr_kernel", "spmm_csr"), ("spmm_long_rows", "spmm_long_rows"),
+    ("pair_softmax_gather_kernel", "pair_softmax_gather_light"),
+    ("spmm_csr_kernel", "spmm_csr"), ("spmm_long_rows", "spmm_long_rows"),
     ("gemm_f32_kernel<128>", "gemm128"), ("gemm_f32_kernel<64>", "gemm64"), ("layernorm", "layernorm"),
     ("dense_chain_kernel<8, 8", "dense_chain_elementwise"), ("dense_chain_kernel<9, 8", "dense_chain_pairwise"),
     ("pair_gather_kernel", "pair_gather_q"), ("dense_chain_kernel<8, 0", "dense_chain_attn_out"),
