@@ -334,7 +334,7 @@ struct RunArgs {
     int dbg;                   // tuning aid (LPF_SEL_DBG): bit 0 = no chained scan (placement is then wrong)
 };
 
-constexpr int S2_PARK = 384;  // kept entries of one item that can wait in LDS for the item's place in the output
+constexpr int S2_PARK = 256;  // kept entries of one item that can wait in LDS for the item's place in the output
 struct RunLds {
     int4 pk[S2_PARK];           // parked entries: type 0 | type 1 | type 2, each in slot order
     int32_t loc[S2_ITEM + 1];   // slot (relative to the item) at which pair pf + i starts
@@ -348,6 +348,9 @@ struct RunLds {
     int64_t ticket;
     int32_t n_pairs;
     int32_t run[3];             // kept entries per type of the item being built
+    int32_t n_t0;               // >1-hop candidates of the item that passed their own threshold ...
+    int16_t t0list[S2_ITEM];    // ... and their slots: typed densely by s2_type_t0 (3 % of the slots, but half of the
+                                // wavefronts hold some and would otherwise run both typing paths)
     // the parked item: what its deferred write-out needs once cand / code / loc belong to the next item
     int64_t p_item, p_pf;
     int32_t p_run[3], p_np, p_last, p_live;
@@ -381,10 +384,11 @@ __device__ __forceinline__ int64_t s2_slot_in_pair(const RunArgs &A, const RunLd
     return s0 > -(1 << 30) ? (int64_t)(l - s0) : (c0 + l) - A.offs[pf + w];  // (clamped only ~2^30 slots back)
 }
 
-// Types one candidate slot (phase B of select_run_kernel).  own: P[own endpoint, node] from the aligned self-PPR
-// array (indexed path) or the T0 value (>1-hop slots).
+// Types one ADJACENCY candidate slot (phase B of select_run_kernel).  own: P[own endpoint, node] from the aligned
+// self-PPR array (indexed path).  Returns true -- and touches nothing -- for a >1-hop slot: those are typed by
+// s2_type_t0 from a compacted list.
 template <bool INDEXED>
-__device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, int64_t pf, int64_t c0, int n_here,
+__device__ __forceinline__ bool s2_type_slot(const RunArgs &A, const RunLds &L, int64_t pf, int64_t c0, int n_here,
                                              int l, float own_in, int &code, float &va, float &vb, bool &fromb) {
     const int32_t x = L.cand[l];
     const int w = L.win[l];
@@ -392,57 +396,61 @@ __device__ __forceinline__ void s2_type_slot(const RunArgs &A, const RunLds &L, 
     const int dA = d.dA, dB = d.dB;
     const int i = (int)s2_slot_in_pair(A, L, pf, c0, w, l);
     const int s0 = L.loc[w];  // slot of the pair's first candidate (may lie before the item)
-    if (i < dA + dB) {
-        const bool from_a = i < dA;
-        // position of x in the OTHER endpoint's adjacency run: in LDS when that run lies inside the item
-        const int o_lo = from_a ? s0 + dA : s0, o_n = from_a ? dB : dA;
-        int j;
-        if (A.dbg & 8) j = -1;
-        else if (s0 > -(1 << 30) && o_lo >= 0 && o_lo + o_n <= n_here) j = s2_find(L.cand + o_lo, o_n, x);
-        else j = s2_find(A.adj_col + (from_a ? d.rb0 : d.ra0), o_n, x);
-        if (!from_a && j >= 0) return;  // a node of N(b) that is also in N(a) is emitted through N(a)
-        const bool cn = from_a && j >= 0;
-        float own, other = 0.f;
-        if (INDEXED) {
-            own = own_in;
-            if (cn) {
-                other = A.selfp[d.rb0 + j];
-            } else if (s2_round_trip(own, false) >= A.th_1 && !(A.dbg & 4)) {  // otherwise it is dropped anyway
-                float v;
-                if (s2_lookup_hashed(A.val_cv, from_a ? d.pb0 : d.pa0, from_a ? d.nPb : d.nPa, x, v))
-                    other = v;
-            }
-        } else {  // general path: both values from the raw PPR rows (absent entries read as 0)
-            const int64_t m0 = from_a ? d.pa0 : d.pb0, v0 = from_a ? d.pb0 : d.pa0;
-            const int im = s2_find(A.val_col + m0, from_a ? d.nPa : d.nPb, x);
-            own = im >= 0 ? A.val_val[m0 + im] : 0.f;
-            if (cn || s2_round_trip(own, false) >= A.th_1) {
-                const int idx = s2_find(A.val_col + v0, from_a ? d.nPb : d.nPa, x);
-                if (idx >= 0) other = A.val_val[v0 + idx];
-            }
+    if (i >= dA + dB) return true;
+    const bool from_a = i < dA;
+    // position of x in the OTHER endpoint's adjacency run: in LDS when that run lies inside the item
+    const int o_lo = from_a ? s0 + dA : s0, o_n = from_a ? dB : dA;
+    int j;
+    if (A.dbg & 8) j = -1;
+    else if (s0 > -(1 << 30) && o_lo >= 0 && o_lo + o_n <= n_here) j = s2_find(L.cand + o_lo, o_n, x);
+    else j = s2_find(A.adj_col + (from_a ? d.rb0 : d.ra0), o_n, x);
+    if (!from_a && j >= 0) return false;  // a node of N(b) that is also in N(a) is emitted through N(a)
+    const bool cn = from_a && j >= 0;
+    float own, other = 0.f;
+    if (INDEXED) {
+        own = own_in;
+        if (cn) {
+            other = A.selfp[d.rb0 + j];
+        } else if (s2_round_trip(own, false) >= A.th_1 && !(A.dbg & 4)) {  // otherwise it is dropped anyway
+            float v;
+            if (s2_lookup_hashed(A.val_cv, from_a ? d.pb0 : d.pa0, from_a ? d.nPb : d.nPa, x, v)) other = v;
         }
-        const float pa = s2_round_trip(from_a ? own : other, cn);
-        const float pb = s2_round_trip(from_a ? other : own, cn);
-        const float th = cn ? A.th_cn : A.th_1;
-        const bool keep = pa >= th && pb >= th;
-        code = keep ? (cn ? 1 : 2) : 0;
-        va = pa; vb = pb; fromb = !from_a;
-        return;
+    } else {  // general path: both values from the raw PPR rows (absent entries read as 0)
+        const int64_t m0 = from_a ? d.pa0 : d.pb0, v0 = from_a ? d.pb0 : d.pa0;
+        const int im = s2_find(A.val_col + m0, from_a ? d.nPa : d.nPb, x);
+        own = im >= 0 ? A.val_val[m0 + im] : 0.f;
+        if (cn || s2_round_trip(own, false) >= A.th_1) {
+            const int idx = s2_find(A.val_col + v0, from_a ? d.nPb : d.nPa, x);
+            if (idx >= 0) other = A.val_val[v0 + idx];
+        }
     }
-    // >1-hop: stored in both T0 rows (p > 0, round trip >= theta_n), adjacent to neither endpoint in the UNMASKED
-    // adjacency; the endpoints themselves may be selected (link_transformer.py:438-443)
+    const float pa = s2_round_trip(from_a ? own : other, cn);
+    const float pb = s2_round_trip(from_a ? other : own, cn);
+    const float th = cn ? A.th_cn : A.th_1;
+    const bool keep = pa >= th && pb >= th;
+    code = keep ? (cn ? 1 : 2) : 0;
+    va = pa; vb = pb; fromb = !from_a;
+    return false;
+}
+
+// Types one >1-hop candidate slot whose own value pw already passed (pw > 0, round trip >= theta_n): stored in the
+// other T0 row too, adjacent to neither endpoint in the UNMASKED adjacency; the endpoints themselves may be selected
+// (link_transformer.py:438-443).
+template <bool INDEXED>
+__device__ __forceinline__ void s2_type_t0(const RunArgs &A, const RunLds &L, int64_t pf, int n_here, int l, float pw,
+                                           int &code, float &va, float &vb) {
+    const int32_t x = L.cand[l];
+    const int w = L.win[l];
+    const PairLite d = s2_pair(A, L, pf, w);
+    const int dA = d.dA, dB = d.dB;
+    const int s0 = L.loc[w];
     const bool walk_a = d.nTa <= d.nTb;
-    const float pw = own_in;
     const float sw = __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f);
-    bool ok = pw > 0.f && sw >= A.th_n;
-    float so = 0.f;
+    float so = 0.f, po;
+    bool ok = s2_lookup_blocked(A.t0_cv, A.t0_skip, walk_a ? d.tb0 : d.ta0, walk_a ? d.nTb : d.nTa, x, po);
     if (ok) {
-        float po;
-        ok = s2_lookup_blocked(A.t0_cv, A.t0_skip, walk_a ? d.tb0 : d.ta0, walk_a ? d.nTb : d.nTa, x, po);
-        if (ok) {
-            so = __fsub_rn(__fadd_rn(po, 1.0f), 1.0f);
-            ok = po > 0.f && so >= A.th_n;
-        }
+        so = __fsub_rn(__fadd_rn(po, 1.0f), 1.0f);
+        ok = po > 0.f && so >= A.th_n;
     }
     if (ok) {
         int ja, jb;
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
             if (v < -(1 << 30)) v = -(1 << 30);
             L.loc[tid] = (int32_t)v;
             const int cntp = __popcll(__ballot(v < n_here));
-            if (tid == 0) L.n_pairs = cntp;
+            if (tid == 0) { L.n_pairs = cntp; L.n_t0 = 0; }
         }
         __syncthreads();
         const int np = L.n_pairs;  // pairs with at least one slot in this item (>= 1)
@@ -570,6 +578,7 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
         for (int r = 0; r < S2_ROUNDS; ++r) {
             const int l = tid + S2_THREADS * r;
             cown[r] = 0.f;
+            bool want_t0 = false;
             if (l < n_here) {
                 int lo = 0, hi = np;  // last window pair with loc <= l
                 while (lo + 1 < hi) {
@@ -592,15 +601,37 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
                 } else {
                     const int nW = d.nTa < d.nTb ? d.nTa : d.nTb;
                     const int64_t wi = i64 - dA - dB;
+                    L.code[l] = 0;  // (phase B leaves >1-hop slots alone)
                     if (wi < nW) {
                         const int2 cv = A.t0_cv[(d.nTa <= d.nTb ? d.ta0 : d.tb0) + wi];
                         x = cv.x;
-                        cown[r] = __int_as_float(cv.y);
+                        const float pw = __int_as_float(cv.y);
+                        want_t0 = pw > 0.f && __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f) >= A.th_n && !(A.dbg & 16);
+                        L.va[l] = pw;
                     }
                 }
                 L.cand[l] = x;
                 L.win[l] = (int16_t)w;
             }
+            const uint64_t bt = __ballot(want_t0);
+            if (bt) {  // (uniform) the slots whose own T0 value passes go on the list of the >1-hop typing pass
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&L.n_t0, __popcll(bt));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (want_t0) L.t0list[base + __popcll(bt & lt_mask)] = (int16_t)l;
+            }
+        }
+        __syncthreads();
+
+        // ---- >1-hop candidates, densely from the list
+        for (int k = tid; k < L.n_t0; k += S2_THREADS) {
+            const int l = L.t0list[k];
+            int code;
+            float va, vb;
+            s2_type_t0<INDEXED>(A, L, pf, n_here, l, L.va[l], code, va, vb);
+            L.code[l] = (uint8_t)code;
+            L.va[l] = va;
+            L.vb[l] = vb;
         }
         __syncthreads();
 
@@ -613,11 +644,16 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
             float va = 0.f, vb = 0.f;
             bool fromb = false;
             const float ownv = r == 0 ? cown[0] : (r == 1 ? cown[1] : (r == 2 ? cown[2] : cown[3]));
+            bool is_t0 = false;
             if (l < n_here && L.cand[l] >= 0)
-                s2_type_slot<INDEXED>(A, L, pf, c0, n_here, l, ownv, code, va, vb, fromb);
-            L.code[l] = (uint8_t)(code | (fromb ? 4 : 0));
-            L.va[l] = va;
-            L.vb[l] = vb;
+                is_t0 = s2_type_slot<INDEXED>(A, L, pf, c0, n_here, l, ownv, code, va, vb, fromb);
+            if (is_t0) {
+                code = L.code[l] & 3;  // typed above
+            } else {
+                L.code[l] = (uint8_t)(code | (fromb ? 4 : 0));
+                L.va[l] = va;
+                L.vb[l] = vb;
+            }
             const uint64_t b0 = __ballot(code == 1), b1 = __ballot(code == 2), b2 = __ballot(code == 3);
             if (lane == 0) {
                 int32_t *c = L.cnt[r * S2_WAVES + wave];
