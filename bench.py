@@ -104,6 +104,7 @@ def main():
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    local = int(os.environ.get("LPF_LOCAL_DEVICE", local))  # (functional multi-rank runs on a one-GPU box)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     cfg = D.CONFIGS[args.config]
@@ -280,9 +281,17 @@ def main():
     pairs_per_s = world * bs * args.steps / elapsed
     value_incl_encoder = world * bs / ((ms_per_step + encoder_ms) * 1e-3)
 
+    kt = KernelTimer.summary() if not args.no_kernel_timing else {}
+    # one instrumented encoder pass for the aggregation kernel's roofline -- on EVERY rank: a row-sharded encoder
+    # all-gathers, and a collective issued by rank 0 alone would wait for ever
+    KernelTimer.reset()
+    KernelTimer.enabled = True
+    model.propagate()
+    enc = KernelTimer.summary()
+    KernelTimer.enabled = False
+
     result = None
     if rank == 0:
-        kt = KernelTimer.summary() if not args.no_kernel_timing else {}
         # ---- roofline: every modelled kernel, the dominant one of the timed region reported as "roofline"
         roofline, rooflines, kernels = None, {}, {}
         if kt:
@@ -362,17 +371,16 @@ def main():
                 roofline["batch_stats"] = {"n_sel": n_sel, "sum_deg": sum_deg, "sum_ppr_len": sum_ppr,
                                            "sum_p1_len": sum_p1, "slots": slots}
         # encoder aggregation kernel (outside the timed pair-stage region): SURVEY 8(d) bytes per layer
-        KernelTimer.reset()
-        KernelTimer.enabled = True
-        model.propagate()
-        enc = KernelTimer.summary()
-        KernelTimer.enabled = False
         if "spmm_csr" in enc:
             a_hat = model._device_graph("prop", data["adj_t"])
-            nnz = a_hat.nnz
-            byts = nnz * 8.0 + 8.0 * (n + 1) + 4.0 * d * nnz + 4.0 * d * n
+            nnz, n_rows = a_hat.nnz, n
+            if world > 1 and model.encoder_mode == "sharded":  # this rank aggregates its row block only
+                lo, hi = LD.row_range(n, world, rank)
+                nnz, n_rows = int(a_hat.rowptr[hi] - a_hat.rowptr[lo]), hi - lo
+            byts = nnz * 8.0 + 8.0 * (n_rows + 1) + 4.0 * d * nnz + 4.0 * d * n_rows
             ach = byts / (enc["spmm_csr"][2] * 1e-3) / 1e9
-            floor = nnz * 8.0 + 8.0 * (n + 1) + 2 * 4.0 * d * n   # every feature row read once + written once
+            # every feature row read once (all of them: any row can be a neighbour) + the local rows written once
+            floor = nnz * 8.0 + 8.0 * (n_rows + 1) + 4.0 * d * n + 4.0 * d * n_rows
             ach_floor = floor / (enc["spmm_csr"][2] * 1e-3) / 1e9
             rooflines["spmm_csr"] = {"kernel": "spmm_csr (encoder, per layer)", "bound": "hbm",
                                      "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

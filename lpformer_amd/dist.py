@@ -28,8 +28,8 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # (LPF_DIST_BACKEND=gloo: functional runs of the N > 1 path with several ranks on ONE GPU)
+            backend = os.environ.get("LPF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
