@@ -133,9 +133,9 @@ int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t bat
  *          pointers counting padded entries, t0_len[i] = real entries of row i, t0_cv = interleaved {int32 column,
  *          float value} pairs (a 16-entry block = one aligned 128-byte line), t0_skip[b] = last column of block b
  *          (+ 40 spare entries): a lookup reads the row's skip entries, then one block that carries the value.
- *   HASHED index (the P1 rows with adj_selfp): row i owns val_len[i] buckets of 16 {column, value} entries (val_cv,
- *          one aligned 128-byte line per bucket, unused entries column INT32_MAX), val_rowptr counting entries
- *          (16 per bucket); entry (i, c) sits in bucket  mulhi_u32(c * 2654435761 mod 2^32, val_len[i])  and no
+ *   HASHED index (the P1 rows with adj_selfp): row i owns val_len[i] buckets of 8 {column, value} entries (val_cv,
+ *          64 aligned bytes per bucket, unused entries column INT32_MAX), val_rowptr counting entries
+ *          (8 per bucket); entry (i, c) sits in bucket  mulhi_u32(c * 2654435761 mod 2^32, val_len[i])  and no
  *          bucket overflows (the builder grows a row's bucket count until that holds): ONE memory round trip per
  *          lookup.  Without adj_selfp (adjacency override) val_col / val_val are the raw PPR rows, plain sorted CSR.
  *   adjx_* UNMASKED adjacency for the >1-hop exclusion (link_transformer.py:443); NULL = the typing adjacency

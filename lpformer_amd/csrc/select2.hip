@@ -191,22 +191,24 @@ __device__ __forceinline__ bool s2_lookup_blocked(const int2 *__restrict__ cv, c
     return eq;
 }
 
-// Lookup in a row of a HASHED index (lpformer_amd/graph.py HashedIndex): the row owns n_buckets buckets of 16
-// {column, value} entries, the key's bucket follows from its hash, and the builder made sure no bucket overflows -- one
-// memory round trip and no search (the blocked layout above needs the row's skip entries first: two dependent round
-// trips and about twice the instructions, and the instruction issue is what select_run_kernel runs at).
+// Lookup in a row of a HASHED index (lpformer_amd/graph.py HashedIndex): the row owns n_buckets buckets of 8
+// {column, value} entries (64 aligned bytes), the key's bucket follows from its hash, and the builder made sure no
+// bucket overflows -- one memory round trip and no search (the blocked layout above needs the row's skip entries
+// first: two dependent round trips and about twice the instructions).  Buckets of 8 rather than 16: every 16-byte load
+// of a lane is a separate line look-up in the vector L1, and half of the slots of a batch come through here.
+constexpr int S2_HASH_BUCKET = 8;
 __device__ __forceinline__ bool s2_lookup_hashed(const int2 *__restrict__ cv, int64_t row0, int n_buckets, int32_t key,
                                                  float &val) {
     if (n_buckets <= 0) return false;
     const uint32_t b = __umulhi((uint32_t)key * 2654435761u, (uint32_t)n_buckets);
-    const int4 *blk = reinterpret_cast<const int4 *>(cv + row0 + 16 * (int64_t)b);  // {col, val, col, val} x 8
+    const int4 *blk = reinterpret_cast<const int4 *>(cv + row0 + S2_HASH_BUCKET * (int64_t)b);  // {col, val, col, val} x 4
     bool eq = false;
     int bits = 0;
-    int4 bv[8];
+    int4 bv[S2_HASH_BUCKET / 2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) bv[q] = blk[q];
+    for (int q = 0; q < S2_HASH_BUCKET / 2; ++q) bv[q] = blk[q];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < S2_HASH_BUCKET / 2; ++q) {
         if (bv[q].x == key) { eq = true; bits = bv[q].y; }
         if (bv[q].z == key) { eq = true; bits = bv[q].w; }
     }

@@ -262,15 +262,16 @@ def ppr_filter_device_blocked(ppr: DeviceCSR, mode: int, theta: float) -> Blocke
 
 
 HASH_MUL = 2654435761  # Fibonacci hashing constant (2^32 / golden ratio)
+HASH_BUCKET = 8        # entries per bucket of a hashed index (one 64-byte half line)
 
 
 @dataclass
 class HashedIndex:
     """A filtered PPR index (P1) laid out for ONE-step lookups (csrc/select2.hip, s2_lookup_hashed): row i owns
-    ``len[i]`` buckets of 16 {column, value bits} entries (one aligned 128-byte line each, empty entries carry column
-    INT32_MAX), entry (i, c) lives in bucket ``((c * HASH_MUL mod 2^32) * len[i]) >> 32`` of the row.  Bucket counts
-    start at one per eight entries and grow for the rows where some bucket would hold more than 16, so a lookup never
-    has to look further than its bucket.  ``rowptr`` counts ENTRIES (16 per bucket), like a blocked index."""
+    ``len[i]`` buckets of HASH_BUCKET = 8 {column, value bits} entries (64 aligned bytes each, empty entries carry
+    column INT32_MAX), entry (i, c) lives in bucket ``((c * HASH_MUL mod 2^32) * len[i]) >> 32`` of the row.  Bucket
+    counts start at one per four entries and grow for the rows where some bucket would hold more than 8, so a lookup
+    never has to look further than its bucket.  ``rowptr`` counts ENTRIES (8 per bucket)."""
     rowptr: torch.Tensor   # int64 [n+1]
     cv: torch.Tensor       # int32 [16 * buckets, 2]
     len: torch.Tensor      # int32 [n]: buckets per row
@@ -297,13 +298,13 @@ def hash_index_device(p: DeviceCSR) -> HashedIndex:
     col = p.col[:nnz].long()
     row = torch.repeat_interleave(torch.arange(n, device=dev), ln)
     h = (col * HASH_MUL) & 0xFFFFFFFF
-    nbk = (ln + 7) // 8
+    nbk = (ln + HASH_BUCKET // 2 - 1) // (HASH_BUCKET // 2)
     for _ in range(64):
         base = torch.cumsum(nbk, 0) - nbk
         total = int(nbk.sum().item())
         key = base[row] + ((h * nbk[row]) >> 32)
         cnt = torch.bincount(key, minlength=max(total, 1))
-        over = cnt > BLOCK
+        over = cnt > HASH_BUCKET
         if nnz == 0 or not bool(over.any().item()):
             break
         bucket_row = torch.repeat_interleave(torch.arange(n, device=dev), nbk)
@@ -311,17 +312,17 @@ def hash_index_device(p: DeviceCSR) -> HashedIndex:
         nbk[bad] = nbk[bad] * 3 // 2 + 1
     else:
         raise RuntimeError("hash_index_device: bucket sizes did not settle")
-    cv = torch.zeros((max(total, 1) * BLOCK, 2), dtype=torch.int32, device=dev)
+    cv = torch.zeros((max(total, 1) * HASH_BUCKET, 2), dtype=torch.int32, device=dev)
     cv[:, 0] = 2**31 - 1
     if nnz:
         order = torch.argsort(key, stable=True)
         key_s = key[order]
         start = torch.cumsum(cnt, 0) - cnt
-        pos = key_s * BLOCK + (torch.arange(nnz, device=dev) - start[key_s])
+        pos = key_s * HASH_BUCKET + (torch.arange(nnz, device=dev) - start[key_s])
         cv[pos, 0] = p.col[:nnz][order]
         cv[pos, 1] = p.val[:nnz].view(torch.int32)[order]
     rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(nbk * BLOCK, 0, out=rowptr[1:])
+    torch.cumsum(nbk * HASH_BUCKET, 0, out=rowptr[1:])
     return HashedIndex(rowptr, cv.contiguous(), nbk.to(torch.int32), n)
 
 

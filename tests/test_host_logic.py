@@ -200,7 +200,7 @@ def test_encoder_plan_cost_model():
 
 def test_hashed_index_layout():
     """graph.hash_index_device: every entry sits in the bucket its hash names, no bucket holds more than 16, the
-    compact view gives the input back (the builder is plain torch, so it runs on the CPU too)."""
+    compact view gives the input back, no bucket holds more than HASH_BUCKET (the builder is plain torch, so it runs on the CPU too)."""
     import torch
     from lpformer_amd import graph
     rng = np.random.default_rng(5)
@@ -222,9 +222,10 @@ def test_hashed_index_layout():
     back = h.to_host_compact()
     assert np.array_equal(back.rowptr, rp) and np.array_equal(back.col, col) and np.array_equal(back.val, val)
     cv, hrp, nbk = h.cv.numpy(), h.rowptr.numpy(), h.len.numpy().astype(np.int64)
-    assert np.array_equal(np.diff(hrp), 16 * nbk) and nbk[7] == 0
+    hb = graph.HASH_BUCKET
+    assert np.array_equal(np.diff(hrp), hb * nbk) and nbk[7] == 0
     for i in (0, 11, 12, 299):
         for c in cols[i][:50]:
             b = ((int(c) * graph.HASH_MUL & 0xFFFFFFFF) * int(nbk[i])) >> 32
-            line = cv[hrp[i] + 16 * b: hrp[i] + 16 * b + 16, 0]
+            line = cv[hrp[i] + hb * b: hrp[i] + hb * b + hb, 0]
             assert c in line
