@@ -95,7 +95,7 @@ def main():
                     help="N > 1: every rank runs the whole encoder, or rows are sharded with an all-gather per layer; "
                          "auto = the cheaper one by lpformer_amd.dist.encoder_plan (measured encoder time and "
                          "measured all-gather rate)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
 
