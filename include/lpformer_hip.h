@@ -74,7 +74,8 @@ int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t 
 
 /* bf16 THROUGHPUT MODE of the aggregation (BASELINE.json config 2 names bf16 storage; SURVEY 8b lpf_spmm_csr_bf16):
  * the gathered table H holds bf16 rows (ldh in bf16 elements, rows 16-byte aligned) -- half the gather bytes, which
- * are what bounds this kernel --, the sum over neighbours, the epilogue and the output stay fp32.  The table comes
+ * are what bounds this kernel --, the sum over neighbours, the epilogue and the output stay fp32 (D % 8 == 0: a lane
+ * gathers 8 bf16 = 16 bytes, so a row needs half the lanes of the fp32 kernel).  The table comes
  * from lpf_gemm_f32_out_bf16 (the layer's X W^T, rounded to nearest even once). */
 int lpf_spmm_csr_bf16(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,
                       const void *H_bf16, int64_t ldh, float *out, int64_t ldo, const float *bias,

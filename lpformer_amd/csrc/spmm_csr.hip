@@ -10,37 +10,48 @@
 
 namespace {
 
-template <int G>
-__device__ __forceinline__ float4 group_layernorm(float4 y, bool act, int D, const float *__restrict__ g,
-                                                  const float *__restrict__ b, int off) {
-    float s = act ? (y.x + y.y + y.z + y.w) : 0.f;
+// A lane holds V consecutive float4 (V = 1: fp32 table, 16 bytes gathered per lane; V = 2: bf16 table, 8 bf16 = 16
+// bytes gathered per lane, so a row needs half the lanes and a wavefront works on twice the rows).
+template <int G, int V>
+__device__ __forceinline__ void group_layernorm(float4 (&y)[V], bool act, int D, const float *__restrict__ g,
+                                                const float *__restrict__ b, int off) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) s += act ? (y[v].x + y[v].y + y[v].z + y[v].w) : 0.f;
     const float mean = lpf_group_sum<G>(s) / (float)D;
-    float4 d = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
-    float q = act ? (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) : 0.f;
+    float q = 0.f;
+    float4 d[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        d[v] = make_float4(y[v].x - mean, y[v].y - mean, y[v].z - mean, y[v].w - mean);
+        q += act ? (d[v].x * d[v].x + d[v].y * d[v].y + d[v].z * d[v].z + d[v].w * d[v].w) : 0.f;
+    }
     const float var = lpf_group_sum<G>(q) / (float)D;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     if (act) {
-        const float4 gg = *reinterpret_cast<const float4 *>(g + off);
-        const float4 bb = *reinterpret_cast<const float4 *>(b + off);
-        y.x = d.x * rstd * gg.x + bb.x;
-        y.y = d.y * rstd * gg.y + bb.y;
-        y.z = d.z * rstd * gg.z + bb.z;
-        y.w = d.w * rstd * gg.w + bb.w;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float4 gg = *reinterpret_cast<const float4 *>(g + off + 4 * v);
+            const float4 bb = *reinterpret_cast<const float4 *>(b + off + 4 * v);
+            y[v].x = d[v].x * rstd * gg.x + bb.x;
+            y[v].y = d[v].y * rstd * gg.y + bb.y;
+            y[v].z = d[v].z * rstd * gg.z + bb.z;
+            y[v].w = d[v].w * rstd * gg.w + bb.w;
+        }
     }
-    return y;
 }
 
 constexpr int SPMM_LONG = 128;  // rows with more stored entries than this are left to spmm_long_rows_kernel
 
 // acc += sum over edges [e0, e1) taken in chunks of G starting at e0 + first_chunk*G with stride chunk_stride*G:
 // a chunk is one coalesced (col, weight) read by the group, then lane-by-lane broadcasts with four 16-byte neighbour
-// gathers in flight.
-// (HB: the gathered table H holds bf16 rows -- half the gather bytes, the bound of this kernel; the sum stays fp32)
-template <int G, bool HB>
-__device__ __forceinline__ void spmm_accumulate(float4 &acc, int64_t e0, int64_t e1, int first_chunk, int chunk_stride,
-                                                const int32_t *__restrict__ col, const float *__restrict__ w,
-                                                const float *__restrict__ H, int64_t ldh, int off, bool act, int gbase,
-                                                int lig) {
+// gathers in flight.  (V = 2: the gathered table H holds bf16 rows -- half the gather bytes, the bound of this kernel;
+// the sum stays fp32.)
+template <int G, int V>
+__device__ __forceinline__ void spmm_accumulate(float4 (&acc)[V], int64_t e0, int64_t e1, int first_chunk,
+                                                int chunk_stride, const int32_t *__restrict__ col,
+                                                const float *__restrict__ w, const float *__restrict__ H, int64_t ldh,
+                                                int off, bool act, int gbase, int lig) {
     for (int64_t e = e0 + (int64_t)first_chunk * G; e < e1; e += (int64_t)chunk_stride * G) {
         const int64_t mine = e + lig;
         int32_t c = 0;
@@ -53,60 +64,78 @@ __device__ __forceinline__ void spmm_accumulate(float4 &acc, int64_t e0, int64_t
         for (int t = 0; t < cnt; t += 4) {  // lanes past `cnt` carry (col 0, weight 0): harmless gathers
             int32_t cc[4];
             float ww[4];
-            float4 h[4];
+            float4 h[4][V];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 cc[u] = __shfl(c, gbase + ((t + u) & (G - 1)), 64);
                 ww[u] = __shfl(wv, gbase + ((t + u) & (G - 1)), 64);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if constexpr (HB) {
-                    uint2 b = make_uint2(0u, 0u);
-                    if (act) b = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(H) +
-                                                                  (int64_t)cc[u] * ldh + off);
-                    h[u] = make_float4(__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
-                                       __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u));
-                } else {
-                    h[u] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
             for (int u = 0; u < 4; ++u) {
-                acc.x = fmaf(ww[u], h[u].x, acc.x);
-                acc.y = fmaf(ww[u], h[u].y, acc.y);
-                acc.z = fmaf(ww[u], h[u].z, acc.z);
-                acc.w = fmaf(ww[u], h[u].w, acc.w);
+                if constexpr (V == 2) {
+                    uint4 b = make_uint4(0u, 0u, 0u, 0u);
+                    if (act) b = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(H) +
+                                                                  (int64_t)cc[u] * ldh + off);
+                    h[u][0] = make_float4(__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
+                                          __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u));
+                    h[u][1] = make_float4(__uint_as_float(b.z << 16), __uint_as_float(b.z & 0xffff0000u),
+                                          __uint_as_float(b.w << 16), __uint_as_float(b.w & 0xffff0000u));
+                } else {
+                    h[u][0] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    acc[v].x = fmaf(ww[u], h[u][v].x, acc[v].x);
+                    acc[v].y = fmaf(ww[u], h[u][v].y, acc[v].y);
+                    acc[v].z = fmaf(ww[u], h[u][v].z, acc[v].z);
+                    acc[v].w = fmaf(ww[u], h[u][v].w, acc[v].w);
+                }
         }
     }
 }
 
 // fused epilogue (GCN.forward lines after conv(); propagate's gnn_norm for the last layer); result stored by the group
-template <int G>
-__device__ __forceinline__ void spmm_epilogue(float4 y, int64_t row, bool live, bool act, int D, int off,
+template <int G, int V>
+__device__ __forceinline__ void spmm_epilogue(float4 (&y)[V], int64_t row, bool live, bool act, int D, int off,
                                               float *__restrict__ out, int64_t ldo, const float *__restrict__ bias,
                                               const float *__restrict__ ln_g, const float *__restrict__ ln_b,
                                               const float *__restrict__ residual, int64_t ldr,
                                               const float *__restrict__ ln2_g, const float *__restrict__ ln2_b,
                                               uint32_t flags) {
     if (bias && act) {
-        const float4 bv = *reinterpret_cast<const float4 *>(bias + off);
-        y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + off + 4 * v);
+            y[v].x += bv.x; y[v].y += bv.y; y[v].z += bv.z; y[v].w += bv.w;
+        }
     }
-    if (ln_g) y = group_layernorm<G>(y, act, D, ln_g, ln_b, off);
+    if (ln_g) group_layernorm<G, V>(y, act, D, ln_g, ln_b, off);
     if (flags & LPF_FLAG_RELU) {
-        y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            y[v].x = fmaxf(y[v].x, 0.f); y[v].y = fmaxf(y[v].y, 0.f);
+            y[v].z = fmaxf(y[v].z, 0.f); y[v].w = fmaxf(y[v].w, 0.f);
+        }
     }
     if (residual && act && live) {
-        const float4 rv = *reinterpret_cast<const float4 *>(residual + row * ldr + off);
-        y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float4 rv = *reinterpret_cast<const float4 *>(residual + row * ldr + off + 4 * v);
+            y[v].x += rv.x; y[v].y += rv.y; y[v].z += rv.z; y[v].w += rv.w;
+        }
     }
-    if (ln2_g) y = group_layernorm<G>(y, act, D, ln2_g, ln2_b, off);
-    if (act && live) *reinterpret_cast<float4 *>(out + row * ldo + off) = y;
+    if (ln2_g) group_layernorm<G, V>(y, act, D, ln2_g, ln2_b, off);
+    if (act && live) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) *reinterpret_cast<float4 *>(out + row * ldo + off + 4 * v) = y[v];
+    }
 }
 
-template <int G, bool HB>
+template <int G, int V>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const int64_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ col, const float *__restrict__ w,
                                                        const float *__restrict__ H, int64_t ldh,
@@ -121,7 +150,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const i
     const int lane = threadIdx.x & 63;
     const int grp = lane / G, lig = lane % G;
     const int gbase = grp * G;
-    const int off = 4 * lig;
+    const int off = 4 * V * lig;
     const bool act = off < D;
     const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -138,16 +167,19 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const i
             live = false;
             e1 = e0;
         }
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        spmm_accumulate<G, HB>(acc, e0, e1, 0, 1, col, w, H, ldh, off, act, gbase, lig);
-        spmm_epilogue<G>(acc, row, live, act, D, off, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags);
+        float4 acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        spmm_accumulate<G, V>(acc, e0, e1, 0, 1, col, w, H, ldh, off, act, gbase, lig);
+        spmm_epilogue<G, V>(acc, row, live, act, D, off, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b,
+                            flags);
     }
 }
 
 // Hub rows (more than SPMM_LONG entries): one 256-thread workgroup per row.  The NG = 256/G lane groups take chunks of
 // G edges round-robin, their partial sums meet in LDS and are added in group order (deterministic), then group 0 runs
 // the same fused epilogue.
-template <int G, bool HB>
+template <int G, int V>
 __global__ __launch_bounds__(256) void spmm_long_rows_kernel(
     const int32_t *__restrict__ long_rows, int D, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ w, const float *__restrict__ H, int64_t ldh, float *__restrict__ out, int64_t ldo,
@@ -155,24 +187,32 @@ __global__ __launch_bounds__(256) void spmm_long_rows_kernel(
     const float *__restrict__ residual, int64_t ldr, const float *__restrict__ ln2_g, const float *__restrict__ ln2_b,
     uint32_t flags) {
     constexpr int NG = 256 / G;
-    __shared__ float4 part[NG][G];
+    __shared__ float4 part[NG][G][V];
     const int tid = threadIdx.x, grp = tid / G, lig = tid % G;
     const int gbase = ((tid & 63) / G) * G;
-    const int off = 4 * lig;
+    const int off = 4 * V * lig;
     const bool act = off < D;
     const int64_t row = long_rows[blockIdx.x];
     const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    spmm_accumulate<G, HB>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
-    part[grp][lig] = acc;
+    float4 acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    spmm_accumulate<G, V>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
+#pragma unroll
+    for (int v = 0; v < V; ++v) part[grp][lig][v] = acc[v];
     __syncthreads();
     if (grp == 0) {
-        float4 y = part[0][lig];
+        float4 y[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) y[v] = part[0][lig][v];
         for (int g = 1; g < NG; ++g) {
-            const float4 v = part[g][lig];
-            y.x += v.x; y.y += v.y; y.z += v.z; y.w += v.w;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float4 x = part[g][lig][v];
+                y[v].x += x.x; y[v].y += x.y; y[v].z += x.z; y[v].w += x.w;
+            }
         }
-        spmm_epilogue<G>(y, row, true, act, D, off, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags);
+        spmm_epilogue<G, V>(y, row, true, act, D, off, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags);
     }
 }
 
@@ -223,29 +263,36 @@ int spmm_launch(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col,
     if (n == 0) return LPF_OK;
     LPF_REQUIRE(n_long >= 0 && (n_long == 0 || long_rows) && n_long < (1ll << 31));
     LPF_REQUIRE(n > 0 && rowptr && col && w && H && out);
-    if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
+    if (D <= 0 || (D & (HB ? 7 : 3)) || D > 256) return LPF_ERR_UNSUPPORTED;
     LPF_REQUIRE(ldh >= D && ldo >= D && (ldh & 3) == 0 && (ldo & 3) == 0 && lpf_aligned16(H) && lpf_aligned16(out));
     LPF_REQUIRE((!ln_g) == (!ln_b) && (!ln2_g) == (!ln2_b));
     LPF_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= D && lpf_aligned16(residual)));
     LPF_REQUIRE(!bias || lpf_aligned16(bias));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int G = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
+    constexpr int V = HB ? 2 : 1;  // float4 per lane
+    const int G = (D <= 64 ? 16 : (D <= 128 ? 32 : 64)) / V;
     const int rpw = 64 / G;
     int64_t blocks = (n + 4 * rpw - 1) / (4 * rpw);
     if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond ~32 blocks per CU
 #define LPF_SPMM_LAUNCH(GG)                                                                                        \
     do {                                                                                                           \
-        hipLaunchKernelGGL((spmm_csr_kernel<GG, HB>), dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr, col,  \
+        hipLaunchKernelGGL((spmm_csr_kernel<GG, V>), dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr, col,   \
                            w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags,              \
                            long_rows ? 1 : 0);                                                                     \
         if (n_long > 0)                                                                                            \
-            hipLaunchKernelGGL((spmm_long_rows_kernel<GG, HB>), dim3((unsigned)n_long), dim3(256), 0, s,           \
+            hipLaunchKernelGGL((spmm_long_rows_kernel<GG, V>), dim3((unsigned)n_long), dim3(256), 0, s,            \
                                long_rows, D, rowptr, col, w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr,    \
                                ln2_g, ln2_b, flags);                                                               \
     } while (0)
-    if (G == 16) LPF_SPMM_LAUNCH(16);
-    else if (G == 32) LPF_SPMM_LAUNCH(32);
-    else LPF_SPMM_LAUNCH(64);
+    if constexpr (HB) {
+        if (G == 8) LPF_SPMM_LAUNCH(8);
+        else if (G == 16) LPF_SPMM_LAUNCH(16);
+        else LPF_SPMM_LAUNCH(32);
+    } else {
+        if (G == 16) LPF_SPMM_LAUNCH(16);
+        else if (G == 32) LPF_SPMM_LAUNCH(32);
+        else LPF_SPMM_LAUNCH(64);
+    }
 #undef LPF_SPMM_LAUNCH
     LPF_CHECK_LAUNCH();
     return LPF_OK;
