@@ -228,7 +228,7 @@ def main():
     #      model.precision = "bf16" (bf16 storage of Z + bf16 matrix cores in the attention kernel)
     bf16 = None
     if not args.no_bf16 and d in (32, 64, 128):
-        model.precision = "bf16"
+        model.precision = model.tail_precision = "bf16"
         for i in range(max(args.warmup, len(lanes))):
             step_on(i)
         torch.cuda.synchronize()
@@ -239,15 +239,16 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el16 = LD.max_over_ranks(time.perf_counter() - t0, dev)
-        model.precision = "f32"
+        model.precision = model.tail_precision = "f32"
         ref_l = model.score_pairs(batches[0], h, score, logits=True).clone()
-        model.precision = "bf16"
+        model.precision = model.tail_precision = "bf16"
         got_l = model.score_pairs(batches[0], h, score, logits=True)
         bf16 = {"value": round(world * bs * args.steps / el16, 1), "unit": "pairs/s",
                 "ms_per_step": round(el16 * 1e3 / args.steps, 4),
                 "max_abs_logit_diff_vs_f32": float((got_l - ref_l).abs().max()),
-                "what": "bf16 storage of the node table Z + v_mfma_f32_32x32x16_bf16 for Wfold h (fp32 accumulate); "
-                        "selection, q, softmax, dense tail in fp32; selected index sets identical to fp32"}
+                "what": "bf16 storage of the node table Z + v_mfma_f32_32x32x16_bf16 for Wfold h, bf16 weights and "
+                        "v_mfma_f32_16x16x16_bf16 for the two GEMMs of the dense tail (fp32 accumulate everywhere); "
+                        "selection, q, softmax, record merge, LayerNorms in fp32; selected index sets identical to fp32"}
         KernelTimer.reset()
         KernelTimer.enabled = True
         for i in range(args.steps):
@@ -256,7 +257,9 @@ def main():
         KernelTimer.enabled = False
         if "pair_attention_fused" in kt16:
             bf16["pair_attention_fused_ms"] = round(kt16["pair_attention_fused"][2], 4)
-        model.precision = "f32"
+        if "tail_chain" in kt16:
+            bf16["tail_chain_ms"] = round(kt16["tail_chain"][2], 4)
+        model.precision = model.tail_precision = "f32"
     if bf16 is not None and encoder_bf16 is not None:
         bf16.update(encoder_bf16)
     elif encoder_bf16 is not None:

@@ -281,6 +281,15 @@ int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, const float
                              const float *bB, const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre,
                              const float *wC_packed, const float *bC, const float *w_dot, const float *b_dot,
                              const int64_t *sel_ctl, float *logit, float *prob, void *stream);
+/* bf16 THROUGHPUT MODE of the dense tail (SURVEY 8b lpf_pair_head_bf16): the two GEMMs run on
+ * v_mfma_f32_16x16x16_bf16 -- weights wB / wC as bf16 images in the same element order as the fp32 ones (a lane's four
+ * consecutive fp32 become its four bf16), activations rounded to bf16 as they enter a GEMM, fp32 accumulate; the
+ * record merge, both LayerNorms, the dot product and the sigmoid stay fp32. */
+int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts, const float *part, const float *bnd,
+                             int64_t units_cap, const int32_t *type_ptr, const float *att_bias, const float *lnA_g, const float *lnA_b, const void *wB_packed_bf16,
+                             const float *bB, const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre,
+                             const void *wC_packed_bf16, const float *bC, const float *w_dot, const float *b_dot,
+                             const int64_t *sel_ctl, float *logit, float *prob, void *stream);
 
 /* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
  * logit or prob may be NULL. */

@@ -41,6 +41,8 @@ HIP_PROTOTYPES = {
     "lpf_pair_attention_fused_bf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_tail_chain_merge_f32": [i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
                                  vp, vp, vp],
+    "lpf_tail_chain_merge_bf16": [i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
+                                 vp, vp, vp],
     "lpf_rowdot_sigmoid_f32": [i64, i32, vp, i64, vp, f32, vp, vp, vp],
     "lpf_tail_chain_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
                            vp, vp],

@@ -11,6 +11,8 @@
 // count features), stage C starts with k-groups read from global memory (r_e, produced on the side stream by the
 // elementwise branch).  Against three separate launches this removes two launch ramps and the round trips of the
 // attention output and of r_p through HBM.
+#include <type_traits>
+
 #include "lpf_common.h"
 
 namespace {
@@ -46,14 +48,17 @@ struct TailArgs {
 
 constexpr int tc_per_thread(int ntp) { return (ntp * 64 + TC_THREADS - 1) / TC_THREADS; }
 
-template <int P>
-__device__ __forceinline__ void tc_load(f32x4 (&r)[P], const float *packed, int stage, int tid) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(packed) + (int64_t)stage * (P * TC_THREADS);
+// weight elements: one per (tile, lane) and k-group -- four fp32 (f32x4) or, in the bf16 variant, four bf16 (uint2) of
+// W[16 c + i][16 ks + 4 q .. + 3]
+typedef short bf16x4_bits __attribute__((ext_vector_type(4)));
+template <int P, typename T>
+__device__ __forceinline__ void tc_load(T (&r)[P], const float *packed, int stage, int tid) {
+    const T *src = reinterpret_cast<const T *>(packed) + (int64_t)stage * (P * TC_THREADS);
 #pragma unroll
     for (int e = 0; e < P; ++e) r[e] = src[e * TC_THREADS + tid];
 }
-template <int P>
-__device__ __forceinline__ void tc_store(const f32x4 (&r)[P], f32x4 *slab, int tid) {
+template <int P, typename T>
+__device__ __forceinline__ void tc_store(const T (&r)[P], T *slab, int tid) {
 #pragma unroll
     for (int e = 0; e < P; ++e) slab[e * TC_THREADS + tid] = r[e];
 }
@@ -68,6 +73,21 @@ __device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const f32x4 *lw, cons
     for (int u = 0; u < 4; ++u)  // consecutive MFMAs go to different accumulators
 #pragma unroll
         for (int c = 0; c < TPW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][u], bv[u], acc[c], 0, 0, 0);
+}
+// bf16 variant: the four fp32 MFMAs of a k-group become ONE v_mfma_f32_16x16x16_bf16 -- a lane's four A values and
+// four B values (k = 4 q .. 4 q + 3 of the group) are exactly that instruction's operands; the activations are rounded
+// to bf16 here, the accumulation stays fp32.
+template <int TPW>
+__device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint2 *lw, const f32x4 bv) {
+    bf16x4_bits b;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = (short)lpf_f32_to_bf16(bv[u]);
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const uint2 w = lw[c * 64];
+        const bf16x4_bits a = {(short)(w.x & 0xffffu), (short)(w.x >> 16), (short)(w.y & 0xffffu), (short)(w.y >> 16)};
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[c], 0, 0, 0);
+    }
 }
 
 __device__ __forceinline__ float tc_quad_sum(float v) {
@@ -125,9 +145,10 @@ struct TcShape {
     static constexpr size_t BYTES = (size_t)(2 * SLAB + HID) * sizeof(f32x4) + TC_WAVES * 16 * sizeof(float);
 };
 
-template <int NTA, int NTB, int NTC>
+template <int NTA, int NTB, int NTC, bool WB = false>
 __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArgs A) {
     using S = TcShape<NTA, NTB, NTC>;
+    using WT = typename std::conditional<WB, uint2, f32x4>::type;  // weight element (WB: bf16 weights, merge mode only)
     constexpr int NTPA = S::NTPA, NTPB = S::NTPB, NTPC = S::NTPC;
     constexpr int TPWA = NTPA / 2, TPWB = NTPB / 2, TPWC = NTPC / 2;
     constexpr int NGE = NTA;  // k-groups of r_e
@@ -150,11 +171,11 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
 #pragma unroll
     for (int c = 0; c < TPWA; ++c) accA[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int seg_cnt[3] = {0, 0, 0};
-    if (A.part == nullptr) {
+    if (!WB && A.part == nullptr) {
         const float *xa = A.x + mm * A.ldx;
         const int ngA = (A.KA + 15) >> 4;
         f32x4 wr[S::PA];
-        tc_load<S::PA>(wr, A.wA, 0, tid);
+        tc_load<S::PA>(wr, A.wA, 0, tid);  // (the GEMM form of stage A exists in fp32 only)
         int kk = 4 * q < A.KA ? 4 * q : A.KA - 4;  // clamped into the row; out-of-range groups are zeroed below
         f32x4 xr = *reinterpret_cast<const f32x4 *>(xa + kk);
 #pragma unroll 1
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
             buf ^= 1;
         }
     }
-    f32x4 wrB[S::PB];
+    WT wrB[S::PB];
     tc_load<S::PB>(wrB, A.wB, 0, tid);  // stage B's first weights fly during the epilogue
     if (A.part == nullptr) {
         const int fbase = 16 * half * TPWA + 4 * q;
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
         }
 #pragma unroll
         for (int kg = 0; kg < NTPA + 1; ++kg) {
-            f32x4 *lw = lds + buf * S::SLAB;
+            WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
             tc_store<S::PB>(wrB, lw, tid);
             __syncthreads();  // (kg == 0: also publishes stage A's hidden tiles)
             if (kg + 1 < NTPA + 1) tc_load<S::PB>(wrB, A.wB, kg + 1, tid);
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
             buf ^= 1;
         }
     }
-    f32x4 wrC[S::PC];
+    WT wrC[S::PC];
     tc_load<S::PC>(wrC, A.wC, 0, tid);
     const float *rer = A.re + mm * A.ldre + 4 * q;
     f32x4 xr = *reinterpret_cast<const f32x4 *>(rer);  // stage C's first input group
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
 #pragma unroll 1
     for (int kg = 0; kg < NGE; ++kg) {  // r_e, read from global memory
         const f32x4 bv = xr;
-        f32x4 *lw = lds + buf * S::SLAB;
+        WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
         tc_store<S::PC>(wrC, lw, tid);
         __syncthreads();
         tc_load<S::PC>(wrC, A.wC, kg + 1, tid);  // (stage NGE exists: the r_p groups follow)
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
     }
 #pragma unroll
     for (int kg = 0; kg < NTPB; ++kg) {  // r_p, straight from LDS
-        f32x4 *lw = lds + buf * S::SLAB;
+        WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
         tc_store<S::PC>(wrC, lw, tid);
         __syncthreads();  // (kg == 0: also publishes stage B's hidden tiles)
         if (kg + 1 < NTPB) tc_load<S::PC>(wrC, A.wC, NGE + kg + 1, tid);
@@ -361,10 +382,10 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
     }
 }
 
-template <int NTA, int NTB, int NTC>
+template <int NTA, int NTB, int NTC, bool WB = false>
 int tc_launch(const TailArgs &a, hipStream_t s) {
     constexpr size_t lds = TcShape<NTA, NTB, NTC>::BYTES;
-    auto kern = tail_chain_kernel<NTA, NTB, NTC>;
+    auto kern = tail_chain_kernel<NTA, NTB, NTC, WB>;
     static bool lds_set = false;  // (per instantiation; the attribute is sticky, one call is enough)
     if (lds > 64 * 1024 && !lds_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -429,6 +450,34 @@ extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, 
         case 32: return tc_launch<2, 3, 4>(a, s);
         case 64: return tc_launch<4, 5, 8>(a, s);
         case 128: return tc_launch<8, 9, 16>(a, s);
+        default: return LPF_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts, const float *part, const float *bnd,
+                                         int64_t units_cap, const int32_t *type_ptr, const float *att_bias,
+                                         const float *lnA_g, const float *lnA_b, const void *wB_packed_bf16,
+                                         const float *bB, const float *lnB_g, const float *lnB_b, const float *r_e,
+                                         int64_t ldre, const void *wC_packed_bf16, const float *bC, const float *w_dot,
+                                         const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob,
+                                         void *stream) {
+    if (M == 0) return LPF_OK;
+    LPF_REQUIRE(M > 0 && part && bnd && units_cap > 0 && lpf_aligned16(bnd) && type_ptr && att_bias && lnA_g && lnA_b &&
+                wB_packed_bf16 && bB && lnB_g && lnB_b && r_e && wC_packed_bf16 && bC && w_dot && b_dot &&
+                (logit || prob));
+    LPF_REQUIRE((n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D);
+    LPF_REQUIRE(lpf_aligned16(part) && lpf_aligned16(att_bias) && lpf_aligned16(r_e) && lpf_aligned16(wB_packed_bf16) &&
+                lpf_aligned16(wC_packed_bf16) && lpf_aligned16(lnA_g) && lpf_aligned16(lnA_b) && lpf_aligned16(bB) &&
+                lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
+    TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0,
+               static_cast<const float *>(wB_packed_bf16), bB, lnB_g, lnB_b, D + n_counts, r_e, ldre,
+               static_cast<const float *>(wC_packed_bf16), bC, 2 * D, w_dot, b_dot, logit, prob,
+               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (D) {
+        case 32: return tc_launch<2, 3, 4, true>(a, s);
+        case 64: return tc_launch<4, 5, 8, true>(a, s);
+        case 128: return tc_launch<8, 9, 16, true>(a, s);
         default: return LPF_ERR_UNSUPPORTED;
     }
 }

@@ -513,6 +513,10 @@ class LinkTransformer(nn.Module):
         # "f32" or "bf16": in bf16 the per-layer table X W^T that the aggregation gathers (and that a row-sharded
         # encoder all-gathers) is stored in bf16; the GEMM, the sums over neighbours and the epilogue stay fp32
         self.encoder_precision = "f32"
+        # "f32" or "bf16": in bf16 the two GEMMs of the dense tail (first layer of pairwise_lin, folded score head) run
+        # on the bf16 matrix cores with bf16 weights and activations rounded to bf16 (fp32 accumulate; record merge,
+        # LayerNorms, dot product and sigmoid stay fp32); logits within 5e-3 of fp32 (observed <= 1e-3).
+        self.tail_precision = "f32"
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self, train_ok: bool = False):
@@ -1053,6 +1057,9 @@ class LinkTransformer(nn.Module):
                                       npy(ps[5]), npy(a)[:, :self.dim + self.dim + self.count_dim], npy(c), npy(ps[6]),
                                       npy(ps[7]), self.dim)
         dev = {k: torch.from_numpy(v).to(self.device) for k, v in tabs.items()}
+        # bf16 images of the two GEMM weights (same element order: a lane's four fp32 become its four bf16)
+        for k in ("wB", "wC"):
+            dev[k + "_bf16"] = torch.from_numpy(fold.to_bf16_bits(tabs[k]).view(np.int16)).to(self.device)
         self._tail_cache = (key, dev)
         return dev
 
@@ -1125,13 +1132,16 @@ class LinkTransformer(nn.Module):
                 tt = self._tail_tables(score_func, a, c)
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):
-                    check(lib.lpf_tail_chain_merge_f32(
+                    b16 = self.tail_precision == "bf16"
+                    fn = lib.lpf_tail_chain_merge_bf16 if b16 else lib.lpf_tail_chain_merge_f32
+                    check(fn(
                         bs, d, self.count_dim, ptr(part), ptr(bnd), units_cap, ptr(ws.type_ptr),
                         ptr(self.att_layers[0].att.bias),
-                        ptr(tt["lnA_g"]), ptr(tt["lnA_b"]), ptr(tt["wB"]), ptr(tt["bB"]), ptr(tt["lnB_g"]),
-                        ptr(tt["lnB_b"]), ptr(r), r.stride(0), ptr(tt["wC"]), ptr(tt["bC"]), ptr(tt["w_dot"]),
+                        ptr(tt["lnA_g"]), ptr(tt["lnA_b"]), ptr(tt["wB_bf16" if b16 else "wB"]), ptr(tt["bB"]),
+                        ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(r), r.stride(0), ptr(tt["wC_bf16" if b16 else "wC"]),
+                        ptr(tt["bC"]), ptr(tt["w_dot"]),
                         ptr(tt["b_dot"]), ptr(ws.ctl), ptr(res) if logits else None, None if logits else ptr(res),
-                        st), "lpf_tail_chain_merge_f32")
+                        st), "lpf_tail_chain_merge")
                 return res
             if d in (32, 64, 128) and self.use_tail_chain:  # attention output + pairwise hidden + head: one launch
                 g, feats = self._pair_attention(batch, x_node, test_set, adj_mask, False, stop_after_gather=True)

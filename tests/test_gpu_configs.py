@@ -375,3 +375,22 @@ def test_bf16_encoder_mode(name, scale, bs):
     print(f"bf16 encoder on {name}: max |dX| {e_h:.3e}, max |dlogit| (full bf16 mode) {e_l:.3e}")
     assert torch.isfinite(h16).all() and 0.0 < e_h <= 3e-2
     assert torch.isfinite(got).all() and e_l <= 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scale,bs", [("collab", 0.1, 4096), ("ppa", 0.02, 3000), ("citation2", 0.01, 3000)])
+def test_bf16_tail_mode(name, scale, bs):
+    """tail_precision = "bf16": the two GEMMs of the dense tail on the bf16 matrix cores (bf16 weights, activations
+    rounded to bf16 as they enter a GEMM, fp32 accumulate; merge, LayerNorms, dot and sigmoid fp32).  Stated tolerance:
+    logits within 5e-3 absolute of the fp32 path (observed <= 1e-3 on logits of magnitude ~0.2: two chained K = 144 /
+    256 products with 8-bit significands)."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale=scale, bs=bs)
+    h = model.propagate()
+    b = torch.from_numpy(batch).to(DEV)
+    ref = model.score_pairs(b, h, score, logits=True).clone()
+    model.tail_precision = "bf16"
+    got = model.score_pairs(b, h, score, logits=True)
+    model.tail_precision = "f32"
+    err = (got - ref).abs().max().item()
+    print(f"bf16 tail on {name}: max |dlogit| {err:.3e}, logit range {ref.abs().max().item():.2f}")
+    assert torch.isfinite(got).all() and 0.0 < err <= 5e-3
