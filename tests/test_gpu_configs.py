@@ -220,10 +220,13 @@ def test_folded_score_path_matches_modules_and_oracle():
         assert np.abs(got_l[:160].cpu().numpy() - ref["logit"]).max() <= 1e-4 * max(1.0, float(np.abs(ref["logit"]).max()))
 
 
-def test_step_replays_from_a_captured_graph():
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_step_replays_from_a_captured_graph(mode):
     """A whole scoring step (selection without read-back, one-pass attention, merged tail, side-stream branches) is
-    captured in a HIP graph once; replays on other batches give bitwise the scores of the eager path."""
+    captured in a HIP graph once; replays on other batches give bitwise the scores of the eager path -- in fp32 and with
+    the bf16 switches of the pair stage on."""
     cfg, n, ei, w, x, data, args, model, score, batch = _setup("collab", scale=0.1, bs=4096)
+    model.precision = model.tail_precision = mode
     h = model.propagate()
     batches = [torch.from_numpy(D.sample_pairs(ei, n, 4096, seed=70 + i)).to(DEV) for i in range(4)]
     scorer = lpformer_amd.GraphedScorer(model, score, h, batches[0], logits=True)
