@@ -6,6 +6,8 @@
 // (ds_bpermute) and gathers the neighbour rows four at a time so four 16-byte gathers are always in flight.  The
 // accumulator never leaves registers: bias, LayerNorm (group-wide butterfly reduction), ReLU, residual and the
 // final `gnn_norm` LayerNorm are applied before the single store.  Bound: HBM / L2 gather bandwidth.
+#include <stdlib.h>
+
 #include "lpf_common.h"
 
 namespace {
@@ -47,7 +49,7 @@ constexpr int SPMM_LONG = 128;  // rows with more stored entries than this are l
 // a chunk is one coalesced (col, weight) read by the group, then lane-by-lane broadcasts with four 16-byte neighbour
 // gathers in flight.  (V = 2: the gathered table H holds bf16 rows -- half the gather bytes, the bound of this kernel;
 // the sum stays fp32.)
-template <int G, int V>
+template <int G, int V, bool HB>
 __device__ __forceinline__ void spmm_accumulate(float4 (&acc)[V], int64_t e0, int64_t e1, int first_chunk,
                                                 int chunk_stride, const int32_t *__restrict__ col,
                                                 const float *__restrict__ w, const float *__restrict__ H, int64_t ldh,
@@ -72,7 +74,8 @@ __device__ __forceinline__ void spmm_accumulate(float4 (&acc)[V], int64_t e0, in
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if constexpr (V == 2) {
+                if constexpr (HB) {
+                    static_assert(V == 2, "a bf16 row piece of 16 bytes is two float4 accumulators");
                     uint4 b = make_uint4(0u, 0u, 0u, 0u);
                     if (act) b = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(H) +
                                                                   (int64_t)cc[u] * ldh + off);
@@ -81,8 +84,10 @@ __device__ __forceinline__ void spmm_accumulate(float4 (&acc)[V], int64_t e0, in
                     h[u][1] = make_float4(__uint_as_float(b.z << 16), __uint_as_float(b.z & 0xffff0000u),
                                           __uint_as_float(b.w << 16), __uint_as_float(b.w & 0xffff0000u));
                 } else {
-                    h[u][0] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        h[u][v] = act ? *reinterpret_cast<const float4 *>(H + (int64_t)cc[u] * ldh + off + 4 * v)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
@@ -135,7 +140,7 @@ __device__ __forceinline__ void spmm_epilogue(float4 (&y)[V], int64_t row, bool 
     }
 }
 
-template <int G, int V>
+template <int G, int V, bool HB>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const int64_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ col, const float *__restrict__ w,
                                                        const float *__restrict__ H, int64_t ldh,
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const i
         float4 acc[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        spmm_accumulate<G, V>(acc, e0, e1, 0, 1, col, w, H, ldh, off, act, gbase, lig);
+        spmm_accumulate<G, V, HB>(acc, e0, e1, 0, 1, col, w, H, ldh, off, act, gbase, lig);
         spmm_epilogue<G, V>(acc, row, live, act, D, off, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b,
                             flags);
     }
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int64_t n, int D, const i
 // Hub rows (more than SPMM_LONG entries): one 256-thread workgroup per row.  The NG = 256/G lane groups take chunks of
 // G edges round-robin, their partial sums meet in LDS and are added in group order (deterministic), then group 0 runs
 // the same fused epilogue.
-template <int G, int V>
+template <int G, int V, bool HB>
 __global__ __launch_bounds__(256) void spmm_long_rows_kernel(
     const int32_t *__restrict__ long_rows, int D, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ w, const float *__restrict__ H, int64_t ldh, float *__restrict__ out, int64_t ldo,
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void spmm_long_rows_kernel(
     float4 acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    spmm_accumulate<G, V>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
+    spmm_accumulate<G, V, HB>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
 #pragma unroll
     for (int v = 0; v < V; ++v) part[grp][lig][v] = acc[v];
     __syncthreads();
@@ -269,29 +274,39 @@ int spmm_launch(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col,
     LPF_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= D && lpf_aligned16(residual)));
     LPF_REQUIRE(!bias || lpf_aligned16(bias));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    constexpr int V = HB ? 2 : 1;  // float4 per lane
+    // float4 per lane: 2 whenever D allows it -- the bf16 table then gives 16 gathered bytes per lane, the fp32 table 32
+    // (twice the rows per wavefront: 235 -> 219 us per layer on the collab-like graph); LPF_SPMM_V=1 (tuning aid)
+    // forces one
+    static int v_f32 = 0;
+    if (v_f32 == 0) {
+        const char *e = getenv("LPF_SPMM_V");
+        v_f32 = (e && atoi(e) == 1) ? 1 : 2;
+    }
+    const int V = HB ? 2 : ((D & 7) ? 1 : v_f32);
     const int G = (D <= 64 ? 16 : (D <= 128 ? 32 : 64)) / V;
     const int rpw = 64 / G;
     int64_t blocks = (n + 4 * rpw - 1) / (4 * rpw);
     if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond ~32 blocks per CU
-#define LPF_SPMM_LAUNCH(GG)                                                                                        \
+#define LPF_SPMM_LAUNCH(GG, VV)                                                                                    \
     do {                                                                                                           \
-        hipLaunchKernelGGL((spmm_csr_kernel<GG, V>), dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr, col,   \
-                           w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags,              \
+        hipLaunchKernelGGL((spmm_csr_kernel<GG, VV, HB>), dim3((unsigned)blocks), dim3(256), 0, s, n, D, rowptr,   \
+                           col, w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags,         \
                            long_rows ? 1 : 0);                                                                     \
         if (n_long > 0)                                                                                            \
-            hipLaunchKernelGGL((spmm_long_rows_kernel<GG, V>), dim3((unsigned)n_long), dim3(256), 0, s,            \
+            hipLaunchKernelGGL((spmm_long_rows_kernel<GG, VV, HB>), dim3((unsigned)n_long), dim3(256), 0, s,       \
                                long_rows, D, rowptr, col, w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr,    \
                                ln2_g, ln2_b, flags);                                                               \
     } while (0)
-    if constexpr (HB) {
-        if (G == 8) LPF_SPMM_LAUNCH(8);
-        else if (G == 16) LPF_SPMM_LAUNCH(16);
-        else LPF_SPMM_LAUNCH(32);
+    if (V == 2) {
+        if (G == 8) LPF_SPMM_LAUNCH(8, 2);
+        else if (G == 16) LPF_SPMM_LAUNCH(16, 2);
+        else LPF_SPMM_LAUNCH(32, 2);
     } else {
-        if (G == 16) LPF_SPMM_LAUNCH(16);
-        else if (G == 32) LPF_SPMM_LAUNCH(32);
-        else LPF_SPMM_LAUNCH(64);
+        if constexpr (!HB) {
+            if (G == 16) LPF_SPMM_LAUNCH(16, 1);
+            else if (G == 32) LPF_SPMM_LAUNCH(32, 1);
+            else LPF_SPMM_LAUNCH(64, 1);
+        }
     }
 #undef LPF_SPMM_LAUNCH
     LPF_CHECK_LAUNCH();
