@@ -282,7 +282,7 @@ int spmm_launch(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col,
         const char *e = getenv("LPF_SPMM_V");
         v_f32 = (e && atoi(e) == 1) ? 1 : 2;
     }
-    const int V = HB ? 2 : ((D & 7) ? 1 : v_f32);
+    const int V = HB ? 2 : (((D & 7) || D > 128) ? 1 : v_f32);  // (D = 256, hub rows only: one float4 measured faster)
     const int G = (D <= 64 ? 16 : (D <= 128 ? 32 : 64)) / V;
     const int rpw = 64 / G;
     int64_t blocks = (n + 4 * rpw - 1) / (4 * rpw);
