@@ -95,6 +95,13 @@ int lpf_gemm_f32_out_bf16(int64_t M, int32_t N, int32_t K, const float *A, int64
                           const float *bias, const float *addend, int64_t ldadd, void *C_bf16, int64_t ldc,
                           uint32_t flags, void *stream);
 
+/* C[N,K] = A[M,N]^T * B[M,K]   -- the weight gradient of a Linear layer (dW = dY^T X; the training step,
+ * src/train/train_model.py:59-77 through autograd).  The reduction over the M rows is split into chunks whose partial
+ * products are added in chunk order (deterministic).  workspace: lpf_gemm_tn_workspace_floats(M, N, K) floats. */
+int64_t lpf_gemm_tn_workspace_floats(int64_t M, int32_t N, int32_t K);
+int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
+                    float *C, int64_t ldc, float *workspace, void *stream);
+
 /* y[i,:] = LN(x[i,:]; g, b) (then ReLU if flagged), in place allowed (nn.LayerNorm eps 1e-5, biased variance).
  * other_models.py:131-132, layers.py:78.  D <= 1024. g/b NULL -> plain ReLU / identity. */
 int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *g, const float *b,

@@ -190,3 +190,107 @@ extern "C" int lpf_gemm_f32_out_bf16(int64_t M, int32_t N, int32_t K, const floa
     return gemm_launch<true>(M, N, K, A, lda, W, ldw, bias, addend, ldadd, static_cast<float *>(C_bf16), ldc, flags,
                              stream);
 }
+
+// ------------------------------------------------------------------------------------------------ C = A^T B
+// Weight gradient of a Linear layer: dW[N, K] = dY[M, N]^T X[M, K] -- the reduction runs over the M rows (hundreds of
+// thousands in the encoder), the output is one or a few 128 x 128 tiles.  lpf_gemm_f32 on transposed copies gave that
+// single tile to a single workgroup (1.1 ms per call, 3/4 of a training step).  Here the rows are split into chunks,
+// a workgroup computes the partial product of one chunk for one output tile (wave w: output rows [32 w, 32 w + 32) x
+// 128 columns; v_mfma_f32_32x32x2_f32 with k = row of the chunk: lane (i, half) feeds A[i][m = 2 s + half] =
+// dY[m][n0 + i] and B[m][c0 + i] = X[m][c0 + i], both coalesced 128-byte row pieces straight from global memory),
+// writes it to a partial buffer, and a second kernel adds the partials in chunk order (deterministic).
+namespace {
+
+constexpr int TN_ROWS = 256;  // rows of a chunk
+
+__global__ __launch_bounds__(256) void gemm_tn_partial_kernel(int64_t M, int N, int K, const float *__restrict__ A,
+                                                              int64_t lda, const float *__restrict__ B, int64_t ldb,
+                                                              float *__restrict__ part, int64_t rows_per_chunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.y * 128 + wave * 32, k0 = blockIdx.z * 128;
+    const int64_t m_lo = (int64_t)blockIdx.x * rows_per_chunk;
+    int64_t m_hi = m_lo + rows_per_chunk;
+    if (m_hi > M) m_hi = M;
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    const bool a_ok = n0 + li < N;
+    bool b_ok[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b_ok[c] = k0 + 32 * c + li < K;
+    const float *ap = A + n0 + li;
+    const float *bp = B + k0 + li;
+    // eight rows (four MFMA steps) per round: their loads are all in flight before the first MFMA of the round
+    for (int64_t m = m_lo; m < m_hi; m += 8) {
+        float av[4], bv[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t mm = m + 2 * s + lh;
+            const bool ok = mm < m_hi;
+            av[s] = (ok && a_ok) ? ap[mm * lda] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[s][c] = (ok && b_ok[c]) ? bp[mm * ldb + 32 * c] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s][c], acc[c], 0, 0, 0);
+    }
+    // partial tile: part[chunk][n][k] (n < N, k < K), accumulator register r of lane (li, lh) = row (r&3)+8(r>>2)+4 lh
+    float *pp = part + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = k0 + 32 * c + li;
+        if (k >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (n < N) pp[(int64_t)n * K + k] = acc[c][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(int64_t elems, int chunks, const float *__restrict__ part,
+                                                             float *__restrict__ C, int K, int64_t ldc) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= elems) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(int64_t)c * elems + e];
+    C[(e / K) * ldc + (e % K)] = s;
+}
+
+}  // namespace
+
+extern "C" int64_t lpf_gemm_tn_workspace_floats(int64_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int64_t chunks = (M + TN_ROWS - 1) / TN_ROWS;
+    if (chunks > 1024) chunks = 1024;
+    return chunks * (int64_t)N * K;
+}
+
+extern "C" int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B,
+                               int64_t ldb, float *C, int64_t ldc, float *workspace, void *stream) {
+    if (N == 0 || K == 0) return LPF_OK;
+    LPF_REQUIRE(M >= 0 && N > 0 && K > 0 && C && ldc >= K && (M == 0 || (A && B && workspace && lda >= N && ldb >= K)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (M == 0) {
+        for (int n = 0; n < N; ++n)
+            if (hipMemsetAsync(C + (int64_t)n * ldc, 0, sizeof(float) * K, s) != hipSuccess) return LPF_ERR_LAUNCH;
+        return LPF_OK;
+    }
+    int64_t chunks = (M + TN_ROWS - 1) / TN_ROWS;
+    if (chunks > 1024) chunks = 1024;
+    int64_t rows = (M + chunks - 1) / chunks;
+    rows = (rows + 7) & ~7ll;  // whole rounds of eight rows
+    chunks = (M + rows - 1) / rows;
+    dim3 grid((unsigned)chunks, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
+    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows);
+    const int64_t elems = (int64_t)N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, elems,
+                       (int)chunks, workspace, C, K, ldc);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

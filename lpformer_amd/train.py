@@ -64,6 +64,19 @@ def _gemm(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a[M, N]^T @ b[M, K] -> [N, K] through lpf_gemm_tn_f32 (the weight gradient of a Linear)."""
+    a, b = a.contiguous(), b.contiguous()
+    m, n = a.shape
+    k = b.shape[1]
+    out = torch.empty(n, k, dtype=torch.float32, device=a.device)
+    lib = _lib.hip()
+    ws = torch.empty(max(int(lib.lpf_gemm_tn_workspace_floats(m, n, k)), 1), dtype=torch.float32, device=a.device)
+    check(lib.lpf_gemm_tn_f32(m, n, k, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), ptr(ws),
+                              _stream(a)), "lpf_gemm_tn_f32")
+    return out
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T (+ b); forward and both gradients on the fp32 matrix cores (lpf_gemm_f32)."""
 
@@ -82,7 +95,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _gemm(dy, weight.t().contiguous()).contiguous()        # [M, N] @ [K, N]^T
         if ctx.needs_input_grad[1]:
-            dw = _gemm(dy.t().contiguous(), x.t().contiguous()).contiguous()   # [N, M] @ [K, M]^T
+            dw = _gemm_tn(dy, x)                                          # dY^T X, rows split over the GPU
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=0)
         return dx, dw, db

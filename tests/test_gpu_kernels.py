@@ -259,3 +259,18 @@ def test_device_ppr_indexes_match_host_twins(theta):
         np.testing.assert_array_equal(got.val.view(np.uint32), want.val.view(np.uint32))
     sp = graph.self_ppr_device(dadj, dppr).cpu().numpy()
     np.testing.assert_array_equal(sp.view(np.uint32), graph.self_ppr(adj, ppr).view(np.uint32))
+
+
+def test_gemm_tn_weight_gradient():
+    """lpf_gemm_tn_f32: C = A^T B with the reduction over the rows split into chunks (dW of a Linear), against fp64
+    torch; ragged N / K / M, a single row, and an empty input."""
+    from lpformer_amd import train
+    torch.manual_seed(11)
+    for m, n, k in ((100_003, 128, 128), (4097, 132, 260), (1, 7, 5), (300, 1, 1433), (0, 16, 8)):
+        a = torch.randn(m, n, device=DEV)
+        b = torch.randn(m, k, device=DEV)
+        got = train._gemm_tn(a, b)
+        want = (a.double().t() @ b.double())
+        scale = max(1.0, float(want.abs().max()))
+        assert got.shape == (n, k) and float((got.double() - want).abs().max()) <= 2e-5 * scale * max(1.0, m ** 0.5 / 30)
+        assert torch.equal(got, train._gemm_tn(a, b))      # deterministic reduction order

@@ -1,0 +1,45 @@
+"""Timing aid: one training step (forward + backward + Adam) of the collab-like config through lpformer_amd/train.py,
+resident graphs (no per-batch masked adjacency), batch = LPF_TRAIN_BS positives + as many negatives."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lpformer_amd
+from lpformer_amd import data as D
+cfg = D.CONFIGS[os.environ.get("LPF_CFG", "collab")]
+n = cfg["n"]; dev = torch.device("cuda:0"); bs = int(os.environ.get("LPF_TRAIN_BS", "8192"))
+ei, w = D.chung_lu_graph(n, cfg["edges"], gamma=cfg["gamma"], seed=0, max_weight=cfg["max_weight"])
+x = np.random.default_rng(1).standard_normal((n, cfg["f_in"])).astype(np.float32)
+data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr_device=dev)
+targs = dict(D.train_args_for(cfg), att_drop=0.1, dropout=0.1, gnn_drop=0.1, feat_drop=0.1)
+torch.manual_seed(0)
+model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev)
+score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2, 0.1).to(dev)
+opt = torch.optim.Adam(list(model.parameters()) + list(score.parameters()), lr=1e-3)
+pos = torch.from_numpy(ei[:, ei[0] < ei[1]]).to(dev)
+def step(i):
+    model.train(); score.train()
+    idx = torch.randint(0, pos.shape[1], (bs,), device=dev)
+    edges = pos[:, idx]
+    pos_loss = -torch.log(score(model(edges)) + 1e-6).mean()
+    neg = torch.randint(0, n, (2, bs), device=dev)
+    neg_loss = -torch.log(1 - score(model(neg)) + 1e-6).mean()
+    loss = pos_loss + neg_loss
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    opt.step(); opt.zero_grad()
+    return loss
+for i in range(3): step(i)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+k = 10
+for i in range(k): l = step(i)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / k
+print(f"train step ({bs} positives + {bs} negatives, two encoder passes): {dt * 1e3:.1f} ms  -> {2 * bs / dt / 1e3:.0f} k pairs/s, loss {float(l):.4f}")
+if os.environ.get("LPF_TRAIN_PROFILE"):
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for i in range(3): step(i)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=15, max_name_column_width=60))
