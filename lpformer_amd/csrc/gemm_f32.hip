@@ -201,7 +201,13 @@ extern "C" int lpf_gemm_f32_out_bf16(int64_t M, int32_t N, int32_t K, const floa
 // writes it to a partial buffer, and a second kernel adds the partials in chunk order (deterministic).
 namespace {
 
-constexpr int TN_ROWS = 256;  // rows of a chunk
+// rows of a chunk: about 512 chunks per output tile column (two workgroups per CU), at least 64 rows each
+__host__ static inline int64_t tn_chunks(int64_t M) {
+    int64_t rows = (M + 511) / 512;
+    if (rows < 64) rows = 64;
+    rows = (rows + 7) & ~7ll;  // whole rounds of eight rows
+    return (M + rows - 1) / rows;
+}
 
 __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(int64_t M, int N, int K, const float *__restrict__ A,
                                                               int64_t lda, const float *__restrict__ B, int64_t ldb,
@@ -266,9 +272,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(int64_t elems, int 
 
 extern "C" int64_t lpf_gemm_tn_workspace_floats(int64_t M, int32_t N, int32_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    int64_t chunks = (M + TN_ROWS - 1) / TN_ROWS;
-    if (chunks > 1024) chunks = 1024;
-    return chunks * (int64_t)N * K;
+    return tn_chunks(M) * (int64_t)N * K;
 }
 
 extern "C" int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B,
@@ -281,11 +285,10 @@ extern "C" int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, 
             if (hipMemsetAsync(C + (int64_t)n * ldc, 0, sizeof(float) * K, s) != hipSuccess) return LPF_ERR_LAUNCH;
         return LPF_OK;
     }
-    int64_t chunks = (M + TN_ROWS - 1) / TN_ROWS;
-    if (chunks > 1024) chunks = 1024;
-    int64_t rows = (M + chunks - 1) / chunks;
-    rows = (rows + 7) & ~7ll;  // whole rounds of eight rows
-    chunks = (M + rows - 1) / rows;
+    int64_t rows = (M + 511) / 512;
+    if (rows < 64) rows = 64;
+    rows = (rows + 7) & ~7ll;  // whole rounds of eight rows (as in tn_chunks)
+    const int64_t chunks = (M + rows - 1) / rows;
     dim3 grid((unsigned)chunks, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
     hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows);
     const int64_t elems = (int64_t)N * K;
