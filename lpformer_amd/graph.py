@@ -174,6 +174,44 @@ def as_coo_numpy(obj):
     raise TypeError(f"unsupported graph container {type(obj)!r}")
 
 
+def as_coo_device(obj, device):
+    """(row, col, val|None, n) as tensors on ``device`` when ``obj`` already lives there (a torch sparse COO tensor or a
+    torch_sparse.SparseTensor-like object with CUDA tensors), else None.  The training loop builds a fresh masked
+    adjacency per batch on the GPU (src/train/train_model.py:40-51): this path keeps it there."""
+    device = torch.device(device)
+    if isinstance(obj, torch.Tensor) and obj.layout == torch.sparse_coo and obj.device == device:
+        t = obj.detach().coalesce()
+        ix = t.indices()
+        return ix[0], ix[1], t.values().to(torch.float32), int(t.shape[0])
+    if hasattr(obj, "coo") and hasattr(obj, "sparse_sizes"):
+        row, col, val = obj.coo()
+        if isinstance(row, torch.Tensor) and row.device == device:
+            return row, col, None if val is None else val.detach().to(torch.float32), int(obj.sparse_sizes()[0])
+    return None
+
+
+def csr_from_coo_device(row: torch.Tensor, col: torch.Tensor, val, n: int, keep_val: bool = True) -> DeviceCSR:
+    """Device twin of ``csr_from_coo``: sorted CSR, duplicate entries summed (coalesce semantics)."""
+    key = row.long() * n + col.long()
+    uniq, inv = torch.unique(key, return_inverse=True)           # sorted
+    out_val = None
+    if keep_val and val is not None:
+        out_val = torch.zeros(uniq.numel(), dtype=torch.float32, device=key.device).index_add_(0, inv, val.float())
+    r = torch.div(uniq, n, rounding_mode="floor")
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    return DeviceCSR(rowptr, (uniq - r * n).to(torch.int32), out_val, n, None)
+
+
+def gcn_structure_csr_device(row: torch.Tensor, col: torch.Tensor, val, n: int) -> DeviceCSR:
+    """Device twin of ``gcn_structure_csr``: off-diagonal entries (duplicates summed) plus every diagonal entry."""
+    w = torch.ones(row.numel(), dtype=torch.float32, device=row.device) if val is None else val.float().reshape(-1)
+    off = row != col
+    d = torch.arange(n, device=row.device, dtype=row.dtype)
+    return csr_from_coo_device(torch.cat([row[off], d]), torch.cat([col[off], d]),
+                               torch.cat([w[off], torch.ones(n, dtype=torch.float32, device=row.device)]), n)
+
+
 def gcn_norm_device(struct: DeviceCSR, stream=None) -> DeviceCSR:
     """Run ``lpf_gcn_norm_csr`` on a structure from ``gcn_structure_csr``; returns a CSR sharing rowptr/col."""
     dev = struct.rowptr.device

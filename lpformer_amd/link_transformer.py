@@ -569,6 +569,13 @@ class LinkTransformer(nn.Module):
                 raise ValueError("the PPR matrix needs values")
             # this package's own containers are sorted and coalesced already: upload as they are
             g = (obj if kind == "ppr" else graph.CSR(obj.rowptr, obj.col, None, obj.n)).to_device(dev)
+        elif kind in ("prop", "mask") and graph.as_coo_device(obj, dev) is not None:
+            # a graph that already lives on this GPU (the training loop's per-batch masked adjacency): stay there
+            row, col, val, n = graph.as_coo_device(obj, dev)
+            if kind == "prop":
+                g = graph.gcn_norm_device(graph.gcn_structure_csr_device(row, col, val, n))
+            else:
+                g = graph.csr_from_coo_device(row, col, None, n)
         else:
             row, col, val, n = graph.as_coo_numpy(obj)
             if kind == "prop":

@@ -216,6 +216,22 @@ def test_masked_adjacency_override_vs_reference():
     feats = model(mb, adj_prop=masked_adjt, adj_mask=masked_adj)
     assert _err(feats.cpu(), fx["masked_prop_combined_feats"]) <= TOL
     assert _err(score.logits(feats).cpu(), fx["masked_prop_logit"]) <= TOL
+    # the same overrides as objects that already live on the GPU (what the reference's loop hands over when its data
+    # sits on the device): converted there, no host round trip
+    class _GpuSparseTensor:
+        def __init__(self, st):
+            r, c, v = st.coo()
+            self._r, self._c, self._v, self._n = r.cuda(), c.cuda(), None if v is None else v.cuda(), st.sparse_sizes()
+
+        def coo(self):
+            return self._r, self._c, self._v
+
+        def sparse_sizes(self):
+            return self._n
+    h_dev = model.propagate(_GpuSparseTensor(masked_adjt))
+    assert _err(h_dev.cpu(), fx["masked_prop_x_node"]) <= TOL
+    feats = model(mb, adj_prop=_GpuSparseTensor(masked_adjt), adj_mask=_GpuSparseTensor(masked_adjt))
+    assert _err(feats.cpu(), fx["masked_prop_combined_feats"]) <= TOL
     # without the override the same batch gives the unmasked result again (no stale override state)
     plain = model.compute_node_mask(mb, False, None)
     assert plain[1][0].shape[1] != fx["masked_sel_onehop_ix"].shape[1]

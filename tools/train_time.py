@@ -16,11 +16,28 @@ model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev)
 score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2, 0.1).to(dev)
 opt = torch.optim.Adam(list(model.parameters()) + list(score.parameters()), lr=1e-3)
 pos = torch.from_numpy(ei[:, ei[0] < ei[1]]).to(dev)
+class _ST:  # torch_sparse.SparseTensor look-alike on the device (what the reference's loop builds per batch)
+    def __init__(self, r, c, v, n): self._r, self._c, self._v, self._n = r, c, v, n
+    def coo(self): return self._r, self._c, self._v
+    def sparse_sizes(self): return (self._n, self._n)
+masked_mode = os.environ.get("LPF_TRAIN_MASKED", "")       # "", "gpu" or "cpu"
+wts = None if w is None else torch.from_numpy(w[ei[0] < ei[1]]).to(dev)
 def step(i):
     model.train(); score.train()
     idx = torch.randint(0, pos.shape[1], (bs,), device=dev)
     edges = pos[:, idx]
-    pos_loss = -torch.log(score(model(edges)) + 1e-6).mean()
+    if masked_mode:
+        # train_model.py:40-51: the batch's positive edges removed from the propagation / typing adjacency
+        keep = torch.ones(pos.shape[1], dtype=torch.bool, device=dev); keep[idx] = False
+        k = pos[:, keep]
+        r, c = torch.cat([k[0], k[1]]), torch.cat([k[1], k[0]])
+        v = None if wts is None else torch.cat([wts[keep], wts[keep]])
+        if masked_mode == "cpu":
+            r, c, v = r.cpu(), c.cpu(), None if v is None else v.cpu()
+        adjt = _ST(r, c, v, n)
+        pos_loss = -torch.log(score(model(edges, adj_prop=adjt, adj_mask=_ST(r, c, None, n))) + 1e-6).mean()
+    else:
+        pos_loss = -torch.log(score(model(edges)) + 1e-6).mean()
     neg = torch.randint(0, n, (2, bs), device=dev)
     neg_loss = -torch.log(1 - score(model(neg)) + 1e-6).mean()
     loss = pos_loss + neg_loss
