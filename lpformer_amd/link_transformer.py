@@ -513,6 +513,9 @@ class LinkTransformer(nn.Module):
         # "f32" or "bf16": in bf16 the per-layer table X W^T that the aggregation gathers (and that a row-sharded
         # encoder all-gathers) is stored in bf16; the GEMM, the sums over neighbours and the epilogue stay fp32
         self.encoder_precision = "f32"
+        # forward() in eval mode keeps the encoder output while none of its inputs has changed (_propagate_reusing)
+        self.reuse_encoder_output = True
+        self._enc_cache = None
         # "f32" or "bf16": in bf16 the two GEMMs of the dense tail (first layer of pairwise_lin, folded score head) run
         # on the bf16 matrix cores with bf16 weights and activations rounded to bf16 (fp32 accumulate; record merge,
         # LayerNorms, dot product and sigmoid stay fp32); logits within 5e-3 of fp32 (observed <= 1e-3).
@@ -1191,10 +1194,32 @@ class LinkTransformer(nn.Module):
         self._check_supported()
         with torch.no_grad():
             batch = self._prep_batch(batch)
-            x_node = self.propagate(adj_prop, test_set)
+            x_node = self._propagate_reusing(adj_prop, test_set)
             out = self.pair_features(batch, x_node, test_set=test_set, adj_mask=adj_mask,
                                      return_weights=return_weights)
             return out
+
+    def _propagate_reusing(self, adj_prop, test_set):
+        """``propagate`` for ``forward`` in eval mode.  The reference's evaluation loop calls ``model(edges)`` per batch
+        and so re-runs the whole encoder per batch (src/train/testing.py:87 -> link_transformer.py:100) on unchanged
+        inputs; here the output is kept while NOTHING it depends on has changed: the graph object of this
+        ``test_set``, the feature tensor (identity and version), every encoder parameter (storage and version: optimiser
+        steps, ``load_state_dict`` and ``.to()`` all change one of them), the precision switch and the shard layout.
+        The objects in the key are held, so an address cannot be recycled under it.  ``reuse_encoder_output = False``
+        turns this off; an ``adj_prop`` override is never cached."""
+        if adj_prop is not None or not self.reuse_encoder_output:
+            return self.propagate(adj_prop, test_set)
+        obj, feats = self._data_obj("adj", test_set), self.data["x"]
+        params = list(self.node_encoder.parameters()) + list(self.gnn_norm.parameters())
+        key = (id(obj), id(feats), getattr(feats, "_version", 0),
+               tuple((q.data_ptr(), q._version) for q in params), self.encoder_precision, self._shard,
+               self.encoder_mode)
+        hit = self._enc_cache
+        if hit is not None and hit[0] == key and hit[1] is obj and hit[2] is feats:
+            return hit[3]
+        x_node = self.propagate(None, test_set)
+        self._enc_cache = (key, obj, feats, x_node)
+        return x_node
 
     @_on_device
     def pair_features(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False):

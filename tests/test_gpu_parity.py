@@ -255,3 +255,39 @@ def test_invalid_inputs_are_rejected_or_harmless():
         model(torch.tensor([[0, fx.n], [1, 2]]), test_set=fx.test_set)       # node id out of range
     with pytest.raises(Exception):
         model(torch.tensor([[0, -1], [1, 2]]), test_set=fx.test_set)
+
+
+def test_forward_reuses_encoder_output_only_while_nothing_changed():
+    """forward() in eval mode keeps the encoder output across calls (the reference re-runs the encoder per batch on the
+    same inputs): the result must equal a fresh propagate after every kind of change -- encoder weights updated in
+    place, a loaded state dict, features changed in place, the other graph of test_set -- and the switch must turn
+    the reuse off."""
+    fx = Fixture("lp_all_d64_residual_valtest")
+    model, score = _build(fx)
+    batch = torch.from_numpy(fx["batch"])
+
+    def fresh(test_set):
+        return model.pair_features(batch, model.propagate(None, test_set), test_set=test_set)
+
+    for ts in (False, True, False):
+        assert torch.equal(model(batch, test_set=ts), fresh(ts))
+    first = model(batch, test_set=False)
+    calls = {"n": 0}
+    orig = model.propagate
+    model.propagate = lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), orig(*a, **k))[1]
+    assert torch.equal(model(batch, test_set=False), first) and calls["n"] == 0          # reused
+    with torch.no_grad():
+        model.node_encoder.gnn_encoder.convs[0].lin.weight.mul_(1.01)                     # optimiser-style update
+    out = model(batch, test_set=False)
+    assert calls["n"] == 1 and not torch.equal(out, first)
+    model.propagate = orig
+    assert torch.equal(out, fresh(False))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["gnn_norm.weight"] = sd["gnn_norm.weight"] * 0.5
+    model.load_state_dict(sd)
+    assert torch.equal(model(batch, test_set=False), fresh(False))
+    with torch.no_grad():
+        model.data["x"].add_(0.25)                                                        # features changed in place
+    assert torch.equal(model(batch, test_set=False), fresh(False))
+    model.reuse_encoder_output = False
+    assert torch.equal(model(batch, test_set=True), fresh(True)) and model._enc_cache is not None
