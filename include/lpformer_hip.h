@@ -278,6 +278,15 @@ int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_t *type_ptr
                                   const float *bfold, const float *att, float *part, float *bnd,
                                   int64_t units_cap, void *stream);
 
+/* The attention OUTPUT of every pair from the records of lpf_pair_attention_fused_f32 (for callers that want
+ * features, calc_pairwise link_transformer.py:132-178, rather than scores):
+ *   out[p, :D] = post_att_norm( merged record of pair p + att_bias )   (layers.py:78,220; PyG softmax, +1e-16 once)
+ *   out[p, D..] = n_cn, n_1hop, [n_non1hop,] n_cn + n_1hop             (get_structure_cnts, link_transformer.py:340-356)
+ * ldo >= D + n_counts, ldo % 4 == 0.  Rows are NaN when sel_ctl[3] != 0 (selection workspace overflow). */
+int lpf_pair_attention_merge_f32(int64_t bs, int32_t D, int32_t n_counts, const float *part, const float *bnd,
+                                 int64_t units_cap, const int32_t *type_ptr, const float *att_bias, const float *ln_g,
+                                 const float *ln_b, const int64_t *sel_ctl, float *out, int64_t ldo, void *stream);
+
 /* lpf_tail_chain_f32 with the attention output taken from the records of lpf_pair_attention_fused_f32 instead of a
  * GEMM:  o = post_att_norm( sum_t e^{m_t-M} acc_t / (sum_t e^{m_t-M} l_t + 1e-16) + att_bias ), M = max_t m_t over the
  * pair's non-empty segments (PyG softmax over ALL entries of the pair, layers.py:220; no entry => o = LN(att_bias)),

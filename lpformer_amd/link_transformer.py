@@ -959,6 +959,42 @@ class LinkTransformer(nn.Module):
         side.wait_stream(main)
         return side
 
+    def _fused_attention(self, batch, x_node, test_set, adj_mask, side):
+        """q gather (side stream) -> selection (two launches, nothing read back) -> one-pass attention.  Returns the
+        selection workspace and the record buffers (part, bnd, units_cap) for ``lpf_tail_chain_merge_*`` /
+        ``lpf_pair_attention_merge_f32``."""
+        lib, st, d = _lib.hip(), _stream(self.device), self.dim
+        bs = batch.shape[1]
+        w = self._fold()
+        z, y = self._node_keys(x_node, w)
+        q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+            with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
+                check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0), None, 0,
+                                              ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
+        ws = self._select_device(batch, test_set, adj_mask)
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        rs = d + 4
+        units_cap = (ws.ent_cap + 15) // 16 + 1
+        part = self._workspace("att_part", 3 * bs * rs, torch.float32, st)
+        bnd = self._workspace("att_bnd", 3 * units_cap * 2 * rs, torch.float32, st)
+        with KernelTimer.span("pair_attention_fused"):
+            if self.precision == "bf16":
+                zb = self._z_bf16(z)
+                check(lib.lpf_pair_attention_fused_bf16(
+                    d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zb), zb.stride(0), ptr(q),
+                    q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed_bf16"]),
+                    ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st),
+                    "lpf_pair_attention_fused_bf16")
+            else:
+                check(lib.lpf_pair_attention_fused_f32(
+                    d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q),
+                    q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]),
+                    ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st),
+                    "lpf_pair_attention_fused_f32")
+        return ws, part, bnd, units_cap
+
     def _pair_attention(self, batch, x_node, test_set, adj_mask, return_weights, stop_after_gather=False):
         """Selection -> PE + attention (+ post-norm) -> count features.  Returns (feats [BS, ld] = [attention output |
         counts | pad], att_weights or None); the caller applies ``pairwise_lin`` (or its folded first layer).
@@ -967,6 +1003,23 @@ class LinkTransformer(nn.Module):
         with torch.no_grad():
             lib, st, d = _lib.hip(), _stream(self.device), self.dim
             bs = batch.shape[1]
+            if (d in (32, 64, 128) and self.use_fused_attention and not return_weights and not stop_after_gather
+                    and bs > 0):
+                # one-pass attention on the selection regions, then the records merged straight into the feature
+                # rows [post_att_norm(attention output) | counts] -- no reference-layout export, nothing read back
+                # (a batch that overflows the selection workspace comes back as NaN: check_selection())
+                side = self._fork()
+                ws, part, bnd, units_cap = self._fused_attention(batch, x_node, test_set, adj_mask, side)
+                ld = (d + self.count_dim + 3) // 4 * 4
+                feats = torch.empty(bs, ld, dtype=torch.float32, device=self.device)
+                layer = self.att_layers[0]
+                with KernelTimer.span("pair_attention_merge"):
+                    check(lib.lpf_pair_attention_merge_f32(
+                        bs, d, self.count_dim, ptr(part), ptr(bnd), units_cap, ptr(ws.type_ptr), ptr(layer.att.bias),
+                        ptr(layer.post_att_norm.weight), ptr(layer.post_att_norm.bias), ptr(ws.ctl), ptr(feats), ld,
+                        st), "lpf_pair_attention_merge_f32")
+                self._last_att = feats[:, :d]
+                return feats, None
             w = self._fold()
             z, y = self._node_keys(x_node, w)
 
@@ -1111,34 +1164,7 @@ class LinkTransformer(nn.Module):
             if d in (32, 64, 128) and self.use_tail_chain and self.use_fused_attention and bs > 0:
                 # hot path: 2 selection launches (nothing read back) -> one-pass attention -> merged dense tail
                 lib, st = _lib.hip(), _stream(self.device)
-                w = self._fold()
-                z, y = self._node_keys(x_node, w)
-                q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
-                with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
-                    with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
-                        check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0), None, 0,
-                                                      ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
-                ws = self._select_device(batch, test_set, adj_mask)
-                if side is not None:
-                    torch.cuda.current_stream(self.device).wait_stream(side)
-                rs = d + 4
-                units_cap = (ws.ent_cap + 15) // 16 + 1
-                part = self._workspace("att_part", 3 * bs * rs, torch.float32, st)
-                bnd = self._workspace("att_bnd", 3 * units_cap * 2 * rs, torch.float32, st)
-                with KernelTimer.span("pair_attention_fused"):
-                    if self.precision == "bf16":
-                        zb = self._z_bf16(z)
-                        check(lib.lpf_pair_attention_fused_bf16(
-                            d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zb), zb.stride(0), ptr(q),
-                            q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed_bf16"]),
-                            ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st),
-                            "lpf_pair_attention_fused_bf16")
-                    else:
-                        check(lib.lpf_pair_attention_fused_f32(
-                            d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q),
-                            q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed"]),
-                            ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st),
-                            "lpf_pair_attention_fused_f32")
+                ws, part, bnd, units_cap = self._fused_attention(batch, x_node, test_set, adj_mask, side)
                 tt = self._tail_tables(score_func, a, c)
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):

@@ -66,7 +66,6 @@ class LPFormer(nn.Module):
         self.core._x_cache = None
         self.core._z_cache = None
         self.core._enc_cache = None
-        core._enc_cache = None
         self._bound = key
 
     def forward(self, batch: torch.Tensor, x: torch.Tensor, edge_index: torch.Tensor, ppr_matrix) -> torch.Tensor:
