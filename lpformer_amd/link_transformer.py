@@ -516,6 +516,7 @@ class LinkTransformer(nn.Module):
         # forward() in eval mode keeps the encoder output while none of its inputs has changed (_propagate_reusing)
         self.reuse_encoder_output = True
         self._enc_cache = None
+        self._unchecked_selection = False
         # "f32" or "bf16": in bf16 the two GEMMs of the dense tail (first layer of pairwise_lin, folded score head) run
         # on the bf16 matrix cores with bf16 weights and activations rounded to bf16 (fp32 accumulate; record merge,
         # LayerNorms, dot product and sigmoid stay fp32); logits within 5e-3 of fp32 (observed <= 1e-3).
@@ -1008,17 +1009,20 @@ class LinkTransformer(nn.Module):
                 # one-pass attention on the selection regions, then the records merged straight into the feature
                 # rows [post_att_norm(attention output) | counts] -- no reference-layout export, nothing read back
                 # (a batch that overflows the selection workspace comes back as NaN: check_selection())
-                side = self._fork()
-                ws, part, bnd, units_cap = self._fused_attention(batch, x_node, test_set, adj_mask, side)
                 ld = (d + self.count_dim + 3) // 4 * 4
                 feats = torch.empty(bs, ld, dtype=torch.float32, device=self.device)
+                if ld > d + self.count_dim:
+                    feats[:, d + self.count_dim:].zero_()
                 layer = self.att_layers[0]
+                side = self._fork()
+                ws, part, bnd, units_cap = self._fused_attention(batch, x_node, test_set, adj_mask, side)
                 with KernelTimer.span("pair_attention_merge"):
                     check(lib.lpf_pair_attention_merge_f32(
-                        bs, d, self.count_dim, ptr(part), ptr(bnd), units_cap, ptr(ws.type_ptr), ptr(layer.att.bias),
-                        ptr(layer.post_att_norm.weight), ptr(layer.post_att_norm.bias), ptr(ws.ctl), ptr(feats), ld,
-                        st), "lpf_pair_attention_merge_f32")
+                        bs, d, self.count_dim, ptr(part), ptr(bnd), units_cap, ptr(ws.type_ptr),
+                        ptr(layer.att.bias), ptr(layer.post_att_norm.weight), ptr(layer.post_att_norm.bias),
+                        ptr(ws.ctl), ptr(feats), ld, st), "lpf_pair_attention_merge_f32")
                 self._last_att = feats[:, :d]
+                self._unchecked_selection = True   # (calc_pairwise reads the status back after queueing its own work)
                 return feats, None
             w = self._fold()
             z, y = self._node_keys(x_node, w)
@@ -1075,8 +1079,17 @@ class LinkTransformer(nn.Module):
         _require_gpu(X_node, "calc_pairwise")
         with torch.no_grad():
             batch = self._prep_batch(batch)
-            feats, att_weights = self._pair_attention(batch, _as_f32_rows(X_node), test_set, adj_mask, return_weights)
-            out = self.pairwise_lin.run(feats[:, :self.dim + self.count_dim], out=_out)
+            for _attempt in range(2):
+                self._unchecked_selection = False
+                feats, att_weights = self._pair_attention(batch, _as_f32_rows(X_node), test_set, adj_mask,
+                                                          return_weights)
+                out = self.pairwise_lin.run(feats[:, :self.dim + self.count_dim], out=_out)
+                # The callers of this API are the reference's loops: they fetch the predictions of every batch right
+                # away and never heard of check_selection().  So the status of the read-back-free selection is read
+                # here, AFTER this call's own launches are queued (the wait is the one the caller's .cpu() would pay),
+                # and a batch that overflowed its workspace is simply run again on the re-sized one.
+                if not self._unchecked_selection or self.check_selection():
+                    break
             return out, att_weights
 
     # ---------------------------------------------------------------------------------- folded score path

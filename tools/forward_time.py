@@ -24,6 +24,8 @@ def t(fn, k=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / k * 1e3
 with torch.no_grad():
     print("model(edges) + score_func (encoder re-run per batch, as testing.py:87): %.3f ms" % t(lambda: score(model(b))))
+    print("  ... with the predictions fetched per batch as the reference does (.cpu()): %.3f ms" % t(lambda: score(model(b)).cpu()))
+    print("score_pairs(...).cpu() per batch: %.3f ms" % t(lambda: model.score_pairs(b, h, score).cpu()))
     print("elementwise_lin + calc_pairwise + score_func on a cached h (testing.py:113-117): %.3f ms" %
           t(lambda: score(torch.cat((model.elementwise_lin(h[b[0]] * h[b[1]]), model.calc_pairwise(b, h)[0]), dim=-1))))
     print("model.score_pairs(edges, h, score_func): %.3f ms" % t(lambda: model.score_pairs(b, h, score)))
