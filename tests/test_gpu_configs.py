@@ -258,6 +258,14 @@ def test_selection_overflow_is_flagged_and_recovered():
     assert model.check_selection() and torch.isfinite(good).all()
     ref = score.logits(model.pair_features(dense, h))
     assert (good - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # the module API (what the reference's loops call) recovers by itself: same overflow, finite features, and they
+    # equal the ones computed on a workspace that was large enough from the start
+    model2 = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
+    model2.load_state_dict(model.state_dict())
+    model2.calc_pairwise(sparse, h)                          # sizes the workspace for the sparse batch
+    out, _ = model2.calc_pairwise(dense, h)                  # overflows inside, is run again
+    want, _ = model.calc_pairwise(dense, h)
+    assert torch.isfinite(out).all() and torch.equal(out, want)
 
 
 @pytest.mark.parametrize("world", [2, 3])
