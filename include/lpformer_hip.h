@@ -107,6 +107,14 @@ int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda
 int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *g, const float *b,
                       float *y, int64_t ldy, uint32_t flags, void *stream);
 
+/* Backward of lpf_layernorm_f32 (no ReLU): dx, dgamma, dbeta from x, dy, gamma (row statistics recomputed from x;
+ * column sums added in a fixed order).  D % 4 == 0, D <= 256; workspace: lpf_layernorm_bwd_workspace_floats(D) floats.
+ * The training step (src/train/train_model.py:59-77 through autograd). */
+int64_t lpf_layernorm_bwd_workspace_floats(int32_t D);
+int lpf_layernorm_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
+                          const float *gamma, float *dx, int64_t lddx, float *dgamma, float *dbeta, float *workspace,
+                          void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pair stage (reference: src/models/link_transformer.py:132-178 calc_pairwise and helpers)
  * ---------------------------------------------------------------------------------------------- */

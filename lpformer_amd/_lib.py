@@ -26,6 +26,8 @@ HIP_PROTOTYPES = {
     "lpf_gcn_norm_csr": [i64, vp, vp, vp, vp, vp, vp],
     "lpf_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],
     "lpf_gemm_f32": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
+    "lpf_layernorm_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp],
+    "lpf_layernorm_bwd_workspace_floats": [i32],
     "lpf_gemm_tn_f32": [i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp],
     "lpf_gemm_tn_workspace_floats": [i64, i32, i32],
     "lpf_gemm_f32_out_bf16": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
@@ -66,7 +68,7 @@ HOST_PROTOTYPES = {
 }
 _RESTYPE = {"lpf_strerror": C.c_char_p, "lpf_last_hip_error": C.c_char_p, "lpf_host_free": None,
             "lpf_ppr_push_workspace_bytes": C.c_int64, "lpf_select_plan_blocks": C.c_int64, "lpf_ppr_pack_workspace_bytes": C.c_int64,
-            "lpf_gemm_tn_workspace_floats": C.c_int64}
+            "lpf_gemm_tn_workspace_floats": C.c_int64, "lpf_layernorm_bwd_workspace_floats": C.c_int64}
 
 
 class LpfError(RuntimeError):

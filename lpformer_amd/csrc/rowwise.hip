@@ -147,3 +147,111 @@ extern "C" int lpf_rowdot_sigmoid_f32(int64_t M, int32_t K, const float *A, int6
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// (the training step, src/train/train_model.py:59-77 through autograd; forward = lpf_layernorm_f32)
+//   xhat = (x - mean) rstd;  g = dy * gamma;  dx = rstd (g - mean(g) - xhat mean(g xhat));
+//   dgamma = sum_rows dy xhat;  dbeta = sum_rows dy
+// Row statistics are recomputed from x (two reads of a row that is in registers anyway: nothing is saved by the
+// forward).  G = D/4 lanes per row; a lane keeps the column sums of its four features over the rows it sees, the
+// groups of a workgroup meet in LDS, every workgroup writes one partial row pair and a second kernel adds them in
+// workgroup order (deterministic).  Bound: HBM (x, dy read once, dx written once).
+namespace {
+
+template <int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, const float *__restrict__ x, int64_t ldx,
+                                                            const float *__restrict__ dy, int64_t ldy,
+                                                            const float *__restrict__ gamma, float *__restrict__ dx,
+                                                            int64_t lddx, float *__restrict__ part) {
+    constexpr int NG = 256 / G;
+    __shared__ float4 red[2][NG][G];
+    const int tid = threadIdx.x, grp = tid / G, lig = tid % G;
+    const int off = 4 * lig;
+    const bool act = off < D;
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) gm = *reinterpret_cast<const float4 *>(gamma + off);
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+    const int64_t g_id = (int64_t)blockIdx.x * NG + grp, n_g = (int64_t)gridDim.x * NG;
+    for (int64_t r0 = 0; r0 < M; r0 += n_g) {  // (every group runs the same number of rounds: the shuffles stay converged)
+        const int64_t r = r0 + g_id;
+        const bool live = r < M && act;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
+        if (live) {
+            xv = *reinterpret_cast<const float4 *>(x + r * ldx + off);
+            dv = *reinterpret_cast<const float4 *>(dy + r * ldy + off);
+        }
+        const float mean = lpf_group_sum<G>(xv.x + xv.y + xv.z + xv.w) / (float)D;
+        float4 c = make_float4(xv.x - mean, xv.y - mean, xv.z - mean, xv.w - mean);
+        if (!live) c = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float var = lpf_group_sum<G>(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) / (float)D;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float4 xh = make_float4(c.x * rstd, c.y * rstd, c.z * rstd, c.w * rstd);
+        const float4 gv = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
+        const float m1 = lpf_group_sum<G>(gv.x + gv.y + gv.z + gv.w) / (float)D;
+        const float m2 = lpf_group_sum<G>(gv.x * xh.x + gv.y * xh.y + gv.z * xh.z + gv.w * xh.w) / (float)D;
+        if (live) {
+            *reinterpret_cast<float4 *>(dx + r * lddx + off) =
+                make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
+                            rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
+            sg.x += dv.x * xh.x; sg.y += dv.y * xh.y; sg.z += dv.z * xh.z; sg.w += dv.w * xh.w;
+            sb.x += dv.x; sb.y += dv.y; sb.z += dv.z; sb.w += dv.w;
+        }
+    }
+    red[0][grp][lig] = sg;
+    red[1][grp][lig] = sb;
+    __syncthreads();
+    if (grp == 0 && act) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float4 s = red[k][0][lig];
+            for (int g = 1; g < NG; ++g) {
+                const float4 v = red[k][g][lig];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4 *>(part + ((int64_t)blockIdx.x * 2 + k) * D + off) = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(int D, int blocks, const float *__restrict__ part,
+                                                                   float *__restrict__ dgamma,
+                                                                   float *__restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * D) return;
+    const int k = c / D, f = c % D;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += part[((int64_t)b * 2 + k) * D + f];
+    (k == 0 ? dgamma : dbeta)[f] = s;
+}
+
+constexpr int LN_BWD_BLOCKS = 1024;
+
+}  // namespace
+
+extern "C" int64_t lpf_layernorm_bwd_workspace_floats(int32_t D) { return (int64_t)LN_BWD_BLOCKS * 2 * (D > 0 ? D : 0); }
+
+extern "C" int lpf_layernorm_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
+                                     const float *gamma, float *dx, int64_t lddx, float *dgamma, float *dbeta,
+                                     float *workspace, void *stream) {
+    if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
+    LPF_REQUIRE(M >= 0 && gamma && dgamma && dbeta && workspace && lpf_aligned16(gamma) && lpf_aligned16(workspace));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int blocks = 0;
+    if (M > 0) {
+        LPF_REQUIRE(x && dy && dx && ldx >= D && ldy >= D && lddx >= D && ((ldx | ldy | lddx) & 3) == 0 &&
+                    lpf_aligned16(x) && lpf_aligned16(dy) && lpf_aligned16(dx));
+        const int G = D <= 32 ? 8 : (D <= 64 ? 16 : (D <= 128 ? 32 : 64));
+        const int64_t want = (M + 256 / G - 1) / (256 / G);
+        blocks = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
+        switch (G) {
+            case 8: hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
+            case 16: hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
+            case 32: hipLaunchKernelGGL(layernorm_bwd_kernel<32>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
+            default: hipLaunchKernelGGL(layernorm_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
+        }
+    }
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, D, blocks, workspace,
+                       dgamma, dbeta);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -5,10 +5,11 @@ mode, ``score_func(h)``, and back-propagates a log-loss.  This module builds tha
 device:
 
 * the heavy, data-sized operators are ``torch.autograd.Function`` wrappers around the C-ABI kernels, forward AND
-  backward: every Linear (``lpf_gemm_f32``: y = x W^T, dx = dy W, dW = dy^T x), the GCN aggregation
+  backward: every Linear (``lpf_gemm_f32``: y = x W^T, dx = dy W; ``lpf_gemm_tn_f32``: dW = dy^T x), every LayerNorm
+  (``lpf_layernorm_f32`` / ``lpf_layernorm_bwd_f32``), the GCN aggregation
   (``lpf_spmm_csr_f32`` with the propagation matrix, its transpose for the gradient) and the node selection
   (``lpf_select_plan`` / ``_run`` / ``_export``; integer work, no gradient);
-* LayerNorm, ReLU, dropout, the leaky-ReLU score, the per-pair segment softmax and the index gathers / scatter-adds
+* ReLU, dropout, the leaky-ReLU score, the per-pair segment softmax and the index gathers / scatter-adds
   around them are ordinary differentiable torch operators on the device in this version (elementwise and
   index-bound; they are the next candidates for dedicated kernels -- DESIGN.md section 8).
 
@@ -151,12 +152,48 @@ class SpmmFn(torch.autograd.Function):
         return _spmm_plain(_transpose_csr(ctx.a_hat), dout.contiguous()), None
 
 
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm (eps 1e-5) through lpf_layernorm_f32 / lpf_layernorm_bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y = torch.empty_like(x2)
+        check(_lib.hip().lpf_layernorm_f32(x2.shape[0], x2.shape[1], ptr(x2), x2.stride(0), ptr(weight), ptr(bias),
+                                           ptr(y), y.stride(0), 0, _stream(x2)), "lpf_layernorm_f32")
+        ctx.save_for_backward(x2, weight)
+        ctx.shape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        d = x2.shape[1]
+        dy2 = dy.reshape(-1, d).contiguous()
+        dx = torch.empty_like(x2)
+        dg, db = torch.empty(d, dtype=torch.float32, device=x2.device), torch.empty(d, dtype=torch.float32, device=x2.device)
+        lib = _lib.hip()
+        ws = torch.empty(int(lib.lpf_layernorm_bwd_workspace_floats(d)), dtype=torch.float32, device=x2.device)
+        check(lib.lpf_layernorm_bwd_f32(x2.shape[0], d, ptr(x2), x2.stride(0), ptr(dy2), dy2.stride(0), ptr(weight),
+                                        ptr(dx), dx.stride(0), ptr(dg), ptr(db), ptr(ws), _stream(x2)),
+              "lpf_layernorm_bwd_f32")
+        return dx.reshape(ctx.shape), dg, db
+
+
+def layer_norm(x, weight, bias):
+    """LayerNorm over the last dimension; the C-ABI kernels when the width allows (D % 4 == 0, D <= 256)."""
+    d = x.shape[-1]
+    if d % 4 or d > 256 or x.numel() == 0:
+        return F.layer_norm(x, (d,), weight, bias)
+    return LayerNormFn.apply(x, weight, bias)
+
+
 def _mlp(mod, x):
     """The reference's MLP (other_models.py:125-138): (Linear -> LayerNorm -> ReLU -> dropout)* -> Linear."""
     for lin in mod.linears[:-1]:
         x = linear(x, lin.weight, lin.bias)
         if mod.norm is not None:
-            x = F.layer_norm(x, (x.shape[-1],), mod.norm.weight, mod.norm.bias)
+            x = layer_norm(x, mod.norm.weight, mod.norm.bias)
         x = F.relu(x)
         x = F.dropout(x, p=mod.dropout, training=True)
     last = mod.linears[-1]
@@ -171,7 +208,7 @@ def _pe_mlp(mod, pa, pb):
 
     def g(x, y):
         hdn = x[:, None] * w[:, 0][None, :] + y[:, None] * w[:, 1][None, :] + b[None, :]
-        hdn = F.relu(F.layer_norm(hdn, (hdn.shape[-1],), mod.norm.weight, mod.norm.bias))
+        hdn = F.relu(layer_norm(hdn, mod.norm.weight, mod.norm.bias))
         return linear(hdn, l1.weight, l1.bias)
 
     return g(pa, pb) + g(pb, pa)
@@ -199,12 +236,12 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     for i, conv in enumerate(enc.convs):
         xi = SpmmFn.apply(linear(x, conv.lin.weight, None), a_hat) + conv.bias
         if enc.lns is not None:
-            xi = F.layer_norm(xi, (xi.shape[-1],), enc.lns[i].weight, enc.lns[i].bias)
+            xi = layer_norm(xi, enc.lns[i].weight, enc.lns[i].bias)
         xi = F.dropout(xi, p=enc.dropout, training=True)
         if enc.relu:
             xi = F.relu(xi)
         x = x + xi if (enc.residual and x.shape[-1] == xi.shape[-1]) else xi
-    x_node = F.layer_norm(x, (d,), model.gnn_norm.weight, model.gnn_norm.bias)
+    x_node = layer_norm(x, model.gnn_norm.weight, model.gnn_norm.bias)
     xa, xb = x_node[batch[0]], x_node[batch[1]]
     ew = _mlp(model.elementwise_lin, xa * xb)
     # ---- selection (integer work, no gradient) in the reference's layout, then the random attention drop
@@ -247,7 +284,7 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     alpha = e / den[pair]
     out = torch.zeros(bs, d, device=dev).index_add(0, pair, k * alpha[:, None]) + att.bias
     layer = model.att_layers[0]
-    out = F.layer_norm(out, (d,), layer.post_att_norm.weight, layer.post_att_norm.bias)
+    out = layer_norm(out, layer.post_att_norm.weight, layer.post_att_norm.bias)
     out = F.dropout(out, p=layer.dropout, training=True)
     # ---- count features + pairwise_lin (link_transformer.py:170-177, 340-356)
     if n_types == 3:

@@ -274,3 +274,24 @@ def test_gemm_tn_weight_gradient():
         scale = max(1.0, float(want.abs().max()))
         assert got.shape == (n, k) and float((got.double() - want).abs().max()) <= 2e-5 * scale * max(1.0, m ** 0.5 / 30)
         assert torch.equal(got, train._gemm_tn(a, b))      # deterministic reduction order
+
+
+def test_layernorm_backward_kernel():
+    """lpf_layernorm_bwd_f32 (through train.layer_norm) against torch autograd in fp64: dx, dgamma, dbeta; several
+    widths, a single row, many rows."""
+    from lpformer_amd import train
+    torch.manual_seed(5)
+    for m, d in ((70_001, 128), (513, 64), (1, 32), (3000, 256), (200, 132)):
+        x = torch.randn(m, d, device=DEV, requires_grad=True)
+        g = (torch.rand(d, device=DEV) + 0.5).requires_grad_()
+        b = torch.randn(d, device=DEV, requires_grad=True)
+        dy = torch.randn(m, d, device=DEV)
+        y = train.layer_norm(x, g, b)
+        y.backward(dy)
+        xr, gr, br = (t.detach().double().requires_grad_() for t in (x, g, b))
+        yr = torch.nn.functional.layer_norm(xr, (d,), gr, br)
+        yr.backward(dy.double())
+        assert (y.double() - yr).abs().max().item() <= 1e-5
+        assert (x.grad.double() - xr.grad).abs().max().item() <= 1e-4 * max(1.0, float(xr.grad.abs().max()))
+        for got, want in ((g.grad, gr.grad), (b.grad, br.grad)):
+            assert (got.double() - want).abs().max().item() <= 1e-4 * max(1.0, float(want.abs().max()))
