@@ -259,13 +259,24 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(int64_t M, int N, 
     }
 }
 
+// 32 output elements x 8 slices of the chunk list per workgroup: a slice adds its chunks in order, the slices meet in
+// LDS and are added in slice order (deterministic)
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(int64_t elems, int chunks, const float *__restrict__ part,
                                                              float *__restrict__ C, int K, int64_t ldc) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= elems) return;
+    __shared__ float red[8][33];
+    const int ex = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + ex;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(int64_t)c * elems + e];
-    C[(e / K) * ldc + (e % K)] = s;
+    if (e < elems)
+        for (int c = slice; c < chunks; c += 8) s += part[(int64_t)c * elems + e];
+    red[slice][ex] = s;
+    __syncthreads();
+    if (slice == 0 && e < elems) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][ex];
+        C[(e / K) * ldc + (e % K)] = t;
+    }
 }
 
 }  // namespace
@@ -292,7 +303,7 @@ extern "C" int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, 
     dim3 grid((unsigned)chunks, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
     hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows);
     const int64_t elems = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, elems,
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s, elems,
                        (int)chunks, workspace, C, K, ldc);
     LPF_CHECK_LAUNCH();
     return LPF_OK;

@@ -213,15 +213,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
     }
 }
 
+// 16 columns x 16 slices of the workgroup list per workgroup: a slice adds its workgroups in order, the slices meet in
+// LDS and are added in slice order (deterministic; one thread per column walking a thousand partials was the slowest
+// kernel of the training step)
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(int D, int blocks, const float *__restrict__ part,
                                                                    float *__restrict__ dgamma,
                                                                    float *__restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * D) return;
-    const int k = c / D, f = c % D;
+    __shared__ float red[16][17];
+    const int colx = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + colx;  // column of the [2 D] row pair
     float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += part[((int64_t)b * 2 + k) * D + f];
-    (k == 0 ? dgamma : dbeta)[f] = s;
+    if (c < 2 * D) {
+        const int k = c / D, f = c % D;
+        for (int b = slice; b < blocks; b += 16) s += part[((int64_t)b * 2 + k) * D + f];
+    }
+    red[slice][colx] = s;
+    __syncthreads();
+    if (slice == 0 && c < 2 * D) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][colx];
+        (c / D == 0 ? dgamma : dbeta)[c % D] = t;
+    }
 }
 
 constexpr int LN_BWD_BLOCKS = 1024;
@@ -250,7 +263,7 @@ extern "C" int lpf_layernorm_bwd_f32(int64_t M, int32_t D, const float *x, int64
             default: hipLaunchKernelGGL(layernorm_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
         }
     }
-    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, D, blocks, workspace,
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, D, blocks, workspace,
                        dgamma, dbeta);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
