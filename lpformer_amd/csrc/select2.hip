@@ -373,8 +373,9 @@ __device__ __forceinline__ PairLite s2_pair(const RunArgs &A, const RunLds &L, i
     p.tb0 = (src).tb0; p.xa0 = (src).xa0; p.xb0 = (src).xb0; p.dA = (src).dA; p.dB = (src).dB;             \
     p.nPa = (src).nPa; p.nPb = (src).nPb; p.nTa = (src).nTa; p.nTb = (src).nTb; p.dxA = (src).dxA;         \
     p.dxB = (src).dxB
-    if (w < S2_WCACHE) { S2_COPY(L.dsc[w]); }
-    else { const PairDesc *d = A.desc + (pf + w); S2_COPY(*d); }
+    // (an item never spans more than S2_WCACHE pairs -- S2_MIN_SLOTS --, so the window's descriptors are all in LDS)
+    (void)A; (void)pf;
+    S2_COPY(L.dsc[w]);
 #undef S2_COPY
     return p;
 }
