@@ -5,12 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+``python bench.py --gpus N`` without torchrun's environment starts its own N ranks (child processes, one per GPU,
+before this process touches a GPU) and rank 0 prints the one JSON line with ``n_gpus: N``.
+
 One "step" = the pair stage of the scoring path over one batch of candidate pairs with the encoder output
 resident in HBM (the reference's HeaRT / citation2 evaluation pattern, src/train/testing.py:96-121:
 ``propagate()`` once, then per batch ``elementwise_lin(h[a]*h[b])``, ``calc_pairwise``, ``score_func``):
 endpoint gathers, q projection, PPR-thresholded node selection, PE + attention, count features, ``pairwise_lin``,
-``elementwise_lin`` and the ``mlp_score`` head, scores landing in device memory.  The encoder (L x GEMM + CSR SpMM,
-row-sharded with an RCCL all-gather per layer when N > 1) is timed separately and reported as ``encoder_ms``; the
+``elementwise_lin`` and the ``mlp_score`` head, scores landing in device memory.  The encoder (L x GEMM + CSR SpMM;
+N > 1: replicated, row-sharded with an RCCL all-gather per layer, or one all-gather of [X | Z | Y] after the last layer,
+chosen by a measured cost model) is timed separately and reported as ``encoder_ms``; the
 throughput including one encoder pass per batch (the reference's ``test_edge`` pattern) is ``value_incl_encoder``.
 
 Data are synthetic (no datasets offline): Chung-Lu power-law graph with ogbl-collab's node/edge counts and integer
@@ -32,11 +36,42 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _self_launch(n_gpus: int) -> int:
+    """``python bench.py --gpus N`` without torchrun: start N ranks as fresh child processes (this process has made no
+    GPU call yet and makes none afterwards -- it only waits), one rank per GPU over RCCL, rendezvous on 127.0.0.1.
+    Rank 0's stdout (the JSON line) passes through; returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LPF_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _ap = argparse.ArgumentParser(add_help=False)
+    _ap.add_argument("--gpus", type=int, default=1)
+    _n = _ap.parse_known_args()[0].gpus
+    if _n > 1:
+        sys.exit(_self_launch(_n))
+
 import lpformer_amd  # noqa: E402
 from lpformer_amd import data as D  # noqa: E402
 from lpformer_amd import dist as LD  # noqa: E402
 from lpformer_amd.profile import KernelTimer  # noqa: E402
 
+PMC_FILE = "r03_pmc_traffic.json"  # committed rocprofv3 PMC passes the `traffic` figures are read from
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 
@@ -52,21 +87,95 @@ def build_problem(cfg, rank, world, threads, ppr_device=None):
     return ei, w, x, data, {"graph_s": t1 - t0, "ppr_s": t2 - t1}
 
 
-def pair_stats(data, batch, thresholds, p1):
-    """Per-batch structural sizes that the algorithmic byte/FLOP counts are built from."""
+def pair_stats(data, batch):
+    """Per-batch structural sizes (reported beside the roofline: what a both-rows walk would have touched)."""
     adj, ppr = data["adj_mask"], data["ppr"]
     a, b = batch[0], batch[1]
     deg = np.diff(adj.rowptr)
     plen = np.diff(ppr.rowptr)
-    p1len = np.minimum(np.diff(p1.rowptr), 256)  # longer P1 rows are binary-searched in place, not streamed
-    return {"sum_deg": int(deg[a].sum() + deg[b].sum()), "sum_ppr_len": int(plen[a].sum() + plen[b].sum()),
-            "sum_p1_len": int(p1len[a].sum() + p1len[b].sum())}
+    return {"sum_deg": int(deg[a].sum() + deg[b].sum()), "sum_ppr_len": int(plen[a].sum() + plen[b].sum())}
 
 
 def slot_count(model, batch_t):
-    """Candidate slots of one batch (adjacency rows of both endpoints + the shorter T0 row, at least one per pair)."""
+    """Candidate slots of one batch as the plan kernel lays them out (a-side walk | b-side walk | >1-hop walk, at
+    least 16 per pair)."""
     ws = model._select_device(batch_t, False, None)
     return int(ws.ctl[0].item())
+
+
+def run_cpu_workers(sample, x_node, mask, ppr, P, cfg, n_proc, chunk):
+    """Scores ``sample`` ([2, n] pairs) with the numpy oracle on ``n_proc`` worker processes (oracle/bench_worker.py:
+    numpy + oracle only), inputs shared through memory-mapped files.  Returns (logits, seconds from the common start
+    signal to the last worker's end)."""
+    import pickle
+    import shutil
+    import subprocess
+    import tempfile
+    n_take = sample.shape[1]
+    spans = [(i, min(i + chunk, n_take)) for i in range(0, n_take, chunk)]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="lpf_bench_", dir=base)
+    procs = []
+    try:
+        arrays = {"sample": sample, "x_node": x_node, "mask_rowptr": mask.rowptr, "mask_col": mask.col.astype(np.int64),
+                  "ppr_rowptr": ppr.rowptr, "ppr_col": ppr.col.astype(np.int64), "ppr_val": ppr.val}
+        for k, v in arrays.items():
+            np.save(os.path.join(d, k + ".npy"), np.ascontiguousarray(v))
+        with open(os.path.join(d, "small.pkl"), "wb") as f:
+            pickle.dump({"P": P, "cfg": cfg, "spans": spans}, f)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.bench_worker", d, str(i), str(n_proc)], cwd=ROOT, env=env)
+                 for i in range(n_proc)]
+        t_dead = time.time() + 600
+        while sum(os.path.exists(os.path.join(d, f"ready.{i}")) for i in range(n_proc)) < n_proc:
+            if time.time() > t_dead or any(p.poll() not in (None, 0) for p in procs):
+                raise RuntimeError("cpu_baseline: a worker did not come up")
+            time.sleep(0.01)
+        t_go = time.time()
+        open(os.path.join(d, "go"), "w").close()
+        for p in procs:
+            if p.wait(timeout=1800) != 0:
+                raise RuntimeError("cpu_baseline: a worker failed")
+        ends = [float(open(os.path.join(d, f"done.{i}")).read().split()[1]) for i in range(n_proc)]
+        logits = np.empty(n_take, np.float32)
+        for i in range(n_proc):
+            part, pos = np.load(os.path.join(d, f"logit.{i}.npy")), 0
+            for lo, hi in spans[i::n_proc]:
+                logits[lo:hi] = part[pos:pos + hi - lo]
+                pos += hi - lo
+        return logits, max(ends) - t_go
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def cpu_baseline(args, model, score, targs, data, batches_np, h, bs, dev):
+    """The numpy oracle's pair stage on a bounded sample of the bench's own batches, on ALL host cores (one worker
+    process per core), next to the GPU's logits for the same pairs."""
+    n_proc = max(1, args.cpu_procs or (os.cpu_count() or 1))
+    n_take = min(args.cpu_sample or 1024 * n_proc, bs * len(batches_np))
+    sample = np.ascontiguousarray(np.concatenate(batches_np, axis=1)[:, :n_take])
+    chunk = max(64, min(1024, n_take // (4 * n_proc) or 64))
+    P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
+    ref_logit, cpu_s = run_cpu_workers(sample, h.cpu().numpy(), data["adj_mask"], data["ppr"], P,
+                                       dict(targs, pred_layers=2), n_proc, chunk)
+    gl = []   # the GPU scores of the same pairs, checked against it while we are here
+    for i in range(0, n_take, bs):
+        for _attempt in range(3):
+            out = model.score_pairs(torch.from_numpy(sample[:, i:i + bs]).to(dev), h, score, logits=True)
+            if model.check_selection():
+                break
+        gl.append(out.cpu().numpy())
+    gl = np.concatenate(gl)
+    return {"value": round(n_take / cpu_s, 1), "unit": "pairs/s", "cores": n_proc, "kind": "port",
+            "sample": f"first {n_take} pairs of the bench's batches (pair stage, encoder output resident) in chunks of "
+                      f"{chunk} on {n_proc} worker processes (host has {os.cpu_count()} cores), one BLAS thread each; "
+                      f"numpy restatement oracle/lpformer_oracle.py, {cpu_s:.2f} s from the common start signal to the "
+                      "last worker's end (process start-up and page-ins excluded)",
+            "max_abs_logit_diff_vs_gpu": float(np.abs(gl - ref_logit).max())}
 
 
 def main():
@@ -78,9 +187,10 @@ def main():
     ap.add_argument("--batches", type=int, default=5,
                     help="distinct candidate batches cycled through (coprime with --streams: every stream sees every batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=98304,
-                    help="pairs timed on the CPU oracle (taken from the bench's own batches; about 10-15 s of CPU work)")
-    ap.add_argument("--cpu-threads", type=int, default=32, help="host threads the CPU baseline may use")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="pairs timed on the CPU oracle, taken from the bench's own batches (0 = 1,024 per worker process, "
+                         "at most all of them: about 1 s of work per core)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the CPU baseline (0 = all host cores)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16 throughput-mode measurement")
     ap.add_argument("--ppr", default="gpu", choices=("gpu", "host"),
@@ -90,19 +200,20 @@ def main():
     ap.add_argument("--no-side-stream", action="store_true",
                     help="keep the elementwise / q branches on the step's own stream (model.use_side_stream = False)")
     ap.add_argument("--repeats", type=int, default=5,
-                    help="timed windows of K steps in total; the FIRST is `value`, min/median/max of all are reported")
-    ap.add_argument("--encoder", default="auto", choices=("auto", "replicated", "sharded"),
-                    help="N > 1: every rank runs the whole encoder, or rows are sharded with an all-gather per layer; "
-                         "auto = the cheaper one by lpformer_amd.dist.encoder_plan (measured encoder time and "
-                         "measured all-gather rate)")
+                    help="timed windows of K steps each; `value` / `ms_per_step` are the MEDIAN window, min/median/max of "
+                         "all are reported")
+    ap.add_argument("--encoder", default="auto", choices=("auto", "replicated", "sharded", "gather_once"),
+                    help="N > 1: every rank runs the whole encoder / rows sharded with an all-gather per layer / the last "
+                         "layer and the per-node attention projections sharded with ONE all-gather of [X | Z | Y]; "
+                         "auto = the cheapest by lpformer_amd.dist.encoder_plan (measured encoder, last-layer and "
+                         "projection times, measured all-gather rate)")
     ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
 
     rank, world, local = LD.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     local = int(os.environ.get("LPF_LOCAL_DEVICE", local))  # (functional multi-rank runs on a one-GPU box)
     dev = torch.device(f"cuda:{local}")
@@ -130,9 +241,20 @@ def main():
             model.propagate()
         torch.cuda.synchronize()
         enc1 = LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / 3, dev)
+        # the parts the single-gather layout shards: the last layer's aggregation and the two per-node projections
+        KernelTimer.reset()
+        KernelTimer.enabled = True
+        hh = model.propagate()
+        model._node_keys(hh, model._fold())
+        kt0 = KernelTimer.summary()
+        KernelTimer.enabled = False
+        last_agg = LD.max_over_ranks(kt0["spmm_csr"][2] if "spmm_csr" in kt0 else enc1 / cfg["gnn_layers"], dev)
+        keys_ms = LD.max_over_ranks(kt0["gemm_node_keys"][1] if "gemm_node_keys" in kt0 else 0.0, dev)
+        del hh
         ag = LD.measure_allgather_gbps(n, d, dev)
-        enc_plan = LD.encoder_plan(enc1, n, d, cfg["gnn_layers"], world, ag)
-        enc_plan["allgather_gbps"] = round(ag, 1)
+        enc_plan = LD.encoder_plan(enc1, n, d, cfg["gnn_layers"], world, ag, last_agg_ms=last_agg,
+                                   node_keys_ms=keys_ms)
+        enc_plan.update(allgather_gbps=round(ag, 1), last_agg_ms=round(last_agg, 4), node_keys_ms=round(keys_ms, 4))
         enc_plan["chosen"] = enc_plan["mode"] if args.encoder == "auto" else args.encoder
         model.set_row_shard(rank, world, enc_plan["chosen"])
 
@@ -172,29 +294,31 @@ def main():
         torch.cuda.synchronize()
         n_spin += 16
 
-    # ---- timed region: EXACTLY `steps` steps, nothing but the scoring path (no event recording)
+    # ---- timed region: windows of EXACTLY `steps` steps, nothing but the scoring path (no event recording); each
+    #      window is bracketed by a barrier + device synchronisation on both sides, time = max over ranks.
     KernelTimer.enabled = False
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step_on(i)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = LD.max_over_ranks(time.perf_counter() - t0, dev)
-    assert torch.isfinite(out).all()
 
-    # ---- the same window repeated (reported only: `value` is the window above); spread of the measurement
-    rep_ms = [elapsed * 1e3 / args.steps]
-    for _ in range(max(0, args.repeats - 1)):
+    def window():
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step_on(i)
+            o = step_on(i)
         torch.cuda.synchronize()
         barrier()
-        rep_ms.append(LD.max_over_ranks(time.perf_counter() - t0, dev) * 1e3 / args.steps)
+        return LD.max_over_ranks(time.perf_counter() - t0, dev), o
+
+    rep_s = []
+    for _ in range(max(1, args.repeats)):
+        el, out = window()
+        rep_s.append(el)
+        assert torch.isfinite(out).all()
+    # the steps never read the selection status back (nothing does while they are queued): read it once per lane now --
+    # a batch that had outgrown its workspace would have come back as NaN and must not count as scored
+    overflows = sum(0 if model.check_selection(lane) else 1 for lane in lanes)
+    assert overflows == 0, "a timed step overflowed its selection workspace: the window is invalid"
+    rep_ms = [e * 1e3 / args.steps for e in rep_s]
+    elapsed = float(np.median(rep_s))   # `value`: the median window
 
     # ---- encoder, timed separately (same output: h stays valid)
     barrier()
@@ -304,13 +428,11 @@ def main():
             # structural totals over the batches actually timed
             tp = [model.compute_node_mask(b) for b in batches]
             nsel = [sum(int(t[0].shape[1]) for t in sel if t is not None) for sel in tp]
-            p1 = model._device_graph("p1", data["ppr"]).to_host_compact()
-            stats = [dict(pair_stats(data, b, cfg["thresholds"], p1), slots=slot_count(model, bt))
-                     for b, bt in zip(batches_np, batches)]
+            stats = [dict(pair_stats(data, b), slots=slot_count(model, bt)) for b, bt in zip(batches_np, batches)]
             used = [i % len(batches) for i in range(args.steps)]
             mean = lambda arr: float(np.mean([arr[i] for i in used]))  # noqa: E731
             n_sel, sum_deg = mean(nsel), mean([s["sum_deg"] for s in stats])
-            sum_ppr, sum_p1 = mean([s["sum_ppr_len"] for s in stats]), mean([s["sum_p1_len"] for s in stats])
+            sum_ppr = mean([s["sum_ppr_len"] for s in stats])
             # algorithmic work per launch: bytes for the HBM-bound kernels, FLOPs for MFMA ones
             slots = mean([s["slots"] for s in stats])
             c = model.count_dim
@@ -320,12 +442,12 @@ def main():
                 # legacy two-pass kernels (D = 256 and the module-by-module API)
                 "pair_scores": ("mfma", n_sel * (2.0 * d * d + 20.0 * d)),
                 "pair_softmax_gather": ("hbm", n_sel * (4.0 * d + 16.0) + bs * (4.0 * (4 * d + 4) + 48.0)),
-                # selection, run kernel: 8 B per candidate slot (column + aligned self-PPR, or T0 column + value),
-                # one 8-byte index lookup (column + value) per adjacency candidate, 148 B per pair (descriptor, offset,
-                # three segment starts), one 16-byte record per selected entry
-                "select_run": ("hbm", 8.0 * slots + 8.0 * sum_deg + 148.0 * bs + 16.0 * n_sel),
-                # plan kernel: two node ids, twelve row pointers, descriptor + offset per pair
-                "select_plan": ("hbm", (16.0 + 12 * 8.0 + 128.0 + 8.0) * bs),
+                # selection, run kernel (walk plan): per candidate slot the walked {node, value} entry (8 B) and the
+                # answer of its one look-up ({node, value | adjacent}: 8 B of a 64-byte bucket), 148 B per pair
+                # (descriptor, offset, three segment starts), one 16-byte record per selected entry
+                "select_run": ("hbm", 16.0 * slots + 148.0 * bs + 16.0 * n_sel),
+                # plan kernel: two node ids, two 64-byte node records, descriptor + offset per pair
+                "select_plan": ("hbm", (16.0 + 2 * 64.0 + 128.0 + 8.0) * bs),
                 "select_export": ("hbm", 2 * 16.0 * n_sel + 40.0 * bs),
                 # q = Y[a] + Y[b]: two gathered rows in, one row out per pair
                 "pair_gather_q": ("hbm", 3.0 * 4.0 * d * bs + 16.0 * bs),
@@ -350,9 +472,9 @@ def main():
             # HBM traffic per launch: NOT measured in this run -- read from the committed rocprofv3 PMC passes
             # (FETCH_SIZE / WRITE_SIZE, gfx950-corrected; tools/collect_profiles.sh) and tagged with that file
             try:
-                if args.config != "collab":
-                    raise KeyError("the committed PMC passes were collected on the collab-like workload only")
-                pmc_file = os.path.join("profiles", "r02_pmc_traffic.json")
+                if args.config != "collab" or world > 1:
+                    raise KeyError("the committed PMC passes were collected on the collab-like workload, one GPU")
+                pmc_file = os.path.join("profiles", PMC_FILE)
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
                 for name, r in rooflines.items():
                     if name in pmc["kernels"]:
@@ -371,13 +493,14 @@ def main():
             modelled = [k for k in sorted(kt, key=lambda k: -kt[k][1]) if k in rooflines]
             if modelled:
                 roofline = dict(rooflines[modelled[0]])
-                roofline["batch_stats"] = {"n_sel": n_sel, "sum_deg": sum_deg, "sum_ppr_len": sum_ppr,
-                                           "sum_p1_len": sum_p1, "slots": slots}
+                roofline["batch_stats"] = {"n_sel": n_sel, "sum_deg": sum_deg, "sum_ppr_len": sum_ppr, "slots": slots}
         # encoder aggregation kernel (outside the timed pair-stage region): SURVEY 8(d) bytes per layer
         if "spmm_csr" in enc:
             a_hat = model._device_graph("prop", data["adj_t"])
             nnz, n_rows = a_hat.nnz, n
             if world > 1 and model.encoder_mode == "sharded":  # this rank aggregates its row block only
+                # (gather_once: the per-launch average mixes whole-graph and row-block launches; N = 1 figures are the
+                #  ones the roofline is quoted on)
                 lo, hi = LD.row_range(n, world, rank)
                 nnz, n_rows = int(a_hat.rowptr[hi] - a_hat.rowptr[lo]), hi - lo
             byts = nnz * 8.0 + 8.0 * (n_rows + 1) + 4.0 * d * nnz + 4.0 * d * n_rows
@@ -394,55 +517,18 @@ def main():
                                      "achieved_compulsory_floor": round(ach_floor, 1),
                                      "frac_compulsory_floor": round(ach_floor / HBM_PEAK_GBS, 4)}
             try:
-                pmc_file = os.path.join("profiles", "r02_pmc_traffic.json")
+                pmc_file = os.path.join("profiles", PMC_FILE)
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
-                if args.config == "collab" and "spmm_csr" in pmc["kernels"]:
+                if args.config == "collab" and world == 1 and "spmm_csr" in pmc["kernels"]:
                     rooflines["spmm_csr"]["traffic"] = pmc["kernels"]["spmm_csr"]["hbm_bytes_per_launch_corrected"]
                     rooflines["spmm_csr"]["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes)"
             except (OSError, KeyError, ValueError):
                 pass
 
-        # ---- CPU baseline: the oracle's pair stage on a bounded sample of the same workload
+        # ---- CPU baseline: the oracle's pair stage on a bounded sample of the same workload (rank 0, N = 1 only)
         cpu = None
-        if not args.no_cpu_baseline:
-            from oracle import lpformer_oracle as O
-            torch.set_num_threads(os.cpu_count() or 8)
-            P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-            P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
-            n_take = min(args.cpu_sample, bs * len(batches_np))
-            sample = np.ascontiguousarray(np.concatenate(batches_np, axis=1)[:, :n_take])
-            hx = h.cpu().numpy()
-            mask, ppr = data["adj_mask"], data["ppr"]
-            okw = dict(x=None, adj_norm=None, adj_mask=(mask.rowptr, mask.col.astype(np.int64)),
-                       ppr=(ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P=P, cfg=dict(targs, pred_layers=2),
-                       x_node=hx)
-            # the numpy port is one thread per call: run it over chunks of the sample on a pool of host threads (numpy
-            # releases the GIL inside its kernels), BLAS pinned to one thread per call; `cores` = threads used
-            from concurrent.futures import ThreadPoolExecutor
-            n_thr = max(1, min(os.cpu_count() or 1, args.cpu_threads))
-            try:
-                from threadpoolctl import threadpool_limits
-                limiter = threadpool_limits(limits=1)
-            except ImportError:
-                limiter = None
-            chunk = max(256, n_take // (4 * n_thr))
-            spans = [(i, min(i + chunk, n_take)) for i in range(0, n_take, chunk)]
-            t0 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=n_thr) as pool:
-                refs = list(pool.map(lambda se: O.forward(sample[:, se[0]:se[1]], **okw)["logit"], spans))
-            cpu_s = time.perf_counter() - t0
-            if limiter is not None:
-                limiter.restore_original_limits()
-            ref_logit = np.concatenate(refs)
-            # check the GPU scores of the same pairs against it while we are here
-            gl = np.concatenate([model.score_pairs(torch.from_numpy(sample[:, i:i + bs]).to(dev), h, score, logits=True)
-                                 .cpu().numpy() for i in range(0, n_take, bs)])
-            cpu = {"value": round(n_take / cpu_s, 1), "unit": "pairs/s", "cores": n_thr,
-                   "kind": "port",
-                   "sample": f"first {n_take} pairs of the bench's batches (pair stage, encoder output resident) in "
-                             f"chunks of {chunk} on {n_thr} host threads of {os.cpu_count()} cores; numpy restatement "
-                             f"oracle/lpformer_oracle.py, {cpu_s:.1f} s",
-                   "max_abs_logit_diff_vs_gpu": float(np.abs(gl - ref_logit).max())}
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(args, model, score, targs, data, batches_np, h, bs, dev)
 
         result = {
             "metric": "candidate link-pairs scored/sec (whole node)", "value": round(pairs_per_s, 1),
@@ -455,9 +541,11 @@ def main():
                                    "encoder output resident",
                        "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
                        "streams": len(lanes), "spinup_s": args.spinup,
-                       "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']}" +
-                                       (" (rows + all-gather per layer)" if enc_plan["chosen"] == "sharded" else
-                                        " (every rank runs it, no exchange)")) if world > 1 else "single GPU",
+                       "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']} " +
+                                       {"sharded": "(rows + all-gather per layer)",
+                                        "gather_once": "(last layer + Z / Y on row blocks, one all-gather of [X | Z | Y])",
+                                        "replicated": "(every rank runs it, no exchange)"}[enc_plan["chosen"]])
+                       if world > 1 else "single GPU",
                        "encoder_plan": enc_plan},
             "encoder_ms": round(encoder_ms, 4), "value_incl_encoder": round(value_incl_encoder, 1),
             "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),

@@ -34,7 +34,7 @@ extern "C" {
 #define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
 #define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
 
-#define LPF_ABI_VERSION 2
+#define LPF_ABI_VERSION 3
 
 /* GEMM / row-wise epilogue flags */
 #define LPF_FLAG_RELU 1u
@@ -175,11 +175,40 @@ int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int3
                    const void *t0_cv, const int32_t *t0_skip, float th_cn, float th_1hop,
                    float th_non1hop, int32_t *type_ptr, void *entries, int64_t ent_cap, int32_t grid_blocks,
                    void *stream);
+/* Selection over the per-model WALK INDEXES (select3.hip) -- the evaluation path: the typing adjacency is the model's
+ * own adj_mask / full_adj_mask (link_transformer.py:226-227 with adj=None), mask modes "all", "1-hop" and "cn"
+ * (:39-44).  Same control block, workspaces, result layout and error bits as lpf_select_plan / lpf_select_run above
+ * (which remain the path for a caller-supplied adjacency override); desc is 128 bytes per pair, a pair owns at least
+ * 16 slots.  Every selected set is an intersection evaluated from its shorter side with one hashed look-up per
+ * candidate.  Index arrays, built once per (adjacency, PPR matrix, thresholds) by
+ * lpformer_amd/graph.py build_walk_index; "cv" = interleaved {int32 node, fp32 value bits} pairs:
+ *   node_rec 64 bytes per node: int64 {adj0, a10, px0, t00, u0} element offsets of the node's rows in adj_cv, a1_cv,
+ *            px_cv, t0_cv (entries) and u_cv (entries, 8 per bucket), int32 {deg, n_a1, n_px, n_t0, u_buckets, 0}
+ *   adj_cv   the adjacency rows with selfp[e] = P[i, j] (0 where the PPR matrix stores nothing)
+ *   a1_cv    the adjacency entries whose own value passes the one-hop test fl32(fl32(p+1)-1) >= theta_1
+ *   px_cv    the PPR entries (i, v), v NOT adjacent to i, that pass the weaker of the one-hop / >1-hop tests
+ *   t0_cv    the px entries with p > 0 and fl32(fl32(p+1)-1) >= theta_n (NULL: no >1-hop nodes -- modes "1-hop", "cn")
+ *   u_cv     HASHED union of a node's adjacency row and its px row: row i owns u_buckets[i] buckets of 8 entries
+ *            (64 aligned bytes, unused entries node INT32_MAX), entry (i, v) in bucket
+ *            mulhi_u32(v * 2654435761 mod 2^32, u_buckets[i]), value = P[i, v] with the SIGN BIT set when v is
+ *            adjacent to i; no bucket overflows (the builder grows a row's bucket count until that holds)
+ * mode_cn: mask mode "cn" -- common neighbours only, round trip with t = 1, thresh_cn filter (:232-247).
+ * use_px:  0 when theta_1 <= 0 (absent PPR entries then pass the one-hop test and px rows cannot stand in for them). */
+int lpf_select3_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
+                     const void *adj_cv, const void *a1_cv, const void *px_cv, const void *t0_cv, int32_t mode_cn,
+                     int32_t use_px, void *desc, int64_t *offs, int32_t *item_pair, int64_t item_cap, int64_t *ctl,
+                     uint64_t *plan_lb, void *stream);
+int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair, int64_t item_cap,
+                    int64_t *ctl, uint64_t *run_lb, const void *u_cv, float th_cn, float th_1hop, float th_non1hop,
+                    int32_t mode_cn, int32_t *type_ptr, void *entries, int64_t ent_cap, int32_t grid_blocks,
+                    void *stream);
+
 /* The reference's layout from the regions above: all CN entries sorted by (pair, node), then all 1-hop (the two runs
  * merged by node id), then all >1-hop (link_transformer.py:161-162); type_ptr64 int64[3*(bs+1)] relative per type,
- * counts_f the float count features of get_structure_cnts (:340-356),  */
+ * counts_f (optional) the float count features: n_counts = 4 -> get_structure_cnts (:340-356) n_cn, n_1hop,
+ * n_non1hop, n_cn + n_1hop; 3 -> without n_non1hop (mask mode "1-hop"); 1 -> n_cn alone (mask mode "cn", :154-155). */
 int lpf_select_export(int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap, int64_t *type_ptr64,
-                      float *counts_f, int64_t ldc, int32_t want_t0, int32_t *sel_pair, int32_t *sel_node,
+                      float *counts_f, int64_t ldc, int32_t n_counts, int32_t *sel_pair, int32_t *sel_node,
                       float *sel_pa, float *sel_pb, void *stream);
 
 /* Attention scores for every selected entry (layers.py:206-218 with get_pos_encodings

@@ -22,14 +22,18 @@
 //     unit after.  The tail kernel (tail_chain.hip, merge mode) finds a pair's records from its segment pointers,
 //     merges them with the same rescaling as the online softmax, adds the bias and applies post_att_norm.
 // Bound: fp32 MFMA (2 D^2 FLOP per entry); one Z row + one 16-byte record read per entry.
-#include <stdlib.h>
-
 #include "pe_common.h"
 
-// Tuning aid, compiled only with -DLPF_FUSED_STAMPS (make EXTRA=-DLPF_FUSED_STAMPS; tools/fused_stamps.py): s_memtime at the
-// phase boundaries of the first eight tiles of 512 wavefronts.
+// Tuning aids, compiled only with -DLPF_FUSED_STAMPS (make EXTRA=-DLPF_FUSED_STAMPS; tools/fused_stamps.py): s_memtime at
+// the phase boundaries of the first eight tiles of 512 wavefronts, and the LPF_FUSED_DBG environment switches that
+// ablate parts of the kernel (bit 0 no Z/q loads, 1 no softmax/flush, 2 no MFMA, 3 no butterfly, 5 stamps).  The
+// default build has neither: PF_DBG() is the constant 0 and no environment variable is read.
 #ifdef LPF_FUSED_STAMPS
+#include <stdlib.h>
 __device__ long long g_pf_stamps[4096 * 8];
+#define PF_DBG(bits) (A.dbg & (bits))
+#else
+#define PF_DBG(bits) (0)
 #endif
 
 namespace {
@@ -55,7 +59,7 @@ struct FusedArgs {
     float *part;               // [3][bs][D+4]
     float *bnd;                // [3][units_cap][2][D+4]
     int64_t units_cap;
-    int dbg;                   // tuning aid (LPF_FUSED_DBG): bit 0 no Z/q loads, 1 no softmax/flush, 2 no MFMA, 3 no butterfly
+    int dbg;                   // tuning aid (LPF_FUSED_STAMPS builds only)
 };
 
 template <int NT, bool BF16>
@@ -85,7 +89,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         tile_cont = ((uint32_t)ent[e0 + 32].x & PF_PAIR_MASK) == ((uint32_t)ent[e0 + 31].x & PF_PAIR_MASK);
 
 #ifdef LPF_FUSED_STAMPS
-    const bool stamp = (A.dbg & 32) && lane == 0 && stamp_slot >= 0;
+    const bool stamp = PF_DBG(32) && lane == 0 && stamp_slot >= 0;
 #define PF_STAMP(k) do { if (stamp) g_pf_stamps[stamp_slot * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
     (void)stamp_slot;
@@ -132,7 +136,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     PF_STAMP(1);
     if constexpr (!BF16) {
 #pragma unroll 1
-        for (int sq = 0; sq < ((A.dbg & 4) ? 0 : NSQ); ++sq) {
+        for (int sq = 0; sq < (PF_DBG(4) ? 0 : NSQ); ++sq) {
             float4 wb[NT];  // (an explicit one-group-ahead prefetch of these measured slower: 198 vs 173 us)
 #pragma unroll
             for (int c = 0; c < NT; ++c) wb[c] = wl[(c * NSQ + sq) * 64];
@@ -155,7 +159,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
         // the bf16 image (element (t, c, s, lane, j) = Wfold_t[32 c + (lane & 31)][16 s + 8 (lane >> 5) + j]).
         const float4 *tk = tab + t * D + 8 * lh;
 #pragma unroll 1
-        for (int ks = 0; ks < ((A.dbg & 4) ? 0 : D / 16); ++ks) {
+        for (int ks = 0; ks < (PF_DBG(4) ? 0 : D / 16); ++ks) {
             bf16x8 wbb[NT];
 #pragma unroll
             for (int c = 0; c < NT; ++c)
@@ -184,7 +188,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
             const int pr0 = __builtin_amdgcn_readlane(pair_a, r0), pr1 = __builtin_amdgcn_readlane(pair_a, r0 + 4);
             const float *qr = A.q + (int64_t)(lh ? pr1 : pr0) * A.ldq + col;
 #pragma unroll
-            for (int c = 0; c < NT; ++c) dst[u][c] = (A.dbg & 1) ? 0.25f : qr[32 * c];
+            for (int c = 0; c < NT; ++c) dst[u][c] = PF_DBG(1) ? 0.25f : qr[32 * c];
         }
     };
     load_q(0, qn);
@@ -203,9 +207,9 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
             for (int c = 0; c < NT; ++c) {  // the staged row of unit entry i (LDS)
                 if constexpr (BF16) {
                     const uint16_t zb = reinterpret_cast<const uint16_t *>(zbuf)[(16 * lh + i) * D + 32 * c + col];
-                    zv[u][c] = (A.dbg & 1) ? 0.5f : __uint_as_float((uint32_t)zb << 16);
+                    zv[u][c] = PF_DBG(1) ? 0.5f : __uint_as_float((uint32_t)zb << 16);
                 } else {
-                    zv[u][c] = (A.dbg & 1) ? 0.5f : zbuf[(16 * lh + i) * D + 32 * c + col];
+                    zv[u][c] = PF_DBG(1) ? 0.5f : zbuf[(16 * lh + i) * D + 32 * c + col];
                 }
             }
         }
@@ -231,7 +235,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     // its partner), 8 + 4 + 2 + 1 adds instead of 16 x 4, then one exchange with the other 16-lane row.  Lane l of
     // the half then holds the total of unit entry l & 15; every lane needs every total (they weight its own feature in
     // the softmax walk), so they are read back lane by lane.
-    if (!(A.dbg & 8)) {
+    if (!PF_DBG(8)) {
         const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
         float r1[8], r2[4], r3[2];
 #pragma unroll
@@ -270,7 +274,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     int64_t left = cnt - e0 - 16 * lh;
     const int nval = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
     if (nval == 0) return;
-    if (A.dbg & 2) {  // (tuning aid: keep the scores alive, skip the softmax walk)
+    if (PF_DBG(2)) {  // (tuning aid: keep the scores alive, skip the softmax walk)
         float t_ = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t_ += sc[i] + acc[0][i];
@@ -380,11 +384,15 @@ int fused_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *ent
     LPF_REQUIRE(ldz >= D && ldq >= D && lpf_aligned16(entries) && lpf_aligned16(pe_tab) &&
                 lpf_aligned16(wfold_packed) && lpf_aligned16(part) && lpf_aligned16(bnd) && lpf_aligned16(Z) &&
                 (ldz * (BF16 ? 2 : 4)) % 16 == 0);
+#ifdef LPF_FUSED_STAMPS
     static int dbg = -1;
     if (dbg < 0) {
         const char *e = getenv("LPF_FUSED_DBG");
         dbg = e ? atoi(e) : 0;
     }
+#else
+    const int dbg = 0;
+#endif
     FusedArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), ldz, q, ldq,
                 pe_tab, pe_stat, static_cast<const float *>(wfold_packed), bfold, att, part, bnd, units_cap, dbg};
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void pair_merge_kernel(int64_t bs, int D, int 
         if (lig == 0) {
             const float n0 = (float)cnt[0], n1 = (float)cnt[1], n2 = (float)cnt[2];
             if (n_counts == 4) { o[D] = n0; o[D + 1] = n1; o[D + 2] = n2; o[D + 3] = n0 + n1; }
-            else { o[D] = n0; o[D + 1] = n1; o[D + 2] = n0 + n1; }
+            else if (n_counts == 3) { o[D] = n0; o[D + 1] = n1; o[D + 2] = n0 + n1; }
+            else { o[D] = n0; }  // mask mode "cn": get_count alone (link_transformer.py:154-155)
         }
     }
 }
@@ -82,7 +83,7 @@ extern "C" int lpf_pair_attention_merge_f32(int64_t bs, int32_t D, int32_t n_cou
                                             int64_t ldo, void *stream) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && part && bnd && units_cap > 0 && type_ptr && att_bias && ln_g && ln_b && out);
-    LPF_REQUIRE((n_counts == 3 || n_counts == 4) && ldo >= D + n_counts && (ldo & 3) == 0);
+    LPF_REQUIRE((n_counts == 1 || n_counts == 3 || n_counts == 4) && ldo >= D + n_counts && (ldo & 3) == 0);
     LPF_REQUIRE(lpf_aligned16(part) && lpf_aligned16(bnd) && lpf_aligned16(att_bias) && lpf_aligned16(ln_g) &&
                 lpf_aligned16(ln_b) && lpf_aligned16(out));
     hipStream_t s = static_cast<hipStream_t>(stream);

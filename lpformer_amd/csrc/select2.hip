@@ -24,15 +24,10 @@
 // Placement is deterministic (it follows the flat slot order, not the schedule).  Inside a pair's one-hop segment
 // the kept nodes of N(a) come before those of N(b) (flag bit 31 of the pair word); lpf_select_export merges the two
 // runs by node id when a caller wants the reference's exact layout (compute_node_mask, attention weights).
-#include <stdlib.h>
-
-#include "lpf_common.h"
+#include "select_common.h"
 
 // the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
 #pragma clang fp contract(off)
-
-// tuning aid (LPF_SEL_DBG bit 1): per-item s_memtime stamps of the run kernel's phases
-__device__ long long g_sel_stamps[16384 * 8];
 
 namespace {
 
@@ -55,65 +50,6 @@ struct alignas(16) PairDesc {
     int64_t pad2, pad3;
 };
 static_assert(sizeof(PairDesc) == 128, "PairDesc is one 128-byte line");
-
-// ------------------------------------------------------------------------------------------- chained scan helpers
-// One 8-byte word per participant: [63:42] launch epoch, [41:40] state (1 = own total, 2 = inclusive prefix),
-// [39:0] value.  Words are written and polled as single agent-scope relaxed 8-byte accesses (value and state travel
-// together, nothing else is handed over), and a word of an older launch simply reads as "not ready": the arrays are
-// never cleared.
-constexpr uint64_t LB_VAL_MASK = (1ull << 40) - 1ull;
-
-__device__ __forceinline__ void lb_store(uint64_t *p, uint32_t epoch, uint32_t state, uint64_t value) {
-    __hip_atomic_store(p, ((uint64_t)epoch << 42) | ((uint64_t)state << 40) | (value & LB_VAL_MASK), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ uint64_t lb_wait(const uint64_t *p, uint32_t epoch) {
-    while (true) {
-        const uint64_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(w >> 42) == epoch && ((w >> 40) & 3ull) != 0ull) return w;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-__device__ __forceinline__ uint64_t lb_wave_sum(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor((unsigned long long)v, d, 64);
-    return v;
-}
-
-// Exclusive prefix of `own` over participants 0..k-1 (k = this participant), computed by ONE WHOLE WAVEFRONT (every
-// lane calls it with the same k / own and gets the result): publishes own total, looks back 64 predecessors at a
-// time -- a participant that already carries an inclusive prefix ends the walk --, then publishes its own prefix.
-// (A 256-word window, four words per lane, measured slower: 326 vs 250 us -- the polling traffic grows with it.)
-__device__ __forceinline__ void lb_publish(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own, int lane) {
-    if (lane == 0) lb_store(lb + k, epoch, k == 0 ? 2 : 1, own);
-}
-// (second half: the walk.  A participant may do other work between the two halves -- nothing a predecessor needs is
-// held back by that, its own total is already out.)
-__device__ __forceinline__ uint64_t lb_lookback(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own, int lane) {
-    if (k == 0) return 0;
-    uint64_t excl = 0;
-    for (int64_t j = k - 1;; j -= 64) {
-        const int64_t idx = j - lane;
-        uint64_t w = 2ull << 40;  // before participant 0: an inclusive prefix of value 0
-        if (idx >= 0) w = lb_wait(lb + idx, epoch);
-        const uint64_t pm = __ballot(((w >> 40) & 3ull) == 2ull);
-        const uint64_t v = w & LB_VAL_MASK;
-        if (pm) {  // nearest predecessor with an inclusive prefix: take it and the totals of the nearer ones
-            const int p = __ffsll((unsigned long long)pm) - 1;
-            excl += lb_wave_sum(lane <= p ? v : 0ull);
-            break;
-        }
-        excl += lb_wave_sum(v);
-    }
-    if (lane == 0) lb_store(lb + k, epoch, 2, excl + own);
-    return excl;
-}
-__device__ __forceinline__ uint64_t lb_exclusive(uint64_t *lb, int64_t k, uint32_t epoch, uint64_t own, int lane) {
-    lb_publish(lb, k, epoch, own, lane);
-    return lb_lookback(lb, k, epoch, own, lane);
-}
 
 // fl32((fl32(fl32(p*t)+t)-t)/t) for t in {1,2}: p*1, p*2, x/1 and x/2 are exact, only the add and subtract round
 __device__ __forceinline__ float s2_round_trip(float p, bool two) {
@@ -333,7 +269,6 @@ struct RunArgs {
     int32_t *type_ptr;         // [3][bs+1]
     int4 *entries;             // [3][ent_cap]
     int64_t ent_cap;
-    int dbg;                   // tuning aid (LPF_SEL_DBG): bit 0 = no chained scan (placement is then wrong)
 };
 
 constexpr int S2_PARK = 256;  // kept entries of one item that can wait in LDS for the item's place in the output
@@ -404,8 +339,7 @@ __device__ __forceinline__ bool s2_type_slot(const RunArgs &A, const RunLds &L, 
     // position of x in the OTHER endpoint's adjacency run: in LDS when that run lies inside the item
     const int o_lo = from_a ? s0 + dA : s0, o_n = from_a ? dB : dA;
     int j;
-    if (A.dbg & 8) j = -1;
-    else if (s0 > -(1 << 30) && o_lo >= 0 && o_lo + o_n <= n_here) j = s2_find(L.cand + o_lo, o_n, x);
+    if (s0 > -(1 << 30) && o_lo >= 0 && o_lo + o_n <= n_here) j = s2_find(L.cand + o_lo, o_n, x);
     else j = s2_find(A.adj_col + (from_a ? d.rb0 : d.ra0), o_n, x);
     if (!from_a && j >= 0) return false;  // a node of N(b) that is also in N(a) is emitted through N(a)
     const bool cn = from_a && j >= 0;
@@ -414,7 +348,7 @@ __device__ __forceinline__ bool s2_type_slot(const RunArgs &A, const RunLds &L, 
         own = own_in;
         if (cn) {
             other = A.selfp[d.rb0 + j];
-        } else if (s2_round_trip(own, false) >= A.th_1 && !(A.dbg & 4)) {  // otherwise it is dropped anyway
+        } else if (s2_round_trip(own, false) >= A.th_1) {  // otherwise it is dropped anyway
             float v;
             if (s2_lookup_hashed(A.val_cv, from_a ? d.pb0 : d.pa0, from_a ? d.nPb : d.nPa, x, v)) other = v;
         }
@@ -510,9 +444,8 @@ __device__ __forceinline__ void s2_finish_parked(const RunArgs &A, RunLds &L, ui
     __syncthreads();
     if (L.p_live) {
         if (wave < 3) {
-            const int64_t base = (A.dbg & 1) ? L.p_item * 64
-                                             : (int64_t)lb_lookback(A.run_lb + (int64_t)wave * A.item_cap, L.p_item,
-                                                                    epoch, (uint64_t)L.p_run[wave], lane);
+            const int64_t base = (int64_t)lb_lookback(A.run_lb + (int64_t)wave * A.item_cap, L.p_item, epoch,
+                                                      (uint64_t)L.p_run[wave], lane);
             if (lane == 0) L.base[wave] = base;
         }
         __syncthreads();
@@ -544,8 +477,6 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
         __syncthreads();
         const int64_t it = L.ticket;
         if (it >= n_items) break;
-        const bool stamp = (A.dbg & 2) && tid == 0 && it < 16384;
-        if (stamp) g_sel_stamps[it * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
         const int64_t c0 = it * S2_ITEM;
         const int n_here = (int)((total - c0) < S2_ITEM ? (total - c0) : S2_ITEM);
         const int64_t pf = A.item_pair[it];
@@ -571,7 +502,6 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
         }
         __syncthreads();
 
-        if (stamp) g_sel_stamps[it * 8 + 1] = (long long)__builtin_amdgcn_s_memtime();
         // ---- phase A: every thread identifies its slots and loads the candidate node (+ its own PPR value)
         // Per-slot state lives in LDS (cand / meta) and the rounds are real loops: four copies of the typing code in
         // one kernel body are what hipcc 7.2 miscompiled (see s2_find), and the per-round register arrays cost
@@ -609,7 +539,7 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
                         const int2 cv = A.t0_cv[(d.nTa <= d.nTb ? d.ta0 : d.tb0) + wi];
                         x = cv.x;
                         const float pw = __int_as_float(cv.y);
-                        want_t0 = pw > 0.f && __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f) >= A.th_n && !(A.dbg & 16);
+                        want_t0 = pw > 0.f && __fsub_rn(__fadd_rn(pw, 1.0f), 1.0f) >= A.th_n;
                         L.va[l] = pw;
                     }
                 }
@@ -638,7 +568,6 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
         }
         __syncthreads();
 
-        if (stamp) g_sel_stamps[it * 8 + 2] = (long long)__builtin_amdgcn_s_memtime();
         // ---- phase B: type, look up the other endpoint's value, round trip, thresholds
 #pragma unroll 1
         for (int r = 0; r < S2_ROUNDS; ++r) {
@@ -665,7 +594,6 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
         }
         __syncthreads();
 
-        if (stamp) g_sel_stamps[it * 8 + 3] = (long long)__builtin_amdgcn_s_memtime();
         // ---- phase C: ranks inside the item; the item's totals go out to the chained scan at once
         if (wave < 3) {  // wavefront t: exclusive scan of type t over the (round, wave) groups in slot order
             constexpr int NG = S2_ROUNDS * S2_WAVES;
@@ -679,14 +607,13 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
             if (lane < NG) L.cnt[lane][wave] = x - v;
             const int run = __shfl(x, NG - 1, 64);
             if (lane == 0) L.run[wave] = run;
-            if (!(A.dbg & 1)) lb_publish(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)run, lane);
+            lb_publish(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)run, lane);
         }
         // ---- phase D, deferred: the item's place in the output depends on every earlier item, and the slowest of the
         //      ~1300 in flight decides when that is known.  So the kept entries are parked in LDS, the workgroup goes
         //      on to type the next item, and only then asks for the parked item's place (by then an answer that
         //      needs no waiting) and writes it out.
         s2_finish_parked(A, L, epoch, bs, lane, wave, tid);  // (starts and ends with a barrier)
-        if (stamp) { g_sel_stamps[it * 8 + 4] = (long long)__builtin_amdgcn_s_memtime(); g_sel_stamps[it * 8 + 6] = n_here; g_sel_stamps[it * 8 + 7] = np; }
         const int run0 = L.run[0], run1 = L.run[1], run2 = L.run[2];
         const int n_kept = run0 + run1 + run2;
         const bool now = n_kept > S2_PARK;  // (does not fit: wait for the place here and write in several passes)
@@ -697,7 +624,7 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
         }
         if (tid < S2_WCACHE) L.ps[tid][3] = 0;
         if (now && wave < 3) {
-            const int64_t base = (A.dbg & 1) ? it * 64 : (int64_t)lb_lookback(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)L.run[wave], lane);
+            const int64_t base = (int64_t)lb_lookback(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)L.run[wave], lane);
             if (lane == 0) L.base[wave] = base;
         }
         __syncthreads();
@@ -731,7 +658,6 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
             s2_write_out(A, L, bs, tid, p_lo, pass == 0);
             __syncthreads();
         }
-        if (stamp) g_sel_stamps[it * 8 + 5] = (long long)__builtin_amdgcn_s_memtime();
     }
     s2_finish_parked(A, L, epoch, bs, lane, wave, tid);
 }
@@ -742,7 +668,7 @@ __global__ __launch_bounds__(S2_THREADS, 5) void select_run_kernel(const RunArgs
 // arrays, int64 segment pointers, float count features.  One wavefront per pair.
 __global__ __launch_bounds__(256) void select_export_kernel(
     int64_t bs, const int32_t *__restrict__ type_ptr, const int4 *__restrict__ entries, int64_t ent_cap,
-    int64_t *__restrict__ type_ptr64, float *__restrict__ counts_f, int64_t ldc, int want_t0,
+    int64_t *__restrict__ type_ptr64, float *__restrict__ counts_f, int64_t ldc, int n_counts,
     int32_t *__restrict__ sel_pair, int32_t *__restrict__ sel_node, float *__restrict__ sel_pa,
     float *__restrict__ sel_pb) {
     const int lane = threadIdx.x & 63;
@@ -773,13 +699,14 @@ __global__ __launch_bounds__(256) void select_export_kernel(
         if (counts_f && lane == 0) {
             float *c = counts_f + p * ldc;
             c[0] = (float)n[0];
-            c[1] = (float)n[1];
-            if (want_t0) {
+            if (n_counts == 4) {          // get_structure_cnts (:340-356): n_cn, n_1hop, n_non1hop, n_cn + n_1hop
+                c[1] = (float)n[1];
                 c[2] = (float)n[2];
                 c[3] = (float)(n[0] + n[1]);
-            } else {
+            } else if (n_counts == 3) {   // mask mode "1-hop"
+                c[1] = (float)n[1];
                 c[2] = (float)(n[0] + n[1]);
-            }
+            }                             // (1: mask mode "cn", get_count alone, :154-155)
         }
         // common neighbours and >1-hop nodes are already in node order
 #pragma unroll
@@ -877,12 +804,6 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     a.t0_cv = static_cast<const int2 *>(t0_cv); a.t0_skip = t0_skip;
     a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop;
     a.type_ptr = type_ptr; a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
-    static int dbg = -1;
-    if (dbg < 0) {
-        const char *e = getenv("LPF_SEL_DBG");
-        dbg = e ? atoi(e) : 0;
-    }
-    a.dbg = dbg;
     // one resident round of workgroups (they are persistent; more than fit only queue up behind the others:
     // 1024 / 1280 / 2048 / 4096 workgroups measured 132 / 132 / 138 / 158 us on 256 CUs)
     static int resident = 0;
@@ -904,22 +825,16 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     return LPF_OK;
 }
 
-extern "C" int lpf_select_debug_stamps(long long *dst_host, int64_t n_items) {
-    if (n_items > 16384) n_items = 16384;
-    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_sel_stamps), (size_t)n_items * 8 * sizeof(long long)) == hipSuccess
-               ? LPF_OK : LPF_ERR_LAUNCH;
-}
-
 extern "C" int lpf_select_export(int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
-                                 int64_t *type_ptr64, float *counts_f, int64_t ldc, int32_t want_t0,
+                                 int64_t *type_ptr64, float *counts_f, int64_t ldc, int32_t n_counts,
                                  int32_t *sel_pair, int32_t *sel_node, float *sel_pa, float *sel_pb, void *stream) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && type_ptr64 && sel_pair && sel_node && sel_pa &&
-                sel_pb && (!counts_f || ldc >= (want_t0 ? 4 : 3)));
+                sel_pb && (n_counts == 1 || n_counts == 3 || n_counts == 4) && (!counts_f || ldc >= n_counts));
     int64_t blocks = (bs + 1 + 3) / 4;
     if (blocks > (1 << 20)) blocks = 1 << 20;
     hipLaunchKernelGGL(select_export_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), bs,
-                       type_ptr, static_cast<const int4 *>(entries), ent_cap, type_ptr64, counts_f, ldc, (int)want_t0,
+                       type_ptr, static_cast<const int4 *>(entries), ent_cap, type_ptr64, counts_f, ldc, (int)n_counts,
                        sel_pair, sel_node, sel_pa, sel_pb);
     LPF_CHECK_LAUNCH();
     return LPF_OK;

@@ -1,0 +1,499 @@
+// PPR-thresholded node selection over per-model WALK INDEXES: two launches, nothing read back by the host.
+//
+// Reference: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (src/models/link_transformer.py:214-319, 434-481),
+// eval mode, typing adjacency == the model's own adj_mask / full_adj_mask (a caller-supplied override goes through
+// select2.hip, which looks values up in the raw PPR rows).  The reference materialises BS x N sparse temporaries and
+// coalesces them seven times; select2.hip (round 2) walked BOTH adjacency rows of every pair and searched the other
+// row for every candidate.  Here the selected sets are written as intersections and every intersection is evaluated
+// from its SHORTER side, one hashed look-up per candidate and no search:
+//
+//   U(i)   = N(i)  u  {v : P[i,v] passes the weaker of the one-hop / >1-hop tests}, hashed by v, each entry carrying
+//            P[i,v] and, in the value's sign bit, "v is adjacent to i"                       ("what is v to i?" in ONE read)
+//   CN(a,b)           = N(a) n N(b)                       walk the SHORTER adjacency row s, look v up in U(other): adjacent
+//   1-hop, s's side   = N(s) \ N(l), both values >= th_1  same walk (FULL): found non-adjacent / not found
+//   1-hop, l's side   = N(l) \ N(s), both values >= th_1  = A1(l) n P1x(s):  A1(l) = entries of N(l) whose own value passes,
+//                                                         P1x(s) = non-neighbours of s whose value passes; walk the
+//                                                         shorter of the two and look up in U of the other endpoint
+//   >1-hop            = T0x(a) n T0x(b), T0x(i) = non-neighbours of i passing the >1-hop test (link_transformer.py:
+//                       443-478: the UNMASKED adjacency, which here is the typing adjacency); walk the shorter one
+//
+// On the collab-like bench batches that is 1.53 M candidate slots instead of 3.76 M (hub rows are only ever looked up
+// in, never walked), and a slot costs one 8-byte read + one 64-byte bucket instead of two binary searches.
+// Every value that is compared or emitted is the same fp32 number as in the reference: the typing comes from the flag
+// (built from the same adjacency), the thresholds are applied in the kernel to the round-tripped values op for op.
+//
+// Skeleton (unchanged from select2.hip): the candidates of a batch form ONE flat slot space, pair k owning
+// [offs[k], offs[k+1]) = a-side walk | b-side walk | >1-hop walk (at least S3_MIN_SLOTS slots), cut into work items of
+// S3_ITEM slots whatever pairs they belong to; a plan kernel builds the walk descriptors and offs[] (chained scan over
+// 256-pair blocks); persistent workgroups of the run kernel draw items from a ticket, type one slot per thread and
+// round, rank the kept entries per type, publish the item's three totals to a second chained scan ordered by ticket,
+// park the entries in LDS, type the NEXT item and only then fetch the parked item's place and write it out.
+// Placement is deterministic (flat slot order): per type one dense region ordered by (pair, slot); inside a pair's
+// one-hop segment the kept nodes of N(a) come before those of N(b) (flag bit 31 of the pair word) -- exactly the layout
+// select2.hip produces, so lpf_select_export and the attention kernels do not care which path ran.
+#include "select_common.h"
+
+// the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int S3_ITEM = LPF_SELECT_ITEM;             // candidate slots per work item
+constexpr int S3_THREADS = 256;
+constexpr int S3_ROUNDS = S3_ITEM / S3_THREADS;      // slots per thread
+constexpr int S3_WAVES = S3_THREADS / 64;
+constexpr int S3_GROUPS = S3_ITEM / 64;              // 64-slot groups of an item (one per wavefront and round)
+constexpr int S3_MIN_SLOTS = 16;                     // slots a pair owns at least => at most S3_PAIRS pairs per item
+constexpr int S3_PAIRS = S3_ITEM / S3_MIN_SLOTS + 2;
+constexpr uint32_t S3_FROM_B = 0x80000000u;
+constexpr uint32_t S3_HASH_MUL = 2654435761u;
+constexpr int S3_BUCKET = 8;
+
+// walk kinds
+constexpr int K_FULL = 0, K_A1 = 1, K_PX = 2, K_T0 = 3;
+constexpr int KF_SRC_A = 4;    // the walked row belongs to endpoint a (its value is pa, the looked-up one pb)
+constexpr int KF_SIDE_B = 8;   // a one-hop node emitted by this walk is a neighbour of b (flag bit 31 of the pair word)
+
+struct alignas(16) NodeRec {   // lpformer_amd/graph.py WalkIndex.rec: where node i's rows start in the index arrays
+    int64_t adj0, a10, px0, t00, u0;   // element offsets into adj_cv / a1_cv / px_cv / t0_cv; entry offset into u_cv
+    int32_t deg, n_a1, n_px, n_t0, u_nb, pad;
+};
+static_assert(sizeof(NodeRec) == 64, "one 64-byte record per node");
+
+struct alignas(16) Walk3 {
+    const int2 *src;     // {node, value bits} entries of the walked row
+    int64_t u0;          // first entry of the looked-up endpoint's U row
+    int32_t unb;         // ... and its bucket count
+    int32_t start;       // slot (inside the pair) at which this walk starts
+    int32_t kind;        // K_* | KF_*
+    int32_t len;
+};
+struct alignas(16) PairDesc3 {
+    Walk3 w[3];
+    int32_t total, a, b, pad[5];
+};
+static_assert(sizeof(Walk3) == 32 && sizeof(PairDesc3) == 128, "descriptor is one 128-byte line");
+
+// fl32((fl32(fl32(p*t)+t)-t)/t) for t in {1,2}: p*1, p*2, x/1 and x/2 are exact, only the add and subtract round
+__device__ __forceinline__ float s3_rt1(float p) { return __fsub_rn(__fadd_rn(p, 1.0f), 1.0f); }
+__device__ __forceinline__ float s3_rt2(float p) { return 0.5f * __fsub_rn(__fadd_rn(p * 2.0f, 2.0f), 2.0f); }
+
+// ------------------------------------------------------------------------------------------- plan
+struct PlanArgs {
+    int64_t bs;
+    const int64_t *batch;
+    int64_t batch_ld, n_nodes;
+    const NodeRec *rec;
+    const int2 *adj_cv, *a1_cv, *px_cv, *t0_cv;   // t0_cv NULL: no >1-hop walk (modes "1-hop", "cn")
+    int32_t mode_cn, use_px;
+    PairDesc3 *desc;
+    int64_t *offs;
+    int32_t *item_pair;
+    int64_t item_cap;
+    int64_t *ctl;
+    uint64_t *plan_lb;
+};
+
+__global__ __launch_bounds__(S3_THREADS) void select3_plan_kernel(const PlanArgs A) {
+    __shared__ int64_t wtot[S3_WAVES];
+    __shared__ int64_t s_base, s_blk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Logical block index = order of arrival (a block only ever waits for blocks that are already running); ctl[7]
+    // only ever grows and every launch on this control block draws exactly gridDim.x tickets, so ticket / gridDim.x is
+    // the launch number that tags the chained-scan words of this launch (see select2.hip, same control block layout).
+    if (tid == 0) s_blk = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 7), 1ull);
+    __syncthreads();
+    const int64_t blk = s_blk % (int64_t)gridDim.x;
+    const uint32_t epoch = (uint32_t)((s_blk / (int64_t)gridDim.x) & ((1 << 22) - 1));
+    const int64_t k = blk * S3_THREADS + tid;
+    int64_t ub = 0;
+    if (k < A.bs) {
+        const int64_t a = A.batch[k], b = A.batch[A.batch_ld + k];
+        PairDesc3 d;
+        __builtin_memset(&d, 0, sizeof(d));
+        if ((uint64_t)a >= (uint64_t)A.n_nodes || (uint64_t)b >= (uint64_t)A.n_nodes) {
+            atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + 3), (unsigned long long)LPF_SELECT_ERR_NODE_RANGE);
+        } else {
+            NodeRec r[2];
+            __builtin_memcpy(&r[0], A.rec + a, sizeof(NodeRec));
+            __builtin_memcpy(&r[1], A.rec + b, sizeof(NodeRec));
+            const int s = r[0].deg <= r[1].deg ? 0 : 1;   // the endpoint whose whole adjacency row is walked
+            int start = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                 // walk e: the nodes that are neighbours of endpoint e
+                const int o = 1 - e;
+                Walk3 &w = d.w[e];
+                const int side = e == 1 ? KF_SIDE_B : 0;
+                if (e == s) {          // common neighbours + this side's one-hop nodes
+                    w.src = A.adj_cv + r[e].adj0; w.len = r[e].deg; w.u0 = r[o].u0; w.unb = r[o].u_nb;
+                    w.kind = K_FULL | (e == 0 ? KF_SRC_A : 0) | side;
+                } else if (A.mode_cn) {
+                    w.len = 0;
+                } else if (A.use_px && r[o].n_px < r[e].n_a1) {   // walk the other endpoint's strong non-neighbours
+                    w.src = A.px_cv + r[o].px0; w.len = r[o].n_px; w.u0 = r[e].u0; w.unb = r[e].u_nb;
+                    w.kind = K_PX | (o == 0 ? KF_SRC_A : 0) | side;
+                } else {                                          // walk this endpoint's strong neighbours
+                    w.src = A.a1_cv + r[e].a10; w.len = r[e].n_a1; w.u0 = r[o].u0; w.unb = r[o].u_nb;
+                    w.kind = K_A1 | (e == 0 ? KF_SRC_A : 0) | side;
+                }
+                w.start = start;
+                start += w.len;
+            }
+            Walk3 &w = d.w[2];
+            w.start = start;
+            if (A.t0_cv) {
+                const int e = r[0].n_t0 <= r[1].n_t0 ? 0 : 1, o = 1 - e;
+                w.src = A.t0_cv + r[e].t00; w.len = r[e].n_t0; w.u0 = r[o].u0; w.unb = r[o].u_nb;
+                w.kind = K_T0 | (e == 0 ? KF_SRC_A : 0);
+                start += w.len;
+            }
+            d.total = start;
+            d.a = (int32_t)a; d.b = (int32_t)b;
+        }
+        ub = d.total < S3_MIN_SLOTS ? S3_MIN_SLOTS : d.total;
+        __builtin_memcpy(A.desc + k, &d, sizeof(PairDesc3));
+    }
+    // inclusive scan of ub inside the block, then the block's base through the chained scan
+    int64_t x = ub;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int64_t y = __shfl_up(x, dlt, 64);
+        if (lane >= dlt) x += y;
+    }
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    int64_t pre = 0, btot = 0;
+#pragma unroll
+    for (int w = 0; w < S3_WAVES; ++w) {
+        if (w < wave) pre += wtot[w];
+        btot += wtot[w];
+    }
+    if (wave == 0) {
+        const int64_t base = (int64_t)lb_exclusive(A.plan_lb, blk, epoch, (uint64_t)btot, lane);
+        if (lane == 0) s_base = base;
+    }
+    __syncthreads();
+    const int64_t o = s_base + pre + x - ub;  // exclusive
+    if (k < A.bs) {
+        A.offs[k] = o;
+        // first pair of every item that starts inside this pair's slots
+        for (int64_t it = (o + S3_ITEM - 1) / S3_ITEM; it * S3_ITEM < o + ub; ++it) {
+            if (it < A.item_cap) A.item_pair[it] = (int32_t)k;
+            else atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + 3), (unsigned long long)LPF_SELECT_ERR_ITEM_CAP);
+        }
+        if (k == A.bs - 1) {
+            const int64_t total = o + ub;
+            A.offs[A.bs] = total;
+            A.ctl[0] = total;
+            A.ctl[1] = (total + S3_ITEM - 1) / S3_ITEM;
+            A.ctl[2] = 0;  // ticket counter of the run kernel (stream order: the previous run kernel has finished)
+            A.ctl[8] = epoch;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- run
+struct RunArgs3 {
+    int64_t bs;
+    const PairDesc3 *desc;
+    const int64_t *offs;
+    const int32_t *item_pair;
+    int64_t item_cap;
+    int64_t *ctl;
+    uint64_t *run_lb;   // [3][item_cap]
+    const int2 *u_cv;   // the hashed union index: buckets of 8 {node, value bits | adjacent << 31}
+    float th_cn, th_1, th_n;
+    int32_t mode_cn;
+    int32_t *type_ptr;  // [3][bs+1]
+    int4 *entries;      // [3][ent_cap]
+    int64_t ent_cap;
+};
+
+struct RunLds3 {
+    int4 pk[S3_ITEM];             // parked entries: type 0 | type 1 | type 2, each in slot order
+    PairDesc3 dsc[S3_PAIRS];      // descriptors of the window pairs (one coalesced copy per item)
+    int32_t loc[S3_PAIRS + 1];    // slot (relative to the item) at which window pair i starts (pair 0: <= 0)
+    uint32_t bits[2 * S3_GROUPS]; // bit l: a window pair (other than the first) starts in slot l
+    int32_t pre[S3_GROUPS];       // window pairs that start before group g (beyond the first)
+    int32_t cnt[S3_GROUPS][4];    // kept entries per type of group g, then their exclusive scan
+    int64_t base[3];
+    int64_t ticket;
+    int32_t n_pairs;
+    int32_t run[3];               // kept entries per type of the item being built
+    // the parked item: what its deferred write-out needs once the window belongs to the next item
+    int64_t p_item, p_pf;
+    int32_t p_run[3], p_np, p_last, p_live;
+    int16_t ps[S3_PAIRS][4];      // {rank of the pair's first slot per type, pair starts in the item}
+};
+static_assert(sizeof(RunLds3) <= 32 * 1024, "five workgroups per CU");
+
+// Entries of the parked item from L.pk to their final place, the segment starts of the pairs that begin in it and,
+// from the last item, the totals.  L.base holds the item's place per type.
+__device__ __forceinline__ void s3_write_out(const RunArgs3 &A, RunLds3 &L, int64_t bs, int tid) {
+    const int r0 = L.p_run[0], r1 = L.p_run[1], r2 = L.p_run[2];
+    const int64_t b0 = L.base[0], b1 = L.base[1], b2 = L.base[2];
+    const int n = r0 + r1 + r2;
+    for (int g = tid; g < n; g += S3_THREADS) {
+        const int t = g < r0 ? 0 : (g < r0 + r1 ? 1 : 2);
+        const int64_t dst = t == 0 ? b0 + g : (t == 1 ? b1 + (g - r0) : b2 + (g - r0 - r1));
+        if (dst < A.ent_cap) {
+            A.entries[(int64_t)t * A.ent_cap + dst] = L.pk[g];
+        } else {
+            atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + 3), (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
+        }
+    }
+    if (tid < L.p_np && L.ps[tid][3]) {
+        const int64_t p = L.p_pf + tid;
+        A.type_ptr[p] = (int32_t)(b0 + L.ps[tid][0]);
+        A.type_ptr[(bs + 1) + p] = (int32_t)(b1 + L.ps[tid][1]);
+        A.type_ptr[2 * (bs + 1) + p] = (int32_t)(b2 + L.ps[tid][2]);
+    }
+    if (tid == 0 && L.p_last) {
+        const int64_t t0 = b0 + r0, t1 = b1 + r1, t2 = b2 + r2;
+        A.type_ptr[bs] = (int32_t)t0;
+        A.type_ptr[(bs + 1) + bs] = (int32_t)t1;
+        A.type_ptr[2 * (bs + 1) + bs] = (int32_t)t2;
+        A.ctl[4] = t0; A.ctl[5] = t1; A.ctl[6] = t2;
+    }
+}
+
+// Write-out of the parked item, if there is one (whole workgroup; barriers at both ends).
+__device__ __forceinline__ void s3_finish_parked(const RunArgs3 &A, RunLds3 &L, uint32_t epoch, int64_t bs, int lane,
+                                                 int wave, int tid) {
+    __syncthreads();
+    if (L.p_live) {
+        if (wave < 3) {
+            const int64_t base = (int64_t)lb_lookback(A.run_lb + (int64_t)wave * A.item_cap, L.p_item, epoch,
+                                                      (uint64_t)L.p_run[wave], lane);
+            if (lane == 0) L.base[wave] = base;
+        }
+        __syncthreads();
+        s3_write_out(A, L, bs, tid);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(S3_THREADS, 5) void select3_run_kernel(const RunArgs3 A) {
+    __shared__ RunLds3 L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const int64_t total = A.ctl[0];
+    int64_t n_items = A.ctl[1];
+    if (n_items > A.item_cap) n_items = A.item_cap;
+    const int64_t bs = A.bs;
+    const uint32_t epoch = (uint32_t)A.ctl[8];  // launch number, written by the plan kernel
+    if (tid == 0) L.p_live = 0;
+
+    while (true) {
+        __syncthreads();  // the previous item's window is no longer needed
+        if (tid == 0) L.ticket = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 2), 1ull);
+        if (tid < 2 * S3_GROUPS) L.bits[tid] = 0u;
+        __syncthreads();
+        const int64_t it = L.ticket;
+        if (it >= n_items) break;
+        const int64_t c0 = it * S3_ITEM;
+        const int n_here = (int)((total - c0) < S3_ITEM ? (total - c0) : S3_ITEM);
+        const int64_t pf = A.item_pair[it];
+
+        // ---- pair window: loc[i] = offs[pf + i] - c0, pairs past the item read n_here; a pair other than the first
+        //      raises the bit of the slot it starts in (every pair owns >= S3_MIN_SLOTS slots: at most S3_PAIRS pairs,
+        //      no two in one slot)
+        if (tid < 128) {
+            int64_t v = n_here;
+            if (tid <= S3_PAIRS && pf + tid <= bs) v = A.offs[pf + tid] - c0;
+            if (v > n_here) v = n_here;
+            if (tid <= S3_PAIRS) L.loc[tid] = (int32_t)v;
+            const bool in = tid <= S3_PAIRS && v < n_here;
+            if (in && tid > 0) atomicOr(&L.bits[v >> 5], 1u << (v & 31));
+            const int cntp = __popcll(__ballot(in));
+            if (lane == 0) L.pre[wave] = cntp;       // (scratch: two partial counts)
+        }
+        __syncthreads();
+        const int np = L.pre[0] + L.pre[1];  // pairs with at least one slot in this item (>= 1)
+        __syncthreads();
+        if (tid < S3_GROUPS) {               // exclusive popcount scan over the 64-slot groups
+            int s = 0;
+            for (int g = 0; g < tid; ++g) s += __popc(L.bits[2 * g]) + __popc(L.bits[2 * g + 1]);
+            L.pre[tid] = s;
+        }
+        {   // descriptors of the window pairs -> LDS (one coalesced copy; every slot reads its pair's walk from there)
+            const int n4 = np * 8;
+            const int4 *src = reinterpret_cast<const int4 *>(A.desc + pf);
+            int4 *dst = reinterpret_cast<int4 *>(L.dsc);
+            for (int i = tid; i < n4; i += S3_THREADS) dst[i] = src[i];
+        }
+        __syncthreads();
+
+        // ---- typing: one slot per thread and round; everything a kept slot needs later stays in registers
+        int code[S3_ROUNDS], node[S3_ROUNDS], win[S3_ROUNDS];
+        float va[S3_ROUNDS], vb[S3_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < S3_ROUNDS; ++r) {
+            const int g = S3_WAVES * r + wave;          // the wavefront's 64-slot group
+            const int l = 64 * g + lane;
+            code[r] = 0; node[r] = 0; win[r] = 0; va[r] = 0.f; vb[r] = 0.f;
+            if (l < n_here) {
+                // window pair of slot l = pairs that start at or before it
+                const uint32_t blo = L.bits[2 * g], bhi = L.bits[2 * g + 1];
+                const uint64_t bm = ((uint64_t)bhi << 32) | blo;
+                const int w = L.pre[g] + __popcll(bm & lt_mask) + (int)((bm >> lane) & 1ull);
+                const PairDesc3 &d = L.dsc[w];
+                const int i = l - L.loc[w];
+                if (i < d.total) {
+                    const int k = (i >= d.w[1].start) + (i >= d.w[2].start);
+                    const Walk3 wk = d.w[k];
+                    const int2 cv = wk.src[i - wk.start];
+                    const int32_t x = cv.x;
+                    const float ws = __int_as_float(cv.y);
+                    // what is x to the other endpoint?  one bucket of its hashed union row
+                    bool found = false;
+                    int bitsv = 0;
+                    if (wk.unb > 0) {
+                        const uint32_t b = __umulhi((uint32_t)x * S3_HASH_MUL, (uint32_t)wk.unb);
+                        const int4 *blk = reinterpret_cast<const int4 *>(A.u_cv + wk.u0 + S3_BUCKET * (int64_t)b);
+                        int4 bv[S3_BUCKET / 2];
+#pragma unroll
+                        for (int q = 0; q < S3_BUCKET / 2; ++q) bv[q] = blk[q];
+#pragma unroll
+                        for (int q = 0; q < S3_BUCKET / 2; ++q) {
+                            if (bv[q].x == x) { found = true; bitsv = bv[q].y; }
+                            if (bv[q].z == x) { found = true; bitsv = bv[q].w; }
+                        }
+                    }
+                    const bool adj = found && bitsv < 0;                     // sign bit: x is adjacent to that endpoint
+                    const float lv = __int_as_float(bitsv & 0x7fffffff);     // its PPR value (0: nothing stored)
+                    const int kind = wk.kind & 3;
+                    const bool cn = kind == K_FULL && adj;
+                    const bool hop = kind == K_FULL ? !adj : (kind == K_A1 ? !adj : (kind == K_PX ? adj : false));
+                    const bool far = kind == K_T0 && found && !adj;
+                    // the reference's round trips (t = 2 for a common neighbour, 1 otherwise; mode "cn": 1)
+                    const bool two = cn && !A.mode_cn;
+                    const float rs = two ? s3_rt2(ws) : s3_rt1(ws);
+                    const float rl = two ? s3_rt2(lv) : s3_rt1(lv);
+                    int c = 0;
+                    if (cn) c = (rs >= A.th_cn && rl >= A.th_cn) ? 1 : 0;
+                    else if (hop) c = (!A.mode_cn && rs >= A.th_1 && rl >= A.th_1) ? 2 : 0;
+                    else if (far) c = (ws > 0.f && lv > 0.f && rs >= A.th_n && rl >= A.th_n) ? 3 : 0;
+                    const bool src_a = wk.kind & KF_SRC_A;
+                    code[r] = c | ((c == 2 && (wk.kind & KF_SIDE_B)) ? 4 : 0);
+                    node[r] = x;
+                    va[r] = src_a ? rs : rl;
+                    vb[r] = src_a ? rl : rs;
+                }
+                win[r] = w;
+            }
+            const int c3 = code[r] & 3;
+            const uint64_t b0 = __ballot(c3 == 1), b1 = __ballot(c3 == 2), b2 = __ballot(c3 == 3);
+            if (lane == 0) {
+                int32_t *c = L.cnt[g];
+                c[0] = __popcll(b0); c[1] = __popcll(b1); c[2] = __popcll(b2);
+            }
+        }
+        __syncthreads();
+
+        // ---- ranks inside the item; the item's totals go out to the chained scan at once
+        if (wave < 3) {  // wavefront t: exclusive scan of type t over the groups in slot order
+            const int v = lane < S3_GROUPS ? L.cnt[lane][wave] : 0;
+            int x = v;
+#pragma unroll
+            for (int dlt = 1; dlt < S3_GROUPS; dlt <<= 1) {
+                const int y = __shfl_up(x, dlt, 64);
+                if (lane >= dlt) x += y;
+            }
+            if (lane < S3_GROUPS) L.cnt[lane][wave] = x - v;
+            const int run = __shfl(x, S3_GROUPS - 1, 64);
+            if (lane == 0) L.run[wave] = run;
+            lb_publish(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)run, lane);
+        }
+        // ---- deferred write-out: the item's place in the output depends on every earlier item, and the slowest of the
+        //      ones in flight decides when that is known.  So the kept entries are parked in LDS, the workgroup went on
+        //      to type this item first, and only now asks for the PREVIOUS item's place (by now an answer that needs
+        //      no waiting) and writes it out.
+        s3_finish_parked(A, L, epoch, bs, lane, wave, tid);  // (starts and ends with a barrier)
+        const int run0 = L.run[0], run1 = L.run[1];
+        if (tid == 0) {
+            L.p_item = it; L.p_pf = pf; L.p_np = np; L.p_last = (c0 + n_here == total);
+            L.p_run[0] = run0; L.p_run[1] = run1; L.p_run[2] = L.run[2];
+            L.p_live = 1;
+        }
+        if (tid < S3_PAIRS) L.ps[tid][3] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < S3_ROUNDS; ++r) {
+            const int g = S3_WAVES * r + wave;
+            const int l = 64 * g + lane;
+            const int c3 = code[r] & 3;
+            const uint64_t b0 = __ballot(c3 == 1), b1 = __ballot(c3 == 2), b2 = __ballot(c3 == 3);
+            if (l >= n_here) continue;
+            const int32_t *gp = L.cnt[g];
+            const int k0 = gp[0] + __popcll(b0 & lt_mask);
+            const int k1 = gp[1] + __popcll(b1 & lt_mask);
+            const int k2 = gp[2] + __popcll(b2 & lt_mask);
+            const int w = win[r];
+            if (c3) {
+                const int pos = c3 == 1 ? k0 : (c3 == 2 ? run0 + k1 : run0 + run1 + k2);
+                L.pk[pos] = make_int4((int32_t)((uint32_t)(pf + w) | ((code[r] & 4) ? S3_FROM_B : 0u)), node[r],
+                                      __float_as_int(va[r]), __float_as_int(vb[r]));
+            }
+            if (l == L.loc[w]) {  // first slot of the pair: its three segment starts
+                L.ps[w][0] = (int16_t)k0; L.ps[w][1] = (int16_t)k1; L.ps[w][2] = (int16_t)k2; L.ps[w][3] = 1;
+            }
+        }
+    }
+    s3_finish_parked(A, L, epoch, bs, lane, wave, tid);
+}
+
+}  // namespace
+
+/* ---- C ABI ---------------------------------------------------------------------------------------------------- */
+extern "C" int lpf_select3_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
+                                const void *adj_cv, const void *a1_cv, const void *px_cv, const void *t0_cv,
+                                int32_t mode_cn, int32_t use_px, void *desc, int64_t *offs, int32_t *item_pair,
+                                int64_t item_cap, int64_t *ctl, uint64_t *plan_lb, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && batch && batch_ld >= bs && n_nodes > 0 && node_rec && adj_cv && a1_cv &&
+                (px_cv || !use_px) && desc && offs && item_pair && item_cap > 0 && ctl && plan_lb &&
+                lpf_aligned16(desc) && lpf_aligned16(node_rec));
+    const int64_t nb = (bs + S3_THREADS - 1) / S3_THREADS;
+    if (nb > 2048) return LPF_ERR_UNSUPPORTED;  // the chained scan wants every block resident: split larger batches
+    PlanArgs a;
+    a.bs = bs; a.batch = batch; a.batch_ld = batch_ld; a.n_nodes = n_nodes;
+    a.rec = static_cast<const NodeRec *>(node_rec);
+    a.adj_cv = static_cast<const int2 *>(adj_cv); a.a1_cv = static_cast<const int2 *>(a1_cv);
+    a.px_cv = static_cast<const int2 *>(px_cv); a.t0_cv = static_cast<const int2 *>(t0_cv);
+    a.mode_cn = mode_cn; a.use_px = use_px;
+    a.desc = static_cast<PairDesc3 *>(desc); a.offs = offs; a.item_pair = item_pair; a.item_cap = item_cap;
+    a.ctl = ctl; a.plan_lb = plan_lb;
+    hipLaunchKernelGGL(select3_plan_kernel, dim3((unsigned)nb), dim3(S3_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+extern "C" int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair,
+                               int64_t item_cap, int64_t *ctl, uint64_t *run_lb, const void *u_cv, float th_cn,
+                               float th_1hop, float th_non1hop, int32_t mode_cn, int32_t *type_ptr, void *entries,
+                               int64_t ent_cap, int32_t grid_blocks, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && u_cv && type_ptr && entries &&
+                ent_cap > 0 && lpf_aligned16(entries) && lpf_aligned16(desc) && lpf_aligned16(u_cv));
+    RunArgs3 a;
+    a.bs = bs; a.desc = static_cast<const PairDesc3 *>(desc); a.offs = offs; a.item_pair = item_pair;
+    a.item_cap = item_cap; a.ctl = ctl; a.run_lb = run_lb; a.u_cv = static_cast<const int2 *>(u_cv);
+    a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop; a.mode_cn = mode_cn;
+    a.type_ptr = type_ptr; a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
+    // one resident round of workgroups (they are persistent; more than fit only queue up behind the others)
+    static int resident = 0;
+    if (resident == 0) {
+        int dev = 0, occ = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, select3_run_kernel, S3_THREADS, 0) != hipSuccess || occ < 1)
+            occ = 4;
+        resident = prop.multiProcessorCount * occ;
+    }
+    int64_t blocks = grid_blocks > 0 ? grid_blocks : resident;
+    if (blocks > item_cap) blocks = item_cap;
+    hipLaunchKernelGGL(select3_run_kernel, dim3((unsigned)blocks), dim3(S3_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -307,7 +307,8 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
                 tailv = *reinterpret_cast<const f32x4 *>(A.tail + mm * A.ldtail);
             } else {  // get_structure_cnts (link_transformer.py:340-356): n_cn, n_1hop, [n_non1hop,] n_cn + n_1hop
                 const float n0 = (float)seg_cnt[0], n1 = (float)seg_cnt[1], n2 = (float)seg_cnt[2];
-                tailv = A.n_counts == 4 ? (f32x4){n0, n1, n2, n0 + n1} : (f32x4){n0, n1, n0 + n1, 0.f};
+                tailv = A.n_counts == 4 ? (f32x4){n0, n1, n2, n0 + n1}
+                                         : (A.n_counts == 3 ? (f32x4){n0, n1, n0 + n1, 0.f} : (f32x4){n0, 0.f, 0.f, 0.f});
             }
         }
 #pragma unroll
@@ -438,7 +439,7 @@ extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, 
     if (M == 0) return LPF_OK;
     LPF_REQUIRE(M > 0 && part && bnd && units_cap > 0 && lpf_aligned16(bnd) && type_ptr && att_bias && lnA_g && lnA_b && wB_packed && bB && lnB_g && lnB_b && r_e &&
                 wC_packed && bC && w_dot && b_dot && (logit || prob));
-    LPF_REQUIRE((n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D);
+    LPF_REQUIRE((n_counts == 1 || n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D);
     LPF_REQUIRE(lpf_aligned16(part) && lpf_aligned16(att_bias) && lpf_aligned16(r_e) && lpf_aligned16(wB_packed) &&
                 lpf_aligned16(wC_packed) && lpf_aligned16(lnA_g) && lpf_aligned16(lnA_b) && lpf_aligned16(bB) &&
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
@@ -465,7 +466,7 @@ extern "C" int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts,
     LPF_REQUIRE(M > 0 && part && bnd && units_cap > 0 && lpf_aligned16(bnd) && type_ptr && att_bias && lnA_g && lnA_b &&
                 wB_packed_bf16 && bB && lnB_g && lnB_b && r_e && wC_packed_bf16 && bC && w_dot && b_dot &&
                 (logit || prob));
-    LPF_REQUIRE((n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D);
+    LPF_REQUIRE((n_counts == 1 || n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D);
     LPF_REQUIRE(lpf_aligned16(part) && lpf_aligned16(att_bias) && lpf_aligned16(r_e) && lpf_aligned16(wB_packed_bf16) &&
                 lpf_aligned16(wC_packed_bf16) && lpf_aligned16(lnA_g) && lpf_aligned16(lnA_b) && lpf_aligned16(bB) &&
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));

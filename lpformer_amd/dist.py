@@ -110,16 +110,25 @@ def measure_allgather_gbps(n: int, d: int, device, reps: int = 3, group=None) ->
     return n * d * 4 / dt / 1e9
 
 
-def encoder_plan(encoder_ms_one_gpu: float, n: int, d: int, n_layers: int, world: int, allgather_gbps: float) -> dict:
-    """Cost model for the encoder on ``world`` GPUs (all times in ms):
-         replicated: every rank runs the whole encoder            = encoder_ms_one_gpu
-         sharded:    1/world of the work + (L + 1) all-gathers of an [n, d] fp32 matrix
-                                                                   = encoder_ms_one_gpu / world + (L + 1) * bytes / rate
-    Returns both estimates and the cheaper mode.  The reference has no counterpart (single device)."""
+def encoder_plan(encoder_ms_one_gpu: float, n: int, d: int, n_layers: int, world: int, allgather_gbps: float,
+                 last_agg_ms: float | None = None, node_keys_ms: float = 0.0) -> dict:
+    """Cost model for the encoder + the per-node attention projections (Z, Y) on ``world`` GPUs (all times in ms):
+         replicated:  every rank runs all of it, no exchange           = enc + keys
+         sharded:     1/world of every layer + (L + 1) all-gathers of an [n, d] fp32 matrix, Z / Y on every rank
+                                                                       = enc / world + (L + 1) * ag + keys
+         gather_once: layers 1..L-1 replicated, the last layer's aggregation and Z / Y on the rank's rows, ONE
+                      all-gather of [X | Z | Y] (3 d floats per node)  = enc - (1 - 1/world) * (last_agg + keys) + 3 * ag
+    ``last_agg_ms``: the last layer's aggregation (SpMM + epilogue) on one GPU (default: 0.7 * enc / L);
+    ``node_keys_ms``: the two N x D x D projections.  Returns the estimates and the cheapest mode.
+    The reference has no counterpart (single device)."""
+    if last_agg_ms is None:
+        last_agg_ms = 0.7 * encoder_ms_one_gpu / max(n_layers, 1)
+    repl = encoder_ms_one_gpu + node_keys_ms
     if world <= 1:
-        return {"mode": "replicated", "replicated_ms": encoder_ms_one_gpu, "sharded_ms": encoder_ms_one_gpu,
+        return {"mode": "replicated", "replicated_ms": repl, "sharded_ms": repl, "gather_once_ms": repl,
                 "allgather_ms": 0.0}
     ag_ms = n * d * 4 / (allgather_gbps * 1e9) * 1e3
-    sharded = encoder_ms_one_gpu / world + (n_layers + 1) * ag_ms
-    return {"mode": "sharded" if sharded < encoder_ms_one_gpu else "replicated",
-            "replicated_ms": encoder_ms_one_gpu, "sharded_ms": sharded, "allgather_ms": ag_ms}
+    sharded = encoder_ms_one_gpu / world + (n_layers + 1) * ag_ms + node_keys_ms
+    once = encoder_ms_one_gpu - (1.0 - 1.0 / world) * (last_agg_ms + node_keys_ms) + node_keys_ms + 3.0 * ag_ms
+    best = min((repl, "replicated"), (sharded, "sharded"), (once, "gather_once"))[1]
+    return {"mode": best, "replicated_ms": repl, "sharded_ms": sharded, "gather_once_ms": once, "allgather_ms": ag_ms}

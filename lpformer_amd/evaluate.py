@@ -46,10 +46,28 @@ def score_edges(model, score_func, edges, batch_size: int = 32768, *, h: Optiona
     lanes = model.lanes(max(1, min(streams, (total + batch_size - 1) // batch_size)))  # persistent: workspaces are per stream
     for s in lanes:
         s.wait_stream(main)  # h, batch and out are ready
+    jobs = [[] for _ in lanes]
     for i, lo in enumerate(range(0, total, batch_size)):
         hi = min(lo + batch_size, total)
+        jobs[i % len(lanes)].append((lo, hi))
         with torch.cuda.stream(lanes[i % len(lanes)]):
             out[lo:hi] = model.score_pairs(batch[:, lo:hi], h, score_func, test_set=test_set, logits=logits)
+    # The selection of a batch is sized from EARLIER batches of its lane and nothing is read back while the sweep is
+    # queued: a batch that outgrows its workspace (hub-heavy negatives after a sparse start) comes back as NaN and
+    # leaves a sticky status on the lane.  Read every lane's status once, at the end, and score the batches of a lane
+    # that reports an overflow again, one at a time with the status checked after each (the first of them re-sizes
+    # the workspace) -- never a NaN, or a silently wrong metric, out of this function.
+    for lane, lane_jobs in zip(lanes, jobs):
+        if model.check_selection(lane):
+            continue
+        with torch.cuda.stream(lane):
+            for lo, hi in lane_jobs:
+                for _attempt in range(4):
+                    out[lo:hi] = model.score_pairs(batch[:, lo:hi], h, score_func, test_set=test_set, logits=logits)
+                    if model.check_selection(lane):
+                        break
+                else:
+                    raise RuntimeError("score_edges: the selection workspace could not be sized")
     for s in lanes:
         main.wait_stream(s)
     return out

@@ -373,3 +373,119 @@ def self_ppr_device(adj: DeviceCSR, ppr: DeviceCSR) -> torch.Tensor:
                                        _lib.ptr(ppr.col), _lib.ptr(ppr.val), _lib.ptr(out),
                                        torch.cuda.current_stream(dev).cuda_stream), "lpf_self_ppr")
     return out[:adj.nnz]
+
+
+# ------------------------------------------------------------------------------------------------ walk indexes
+@dataclass
+class WalkIndex:
+    """Per-model indexes of the walk-plan selection (csrc/select3.hip, include/lpformer_hip.h ``lpf_select3_*``), built
+    once per (adjacency, PPR matrix, thresholds).  All "cv" arrays are int32 [entries, 2] = {node, fp32 value bits}.
+
+    * ``adj_cv``  adjacency rows with the PPR of the row's node to that neighbour (0 where nothing is stored);
+    * ``a1_cv``   the adjacency entries whose own value passes the one-hop test ``fl32(fl32(p+1)-1) >= theta_1``;
+    * ``px_cv``   PPR entries (i, v) with v NOT adjacent to i that pass the weaker of the one-hop / >1-hop tests;
+    * ``t0_cv``   the px entries that pass the >1-hop test (``p > 0`` and round trip ``>= theta_n``), None without them;
+    * ``u``       hashed union of adjacency row and px row (``HashedIndex``), the sign bit of a value = "adjacent";
+    * ``rec``     int32 [n, 16]: one 64-byte record per node with the five row starts (int64) and the five lengths.
+    """
+    rec: torch.Tensor
+    adj_cv: torch.Tensor
+    a1_cv: torch.Tensor
+    px_cv: torch.Tensor
+    t0_cv: Optional[torch.Tensor]
+    u: "HashedIndex"
+    n: int
+    use_px: bool
+
+    def lengths(self):
+        """(deg, n_a1, n_px, n_t0, u_buckets) as int32 [n] views of ``rec`` (statistics, tests)."""
+        return tuple(self.rec[:, 10 + i] for i in range(5))
+
+
+def _csr_rows(rowptr: torch.Tensor, n: int) -> torch.Tensor:
+    return torch.repeat_interleave(torch.arange(n, device=rowptr.device), rowptr[1:] - rowptr[:-1])
+
+
+def _round_trip1(v: torch.Tensor) -> torch.Tensor:
+    """fl32(fl32(v + 1) - 1): the reference's round trip for t = 1 (src/models/link_transformer.py:290-291,316-317 and
+    :464-476), two separately rounded fp32 operations."""
+    one = torch.ones((), dtype=torch.float32, device=v.device)
+    return (v + one) - one
+
+
+def _cv(col: torch.Tensor, bits: torch.Tensor) -> torch.Tensor:
+    out = torch.stack([col.to(torch.int32), bits.view(torch.int32) if bits.dtype == torch.float32 else bits], dim=1)
+    if out.shape[0] == 0:  # (the kernels want non-null pointers)
+        out = torch.zeros((1, 2), dtype=torch.int32, device=col.device)
+    return out.contiguous()
+
+
+def build_walk_index(adj, ppr, th_1hop: float, th_non1hop: float, want_t0: bool) -> WalkIndex:
+    """Builds the ``WalkIndex`` of an adjacency (``rowptr``, ``col``, ``n``; sorted, duplicate-free) and a PPR matrix
+    (``rowptr``, ``col``, ``val``) that live on one device -- a few sorts / searches in torch, one-time.  Works on CPU
+    tensors too (tests)."""
+    dev, n = adj.rowptr.device, adj.n
+    f32 = torch.float32
+    deg = adj.rowptr[1:] - adj.rowptr[:-1]
+    nnz_a, nnz_p = int(adj.rowptr[-1].item()), int(ppr.rowptr[-1].item())
+    akey = _csr_rows(adj.rowptr, n) * n + adj.col[:nnz_a].long()          # ascending: rows, columns inside rows
+    prow = _csr_rows(ppr.rowptr, n)
+    pkey = prow * n + ppr.col[:nnz_p].long()
+    pval = ppr.val[:nnz_p].to(f32)
+
+    def member(sorted_keys, query):
+        """(hit mask, position) of ``query`` in ``sorted_keys``."""
+        if sorted_keys.numel() == 0 or query.numel() == 0:
+            z = torch.zeros(query.numel(), dtype=torch.long, device=dev)
+            return torch.zeros(query.numel(), dtype=torch.bool, device=dev), z
+        pos = torch.searchsorted(sorted_keys, query).clamp_(max=sorted_keys.numel() - 1)
+        return sorted_keys[pos] == query, pos
+
+    # self PPR of every adjacency entry
+    selfp = torch.zeros(nnz_a, dtype=f32, device=dev)
+    hit, pos = member(pkey, akey)
+    selfp[hit] = pval[pos[hit]]
+    t1 = torch.tensor(float(th_1hop), dtype=f32, device=dev)
+    tn = torch.tensor(float(th_non1hop), dtype=f32, device=dev)
+    strong = _round_trip1(selfp) >= t1
+    # px: PPR entries passing the weaker test, not adjacent
+    rt = _round_trip1(pval)
+    keep = rt >= (torch.minimum(t1, tn) if want_t0 else t1)
+    pk, pv = pkey[keep], pval[keep]
+    is_adj, _ = member(akey, pk)
+    px_key, px_val = pk[~is_adj], pv[~is_adj]
+    px_row = torch.div(px_key, n, rounding_mode="floor")
+    px_col = px_key - px_row * n
+    far = (px_val > 0) & (_round_trip1(px_val) >= tn) if want_t0 else None
+
+    def starts(lens):
+        return torch.cumsum(lens, 0) - lens
+
+    arow = _csr_rows(adj.rowptr, n)
+    n_a1 = torch.bincount(arow[strong], minlength=n)
+    n_px = torch.bincount(px_row, minlength=n)
+    n_t0 = torch.bincount(px_row[far], minlength=n) if want_t0 else torch.zeros(n, dtype=torch.long, device=dev)
+    # hashed union: adjacency entries (sign bit set) + px entries, merged in key order
+    sign = torch.tensor(-2**31, dtype=torch.int32, device=dev)
+    ukey = torch.cat([akey, px_key])
+    ubits = torch.cat([selfp.view(torch.int32) | sign, px_val.view(torch.int32)])
+    order = torch.argsort(ukey)
+    ukey, ubits = ukey[order], ubits[order]
+    urow = torch.div(ukey, n, rounding_mode="floor")
+    u_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.bincount(urow, minlength=n), 0, out=u_rowptr[1:])
+    u = hash_index_device(DeviceCSR(u_rowptr, (ukey - urow * n).to(torch.int32), ubits.view(f32), n, None))
+
+    rec64 = torch.zeros((n, 8), dtype=torch.int64, device=dev)
+    rec64[:, 0] = adj.rowptr[:-1]
+    rec64[:, 1] = starts(n_a1)
+    rec64[:, 2] = starts(n_px)
+    rec64[:, 3] = starts(n_t0)
+    rec64[:, 4] = u.rowptr[:-1]
+    rec = rec64.view(torch.int32)                      # [n, 16]; little endian: int64 field f = columns 2f, 2f+1
+    for i, lens in enumerate((deg, n_a1, n_px, n_t0, u.len)):
+        rec[:, 10 + i] = lens.to(torch.int32)
+    return WalkIndex(rec=rec.contiguous(), adj_cv=_cv(adj.col[:nnz_a], selfp),
+                     a1_cv=_cv(adj.col[:nnz_a][strong], selfp[strong]), px_cv=_cv(px_col, px_val),
+                     t0_cv=_cv(px_col[far], px_val[far]) if want_t0 else None, u=u, n=n,
+                     use_px=float(th_1hop) > 0.0)

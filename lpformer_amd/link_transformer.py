@@ -516,7 +516,6 @@ class LinkTransformer(nn.Module):
         # forward() in eval mode keeps the encoder output while none of its inputs has changed (_propagate_reusing)
         self.reuse_encoder_output = True
         self._enc_cache = None
-        self._unchecked_selection = False
         # "f32" or "bf16": in bf16 the two GEMMs of the dense tail (first layer of pairwise_lin, folded score head) run
         # on the bf16 matrix cores with bf16 weights and activations rounded to bf16 (fp32 accumulate; record merge,
         # LayerNorms, dot product and sigmoid stay fp32); logits within 5e-3 of fp32 (observed <= 1e-3).
@@ -524,9 +523,6 @@ class LinkTransformer(nn.Module):
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self, train_ok: bool = False):
-        if self.mask == "cn":
-            raise NotImplementedError("mask mode 'cn' (thresh_1hop == thresh_non1hop == 1) is unspecified: the "
-                                      "reference itself crashes in this mode on torch >= 2.1")
         if self.num_layers != 1 or self.train_args["num_heads"] != 1:
             raise NotImplementedError("the HIP path covers trans_layers=1, num_heads=1 (every shipped script); the "
                                       "reference is shape-inconsistent for heads>1 with layers>1")
@@ -633,7 +629,7 @@ class LinkTransformer(nn.Module):
         if self._folded is not None and self._folded[0] == key:
             return self._folded[1]
         sd = {k: v for k, v in self.state_dict().items()}
-        n_types = 3 if self.mask == "all" else 2
+        n_types = {"all": 3, "1-hop": 2, "cn": 1}[self.mask]
         out = fold.fold_attention(sd, self.dim, n_types)
         out["pe_tab"], out["pe_stat"] = fold.pe_tables(sd, self.dim, n_types)
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
@@ -661,6 +657,29 @@ class LinkTransformer(nn.Module):
                     if _layers_out is not None:
                         _layers_out.append(x)
                     x = self._layer_aggregate(i, a_hat, self._layer_transform(i, x), 0, self.num_nodes, x)
+            elif self.encoder_mode == "gather_once":
+                # BASELINE.json's literal layout -- "a single RCCL all-gather of node embeddings after the encoder":
+                # layers 1..L-1 run on every rank (no exchange), the LAST layer's aggregation + epilogue and the two
+                # per-node projections of the attention (Z, Y: _node_keys) run on the rank's row block only, and ONE
+                # all-gather of [X_node | Z | Y] rows (3 D floats per node) hands every rank all three tables.  The
+                # last layer's X W^T stays replicated: a row's aggregation reads the transformed rows of all its
+                # neighbours, and keeping the GEMM whole keeps every element bitwise equal to the unsharded encoder.
+                x = self._features()
+                for i in range(n_layers - 1):
+                    x = self._layer_aggregate(i, a_hat, self._layer_transform(i, x), 0, self.num_nodes, x)
+                lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
+                last = n_layers - 1
+                x_rows = self._layer_aggregate(last, a_hat, self._layer_transform(last, x), lo, hi, x[lo:hi])
+                w = self._fold()
+                d = self.dim
+                pack = torch.empty(hi - lo, 3 * d, dtype=torch.float32, device=self.device)
+                pack[:, :d] = x_rows
+                gemm(x_rows, w["w_rx"], w["b_r"], out=pack[:, d:2 * d], tag="gemm_node_keys")
+                gemm(x_rows, w["w_l"], w["b_l"], out=pack[:, 2 * d:], tag="gemm_node_keys")
+                full = lpf_dist.allgather_rows(pack, self.num_nodes)      # the all-gather of node embeddings
+                x = full[:, :d]
+                torch.cuda.current_stream(self.device).synchronize()      # other streams read Z, Y (as _node_keys)
+                self._z_cache = (weakref.ref(x), x._version, full[:, d:2 * d], full[:, 2 * d:])
             else:
                 lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
                 x = self._features()[lo:hi]                      # the rank's rows of the layer input
@@ -729,12 +748,14 @@ class LinkTransformer(nn.Module):
 
     def set_row_shard(self, rank: int, world: int, mode: str = "sharded"):
         """This process is rank ``rank`` of ``world`` (default process group, lpformer_amd/dist.py).  ``mode``:
-        "sharded" = row-sharded encoder with an all-gather per layer, "replicated" = every rank runs the whole encoder
-        (no exchange; pays when the encoder is cheaper than L all-gathers -- ``lpformer_amd.dist.encoder_plan``)."""
+        "sharded" = row-sharded encoder with an all-gather per layer (L + 1 collectives), "replicated" = every rank runs
+        the whole encoder (no exchange), "gather_once" = layers 1..L-1 replicated, the last layer's aggregation and the
+        per-node attention projections row-sharded, ONE all-gather of [X_node | Z | Y]
+        (``lpformer_amd.dist.encoder_plan`` prices the three)."""
         if not (0 <= rank < world):
             raise ValueError("need 0 <= rank < world")
-        if mode not in ("sharded", "replicated"):
-            raise ValueError("mode must be 'sharded' or 'replicated'")
+        if mode not in ("sharded", "replicated", "gather_once"):
+            raise ValueError("mode must be 'sharded', 'replicated' or 'gather_once'")
         self._shard = (rank, world)
         self.encoder_mode = mode
 
@@ -774,10 +795,25 @@ class LinkTransformer(nn.Module):
         return ws
 
     def _select_launch(self, ws, batch, graphs):
-        """The two selection launches (lpf_select_plan, lpf_select_run) on the current stream; no host sync."""
+        """The two selection launches on the current stream; no host sync.  ``graphs`` is a ``graph.WalkIndex`` (the
+        evaluation path, lpf_select3_*) or the tuple of the general path (adjacency override: lpf_select_plan / _run
+        over the raw PPR rows)."""
         lib, st = _lib.hip(), _stream(self.device)
-        adj, adjx, val, t0, selfp = graphs
         bs = batch.shape[1]
+        if isinstance(graphs, graph.WalkIndex):
+            wi, cn = graphs, 1 if self.mask == "cn" else 0
+            with KernelTimer.span("select_plan"):
+                check(lib.lpf_select3_plan(bs, ptr(batch), batch.stride(0), self.num_nodes, ptr(wi.rec), ptr(wi.adj_cv),
+                                           ptr(wi.a1_cv), ptr(wi.px_cv), ptr(wi.t0_cv), cn, 1 if wi.use_px else 0,
+                                           ptr(ws.desc), ptr(ws.offs), ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl),
+                                           ptr(ws.plan_lb), st), "lpf_select3_plan")
+            with KernelTimer.span("select_run"):
+                check(lib.lpf_select3_run(bs, ptr(ws.desc), ptr(ws.offs), ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl),
+                                          ptr(ws.run_lb), ptr(wi.u.cv), float(self.thresh_cn), float(self.thresh_1hop),
+                                          float(self.thresh_non1hop), cn, ptr(ws.type_ptr), ptr(ws.entries),
+                                          ws.ent_cap, 0, st), "lpf_select3_run")
+            return
+        adj, adjx, val, t0, selfp = graphs
         with KernelTimer.span("select_plan"):
             check(lib.lpf_select_plan(bs, ptr(batch), batch.stride(0), self.num_nodes, ptr(adj.rowptr),
                                       ptr(val.rowptr), ptr(t0.rowptr) if t0 is not None else None,
@@ -798,20 +834,32 @@ class LinkTransformer(nn.Module):
                                      float(self.thresh_1hop), float(self.thresh_non1hop), ptr(ws.type_ptr),
                                      ptr(ws.entries), ws.ent_cap, 0, st), "lpf_select_run")
 
+    def _walk_index(self, mask_obj, ppr_obj) -> graph.WalkIndex:
+        """The per-model indexes of the walk-plan selection for this (adjacency, PPR matrix) pair of ``self.data``,
+        built on the device on first use and kept with the graphs."""
+        key = ("walk", id(mask_obj), id(ppr_obj))
+        hit = self._graphs.get(key)
+        if hit is None or hit[0] is not mask_obj or hit[1] is not ppr_obj:
+            wi = graph.build_walk_index(self._device_graph("mask", mask_obj), self._device_graph("ppr", ppr_obj),
+                                        self.thresh_1hop, self.thresh_non1hop, want_t0=self.mask == "all")
+            hit = self._graphs[key] = (mask_obj, ppr_obj, wi)
+        return hit[2]
+
     def _select_graphs(self, test_set: bool, adj_mask=None):
-        """(typing adjacency, unmasked adjacency, value rows, T0 rows or None, self-PPR or None) on the device."""
+        """What the selection launches read.  Evaluation (the typing adjacency is the model's own): the walk indexes
+        (``graph.WalkIndex``).  A caller-supplied adjacency override (training) or ``use_select_index = False``: the
+        tuple (typing adjacency, unmasked adjacency, raw PPR rows, T0 rows or None, None) of the general path."""
         ppr_obj, mask_obj = self._data_obj("ppr", test_set), self._data_obj("mask", test_set)
+        if adj_mask is None and self.use_select_index:
+            return self._walk_index(mask_obj, ppr_obj)
+        if self.mask == "cn":
+            raise NotImplementedError("mask mode 'cn' runs on the walk indexes only (no adjacency override, "
+                                      "use_select_index = True)")
         ppr = self._device_graph("ppr", ppr_obj)
         adjx = self._device_graph("mask", mask_obj)
         adj = adjx if adj_mask is None else self._device_graph("mask", adj_mask)
         t0 = self._device_graph("t0", ppr_obj) if self.mask == "all" else None
-        # Evaluation fast path: per-model indexes over the PPR matrix (self PPR aligned with the adjacency, one-hop
-        # prefiltered rows).  A caller-supplied adjacency override (training) looks values up in the raw PPR rows.
-        selfp, val = None, ppr
-        if adj is adjx and self.use_select_index:
-            selfp = self._self_ppr(mask_obj, ppr_obj, adjx, ppr)
-            val = self._device_graph("p1", ppr_obj)
-        return adj, adjx, val, t0, selfp
+        return adj, adjx, ppr, t0, None
 
     def _select_device(self, batch: torch.Tensor, test_set: bool, adj_mask=None) -> "_SelectWorkspace":
         """Selection for the hot path: the result stays in the stream's workspace (per-type entry regions + int32
@@ -870,7 +918,6 @@ class LinkTransformer(nn.Module):
         arrays (type-major entries sorted by (pair, node), int64 segment pointers, float count features)."""
         lib, st = _lib.hip(), _stream(self.device)
         bs = batch.shape[1]
-        want_t0 = self.mask == "all"
         ldf = _pad4(self.dim + self.count_dim)
         feats = torch.empty(bs, ldf, dtype=torch.float32, device=self.device)  # [att out | counts | pad]
         if ldf > self.dim + self.count_dim:
@@ -900,7 +947,7 @@ class LinkTransformer(nn.Module):
         sel_pb = self._workspace("sel_pb", cap, torch.float32, st)
         with KernelTimer.span("select_export"):
             check(lib.lpf_select_export(bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(type_ptr),
-                                        feats.data_ptr() + 4 * self.dim, ldf, 1 if want_t0 else 0, ptr(sel_pair),
+                                        feats.data_ptr() + 4 * self.dim, ldf, self.count_dim, ptr(sel_pair),
                                         ptr(sel_node), ptr(sel_pa), ptr(sel_pb), st), "lpf_select_export")
         return {"bs": bs, "cap": max(cap, 1), "type_ptr": type_ptr, "sel_pair": sel_pair, "sel_node": sel_node,
                 "sel_pa": sel_pa, "sel_pb": sel_pb, "feats": feats, "ldf": ldf}
@@ -918,7 +965,8 @@ class LinkTransformer(nn.Module):
     @_on_device
     def compute_node_mask(self, batch, test_set=False, adj=None):
         """Reference-format selection result (:214-276): three tuples (ix int64 [2,n], ppr_src, ppr_tgt) for CN,
-        1-hop and >1-hop nodes (None for >1-hop in "1-hop" mode), each sorted by (pair position, node)."""
+        1-hop and >1-hop nodes (None for >1-hop in "1-hop" mode, for both in "cn" mode), each sorted by (pair
+        position, node)."""
         self._check_supported()
         with torch.no_grad():
             batch = self._prep_batch(batch)
@@ -928,8 +976,8 @@ class LinkTransformer(nn.Module):
             tot = tp[:, bs].tolist()
             out, base = [], 0
             for t in range(3):
-                if t == 2 and self.mask != "all":
-                    out.append(None)
+                if (t == 2 and self.mask != "all") or (t == 1 and self.mask == "cn"):
+                    out.append(None)   # (mode "1-hop": no >1-hop tuple; mode "cn": common neighbours only, :271-274)
                     continue
                 sl = slice(base, base + tot[t])
                 ix = torch.stack([s["sel_pair"][sl].long(), s["sel_node"][sl].long()])
@@ -998,9 +1046,10 @@ class LinkTransformer(nn.Module):
 
     def _pair_attention(self, batch, x_node, test_set, adj_mask, return_weights, stop_after_gather=False):
         """Selection -> PE + attention (+ post-norm) -> count features.  Returns (feats [BS, ld] = [attention output |
-        counts | pad], att_weights or None); the caller applies ``pairwise_lin`` (or its folded first layer).
-        ``stop_after_gather``: return (G [BS, 4D+4], feats) right after the softmax-gather instead (the attention
-        output projection then belongs to ``lpf_tail_chain_f32``)."""
+        counts | pad], att_weights or None, unchecked); the caller applies ``pairwise_lin`` (or its folded first
+        layer).  ``unchecked``: the selection ran without a read-back, so the caller owes a ``check_selection()``.
+        ``stop_after_gather``: return (G [BS, 4D+4], feats, False) right after the softmax-gather instead (the
+        attention output projection then belongs to ``lpf_tail_chain_f32``)."""
         with torch.no_grad():
             lib, st, d = _lib.hip(), _stream(self.device), self.dim
             bs = batch.shape[1]
@@ -1022,8 +1071,7 @@ class LinkTransformer(nn.Module):
                         ptr(layer.att.bias), ptr(layer.post_att_norm.weight), ptr(layer.post_att_norm.bias),
                         ptr(ws.ctl), ptr(feats), ld, st), "lpf_pair_attention_merge_f32")
                 self._last_att = feats[:, :d]
-                self._unchecked_selection = True   # (calc_pairwise reads the status back after queueing its own work)
-                return feats, None
+                return feats, None, True   # (unchecked: calc_pairwise reads the status back after queueing its own work)
             w = self._fold()
             z, y = self._node_keys(x_node, w)
 
@@ -1055,7 +1103,7 @@ class LinkTransformer(nn.Module):
                       "lpf_pair_softmax_gather_f32")
             feats = s["feats"]
             if stop_after_gather:
-                return g, feats
+                return g, feats, False
             att_view = feats[:, :d]
             layer = self.att_layers[0]
             # sum_e alpha_e k_e + bias, then post_att_norm: one launch (or GEMM + LayerNorm for unbuilt shapes)
@@ -1069,7 +1117,7 @@ class LinkTransformer(nn.Module):
                 tp = s["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)
                 total = int(tp[:, bs].sum().item())
                 att_weights = torch.stack((s["sel_pair"][:total].float(), alpha[:total]))
-            return feats, att_weights
+            return feats, att_weights, False   # (_select read the status back already)
 
     @_on_device
     def calc_pairwise(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False, _out=None):
@@ -1079,17 +1127,19 @@ class LinkTransformer(nn.Module):
         _require_gpu(X_node, "calc_pairwise")
         with torch.no_grad():
             batch = self._prep_batch(batch)
-            for _attempt in range(2):
-                self._unchecked_selection = False
-                feats, att_weights = self._pair_attention(batch, _as_f32_rows(X_node), test_set, adj_mask,
-                                                          return_weights)
+            for _attempt in range(3):
+                feats, att_weights, unchecked = self._pair_attention(batch, _as_f32_rows(X_node), test_set, adj_mask,
+                                                                     return_weights)
                 out = self.pairwise_lin.run(feats[:, :self.dim + self.count_dim], out=_out)
                 # The callers of this API are the reference's loops: they fetch the predictions of every batch right
                 # away and never heard of check_selection().  So the status of the read-back-free selection is read
                 # here, AFTER this call's own launches are queued (the wait is the one the caller's .cpu() would pay),
                 # and a batch that overflowed its workspace is simply run again on the re-sized one.
-                if not self._unchecked_selection or self.check_selection():
+                # (node ids out of range raise IndexError from check_selection; `_out` then holds NaN rows)
+                if not unchecked or self.check_selection():
                     break
+            else:
+                raise _lib.LpfError("calc_pairwise: the selection workspace could not be sized")
             return out, att_weights
 
     # ---------------------------------------------------------------------------------- folded score path
@@ -1193,7 +1243,7 @@ class LinkTransformer(nn.Module):
                         st), "lpf_tail_chain_merge")
                 return res
             if d in (32, 64, 128) and self.use_tail_chain:  # attention output + pairwise hidden + head: one launch
-                g, feats = self._pair_attention(batch, x_node, test_set, adj_mask, False, stop_after_gather=True)
+                g, feats, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False, stop_after_gather=True)
                 tt = self._tail_tables(score_func, a, c)
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):
@@ -1204,7 +1254,7 @@ class LinkTransformer(nn.Module):
                         ptr(tt["b_dot"]), ptr(res) if logits else None, None if logits else ptr(res),
                         _stream(self.device)), "lpf_tail_chain_f32")
                 return res
-            feats, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False)  # joins the side stream
+            feats, _, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False)  # joins the side stream
             xin = feats[:, :pd]
             t = pw._chain1.tables(pw.linears[0].weight, pw.linears[0].bias, pw.norm.weight, pw.norm.bias)
             if pw._chain1.run(t, xin, relu=True, out=r[:, d:d + pd]) is None:

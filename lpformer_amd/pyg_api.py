@@ -71,7 +71,14 @@ class LPFormer(nn.Module):
     def forward(self, batch: torch.Tensor, x: torch.Tensor, edge_index: torch.Tensor, ppr_matrix) -> torch.Tensor:
         """Logits [BS] for the candidate pairs ``batch`` [2, BS]."""
         self._bind(x, edge_index, ppr_matrix)
-        return self.core.score_pairs(batch, self.core.propagate(), self.score, logits=True)
+        h = self.core.propagate()
+        for _attempt in range(4):
+            out = self.core.score_pairs(batch, h, self.score, logits=True)
+            # the caller gets logits it will use right away: read the selection status here (a batch that outgrew the
+            # workspace sized from earlier batches would otherwise come back as NaN) and score it again if needed
+            if self.core.check_selection():
+                return out
+        raise RuntimeError("LPFormer.forward: the selection workspace could not be sized")
 
     def propagate(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         self._bind(x, edge_index, self.core.data.get("ppr"))

@@ -174,14 +174,14 @@ def select_nodes(batch, adj, ppr, thresholds, *, n, adj_unmasked=None):
     coalesced COO the reference reads them from.  Modes follow :39-44."""
     th_cn, th_1, th_n = thresholds
     mode = "cn" if (th_n == 1 and th_1 == 1) else ("1-hop" if (th_n == 1 and th_1 < 1) else "all")
-    if mode == "cn":
-        raise NotImplementedError("mode 'cn' crashes in the reference under torch>=2.1 (SURVEY 8c); unspecified")
     batch = np.asarray(batch, dtype=np.int64)
     a, b = batch[0], batch[1]
     N = np.int64(n)
     a_rp, a_col = adj
     p_rp, p_col, p_val = ppr
     p_val = p_val.astype(F32)
+    if mode == "cn":
+        return {"cn": _select_cn_only(a, b, N, a_rp, a_col, p_rp, p_col, p_val, th_cn)}
 
     # union of the two adjacency rows with multiplicity t (sparse add, :237)
     pos_a, fl_a = _expand_rows(a_rp, a)
@@ -230,6 +230,32 @@ def select_nodes(batch, adj, ppr, thresholds, *, n, adj_unmasked=None):
     k = common[far][ok]
     out["non1hop"] = (np.stack([k // N, k % N]).astype(np.int64), sa[ok], sb[ok])
     return out
+
+
+def _select_cn_only(a, b, N, a_rp, a_col, p_rp, p_col, p_val, th_cn):
+    """Mask mode "cn" (thresh_1hop == thresh_non1hop == 1, src/models/link_transformer.py:39-44).  PARITY UNPINNED:
+    the reference crashes in this mode under torch >= 2.1 (sparse * sparse now keeps explicit zeros and the
+    work-around at :304-313 indexes with a mask of the wrong length), so no reference output can be recorded here;
+    this restates what the code computes on the torch versions it was written for.
+      pair_adj = src_adj * tgt_adj (:232-234): value 1 exactly at the common neighbours, nothing elsewhere;
+      get_ppr_vals with t = 1 everywhere (:290-291,316-317): pa = fl32(fl32(fl32(P[a,v]*1)+1)-1)/1, likewise pb
+        (P reads 0 where not stored);
+      node_type == 1 for every entry, so the filter is cn_filt_cond (:241-247): pa >= thresh_cn and pb >= thresh_cn;
+      returned as (pair_ix, src_ppr, tgt_ppr), None, None (:271-272), sorted by (pair position, node)."""
+    pos_a, fl_a = _expand_rows(a_rp, a)
+    pos_b, fl_b = _expand_rows(a_rp, b)
+    ka, kb = pos_a * N + a_col[fl_a], pos_b * N + a_col[fl_b]
+    ukeys = np.intersect1d(ka, kb)          # rows are duplicate-free: the intersection is the common neighbours
+    ppos_a, pfl_a = _expand_rows(p_rp, a)
+    ppos_b, pfl_b = _expand_rows(p_rp, b)
+    raw_a, _ = _lookup(ppos_a * N + p_col[pfl_a], p_val[pfl_a], ukeys)
+    raw_b, _ = _lookup(ppos_b * N + p_col[pfl_b], p_val[pfl_b], ukeys)
+    one = F32(1)
+    pa = (((raw_a * one + one) - one) / one).astype(F32)
+    pb = (((raw_b * one + one) - one) / one).astype(F32)
+    keep = (pa >= F32(th_cn)) & (pb >= F32(th_cn))
+    k = ukeys[keep]
+    return np.stack([k // N, k % N]).astype(np.int64), pa[keep], pb[keep]
 
 
 # =============================================================================== a9, a13: MLPs
@@ -288,6 +314,8 @@ def structure_counts(sel, bs):
             np.add.at(c, sel[tag][0][0], F32(1))
         return c
     n_cn, n_1 = cnt("cn"), cnt("onehop")
+    if "onehop" not in sel:  # mode "cn": the single count of get_count (:155)
+        return n_cn[:, None].astype(F32)
     cols = [n_cn, n_1]
     if "non1hop" in sel:
         cols.append(cnt("non1hop"))

@@ -88,6 +88,22 @@ def jitter_near(rng, val, thresholds, frac=0.25):
     return val
 
 
+def jitter_grid(rng, val, thresholds, frac=0.35):
+    """Move a fraction of the PPR values onto and around the points where the reference's round trip changes its mind:
+    fl32(fl32(p*t)+t) lives on a 2^-23 grid in p for t = 1 AND t = 2 (2p + 2 in [2, 4) has ulp 2^-22), so the values
+    theta + k 2^-23 and the ties theta + (k + 1/2) 2^-23, k = -6..6, decide `>= theta` one way or the other after
+    the round trip, where a plain `p >= theta` would not (link_transformer.py:241-250 with :290-291,316-317)."""
+    val = val.copy()
+    pick = np.nonzero((rng.random(val.size) < frac) & (val < 0.14))[0]
+    g = np.float64(2.0 ** -23)
+    for i in pick:
+        th = np.float64(np.float32(thresholds[rng.integers(0, len(thresholds))]))
+        k = int(rng.integers(-6, 7))
+        half = 0.5 if rng.random() < 0.4 else 0.0
+        val[i] = np.float32(max(th + (k + half) * g, 1e-9))
+    return val
+
+
 def make_pairs(rng, n, edge_index, bs, isolated):
     """Pair batch with a==b, existing edges (a~b), duplicates, isolated endpoints and random pairs."""
     e = edge_index[:, rng.integers(0, edge_index.shape[1], size=bs // 3)]
@@ -119,7 +135,9 @@ def build_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, 
 
     adj_t, adj_mask = adj_pack(edge_index, edge_w)
     pr, pc, pv = reference_ppr(edge_index, n, eps)
-    if jitter:
+    if jitter == "grid":
+        pv = jitter_grid(rng, pv, [t for t in (th_cn, th_1, th_n) if 0 < t < 1])
+    elif jitter:
         pv = jitter_near(rng, pv, [t for t in (th_1, th_n) if 0 < t < 1])
     ppr = torch.sparse_coo_tensor(torch.from_numpy(np.stack([pr, pc])), torch.from_numpy(pv), (n, n)).coalesce()
 
@@ -352,6 +370,10 @@ def main(only=()):
     # the training loop's masked-adjacency overrides (train_model.py:40-59), weighted graph, jittered PPR values
     build_case("lp_all_d64_maskedadj", 6, n=340, m=1000, f_in=32, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
                eps=1e-3, bs=180, weighted=True, power=0.4, n_isolated=4, jitter=True, masked=True)
+    # theta_cn > 0 (no shipped script sets it, the code path exists: link_transformer.py:241): the t = 2 round trip
+    # decides which common neighbours stay; PPR values placed on the 2^-23 grid points around all three thresholds
+    build_case("lp_all_d64_thcn", 11, n=300, m=1500, f_in=24, dim=64, gnn_layers=2, thresholds=(2e-3, 1e-3, 3e-3),
+               eps=1e-3, bs=192, power=0.5, n_isolated=4, jitter="grid")
     # one deterministic training step (all dropouts 0): loss + gradients of every parameter
     build_train_case("train_step_d64", 9, n=300, m=900, f_in=32, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
                      eps=1e-3, bs=96, weighted=True, power=0.4, n_isolated=3, mask_input=True)

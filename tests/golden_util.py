@@ -8,7 +8,7 @@ from oracle.fixture_weights import make_state
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 LP_CASES = ["lp_all_d64", "lp_all_d128_weighted", "lp_all_d64_residual_valtest", "lp_1hop_d64_dense",
-            "lp_all_d256_noln", "lp_all_d64_maskedadj"]
+            "lp_all_d256_noln", "lp_all_d64_maskedadj", "lp_all_d64_thcn"]
 MASKED_CASES = ["lp_all_d64_maskedadj"]  # also hold the training loop's adjacency-override calls (masked_* keys)
 PPR_CASES = ["ppr_push_small", "ppr_push_powerlaw"]
 

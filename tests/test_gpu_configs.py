@@ -268,6 +268,103 @@ def test_selection_overflow_is_flagged_and_recovered():
     assert torch.isfinite(out).all() and torch.equal(out, want)
 
 
+def _sparse_then_hub_edges(n, data, rng, n_sparse, n_dense, n_hubs=64):
+    deg = np.diff(data["adj_mask"].rowptr)
+    hubs = np.argsort(deg)[-n_hubs:]
+    sparse = rng.integers(0, n, size=(n_sparse, 2))
+    dense = np.stack([rng.choice(hubs, n_dense), rng.choice(hubs, n_dense)], axis=1)
+    return sparse, dense
+
+
+def test_sweep_with_late_hub_batches_is_finite_and_right():
+    """score_edges / score_negatives size a lane's selection workspace from its FIRST batch; later hub-heavy batches
+    overflow it.  The sweep must notice (sticky status per lane), score those batches again and return finite scores
+    equal to the per-batch loop -- and the ranking metrics computed from them must be the ones of the loop
+    (a NaN score would compare False in `neg >= pos` and silently improve every rank)."""
+    from lpformer_amd import evaluate as E
+    cfg, n, ei, w, x, data, args, model, score, _ = _setup("collab", scale=0.05, bs=1024)
+    h = model.propagate()
+    rng = np.random.default_rng(5)
+    sparse, dense = _sparse_then_hub_edges(n, data, rng, 4096, 6144)
+    edges = torch.from_numpy(np.concatenate([sparse, dense]))            # sparse batches first, hub batches after
+    for streams in (1, 3):
+        model._ws.clear()                                                 # fresh workspaces: sized from the sparse start
+        sweep = E.score_edges(model, score, edges, batch_size=1024, h=h, streams=streams)
+        assert torch.isfinite(sweep).all()
+        loop = torch.cat([score(model.pair_features(edges[i:i + 1024].t().contiguous().to(DEV), h))
+                          for i in range(0, edges.shape[0], 1024)])
+        assert (sweep - loop).abs().max().item() <= 2e-6
+        for lane in model.lanes(streams):
+            assert model.check_selection(lane)                            # nothing left pending
+    # HeaRT layout: positives with K negatives each, the hub-heavy negatives at the end of the flattened list
+    model._ws.clear()
+    pos = torch.from_numpy(sparse[:64])
+    neg = torch.from_numpy(np.concatenate([sparse[64:64 + 64 * 20], dense[:64 * 44]]).reshape(64, 64, 2))
+    sp = E.score_edges(model, score, pos, batch_size=64, h=h, streams=1)
+    sn = E.score_negatives(model, score, neg, batch_size=512, h=h, streams=2)
+    assert torch.isfinite(sn).all()
+    ref_n = torch.cat([score(model.pair_features(neg.reshape(-1, 2)[i:i + 512].t().contiguous().to(DEV), h))
+                       for i in range(0, 64 * 64, 512)]).view(64, 64)
+    got, want = E.ranking_metrics(sp, sn), E.ranking_metrics(sp, ref_n)
+    assert got == want or all(abs(got[k] - want[k]) <= 1e-6 for k in got)
+
+
+def test_graphed_scorer_survives_cache_replacement_staleness_and_overflow():
+    """The captured graph reads Z / Y / folded tables / workspaces through raw pointers: (a) scoring ANOTHER encoder
+    output through the model (second scorer, eager calls) must not disturb replays of the first; (b) a parameter
+    update is noticed and the graph captured again; (c) a batch that overflows the captured workspace is reported by
+    check() and right after the re-capture."""
+    cfg, n, ei, w, x, data, args, model, score, _ = _setup("collab", scale=0.05, bs=2048)
+    rng = np.random.default_rng(9)
+    sparse, dense = _sparse_then_hub_edges(n, data, rng, 2048, 2048)
+    b0 = torch.from_numpy(sparse.T.copy()).to(DEV)
+    b1 = torch.from_numpy(D.sample_pairs(ei, n, 2048, seed=3)).to(DEV)
+    bd = torch.from_numpy(dense.T.copy()).to(DEV)
+    h = model.propagate()
+    s1 = lpformer_amd.GraphedScorer(model, score, h, b1, logits=True)
+    want1 = model.score_pairs(b1, h, score, logits=True).clone()
+    # (a) another encoder output goes through the model's caches (Z / Y / bf16 copy replaced, workspaces reused)
+    x2 = data["x"].clone()
+    data["x"] = x2 * 1.5
+    model._x_cache = None
+    h2 = model.propagate()
+    s2 = lpformer_amd.GraphedScorer(model, score, h2, b1, logits=True)
+    for _ in range(3):
+        model.score_pairs(b0, h2, score)
+        torch.empty(64 << 20, device=DEV).fill_(1.0)        # churn the allocator: freed blocks get reused
+    torch.cuda.synchronize()
+    assert torch.equal(s1(b1), want1)
+    assert torch.equal(s2(b1), model.score_pairs(b1, h2, score, logits=True))
+    # (b) parameter update -> re-capture, new scores
+    caps = s1.captures
+    with torch.no_grad():
+        score.lins[1].bias.add_(0.25)
+    got = s1(b1).clone()
+    assert s1.captures == caps + 1
+    assert (got - (want1 + 0.25)).abs().max().item() <= 1e-5
+    # (c) overflow: workspace of s3 is sized from a sparse batch, the hub batch does not fit
+    s3 = lpformer_amd.GraphedScorer(model, score, h, b0, logits=True)
+    bad = s3(bd)
+    assert not s3.check() and torch.isnan(bad).all()
+    good = s3(bd).clone()
+    assert s3.check() and torch.isfinite(good).all()
+    assert torch.equal(good, model.score_pairs(bd, h, score, logits=True))
+
+
+def test_pyg_facade_recovers_from_selection_overflow():
+    cfg, n, ei, w, x, data, args, model, score, _ = _setup("collab", scale=0.05, bs=1024)
+    rng = np.random.default_rng(2)
+    sparse, dense = _sparse_then_hub_edges(n, data, rng, 1024, 1024)
+    m = lpformer_amd.LPFormer(cfg["f_in"], cfg["dim"], num_gnn_layers=cfg["gnn_layers"],
+                              ppr_thresholds=list(cfg["thresholds"]), device=DEV).to(DEV).eval()
+    xt, et = torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV)
+    a = m(torch.from_numpy(sparse.T.copy()).to(DEV), xt, et, data["ppr"])
+    b = m(torch.from_numpy(dense.T.copy()).to(DEV), xt, et, data["ppr"])       # overflows the workspace sized by `a`
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    m.core._ws.clear()
+    assert torch.equal(b, m(torch.from_numpy(dense.T.copy()).to(DEV), xt, et, data["ppr"]))
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_sharded_encoder_matches_unsharded(world):
     """The row-sharded encoder of every rank, emulated on one GPU (ragged N: not a multiple of the world size): per

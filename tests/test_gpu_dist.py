@@ -1,0 +1,42 @@
+"""The N > 1 encoder layouts under a real process group on the GPU box: WORLD ranks (child processes, backend gloo, all
+on the one MI355X of the box) run every layout of ``set_row_shard`` -- replicated, row-sharded with an all-gather per
+layer, and the single all-gather of [X_node | Z | Y] -- through ``propagate()`` and the pair stage and compare with the
+unsharded result bit for bit (tests/dist_gpu_worker.py).  RCCL over xGMI needs more than one GPU, which the build loop
+does not have; what this pins is everything around the collective: row blocks (even and ragged), the order of the
+per-layer exchanges, the Z / Y hand-over of the single-gather layout, pair shards."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,ragged", [(2, False), (3, True)])
+def test_encoder_layouts_under_a_process_group(world, ragged):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LPF_DIST_BACKEND="gloo", LPF_TEST_RAGGED="1" if ragged else "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)

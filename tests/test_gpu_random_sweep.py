@@ -1,4 +1,4 @@
-"""Seeded random sweep: HIP path vs the CPU oracle over model widths, modes, thresholds, hub-heavy graphs
+"""Seeded random sweep: HIP path vs the CPU oracle over model widths, mask modes ("all", "1-hop", "cn"), thresholds, hub-heavy graphs
 (degrees above the 512-candidate item size, PPR rows above the 256-entry LDS cap), weighted / residual encoders and
 batches with a == b, duplicate and isolated pairs.  Selection must be bit-exact through both selection kernels."""
 import numpy as np
@@ -24,6 +24,11 @@ CASES = [
     (5, 1200, 15000, 2.05, 128, 1, False, (0.0, 1e-5, 1e-3), 5e-5, True),  # long PPR rows, many >1-hop nodes
     (6, 300, 600, 2.5, 32, 2, True, (5e-2, 5e-2, 5e-2), 1e-3, False),     # high thresholds: mostly empty pairs
     (7, 800, 12000, 2.02, 256, 2, True, (0.0, 1e-4, 1e-2), 1e-4, True),
+    # mask mode "cn" (thresh_1hop == thresh_non1hop == 1, replicate_heart.sh:7,10): common neighbours only, t = 1 round
+    # trip, one count feature.  The reference crashes here on torch >= 2.1: HIP vs the oracle's restatement only.
+    (8, 700, 9000, 2.3, 64, 2, False, (0.0, 1.0, 1.0), 1e-4, False),
+    (9, 500, 12000, 2.6, 128, 1, False, (2e-3, 1.0, 1.0), 1e-4, True),
+    (10, 400, 8000, 3.0, 256, 1, False, (0.0, 1.0, 1.0), 1e-3, False),
 ]
 
 
@@ -62,8 +67,10 @@ def test_random_config_matches_oracle(case):
         batch[:, 6] = iso[:2]
     ref = O.forward(batch, x, O.gcn_norm(ei, w, n), O.symmetric_mask_csr(ei, n),
                     (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P, dict(cfg, pred_layers=2))
-    tags = ("cn", "onehop", "non1hop") if model.mask == "all" else ("cn", "onehop")
-    for indexed in (True, False):
+    tags = {"all": ("cn", "onehop", "non1hop"), "1-hop": ("cn", "onehop"), "cn": ("cn",)}[model.mask]
+    assert all(i is None for i in model.compute_node_mask(torch.from_numpy(batch))[len(tags):])
+    assert sum(ref["sel"][t][0].shape[1] for t in tags) > 100
+    for indexed in ((True, False) if model.mask != "cn" else (True,)):  # (mode "cn": walk indexes only)
         model.use_select_index = indexed
         infos = model.compute_node_mask(torch.from_numpy(batch))
         for tag, info in zip(tags, infos):

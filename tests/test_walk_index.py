@@ -1,0 +1,199 @@
+"""Host-side checks of the walk-plan selection (csrc/select3.hip) without a GPU: the index builder
+(``lpformer_amd.graph.build_walk_index``, plain torch, runs on CPU tensors) and a line-by-line Python emulation of the
+plan + run kernels' per-slot logic over those indexes, compared bit for bit with the oracle's ``select_nodes``
+(src/models/link_transformer.py:214-319, 434-481).  What this pins is the ALGEBRA of the path -- every selected set
+written as an intersection evaluated from its shorter side through the hashed union index -- on the cases where it could
+go wrong: a == b, adjacent endpoints, duplicates, isolated nodes, theta_1 <= 0 (absent PPR entries pass), theta_cn > 0,
+theta_n < theta_1, PPR values within a few ulp of the thresholds, mask modes "all", "1-hop" and "cn"."""
+import numpy as np
+import pytest
+import torch
+
+from lpformer_amd import graph
+from oracle import lpformer_oracle as O
+
+F32 = np.float32
+HASH_MUL = 2654435761
+K_FULL, K_A1, K_PX, K_T0 = 0, 1, 2, 3
+
+
+def _dev(c: graph.CSR) -> graph.DeviceCSR:
+    return graph.DeviceCSR(torch.from_numpy(c.rowptr), torch.from_numpy(c.col),
+                           None if c.val is None else torch.from_numpy(c.val), c.n, c)
+
+
+def _rt1(p):
+    return F32(F32(F32(p) + F32(1)) - F32(1))
+
+
+def _rt2(p):
+    return F32(F32(0.5) * F32(F32(F32(p) * F32(2) + F32(2)) - F32(2)))
+
+
+def emulate_select3(wi: graph.WalkIndex, batch, thresholds, mode):
+    """The plan kernel's walk choice and the run kernel's slot typing (select3.hip), one slot at a time."""
+    th_cn, th_1, th_n = (F32(t) for t in thresholds)
+    rec = wi.rec.numpy()
+    r64 = wi.rec.view(torch.int64).numpy()
+    cvs = {"adj": wi.adj_cv.numpy(), "a1": wi.a1_cv.numpy(), "px": wi.px_cv.numpy(),
+           "t0": None if wi.t0_cv is None else wi.t0_cv.numpy()}
+    ucv = wi.u.cv.numpy()
+    mode_cn = mode == "cn"
+    out = {1: [], 2: [], 3: []}
+
+    def node(i):
+        return dict(adj0=r64[i, 0], a10=r64[i, 1], px0=r64[i, 2], t00=r64[i, 3], u0=r64[i, 4], deg=rec[i, 10],
+                    n_a1=rec[i, 11], n_px=rec[i, 12], n_t0=rec[i, 13], unb=rec[i, 14])
+
+    def lookup(u0, unb, x):
+        if unb <= 0:
+            return False, False, F32(0)
+        b = ((int(x) * HASH_MUL % 2**32) * int(unb)) >> 32
+        blk = ucv[u0 + 8 * b: u0 + 8 * b + 8]
+        for c, v in blk:
+            if c == x:
+                bits = int(v) & 0xFFFFFFFF
+                return True, bool(bits >> 31), np.array([bits & 0x7FFFFFFF], np.uint32).view(F32)[0]
+        return False, False, F32(0)
+
+    for k in range(batch.shape[1]):
+        a, b = int(batch[0, k]), int(batch[1, k])
+        r = [node(a), node(b)]
+        s = 0 if r[0]["deg"] <= r[1]["deg"] else 1
+        walks = []
+        for e in (0, 1):
+            o = 1 - e
+            if e == s:
+                walks.append((K_FULL, "adj", r[e]["adj0"], r[e]["deg"], r[o], e == 0, e == 1))
+            elif mode_cn:
+                continue
+            elif wi.use_px and r[o]["n_px"] < r[e]["n_a1"]:
+                walks.append((K_PX, "px", r[o]["px0"], r[o]["n_px"], r[e], o == 0, e == 1))
+            else:
+                walks.append((K_A1, "a1", r[e]["a10"], r[e]["n_a1"], r[o], e == 0, e == 1))
+        if cvs["t0"] is not None:
+            e = 0 if r[0]["n_t0"] <= r[1]["n_t0"] else 1
+            walks.append((K_T0, "t0", r[e]["t00"], r[e]["n_t0"], r[1 - e], e == 0, False))
+        for kind, arr, src0, ln, look, src_a, side_b in walks:
+            for j in range(int(ln)):
+                x, bits = cvs[arr][src0 + j]
+                ws = np.array([bits], np.int32).view(F32)[0]
+                found, adj, lv = lookup(look["u0"], look["unb"], x)
+                cn = kind == K_FULL and adj
+                hop = (kind in (K_FULL, K_A1) and not adj) or (kind == K_PX and adj)
+                far = kind == K_T0 and found and not adj
+                two = cn and not mode_cn
+                rs, rl = (_rt2(ws), _rt2(lv)) if two else (_rt1(ws), _rt1(lv))
+                c = 0
+                if cn:
+                    c = 1 if (rs >= th_cn and rl >= th_cn) else 0
+                elif hop:
+                    c = 2 if (not mode_cn and rs >= th_1 and rl >= th_1) else 0
+                elif far:
+                    c = 3 if (ws > 0 and lv > 0 and rs >= th_n and rl >= th_n) else 0
+                if c:
+                    out[c].append((k, int(x), rs if src_a else rl, rl if src_a else rs, side_b))
+    res = {}
+    for c, tag in ((1, "cn"), (2, "onehop"), (3, "non1hop")):
+        ent = out[c]
+        if tag == "onehop":  # the export kernel merges the N(a) run and the N(b) run by node id
+            ent = sorted(ent, key=lambda t: (t[0], t[1]))
+        ix = np.array([[t[0] for t in ent], [t[1] for t in ent]], np.int64).reshape(2, -1)
+        res[tag] = (ix, np.array([t[2] for t in ent], F32), np.array([t[3] for t in ent], F32))
+    return res
+
+
+def _case(seed, n, m, thresholds, jitter=True):
+    rng = np.random.default_rng(seed)
+    ei = rng.integers(0, n, size=(2, m))
+    ei = ei[:, ei[0] != ei[1]]
+    ei = np.concatenate([ei, ei[::-1]], axis=1)
+    adj = graph.mask_csr(ei, n)
+    # a synthetic "PPR" matrix: diagonal 0.15+, neighbours and random far nodes, values clustered around the thresholds
+    rows, cols, vals = [], [], []
+    ths = [t for t in thresholds if 0 < t < 1] or [1e-2]
+    for i in range(n):
+        if i % 17 == 3:
+            continue  # a row with nothing stored at all
+        nb = adj.col[adj.rowptr[i]:adj.rowptr[i + 1]]
+        far = rng.integers(0, n, size=rng.integers(0, 12))
+        cs = np.unique(np.concatenate([[i], nb[rng.random(nb.size) < 0.8], far]))
+        v = rng.choice(ths, size=cs.size).astype(F32)
+        if jitter:  # +-6 ulp of fl32(1 + theta) => decides the round-tripped comparison
+            v = (v + (rng.integers(-6, 7, size=cs.size) * F32(2.0 ** -23)).astype(F32)).astype(F32)
+        v[rng.random(cs.size) < 0.3] *= F32(3.7)
+        v = np.abs(v)
+        v[cs == i] = F32(0.15) + rng.random(1).astype(F32)[0] * F32(0.2)
+        rows.append(np.full(cs.size, i)); cols.append(cs); vals.append(v)
+    ppr = graph.csr_from_coo(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), n)
+    bs = 160
+    batch = rng.integers(0, n, size=(2, bs))
+    batch[:, :8] = batch[0, :8]                       # a == b
+    k = min(20, ei.shape[1])
+    batch[:, 8:8 + k] = ei[:, rng.integers(0, ei.shape[1], size=k)]   # adjacent endpoints
+    batch[:, 30:34] = batch[:, 8:12]                  # duplicates
+    iso = np.setdiff1d(np.arange(n), np.unique(ei))[:4]
+    batch[0, 40:40 + iso.size] = iso                  # isolated endpoints
+    return adj, ppr, batch
+
+
+CASES = [
+    ("all", (0.0, 1e-3, 1e-2)), ("all", (1e-3, 1e-2, 1e-2)), ("all", (0.0, 1e-2, 1e-3)),   # theta_n < theta_1
+    ("all", (0.0, 0.0, 1e-2)), ("all", (2e-3, -1.0, 0.0)),                                    # theta_1 <= 0
+    ("1-hop", (0.0, 1e-2, 1.0)), ("1-hop", (1e-2, 0.0, 1.0)), ("cn", (0.0, 1.0, 1.0)), ("cn", (1e-2, 1.0, 1.0)),
+]
+
+
+@pytest.mark.parametrize("mode,thresholds", CASES)
+@pytest.mark.parametrize("seed", [0, 1])
+def test_walk_plan_matches_oracle(mode, thresholds, seed):
+    n = 220
+    adj, ppr, batch = _case(seed, n, 900 if seed else 500, thresholds)
+    wi = graph.build_walk_index(_dev(adj), _dev(ppr), thresholds[1], thresholds[2], want_t0=(mode == "all"))
+    got = emulate_select3(wi, batch, thresholds, mode)
+    ref = O.select_nodes(batch, (adj.rowptr, adj.col.astype(np.int64)),
+                         (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), thresholds, n=n)
+    for tag in ("cn", "onehop", "non1hop"):
+        if tag not in ref:
+            assert got[tag][0].shape[1] == 0
+            continue
+        assert np.array_equal(got[tag][0], ref[tag][0]), (mode, tag)
+        assert np.array_equal(got[tag][1].view(np.uint32), ref[tag][1].view(np.uint32)), (mode, tag, "pa")
+        assert np.array_equal(got[tag][2].view(np.uint32), ref[tag][2].view(np.uint32)), (mode, tag, "pb")
+    assert sum(ref[t][0].shape[1] for t in ref) > 10  # the case selects something
+
+
+def test_walk_index_layout():
+    """Every adjacency entry and every px entry is found in its hashed bucket with the right flag and value; a1 / px / t0
+    rows hold exactly the entries their definitions name."""
+    n, th = 150, (0.0, 1e-2, 2e-2)
+    adj, ppr, _ = _case(3, n, 600, th)
+    wi = graph.build_walk_index(_dev(adj), _dev(ppr), th[1], th[2], want_t0=True)
+    rec, r64, ucv = wi.rec.numpy(), wi.rec.view(torch.int64).numpy(), wi.u.cv.numpy()
+    selfp = graph.self_ppr(adj, ppr)
+    assert np.array_equal(wi.adj_cv.numpy()[:, 0], adj.col) and np.array_equal(wi.adj_cv.numpy()[:, 1].view(F32), selfp)
+    one = F32(1)
+    for i in range(n):
+        nb = adj.col[adj.rowptr[i]:adj.rowptr[i + 1]]
+        sp = selfp[adj.rowptr[i]:adj.rowptr[i + 1]]
+        strong = ((sp + one) - one) >= F32(th[1])
+        a1 = wi.a1_cv.numpy()[r64[i, 1]: r64[i, 1] + rec[i, 11]]
+        assert np.array_equal(a1[:, 0], nb[strong]) and np.array_equal(a1[:, 1].view(F32), sp[strong])
+        pc, pv = ppr.col[ppr.rowptr[i]:ppr.rowptr[i + 1]], ppr.val[ppr.rowptr[i]:ppr.rowptr[i + 1]]
+        keep = (((pv + one) - one) >= F32(min(th[1], th[2]))) & ~np.isin(pc, nb)
+        px = wi.px_cv.numpy()[r64[i, 2]: r64[i, 2] + rec[i, 12]]
+        assert np.array_equal(px[:, 0], pc[keep]) and np.array_equal(px[:, 1].view(F32), pv[keep])
+        far = keep & (pv > 0) & (((pv + one) - one) >= F32(th[2]))
+        t0 = wi.t0_cv.numpy()[r64[i, 3]: r64[i, 3] + rec[i, 13]]
+        assert np.array_equal(t0[:, 0], pc[far])
+        want = {int(c): (True, v) for c, v in zip(nb, sp)}
+        want.update({int(c): (False, v) for c, v in zip(pc[keep], pv[keep])})
+        row = ucv[r64[i, 4]: r64[i, 4] + 8 * rec[i, 14]]
+        live = row[row[:, 0] != 2**31 - 1]
+        assert live.shape[0] == len(want)
+        for c, bits in live:
+            b = ((int(c) * HASH_MUL % 2**32) * int(rec[i, 14])) >> 32
+            assert (row[8 * b: 8 * b + 8, 0] == c).sum() == 1          # in the bucket its hash names
+            flag, v = want[int(c)]
+            assert bool((int(bits) >> 31) & 1) == flag
+            assert np.array([int(bits) & 0x7FFFFFFF], np.uint32).view(F32)[0] == v
