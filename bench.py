@@ -157,7 +157,7 @@ def cpu_baseline(args, model, score, targs, data, batches_np, h, bs, dev):
     n_proc = max(1, args.cpu_procs or (os.cpu_count() or 1))
     n_take = min(args.cpu_sample or 1024 * n_proc, bs * len(batches_np))
     sample = np.ascontiguousarray(np.concatenate(batches_np, axis=1)[:, :n_take])
-    chunk = max(64, min(1024, n_take // (4 * n_proc) or 64))
+    chunk = max(64, min(1024, n_take // (2 * n_proc) or 64))
     P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
     ref_logit, cpu_s = run_cpu_workers(sample, h.cpu().numpy(), data["adj_mask"], data["ppr"], P,

@@ -179,7 +179,7 @@ def select_nodes(batch, adj, ppr, thresholds, *, n, adj_unmasked=None):
     N = np.int64(n)
     a_rp, a_col = adj
     p_rp, p_col, p_val = ppr
-    p_val = p_val.astype(F32)
+    p_val = np.asarray(p_val, dtype=F32)   # (no copy when it already is fp32: callers pass whole-graph arrays)
     if mode == "cn":
         return {"cn": _select_cn_only(a, b, N, a_rp, a_col, p_rp, p_col, p_val, th_cn)}
 

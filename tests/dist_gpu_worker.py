@@ -42,10 +42,12 @@ def main():
         if not torch.equal(h, want_x):
             bad.append(f"{mode}: encoder output differs by {(h - want_x).abs().max().item():.3e}")
         got = model.score_pairs(mine, h, score, logits=True)
-        if not model.check_selection() or not torch.equal(got, want_s[lo:hi]):
-            bad.append(f"{mode}: scores of this rank's pairs differ")
+        # (a sub-batch is not bitwise the full batch: the one-pass attention merges the pieces of a pair's segment in an
+        #  order that depends on where the segment falls in the tile grid -- DESIGN.md section 2 -- hence 2e-6)
+        if not model.check_selection() or (got - want_s[lo:hi]).abs().max().item() > 2e-6:
+            bad.append(f"{mode}: scores of this rank's pairs differ by {(got - want_s[lo:hi]).abs().max().item():.2e}")
         allsc = LD.gather_scores(got, batch.shape[1])
-        if not torch.equal(allsc, want_s):
+        if allsc.shape != want_s.shape or (allsc - want_s).abs().max().item() > 2e-6:
             bad.append(f"{mode}: gathered scores differ")
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
