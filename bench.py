@@ -351,7 +351,7 @@ def main():
     # ---- bf16 throughput mode (extra keys; the headline stays fp32 = the reference's precision): same steps with
     #      model.precision = "bf16" (bf16 storage of Z + bf16 matrix cores in the attention kernel)
     bf16 = None
-    if not args.no_bf16 and d in (32, 64, 128):
+    if not args.no_bf16 and d in (32, 64, 128, 256):
         model.precision = model.tail_precision = "bf16"
         for i in range(max(args.warmup, len(lanes))):
             step_on(i)

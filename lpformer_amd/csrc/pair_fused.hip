@@ -44,8 +44,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // wavefronts per workgroup sharing one LDS copy of Wfold_t = one workgroup per CU at the register budget of the tile
 // code (NT = 1: 88 VGPRs -> 4 waves per SIMD; NT = 2: 142 -> 3; NT = 4: ~200 -> 2 -- at 3 waves per SIMD it spills 82
 // registers to scratch, which cost more than half of the kernel's time); LDS: 16 NT KB of Z rows per wavefront
+// NT = 8 (D = 256): 128 accumulator registers + a prefetched weight group -> ~300 VGPRs, ONE wave per SIMD (4 per
+// workgroup), 32 KB of Z rows per wavefront.
 template <int NT>
-constexpr int pf_waves() { return NT == 1 ? 16 : (NT == 2 ? 12 : 8); }
+constexpr int pf_waves() { return NT == 1 ? 16 : (NT == 2 ? 12 : (NT == 4 ? 8 : 4)); }
 constexpr uint32_t PF_PAIR_MASK = 0x7fffffffu;
 
 struct FusedArgs {
@@ -134,7 +136,47 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &A, int t, int64_t id
     // (Letting the wavefronts of a SIMD take turns in the MFMA loop through an LDS token -- to keep one wave's
     // epilogue beside another's matrix loop -- measured slower: 203 vs 194 us.)
     PF_STAMP(1);
-    if constexpr (!BF16) {
+    if constexpr (!BF16 && NT == 8) {
+        // D = 256: ONE wavefront per SIMD, so nobody covers the L2 round trip of a weight group (8 x 16 bytes per lane
+        // and k-group).  The groups are double-buffered by hand: group k + 1 is requested before the 32 MFMAs of
+        // group k.  Written with inline assembly because hipcc 7.2 sinks a C++ prefetch back to its use (the
+        // load of the NEXT iteration's operands ends up at the top of that iteration, in front of an s_waitcnt: 138 k
+        // instead of 66 k clocks per tile); the waits are counted by hand -- vmcnt(8) = "everything but the eight
+        // newest requests has landed".  Older requests (the Z-row DMA, the records) are in front of them in the queue.
+        typedef float f32x4n __attribute__((ext_vector_type(4)));  // (a native vector: inline-asm register operand)
+        f32x4n w0[NT], w1[NT];
+        auto issue = [&](f32x4n (&w)[NT], int sq) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[c]) : "v"(wl + (PF_DBG(64) ? 0 : (c * NSQ + sq) * 64)) : "memory");
+        };
+        auto group = [&](f32x4n (&w)[NT], int sq) __attribute__((always_inline)) {
+            float h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h[u] = pe_hidden(tb[4 * sq + u], pa, pb, r_ab, r_ba);
+            // (the group's registers pass THROUGH the wait: nothing that reads them can be scheduled in front of it)
+            asm volatile("s_waitcnt vmcnt(8)"
+                         : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])
+                         :: "memory");
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[0], w[c][0], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[1], w[c][1], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[2], w[c][2], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[3], w[c][3], acc[c], 0, 0, 0);
+        };
+        issue(w0, 0);
+#pragma unroll 1
+        for (int sq = 0; sq < NSQ; sq += 2) {
+            issue(w1, sq + 1);
+            group(w0, sq);
+            issue(w0, sq + 2 < NSQ ? sq + 2 : sq);   // (the last one is a dummy: the count of requests in flight stays 8)
+            group(w1, sq + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (!BF16) {
 #pragma unroll 1
         for (int sq = 0; sq < (PF_DBG(4) ? 0 : NSQ); ++sq) {
             float4 wb[NT];  // (an explicit one-group-ahead prefetch of these measured slower: 198 vs 173 us)
@@ -430,7 +472,8 @@ int fused_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *ent
         case 32: LPF_FUSED(1); break;
         case 64: LPF_FUSED(2); break;
         case 128: LPF_FUSED(4); break;
-        default: return LPF_ERR_UNSUPPORTED;  // D = 256: the two-pass kernels
+        case 256: LPF_FUSED(8); break;
+        default: return LPF_ERR_UNSUPPORTED;
     }
 #undef LPF_FUSED
     // (the boundary records of segments that cross units are merged by the consumer, lpf_tail_chain_merge_f32, which

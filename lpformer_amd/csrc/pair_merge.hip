@@ -99,6 +99,7 @@ extern "C" int lpf_pair_attention_merge_f32(int64_t bs, int32_t D, int32_t n_cou
         case 32: LPF_MERGE(8); break;
         case 64: LPF_MERGE(16); break;
         case 128: LPF_MERGE(32); break;
+        case 256: LPF_MERGE(64); break;
         default: return LPF_ERR_UNSUPPORTED;
     }
 #undef LPF_MERGE

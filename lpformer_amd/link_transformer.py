@@ -506,7 +506,7 @@ class LinkTransformer(nn.Module):
         self.use_side_stream = True
         self._side = None
         self.use_tail_chain = True    # score_pairs: lpf_tail_chain_f32 instead of three dense-chain launches
-        self.use_fused_attention = True  # score_pairs: one-pass attention on the selection regions (D <= 128)
+        self.use_fused_attention = True  # one-pass attention on the selection regions
         # "f32" (parity mode, logits within 1e-4 of the reference) or "bf16" (throughput mode of score_pairs: the node
         # table Z is stored in bf16 and Wfold h runs on the bf16 matrix cores; selection and everything else as in f32)
         self.precision = "f32"
@@ -1053,7 +1053,7 @@ class LinkTransformer(nn.Module):
         with torch.no_grad():
             lib, st, d = _lib.hip(), _stream(self.device), self.dim
             bs = batch.shape[1]
-            if (d in (32, 64, 128) and self.use_fused_attention and not return_weights and not stop_after_gather
+            if (d in (32, 64, 128, 256) and self.use_fused_attention and not return_weights and not stop_after_gather
                     and bs > 0):
                 # one-pass attention on the selection regions, then the records merged straight into the feature
                 # rows [post_att_norm(attention output) | counts] -- no reference-layout export, nothing read back

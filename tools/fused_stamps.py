@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import lpformer_amd
 from lpformer_amd import data as D, _lib
-cfg = D.CONFIGS["collab"]
+cfg = D.CONFIGS[os.environ.get("LPF_CFG", "collab")]
 n, bs = cfg["n"], cfg["batch"]
 dev = torch.device("cuda:0")
 ei, w = D.chung_lu_graph(n, cfg["edges"], gamma=cfg["gamma"], seed=0, max_weight=cfg["max_weight"])
@@ -38,4 +38,4 @@ tot = (s[:, :, 5] - s[:, :, 0])[ok]
 print("tile total mean", tot.mean(), " between tiles (end -> next start):",
       np.mean([(s[w_, k + 1, 0] - s[w_, k, 5]) for w_ in range(512) for k in range(7) if ok[w_, k] and ok[w_, k + 1]]))
 print("wave 0 tile starts:", (s[0, :, 0] - s[0, 0, 0]).tolist())
-print("wave 4 tile starts:", (s[4, :, 0] - s[0, 0, 0]).tolist(), "(same SIMD as wave 0)")
+print("wave 4 tile starts:", (s[4, :, 0] - s[0, 0, 0]).tolist(), "(D <= 128: same SIMD as wave 0)")
