@@ -16,6 +16,16 @@ from . import graph
 from .ppr import calc_ppr, calc_ppr_gpu
 
 
+def to_undirected(edge_index, num_nodes: int) -> np.ndarray:
+    """PyG ``to_undirected`` for an unweighted edge list (what the reference applies to the validation edges,
+    src/util/read_datasets.py:98-99): both directions of every edge, then COALESCED -- duplicate and reciprocal input
+    pairs end up once per direction -- sorted by (row, col)."""
+    ei = np.asarray(edge_index, dtype=np.int64).reshape(2, -1)
+    row, col = np.concatenate([ei[0], ei[1]]), np.concatenate([ei[1], ei[0]])
+    key = np.unique(row * np.int64(num_nodes) + col)
+    return np.stack([key // num_nodes, key % num_nodes]).astype(np.int64)
+
+
 def build_data(edge_index, x, num_nodes: int, *, edge_weight=None, eps: float = 5e-5, alpha: float = 0.15,
                ppr: Optional[graph.CSR] = None, val_edge_index=None, ppr_test: Optional[graph.CSR] = None,
                ppr_threads: int = 0, ppr_device=None) -> dict:
@@ -37,8 +47,7 @@ def build_data(edge_index, x, num_nodes: int, *, edge_weight=None, eps: float = 
 
     data["ppr"] = ppr if ppr is not None else producer(ei)
     if val_edge_index is not None:
-        vei = np.asarray(val_edge_index, dtype=np.int64)
-        vei = np.concatenate([vei, vei[::-1]], axis=1)  # to_undirected
+        vei = to_undirected(val_edge_index, n)           # mirrored AND coalesced (read_datasets.py:98-99)
         full = np.concatenate([ei, vei], axis=1)
         fw = np.concatenate([np.ones(ei.shape[1], np.float32) if w is None else w, np.ones(vei.shape[1], np.float32)])
         data["full_adj_t"] = graph.csr_from_coo(full[0], full[1], fw, n)

@@ -311,7 +311,7 @@ class HashedIndex:
     counts start at one per four entries and grow for the rows where some bucket would hold more than 8, so a lookup
     never has to look further than its bucket.  ``rowptr`` counts ENTRIES (8 per bucket)."""
     rowptr: torch.Tensor   # int64 [n+1]
-    cv: torch.Tensor       # int32 [16 * buckets, 2]
+    cv: torch.Tensor       # int32 [HASH_BUCKET * buckets, 2] = 8 entries per bucket
     len: torch.Tensor      # int32 [n]: buckets per row
     n: int
 

@@ -153,7 +153,49 @@ def load_or_calc_ppr(edge_index, num_nodes: int, alpha: float = 0.15, eps: float
     return csr
 
 
-def get_ppr(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5) -> torch.Tensor:
-    """torch sparse COO PPR matrix, the object the reference stores in ``data['ppr']``
-    (calc_ppr_scores.py:245-270, minus the on-disk cache -- see ``load_or_calc_ppr``)."""
+def ppr_reference_cache_path(root_dir: str, dataset: str, alpha: float, eps: float, is_val: bool = False) -> str:
+    """Exactly the reference's cache file (calc_ppr_scores.py:249-257):
+    ``<root_dir>/node_subsets/ppr/<dataset>/sparse_adj-015_eps-5e-05[_val].pt``."""
+    import os
+    val_suf = "_val" if is_val else ""
+    name = f"sparse_adj-{str(alpha).replace('.', '')}_eps-{str(eps).replace('.', '')}{val_suf}.pt"
+    return os.path.join(root_dir, "node_subsets", "ppr", dataset, name)
+
+
+def get_ppr(dataset, edge_index, num_nodes, alpha, eps, is_val, *, root_dir=None, device=None,
+            num_threads: int = 0) -> torch.Tensor:
+    """Drop-in for the reference's ``get_ppr(dataset, edge_index, num_nodes, alpha, eps, is_val)``
+    (src/util/calc_ppr_scores.py:245-270): same six positional arguments, same cache directory and file NAME, same
+    return type (a coalesced torch sparse COO tensor, what ``read_datasets.py:122-129`` stores in ``data['ppr']``).
+
+    Cache: the reference ``torch.save``s a ``torch_sparse.SparseTensor`` at that path.  When ``torch_sparse`` is
+    importable such a file is read (a cache written by the reference is picked up) and written in that format; without
+    the package a ``.lpf.npz`` sibling with the same stem carries the CSR triplet (``load_or_calc_ppr``).
+    ``root_dir``: the directory that holds ``node_subsets/`` (the reference uses its repo root); default: the current
+    working directory.  ``device``: run the MI355X producer instead of the host one (bit-identical result)."""
+    import os
+    root_dir = os.getcwd() if root_dir is None else root_dir
+    ref_path = ppr_reference_cache_path(root_dir, dataset, alpha, eps, is_val)
+    os.makedirs(os.path.dirname(ref_path), exist_ok=True)
+    try:
+        from torch_sparse import SparseTensor  # noqa: F401  (only to read / write the reference's own cache format)
+        have_ts = True
+    except Exception:  # noqa: BLE001
+        have_ts = False
+    if have_ts and os.path.isfile(ref_path):
+        print("PPR matrix exists. Loading from file...", flush=True)
+        return torch.load(ref_path, weights_only=False).to_torch_sparse_coo_tensor()
+    csr = load_or_calc_ppr(edge_index, int(num_nodes), alpha, eps, cache_root=root_dir, dataset=dataset, is_val=is_val,
+                           device=device, num_threads=num_threads)
+    coo = csr.to_torch_sparse_coo()
+    if have_ts:
+        from torch_sparse import SparseTensor
+        ix = coo.indices()
+        print(f"Saving data to {ref_path}...", flush=True)
+        torch.save(SparseTensor(row=ix[0], col=ix[1], value=coo.values(), sparse_sizes=(int(num_nodes),) * 2), ref_path)
+    return coo
+
+
+def ppr_coo(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5) -> torch.Tensor:
+    """torch sparse COO PPR matrix without any cache (``calc_ppr(...).to_torch_sparse_coo()``)."""
     return calc_ppr(edge_index, num_nodes, alpha, eps).to_torch_sparse_coo()

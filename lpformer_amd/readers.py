@@ -75,7 +75,7 @@ def _finish(data: dict, name: str, edge_index: np.ndarray, weight, n: int, x, ep
                            device=ppr_device, num_threads=ppr_threads)
     ppr_test = None
     if val_edges is not None:
-        vei = np.concatenate([val_edges, val_edges[::-1]], axis=1)
+        vei = D.to_undirected(val_edges, n)   # coalesced: a validation pair given twice / in both directions counts once
         full = np.concatenate([pe, vei], axis=1)
         ppr_test = load_or_calc_ppr(full, n, 0.15, eps, cache_root=cache_root, dataset=name, is_val=True,
                                     device=ppr_device, num_threads=ppr_threads)

@@ -238,3 +238,25 @@ def test_hashed_index_layout():
             b = ((int(c) * graph.HASH_MUL & 0xFFFFFFFF) * int(nbk[i])) >> 32
             line = cv[hrp[i] + hb * b: hrp[i] + hb * b + hb, 0]
             assert c in line
+
+
+def test_get_ppr_has_the_reference_signature_and_cache_name(tmp_path):
+    """``get_ppr(dataset, edge_index, num_nodes, alpha, eps, is_val)`` (src/util/calc_ppr_scores.py:245-270): the six
+    positional arguments, the cache directory and file stem of the reference, a coalesced sparse COO tensor out; the
+    second call loads the cache."""
+    import os
+    import lpformer_amd
+    from lpformer_amd import ppr as P
+    rng = np.random.default_rng(0)
+    n = 40
+    e = rng.integers(0, n, (2, 120))
+    ei = np.concatenate([e, e[::-1]], axis=1)
+    a = lpformer_amd.get_ppr("toy", torch.from_numpy(ei), n, 0.15, 1e-3, True, root_dir=str(tmp_path))
+    assert a.layout == torch.sparse_coo and a.is_coalesced() and tuple(a.shape) == (n, n)
+    ref = P.ppr_reference_cache_path(str(tmp_path), "toy", 0.15, 1e-3, True)
+    assert ref.endswith(os.path.join("node_subsets", "ppr", "toy", "sparse_adj-015_eps-0001_val.pt"))
+    assert os.path.isfile(ref[:-3] + ".lpf.npz")               # (no torch_sparse here: the CSR sibling)
+    b = lpformer_amd.get_ppr("toy", torch.from_numpy(ei), n, 0.15, 1e-3, True, root_dir=str(tmp_path))
+    assert torch.equal(a.indices(), b.indices()) and torch.equal(a.values(), b.values())
+    want = lpformer_amd.calc_ppr(ei, n, 0.15, 1e-3)
+    assert a._nnz() == want.nnz and torch.equal(a.values(), torch.from_numpy(want.val))

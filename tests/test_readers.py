@@ -67,6 +67,28 @@ def test_read_ogb_collab_layout(tmp_path):
     assert d["ppr"].n == n and np.all(np.diff(d["ppr"].rowptr) >= 1)       # every row holds at least its own node
 
 
+def test_validation_edges_are_coalesced_like_to_undirected():
+    """read_datasets.py:98-107: ``to_undirected(val_edge_index)`` mirrors AND coalesces, so a validation pair listed
+    twice, or in both directions, adds weight 1 once per direction to ``full_adj_t`` (not 2)."""
+    from lpformer_amd import data as D
+    n = 6
+    ei = np.array([[0, 1, 1, 2], [1, 0, 2, 1]])
+    val = np.array([[3, 3, 4, 5], [4, 4, 3, 0]])                  # (3,4) twice and (4,3): one undirected edge; (5,0)
+    und = D.to_undirected(val, n)
+    assert und.tolist() == [[0, 3, 4, 5], [5, 4, 3, 0]]
+    x = np.zeros((n, 4), np.float32)
+    d = D.build_data(ei, x, n, eps=1e-2, val_edge_index=val)
+    full = d["full_adj_t"]
+    dense = np.zeros((n, n))
+    dense[np.repeat(np.arange(n), np.diff(full.rowptr)), full.col] = full.val
+    want = np.zeros((n, n))
+    for a, b in ((0, 1), (1, 2), (3, 4), (5, 0)):
+        want[a, b] = want[b, a] = 1
+    assert np.array_equal(dense, want)
+    mask = d["full_adj_mask"]
+    assert mask.col.size == 8
+
+
 def test_read_ogb_citation2_and_ddi_layouts(tmp_path):
     rng = np.random.default_rng(1)
     n = 40
