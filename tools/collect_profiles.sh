@@ -2,7 +2,7 @@
 # Round profile collection on the GPU box (run through gpurun from the repo root):
 #   tools/collect_profiles.sh r02 <commit>   ->   gpurun_out/<tag>_*  (copy the summaries into profiles/ afterwards)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out

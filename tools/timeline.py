@@ -10,7 +10,7 @@ path = sys.argv[1]
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (12, 42)
 rows = list(csv.DictReader(open(path)))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-marks = [s for s, e, n in ks if "select_plan_kernel" in n]
+marks = [s for s, e, n in ks if "_plan_kernel" in n]
 w0, w1 = marks[lo], marks[hi]
 win = [(s, e, n) for s, e, n in ks if w0 <= s < w1]
 steps = hi - lo
