@@ -393,6 +393,47 @@ int lpf_self_ppr(int64_t n, const int64_t *adj_rowptr, const int32_t *adj_col, c
                  const int32_t *ppr_col, const float *ppr_val, float *selfp, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training step of the pair stage (pair_train.hip): the forward of get_pos_encodings
+ * (link_transformer.py:182-211) and LinkAttention.message + PyG softmax + scatter-sum (layers.py:193-224) with the
+ * state a backward pass needs, and the gradients torch autograd derives from them (the reference's training step,
+ * src/train/train_model.py:59-77).  Entries are sorted by (type, pair); seg int64[3][bs+1] = first entry of pair p's
+ * type-t segment (global entry index, seg[t][bs] = end of type t).  D in {32, 64, 128, 256}; rows 16-byte aligned.
+ * Sums over entries / pairs go through per-block partials added in block order (deterministic); dZ and
+ * lpf_pair_scatter_add_f32 use float atomics.  workspace: lpf_train_partial_blocks(units) * k * D floats (k below;
+ * units = rows the call reduces over -- today a constant bound, 512 blocks).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t lpf_train_partial_blocks(int64_t units);
+/* H[e,:] = ReLU(LN(W1 [pa,pb] + b1)) + ReLU(LN(W1 [pb,pa] + b1)) for the entries of ONE type (w1 float[D][2],
+ * b1 / gamma / beta float[D]: the first Linear and the LayerNorm of that type's ppr_encoder_* MLP). */
+int lpf_pe_hidden_fwd_f32(int64_t n_entries, int32_t D, const float *w1, const float *b1, const float *gamma,
+                          const float *beta, const float *pa, const float *pb, float *H, int64_t ldh, void *stream);
+/* grads float[5][D] = (dW1[:,0], dW1[:,1], db1, dgamma, dbeta) from dH; workspace k = 5. */
+int lpf_pe_hidden_bwd_f32(int64_t n_entries, int32_t D, const float *w1, const float *b1, const float *gamma,
+                          const float *beta, const float *pa, const float *pb, const float *dH, int64_t ldh,
+                          float *grads, float *workspace, void *stream);
+/* out[c] = sum_r x[r, c]  (bias gradients); workspace k = 1. */
+int lpf_colsum_f32(int64_t M, int32_t D, const float *x, int64_t ldx, float *out, float *workspace, void *stream);
+/* k_e = Z[node_e] + KP[e]; s_e = att . leaky_relu(k_e * q[p], 0.2); out[p] = sum_e softmax_p(s)_e k_e + bias.
+ * Saves the raw scores and per pair the segment max and 1 / (sum exp + 1e-16) (0 for a pair without entries). */
+int lpf_pair_attention_train_fwd_f32(int64_t bs, int64_t n_entries, int32_t D, const int64_t *seg,
+                                     const int32_t *e_node, const float *Z, int64_t ldz, const float *KP, int64_t ldk,
+                                     const float *q, int64_t ldq, const float *att, const float *bias, float *out,
+                                     int64_t ldo, float *score, float *pmax, float *pinv, void *stream);
+/* Gradients of the above from dout: dK[e] (entry-major), dZ[node_e] += dk_e (dZ zeroed by the caller), dq[p],
+ * datt_dbias float[2][D]; workspace k = 2. */
+int lpf_pair_attention_train_bwd_f32(int64_t bs, int64_t n_entries, int32_t D, const int64_t *seg,
+                                     const int32_t *e_node, const float *Z, int64_t ldz, const float *KP, int64_t ldk,
+                                     const float *q, int64_t ldq, const float *att, const float *bias, const float *out,
+                                     int64_t ldo, const float *score, const float *pmax, const float *pinv,
+                                     const float *dout, int64_t lddo, float *dK, int64_t lddk, float *dZ, int64_t lddz,
+                                     float *dq, int64_t lddq, float *datt_dbias, float *workspace, void *stream);
+/* Gradient of lpf_pair_gather_f32: dX[a_k] += dsum[k] + dmul[k] * X[b_k], dX[b_k] += dsum[k] + dmul[k] * X[a_k]
+ * (dmul or dsum may be NULL; dX is accumulated into). */
+int lpf_pair_scatter_add_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, int64_t n_rows,
+                             const float *X, int64_t ldx, const float *dmul, int64_t ldm, const float *dsum,
+                             int64_t lds, float *dX, int64_t lddx, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host side (liblpformer_host.so)
  * ---------------------------------------------------------------------------------------------- */
 

@@ -60,6 +60,15 @@ HIP_PROTOTYPES = {
     "lpf_ppr_push_f64": [i64, vp, vp, C.c_double, C.c_double, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp],
     "lpf_ppr_pack_workspace_bytes": [i64, i64],
     "lpf_ppr_pack_csr": [i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp],
+    "lpf_train_partial_blocks": [i64],
+    "lpf_pe_hidden_fwd_f32": [i64, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "lpf_pe_hidden_bwd_f32": [i64, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
+    "lpf_colsum_f32": [i64, i32, vp, i64, vp, vp, vp],
+    "lpf_pair_attention_train_fwd_f32": [i64, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp,
+                                         vp],
+    "lpf_pair_attention_train_bwd_f32": [i64, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp,
+                                         vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp],
+    "lpf_pair_scatter_add_f32": [i64, i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lpf_dense_chain_f32": [i64, i32, vp, i64, vp, i64, i64, i32, vp, i32, vp, vp, i64, vp, vp, u32, vp, i32, vp, vp, i64,
                             vp, vp],
 }
@@ -70,7 +79,8 @@ HOST_PROTOTYPES = {
 }
 _RESTYPE = {"lpf_strerror": C.c_char_p, "lpf_last_hip_error": C.c_char_p, "lpf_host_free": None,
             "lpf_ppr_push_workspace_bytes": C.c_int64, "lpf_select_plan_blocks": C.c_int64, "lpf_ppr_pack_workspace_bytes": C.c_int64,
-            "lpf_gemm_tn_workspace_floats": C.c_int64, "lpf_layernorm_bwd_workspace_floats": C.c_int64}
+            "lpf_gemm_tn_workspace_floats": C.c_int64, "lpf_layernorm_bwd_workspace_floats": C.c_int64,
+            "lpf_train_partial_blocks": C.c_int64}
 
 
 class LpfError(RuntimeError):

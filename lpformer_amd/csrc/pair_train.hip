@@ -165,11 +165,16 @@ __global__ __launch_bounds__(PT_THREADS) void pe_hidden_bwd_kernel(int64_t lo, i
 // out[i][c] = sum over blocks (in block order) of partial[block][i][c]
 __global__ __launch_bounds__(256) void partial_sum_kernel(int64_t n_blocks, int64_t width, const float *__restrict__ partial,
                                                           float *__restrict__ out) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
+    // 64 columns per workgroup, four row strips of the partials each (fixed strip -> fixed order of additions)
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, strip = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + cl;
     float v = 0.f;
-    for (int64_t b = 0; b < n_blocks; ++b) v += partial[b * width + c];
-    out[c] = v;
+    if (c < width)
+        for (int64_t b = strip; b < n_blocks; b += 4) v += partial[b * width + c];
+    red[strip][cl] = v;
+    __syncthreads();
+    if (strip == 0 && c < width) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // partial[block][c] = sum of the block's rows of x[:, c]  (block b owns rows b, b + n_blocks, ... by waves)
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(PT_THREADS) void pair_scatter_kernel(int64_t bs, in
 inline int pt_blocks(int64_t units, int per_block) {
     int64_t b = (units + per_block - 1) / per_block;
     if (b < 1) b = 1;
-    if (b > 2048) b = 2048;
+    if (b > 512) b = 512;   // two resident workgroups per CU; the final pass adds the partial rows serially
     return (int)b;
 }
 
@@ -402,7 +407,7 @@ inline int pt_blocks(int64_t units, int per_block) {
 
 }  // namespace
 
-extern "C" int64_t lpf_train_partial_blocks(int64_t units) { return pt_blocks(units, 64); }
+extern "C" int64_t lpf_train_partial_blocks(int64_t units) { (void)units; return 512; }  // the launch cap of pt_blocks
 
 extern "C" int lpf_pe_hidden_fwd_f32(int64_t n_entries, int32_t D, const float *w1, const float *b1, const float *gamma,
                                      const float *beta, const float *pa, const float *pb, float *H, int64_t ldh,
@@ -429,7 +434,7 @@ extern "C" int lpf_pe_hidden_bwd_f32(int64_t n_entries, int32_t D, const float *
     const int nb = pt_blocks(n_entries, 64);
     PT_DISPATCH(D, hipLaunchKernelGGL(pe_hidden_bwd_kernel<GG>, dim3(nb), dim3(PT_THREADS), 0, s, (int64_t)0, n_entries,
                                       (int)D, P, pa, pb, dH, ldh, workspace));
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((5 * D + 255) / 256), dim3(256), 0, s, (int64_t)nb, (int64_t)5 * D,
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((5 * D + 63) / 64), dim3(256), 0, s, (int64_t)nb, (int64_t)5 * D,
                        workspace, grads);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
@@ -442,7 +447,7 @@ extern "C" int lpf_colsum_f32(int64_t M, int32_t D, const float *x, int64_t ldx,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = pt_blocks(M, 256);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(PT_THREADS), 0, s, M, (int)D, x, ldx, workspace);
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (int64_t)nb, (int64_t)D, workspace, out);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((D + 63) / 64), dim3(256), 0, s, (int64_t)nb, (int64_t)D, workspace, out);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
@@ -493,7 +498,7 @@ extern "C" int lpf_pair_attention_train_bwd_f32(int64_t bs, int64_t n_entries, i
     int nb = 1;
     PT_DISPATCH(D, { nb = pt_blocks(bs, 4 * (64 / GG));
                      hipLaunchKernelGGL(pair_attn_train_bwd_kernel<GG>, dim3(nb), dim3(PT_THREADS), 0, s, a); });
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, (int64_t)nb, (int64_t)2 * D,
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, (int64_t)nb, (int64_t)2 * D,
                        workspace, datt_dbias);
     LPF_CHECK_LAUNCH();
     return LPF_OK;

@@ -9,9 +9,11 @@ device:
   (``lpf_layernorm_f32`` / ``lpf_layernorm_bwd_f32``), the GCN aggregation
   (``lpf_spmm_csr_f32`` with the propagation matrix, its transpose for the gradient) and the node selection
   (``lpf_select_plan`` / ``_run`` / ``_export``; integer work, no gradient);
-* ReLU, dropout, the leaky-ReLU score, the per-pair segment softmax and the index gathers / scatter-adds
-  around them are ordinary differentiable torch operators on the device in this version (elementwise and
-  index-bound; they are the next candidates for dedicated kernels -- DESIGN.md section 8).
+* the pair stage has kernels of its own (csrc/pair_train.hip): the PE hidden layer, the per-pair leaky-ReLU attention
+  with PyG's segment softmax (forward saving the raw scores and the per-pair softmax state, backward producing dK, dZ,
+  dq, datt, dbias), the gradients of the PE hidden layer, the endpoint gathers and their scatter-add, column sums;
+* ReLU, dropout masks, bias adds, the parameter-sized folds (W_rp W2) and the integer bookkeeping of the random
+  attention drop are ordinary torch operators on the device.
 
 Evaluation never comes through here: ``model.eval()`` takes the fused inference kernels.  Gradients are pinned by
 reference-generated fixtures (tests/golden/train_step_*.npz, tests/test_gpu_train.py).
@@ -78,6 +80,18 @@ def _gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _colsum(x: torch.Tensor) -> torch.Tensor:
+    """Column sums of a [M, D] matrix (bias gradients) through lpf_colsum_f32 (deterministic); torch for odd widths."""
+    m, d = x.shape
+    if d % 4 or d > 256 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        return x.sum(dim=0)
+    out = torch.empty(d, dtype=torch.float32, device=x.device)
+    lib = _lib.hip()
+    ws = torch.empty(int(lib.lpf_train_partial_blocks(m)) * d, dtype=torch.float32, device=x.device)
+    check(lib.lpf_colsum_f32(m, d, ptr(x), x.stride(0), ptr(out), ptr(ws), _stream(x)), "lpf_colsum_f32")
+    return out
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T (+ b); forward and both gradients on the fp32 matrix cores (lpf_gemm_f32)."""
 
@@ -98,7 +112,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _gemm_tn(dy, x)                                          # dY^T X, rows split over the GPU
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=0)
+            db = _colsum(dy)
         return dx, dw, db
 
 
@@ -242,57 +256,182 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
             xi = F.relu(xi)
         x = x + xi if (enc.residual and x.shape[-1] == xi.shape[-1]) else xi
     x_node = layer_norm(x, model.gnn_norm.weight, model.gnn_norm.bias)
-    xa, xb = x_node[batch[0]], x_node[batch[1]]
-    ew = _mlp(model.elementwise_lin, xa * xb)
+    x_node = x_node.contiguous()
+    ew = _mlp(model.elementwise_lin, PairGatherFn.apply(x_node, batch, True))            # x_a * x_b (:101-102)
     # ---- selection (integer work, no gradient) in the reference's layout, then the random attention drop
+    n_types = {"all": 3, "1-hop": 2, "cn": 1}[model.mask]
     with torch.no_grad():
         s = model._select(batch, test_set, adj_mask)
         tp = s["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)
         tot = [int(v) for v in tp[:, bs].tolist()]
-        n_types = 3 if model.mask == "all" else 2
-        segs, base = [], 0
-        for t in range(3):
-            sl = slice(base, base + tot[t])
-            segs.append((s["sel_pair"][sl].long(), s["sel_node"][sl].long(), s["sel_pa"][sl].clone(),
-                         s["sel_pb"][sl].clone()))
-            base += tot[t]
-        if model.att_drop > 0:
-            # CN and 1-hop are dropped together, >1-hop separately (link_transformer.py:257-260)
+        n_all = sum(tot)
+        e_pair, e_node = s["sel_pair"][:n_all], s["sel_node"][:n_all]
+        e_pa, e_pb = s["sel_pa"][:n_all], s["sel_pb"][:n_all]
+        if model.att_drop > 0 and n_all > 0:
+            # drop_pairwise (link_transformer.py:322-337): ceil(n (1 - p)) entries of a random permutation survive, CN
+            # and 1-hop together, >1-hop separately (:257-260).  The survivors are kept in (type, pair) order -- the
+            # reference leaves them in permuted order, which only the summation order of its scatters can see.
             n01 = tot[0] + tot[1]
-            keep = drop_pairwise(n01, model.att_drop, dev)
-            k0, k1 = keep[keep < tot[0]], keep[keep >= tot[0]] - tot[0]
-            segs[0] = tuple(v[k0] for v in segs[0])
-            segs[1] = tuple(v[k1] for v in segs[1])
-            if n_types == 3:
-                k2 = drop_pairwise(tot[2], model.att_drop, dev)
-                segs[2] = tuple(v[k2] for v in segs[2])
-        counts = [torch.bincount(sg[0], minlength=bs).float() for sg in segs]
-    # ---- positional encodings + attention (link_transformer.py:182-211, layers.py:161-224)
-    encoders = [model.ppr_encoder_cn, model.ppr_encoder_onehop] + ([model.ppr_encoder_non1hop] if n_types == 3 else [])
-    pair = torch.cat([segs[t][0] for t in range(n_types)])
-    node = torch.cat([segs[t][1] for t in range(n_types)])
-    pes = torch.cat([_pe_mlp(encoders[t], segs[t][2], segs[t][3]) for t in range(n_types)])
+            keep = torch.zeros(n_all, dtype=torch.bool, device=dev)
+            keep[drop_pairwise(n01, model.att_drop, dev)] = True
+            if tot[2] > 0:
+                keep[n01 + drop_pairwise(tot[2], model.att_drop, dev)] = True
+            tid = torch.repeat_interleave(torch.arange(3, device=dev), torch.tensor(tot, device=dev))[keep]
+            e_pair, e_node, e_pa, e_pb = e_pair[keep], e_node[keep], e_pa[keep], e_pb[keep]
+            cnt = torch.bincount(tid * bs + e_pair.long(), minlength=3 * bs).view(3, bs)
+        else:
+            cnt = (tp[:, 1:] - tp[:, :-1]).long()
+        tot = [int(v) for v in cnt.sum(dim=1).tolist()]
+        tbase = [0, tot[0], tot[0] + tot[1], tot[0] + tot[1] + tot[2]]
+        seg = torch.zeros(3, bs + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(cnt, dim=1, out=seg[:, 1:])
+        seg += torch.tensor(tbase[:3], dtype=torch.int64, device=dev)[:, None]
+        # (copies: the export arrays live in per-stream workspaces that the next forward overwrites, and the backward
+        #  pass of THIS forward still needs them)
+        e_node = e_node.to(torch.int32).clone()
+        e_pa, e_pb = e_pa.clone(), e_pb.clone()
+        counts = cnt.float()
+    # ---- positional encodings + attention (link_transformer.py:182-211, layers.py:161-224): dedicated kernels
     att = model.att_layers[0].att
-    k = linear(torch.cat([x_node[node], pes], dim=1), att.lin_r.weight, att.lin_r.bias)
-    q = linear(xa, att.lin_l.weight, att.lin_l.bias) + linear(xb, att.lin_l.weight, att.lin_l.bias)
-    score = (F.leaky_relu(k * q[pair], 0.2) * att.att.reshape(1, -1)).sum(dim=-1)
-    # PyG softmax over the entries of a pair: shift by the segment max, denominator + 1e-16
-    smax = torch.full((bs,), float("-inf"), device=dev).scatter_reduce(0, pair, score.detach(), "amax",
-                                                                      include_self=True)
-    e = torch.exp(score - smax[pair])
-    den = torch.zeros(bs, device=dev).index_add(0, pair, e) + 1e-16
-    alpha = e / den[pair]
-    out = torch.zeros(bs, d, device=dev).index_add(0, pair, k * alpha[:, None]) + att.bias
+    encoders = [model.ppr_encoder_cn, getattr(model, "ppr_encoder_onehop", None),
+                getattr(model, "ppr_encoder_non1hop", None)][:n_types]
+    w_rx, w_rp = att.lin_r.weight[:, :d], att.lin_r.weight[:, d:]
+    z = linear(x_node, w_rx, att.lin_r.bias)                        # node half of lin_r, once per node
+    y = linear(x_node, att.lin_l.weight, att.lin_l.bias)            # lin_l per node: q = Y[a] + Y[b] (:212-215)
+    q = PairGatherFn.apply(y, batch, False)
+    # the second PE Linear folded into the PE half of lin_r: k_e = Z[v] + (W_rp W2_t) h_e + W_rp (2 b2_t)
+    wfold = torch.stack([linear(w_rp, e.linears[1].weight.t()) for e in encoders])
+    bfold = torch.stack([linear(2.0 * e.linears[1].bias[None, :], w_rp)[0] for e in encoders])
+    w1s = torch.stack([e.linears[0].weight for e in encoders])
+    b1s = torch.stack([e.linears[0].bias for e in encoders])
+    gams = torch.stack([e.norm.weight for e in encoders])
+    bets = torch.stack([e.norm.bias for e in encoders])
+    out = PairAttentionFn.apply(z, q, att.att.reshape(-1), att.bias, wfold, bfold, w1s, b1s, gams, bets, e_node, e_pa,
+                                e_pb, seg, tuple(tbase))
     layer = model.att_layers[0]
     out = layer_norm(out, layer.post_att_norm.weight, layer.post_att_norm.bias)
     out = F.dropout(out, p=layer.dropout, training=True)
     # ---- count features + pairwise_lin (link_transformer.py:170-177, 340-356)
     if n_types == 3:
         cf = torch.stack([counts[0], counts[1], counts[2], counts[0] + counts[1]], dim=1)
-    else:
+    elif n_types == 2:
         cf = torch.stack([counts[0], counts[1], counts[0] + counts[1]], dim=1)
+    else:
+        cf = counts[0][:, None]
     pw = _mlp(model.pairwise_lin, torch.cat([out, cf], dim=1))
     return torch.cat([ew, pw], dim=-1)
+
+
+class PairGatherFn(torch.autograd.Function):
+    """x_a * x_b (``product``) or x_a + x_b of the pairs' endpoint rows (link_transformer.py:101-102, layers.py:212-215)
+    through lpf_pair_gather_f32; the gradient is scattered back with float atomics (lpf_pair_scatter_add_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, batch, product):
+        x = x.contiguous()
+        bs, d = batch.shape[1], x.shape[1]
+        out = torch.empty(bs, d, dtype=torch.float32, device=x.device)
+        args = (ptr(out), d, None, 0) if product else (None, 0, ptr(out), d)
+        check(_lib.hip().lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), x.shape[0], ptr(x), x.stride(0), *args,
+                                             _stream(x)), "lpf_pair_gather_f32")
+        ctx.save_for_backward(x, batch)
+        ctx.product = product
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, batch = ctx.saved_tensors
+        dout = dout.contiguous()
+        bs, d = batch.shape[1], x.shape[1]
+        dx = torch.zeros_like(x)
+        dm, ds = (dout, None) if ctx.product else (None, dout)
+        check(_lib.hip().lpf_pair_scatter_add_f32(bs, d, ptr(batch), batch.stride(0), x.shape[0], ptr(x), x.stride(0),
+                                                  ptr(dm), d, ptr(ds), d, ptr(dx), dx.stride(0), _stream(x)),
+              "lpf_pair_scatter_add_f32")
+        return dx, None, None
+
+
+def _partial_ws(d: int, k: int, device) -> torch.Tensor:
+    return torch.empty(int(_lib.hip().lpf_train_partial_blocks(0)) * k * d, dtype=torch.float32, device=device)
+
+
+class PairAttentionFn(torch.autograd.Function):
+    """PE hidden layer -> folded key projection -> per-pair leaky-ReLU attention with PyG's segment softmax
+    (layers.py:193-224, link_transformer.py:182-211), forward and backward on the kernels of csrc/pair_train.hip plus
+    lpf_gemm_f32 / lpf_gemm_tn_f32 for the entry-sized products (dH = dK Wfold, dWfold = dK^T H)."""
+
+    @staticmethod
+    def forward(ctx, z, q, att, bias, wfold, bfold, w1s, b1s, gams, bets, e_node, e_pa, e_pb, seg, tbase):
+        lib, st = _lib.hip(), _stream(z)
+        z, q = z.contiguous(), q.contiguous()
+        att, bias = att.contiguous(), bias.contiguous()
+        wfold, bfold = wfold.contiguous(), bfold.contiguous()
+        w1s, b1s, gams, bets = w1s.contiguous(), b1s.contiguous(), gams.contiguous(), bets.contiguous()
+        bs, d, n = q.shape[0], q.shape[1], int(e_node.numel())
+        dev = z.device
+        h = torch.empty(max(n, 1), d, dtype=torch.float32, device=dev)
+        kp = torch.empty(max(n, 1), d, dtype=torch.float32, device=dev)
+        for t in range(wfold.shape[0]):
+            lo, hi = tbase[t], tbase[t + 1]
+            if hi <= lo:
+                continue
+            check(lib.lpf_pe_hidden_fwd_f32(hi - lo, d, ptr(w1s[t]), ptr(b1s[t]), ptr(gams[t]), ptr(bets[t]),
+                                            e_pa.data_ptr() + 4 * lo, e_pb.data_ptr() + 4 * lo, ptr(h[lo:]), d, st),
+                  "lpf_pe_hidden_fwd_f32")
+            check(lib.lpf_gemm_f32(hi - lo, d, d, ptr(h[lo:]), d, ptr(wfold[t]), d, ptr(bfold[t]), None, 0, ptr(kp[lo:]),
+                                   d, 0, st), "lpf_gemm_f32")
+        out = torch.empty(bs, d, dtype=torch.float32, device=dev)
+        score = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        pmax = torch.empty(bs, dtype=torch.float32, device=dev)
+        pinv = torch.empty(bs, dtype=torch.float32, device=dev)
+        check(lib.lpf_pair_attention_train_fwd_f32(bs, n, d, ptr(seg), ptr(e_node), ptr(z), z.stride(0), ptr(kp), d, ptr(q),
+                                                   d, ptr(att), ptr(bias), ptr(out), d, ptr(score), ptr(pmax), ptr(pinv),
+                                                   st), "lpf_pair_attention_train_fwd_f32")
+        ctx.save_for_backward(z, q, att, bias, wfold, w1s, b1s, gams, bets, e_node, e_pa, e_pb, seg, h, kp, out, score,
+                              pmax, pinv)
+        ctx.tbase = tbase
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (z, q, att, bias, wfold, w1s, b1s, gams, bets, e_node, e_pa, e_pb, seg, h, kp, out, score, pmax,
+         pinv) = ctx.saved_tensors
+        lib, st, tbase = _lib.hip(), _stream(z), ctx.tbase
+        dout = dout.contiguous()
+        bs, d, n = q.shape[0], q.shape[1], int(e_node.numel())
+        dev = z.device
+        dk = torch.empty(max(n, 1), d, dtype=torch.float32, device=dev)
+        dz = torch.zeros_like(z)
+        dq = torch.empty_like(q)
+        dab = torch.empty(2, d, dtype=torch.float32, device=dev)
+        check(lib.lpf_pair_attention_train_bwd_f32(
+            bs, n, d, ptr(seg), ptr(e_node), ptr(z), z.stride(0), ptr(kp), d, ptr(q), d, ptr(att), ptr(bias), ptr(out), d,
+            ptr(score), ptr(pmax), ptr(pinv), ptr(dout), d, ptr(dk), d, ptr(dz), dz.stride(0), ptr(dq), d, ptr(dab),
+            ptr(_partial_ws(d, 2, dev)), st), "lpf_pair_attention_train_bwd_f32")
+        n_t = wfold.shape[0]
+        dwfold = torch.zeros_like(wfold)
+        dbfold = torch.zeros(n_t, d, dtype=torch.float32, device=dev)
+        g5 = torch.zeros(n_t, 5, d, dtype=torch.float32, device=dev)
+        dh = torch.empty(max(n, 1), d, dtype=torch.float32, device=dev)
+        for t in range(n_t):
+            lo, hi = tbase[t], tbase[t + 1]
+            if hi <= lo:
+                continue
+            m = hi - lo
+            wt = wfold[t].t().contiguous()                                  # dH = dK Wfold
+            check(lib.lpf_gemm_f32(m, d, d, ptr(dk[lo:]), d, ptr(wt), d, None, None, 0, ptr(dh[lo:]), d, 0, st),
+                  "lpf_gemm_f32")
+            ws = torch.empty(max(int(lib.lpf_gemm_tn_workspace_floats(m, d, d)), 1), dtype=torch.float32, device=dev)
+            check(lib.lpf_gemm_tn_f32(m, d, d, ptr(dk[lo:]), d, ptr(h[lo:]), d, ptr(dwfold[t]), d, ptr(ws), st),
+                  "lpf_gemm_tn_f32")                                       # dWfold = dK^T H
+            check(lib.lpf_colsum_f32(m, d, ptr(dk[lo:]), d, ptr(dbfold[t]), ptr(_partial_ws(d, 1, dev)), st),
+                  "lpf_colsum_f32")
+            check(lib.lpf_pe_hidden_bwd_f32(m, d, ptr(w1s[t]), ptr(b1s[t]), ptr(gams[t]), ptr(bets[t]),
+                                            e_pa.data_ptr() + 4 * lo, e_pb.data_ptr() + 4 * lo, ptr(dh[lo:]), d,
+                                            ptr(g5[t]), ptr(_partial_ws(d, 5, dev)), st), "lpf_pe_hidden_bwd_f32")
+        dw1s = torch.stack([g5[:, 0], g5[:, 1]], dim=2)                    # [T, D, 2]
+        return (dz, dq, dab[0], dab[1], dwfold, dbfold, dw1s, g5[:, 2], g5[:, 3], g5[:, 4], None, None, None, None,
+                None)
 
 
 def score_train(score_func, x):
