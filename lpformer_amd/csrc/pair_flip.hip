@@ -1,0 +1,229 @@
+// Pairwise PPR-positional attention in one pass WITHOUT the D x D product per entry: the key projection of the
+// positional encoding is evaluated through the ReLU activation pattern of its hidden layer.
+//
+// Reference: LinkAttention.message + PyG softmax + scatter-sum (src/modules/layers.py:193-224) with get_pos_encodings
+// (src/models/link_transformer.py:182-211) folded in:
+//     h_e = ReLU(y(pa,pb)) + ReLU(y(pb,pa)),  y_k(x,y) = r(x,y) (ta_k x + tc_k y + td_k) + beta_k     (closed-form LN)
+//     k_e = Z[v_e] + Wfold_t h_e + bfold_t ;  s_e = att . leaky_relu(k_e * q_pair, 0.2) ;  segment softmax ;  sum alpha k
+// pair_fused.hip spends 2 D^2 FLOP per entry on Wfold_t h_e (fp32 matrix cores, the dominant kernel of the step).
+// But y_k is AFFINE in (r x, r y, r, 1), so for a fixed set S of active hidden units
+//     sum_{k in S} Wfold[:,k] y_k  =  P_S (r x) + Q_S (r y) + R_S r + B_S          (four D-vectors that depend on S only)
+// and the PPR values are small numbers: almost every entry has the activation pattern S0 of the point (0, 0), and one
+// that does not differs from it in a few units.  With the four vectors of S0 precomputed (host, float64) the product is
+//     Wfold h_e = P0 (r1 pa + r2 pb) + Q0 (r1 pb + r2 pa) + R0 (r1 + r2) + 2 B0 + sum_{k flipped} Wfold[:,k] |y_k|
+// -- exact in real arithmetic for EVERY input (relu(y) - [k in S0] y = |y| on a flipped unit, whichever way it flipped);
+// only the cost depends on the data: ~10 D FLOP per entry plus 2 D per flipped unit (collab-like bench: 0.66 flips per
+// entry, 99th percentile 8, D = 128) instead of 2 D^2.  The kernel is then bound by the Z-row gather, not by the
+// matrix pipe.  Worst case (every unit flips on every entry) it degenerates into a D x D product on the vector ALUs;
+// the matrix-core kernel stays in the library for such weights (LinkTransformer.attention_impl).
+//
+// Layout: G = D/4 lanes own one entry -- lane j of the group holds features AND hidden units 4j .. 4j+3 --, a group
+// walks one UNIT of 16 consecutive same-type entries with an online softmax and leaves exactly the records
+// pair_fused.hip leaves (part[t][pair] for a segment inside one unit, boundary records otherwise), so the consumers
+// (tail_chain.hip merge mode, pair_merge.hip) do not care which kernel ran.  64 / G units per wavefront at a time.
+#include "pe_common.h"
+
+namespace {
+
+constexpr uint32_t FL_PAIR_MASK = 0x7fffffffu;
+
+struct FlipArgs {
+    int64_t bs;
+    const int32_t *type_ptr;   // [3][bs+1]
+    const int4 *entries;       // [3][ent_cap]
+    int64_t ent_cap;
+    const float *Z; int64_t ldz;
+    const float *q; int64_t ldq;
+    const float *pe_tab;       // [3][D][4]   (ta, tc, td, beta) per hidden unit
+    const float *pe_stat;      // [3][8]
+    const float *base;         // [3][4][D]   P0, Q0, R0, C0 = 2 B0 + bfold
+    const uint32_t *s0;        // [3][D]      1 = unit active at (0, 0)
+    const float *wfoldT;       // [3][D][D]   wfoldT[t][k][c] = Wfold_t[c][k]
+    const float *att;          // [D]
+    float *part;               // [3][bs][D+4]
+    float *bnd;                // [3][units_cap][2][D+4]
+    int64_t units_cap;
+};
+
+template <int G>
+__device__ __forceinline__ float fl_group_max_i(int v) {
+#pragma unroll
+    for (int m = G >> 1; m > 0; m >>= 1) { const int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+    return v;
+}
+
+template <int G>
+__global__ __launch_bounds__(256, 3) void pair_flip_kernel(const FlipArgs A) {
+    constexpr int D = 4 * G, RS = D + 4, EPW = 64 / G;
+    const int lane = threadIdx.x & 63, grp = lane / G, lj = lane % G, off = 4 * lj;
+    int64_t n[3], units[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        n[t] = A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs];
+        if (n[t] > A.ent_cap) n[t] = A.ent_cap;   // (overflow: flagged by the selection kernel, stay inside the region)
+        units[t] = (n[t] + 15) >> 4;
+    }
+    const int64_t total_units = units[0] + units[1] + units[2];
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float4 at = *reinterpret_cast<const float4 *>(A.att + off);
+
+    for (int64_t u0 = wave_id * EPW; u0 < total_units; u0 += n_waves * EPW) {
+        const int64_t ug = u0 + grp;
+        const bool live = ug < total_units;
+        const int64_t uu = live ? ug : total_units - 1;
+        const int t = uu < units[0] ? 0 : (uu < units[0] + units[1] ? 1 : 2);
+        const int64_t U = uu - (t == 0 ? 0 : (t == 1 ? units[0] : units[0] + units[1]));
+        const int64_t cnt = t == 0 ? n[0] : (t == 1 ? n[1] : n[2]);
+        const int4 *ent = A.entries + (int64_t)t * A.ent_cap;
+        const int64_t e0 = U * 16;
+        const int nval = live ? (int)(cnt - e0 < 16 ? cnt - e0 : 16) : 0;   // >= 1 for a live unit
+
+        // per-type constants of this lane's four hidden units / features
+        float4 tab[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tab[j] = *reinterpret_cast<const float4 *>(A.pe_tab + ((int64_t)t * D + off + j) * 4);
+        const uint4 s0v = *reinterpret_cast<const uint4 *>(A.s0 + (int64_t)t * D + off);
+        const bool s0a[4] = {s0v.x != 0u, s0v.y != 0u, s0v.z != 0u, s0v.w != 0u};
+        const float *bt = A.base + (int64_t)t * 4 * D + off;
+        const float4 P0 = *reinterpret_cast<const float4 *>(bt), Q0 = *reinterpret_cast<const float4 *>(bt + D);
+        const float4 R0 = *reinterpret_cast<const float4 *>(bt + 2 * D), C0 = *reinterpret_cast<const float4 *>(bt + 3 * D);
+        const PeStat st = pe_load_stat(A.pe_stat, t);
+        const float *wT = A.wfoldT + (int64_t)t * D * D + off;
+
+        // neighbours of the unit: does its first entry start a segment, does its last one end one?
+        int prev_pair = -1;
+        if (e0 > 0) prev_pair = (int)((uint32_t)ent[e0 - 1].x & FL_PAIR_MASK);
+        bool cont = false;
+        if (nval == 16 && e0 + 16 < cnt)
+            cont = ((uint32_t)ent[e0 + 16].x & FL_PAIR_MASK) == ((uint32_t)ent[e0 + 15].x & FL_PAIR_MASK);
+        float *const part_t = A.part + (int64_t)t * A.bs * RS;
+        float *const bnd_u = A.bnd + (((int64_t)t * A.units_cap + U) * 2) * RS;
+
+        // the walk: records two entries ahead, Z / q rows one entry ahead of the arithmetic
+        auto rec_at = [&](int i) __attribute__((always_inline)) {
+            const int64_t e = e0 + (i < nval ? i : (nval > 0 ? nval - 1 : 0));
+            return ent[live ? e : 0];
+        };
+        int4 rc = rec_at(0), rn = rec_at(1);
+        auto rows = [&](const int4 &r, float4 &z, float4 &qq) __attribute__((always_inline)) {
+            z = *reinterpret_cast<const float4 *>(A.Z + (int64_t)r.y * A.ldz + off);
+            qq = *reinterpret_cast<const float4 *>(A.q + (int64_t)((uint32_t)r.x & FL_PAIR_MASK) * A.ldq + off);
+        };
+        float4 zc, qc;
+        rows(rc, zc, qc);
+        float m = -INFINITY, l = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool first = true;                       // no record flushed yet by this unit
+        const bool st0 = e0 == 0 || prev_pair != (int)((uint32_t)rc.x & FL_PAIR_MASK);   // entry 0 starts a segment
+        int cur_pair = (int)((uint32_t)rc.x & FL_PAIR_MASK), last_pair = prev_pair;
+        auto flush = [&](int pair, bool cfront, bool cback) __attribute__((always_inline)) {
+            float *dst = (cfront && cback) ? part_t + (int64_t)pair * RS : bnd_u + (cfront ? RS : 0);
+            *reinterpret_cast<float4 *>(dst + off) = o;
+            if (lj == 0) *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, __int_as_float(pair), cback ? 0.f : 1.f);
+        };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int4 rnn = rec_at(i + 2);
+            float4 zn, qn;
+            rows(rn, zn, qn);
+            const bool on = i < nval;
+            const float pa = __int_as_float(rc.z), pb = __int_as_float(rc.w);
+            const int pair_i = (int)((uint32_t)rc.x & FL_PAIR_MASK);
+            // hidden layer: this lane's four units, both argument orders; which of them left the pattern of (0, 0)?
+            const float r1 = pe_rstd(st, pa, pb), r2 = pe_rstd(st, pb, pa);
+            float ay[2][4];
+            bool fl = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y1 = fmaf(r1, fmaf(tab[j].x, pa, fmaf(tab[j].y, pb, tab[j].z)), tab[j].w);
+                const float y2 = fmaf(r2, fmaf(tab[j].x, pb, fmaf(tab[j].y, pa, tab[j].z)), tab[j].w);
+                const bool f1 = (y1 > 0.f) != s0a[j], f2 = (y2 > 0.f) != s0a[j];
+                ay[0][j] = f1 ? fabsf(y1) : 0.f;
+                ay[1][j] = f2 ? fabsf(y2) : 0.f;
+                fl = fl || f1 || f2;
+            }
+            const float ca = fmaf(r1, pa, r2 * pb), cb = fmaf(r1, pb, r2 * pa), cr = r1 + r2;
+            float k[4] = {zc.x + fmaf(P0.x, ca, fmaf(Q0.x, cb, fmaf(R0.x, cr, C0.x))),
+                          zc.y + fmaf(P0.y, ca, fmaf(Q0.y, cb, fmaf(R0.y, cr, C0.y))),
+                          zc.z + fmaf(P0.z, ca, fmaf(Q0.z, cb, fmaf(R0.z, cr, C0.z))),
+                          zc.w + fmaf(P0.w, ca, fmaf(Q0.w, cb, fmaf(R0.w, cr, C0.w)))};
+            if (__ballot(fl && on)) {   // rare: add Wfold[:, k] |y_k| for every flipped unit of every group of the wave
+#pragma unroll
+                for (int oj = 0; oj < 8; ++oj) {
+                    const float mine = ay[oj >> 2][oj & 3];
+                    uint64_t bm = __ballot(mine != 0.f && on);
+                    while (bm) {
+                        const int b = __ffsll((unsigned long long)bm) - 1;
+                        bm &= bm - 1;
+                        const float val = __shfl(mine, b, 64);
+                        if (b / G == grp) {
+                            const int kk = 4 * (b % G) + (oj & 3);
+                            const float4 w = *reinterpret_cast<const float4 *>(wT + (int64_t)kk * D);
+                            k[0] = fmaf(w.x, val, k[0]); k[1] = fmaf(w.y, val, k[1]);
+                            k[2] = fmaf(w.z, val, k[2]); k[3] = fmaf(w.w, val, k[3]);
+                        }
+                    }
+                }
+            }
+            // score of the entry: att . leaky_relu(k * q, 0.2), summed over the group's lanes
+            float x0 = k[0] * qc.x, x1 = k[1] * qc.y, x2 = k[2] * qc.z, x3 = k[3] * qc.w;
+            x0 = fmaxf(x0, 0.2f * x0); x1 = fmaxf(x1, 0.2f * x1); x2 = fmaxf(x2, 0.2f * x2); x3 = fmaxf(x3, 0.2f * x3);
+            const float s = lpf_group_sum<G>(fmaf(x0, at.x, fmaf(x1, at.y, fmaf(x2, at.z, x3 * at.w))));
+            if (on) {
+                if (i > 0 && pair_i != last_pair) {   // the previous entry closed a segment
+                    flush(cur_pair, first ? st0 : true, true);
+                    m = -INFINITY; l = 0.f;
+                    o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    first = false;
+                }
+                cur_pair = pair_i;
+                const float mn = fmaxf(m, s);
+                const float sca = __expf(m - mn), w = __expf(s - mn);
+                l = fmaf(l, sca, w);
+                o = make_float4(fmaf(o.x, sca, w * k[0]), fmaf(o.y, sca, w * k[1]), fmaf(o.z, sca, w * k[2]),
+                                fmaf(o.w, sca, w * k[3]));
+                m = mn;
+                last_pair = pair_i;
+            }
+            rc = rn; rn = rnn; zc = zn; qc = qn;
+            __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler hoists the whole unit's loads: 170 VGPRs)
+        }
+        if (nval > 0) flush(cur_pair, first ? st0 : true, !cont);
+    }
+}
+
+}  // namespace
+
+extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                           int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
+                                           const float *pe_tab, const float *pe_stat, const float *base,
+                                           const uint32_t *s0, const float *wfold_t, const float *att, float *part,
+                                           float *bnd, int64_t units_cap, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && Z && q && pe_tab && pe_stat && base && s0 && wfold_t &&
+                att && part && bnd && units_cap >= (ent_cap + 15) / 16);
+    LPF_REQUIRE(ldz >= D && ldq >= D && (ldz & 3) == 0 && (ldq & 3) == 0 && lpf_aligned16(entries) && lpf_aligned16(Z) &&
+                lpf_aligned16(q) && lpf_aligned16(pe_tab) && lpf_aligned16(base) && lpf_aligned16(s0) &&
+                lpf_aligned16(wfold_t) && lpf_aligned16(att) && lpf_aligned16(part) && lpf_aligned16(bnd));
+    const FlipArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, Z, ldz, q, ldq, pe_tab, pe_stat, base, s0,
+                     wfold_t, att, part, bnd, units_cap};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t max_units = 3 * ((ent_cap + 15) / 16) + 3;
+#define LPF_FLIP(GG)                                                                                          \
+    do {                                                                                                      \
+        int64_t groups = (max_units + 4 * (64 / GG) - 1) / (4 * (64 / GG));                                   \
+        if (groups > 256 * 32) groups = 256 * 32; /* the kernel strides over the units it finds */           \
+        hipLaunchKernelGGL(pair_flip_kernel<GG>, dim3((unsigned)groups), dim3(256), 0, s, a);                 \
+    } while (0)
+    switch (D) {
+        case 32: LPF_FLIP(8); break;
+        case 64: LPF_FLIP(16); break;
+        case 128: LPF_FLIP(32); break;
+        case 256: LPF_FLIP(64); break;
+        default: return LPF_ERR_UNSUPPORTED;
+    }
+#undef LPF_FLIP
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

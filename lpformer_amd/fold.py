@@ -42,6 +42,39 @@ def pe_tables(state: dict, dim: int, n_types: int):
     return tab.astype(np.float32), stat.astype(np.float32)
 
 
+def flip_tables(state: dict, dim: int, n_types: int, prefix="att_layers.0.att"):
+    """Tables of the activation-pattern attention kernel (csrc/pair_flip.hip).  The hidden layer of a PE MLP is
+    y_k(x, y) = r(x, y) (ta_k x + tc_k y + td_k) + beta_k followed by ReLU (``pe_tables``), so for the set S0 of units
+    that are active at (x, y) = (0, 0)
+        sum_{k in S0} Wfold[:, k] y_k = P0 (r x) + Q0 (r y) + R0 r + B0,
+    and summed over both argument orders, with bfold:  P0 (r1 pa + r2 pb) + Q0 (r1 pb + r2 pa) + R0 (r1 + r2) + C0,
+    C0 = 2 B0 + bfold.  Returns  base float32[3, 4, D] = (P0, Q0, R0, C0),  s0 uint32[3, D] (1 = unit in S0),
+    wfold_t float32[3, D, D] with wfold_t[t, k, c] = Wfold_t[c, k] (the column added for a unit that left S0).
+    Everything in float64 on the host, stored as fp32."""
+    w_r = _f64(state[f"{prefix}.lin_r.weight"])
+    w_rp = w_r[:, dim:]
+    base = np.zeros((3, 4, dim))
+    s0 = np.zeros((3, dim), np.uint32)
+    wt = np.zeros((3, dim, dim))
+    for t in range(n_types):
+        k = PE_KEYS[t]
+        w1, b1 = _f64(state[f"{k}.linears.0.weight"]), _f64(state[f"{k}.linears.0.bias"])
+        g, be = _f64(state[f"{k}.norm.weight"]), _f64(state[f"{k}.norm.bias"])
+        w2, b2 = _f64(state[f"{k}.linears.1.weight"]), _f64(state[f"{k}.linears.1.bias"])
+        wfold, bfold = w_rp @ w2, w_rp @ (2.0 * b2)
+        ta, tc = g * (w1[:, 0] - w1[:, 0].mean()), g * (w1[:, 1] - w1[:, 1].mean())
+        bc = b1 - b1.mean()
+        td = g * bc
+        r0 = 1.0 / np.sqrt((bc * bc).mean() + 1e-5)          # LayerNorm of the hidden pre-activations at (0, 0)
+        on = (td * r0 + be) > 0
+        s0[t] = on
+        ws = wfold[:, on]
+        base[t, 0], base[t, 1], base[t, 2] = ws @ ta[on], ws @ tc[on], ws @ td[on]
+        base[t, 3] = 2.0 * (ws @ be[on]) + bfold
+        wt[t] = wfold.T
+    return base.astype(np.float32), s0, np.ascontiguousarray(wt.astype(np.float32))
+
+
 def fold_attention(state: dict, dim: int, n_types: int, prefix="att_layers.0.att"):
     """Returns dict of fp32 arrays: w_rx [D,D], b_r [D], wfold [3,D,D], bfold [3,D], wfold_packed (MFMA A-operand
     order), wcat [D, 3D+4] = [Wfold_0 | Wfold_1 | Wfold_2 | bfold_0 bfold_1 bfold_2 | att bias], w_l, b_l2 = 2 b_l."""

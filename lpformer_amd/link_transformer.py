@@ -507,6 +507,11 @@ class LinkTransformer(nn.Module):
         self._side = None
         self.use_tail_chain = True    # score_pairs: lpf_tail_chain_f32 instead of three dense-chain launches
         self.use_fused_attention = True  # one-pass attention on the selection regions
+        # fp32 one-pass attention: "flip" = the key projection of the positional encoding evaluated through the ReLU
+        # activation pattern of its hidden layer (csrc/pair_flip.hip: O(D) per entry + O(D) per unit that left the
+        # pattern of (0, 0); gather-bound), "mfma" = the D x D product per entry on the fp32 matrix cores
+        # (csrc/pair_fused.hip; its cost does not depend on the weights).  Same records, same consumers.
+        self.attention_impl = "flip"
         # "f32" (parity mode, logits within 1e-4 of the reference) or "bf16" (throughput mode of score_pairs: the node
         # table Z is stored in bf16 and Wfold h runs on the bf16 matrix cores; selection and everything else as in f32)
         self.precision = "f32"
@@ -632,7 +637,9 @@ class LinkTransformer(nn.Module):
         n_types = {"all": 3, "1-hop": 2, "cn": 1}[self.mask]
         out = fold.fold_attention(sd, self.dim, n_types)
         out["pe_tab"], out["pe_stat"] = fold.pe_tables(sd, self.dim, n_types)
-        dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
+        out["flip_base"], out["flip_s0"], out["wfold_t"] = fold.flip_tables(sd, self.dim, n_types)
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v.view(np.int32) if v.dtype == np.uint32 else v)).to(self.device)
+               for k, v in out.items()}
         self._folded = (key, dev)
         self._z_cache = None
         self._chain_att._key = None
@@ -1036,6 +1043,11 @@ class LinkTransformer(nn.Module):
                     q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed_bf16"]),
                     ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st),
                     "lpf_pair_attention_fused_bf16")
+            elif self.attention_impl == "flip":
+                check(lib.lpf_pair_attention_flip_f32(
+                    d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q), q.stride(0),
+                    ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["flip_s0"]), ptr(w["wfold_t"]),
+                    ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st), "lpf_pair_attention_flip_f32")
             else:
                 check(lib.lpf_pair_attention_fused_f32(
                     d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q),
