@@ -320,12 +320,14 @@ int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_t *type_ptr
  * every set of active units, so with the four D-vectors of the units active at (0, 0) precomputed
  *   Wfold_t h_e + bfold_t = P0 (r1 pa + r2 pb) + Q0 (r1 pb + r2 pa) + R0 (r1 + r2) + C0 + sum_{k flipped} Wfold_t[:,k] |y_k|
  * (exact for every input; a unit is "flipped" when its ReLU state differs from the one at (0, 0)).  Tables from
- * lpformer_amd/fold.py flip_tables: base float[3][4][D] = (P0, Q0, R0, C0), s0 uint32[3][D], wfold_t float[3][D][D]
- * (wfold_t[t][k][c] = Wfold_t[c][k]).  Bound: the Z-row gather (4 D + 16 bytes per entry) when flips are rare. */
+ * lpformer_amd/fold.py flip_tables: pe_tab_signed float[3][D][4] = the pe_tab row of a unit times +1 when the unit is
+ * active at (0, 0) and -1 when it is not (the kernel then sees a flipped unit as a NEGATIVE pre-activation of
+ * magnitude |y_k|), base float[3][4][D] = (P0, Q0, R0, C0), wfold_t float[3][D][D] (wfold_t[t][k][c] = Wfold_t[c][k]).
+ * Bound: the Z-row gather (4 D + 16 bytes per entry) when flips are rare. */
 int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
-                                const float *Z, int64_t ldz, const float *q, int64_t ldq, const float *pe_tab,
-                                const float *pe_stat, const float *base, const uint32_t *s0, const float *wfold_t,
-                                const float *att, float *part, float *bnd, int64_t units_cap, void *stream);
+                                const float *Z, int64_t ldz, const float *q, int64_t ldq, const float *pe_tab_signed,
+                                const float *pe_stat, const float *base, const float *wfold_t, const float *att,
+                                float *part, float *bnd, int64_t units_cap, void *stream);
 
 /* The attention OUTPUT of every pair from the records of lpf_pair_attention_fused_f32 (for callers that want
  * features, calc_pairwise link_transformer.py:132-178, rather than scores):

@@ -34,10 +34,9 @@ struct FlipArgs {
     int64_t ent_cap;
     const float *Z; int64_t ldz;
     const float *q; int64_t ldq;
-    const float *pe_tab;       // [3][D][4]   (ta, tc, td, beta) per hidden unit
+    const float *pe_tab;       // [3][D][4]   (ta, tc, td, beta) per hidden unit, times +1 (unit in S0) or -1
     const float *pe_stat;      // [3][8]
     const float *base;         // [3][4][D]   P0, Q0, R0, C0 = 2 B0 + bfold
-    const uint32_t *s0;        // [3][D]      1 = unit active at (0, 0)
     const float *wfoldT;       // [3][D][D]   wfoldT[t][k][c] = Wfold_t[c][k]
     const float *att;          // [D]
     float *part;               // [3][bs][D+4]
@@ -45,15 +44,37 @@ struct FlipArgs {
     int64_t units_cap;
 };
 
+// Sum over the G lanes of a group, the same bits in every lane: DPP butterflies inside a row of 16 lanes (quad
+// permutes, then the half-row and the row mirrored: after two steps a quad holds one value, so a mirror IS the xor
+// partner), one swizzle across the rows, one pair of lane reads across the halves -- no LDS round trip per step
+// (__shfl_xor compiles to ds_bpermute_b32: five dependent round trips per entry were a third of this kernel).
+template <int CTRL>
+__device__ __forceinline__ float fl_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 template <int G>
-__device__ __forceinline__ float fl_group_max_i(int v) {
-#pragma unroll
-    for (int m = G >> 1; m > 0; m >>= 1) { const int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+__device__ __forceinline__ float fl_group_sum(float v) {
+    v += fl_dpp<0xB1>(v);                   // quad_perm [1,0,3,2]
+    v += fl_dpp<0x4E>(v);                   // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += fl_dpp<0x141>(v);    // row_half_mirror
+    if constexpr (G >= 16) v += fl_dpp<0x140>(v);   // row_mirror
+    if constexpr (G >= 32)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f));  // lane ^ 16
+    if constexpr (G >= 64) {
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+        const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+        v = a + b;
+    }
     return v;
+}
+// 1 / sqrt(var + eps) of the hidden layer's LayerNorm (closed form, pe_common.h) with the hardware reciprocal square root
+__device__ __forceinline__ float fl_rstd(const PeStat &s, float x, float y) {
+    const float var = s.c00 * x * x + s.c11 * y * y + s.cbb + 2.0f * (s.c01 * x * y + s.c0b * x + s.c1b * y);
+    return __builtin_amdgcn_rsqf(fmaxf(var, 0.0f) + 1e-5f);
 }
 
 template <int G>
-__global__ __launch_bounds__(256, 3) void pair_flip_kernel(const FlipArgs A) {
+__global__ __launch_bounds__(256, 4) void pair_flip_kernel(const FlipArgs A) {
     constexpr int D = 4 * G, RS = D + 4, EPW = 64 / G;
     const int lane = threadIdx.x & 63, grp = lane / G, lj = lane % G, off = 4 * lj;
     int64_t n[3], units[3];
@@ -63,6 +84,20 @@ __global__ __launch_bounds__(256, 3) void pair_flip_kernel(const FlipArgs A) {
         if (n[t] > A.ent_cap) n[t] = A.ent_cap;   // (overflow: flagged by the selection kernel, stay inside the region)
         units[t] = (n[t] + 15) >> 4;
     }
+    // per wavefront: one list of flipped units per group ({hidden unit, |y|}; 2 D slots = every unit in both orders)
+    __shared__ int2 flist_all[4][EPW * 2 * D];
+    __shared__ int fcnt_all[4][EPW];
+    // the per-type tables: tab float4[3][D] (one per hidden unit), base float4[3][4][G] (P0, Q0, R0, C0 by feature quad)
+    __shared__ float4 ltab[3 * D];
+    __shared__ float4 lbase[3 * D];
+    for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) {
+        ltab[i] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
+        lbase[i] = reinterpret_cast<const float4 *>(A.base)[i];   // [t][4][D] floats = [t][4][G] float4 = 3 D float4
+    }
+    __syncthreads();
+    int2 *const flist = flist_all[threadIdx.x >> 6];
+    int *const fcnt = fcnt_all[threadIdx.x >> 6];
+    if (lj == 0) fcnt[grp] = 0;
     const int64_t total_units = units[0] + units[1] + units[2];
     const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -79,15 +114,10 @@ __global__ __launch_bounds__(256, 3) void pair_flip_kernel(const FlipArgs A) {
         const int64_t e0 = U * 16;
         const int nval = live ? (int)(cnt - e0 < 16 ? cnt - e0 : 16) : 0;   // >= 1 for a live unit
 
-        // per-type constants of this lane's four hidden units / features
-        float4 tab[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tab[j] = *reinterpret_cast<const float4 *>(A.pe_tab + ((int64_t)t * D + off + j) * 4);
-        const uint4 s0v = *reinterpret_cast<const uint4 *>(A.s0 + (int64_t)t * D + off);
-        const bool s0a[4] = {s0v.x != 0u, s0v.y != 0u, s0v.z != 0u, s0v.w != 0u};
-        const float *bt = A.base + (int64_t)t * 4 * D + off;
-        const float4 P0 = *reinterpret_cast<const float4 *>(bt), Q0 = *reinterpret_cast<const float4 *>(bt + D);
-        const float4 R0 = *reinterpret_cast<const float4 *>(bt + 2 * D), C0 = *reinterpret_cast<const float4 *>(bt + 3 * D);
+        // per-type constants of this lane's four hidden units / features: read from LDS per entry (kept in registers
+        // they cost 32 VGPRs and the kernel a wavefront of occupancy per SIMD)
+        const float4 *tabl0 = ltab + t * D + off;
+        const float4 *basel0 = lbase + t * D + lj;
         const PeStat st = pe_load_stat(A.pe_stat, t);
         const float *wT = A.wfoldT + (int64_t)t * D * D + off;
 
@@ -122,7 +152,7 @@ __global__ __launch_bounds__(256, 3) void pair_flip_kernel(const FlipArgs A) {
             *reinterpret_cast<float4 *>(dst + off) = o;
             if (lj == 0) *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, __int_as_float(pair), cback ? 0.f : 1.f);
         };
-#pragma unroll
+#pragma unroll 2
         for (int i = 0; i < 16; ++i) {
             const int4 rnn = rec_at(i + 2);
             float4 zn, qn;
@@ -130,46 +160,74 @@ __global__ __launch_bounds__(256, 3) void pair_flip_kernel(const FlipArgs A) {
             const bool on = i < nval;
             const float pa = __int_as_float(rc.z), pb = __int_as_float(rc.w);
             const int pair_i = (int)((uint32_t)rc.x & FL_PAIR_MASK);
-            // hidden layer: this lane's four units, both argument orders; which of them left the pattern of (0, 0)?
-            const float r1 = pe_rstd(st, pa, pb), r2 = pe_rstd(st, pb, pa);
-            float ay[2][4];
-            bool fl = false;
+            // (the table reads below do not depend on the entry: hide that from the optimiser, or it hoists all eight
+            //  of them out of the loop and the registers are gone again)
+            int toff = 0;
+            asm volatile("" : "+v"(toff));
+            const float4 *tabl = tabl0 + toff, *basel = basel0 + toff;
+            // hidden layer: this lane's four units, both argument orders.  The table rows carry the sign of the unit's
+            // state at (0, 0), so z = (+-) y is negative exactly on the units that left that pattern, and |y| = -z.
+            const float r1 = fl_rstd(st, pa, pb), r2 = fl_rstd(st, pb, pa);
+            float zz[2][4];
+            float zmin = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float y1 = fmaf(r1, fmaf(tab[j].x, pa, fmaf(tab[j].y, pb, tab[j].z)), tab[j].w);
-                const float y2 = fmaf(r2, fmaf(tab[j].x, pb, fmaf(tab[j].y, pa, tab[j].z)), tab[j].w);
-                const bool f1 = (y1 > 0.f) != s0a[j], f2 = (y2 > 0.f) != s0a[j];
-                ay[0][j] = f1 ? fabsf(y1) : 0.f;
-                ay[1][j] = f2 ? fabsf(y2) : 0.f;
-                fl = fl || f1 || f2;
+                const float4 tj = tabl[j];
+                zz[0][j] = fmaf(r1, fmaf(tj.x, pa, fmaf(tj.y, pb, tj.z)), tj.w);
+                zz[1][j] = fmaf(r2, fmaf(tj.x, pb, fmaf(tj.y, pa, tj.z)), tj.w);
+                zmin = fminf(zmin, fminf(zz[0][j], zz[1][j]));
             }
+            const bool fl = zmin < 0.f;
             const float ca = fmaf(r1, pa, r2 * pb), cb = fmaf(r1, pb, r2 * pa), cr = r1 + r2;
+            const float4 P0 = basel[0], Q0 = basel[G], R0 = basel[2 * G], C0 = basel[3 * G];
             float k[4] = {zc.x + fmaf(P0.x, ca, fmaf(Q0.x, cb, fmaf(R0.x, cr, C0.x))),
                           zc.y + fmaf(P0.y, ca, fmaf(Q0.y, cb, fmaf(R0.y, cr, C0.y))),
                           zc.z + fmaf(P0.z, ca, fmaf(Q0.z, cb, fmaf(R0.z, cr, C0.z))),
                           zc.w + fmaf(P0.w, ca, fmaf(Q0.w, cb, fmaf(R0.w, cr, C0.w)))};
-            if (__ballot(fl && on)) {   // rare: add Wfold[:, k] |y_k| for every flipped unit of every group of the wave
+            if (__ballot(fl && on)) {
+                // Some unit of some group left the pattern of (0, 0): every lane of that group owes Wfold[:, k] |y_k| for
+                // it.  The lanes that own flipped units append {k, |y_k|} to their group's list in LDS (wave-private,
+                // 2 D slots: cannot overflow), then every lane walks its group's list, four columns of Wfold^T in
+                // flight at a time.
+                if (fl && on) {
 #pragma unroll
-                for (int oj = 0; oj < 8; ++oj) {
-                    const float mine = ay[oj >> 2][oj & 3];
-                    uint64_t bm = __ballot(mine != 0.f && on);
-                    while (bm) {
-                        const int b = __ffsll((unsigned long long)bm) - 1;
-                        bm &= bm - 1;
-                        const float val = __shfl(mine, b, 64);
-                        if (b / G == grp) {
-                            const int kk = 4 * (b % G) + (oj & 3);
-                            const float4 w = *reinterpret_cast<const float4 *>(wT + (int64_t)kk * D);
-                            k[0] = fmaf(w.x, val, k[0]); k[1] = fmaf(w.y, val, k[1]);
-                            k[2] = fmaf(w.z, val, k[2]); k[3] = fmaf(w.w, val, k[3]);
+                    for (int oj = 0; oj < 8; ++oj) {
+                        const float mine = -zz[oj >> 2][oj & 3];
+                        if (mine > 0.f) {
+                            const int slot = atomicAdd(&fcnt[grp], 1);
+                            flist[grp * 2 * D + slot] = make_int2(off + (oj & 3), __float_as_int(mine));
                         }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int mine_n = fcnt[grp];
+                int max_n = mine_n;
+#pragma unroll
+                for (int dd = G; dd < 64; dd <<= 1) { const int o2 = __shfl_xor(max_n, dd, 64); max_n = o2 > max_n ? o2 : max_n; }
+                max_n = __builtin_amdgcn_readfirstlane(max_n);
+                for (int it = 0; it < max_n; it += 4) {
+                    int2 fe[4];
+                    float4 w4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        fe[u] = it + u < mine_n ? flist[grp * 2 * D + it + u] : make_int2(0, 0);   // (0: adds nothing)
+                        w4[u] = *reinterpret_cast<const float4 *>(wT + (int64_t)fe[u].x * D);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float val = __int_as_float(fe[u].y);
+                        k[0] = fmaf(w4[u].x, val, k[0]); k[1] = fmaf(w4[u].y, val, k[1]);
+                        k[2] = fmaf(w4[u].z, val, k[2]); k[3] = fmaf(w4[u].w, val, k[3]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lj == 0) fcnt[grp] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             // score of the entry: att . leaky_relu(k * q, 0.2), summed over the group's lanes
             float x0 = k[0] * qc.x, x1 = k[1] * qc.y, x2 = k[2] * qc.z, x3 = k[3] * qc.w;
             x0 = fmaxf(x0, 0.2f * x0); x1 = fmaxf(x1, 0.2f * x1); x2 = fmaxf(x2, 0.2f * x2); x3 = fmaxf(x3, 0.2f * x3);
-            const float s = lpf_group_sum<G>(fmaf(x0, at.x, fmaf(x1, at.y, fmaf(x2, at.z, x3 * at.w))));
+            const float s = fl_group_sum<G>(fmaf(x0, at.x, fmaf(x1, at.y, fmaf(x2, at.z, x3 * at.w))));
             if (on) {
                 if (i > 0 && pair_i != last_pair) {   // the previous entry closed a segment
                     flush(cur_pair, first ? st0 : true, true);
@@ -197,16 +255,16 @@ __global__ __launch_bounds__(256, 3) void pair_flip_kernel(const FlipArgs A) {
 
 extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
                                            int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
-                                           const float *pe_tab, const float *pe_stat, const float *base,
-                                           const uint32_t *s0, const float *wfold_t, const float *att, float *part,
+                                           const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                           const float *wfold_t, const float *att, float *part,
                                            float *bnd, int64_t units_cap, void *stream) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && Z && q && pe_tab && pe_stat && base && s0 && wfold_t &&
+    LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && Z && q && pe_tab_signed && pe_stat && base && wfold_t &&
                 att && part && bnd && units_cap >= (ent_cap + 15) / 16);
     LPF_REQUIRE(ldz >= D && ldq >= D && (ldz & 3) == 0 && (ldq & 3) == 0 && lpf_aligned16(entries) && lpf_aligned16(Z) &&
-                lpf_aligned16(q) && lpf_aligned16(pe_tab) && lpf_aligned16(base) && lpf_aligned16(s0) &&
+                lpf_aligned16(q) && lpf_aligned16(pe_tab_signed) && lpf_aligned16(base) &&
                 lpf_aligned16(wfold_t) && lpf_aligned16(att) && lpf_aligned16(part) && lpf_aligned16(bnd));
-    const FlipArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, Z, ldz, q, ldq, pe_tab, pe_stat, base, s0,
+    const FlipArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, base,
                      wfold_t, att, part, bnd, units_cap};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t max_units = 3 * ((ent_cap + 15) / 16) + 3;

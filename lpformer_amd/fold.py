@@ -48,12 +48,15 @@ def flip_tables(state: dict, dim: int, n_types: int, prefix="att_layers.0.att"):
     that are active at (x, y) = (0, 0)
         sum_{k in S0} Wfold[:, k] y_k = P0 (r x) + Q0 (r y) + R0 r + B0,
     and summed over both argument orders, with bfold:  P0 (r1 pa + r2 pb) + Q0 (r1 pb + r2 pa) + R0 (r1 + r2) + C0,
-    C0 = 2 B0 + bfold.  Returns  base float32[3, 4, D] = (P0, Q0, R0, C0),  s0 uint32[3, D] (1 = unit in S0),
-    wfold_t float32[3, D, D] with wfold_t[t, k, c] = Wfold_t[c, k] (the column added for a unit that left S0).
+    C0 = 2 B0 + bfold.  Returns  tab_signed float32[3, D, 4] = (ta, tc, td, beta) of every unit times +1 (unit in S0)
+    or -1 (not in S0) -- the kernel evaluates z_k = (+-) y_k and a unit has left the pattern of (0, 0) exactly when
+    z_k < 0, its correction being Wfold[:, k] |y_k| = -Wfold[:, k] z_k --,  base float32[3, 4, D] = (P0, Q0, R0, C0),
+    s0 uint32[3, D] (1 = unit in S0; tests),  wfold_t float32[3, D, D] with wfold_t[t, k, c] = Wfold_t[c, k].
     Everything in float64 on the host, stored as fp32."""
     w_r = _f64(state[f"{prefix}.lin_r.weight"])
     w_rp = w_r[:, dim:]
     base = np.zeros((3, 4, dim))
+    tabs = np.zeros((3, dim, 4))
     s0 = np.zeros((3, dim), np.uint32)
     wt = np.zeros((3, dim, dim))
     for t in range(n_types):
@@ -68,11 +71,12 @@ def flip_tables(state: dict, dim: int, n_types: int, prefix="att_layers.0.att"):
         r0 = 1.0 / np.sqrt((bc * bc).mean() + 1e-5)          # LayerNorm of the hidden pre-activations at (0, 0)
         on = (td * r0 + be) > 0
         s0[t] = on
+        tabs[t] = np.stack([ta, tc, td, be], axis=1) * np.where(on, 1.0, -1.0)[:, None]
         ws = wfold[:, on]
         base[t, 0], base[t, 1], base[t, 2] = ws @ ta[on], ws @ tc[on], ws @ td[on]
         base[t, 3] = 2.0 * (ws @ be[on]) + bfold
         wt[t] = wfold.T
-    return base.astype(np.float32), s0, np.ascontiguousarray(wt.astype(np.float32))
+    return tabs.astype(np.float32), base.astype(np.float32), s0, np.ascontiguousarray(wt.astype(np.float32))
 
 
 def fold_attention(state: dict, dim: int, n_types: int, prefix="att_layers.0.att"):

@@ -637,9 +637,8 @@ class LinkTransformer(nn.Module):
         n_types = {"all": 3, "1-hop": 2, "cn": 1}[self.mask]
         out = fold.fold_attention(sd, self.dim, n_types)
         out["pe_tab"], out["pe_stat"] = fold.pe_tables(sd, self.dim, n_types)
-        out["flip_base"], out["flip_s0"], out["wfold_t"] = fold.flip_tables(sd, self.dim, n_types)
-        dev = {k: torch.from_numpy(np.ascontiguousarray(v.view(np.int32) if v.dtype == np.uint32 else v)).to(self.device)
-               for k, v in out.items()}
+        out["flip_tab"], out["flip_base"], _, out["wfold_t"] = fold.flip_tables(sd, self.dim, n_types)
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
         self._folded = (key, dev)
         self._z_cache = None
         self._chain_att._key = None
@@ -1046,7 +1045,7 @@ class LinkTransformer(nn.Module):
             elif self.attention_impl == "flip":
                 check(lib.lpf_pair_attention_flip_f32(
                     d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q), q.stride(0),
-                    ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["flip_s0"]), ptr(w["wfold_t"]),
+                    ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["wfold_t"]),
                     ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st), "lpf_pair_attention_flip_f32")
             else:
                 check(lib.lpf_pair_attention_fused_f32(

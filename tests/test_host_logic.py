@@ -148,6 +148,46 @@ def test_fold_algebra_matches_oracle():
     assert pk[2, c, sq, lane, u] == w["wfold"][2, 32 * c + (lane & 31), (lane >> 5) * (d // 2) + 4 * sq + u]
 
 
+def test_flip_tables_reproduce_the_key_projection():
+    """The activation-pattern form of the PE key projection (csrc/pair_flip.hip): with the four base vectors of the units
+    active at (0, 0) and a correction Wfold[:, k] |y_k| per unit whose ReLU state differs from that pattern,
+    Wfold h_e + bfold comes out as the reference's lin_r([. ; pe_e]) -- for inputs near 0 (no unit flips), for typical PPR
+    values and for large ones (many flips), in float64 to 1e-9 of the direct product."""
+    fx = Fixture("lp_all_d64")
+    m_sd, _ = fx.state_dicts()
+    sd = {k: torch.from_numpy(v) for k, v in m_sd.items()}
+    d = fx.cfg["dim"]
+    w = fold.fold_attention(sd, d, 3)
+    tab, stat = (a.astype(np.float64) for a in fold.pe_tables(sd, d, 3))
+    tabs, base, s0, wt = fold.flip_tables(sd, d, 3)
+    tabs, base, wt = tabs.astype(np.float64), base.astype(np.float64), wt.astype(np.float64)
+    rng = np.random.default_rng(1)
+    flips_seen = 0
+    for scale in (1e-4, 2e-2, 0.5, 5.0):
+        pa, pb = rng.random(64) * scale, rng.random(64) * scale
+        for t in range(3):
+            def rstd(x, y):
+                var = (stat[t, 0] * x * x + stat[t, 1] * y * y + stat[t, 2]
+                       + 2 * (stat[t, 3] * x * y + stat[t, 4] * x + stat[t, 5] * y))
+                return 1.0 / np.sqrt(var + 1e-5)
+
+            def pre(tb, x, y, r):
+                return r[:, None] * (tb[t, :, 0][None] * x[:, None] + tb[t, :, 1][None] * y[:, None] + tb[t, :, 2][None]) \
+                    + tb[t, :, 3][None]
+            r1, r2 = rstd(pa, pb), rstd(pb, pa)
+            h = np.maximum(pre(tab, pa, pb, r1), 0) + np.maximum(pre(tab, pb, pa, r2), 0)
+            want = h @ w["wfold"][t].astype(np.float64).T + w["bfold"][t]
+            # the kernel's evaluation
+            z1, z2 = pre(tabs, pa, pb, r1), pre(tabs, pb, pa, r2)        # negative <=> the unit left the pattern of (0, 0)
+            got = (base[t, 0][None] * (r1 * pa + r2 * pb)[:, None] + base[t, 1][None] * (r1 * pb + r2 * pa)[:, None]
+                   + base[t, 2][None] * (r1 + r2)[:, None] + base[t, 3][None])
+            got = got + np.maximum(-z1, 0) @ wt[t] + np.maximum(-z2, 0) @ wt[t]
+            flips_seen += int((z1 < 0).sum() + (z2 < 0).sum())
+            assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())   # (fp32-stored tables)
+    assert flips_seen > 100           # the large inputs did exercise the correction path
+    assert set(np.unique(s0)) <= {0, 1}
+
+
 def test_ppr_cache_round_trip(tmp_path):
     """load_or_calc_ppr: first call computes and stores under the reference's directory / file naming, the second
     call reads the same matrix back; a cache for another graph size is refused."""
