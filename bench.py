@@ -207,6 +207,9 @@ def main():
                          "layer and the per-node attention projections sharded with ONE all-gather of [X | Z | Y]; "
                          "auto = the cheapest by lpformer_amd.dist.encoder_plan (measured encoder, last-layer and "
                          "projection times, measured all-gather rate)")
+    ap.add_argument("--attention", default="auto", choices=("auto", "flip", "mfma"),
+                    help="fp32 one-pass attention kernel: activation-pattern evaluation of the PE key projection "
+                         "(pair_flip.hip, gather-bound) or the D x D product on the fp32 matrix cores (pair_fused.hip)")
     ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
@@ -228,6 +231,7 @@ def main():
     model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev).eval()
     score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
     model.use_side_stream = not args.no_side_stream
+    model.attention_impl = args.attention
     enc_plan = None
     if world > 1:
         # encoder layout: measure the whole encoder on one GPU (replicated mode) and the all-gather of an [N, D] fp32
@@ -437,8 +441,13 @@ def main():
             slots = mean([s["slots"] for s in stats])
             c = model.count_dim
             work = {
-                # one-pass attention (score + segment softmax + weighted sum): SURVEY 8(d) n_sel * (2 D^2 + ~20 D)
-                "pair_attention_fused": ("mfma", n_sel * (2.0 * d * d + 20.0 * d)),
+                # one-pass attention (score + segment softmax + weighted sum).  "mfma": SURVEY 8(d) n_sel * (2 D^2 +
+                # ~20 D) FLOP on the fp32 matrix cores.  "flip" (default): the D x D product is gone, what
+                # is left is the gather -- one fp32 Z row + one 16-byte record per selected entry, one q row read and
+                # about one (D + 4)-float record written per pair: SURVEY 8(d)'s e D (2 + n_sel) term of B_pair
+                "pair_attention_fused": (("hbm", n_sel * (4.0 * d + 16.0) + bs * (4.0 * d + 4.0 * (d + 4)))
+                                         if model.attention_kernel() == "flip" else
+                                         ("mfma", n_sel * (2.0 * d * d + 20.0 * d))),
                 # legacy two-pass kernels (D = 256 and the module-by-module API)
                 "pair_scores": ("mfma", n_sel * (2.0 * d * d + 20.0 * d)),
                 "pair_softmax_gather": ("hbm", n_sel * (4.0 * d + 16.0) + bs * (4.0 * (4 * d + 4) + 48.0)),
@@ -540,7 +549,7 @@ def main():
                                    f"PPR eps={cfg['eps']}), {bs} candidate pairs per GPU per step, pair stage with "
                                    "encoder output resident",
                        "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
-                       "streams": len(lanes), "spinup_s": args.spinup,
+                       "streams": len(lanes), "spinup_s": args.spinup, "attention_impl": model.attention_kernel(),
                        "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']} " +
                                        {"sharded": "(rows + all-gather per layer)",
                                         "gather_once": "(last layer + Z / Y on row blocks, one all-gather of [X | Z | Y])",

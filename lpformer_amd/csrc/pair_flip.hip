@@ -73,9 +73,17 @@ __device__ __forceinline__ float fl_rstd(const PeStat &s, float x, float y) {
     return __builtin_amdgcn_rsqf(fmaxf(var, 0.0f) + 1e-5f);
 }
 
-template <int G>
-__global__ __launch_bounds__(256, 4) void pair_flip_kernel(const FlipArgs A) {
+// G = D/4 lanes per entry; NTH threads per workgroup; WTL = how many types keep their Wfold^T in LDS (1: the one-hop
+// type, which holds most of the entries -- and most of the flips: they sit in the ~10 % of the entries with a PPR value
+// above ~0.03, typically six or seven units each; 3: all; 0: none, the columns come from L2).  A correction column read
+// from LDS costs a dozen instructions; fetched from L2 it cost as much as the rest of the kernel (105 vs 55 us).
+template <int G, int NTH, int WTL>
+__global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(const FlipArgs A) {
     constexpr int D = 4 * G, RS = D + 4, EPW = 64 / G;
+    extern __shared__ __attribute__((aligned(16))) float4 fl_lds[];
+    float4 *const ltab = fl_lds;                 // [4][3][G]: row j of hidden unit 4 lj + j, type t -> ((j * 3 + t) * G + lj)
+    float4 *const lbase = fl_lds + 3 * D;        // [3][4][G]: P0, Q0, R0, C0 by feature quad
+    float4 *const lwt = fl_lds + 6 * D;          // [WTL][D][G]: Wfold^T rows of the resident types
     const int lane = threadIdx.x & 63, grp = lane / G, lj = lane % G, off = 4 * lj;
     int64_t n[3], units[3];
 #pragma unroll
@@ -84,23 +92,20 @@ __global__ __launch_bounds__(256, 4) void pair_flip_kernel(const FlipArgs A) {
         if (n[t] > A.ent_cap) n[t] = A.ent_cap;   // (overflow: flagged by the selection kernel, stay inside the region)
         units[t] = (n[t] + 15) >> 4;
     }
-    // per wavefront: one list of flipped units per group ({hidden unit, |y|}; 2 D slots = every unit in both orders)
-    __shared__ int2 flist_all[4][EPW * 2 * D];
-    __shared__ int fcnt_all[4][EPW];
-    // the per-type tables: tab float4[3][D] (one per hidden unit), base float4[3][4][G] (P0, Q0, R0, C0 by feature quad)
-    __shared__ float4 ltab[3 * D];
-    __shared__ float4 lbase[3 * D];
-    for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) {
-        ltab[i] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
-        lbase[i] = reinterpret_cast<const float4 *>(A.base)[i];   // [t][4][D] floats = [t][4][G] float4 = 3 D float4
+    const int64_t total_units = units[0] + units[1] + units[2];
+    if ((int64_t)blockIdx.x * (NTH / 64) * EPW >= total_units) return;
+    for (int i = threadIdx.x; i < 3 * D; i += NTH) {
+        const int t = i / D, k = i % D;           // pe_tab[t][k] -> row k & 3 of the lane that owns unit k
+        ltab[((k & 3) * 3 + t) * G + (k >> 2)] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
+        lbase[i] = reinterpret_cast<const float4 *>(A.base)[i];   // [t][4][D] floats = [t][4][G] float4
+    }
+    if constexpr (WTL > 0) {
+        const float4 *src = reinterpret_cast<const float4 *>(A.wfoldT) + (WTL == 1 ? (int64_t)D * G : 0);
+        for (int i = threadIdx.x; i < WTL * D * G; i += NTH) lwt[i] = src[i];
     }
     __syncthreads();
-    int2 *const flist = flist_all[threadIdx.x >> 6];
-    int *const fcnt = fcnt_all[threadIdx.x >> 6];
-    if (lj == 0) fcnt[grp] = 0;
-    const int64_t total_units = units[0] + units[1] + units[2];
-    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave_id = (int64_t)blockIdx.x * (NTH / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (NTH / 64);
     const float4 at = *reinterpret_cast<const float4 *>(A.att + off);
 
     for (int64_t u0 = wave_id * EPW; u0 < total_units; u0 += n_waves * EPW) {
@@ -113,50 +118,59 @@ __global__ __launch_bounds__(256, 4) void pair_flip_kernel(const FlipArgs A) {
         const int4 *ent = A.entries + (int64_t)t * A.ent_cap;
         const int64_t e0 = U * 16;
         const int nval = live ? (int)(cnt - e0 < 16 ? cnt - e0 : 16) : 0;   // >= 1 for a live unit
-
-        // per-type constants of this lane's four hidden units / features: read from LDS per entry (kept in registers
-        // they cost 32 VGPRs and the kernel a wavefront of occupancy per SIMD)
-        const float4 *tabl0 = ltab + t * D + off;
-        const float4 *basel0 = lbase + t * D + lj;
+        const float4 *tabl0 = ltab + t * G + lj;      // rows j at tabl0[3 G j]
+        const float4 *basel0 = lbase + t * D + lj;    // P0, Q0, R0, C0 at basel0[G v]
         const PeStat st = pe_load_stat(A.pe_stat, t);
         const float *wT = A.wfoldT + (int64_t)t * D * D + off;
+        const bool wt_lds = WTL == 3 || (WTL == 1 && t == 1);
+        const float4 *lw = lwt + (WTL == 3 ? t * D * G : 0) + lj;
 
         // neighbours of the unit: does its first entry start a segment, does its last one end one?
-        int prev_pair = -1;
-        if (e0 > 0) prev_pair = (int)((uint32_t)ent[e0 - 1].x & FL_PAIR_MASK);
-        bool cont = false;
-        if (nval == 16 && e0 + 16 < cnt)
-            cont = ((uint32_t)ent[e0 + 16].x & FL_PAIR_MASK) == ((uint32_t)ent[e0 + 15].x & FL_PAIR_MASK);
-        float *const part_t = A.part + (int64_t)t * A.bs * RS;
-        float *const bnd_u = A.bnd + (((int64_t)t * A.units_cap + U) * 2) * RS;
-
-        // the walk: records two entries ahead, Z / q rows one entry ahead of the arithmetic
-        auto rec_at = [&](int i) __attribute__((always_inline)) {
+        auto rec_at = [&](int64_t i) __attribute__((always_inline)) {   // (clamped into the unit's valid entries)
             const int64_t e = e0 + (i < nval ? i : (nval > 0 ? nval - 1 : 0));
             return ent[live ? e : 0];
         };
-        int4 rc = rec_at(0), rn = rec_at(1);
-        auto rows = [&](const int4 &r, float4 &z, float4 &qq) __attribute__((always_inline)) {
-            z = *reinterpret_cast<const float4 *>(A.Z + (int64_t)r.y * A.ldz + off);
-            qq = *reinterpret_cast<const float4 *>(A.q + (int64_t)((uint32_t)r.x & FL_PAIR_MASK) * A.ldq + off);
-        };
-        float4 zc, qc;
-        rows(rc, zc, qc);
+        const int4 r_prev = ent[e0 > 0 ? e0 - 1 : 0], r_next = ent[(nval == 16 && e0 + 16 < cnt) ? e0 + 16 : e0];
+        const int4 r_last = rec_at(15);
+        const int prev_pair = e0 > 0 ? (int)((uint32_t)r_prev.x & FL_PAIR_MASK) : -1;
+        const bool cont = nval == 16 && e0 + 16 < cnt &&
+                          ((uint32_t)r_next.x & FL_PAIR_MASK) == ((uint32_t)r_last.x & FL_PAIR_MASK);
+        float *const part_t = A.part + (int64_t)t * A.bs * RS;
+        float *const bnd_u = A.bnd + (((int64_t)t * A.units_cap + U) * 2) * RS;
+
         float m = -INFINITY, l = 0.f;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         bool first = true;                       // no record flushed yet by this unit
-        const bool st0 = e0 == 0 || prev_pair != (int)((uint32_t)rc.x & FL_PAIR_MASK);   // entry 0 starts a segment
-        int cur_pair = (int)((uint32_t)rc.x & FL_PAIR_MASK), last_pair = prev_pair;
+        int cur_pair = 0, last_pair = prev_pair;
+        bool st0 = false;
         auto flush = [&](int pair, bool cfront, bool cback) __attribute__((always_inline)) {
             float *dst = (cfront && cback) ? part_t + (int64_t)pair * RS : bnd_u + (cfront ? RS : 0);
             *reinterpret_cast<float4 *>(dst + off) = o;
             if (lj == 0) *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, __int_as_float(pair), cback ? 0.f : 1.f);
         };
-#pragma unroll 2
-        for (int i = 0; i < 16; ++i) {
-            const int4 rnn = rec_at(i + 2);
-            float4 zn, qn;
-            rows(rn, zn, qn);
+        // the walk, four entries at a time: their records, then their four Z rows, are requested together (one memory
+        // round trip per four entries); the q row of the next entry rides one step ahead of the arithmetic
+#pragma unroll 1
+        for (int qt = 0; qt < 4; ++qt) {
+          int4 rec4[4];
+          float4 z4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rec4[u] = rec_at(4 * qt + u);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) z4[u] = *reinterpret_cast<const float4 *>(A.Z + (int64_t)rec4[u].y * A.ldz + off);
+          float4 qc = *reinterpret_cast<const float4 *>(A.q + (int64_t)((uint32_t)rec4[0].x & FL_PAIR_MASK) * A.ldq + off);
+          if (qt == 0) {
+              cur_pair = (int)((uint32_t)rec4[0].x & FL_PAIR_MASK);
+              st0 = e0 == 0 || prev_pair != cur_pair;      // entry 0 starts a segment
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = 4 * qt + u;
+            const int4 rc = rec4[u];
+            const float4 zc = z4[u];
+            const float4 qn = *reinterpret_cast<const float4 *>(
+                A.q + (int64_t)((uint32_t)rec4[u < 3 ? u + 1 : 3].x & FL_PAIR_MASK) * A.ldq + off);
             const bool on = i < nval;
             const float pa = __int_as_float(rc.z), pb = __int_as_float(rc.w);
             const int pair_i = (int)((uint32_t)rc.x & FL_PAIR_MASK);
@@ -172,57 +186,39 @@ __global__ __launch_bounds__(256, 4) void pair_flip_kernel(const FlipArgs A) {
             float zmin = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 tj = tabl[j];
+                const float4 tj = tabl[3 * G * j];
                 zz[0][j] = fmaf(r1, fmaf(tj.x, pa, fmaf(tj.y, pb, tj.z)), tj.w);
                 zz[1][j] = fmaf(r2, fmaf(tj.x, pb, fmaf(tj.y, pa, tj.z)), tj.w);
                 zmin = fminf(zmin, fminf(zz[0][j], zz[1][j]));
             }
-            const bool fl = zmin < 0.f;
+            const bool fl = zmin < 0.f && on;
             const float ca = fmaf(r1, pa, r2 * pb), cb = fmaf(r1, pb, r2 * pa), cr = r1 + r2;
             const float4 P0 = basel[0], Q0 = basel[G], R0 = basel[2 * G], C0 = basel[3 * G];
             float k[4] = {zc.x + fmaf(P0.x, ca, fmaf(Q0.x, cb, fmaf(R0.x, cr, C0.x))),
                           zc.y + fmaf(P0.y, ca, fmaf(Q0.y, cb, fmaf(R0.y, cr, C0.y))),
                           zc.z + fmaf(P0.z, ca, fmaf(Q0.z, cb, fmaf(R0.z, cr, C0.z))),
                           zc.w + fmaf(P0.w, ca, fmaf(Q0.w, cb, fmaf(R0.w, cr, C0.w)))};
-            if (__ballot(fl && on)) {
+            if (__ballot(fl)) {
                 // Some unit of some group left the pattern of (0, 0): every lane of that group owes Wfold[:, k] |y_k| for
-                // it.  The lanes that own flipped units append {k, |y_k|} to their group's list in LDS (wave-private,
-                // 2 D slots: cannot overflow), then every lane walks its group's list, four columns of Wfold^T in
-                // flight at a time.
-                if (fl && on) {
+                // it.  One pass over the eight (order, unit-of-the-lane) slots; the flipped lanes of a slot are taken one
+                // at a time (scalar loop), the owner's |y| is read across the wave, the group's lanes add their piece of
+                // the column -- from LDS when the type's table is resident.
 #pragma unroll
-                    for (int oj = 0; oj < 8; ++oj) {
-                        const float mine = -zz[oj >> 2][oj & 3];
-                        if (mine > 0.f) {
-                            const int slot = atomicAdd(&fcnt[grp], 1);
-                            flist[grp * 2 * D + slot] = make_int2(off + (oj & 3), __float_as_int(mine));
+                for (int oj = 0; oj < 8; ++oj) {
+                    const float zv = zz[oj >> 2][oj & 3];
+                    uint64_t bm = __ballot(zv < 0.f && on);
+                    while (bm) {
+                        const int b = __builtin_ctzll(bm);
+                        bm &= bm - 1;
+                        const float val = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zv), b));
+                        if (b / G == grp) {
+                            const int kk = 4 * (b % G) + (oj & 3);
+                            const float4 w = wt_lds ? lw[kk * G] : *reinterpret_cast<const float4 *>(wT + (int64_t)kk * D);
+                            k[0] = fmaf(w.x, val, k[0]); k[1] = fmaf(w.y, val, k[1]);
+                            k[2] = fmaf(w.z, val, k[2]); k[3] = fmaf(w.w, val, k[3]);
                         }
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int mine_n = fcnt[grp];
-                int max_n = mine_n;
-#pragma unroll
-                for (int dd = G; dd < 64; dd <<= 1) { const int o2 = __shfl_xor(max_n, dd, 64); max_n = o2 > max_n ? o2 : max_n; }
-                max_n = __builtin_amdgcn_readfirstlane(max_n);
-                for (int it = 0; it < max_n; it += 4) {
-                    int2 fe[4];
-                    float4 w4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        fe[u] = it + u < mine_n ? flist[grp * 2 * D + it + u] : make_int2(0, 0);   // (0: adds nothing)
-                        w4[u] = *reinterpret_cast<const float4 *>(wT + (int64_t)fe[u].x * D);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float val = __int_as_float(fe[u].y);
-                        k[0] = fmaf(w4[u].x, val, k[0]); k[1] = fmaf(w4[u].y, val, k[1]);
-                        k[2] = fmaf(w4[u].z, val, k[2]); k[3] = fmaf(w4[u].w, val, k[3]);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (lj == 0) fcnt[grp] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             // score of the entry: att . leaky_relu(k * q, 0.2), summed over the group's lanes
             float x0 = k[0] * qc.x, x1 = k[1] * qc.y, x2 = k[2] * qc.z, x3 = k[3] * qc.w;
@@ -244,8 +240,9 @@ __global__ __launch_bounds__(256, 4) void pair_flip_kernel(const FlipArgs A) {
                 m = mn;
                 last_pair = pair_i;
             }
-            rc = rn; rn = rnn; zc = zn; qc = qn;
-            __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler hoists the whole unit's loads: 170 VGPRs)
+            qc = qn;
+            __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler hoists every load of the batch to its top)
+          }
         }
         if (nval > 0) flush(cur_pair, first ? st0 : true, !cont);
     }
@@ -267,18 +264,36 @@ extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t 
     const FlipArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, base,
                      wfold_t, att, part, bnd, units_cap};
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
+        n_cu = prop.multiProcessorCount;
+    }
     const int64_t max_units = 3 * ((ent_cap + 15) / 16) + 3;
-#define LPF_FLIP(GG)                                                                                          \
-    do {                                                                                                      \
-        int64_t groups = (max_units + 4 * (64 / GG) - 1) / (4 * (64 / GG));                                   \
-        if (groups > 256 * 32) groups = 256 * 32; /* the kernel strides over the units it finds */           \
-        hipLaunchKernelGGL(pair_flip_kernel<GG>, dim3((unsigned)groups), dim3(256), 0, s, a);                 \
+    // persistent workgroups (they stride over the units they find): two of 512 threads per CU when a Wfold^T table lives
+    // in LDS (64 KB at D = 128), three of 256 otherwise
+#define LPF_FLIP(GG, NTH, WTL, PER_CU)                                                                          \
+    do {                                                                                                        \
+        auto kern = pair_flip_kernel<GG, NTH, WTL>;                                                             \
+        constexpr size_t lds = (size_t)(6 * 4 * GG + WTL * 4 * GG * GG) * sizeof(float4);                       \
+        static bool lds_set = false;                                                                            \
+        if (lds > 64 * 1024 && !lds_set) {                                                                      \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds) != hipSuccess)                                                    \
+                return LPF_ERR_LAUNCH;                                                                          \
+            lds_set = true;                                                                                     \
+        }                                                                                                       \
+        int64_t groups = (max_units + (NTH / 64) * (64 / GG) - 1) / ((NTH / 64) * (64 / GG));                   \
+        if (groups > (int64_t)n_cu * PER_CU) groups = (int64_t)n_cu * PER_CU;                                   \
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(NTH), lds, s, a);                                 \
     } while (0)
     switch (D) {
-        case 32: LPF_FLIP(8); break;
-        case 64: LPF_FLIP(16); break;
-        case 128: LPF_FLIP(32); break;
-        case 256: LPF_FLIP(64); break;
+        case 32: LPF_FLIP(8, 512, 3, 2); break;
+        case 64: LPF_FLIP(16, 512, 3, 2); break;
+        case 128: LPF_FLIP(32, 512, 1, 2); break;
+        case 256: LPF_FLIP(64, 256, 0, 3); break;
         default: return LPF_ERR_UNSUPPORTED;
     }
 #undef LPF_FLIP

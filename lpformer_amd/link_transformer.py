@@ -511,7 +511,8 @@ class LinkTransformer(nn.Module):
         # activation pattern of its hidden layer (csrc/pair_flip.hip: O(D) per entry + O(D) per unit that left the
         # pattern of (0, 0); gather-bound), "mfma" = the D x D product per entry on the fp32 matrix cores
         # (csrc/pair_fused.hip; its cost does not depend on the weights).  Same records, same consumers.
-        self.attention_impl = "flip"
+        self.attention_impl = "auto"   # "auto": "flip" for D >= 128, "mfma" below (at D = 64 the matrix-core kernel's
+        #                                2 D^2 FLOP per entry take 22 us on the ppa-like batch, the flip kernel 33)
         # "f32" (parity mode, logits within 1e-4 of the reference) or "bf16" (throughput mode of score_pairs: the node
         # table Z is stored in bf16 and Wfold h runs on the bf16 matrix cores; selection and everything else as in f32)
         self.precision = "f32"
@@ -1014,6 +1015,12 @@ class LinkTransformer(nn.Module):
         side.wait_stream(main)
         return side
 
+    def attention_kernel(self) -> str:
+        """The fp32 one-pass attention kernel this model runs: ``attention_impl`` with "auto" resolved."""
+        if self.attention_impl == "auto":
+            return "flip" if self.dim >= 128 else "mfma"
+        return self.attention_impl
+
     def _fused_attention(self, batch, x_node, test_set, adj_mask, side):
         """q gather (side stream) -> selection (two launches, nothing read back) -> one-pass attention.  Returns the
         selection workspace and the record buffers (part, bnd, units_cap) for ``lpf_tail_chain_merge_*`` /
@@ -1042,7 +1049,7 @@ class LinkTransformer(nn.Module):
                     q.stride(0), ptr(w["pe_tab"]), ptr(w["pe_stat"]), ptr(w["wfold_packed_bf16"]),
                     ptr(w["bfold"]), ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st),
                     "lpf_pair_attention_fused_bf16")
-            elif self.attention_impl == "flip":
+            elif self.attention_kernel() == "flip":
                 check(lib.lpf_pair_attention_flip_f32(
                     d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(z), z.stride(0), ptr(q), q.stride(0),
                     ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["wfold_t"]),

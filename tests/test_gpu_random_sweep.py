@@ -77,8 +77,59 @@ def test_random_config_matches_oracle(case):
             np.testing.assert_array_equal(info[0].cpu().numpy(), ref["sel"][tag][0])
             np.testing.assert_array_equal(info[1].cpu().numpy().view(np.uint32), ref["sel"][tag][1].view(np.uint32))
             np.testing.assert_array_equal(info[2].cpu().numpy().view(np.uint32), ref["sel"][tag][2].view(np.uint32))
-        feats = model(torch.from_numpy(batch))
-        scale = max(1.0, float(np.abs(ref["combined_feats"]).max()))
-        assert np.abs(feats.cpu().numpy() - ref["combined_feats"]).max() <= TOL * scale
-        assert np.abs(score.logits(feats).cpu().numpy() - ref["logit"]).max() <= TOL * max(1.0, float(np.abs(ref["logit"]).max()))
+        for impl in ("flip", "mfma"):   # activation-pattern kernel and matrix-core kernel: same records, same features
+            model.attention_impl = impl
+            feats = model(torch.from_numpy(batch))
+            scale = max(1.0, float(np.abs(ref["combined_feats"]).max()))
+            assert np.abs(feats.cpu().numpy() - ref["combined_feats"]).max() <= TOL * scale, impl
+            assert np.abs(score.logits(feats).cpu().numpy() - ref["logit"]).max() <= \
+                TOL * max(1.0, float(np.abs(ref["logit"]).max())), impl
     assert deg.max() > 512 or seed not in HUB_SEEDS, "hub cases must exercise sliced pairs"
+
+
+@pytest.mark.parametrize("dim,gain", [(32, 40.0), (64, 25.0), (128, 60.0), (256, 15.0)])
+def test_flip_attention_with_weights_that_flip_most_units(dim, gain):
+    """The activation-pattern kernel is exact for every input, only its cost depends on the weights: first PE layers
+    scaled up (and shifted LayerNorm offsets) until a large share of the hidden units leaves the pattern of (0, 0) on a
+    typical entry -- the correction path carries most of the product -- still match the oracle and the matrix-core
+    kernel."""
+    seed = 21
+    rng = np.random.default_rng(seed)
+    n = 500
+    ei, w = D.chung_lu_graph(n, 6000, gamma=2.3, seed=seed, max_weight=0)
+    x = rng.standard_normal((n, 24)).astype(np.float32)
+    ppr = lpformer_amd.calc_ppr(ei, n, 0.15, 1e-4)
+    d = D.build_data(ei, x, n, edge_weight=w, ppr=ppr)
+    cfg = D.train_args_for(dict(thresholds=(0.0, 1e-3, 1e-2), dim=dim, gnn_layers=1, residual=False))
+    torch.manual_seed(seed)
+    model = lpformer_amd.LinkTransformer(cfg, d, device=DEV).to(DEV).eval()
+    score = lpformer_amd.mlp_score(2 * dim, 2 * dim, 1, 2).to(DEV).eval()
+    with torch.no_grad():
+        for enc in (model.ppr_encoder_cn, model.ppr_encoder_onehop, model.ppr_encoder_non1hop):
+            enc.linears[0].weight.mul_(gain)
+            enc.norm.bias.add_(0.3 * torch.randn_like(enc.norm.bias))
+    P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
+    batch = D.sample_pairs(ei, n, 600, seed=seed + 1)
+    ref = O.forward(batch, x, O.gcn_norm(ei, w, n), O.symmetric_mask_csr(ei, n),
+                    (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P, dict(cfg, pred_layers=2))
+    # how many units flip?  (restated from lpformer_amd.fold.flip_tables: z < 0 <=> the unit left the pattern of (0, 0))
+    from lpformer_amd import fold
+    tabs, _, _, _ = fold.flip_tables({k: v for k, v in model.state_dict().items()}, dim, 3)
+    _, stat = fold.pe_tables({k: v for k, v in model.state_dict().items()}, dim, 3)
+    pa, pb = ref["sel"]["onehop"][1].astype(np.float64), ref["sel"]["onehop"][2].astype(np.float64)
+    var = stat[1, 0] * pa * pa + stat[1, 1] * pb * pb + stat[1, 2] + 2 * (stat[1, 3] * pa * pb + stat[1, 4] * pa + stat[1, 5] * pb)
+    z = (tabs[1, :, 0][None] * pa[:, None] + tabs[1, :, 1][None] * pb[:, None] + tabs[1, :, 2][None]) \
+        / np.sqrt(var + 1e-5)[:, None] + tabs[1, :, 3][None]
+    assert (z < 0).mean() > 0.05, "the case must flip a sizeable share of the units"
+    outs = {}
+    for impl in ("flip", "mfma"):
+        model.attention_impl = impl
+        feats = model(torch.from_numpy(batch))
+        outs[impl] = feats
+        scale = max(1.0, float(np.abs(ref["combined_feats"]).max()))
+        assert np.abs(feats.cpu().numpy() - ref["combined_feats"]).max() <= TOL * scale, impl
+        lg = model.score_pairs(torch.from_numpy(batch).to(DEV), model.propagate(), score, logits=True)
+        assert model.check_selection()
+        assert np.abs(lg.cpu().numpy() - ref["logit"]).max() <= TOL * max(1.0, float(np.abs(ref["logit"]).max())), impl
+    assert (outs["flip"] - outs["mfma"]).abs().max().item() <= 1e-5 * max(1.0, outs["mfma"].abs().max().item())
