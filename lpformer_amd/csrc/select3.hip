@@ -225,7 +225,7 @@ struct RunLds3 {
     int32_t p_run[3], p_np, p_last, p_live;
     int16_t ps[S3_PAIRS][4];      // {rank of the pair's first slot per type, pair starts in the item}
 };
-static_assert(sizeof(RunLds3) <= 32 * 1024, "five workgroups per CU");
+static_assert(sizeof(RunLds3) <= 32 * 1024, "four or five workgroups per CU");
 
 // Entries of the parked item from L.pk to their final place, the segment starts of the pairs that begin in it and,
 // from the last item, the totals.  L.base holds the item's place per type.
@@ -273,7 +273,7 @@ __device__ __forceinline__ void s3_finish_parked(const RunArgs3 &A, RunLds3 &L, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(S3_THREADS, 5) void select3_run_kernel(const RunArgs3 A) {
+__global__ __launch_bounds__(S3_THREADS, 4) void select3_run_kernel(const RunArgs3 A) {
     __shared__ RunLds3 L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -324,14 +324,22 @@ __global__ __launch_bounds__(S3_THREADS, 5) void select3_run_kernel(const RunArg
         }
         __syncthreads();
 
-        // ---- typing: one slot per thread and round; everything a kept slot needs later stays in registers
+        // ---- typing: one slot per thread and round; everything a kept slot needs later stays in registers.  The rounds
+        //      are taken together, phase by phase, so that their memory round trips overlap: first every round's walked
+        //      entry is requested, then every round's bucket (four 16-byte reads each), then the arithmetic -- two
+        //      dependent round trips per item instead of eight.
         int code[S3_ROUNDS], node[S3_ROUNDS], win[S3_ROUNDS];
         float va[S3_ROUNDS], vb[S3_ROUNDS];
+        int kindr[S3_ROUNDS], unbr[S3_ROUNDS];
+        int64_t u0r[S3_ROUNDS];
+        int2 cvr[S3_ROUNDS];
+        bool act[S3_ROUNDS];
 #pragma unroll
         for (int r = 0; r < S3_ROUNDS; ++r) {
             const int g = S3_WAVES * r + wave;          // the wavefront's 64-slot group
             const int l = 64 * g + lane;
             code[r] = 0; node[r] = 0; win[r] = 0; va[r] = 0.f; vb[r] = 0.f;
+            act[r] = false; kindr[r] = 0; unbr[r] = 0; u0r[r] = 0; cvr[r] = make_int2(0, 0);
             if (l < n_here) {
                 // window pair of slot l = pairs that start at or before it
                 const uint32_t blo = L.bits[2 * g], bhi = L.bits[2 * g + 1];
@@ -339,48 +347,58 @@ __global__ __launch_bounds__(S3_THREADS, 5) void select3_run_kernel(const RunArg
                 const int w = L.pre[g] + __popcll(bm & lt_mask) + (int)((bm >> lane) & 1ull);
                 const PairDesc3 &d = L.dsc[w];
                 const int i = l - L.loc[w];
+                win[r] = w;
                 if (i < d.total) {
                     const int k = (i >= d.w[1].start) + (i >= d.w[2].start);
                     const Walk3 wk = d.w[k];
-                    const int2 cv = wk.src[i - wk.start];
-                    const int32_t x = cv.x;
-                    const float ws = __int_as_float(cv.y);
-                    // what is x to the other endpoint?  one bucket of its hashed union row
-                    bool found = false;
-                    int bitsv = 0;
-                    if (wk.unb > 0) {
-                        const uint32_t b = __umulhi((uint32_t)x * S3_HASH_MUL, (uint32_t)wk.unb);
-                        const int4 *blk = reinterpret_cast<const int4 *>(A.u_cv + wk.u0 + S3_BUCKET * (int64_t)b);
-                        int4 bv[S3_BUCKET / 2];
-#pragma unroll
-                        for (int q = 0; q < S3_BUCKET / 2; ++q) bv[q] = blk[q];
-#pragma unroll
-                        for (int q = 0; q < S3_BUCKET / 2; ++q) {
-                            if (bv[q].x == x) { found = true; bitsv = bv[q].y; }
-                            if (bv[q].z == x) { found = true; bitsv = bv[q].w; }
-                        }
-                    }
-                    const bool adj = found && bitsv < 0;                     // sign bit: x is adjacent to that endpoint
-                    const float lv = __int_as_float(bitsv & 0x7fffffff);     // its PPR value (0: nothing stored)
-                    const int kind = wk.kind & 3;
-                    const bool cn = kind == K_FULL && adj;
-                    const bool hop = kind == K_FULL ? !adj : (kind == K_A1 ? !adj : (kind == K_PX ? adj : false));
-                    const bool far = kind == K_T0 && found && !adj;
-                    // the reference's round trips (t = 2 for a common neighbour, 1 otherwise; mode "cn": 1)
-                    const bool two = cn && !A.mode_cn;
-                    const float rs = two ? s3_rt2(ws) : s3_rt1(ws);
-                    const float rl = two ? s3_rt2(lv) : s3_rt1(lv);
-                    int c = 0;
-                    if (cn) c = (rs >= A.th_cn && rl >= A.th_cn) ? 1 : 0;
-                    else if (hop) c = (!A.mode_cn && rs >= A.th_1 && rl >= A.th_1) ? 2 : 0;
-                    else if (far) c = (ws > 0.f && lv > 0.f && rs >= A.th_n && rl >= A.th_n) ? 3 : 0;
-                    const bool src_a = wk.kind & KF_SRC_A;
-                    code[r] = c | ((c == 2 && (wk.kind & KF_SIDE_B)) ? 4 : 0);
-                    node[r] = x;
-                    va[r] = src_a ? rs : rl;
-                    vb[r] = src_a ? rl : rs;
+                    cvr[r] = wk.src[i - wk.start];
+                    kindr[r] = wk.kind; unbr[r] = wk.unb; u0r[r] = wk.u0;
+                    act[r] = true;
                 }
-                win[r] = w;
+            }
+        }
+        int4 bv[S3_ROUNDS][S3_BUCKET / 2];
+#pragma unroll
+        for (int r = 0; r < S3_ROUNDS; ++r) {
+            // what is x to the other endpoint?  one bucket of its hashed union row
+            const bool look = act[r] && unbr[r] > 0;
+            const uint32_t b = look ? __umulhi((uint32_t)cvr[r].x * S3_HASH_MUL, (uint32_t)unbr[r]) : 0u;
+            const int4 *blk = reinterpret_cast<const int4 *>(A.u_cv + (look ? u0r[r] + S3_BUCKET * (int64_t)b : 0));
+#pragma unroll
+            for (int q = 0; q < S3_BUCKET / 2; ++q) bv[r][q] = look ? blk[q] : make_int4(-1, 0, -1, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < S3_ROUNDS; ++r) {
+            const int g = S3_WAVES * r + wave;
+            if (act[r]) {
+                const int32_t x = cvr[r].x;
+                const float ws = __int_as_float(cvr[r].y);
+                bool found = false;
+                int bitsv = 0;
+#pragma unroll
+                for (int q = 0; q < S3_BUCKET / 2; ++q) {
+                    if (bv[r][q].x == x) { found = true; bitsv = bv[r][q].y; }
+                    if (bv[r][q].z == x) { found = true; bitsv = bv[r][q].w; }
+                }
+                const bool adj = found && bitsv < 0;                     // sign bit: x is adjacent to that endpoint
+                const float lv = __int_as_float(bitsv & 0x7fffffff);     // its PPR value (0: nothing stored)
+                const int kind = kindr[r] & 3;
+                const bool cn = kind == K_FULL && adj;
+                const bool hop = kind == K_FULL ? !adj : (kind == K_A1 ? !adj : (kind == K_PX ? adj : false));
+                const bool far = kind == K_T0 && found && !adj;
+                // the reference's round trips (t = 2 for a common neighbour, 1 otherwise; mode "cn": 1)
+                const bool two = cn && !A.mode_cn;
+                const float rs = two ? s3_rt2(ws) : s3_rt1(ws);
+                const float rl = two ? s3_rt2(lv) : s3_rt1(lv);
+                int c = 0;
+                if (cn) c = (rs >= A.th_cn && rl >= A.th_cn) ? 1 : 0;
+                else if (hop) c = (!A.mode_cn && rs >= A.th_1 && rl >= A.th_1) ? 2 : 0;
+                else if (far) c = (ws > 0.f && lv > 0.f && rs >= A.th_n && rl >= A.th_n) ? 3 : 0;
+                const bool src_a = kindr[r] & KF_SRC_A;
+                code[r] = c | ((c == 2 && (kindr[r] & KF_SIDE_B)) ? 4 : 0);
+                node[r] = x;
+                va[r] = src_a ? rs : rl;
+                vb[r] = src_a ? rl : rs;
             }
             const int c3 = code[r] & 3;
             const uint64_t b0 = __ballot(c3 == 1), b1 = __ballot(c3 == 2), b2 = __ballot(c3 == 3);
