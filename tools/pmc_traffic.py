@@ -12,7 +12,7 @@ from collections import defaultdict
 SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
     ("select3_run_kernel", "select_run"), ("select3_plan_kernel", "select_plan"),
     ("select_run_kernel", "select_run_general"), ("select_plan_kernel", "select_plan"), ("select_export", "select_export"),
-    ("pair_fused_kernel", "pair_attention_fused"),
+    ("pair_flip_kernel", "pair_attention_fused"), ("pair_fused_kernel", "pair_attention_fused_mfma"),
     ("tail_chain_kernel", "tail_chain"), ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"),
     ("pair_scores_", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
     ("pair_softmax_gather_kernel", "pair_softmax_gather_light"),
