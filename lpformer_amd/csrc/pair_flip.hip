@@ -21,6 +21,8 @@
 // walks one UNIT of 16 consecutive same-type entries with an online softmax and leaves exactly the records
 // pair_fused.hip leaves (part[t][pair] for a segment inside one unit, boundary records otherwise), so the consumers
 // (tail_chain.hip merge mode, pair_merge.hip) do not care which kernel ran.  64 / G units per wavefront at a time.
+#include <stdlib.h>
+
 #include "pe_common.h"
 
 namespace {
@@ -203,6 +205,10 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
                 // it.  One pass over the eight (order, unit-of-the-lane) slots; the flipped lanes of a slot are taken one
                 // at a time (scalar loop), the owner's |y| is read across the wave, the group's lanes add their piece of
                 // the column -- from LDS when the type's table is resident.
+                // (software-pipelined by one: a column is requested, then the PREVIOUS flip's column is added, so the
+                //  scalar work of the next flip runs under the LDS / L2 round trip of this one)
+                float4 wp = make_float4(0.f, 0.f, 0.f, 0.f);
+                float vp = 0.f;
 #pragma unroll
                 for (int oj = 0; oj < 8; ++oj) {
                     const float zv = zz[oj >> 2][oj & 3];
@@ -211,14 +217,17 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
                         const int b = __builtin_ctzll(bm);
                         bm &= bm - 1;
                         const float val = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zv), b));
-                        if (b / G == grp) {
-                            const int kk = 4 * (b % G) + (oj & 3);
-                            const float4 w = wt_lds ? lw[kk * G] : *reinterpret_cast<const float4 *>(wT + (int64_t)kk * D);
-                            k[0] = fmaf(w.x, val, k[0]); k[1] = fmaf(w.y, val, k[1]);
-                            k[2] = fmaf(w.z, val, k[2]); k[3] = fmaf(w.w, val, k[3]);
-                        }
+                        const bool mine = b / G == grp;
+                        const int kk = mine ? 4 * (b % G) + (oj & 3) : 0;
+                        const float4 w = wt_lds ? lw[kk * G] : *reinterpret_cast<const float4 *>(wT + (int64_t)kk * D);
+                        k[0] = fmaf(wp.x, vp, k[0]); k[1] = fmaf(wp.y, vp, k[1]);
+                        k[2] = fmaf(wp.z, vp, k[2]); k[3] = fmaf(wp.w, vp, k[3]);
+                        wp = w;
+                        vp = mine ? val : 0.f;
                     }
                 }
+                k[0] = fmaf(wp.x, vp, k[0]); k[1] = fmaf(wp.y, vp, k[1]);
+                k[2] = fmaf(wp.z, vp, k[2]); k[3] = fmaf(wp.w, vp, k[3]);
             }
             // score of the entry: att . leaky_relu(k * q, 0.2), summed over the group's lanes
             float x0 = k[0] * qc.x, x1 = k[1] * qc.y, x2 = k[2] * qc.z, x3 = k[3] * qc.w;
@@ -286,7 +295,8 @@ extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t 
             lds_set = true;                                                                                     \
         }                                                                                                       \
         int64_t groups = (max_units + (NTH / 64) * (64 / GG) - 1) / ((NTH / 64) * (64 / GG));                   \
-        if (groups > (int64_t)n_cu * PER_CU) groups = (int64_t)n_cu * PER_CU;                                   \
+        { const char *e_ = getenv("LPF_FLIP_PER_CU"); const int pc_ = e_ ? atoi(e_) : PER_CU;                   \
+          if (groups > (int64_t)n_cu * pc_) groups = (int64_t)n_cu * pc_; }                                     \
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(NTH), lds, s, a);                                 \
     } while (0)
     switch (D) {

@@ -19,7 +19,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TC_GROUPS = 4;               // 16-sample groups per workgroup
+#ifndef LPF_TC_GROUPS
+#define LPF_TC_GROUPS 4
+#endif
+constexpr int TC_GROUPS = LPF_TC_GROUPS;   // 16-sample groups per workgroup
 constexpr int TC_WAVES = 2 * TC_GROUPS;    // a wave pair per group
 constexpr int TC_THREADS = 64 * TC_WAVES;
 
@@ -47,15 +50,20 @@ struct TailArgs {
 };
 
 constexpr int tc_per_thread(int ntp) { return (ntp * 64 + TC_THREADS - 1) / TC_THREADS; }
+// elements between two stages of a packed weight image (lpformer_amd/fold.py pack_dense: padded to 512 per stage)
+constexpr int tc_stage_stride(int ntp) { return (ntp * 64 + 511) / 512 * 512; }
 
 // weight elements: one per (tile, lane) and k-group -- four fp32 (f32x4) or, in the bf16 variant, four bf16 (uint2) of
 // W[16 c + i][16 ks + 4 q .. + 3]
 typedef short bf16x4_bits __attribute__((ext_vector_type(4)));
-template <int P, typename T>
+template <int P, int NTP, typename T>
 __device__ __forceinline__ void tc_load(T (&r)[P], const float *packed, int stage, int tid) {
-    const T *src = reinterpret_cast<const T *>(packed) + (int64_t)stage * (P * TC_THREADS);
+    const T *src = reinterpret_cast<const T *>(packed) + (int64_t)stage * tc_stage_stride(NTP);
 #pragma unroll
-    for (int e = 0; e < P; ++e) r[e] = src[e * TC_THREADS + tid];
+    for (int e = 0; e < P; ++e) {
+        const int i = e * TC_THREADS + tid;
+        r[e] = src[i < tc_stage_stride(NTP) ? i : 0];   // (the last strip of a thread may lie past the stage's padding)
+    }
 }
 template <int P, typename T>
 __device__ __forceinline__ void tc_store(const T (&r)[P], T *slab, int tid) {
@@ -146,7 +154,7 @@ struct TcShape {
 };
 
 template <int NTA, int NTB, int NTC, bool WB = false>
-__global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArgs A) {
+__global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_chain_kernel(const TailArgs A) {
     using S = TcShape<NTA, NTB, NTC>;
     using WT = typename std::conditional<WB, uint2, f32x4>::type;  // weight element (WB: bf16 weights, merge mode only)
     constexpr int NTPA = S::NTPA, NTPB = S::NTPB, NTPC = S::NTPC;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
         const float *xa = A.x + mm * A.ldx;
         const int ngA = (A.KA + 15) >> 4;
         f32x4 wr[S::PA];
-        tc_load<S::PA>(wr, A.wA, 0, tid);  // (the GEMM form of stage A exists in fp32 only)
+        tc_load<S::PA, NTPA>(wr, A.wA, 0, tid);  // (the GEMM form of stage A exists in fp32 only)
         int kk = 4 * q < A.KA ? 4 * q : A.KA - 4;  // clamped into the row; out-of-range groups are zeroed below
         f32x4 xr = *reinterpret_cast<const f32x4 *>(xa + kk);
 #pragma unroll 1
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
             tc_store<S::PA>(wr, lw, tid);
             __syncthreads();
             if (kg + 1 < ngA) {  // next k-group's operands fly while this one's MFMAs run
-                tc_load<S::PA>(wr, A.wA, kg + 1, tid);
+                tc_load<S::PA, NTPA>(wr, A.wA, kg + 1, tid);
                 kk = 16 * (kg + 1) + 4 * q;
                 kk = kk < A.KA ? kk : A.KA - 4;
                 xr = *reinterpret_cast<const f32x4 *>(xa + kk);
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
         }
     }
     WT wrB[S::PB];
-    tc_load<S::PB>(wrB, A.wB, 0, tid);  // stage B's first weights fly during the epilogue
+    tc_load<S::PB, NTPB>(wrB, A.wB, 0, tid);  // stage B's first weights fly during the epilogue
     if (A.part == nullptr) {
         const int fbase = 16 * half * TPWA + 4 * q;
         f32x4 ad[TPWA];
@@ -316,14 +324,14 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
             WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
             tc_store<S::PB>(wrB, lw, tid);
             __syncthreads();  // (kg == 0: also publishes stage A's hidden tiles)
-            if (kg + 1 < NTPA + 1) tc_load<S::PB>(wrB, A.wB, kg + 1, tid);
+            if (kg + 1 < NTPA + 1) tc_load<S::PB, NTPB>(wrB, A.wB, kg + 1, tid);
             const f32x4 bv = kg < NTPA ? my_hid[(kg < NTPA ? kg : 0) * 64] : tailv;
             tc_mfma<TPWB>(accB, lw + (half * TPWB) * 64 + lane, bv);
             buf ^= 1;
         }
     }
     WT wrC[S::PC];
-    tc_load<S::PC>(wrC, A.wC, 0, tid);
+    tc_load<S::PC, NTPC>(wrC, A.wC, 0, tid);
     const float *rer = A.re + mm * A.ldre + 4 * q;
     f32x4 xr = *reinterpret_cast<const f32x4 *>(rer);  // stage C's first input group
     {
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
         WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
         tc_store<S::PC>(wrC, lw, tid);
         __syncthreads();
-        tc_load<S::PC>(wrC, A.wC, kg + 1, tid);  // (stage NGE exists: the r_p groups follow)
+        tc_load<S::PC, NTPC>(wrC, A.wC, kg + 1, tid);  // (stage NGE exists: the r_p groups follow)
         if (kg + 1 < NGE) xr = *reinterpret_cast<const f32x4 *>(rer + 16 * (kg + 1));
         tc_mfma<TPWC>(accC, lw + (half * TPWC) * 64 + lane, bv);
         buf ^= 1;
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(TC_THREADS, 4) void tail_chain_kernel(const TailArg
         WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
         tc_store<S::PC>(wrC, lw, tid);
         __syncthreads();  // (kg == 0: also publishes stage B's hidden tiles)
-        if (kg + 1 < NTPB) tc_load<S::PC>(wrC, A.wC, NGE + kg + 1, tid);
+        if (kg + 1 < NTPB) tc_load<S::PC, NTPC>(wrC, A.wC, NGE + kg + 1, tid);
         tc_mfma<TPWC>(accC, lw + (half * TPWC) * 64 + lane, my_hid[kg * 64]);
         buf ^= 1;
     }
