@@ -129,7 +129,8 @@ int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t bat
                         int64_t ldx, float *mul, int64_t ldm, float *sum, int64_t lds, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Selection (select2.hip): two launches, nothing read back by the host.
+ * Selection, GENERAL path (select2.hip; a caller-supplied typing adjacency -- for the model's own adjacency see
+ * lpf_select3_* below): two launches, nothing read back by the host.
  * compute_node_mask + get_ppr_vals + get_non_1hop_ppr (link_transformer.py:214-319,434-481), eval mode; bit-exact.
  * The candidates of the batch form one flat slot space -- pair k owns N(a_k) | N(b_k) | the shorter of the two T0
  * rows, at least one slot -- cut into work items of LPF_SELECT_ITEM slots; one thread per slot.
@@ -142,9 +143,9 @@ int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t bat
  *         ever cleared and no per-launch value comes from the host, so the two launches replay from a captured graph)
  *   desc  128 bytes per pair;  offs int64[bs+1];  item_pair int32[item_cap];  plan_lb uint64[lpf_select_plan_blocks(bs)]
  *   run_lb uint64[3*item_cap];  type_ptr int32[3*(bs+1)];  entries 16 bytes x 3 x ent_cap
- *   val_*  the rows PPR values are looked up in: with adj_selfp (evaluation) the prefiltered one-hop index P1
- *          (lpf_ppr_filter_*, mode 1) -- the PPR of a node to its own neighbours then comes from adj_selfp --,
- *          without it (adjacency override of the training loop) the raw PPR matrix
+ *   val_*  the rows PPR values are looked up in: the raw PPR matrix, plain sorted CSR (val_rowptr / val_col / val_val;
+ *          val_len NULL).  adj_selfp and val_cv must be NULL: round 2's indexed form of this call (self-PPR aligned
+ *          with the adjacency + a hashed one-hop index) was superseded by lpf_select3_* and returns LPF_ERR_UNSUPPORTED
  *   BLOCKED index (the T0 rows): every row padded to a multiple of 16 entries (column INT32_MAX, value 0), row
  *          pointers counting padded entries, t0_len[i] = real entries of row i, t0_cv = interleaved {int32 column,
  *          float value} pairs (a 16-entry block = one aligned 128-byte line), t0_skip[b] = last column of block b

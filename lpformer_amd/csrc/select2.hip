@@ -1,11 +1,12 @@
-// PPR-thresholded node selection: two launches, nothing read back by the host.
+// PPR-thresholded node selection, GENERAL path: two launches, nothing read back by the host.
 //
 // Reference: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (src/models/link_transformer.py:214-319, 434-481),
-// eval mode.  The reference materialises BS x N sparse temporaries and coalesces them seven times; round 1 of this
-// project cut a batch into one-wavefront work items and needed seven launches plus a 16-byte read-back to size its
-// staging area (removed).
+// eval mode.  This file serves a caller-supplied typing adjacency (the training loop's masked adjacency,
+// src/train/train_model.py:40-59), for which no per-model index exists: both PPR values of a candidate are looked up
+// in the raw PPR rows (binary searches), the >1-hop exclusion uses the unmasked adjacency.  The model's own adjacency
+// goes through select3.hip (walk indexes).  lpf_select_export (reference layout) lives here too.
 //
-// Here the candidates of a batch form ONE flat index space: pair k owns the slots
+// The candidates of a batch form ONE flat index space: pair k owns the slots
 //     [offs[k], offs[k+1])  =  N(a_k)  |  N(b_k)  |  the shorter of T0[a_k], T0[b_k]     (at least one slot per pair)
 // and the space is cut into work items of S2_ITEM consecutive slots, whatever pairs they belong to -- a hub pair
 // simply spans many items, a run of small pairs shares one.  Each slot is owned by one thread:
@@ -14,7 +15,7 @@
 //                   checked here (a bad id raises a sticky error bit instead of reading out of bounds).
 //   * run kernel    persistent workgroups draw items from a ticket counter.  A thread types its candidate (binary
 //                   search in the other endpoint's adjacency run -- in LDS when that run lies inside the item --,
-//                   then at most one lookup in the prefiltered one-hop rows / the other >1-hop row), applies the
+//                   then the two PPR values from the raw rows / the other >1-hop row), applies the
 //                   reference's fp32 round trip and thresholds op for op, and keeps the result in registers.  Kept
 //                   entries are ranked per type inside the item (ballots), the item's three totals go through a
 //                   second chained scan ordered by ticket, and the entries land at their FINAL position: per type
@@ -791,9 +792,10 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && adj_col && type_ptr &&
                 entries && ent_cap > 0 && lpf_aligned16(entries) && lpf_aligned16(desc));
-    // indexed path: self-PPR + blocked P1 index; general path: raw PPR rows
-    LPF_REQUIRE(adj_selfp ? (val_cv && lpf_aligned16(val_cv))
-                          : (val_col && val_val));
+    // Round 2's indexed path (self-PPR aligned with the adjacency + hashed one-hop index) was replaced by the walk
+    // indexes of select3.hip; what remains here is the general path over the raw PPR rows.
+    if (adj_selfp || val_cv) return LPF_ERR_UNSUPPORTED;
+    LPF_REQUIRE(val_col && val_val);
     LPF_REQUIRE((t0_cv == nullptr) == (t0_skip == nullptr) && lpf_aligned16(t0_cv) && lpf_aligned16(t0_skip));
     RunArgs a;
     a.bs = bs; a.desc = static_cast<const PairDesc *>(desc); a.offs = offs; a.item_pair = item_pair;
@@ -811,7 +813,7 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
         int dev = 0, occ = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, select_run_kernel<true>, S2_THREADS, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, select_run_kernel<false>, S2_THREADS, 0) != hipSuccess ||
             occ < 1)
             occ = 4;
         resident = prop.multiProcessorCount * occ;
@@ -819,8 +821,7 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     int64_t blocks = grid_blocks > 0 ? grid_blocks : resident;
     if (blocks > item_cap) blocks = item_cap;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (adj_selfp) hipLaunchKernelGGL(select_run_kernel<true>, dim3((unsigned)blocks), dim3(S2_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(select_run_kernel<false>, dim3((unsigned)blocks), dim3(S2_THREADS), 0, s, a);
+    hipLaunchKernelGGL(select_run_kernel<false>, dim3((unsigned)blocks), dim3(S2_THREADS), 0, s, a);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

@@ -552,7 +552,7 @@ class LinkTransformer(nn.Module):
         return any(obj is v for v in self.data.values())
 
     def _device_graph(self, kind: str, obj) -> graph.DeviceCSR:
-        """kind in {'prop' (GCN-normalised), 'mask', 'ppr', 't0' / 'p1' (prefiltered PPR indexes)}.
+        """kind in {'prop' (GCN-normalised), 'mask', 'ppr', 't0' (blocked >1-hop index of the general selection path)}.
         Graphs held in ``self.data`` are converted once and stay resident.  A caller-supplied override (the training
         loop passes a fresh ``adj_mask`` / ``adj_prop`` per batch, src/train/train_model.py:40-59) only occupies ONE
         slot per kind: the previous override's device copy is released when the next one arrives."""
@@ -568,8 +568,6 @@ class LinkTransformer(nn.Module):
         dev = self.device
         if kind == "t0":    # per-model indexes: filtered on the device from the resident PPR matrix
             g = graph.ppr_filter_device_blocked(self._device_graph("ppr", obj), 0, self.thresh_non1hop)
-        elif kind == "p1":
-            g = graph.hash_index_device(graph.ppr_filter_device(self._device_graph("ppr", obj), 1, self.thresh_1hop))
         elif isinstance(obj, graph.CSR) and kind in ("mask", "ppr"):
             if kind == "ppr" and obj.val is None:
                 raise ValueError("the PPR matrix needs values")
@@ -599,15 +597,6 @@ class LinkTransformer(nn.Module):
         else:
             self._override[kind] = (obj, g)
         return g
-
-    def _self_ppr(self, mask_obj, ppr_obj, adj: graph.DeviceCSR, ppr: graph.DeviceCSR) -> torch.Tensor:
-        key = ("selfp", id(mask_obj), id(ppr_obj))
-        hit = self._graphs.get(key)
-        if hit is None or hit[0] is not mask_obj or hit[1] is not ppr_obj:
-            t = graph.self_ppr_device(adj, ppr)
-            self._graphs[key] = (mask_obj, ppr_obj, t)
-            return t
-        return hit[2]
 
     def _features(self) -> torch.Tensor:
         x = self.data["x"]
@@ -820,7 +809,7 @@ class LinkTransformer(nn.Module):
                                           float(self.thresh_non1hop), cn, ptr(ws.type_ptr), ptr(ws.entries),
                                           ws.ent_cap, 0, st), "lpf_select3_run")
             return
-        adj, adjx, val, t0, selfp = graphs
+        adj, adjx, val, t0 = graphs
         with KernelTimer.span("select_plan"):
             check(lib.lpf_select_plan(bs, ptr(batch), batch.stride(0), self.num_nodes, ptr(adj.rowptr),
                                       ptr(val.rowptr), ptr(t0.rowptr) if t0 is not None else None,
@@ -831,11 +820,8 @@ class LinkTransformer(nn.Module):
                   "lpf_select_plan")
         with KernelTimer.span("select_run"):
             check(lib.lpf_select_run(bs, ptr(ws.desc), ptr(ws.offs), ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl),
-                                     ptr(ws.run_lb), ptr(adj.col), ptr(selfp),
-                                     ptr(adjx.col) if adjx is not adj else None,
-                                     None if selfp is not None else ptr(val.col),
-                                     None if selfp is not None else ptr(val.val),
-                                     ptr(val.cv) if selfp is not None else None,
+                                     ptr(ws.run_lb), ptr(adj.col), None,
+                                     ptr(adjx.col) if adjx is not adj else None, ptr(val.col), ptr(val.val), None,
                                      ptr(t0.cv) if t0 is not None else None,
                                      ptr(t0.skip) if t0 is not None else None, float(self.thresh_cn),
                                      float(self.thresh_1hop), float(self.thresh_non1hop), ptr(ws.type_ptr),
@@ -855,7 +841,7 @@ class LinkTransformer(nn.Module):
     def _select_graphs(self, test_set: bool, adj_mask=None):
         """What the selection launches read.  Evaluation (the typing adjacency is the model's own): the walk indexes
         (``graph.WalkIndex``).  A caller-supplied adjacency override (training) or ``use_select_index = False``: the
-        tuple (typing adjacency, unmasked adjacency, raw PPR rows, T0 rows or None, None) of the general path."""
+        tuple (typing adjacency, unmasked adjacency, raw PPR rows, T0 rows or None) of the general path."""
         ppr_obj, mask_obj = self._data_obj("ppr", test_set), self._data_obj("mask", test_set)
         if adj_mask is None and self.use_select_index:
             return self._walk_index(mask_obj, ppr_obj)
@@ -866,7 +852,7 @@ class LinkTransformer(nn.Module):
         adjx = self._device_graph("mask", mask_obj)
         adj = adjx if adj_mask is None else self._device_graph("mask", adj_mask)
         t0 = self._device_graph("t0", ppr_obj) if self.mask == "all" else None
-        return adj, adjx, ppr, t0, None
+        return adj, adjx, ppr, t0
 
     def _select_device(self, batch: torch.Tensor, test_set: bool, adj_mask=None) -> "_SelectWorkspace":
         """Selection for the hot path: the result stays in the stream's workspace (per-type entry regions + int32
