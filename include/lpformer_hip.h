@@ -111,6 +111,12 @@ int lpf_layernorm_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const f
  * column sums added in a fixed order).  D % 4 == 0, D <= 256; workspace: lpf_layernorm_bwd_workspace_floats(D) floats.
  * The training step (src/train/train_model.py:59-77 through autograd). */
 int64_t lpf_layernorm_bwd_workspace_floats(int32_t D);
+/* The same for y = ReLU(LN(x)) (the GCN layer's epilogue, other_models.py:66-69, and the MLPs' hidden layers, :131-133):
+ * dy counts only where gamma xhat + beta > 0; dxsum[D] = column sums of dx, the gradient of a bias added in front of
+ * the LayerNorm.  Same workspace. */
+int lpf_layernorm_relu_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
+                               const float *gamma, const float *beta, float *dx, int64_t lddx, float *dgamma,
+                               float *dbeta, float *dxsum, float *workspace, void *stream);
 int lpf_layernorm_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
                           const float *gamma, float *dx, int64_t lddx, float *dgamma, float *dbeta, float *workspace,
                           void *stream);

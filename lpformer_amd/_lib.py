@@ -28,6 +28,7 @@ HIP_PROTOTYPES = {
     "lpf_gemm_f32": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
     "lpf_layernorm_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp],
     "lpf_layernorm_bwd_workspace_floats": [i32],
+    "lpf_layernorm_relu_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "lpf_gemm_tn_f32": [i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp],
     "lpf_gemm_tn_workspace_floats": [i64, i32, i32],
     "lpf_gemm_f32_out_bf16": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],

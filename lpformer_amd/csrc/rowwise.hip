@@ -158,19 +158,24 @@ extern "C" int lpf_rowdot_sigmoid_f32(int64_t M, int32_t K, const float *A, int6
 // workgroup order (deterministic).  Bound: HBM (x, dy read once, dx written once).
 namespace {
 
-template <int G>
+// RELU variant (lpf_layernorm_relu_bwd_f32): the forward was y = ReLU(LN(x)), so dy only counts where gamma xhat + beta
+// > 0, and a third partial carries the column sums of dx -- the gradient of the bias that was added in front of the
+// LayerNorm (the GCN layer's `conv.bias`, other_models.py:66-69).
+template <int G, bool RELU>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, const float *__restrict__ x, int64_t ldx,
                                                             const float *__restrict__ dy, int64_t ldy,
-                                                            const float *__restrict__ gamma, float *__restrict__ dx,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ dx,
                                                             int64_t lddx, float *__restrict__ part) {
-    constexpr int NG = 256 / G;
-    __shared__ float4 red[2][NG][G];
+    constexpr int NG = 256 / G, NP = RELU ? 3 : 2;
+    __shared__ float4 red[NP][NG][G];
     const int tid = threadIdx.x, grp = tid / G, lig = tid % G;
     const int off = 4 * lig;
     const bool act = off < D;
-    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), bt = gm;
     if (act) gm = *reinterpret_cast<const float4 *>(gamma + off);
-    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+    if (RELU && act) bt = *reinterpret_cast<const float4 *>(beta + off);
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg, sx = sg;
     const int64_t g_id = (int64_t)blockIdx.x * NG + grp, n_g = (int64_t)gridDim.x * NG;
     for (int64_t r0 = 0; r0 < M; r0 += n_g) {  // (every group runs the same number of rounds: the shuffles stay converged)
         const int64_t r = r0 + g_id;
@@ -186,29 +191,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
         const float var = lpf_group_sum<G>(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) / (float)D;
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         const float4 xh = make_float4(c.x * rstd, c.y * rstd, c.z * rstd, c.w * rstd);
+        if (RELU) {   // the gradient passes only where the forward's ReLU did
+            if (!(fmaf(gm.x, xh.x, bt.x) > 0.f)) dv.x = 0.f;
+            if (!(fmaf(gm.y, xh.y, bt.y) > 0.f)) dv.y = 0.f;
+            if (!(fmaf(gm.z, xh.z, bt.z) > 0.f)) dv.z = 0.f;
+            if (!(fmaf(gm.w, xh.w, bt.w) > 0.f)) dv.w = 0.f;
+        }
         const float4 gv = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
         const float m1 = lpf_group_sum<G>(gv.x + gv.y + gv.z + gv.w) / (float)D;
         const float m2 = lpf_group_sum<G>(gv.x * xh.x + gv.y * xh.y + gv.z * xh.z + gv.w * xh.w) / (float)D;
         if (live) {
-            *reinterpret_cast<float4 *>(dx + r * lddx + off) =
-                make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
-                            rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
+            const float4 dxv = make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
+                                           rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
+            *reinterpret_cast<float4 *>(dx + r * lddx + off) = dxv;
+            if (RELU) { sx.x += dxv.x; sx.y += dxv.y; sx.z += dxv.z; sx.w += dxv.w; }
             sg.x += dv.x * xh.x; sg.y += dv.y * xh.y; sg.z += dv.z * xh.z; sg.w += dv.w * xh.w;
             sb.x += dv.x; sb.y += dv.y; sb.z += dv.z; sb.w += dv.w;
         }
     }
     red[0][grp][lig] = sg;
     red[1][grp][lig] = sb;
+    if (RELU) red[NP - 1][grp][lig] = sx;
     __syncthreads();
     if (grp == 0 && act) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NP; ++k) {
             float4 s = red[k][0][lig];
             for (int g = 1; g < NG; ++g) {
                 const float4 v = red[k][g][lig];
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
-            *reinterpret_cast<float4 *>(part + ((int64_t)blockIdx.x * 2 + k) * D + off) = s;
+            *reinterpret_cast<float4 *>(part + ((int64_t)blockIdx.x * NP + k) * D + off) = s;
         }
     }
 }
@@ -216,24 +229,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
 // 16 columns x 16 slices of the workgroup list per workgroup: a slice adds its workgroups in order, the slices meet in
 // LDS and are added in slice order (deterministic; one thread per column walking a thousand partials was the slowest
 // kernel of the training step)
-__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(int D, int blocks, const float *__restrict__ part,
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(int D, int np, int blocks,
+                                                                   const float *__restrict__ part,
                                                                    float *__restrict__ dgamma,
-                                                                   float *__restrict__ dbeta) {
+                                                                   float *__restrict__ dbeta,
+                                                                   float *__restrict__ dxsum) {
     __shared__ float red[16][17];
     const int colx = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + colx;  // column of the [2 D] row pair
+    const int c = blockIdx.x * 16 + colx;  // column of the [np D] row group
     float s = 0.f;
-    if (c < 2 * D) {
+    if (c < np * D) {
         const int k = c / D, f = c % D;
-        for (int b = slice; b < blocks; b += 16) s += part[((int64_t)b * 2 + k) * D + f];
+        for (int b = slice; b < blocks; b += 16) s += part[((int64_t)b * np + k) * D + f];
     }
     red[slice][colx] = s;
     __syncthreads();
-    if (slice == 0 && c < 2 * D) {
+    if (slice == 0 && c < np * D) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][colx];
-        (c / D == 0 ? dgamma : dbeta)[c % D] = t;
+        (c / D == 0 ? dgamma : (c / D == 1 ? dbeta : dxsum))[c % D] = t;
     }
 }
 
@@ -241,13 +256,16 @@ constexpr int LN_BWD_BLOCKS = 1024;
 
 }  // namespace
 
-extern "C" int64_t lpf_layernorm_bwd_workspace_floats(int32_t D) { return (int64_t)LN_BWD_BLOCKS * 2 * (D > 0 ? D : 0); }
+extern "C" int64_t lpf_layernorm_bwd_workspace_floats(int32_t D) { return (int64_t)LN_BWD_BLOCKS * 3 * (D > 0 ? D : 0); }
 
-extern "C" int lpf_layernorm_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
-                                     const float *gamma, float *dx, int64_t lddx, float *dgamma, float *dbeta,
-                                     float *workspace, void *stream) {
+namespace {
+template <bool RELU>
+int ln_bwd_launch(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy, const float *gamma,
+                  const float *beta, float *dx, int64_t lddx, float *dgamma, float *dbeta, float *dxsum,
+                  float *workspace, void *stream) {
     if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
-    LPF_REQUIRE(M >= 0 && gamma && dgamma && dbeta && workspace && lpf_aligned16(gamma) && lpf_aligned16(workspace));
+    LPF_REQUIRE(M >= 0 && gamma && dgamma && dbeta && workspace && lpf_aligned16(gamma) && lpf_aligned16(workspace) &&
+                (!RELU || (beta && dxsum && lpf_aligned16(beta))));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int blocks = 0;
     if (M > 0) {
@@ -256,15 +274,32 @@ extern "C" int lpf_layernorm_bwd_f32(int64_t M, int32_t D, const float *x, int64
         const int G = D <= 32 ? 8 : (D <= 64 ? 16 : (D <= 128 ? 32 : 64));
         const int64_t want = (M + 256 / G - 1) / (256 / G);
         blocks = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
+#define LPF_LNB(GG) hipLaunchKernelGGL((layernorm_bwd_kernel<GG, RELU>), dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, \
+                                       ldy, gamma, beta, dx, lddx, workspace)
         switch (G) {
-            case 8: hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
-            case 16: hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
-            case 32: hipLaunchKernelGGL(layernorm_bwd_kernel<32>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
-            default: hipLaunchKernelGGL(layernorm_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, ldy, gamma, dx, lddx, workspace); break;
+            case 8: LPF_LNB(8); break;
+            case 16: LPF_LNB(16); break;
+            case 32: LPF_LNB(32); break;
+            default: LPF_LNB(64); break;
         }
+#undef LPF_LNB
     }
-    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, D, blocks, workspace,
-                       dgamma, dbeta);
+    const int np = RELU ? 3 : 2;
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((np * D + 15) / 16), dim3(256), 0, s, D, np, blocks, workspace,
+                       dgamma, dbeta, dxsum);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
+}
+}  // namespace
+
+extern "C" int lpf_layernorm_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
+                                     const float *gamma, float *dx, int64_t lddx, float *dgamma, float *dbeta,
+                                     float *workspace, void *stream) {
+    return ln_bwd_launch<false>(M, D, x, ldx, dy, ldy, gamma, nullptr, dx, lddx, dgamma, dbeta, nullptr, workspace, stream);
+}
+
+extern "C" int lpf_layernorm_relu_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
+                                          const float *gamma, const float *beta, float *dx, int64_t lddx, float *dgamma,
+                                          float *dbeta, float *dxsum, float *workspace, void *stream) {
+    return ln_bwd_launch<true>(M, D, x, ldx, dy, ldy, gamma, beta, dx, lddx, dgamma, dbeta, dxsum, workspace, stream);
 }

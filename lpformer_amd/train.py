@@ -120,8 +120,8 @@ def linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias)
 
 
-def _spmm_plain(a: graph.DeviceCSR, h: torch.Tensor) -> torch.Tensor:
-    """out = A h (no epilogue) through lpf_spmm_csr_f32."""
+def _spmm_plain(a: graph.DeviceCSR, h: torch.Tensor, bias=None) -> torch.Tensor:
+    """out = A h (+ bias) through lpf_spmm_csr_f32 (no other epilogue)."""
     h = _rows4(h)
     n, d = a.n, h.shape[1]
     out = torch.empty(n, d, dtype=torch.float32, device=h.device)
@@ -132,7 +132,7 @@ def _spmm_plain(a: graph.DeviceCSR, h: torch.Tensor) -> torch.Tensor:
         cache = a.__dict__["_long_rows_full"] = (rows if rows.numel() else False)
     long_rows = cache if cache is not False else None
     check(_lib.hip().lpf_spmm_csr_f32(n, d, ptr(a.rowptr), ptr(a.col), ptr(a.val), ptr(h), h.stride(0), ptr(out),
-                                      out.stride(0), None, None, None, None, 0, None, None, 0, ptr(long_rows),
+                                      out.stride(0), ptr(bias), None, None, None, 0, None, None, 0, ptr(long_rows),
                                       0 if long_rows is None else long_rows.numel(), _stream(h)), "lpf_spmm_csr_f32")
     return out
 
@@ -194,6 +194,67 @@ class LayerNormFn(torch.autograd.Function):
         return dx.reshape(ctx.shape), dg, db
 
 
+class LnReluFn(torch.autograd.Function):
+    """ReLU(LayerNorm(x)) as one forward kernel (lpf_layernorm_f32 with the ReLU flag) and one backward kernel
+    (lpf_layernorm_relu_bwd_f32: the ReLU mask is recomputed from x, nothing but x is saved)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y = torch.empty_like(x2)
+        check(_lib.hip().lpf_layernorm_f32(x2.shape[0], x2.shape[1], ptr(x2), x2.stride(0), ptr(weight), ptr(bias),
+                                           ptr(y), y.stride(0), _lib.FLAG_RELU, _stream(x2)), "lpf_layernorm_f32")
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.shape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        dx, dg, db, _ = _ln_relu_bwd(x2, dy.reshape(-1, x2.shape[1]).contiguous(), weight, bias)
+        return dx.reshape(ctx.shape), dg, db
+
+
+def _ln_relu_bwd(x2, dy2, weight, bias):
+    """(dx, dgamma, dbeta, column sums of dx) of y = ReLU(LN(x)) through lpf_layernorm_relu_bwd_f32."""
+    d = x2.shape[1]
+    dev = x2.device
+    dx = torch.empty_like(x2)
+    dg = torch.empty(d, dtype=torch.float32, device=dev)
+    db = torch.empty(d, dtype=torch.float32, device=dev)
+    dxs = torch.empty(d, dtype=torch.float32, device=dev)
+    lib = _lib.hip()
+    ws = torch.empty(int(lib.lpf_layernorm_bwd_workspace_floats(d)), dtype=torch.float32, device=dev)
+    check(lib.lpf_layernorm_relu_bwd_f32(x2.shape[0], d, ptr(x2), x2.stride(0), ptr(dy2), dy2.stride(0), ptr(weight),
+                                         ptr(bias), ptr(dx), dx.stride(0), ptr(dg), ptr(db), ptr(dxs), ptr(ws),
+                                         _stream(x2)), "lpf_layernorm_relu_bwd_f32")
+    return dx, dg, db, dxs
+
+
+class GcnLayerFn(torch.autograd.Function):
+    """One GCN layer behind its Linear: r = ReLU(LN(A_hat t + b)) (other_models.py:66-69 with the dropout moved behind
+    the ReLU, which it commutes with).  Forward: the aggregation with the bias added in its epilogue
+    (lpf_spmm_csr_f32), then LayerNorm + ReLU in one kernel; only the pre-norm tensor is saved.  Backward: one fused
+    LayerNorm/ReLU backward that also yields the bias gradient, then the aggregation with A_hat^T."""
+
+    @staticmethod
+    def forward(ctx, t, a_hat, conv_bias, ln_w, ln_b):
+        u = _spmm_plain(a_hat, t, bias=conv_bias)
+        r = torch.empty_like(u)
+        check(_lib.hip().lpf_layernorm_f32(u.shape[0], u.shape[1], ptr(u), u.stride(0), ptr(ln_w), ptr(ln_b), ptr(r),
+                                           r.stride(0), _lib.FLAG_RELU, _stream(u)), "lpf_layernorm_f32")
+        ctx.save_for_backward(u, ln_w, ln_b)
+        ctx.a_hat = a_hat
+        return r
+
+    @staticmethod
+    def backward(ctx, dr):
+        u, ln_w, ln_b = ctx.saved_tensors
+        du, dg, db, dbias = _ln_relu_bwd(u, dr.contiguous(), ln_w, ln_b)
+        dt = _spmm_plain(_transpose_csr(ctx.a_hat), du)
+        return dt, None, dbias, dg, db
+
+
 def layer_norm(x, weight, bias):
     """LayerNorm over the last dimension; the C-ABI kernels when the width allows (D % 4 == 0, D <= 256)."""
     d = x.shape[-1]
@@ -206,9 +267,12 @@ def _mlp(mod, x):
     """The reference's MLP (other_models.py:125-138): (Linear -> LayerNorm -> ReLU -> dropout)* -> Linear."""
     for lin in mod.linears[:-1]:
         x = linear(x, lin.weight, lin.bias)
-        if mod.norm is not None:
-            x = layer_norm(x, mod.norm.weight, mod.norm.bias)
-        x = F.relu(x)
+        if mod.norm is not None and x.shape[-1] % 4 == 0 and x.shape[-1] <= 256 and x.numel() > 0:
+            x = LnReluFn.apply(x, mod.norm.weight, mod.norm.bias)
+        else:
+            if mod.norm is not None:
+                x = layer_norm(x, mod.norm.weight, mod.norm.bias)
+            x = F.relu(x)
         x = F.dropout(x, p=mod.dropout, training=True)
     last = mod.linears[-1]
     return linear(x, last.weight, last.bias)
@@ -248,12 +312,19 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     x = model._features()
     x = F.dropout(x, p=model.node_encoder.feat_drop, training=True)
     for i, conv in enumerate(enc.convs):
-        xi = SpmmFn.apply(linear(x, conv.lin.weight, None), a_hat) + conv.bias
-        if enc.lns is not None:
-            xi = layer_norm(xi, enc.lns[i].weight, enc.lns[i].bias)
-        xi = F.dropout(xi, p=enc.dropout, training=True)
-        if enc.relu:
-            xi = F.relu(xi)
+        t = linear(x, conv.lin.weight, None)
+        if enc.lns is not None and enc.relu and t.shape[1] % 4 == 0 and t.shape[1] <= 256:
+            # aggregation + bias, LayerNorm + ReLU: two forward and two backward kernels; the dropout (a non-negative
+            # mask) is applied behind the ReLU, with which it commutes
+            xi = GcnLayerFn.apply(t, a_hat, conv.bias, enc.lns[i].weight, enc.lns[i].bias)
+            xi = F.dropout(xi, p=enc.dropout, training=True)
+        else:
+            xi = SpmmFn.apply(t, a_hat) + conv.bias
+            if enc.lns is not None:
+                xi = layer_norm(xi, enc.lns[i].weight, enc.lns[i].bias)
+            xi = F.dropout(xi, p=enc.dropout, training=True)
+            if enc.relu:
+                xi = F.relu(xi)
         x = x + xi if (enc.residual and x.shape[-1] == xi.shape[-1]) else xi
     x_node = layer_norm(x, model.gnn_norm.weight, model.gnn_norm.bias)
     x_node = x_node.contiguous()
