@@ -330,7 +330,8 @@ int lpf_pair_attention_fused_bf16(int32_t D, int64_t bs, const int32_t *type_ptr
  * lpformer_amd/fold.py flip_tables: pe_tab_signed float[3][D][4] = the pe_tab row of a unit times +1 when the unit is
  * active at (0, 0) and -1 when it is not (the kernel then sees a flipped unit as a NEGATIVE pre-activation of
  * magnitude |y_k|), base float[3][4][D] = (P0, Q0, R0, C0), wfold_t float[3][D][D] (wfold_t[t][k][c] = Wfold_t[c][k]).
- * Bound: the Z-row gather (4 D + 16 bytes per entry) when flips are rare. */
+ * Bound: vector-ALU issue (about ninety instructions per entry plus a dozen per flipped unit); the Z-row gather
+ * (4 D + 16 bytes per entry) hides under it. */
 int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
                                 const float *Z, int64_t ldz, const float *q, int64_t ldq, const float *pe_tab_signed,
                                 const float *pe_stat, const float *base, const float *wfold_t, const float *att,

@@ -31,6 +31,7 @@
 // Placement is deterministic (flat slot order): per type one dense region ordered by (pair, slot); inside a pair's
 // one-hop segment the kept nodes of N(a) come before those of N(b) (flag bit 31 of the pair word) -- exactly the layout
 // select2.hip produces, so lpf_select_export and the attention kernels do not care which path ran.
+
 #include "select_common.h"
 
 // the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
