@@ -116,6 +116,9 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
         const float4 *src = reinterpret_cast<const float4 *>(A.wfoldT) + (int64_t)T_LO * D * G;
         for (int i = threadIdx.x; i < WTL * D * G; i += NTH) lwt[i] = src[i];
     }
+#ifdef FL_STAMPS
+    const uint64_t t_start = wall_clock64();
+#endif
     int *const lticket = reinterpret_cast<int *>(lsc + (NTH / 64) * EPW * 16);
     if (threadIdx.x == 0) *lticket = 0;
     __syncthreads();
@@ -351,6 +354,14 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
         u0 = bundle(NTH / 64 + __builtin_amdgcn_readfirstlane(tk_next));
         if (u0 < total_units) tk_next = draw();
     }
+#ifdef FL_STAMPS
+    // (tuning builds only: end time of every wavefront into the tail of the boundary-record buffer)
+    if (lane == 0) {
+        uint64_t *stamps = reinterpret_cast<uint64_t *>(A.bnd + (int64_t)3 * A.units_cap * 2 * RS) - (int64_t)gridDim.x * (NTH / 64) - 1;
+        stamps[(int64_t)blockIdx.x * (NTH / 64) + (threadIdx.x >> 6)] = wall_clock64();
+        if (blockIdx.x == 0 && threadIdx.x == 0) stamps[(int64_t)gridDim.x * (NTH / 64)] = t_start;
+    }
+#endif
 }
 
 }  // namespace
@@ -397,7 +408,12 @@ extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t 
     switch (D) {
         case 32: LPF_FLIP(8, 512, 3, 2); break;
         case 64: LPF_FLIP(16, 512, 3, 2); break;
+#ifdef FL_CFG128      /* (tuning builds: other shapes of the D = 128 launch) */
+#define LPF_FLIP_X(...) LPF_FLIP(__VA_ARGS__)
+        case 128: LPF_FLIP_X(FL_CFG128); break;
+#else
         case 128: LPF_FLIP(32, 1024, 2, 1); break;
+#endif
         case 256: LPF_FLIP(64, 256, 0, 3); break;
         default: return LPF_ERR_UNSUPPORTED;
     }
