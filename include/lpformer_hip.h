@@ -72,6 +72,29 @@ int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t 
                      const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *long_rows,
                      int64_t n_long, void *stream);
 
+/* One GCN layer in one launch, square case (in = out = D in {32, 64, 128}): aggregate first, transform in registers
+ * (gcn_fused.hip).  Replaces lpf_gemm_f32 + lpf_spmm_csr_f32 for such a layer (other_models.py:61-76 -> GCNConv):
+ *   out[r - row_base] = epilogue( (sum_e w_e H[col_e]) W^T ),  epilogue = + bias, LayerNorm, ReLU, + residual, gnn_norm
+ * as lpf_spmm_csr_f32 (same flags).  row_order int32[16 n_tiles]: the rows to produce, in the order they are worked on
+ * -- any order is correct; lpformer_amd/graph.py fused_row_order sorts by degree so that the 16 rows of a tile, which
+ * advance in lockstep, are equally long -- with -1 = padding and v <= -2 = hub number (-2 - v): hubs int32[n_hub][3] =
+ * (row id, first slice, number of slices), the hub row's entry list being replaced by rows first .. first + number - 1
+ * of t_parts (float[n_slices][D], lpf_spmm_row_parts_f32), each with weight 1.  rowptr is indexed by the global row
+ * id; out / residual hold rows row_base...  w_packed = the weight image of lpformer_amd/fold.py pack_dense(W, 1)
+ * (W = GCNConv.lin.weight, [D, D]).  Rounding order differs from transform-then-aggregate (A (X W^T) vs (A X) W^T);
+ * identical from launch to launch. */
+int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
+                            const int64_t *rowptr, const int32_t *col, const float *w, const float *H, int64_t ldh,
+                            const float *w_packed, float *out, int64_t ldo, const float *bias, const float *ln_g,
+                            const float *ln_b, const float *residual, int64_t ldr, const float *ln2_g,
+                            const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
+                            void *stream);
+
+/* Sums of slices of (hub) rows: out[p][:D] = sum over the stored entries e in [parts[2p], parts[2p+1]) of w_e H[col_e]
+ * (one workgroup per slice, partial sums added in a fixed order).  D a multiple of 8, <= 128. */
+int lpf_spmm_row_parts_f32(int32_t D, const int64_t *parts, int64_t n_parts, const int32_t *col, const float *w,
+                           const float *H, int64_t ldh, float *out, void *stream);
+
 /* bf16 THROUGHPUT MODE of the aggregation (BASELINE.json config 2 names bf16 storage; SURVEY 8b lpf_spmm_csr_bf16):
  * the gathered table H holds bf16 rows (ldh in bf16 elements, rows 16-byte aligned) -- half the gather bytes, which
  * are what bounds this kernel --, the sum over neighbours, the epilogue and the output stay fp32 (D % 8 == 0: a lane

@@ -1,0 +1,265 @@
+// One GCN layer in ONE launch, square case (in = out = D <= 128): aggregate first, transform in registers.
+//
+// Reference: GCN.forward (src/models/other_models.py:61-76) -> PyG GCNConv: lin(x), then propagate with the gcn_norm
+// weights, + bias; LayerNorm / ReLU / residual after it; LinkTransformer.propagate's gnn_norm for the last layer
+// (src/models/link_transformer.py:110-129).  A_hat (X W^T) = (A_hat X) W^T, so the layer is
+//     out[r] = epilogue( (sum_e w_e X[col_e]) W^T )
+// and the two launches of the unfused path (gemm_f32.hip: N x D x D product, 118 us on the collab-like graph, then
+// spmm_csr.hip: 215 us) with the N x D round trip between them become one gather-bound kernel whose matrix work hides
+// under the gather (different rounding order than transform-then-aggregate; same order in every row, every launch).
+//
+// Layout.  v_mfma_f32_16x16x4_f32 with the NODES ON THE COLUMNS: a wavefront owns a tile of 16 output rows, lane
+// (j = lane % 16, q = lane / 16) accumulates row j's input features 16 g + 4 q + 0..3 (g = 0 .. D/16 - 1) -- NT float4
+// per lane, each neighbour row fetched as 16-byte pieces, 64 contiguous bytes per (row, g) -- and those accumulators
+// ARE the B operands of the product (k = 16 g + 4 q + u for the u-th MFMA of k-group g, the packing of
+// lpformer_amd/fold.py pack_dense): no transposition, no LDS staging of activations.  W^T sits packed in LDS (NT
+// stages x 8 KB), shared by the workgroup's wavefronts, which otherwise never meet: after the first tile they drift
+// apart, some gathering while others multiply.  The product leaves lane (j, q) with out[j][16 c + 4 q + 0..3] for
+// c = 0 .. NT-1: the epilogue's LayerNorm is an in-lane sum plus two cross-lane steps, loads and stores are float4.
+//
+// The 16 rows of a tile advance through their edge lists in lockstep, so tiles are cut from a DEGREE-SORTED row order
+// (lpformer_amd/graph.py fused_row_order; any permutation is correct, this one keeps the 16 rows equally long).  Hub
+// rows (> 128 entries) are cut into slices of 256 entries that spmm_row_parts_kernel (spmm_csr.hip) sums into a
+// compact table, one workgroup per slice; here a hub row is a row whose "neighbours" are its slices, weight 1.
+#include "lpf_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GcnFusedArgs {
+    int64_t n_tiles;
+    const int32_t *row_order;    // [16 n_tiles]: row id >= 0; -1 = padding; <= -2: hub number -2 - v
+    int64_t row_base;            // out / residual hold rows row_base ..
+    const int64_t *rowptr;
+    const int32_t *col;
+    const float *w;
+    const float *H; int64_t ldh;
+    const float *wp;             // pack_dense(W, 1): [NT stages][512] float4
+    float *out; int64_t ldo;
+    const float *bias, *ln_g, *ln_b;
+    const float *residual; int64_t ldr;
+    const float *ln2_g, *ln2_b;
+    uint32_t flags;
+    const int32_t *hubs;         // [n_hub][3]: row id, first slice, number of slices
+    const float *t_parts;        // [n_slices][D]: the slices' sums
+};
+
+constexpr int GF_THREADS = 512;
+constexpr int GF_STAGE = 512;    // float4 per packed stage (pack_dense pads a stage to 512)
+
+__device__ __forceinline__ float gf_row_sum(float v) {   // over the four lanes (q) of a row
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int NT>
+__device__ __forceinline__ void gf_layernorm(f32x4 (&y)[NT], const float *g, const float *b, int q) {
+    constexpr float inv_d = 1.0f / (16 * NT);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) s += (y[c][0] + y[c][1]) + (y[c][2] + y[c][3]);
+    const float mean = gf_row_sum(s) * inv_d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = y[c][r] - mean;
+            s2 = fmaf(d, d, s2);
+        }
+    const float rstd = 1.0f / sqrtf(gf_row_sum(s2) * inv_d + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + 16 * c + 4 * q);
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(b + 16 * c + 4 * q);
+        y[c] = (y[c] - mean) * rstd * gg + bb;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(GF_THREADS, 4) void gcn_fused_kernel(const GcnFusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 gf_lds[];
+    f32x4 *const lw = gf_lds;                                       // [NT][GF_STAGE]
+    int *const lticket = reinterpret_cast<int *>(gf_lds + NT * GF_STAGE);
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    for (int i = threadIdx.x; i < NT * GF_STAGE; i += GF_THREADS) lw[i] = reinterpret_cast<const f32x4 *>(A.wp)[i];
+    if (threadIdx.x == 0) *lticket = 0;
+    __syncthreads();
+
+    // tiles: a workgroup owns every gridDim.x-th one, its wavefronts draw them from a ticket in LDS (first round by
+    // position), the next ticket is drawn before the current tile is worked on
+    auto draw = [&]() __attribute__((always_inline)) {
+        int tk = 0;
+        if (lane == 0) tk = atomicAdd(lticket, 1);
+        return tk;
+    };
+    auto tile_of = [&](int k) __attribute__((always_inline)) { return (int64_t)k * gridDim.x + blockIdx.x; };
+    int tk_next = draw();
+    for (int64_t tile = tile_of(threadIdx.x >> 6); tile < A.n_tiles;) {
+        const int ro = A.row_order[tile * 16 + j];
+        const bool live = ro != -1, hub = ro < -1;
+        // the row's entry list: [e, e + n_total) of (col, w), or the hub's slices
+        int64_t row = live ? ro : 0, e = 0;
+        int n_total = 0;
+        int32_t hub_c = 0;
+        if (hub) {
+            const int32_t *hb = A.hubs + 3 * (int64_t)(-2 - ro);
+            row = hb[0];
+            hub_c = hb[1];
+            n_total = hb[2];
+        } else if (live) {
+            e = A.rowptr[row];
+            n_total = (int)(A.rowptr[row + 1] - e);
+        }
+        const float *tab = (hub ? A.t_parts : A.H) + 4 * q;
+        const int64_t ldt = hub ? 16 * NT : A.ldh;
+
+        f32x4 acc[NT];
+#pragma unroll
+        for (int g = 0; g < NT; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef GF_NOGATHER
+        // The gather, two neighbours per step; the (col, weight) pairs of the NEXT step are requested before this
+        // step's rows are added.  Entries past the end of a row are (row 0, weight 0).
+        auto edge = [&](int k, int32_t &c, float &wv) __attribute__((always_inline)) {
+            c = 0;
+            wv = 0.f;
+            if (k < n_total) {
+                if (hub) {
+                    c = hub_c + k;
+                    wv = 1.0f;
+                } else {
+                    c = A.col[e + k];
+                    wv = A.w[e + k];
+                }
+            }
+        };
+        int32_t c0, c1;
+        float w0, w1;
+        edge(0, c0, w0);
+        edge(1, c1, w1);
+        for (int k = 0; __any(k < n_total); k += 2) {
+            const float *p0 = tab + (int64_t)c0 * ldt, *p1 = tab + (int64_t)c1 * ldt;
+            const float u0 = w0, u1 = w1;
+            f32x4 h0[NT], h1[NT];
+#pragma unroll
+            for (int g = 0; g < NT; ++g) h0[g] = *reinterpret_cast<const f32x4 *>(p0 + 16 * g);
+#pragma unroll
+            for (int g = 0; g < NT; ++g) h1[g] = *reinterpret_cast<const f32x4 *>(p1 + 16 * g);
+            edge(k + 2, c0, w0);
+            edge(k + 3, c1, w1);
+#pragma unroll
+            for (int g = 0; g < NT; ++g) acc[g] += h0[g] * u0;
+#pragma unroll
+            for (int g = 0; g < NT; ++g) acc[g] += h1[g] * u1;
+        }
+#endif
+
+        // out^T tile = W . acc: NT output tiles x NT k-groups x 4 MFMAs
+        f32x4 y[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) y[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef GF_NOMFMA
+#pragma unroll
+        for (int c = 0; c < NT; ++c) y[c] = acc[c];
+#else
+#pragma unroll
+        for (int g = 0; g < NT; ++g) {
+            const f32x4 *lg = lw + g * GF_STAGE + lane;
+#pragma unroll
+            for (int c0_ = 0; c0_ < NT; c0_ += 4) {      // four tiles' operands at a time
+                f32x4 a[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = (c0_ + c < NT) ? lg[(c0_ + c) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c0_ + c < NT)
+                            y[c0_ + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][u], acc[g][u], y[c0_ + c], 0, 0, 0);
+            }
+        }
+#endif
+
+        // epilogue: + bias, LayerNorm, ReLU, + residual, gnn_norm; lane (j, q) holds out[row j][16 c + 4 q + 0..3]
+        if (A.bias) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c) y[c] += *reinterpret_cast<const f32x4 *>(A.bias + 16 * c + 4 * q);
+        }
+        if (A.ln_g) gf_layernorm<NT>(y, A.ln_g, A.ln_b, q);
+        if (A.flags & LPF_FLAG_RELU) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[c][r] = fmaxf(y[c][r], 0.f);
+        }
+        const int64_t orow = row - A.row_base;
+        if (A.residual && live) {
+            const float *rp = A.residual + orow * A.ldr + 4 * q;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) y[c] += *reinterpret_cast<const f32x4 *>(rp + 16 * c);
+        }
+        if (A.ln2_g) gf_layernorm<NT>(y, A.ln2_g, A.ln2_b, q);
+        if (live) {
+            float *op = A.out + orow * A.ldo + 4 * q;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) *reinterpret_cast<f32x4 *>(op + 16 * c) = y[c];
+        }
+        tile = tile_of(GF_THREADS / 64 + __builtin_amdgcn_readfirstlane(tk_next));
+        if (tile < A.n_tiles) tk_next = draw();
+    }
+}
+
+}  // namespace
+
+extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
+                                       const int64_t *rowptr, const int32_t *col, const float *w, const float *H,
+                                       int64_t ldh, const float *w_packed, float *out, int64_t ldo, const float *bias,
+                                       const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                                       const float *ln2_g, const float *ln2_b, uint32_t flags,
+                                       const int32_t *hubs, const float *t_parts, void *stream) {
+    if (n_tiles == 0) return LPF_OK;
+    LPF_REQUIRE(n_tiles > 0 && row_order && rowptr && col && w && H && w_packed && out);
+    if (D != 32 && D != 64 && D != 128) return LPF_ERR_UNSUPPORTED;
+    LPF_REQUIRE(ldh >= D && ldo >= D && (ldh & 3) == 0 && (ldo & 3) == 0 && lpf_aligned16(H) && lpf_aligned16(out) &&
+                lpf_aligned16(w_packed));
+    LPF_REQUIRE((!ln_g) == (!ln_b) && (!ln2_g) == (!ln2_b) && (!hubs) == (!t_parts));
+    LPF_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= D && lpf_aligned16(residual)));
+    LPF_REQUIRE((!bias || lpf_aligned16(bias)) && (!ln_g || (lpf_aligned16(ln_g) && lpf_aligned16(ln_b))) &&
+                (!ln2_g || (lpf_aligned16(ln2_g) && lpf_aligned16(ln2_b))) && (!t_parts || lpf_aligned16(t_parts)));
+    const GcnFusedArgs a{n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
+                         residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
+        n_cu = prop.multiProcessorCount;
+    }
+    // persistent workgroups, two of 512 threads per CU (64 KB of W^T each at D = 128)
+    int64_t groups = (n_tiles + GF_THREADS / 64 - 1) / (GF_THREADS / 64);
+    if (groups > 2ll * n_cu) groups = 2ll * n_cu;
+#define LPF_GF(NT)                                                                                                  \
+    do {                                                                                                            \
+        auto kern = gcn_fused_kernel<NT>;                                                                           \
+        constexpr size_t lds = (size_t)(NT * GF_STAGE + 1) * sizeof(f32x4);                                         \
+        static bool lds_set = false;                                                                                \
+        if (lds > 64 * 1024 && !lds_set) {                                                                          \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds) != hipSuccess)                                                        \
+                return LPF_ERR_LAUNCH;                                                                              \
+            lds_set = true;                                                                                         \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(GF_THREADS), lds, s, a);                              \
+    } while (0)
+    switch (D) {
+        case 32: LPF_GF(2); break;
+        case 64: LPF_GF(4); break;
+        default: LPF_GF(8); break;
+    }
+#undef LPF_GF
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -6,8 +6,6 @@
 // (ds_bpermute) and gathers the neighbour rows four at a time so four 16-byte gathers are always in flight.  The
 // accumulator never leaves registers: bias, LayerNorm (group-wide butterfly reduction), ReLU, residual and the
 // final `gnn_norm` LayerNorm are applied before the single store.  Bound: HBM / L2 gather bandwidth.
-#include <stdlib.h>
-
 #include "lpf_common.h"
 
 namespace {
@@ -221,6 +219,41 @@ __global__ __launch_bounds__(256) void spmm_long_rows_kernel(
     }
 }
 
+// Slices of hub rows for gcn_fused.hip: workgroup p sums the stored entries [parts[2p], parts[2p+1]) of one row -- its
+// 256 / G lane groups take chunks of G entries round-robin, the partial sums are added in group order -- and writes the
+// plain sum (no epilogue) to row p of a compact table.
+template <int G, int V>
+__global__ __launch_bounds__(256) void spmm_row_parts_kernel(const int64_t *__restrict__ parts, int D,
+                                                             const int32_t *__restrict__ col,
+                                                             const float *__restrict__ w, const float *__restrict__ H,
+                                                             int64_t ldh, float *__restrict__ out) {
+    constexpr int NG = 256 / G;
+    __shared__ float4 part[NG][G][V];
+    const int tid = threadIdx.x, grp = tid / G, lig = tid % G;
+    const int gbase = ((tid & 63) / G) * G;
+    const int off = 4 * V * lig;
+    const bool act = off < D;
+    const int64_t e0 = parts[2 * (int64_t)blockIdx.x], e1 = parts[2 * (int64_t)blockIdx.x + 1];
+    float4 acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    spmm_accumulate<G, V, false>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
+#pragma unroll
+    for (int v = 0; v < V; ++v) part[grp][lig][v] = acc[v];
+    __syncthreads();
+    if (grp == 0 && act) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float4 y = part[0][lig][v];
+            for (int g = 1; g < NG; ++g) {
+                const float4 x = part[g][lig][v];
+                y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
+            }
+            *reinterpret_cast<float4 *>(out + (int64_t)blockIdx.x * D + off + 4 * v) = y;
+        }
+    }
+}
+
 // deg^-1/2 with the diagonal forced to weight 1 (torch_sparse.fill_diag semantics)
 __global__ void gcn_deg_kernel(int64_t n, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                const float *__restrict__ w, float *__restrict__ dis) {
@@ -275,13 +308,12 @@ int spmm_launch(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col,
     LPF_REQUIRE(!bias || lpf_aligned16(bias));
     hipStream_t s = static_cast<hipStream_t>(stream);
     // float4 per lane: 2 whenever D allows it -- the bf16 table then gives 16 gathered bytes per lane, the fp32 table 32
-    // (twice the rows per wavefront: 235 -> 219 us per layer on the collab-like graph); LPF_SPMM_V=1 (tuning aid)
-    // forces one
-    static int v_f32 = 0;
-    if (v_f32 == 0) {
-        const char *e = getenv("LPF_SPMM_V");
-        v_f32 = (e && atoi(e) == 1) ? 1 : 2;
-    }
+    // (twice the rows per wavefront: 235 -> 219 us per layer on the collab-like graph; -DLPF_SPMM_V=1 builds the
+    // one-float4 shape for comparison)
+#ifndef LPF_SPMM_V
+#define LPF_SPMM_V 2
+#endif
+    constexpr int v_f32 = LPF_SPMM_V;
     const int V = HB ? 2 : (((D & 7) || D > 128) ? 1 : v_f32);  // (D = 256, hub rows only: one float4 measured faster)
     const int G = (D <= 64 ? 16 : (D <= 128 ? 32 : 64)) / V;
     const int rpw = 64 / G;
@@ -321,6 +353,23 @@ extern "C" int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, con
                                 int64_t n_long, void *stream) {
     return spmm_launch<false>(n, D, rowptr, col, w, H, ldh, out, ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b,
                               flags, long_rows, n_long, stream);
+}
+
+extern "C" int lpf_spmm_row_parts_f32(int32_t D, const int64_t *parts, int64_t n_parts, const int32_t *col, const float *w,
+                                      const float *H, int64_t ldh, float *out, void *stream) {
+    if (n_parts == 0) return LPF_OK;
+    LPF_REQUIRE(n_parts > 0 && n_parts < (1ll << 31) && parts && col && w && H && out);
+    if (D <= 0 || (D & 7) || D > 128) return LPF_ERR_UNSUPPORTED;
+    LPF_REQUIRE(ldh >= D && (ldh & 3) == 0 && lpf_aligned16(H) && lpf_aligned16(out));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (D <= 64)
+        hipLaunchKernelGGL((spmm_row_parts_kernel<8, 2>), dim3((unsigned)n_parts), dim3(256), 0, s, parts, D, col, w, H,
+                           ldh, out);
+    else
+        hipLaunchKernelGGL((spmm_row_parts_kernel<16, 2>), dim3((unsigned)n_parts), dim3(256), 0, s, parts, D, col, w, H,
+                           ldh, out);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
 }
 
 extern "C" int lpf_spmm_csr_bf16(int64_t n, int32_t D, const int64_t *rowptr, const int32_t *col, const float *w,

@@ -118,7 +118,9 @@ def encoder_plan(encoder_ms_one_gpu: float, n: int, d: int, n_layers: int, world
                                                                        = enc / world + (L + 1) * ag + keys
          gather_once: layers 1..L-1 replicated, the last layer's aggregation and Z / Y on the rank's rows, ONE
                       all-gather of [X | Z | Y] (3 d floats per node)  = enc - (1 - 1/world) * (last_agg + keys) + 3 * ag
-    ``last_agg_ms``: the last layer's aggregation (SpMM + epilogue) on one GPU (default: 0.7 * enc / L);
+    ``last_agg_ms``: the row-shardable part of the last layer on one GPU -- its aggregation (SpMM + epilogue), or the
+    whole layer when it runs as one fused launch (default: 0.7 * enc / L).  A sharded encoder whose layers are all
+    fused needs L all-gathers, not L + 1 (layer 0 reads the replicated features): the estimate is on the safe side;
     ``node_keys_ms``: the two N x D x D projections.  Returns the estimates and the cheapest mode.
     The reference has no counterpart (single device)."""
     if last_agg_ms is None:

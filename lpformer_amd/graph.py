@@ -67,6 +67,38 @@ class DeviceCSR:
         return self.host
 
 
+def fused_row_order(rowptr: torch.Tensor, lo: int, hi: int, long_threshold: int = 128, part: int = 256):
+    """Work order of rows [lo, hi) for ``lpf_gcn_layer_fused_f32`` (csrc/gcn_fused.hip).  Returns
+    ``(order, hubs, parts)``: ``order`` int32 codes, 16 per tile -- hub rows first (more than ``long_threshold`` stored
+    entries; code -2 - k for the k-th one), then the other rows by falling degree (stable), padded with -1;
+    ``hubs`` int32 [n_hub, 3] = (global row id, first slice, number of slices) and ``parts`` int64 [n_slices, 2] =
+    the slices' entry ranges (``part`` entries each, ``lpf_spmm_row_parts_f32``), both None without hub rows.
+    The 16 rows of a tile walk their entry lists in lockstep: sorted, they are equally long."""
+    dev = rowptr.device
+    deg = rowptr[lo + 1:hi + 1] - rowptr[lo:hi]
+    rows = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+    is_long = deg > long_threshold
+    long_rows = rows[is_long]
+    short = rows[~is_long]
+    _, perm = torch.sort(deg[~is_long], descending=True, stable=True)
+    codes = torch.cat([-2 - torch.arange(long_rows.numel(), dtype=torch.int64, device=dev), short[perm]])
+    pad = (-codes.numel()) % 16
+    if pad:
+        codes = torch.cat([codes, torch.full((pad,), -1, dtype=torch.int64, device=dev)])
+    order = codes.to(torch.int32).contiguous()
+    if long_rows.numel() == 0:
+        return order, None, None
+    ldeg = deg[is_long]
+    n_sl = (ldeg + part - 1) // part
+    first = torch.cumsum(n_sl, 0) - n_sl
+    hubs = torch.stack([long_rows, first, n_sl], dim=1).to(torch.int32).contiguous()
+    owner = torch.repeat_interleave(torch.arange(long_rows.numel(), device=dev), n_sl)
+    within = torch.arange(int(n_sl.sum()), device=dev) - first[owner]
+    e0 = rowptr[long_rows][owner] + within * part
+    e1 = torch.minimum(e0 + part, rowptr[long_rows + 1][owner])
+    return order, hubs, torch.stack([e0, e1], dim=1).to(torch.int64).contiguous()
+
+
 def _from_scipy(m: sp.spmatrix, n: int, keep_val: bool) -> CSR:
     m = m.tocsr()
     m.sum_duplicates()

@@ -122,6 +122,22 @@ class _PaddedLinear:
         return self._w
 
 
+class _PackedSquare:
+    """``fold.pack_dense(W, 1)`` image of a square fp32 weight on its device (csrc/gcn_fused.hip), refreshed when the
+    parameter changes."""
+
+    def __init__(self):
+        self._key = None
+        self._w = None
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        key = (weight.data_ptr(), weight._version, weight.device)
+        if key != self._key:
+            img = fold.pack_dense(weight.detach().to(torch.float32).cpu().numpy(), 1)
+            self._w, self._key = torch.from_numpy(img).to(weight.device), key
+        return self._w
+
+
 class DenseChain:
     """Cached device tables + launcher for ``lpf_dense_chain_f32``: Linear (+addend) (+LayerNorm) (+ReLU) (+Linear),
     refreshed when a parameter changes.  ``run`` returns None when the shape has no fused instantiation (the caller
@@ -497,6 +513,10 @@ class LinkTransformer(nn.Module):
         self._param_list = None  # cached list(self.parameters()) for the fold key
         self._chain_att = DenseChain("dense_chain_attn_out")   # attention output projection + post_att_norm
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
+        self._conv_packs = [_PackedSquare() for _ in self.node_encoder.gnn_encoder.convs]
+        # square GCN layers (in = out = D <= 128) in one launch, aggregate-then-transform (csrc/gcn_fused.hip); False:
+        # always lpf_gemm_f32 + lpf_spmm_csr_f32
+        self.encoder_fused = True
         self.last_stats = {}
         self._shard = (0, 1)   # (rank, world)
         self.encoder_mode = "sharded"  # with world > 1: "sharded" (rows + all-gather per layer) or "replicated"
@@ -652,20 +672,20 @@ class LinkTransformer(nn.Module):
                 for i in range(n_layers):
                     if _layers_out is not None:
                         _layers_out.append(x)
-                    x = self._layer_aggregate(i, a_hat, self._layer_transform(i, x), 0, self.num_nodes, x)
+                    x = self._layer(i, a_hat, x, 0, self.num_nodes)
             elif self.encoder_mode == "gather_once":
                 # BASELINE.json's literal layout -- "a single RCCL all-gather of node embeddings after the encoder":
                 # layers 1..L-1 run on every rank (no exchange), the LAST layer's aggregation + epilogue and the two
                 # per-node projections of the attention (Z, Y: _node_keys) run on the rank's row block only, and ONE
-                # all-gather of [X_node | Z | Y] rows (3 D floats per node) hands every rank all three tables.  The
-                # last layer's X W^T stays replicated: a row's aggregation reads the transformed rows of all its
-                # neighbours, and keeping the GEMM whole keeps every element bitwise equal to the unsharded encoder.
+                # all-gather of [X_node | Z | Y] rows (3 D floats per node) hands every rank all three tables.  A fused
+                # last layer (csrc/gcn_fused.hip) is row-sharded whole; an unfused one keeps its X W^T replicated (a
+                # row's aggregation reads the transformed rows of all its neighbours).  Every element stays bitwise
+                # equal to the unsharded encoder.
                 x = self._features()
                 for i in range(n_layers - 1):
-                    x = self._layer_aggregate(i, a_hat, self._layer_transform(i, x), 0, self.num_nodes, x)
+                    x = self._layer(i, a_hat, x, 0, self.num_nodes)
                 lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
-                last = n_layers - 1
-                x_rows = self._layer_aggregate(last, a_hat, self._layer_transform(last, x), lo, hi, x[lo:hi])
+                x_rows = self._layer(n_layers - 1, a_hat, x, lo, hi)
                 w = self._fold()
                 d = self.dim
                 pack = torch.empty(hi - lo, 3 * d, dtype=torch.float32, device=self.device)
@@ -677,15 +697,71 @@ class LinkTransformer(nn.Module):
                 torch.cuda.current_stream(self.device).synchronize()      # other streams read Z, Y (as _node_keys)
                 self._z_cache = (weakref.ref(x), x._version, full[:, d:2 * d], full[:, 2 * d:])
             else:
+                # row-sharded: a rank produces its block of rows of every layer.  A fused layer (aggregate, then
+                # transform) reads the layer INPUT of all nodes -- the features for layer 0 (replicated: no exchange),
+                # an all-gather of the previous layer's rows after that; an unfused one transforms the rank's rows
+                # and all-gathers the transformed rows.  Either way one all-gather per layer, and one of the output.
                 lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
-                x = self._features()[lo:hi]                      # the rank's rows of the layer input
+                x_full = self._features()
+                x = x_full[lo:hi]                                # the rank's rows of the layer input
                 for i in range(n_layers):
-                    t = lpf_dist.allgather_rows(self._layer_transform(i, x), self.num_nodes)   # [N, D] on every rank
-                    x = self._layer_aggregate(i, a_hat, t, lo, hi, x)
+                    if self._fusable(i, x.shape[1]):
+                        if x_full is None:
+                            x_full = lpf_dist.allgather_rows(x, self.num_nodes)
+                        x = self._layer_fused(i, a_hat, _as_f32_rows(x_full), lo, hi)
+                    else:
+                        t = lpf_dist.allgather_rows(self._layer_transform(i, x), self.num_nodes)   # [N, D] everywhere
+                        x = self._layer_aggregate(i, a_hat, t, lo, hi, x)
+                    x_full = None
                 x = lpf_dist.allgather_rows(x, self.num_nodes)  # the all-gather of node embeddings
             if _layers_out is not None:
                 _layers_out.append(x)
             return x
+
+    def _layer(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+        """Rows [lo, hi) of layer i's output from the layer input ``x`` of ALL nodes: one launch when the layer is
+        square and small enough for the fused kernel, transform + aggregate otherwise."""
+        x = _as_f32_rows(x)
+        if self._fusable(i, x.shape[1]):
+            return self._layer_fused(i, a_hat, x, lo, hi)
+        return self._layer_aggregate(i, a_hat, self._layer_transform(i, x), lo, hi, x[lo:hi])
+
+    def _fusable(self, i: int, in_dim: int) -> bool:
+        """Layer i as ONE launch (csrc/gcn_fused.hip)?  fp32 table, square weight, D in {32, 64, 128}."""
+        d_out, d_in = self.node_encoder.gnn_encoder.convs[i].lin.weight.shape
+        return (self.encoder_fused and self.encoder_precision != "bf16" and d_in == d_out and d_out in (32, 64, 128)
+                and in_dim == d_in)
+
+    def _layer_fused(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+        """``lpf_gcn_layer_fused_f32``: out[r] = epilogue((sum_e w_e x[col_e]) W^T) for r in [lo, hi) -- the same layer
+        as ``_layer_transform`` + ``_layer_aggregate`` with the sum taken before the product."""
+        enc = self.node_encoder.gnn_encoder
+        conv = enc.convs[i]
+        d = x.shape[1]
+        last = i == len(enc.convs) - 1
+        lib, st = _lib.hip(), _stream(self.device)
+        cache = a_hat.__dict__.setdefault("_fused_order", {})
+        if (lo, hi) not in cache:
+            cache[(lo, hi)] = graph.fused_row_order(a_hat.rowptr, lo, hi)
+        order, hubs, parts = cache[(lo, hi)]
+        ln = enc.lns[i] if enc.lns is not None else None
+        res = x[lo:hi] if enc.residual else None
+        out = torch.empty(hi - lo, d, dtype=torch.float32, device=self.device)
+        t_parts = None
+        if hubs is not None:   # hub rows: their slices are summed first, the layer kernel reads the sums
+            t_parts = self._workspace("gcn_t_parts", parts.shape[0] * d, torch.float32, st)
+            with KernelTimer.span("spmm_row_parts"):
+                check(lib.lpf_spmm_row_parts_f32(d, ptr(parts), parts.shape[0], ptr(a_hat.col), ptr(a_hat.val), ptr(x),
+                                                 x.stride(0), ptr(t_parts), st), "lpf_spmm_row_parts_f32")
+        with KernelTimer.span("gcn_layer_fused"):
+            check(lib.lpf_gcn_layer_fused_f32(
+                d, order.numel() // 16, ptr(order), lo, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x),
+                x.stride(0), ptr(self._conv_packs[i].get(conv.lin.weight)), ptr(out), out.stride(0), ptr(conv.bias),
+                ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
+                ptr(res), 0 if res is None else res.stride(0),
+                ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
+                FLAG_RELU if enc.relu else 0, ptr(hubs), ptr(t_parts), st), "lpf_gcn_layer_fused_f32")
+        return out
 
     def _layer_transform(self, i: int, x_rows: torch.Tensor) -> torch.Tensor:
         """GCNConv.lin of layer i on the given rows (other_models.py:66 -> PyG GCNConv: x W^T, no bias).  With

@@ -368,19 +368,31 @@ def test_pyg_facade_recovers_from_selection_overflow():
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_sharded_encoder_matches_unsharded(world):
     """The row-sharded encoder of every rank, emulated on one GPU (ragged N: not a multiple of the world size): per
-    layer each rank transforms and aggregates its own row block, the blocks are stitched where the RCCL all-gather
-    would assemble them; the result is bitwise the unsharded encoder output.  Residual GCN (the shard must add its own
-    rows of the layer input) with hub rows in every block."""
+    layer each rank produces its own row block -- a fused layer from the stitched layer input, an unfused one by
+    transforming its rows and aggregating the stitched transformed rows --, the blocks are stitched where the RCCL
+    all-gather would assemble them; the result is bitwise the unsharded encoder output.  Residual GCN (the shard must
+    add its own rows of the layer input) with hub rows in every block; ppa-like: F = 58, D = 64, so layer 0 takes the
+    two-launch path and layers 1, 2 the fused one."""
     from lpformer_amd import dist as LD
     cfg, n, ei, w, x, data, args, model, score, batch = _setup("ppa", scale=0.03)
     want = model.propagate()
-    a_hat = model._device_graph("prop", data["adj_t"])
+    a_hat = model._device_graph("prop", model._data_obj("adj", False))
     n_layers = args["gnn_layers"]
     spans = [LD.row_range(n, world, r) for r in range(world)]
-    xs = [model._features()[lo:hi] for lo, hi in spans]
+    x_full = model._features()
+    xs = [x_full[lo:hi] for lo, hi in spans]
+    kinds = []
     for i in range(n_layers):
-        t_full = torch.cat([model._layer_transform(i, xr) for xr in xs])        # <- all-gather of the transformed rows
-        xs = [model._layer_aggregate(i, a_hat, t_full, lo, hi, xr) for (lo, hi), xr in zip(spans, xs)]
+        kinds.append(model._fusable(i, xs[0].shape[1]))
+        if kinds[-1]:
+            if x_full is None:
+                x_full = torch.cat(xs)                                           # <- all-gather of the layer input
+            xs = [model._layer_fused(i, a_hat, x_full, lo, hi) for lo, hi in spans]
+        else:
+            t_full = torch.cat([model._layer_transform(i, xr) for xr in xs])    # <- all-gather of the transformed rows
+            xs = [model._layer_aggregate(i, a_hat, t_full, lo, hi, xr) for (lo, hi), xr in zip(spans, xs)]
+        x_full = None
+    assert kinds == [False, True, True]
     got = torch.cat(xs)                                                          # <- all-gather of node embeddings
     assert torch.equal(got, want)
     # pairs are split by index, scores need no exchange: scoring the shards separately = scoring the batch
@@ -502,3 +514,45 @@ def test_bf16_tail_mode(name, scale, bs):
     err = (got - ref).abs().max().item()
     print(f"bf16 tail on {name}: max |dlogit| {err:.3e}, logit range {ref.abs().max().item():.2f}")
     assert torch.isfinite(got).all() and 0.0 < err <= 5e-3
+
+
+@pytest.mark.parametrize("dim,f_in", [(128, 128), (64, 64), (32, 32), (64, 40)])
+def test_fused_gcn_layer_matches_two_launches(dim, f_in):
+    """lpf_gcn_layer_fused_f32 (aggregate, then transform in registers) against lpf_gemm_f32 + lpf_spmm_csr_f32 on a
+    heavy-tailed graph with hub rows (> 128 entries), isolated nodes and a row count that is no multiple of 16; whole
+    encoder and a row block (the gather_once layout's last layer).  f_in != dim: layer 0 cannot fuse, the others do."""
+    cfg = dict(D.CONFIGS["collab"], n=20011, edges=90000, f_in=f_in)
+    n = cfg["n"]
+    ei, w = D.chung_lu_graph(n, cfg["edges"], gamma=2.1, seed=3, max_weight=cfg["max_weight"])
+    keep = (ei[0] < n - 7) & (ei[1] < n - 7)           # the last seven nodes keep only their self loops
+    ei, w = ei[:, keep], (None if w is None else w[keep])
+    x = np.random.default_rng(4).standard_normal((n, f_in)).astype(np.float32)
+    data = D.build_data(ei, x, n, edge_weight=w, eps=1e-3)
+    args = dict(D.train_args_for(cfg), dim=dim)
+    torch.manual_seed(5)
+    model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
+    with torch.no_grad():   # biases / LayerNorm affine parameters away from their initial 0 / 1
+        for p in model.node_encoder.parameters():
+            if p.dim() == 1:
+                p.add_(0.3 * torch.randn_like(p))
+    a_hat = model._device_graph("prop", model._data_obj("adj", False))
+    deg = (a_hat.rowptr[1:] - a_hat.rowptr[:-1])
+    assert int(deg.max()) > 128 and int(deg.min()) == 1
+    model.encoder_fused = True
+    fused_layers = []
+    h1 = model.propagate(_layers_out=fused_layers)
+    model.encoder_fused = False
+    plain_layers = []
+    h0 = model.propagate(_layers_out=plain_layers)
+    assert torch.isfinite(h1).all()
+    for a, b in zip(fused_layers, plain_layers):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    # a row block of the last layer, input = the plain path's input of that layer
+    last = len(model.node_encoder.gnn_encoder.convs) - 1
+    lo, hi = 5003, 17011
+    model.encoder_fused = True
+    blk = model._layer(last, a_hat, plain_layers[last], lo, hi)
+    assert float((blk - h0[lo:hi]).abs().max()) <= 2e-5 * max(1.0, float(h0.abs().max()))
+    # launch-to-launch determinism
+    again = model._layer(last, a_hat, plain_layers[last], lo, hi)
+    assert torch.equal(blk, again)

@@ -300,3 +300,39 @@ def test_get_ppr_has_the_reference_signature_and_cache_name(tmp_path):
     assert torch.equal(a.indices(), b.indices()) and torch.equal(a.values(), b.values())
     want = lpformer_amd.calc_ppr(ei, n, 0.15, 1e-3)
     assert a._nnz() == want.nnz and torch.equal(a.values(), torch.from_numpy(want.val))
+
+
+def test_fused_row_order_covers_rows_once_and_slices_hubs():
+    """graph.fused_row_order (work list of csrc/gcn_fused.hip): every row of the block exactly once, hub rows as codes
+    <= -2 in front, the rest by falling degree, padding -1; the hubs' slices tile their entry ranges."""
+    import torch
+    from lpformer_amd import graph as G
+    rng = np.random.default_rng(0)
+    deg = rng.integers(0, 40, size=1000)
+    deg[[3, 500, 777]] = [129, 1000, 257]
+    deg[10] = 128
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)]).astype(np.int64))
+    for lo, hi in ((0, 1000), (2, 779), (4, 500)):
+        order, hubs, parts = G.fused_row_order(rowptr, lo, hi)
+        o = order.numpy()
+        assert o.size % 16 == 0
+        hub_rows = [r for r in (3, 500, 777) if lo <= r < hi]
+        if not hub_rows:
+            assert hubs is None and parts is None
+            n_h = 0
+        else:
+            h, p = hubs.numpy(), parts.numpy()
+            n_h = len(hub_rows)
+            assert h[:, 0].tolist() == hub_rows and (o[:n_h] == -2 - np.arange(n_h)).all()
+            for k, r in enumerate(hub_rows):
+                sl = p[h[k, 1]:h[k, 1] + h[k, 2]]
+                assert sl[0, 0] == rowptr[r] and sl[-1, 1] == rowptr[r + 1]
+                assert (sl[1:, 0] == sl[:-1, 1]).all() and ((sl[:, 1] - sl[:, 0]) <= 256).all()
+                assert h[k, 2] == -(-deg[r] // 256)
+            assert h[:, 1].tolist() == np.concatenate([[0], np.cumsum(h[:-1, 2])]).tolist()
+        body = o[n_h:]
+        live = body[body >= 0]
+        assert (body[live.size:] == -1).all()
+        assert sorted(live.tolist() + hub_rows) == list(range(lo, hi))
+        d = deg[live]
+        assert (d[:-1] >= d[1:]).all() and d.max() <= 128
