@@ -515,8 +515,13 @@ def main():
             if modelled:
                 roofline = dict(rooflines[modelled[0]])
                 roofline["batch_stats"] = {"n_sel": n_sel, "sum_deg": sum_deg, "sum_ppr_len": sum_ppr, "slots": slots}
-        # encoder aggregation kernel (outside the timed pair-stage region): SURVEY 8(d) bytes per layer
-        if "spmm_csr" in enc:
+        # encoder aggregation kernel (outside the timed pair-stage region): SURVEY 8(d) bytes per layer.  A square layer
+        # runs as ONE launch (gcn_layer_fused: aggregation + transform + epilogue, csrc/gcn_fused.hip) with the same
+        # algorithmic bytes as the aggregation alone -- the D x D product adds no memory traffic
+        for ename, label in (("gcn_layer_fused", "gcn_layer_fused (encoder: aggregation + transform, per layer)"),
+                             ("spmm_csr", "spmm_csr (encoder, per layer)")):
+            if ename not in enc:
+                continue
             a_hat = model._device_graph("prop", data["adj_t"])
             nnz, n_rows = a_hat.nnz, n
             if world > 1 and model.encoder_mode == "sharded":  # this rank aggregates its row block only
@@ -525,24 +530,24 @@ def main():
                 lo, hi = LD.row_range(n, world, rank)
                 nnz, n_rows = int(a_hat.rowptr[hi] - a_hat.rowptr[lo]), hi - lo
             byts = nnz * 8.0 + 8.0 * (n_rows + 1) + 4.0 * d * nnz + 4.0 * d * n_rows
-            ach = byts / (enc["spmm_csr"][2] * 1e-3) / 1e9
+            ach = byts / (enc[ename][2] * 1e-3) / 1e9
             # every feature row read once (all of them: any row can be a neighbour) + the local rows written once
             floor = nnz * 8.0 + 8.0 * (n_rows + 1) + 4.0 * d * n + 4.0 * d * n_rows
-            ach_floor = floor / (enc["spmm_csr"][2] * 1e-3) / 1e9
-            rooflines["spmm_csr"] = {"kernel": "spmm_csr (encoder, per layer)", "bound": "hbm",
-                                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                     "launch_ms": round(enc["spmm_csr"][2], 4),
-                                     # gathered bytes (every neighbour row counted, L2 / Infinity Cache
-                                     # serve most of them) above; the compulsory floor (each row once) here
-                                     "achieved_compulsory_floor": round(ach_floor, 1),
-                                     "frac_compulsory_floor": round(ach_floor / HBM_PEAK_GBS, 4)}
+            ach_floor = floor / (enc[ename][2] * 1e-3) / 1e9
+            rooflines[ename] = {"kernel": label, "bound": "hbm",
+                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                "launch_ms": round(enc[ename][2], 4),
+                                # gathered bytes (every neighbour row counted, L2 / Infinity Cache
+                                # serve most of them) above; the compulsory floor (each row once) here
+                                "achieved_compulsory_floor": round(ach_floor, 1),
+                                "frac_compulsory_floor": round(ach_floor / HBM_PEAK_GBS, 4)}
             try:
                 pmc_file = os.path.join("profiles", PMC_FILE)
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
-                if args.config == "collab" and world == 1 and "spmm_csr" in pmc["kernels"]:
-                    rooflines["spmm_csr"]["traffic"] = pmc["kernels"]["spmm_csr"]["hbm_bytes_per_launch_corrected"]
-                    rooflines["spmm_csr"]["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes)"
+                if args.config == "collab" and world == 1 and ename in pmc["kernels"]:
+                    rooflines[ename]["traffic"] = pmc["kernels"][ename]["hbm_bytes_per_launch_corrected"]
+                    rooflines[ename]["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes)"
             except (OSError, KeyError, ValueError):
                 pass
 

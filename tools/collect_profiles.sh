@@ -19,7 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_wri
 python3 tools/pmc_traffic.py $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_pmc_traffic.json $COMMIT
 # 4. matrix-core utilisation of the shipped MFMA kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/${TAG}_mfma -- python3 bench.py --streams 1 --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-timing --no-bf16 > /dev/null 2>&1
-python3 tools/pmc_summary.py $OUT/${TAG}_mfma pair_fused_kernel pair_flip_kernel tail_chain_kernel dense_chain_kernel gemm_f32 > $OUT/${TAG}_pmc_mfma_util.txt 2>&1
+python3 tools/pmc_summary.py $OUT/${TAG}_mfma pair_fused_kernel pair_flip_kernel tail_chain_kernel dense_chain_kernel gcn_fused_kernel gemm_f32 > $OUT/${TAG}_pmc_mfma_util.txt 2>&1
 echo "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); collected at commit $COMMIT" >> $OUT/${TAG}_pmc_mfma_util.txt
 # 5. timeline of the pipelined run
 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_tl -- python3 bench.py --no-cpu-baseline --no-kernel-timing --no-bf16 --repeats 1 --steps 40 > /dev/null 2>&1

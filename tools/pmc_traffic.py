@@ -16,6 +16,7 @@ SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
     ("tail_chain_kernel", "tail_chain"), ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"),
     ("pair_scores_", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
     ("pair_softmax_gather_kernel", "pair_softmax_gather_light"),
+    ("gcn_fused_kernel", "gcn_layer_fused"), ("spmm_row_parts", "spmm_row_parts"),
     ("spmm_csr_kernel", "spmm_csr"), ("spmm_long_rows", "spmm_long_rows"),
     ("gemm_f32_kernel<128>", "gemm128"), ("gemm_f32_kernel<64>", "gemm64"), ("layernorm", "layernorm"),
     ("dense_chain_kernel<8, 8", "dense_chain_elementwise"), ("dense_chain_kernel<9, 8", "dense_chain_pairwise"),
