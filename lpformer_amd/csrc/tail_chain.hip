@@ -71,27 +71,31 @@ __device__ __forceinline__ void tc_store(const T (&r)[P], T *slab, int tid) {
     for (int e = 0; e < P; ++e) slab[e * TC_THREADS + tid] = r[e];
 }
 
-// acc[c] += W[16 (c0 + c) + i][k-group] * bv for this wave's TPW tiles; lw = slab + c0 * 64 + lane
+// acc[c] += W[16 (c0 + c) + i][k-group] * bv for this wave's TPW tiles; lw = slab + c0 * 64 + lane.  last = false (the
+// same for the whole wavefront): the wave's last tile is padding -- all-zero weight rows -- and is left out.
 template <int TPW>
-__device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const f32x4 *lw, const f32x4 bv) {
+__device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const f32x4 *lw, const f32x4 bv, bool last = true) {
     f32x4 a[TPW];
 #pragma unroll
     for (int c = 0; c < TPW; ++c) a[c] = lw[c * 64];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)  // consecutive MFMAs go to different accumulators
+    for (int u = 0; u < 4; ++u) {  // consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int c = 0; c < TPW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][u], bv[u], acc[c], 0, 0, 0);
+        for (int c = 0; c < TPW - 1; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][u], bv[u], acc[c], 0, 0, 0);
+        if (last) acc[TPW - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[TPW - 1][u], bv[u], acc[TPW - 1], 0, 0, 0);
+    }
 }
 // bf16 variant: the four fp32 MFMAs of a k-group become ONE v_mfma_f32_16x16x16_bf16 -- a lane's four A values and
 // four B values (k = 4 q .. 4 q + 3 of the group) are exactly that instruction's operands; the activations are rounded
 // to bf16 here, the accumulation stays fp32.
 template <int TPW>
-__device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint2 *lw, const f32x4 bv) {
+__device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint2 *lw, const f32x4 bv, bool last = true) {
     bf16x4_bits b;
 #pragma unroll
     for (int u = 0; u < 4; ++u) b[u] = (short)lpf_f32_to_bf16(bv[u]);
 #pragma unroll
     for (int c = 0; c < TPW; ++c) {
+        if (c == TPW - 1 && !last) break;
         const uint2 w = lw[c * 64];
         const bf16x4_bits a = {(short)(w.x & 0xffffu), (short)(w.x >> 16), (short)(w.y & 0xffffu), (short)(w.y >> 16)};
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[c], 0, 0, 0);
@@ -326,7 +330,8 @@ __global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_ch
             __syncthreads();  // (kg == 0: also publishes stage A's hidden tiles)
             if (kg + 1 < NTPA + 1) tc_load<S::PB, NTPB>(wrB, A.wB, kg + 1, tid);
             const f32x4 bv = kg < NTPA ? my_hid[(kg < NTPA ? kg : 0) * 64] : tailv;
-            tc_mfma<TPWB>(accB, lw + (half * TPWB) * 64 + lane, bv);
+            // (NTB odd: tile NTPB - 1, the second wave's last one, is padding -- its accumulators stay 0)
+            tc_mfma<TPWB>(accB, lw + (half * TPWB) * 64 + lane, bv, !((NTB & 1) && half == 1));
             buf ^= 1;
         }
     }
@@ -360,11 +365,11 @@ __global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_ch
         buf ^= 1;
     }
 #pragma unroll
-    for (int kg = 0; kg < NTPB; ++kg) {  // r_p, straight from LDS
+    for (int kg = 0; kg < NTB; ++kg) {  // r_p, straight from LDS (its padding tile, all zeros, is no k-group worth running)
         WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
         tc_store<S::PC>(wrC, lw, tid);
         __syncthreads();  // (kg == 0: also publishes stage B's hidden tiles)
-        if (kg + 1 < NTPB) tc_load<S::PC, NTPC>(wrC, A.wC, NGE + kg + 1, tid);
+        if (kg + 1 < NTB) tc_load<S::PC, NTPC>(wrC, A.wC, NGE + kg + 1, tid);
         tc_mfma<TPWC>(accC, lw + (half * TPWC) * 64 + lane, my_hid[kg * 64]);
         buf ^= 1;
     }
