@@ -346,6 +346,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     encoder_ms = LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / enc_reps, dev)
+    # ... and with what every NEW encoder output costs on top: the two per-node projections Z | Y of the attention
+    # (one [N, D] x [D, 2D] product, cached per encoder output; the gather_once layout computes them inside propagate())
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(enc_reps):
+        h2 = model.propagate()
+        model._node_keys(h2, model._fold())
+    torch.cuda.synchronize()
+    barrier()
+    node_keys_ms = max(0.0, LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / enc_reps, dev) - encoder_ms)
     # the same with the gathered per-layer table stored in bf16 (lpf_gemm_f32_out_bf16 + lpf_spmm_csr_bf16)
     encoder_bf16 = None
     if not args.no_bf16:
@@ -422,7 +433,7 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     pairs_per_s = world * bs * args.steps / elapsed
-    value_incl_encoder = world * bs / ((ms_per_step + encoder_ms) * 1e-3)
+    value_incl_encoder = world * bs / ((ms_per_step + encoder_ms + node_keys_ms) * 1e-3)
 
     kt = KernelTimer.summary() if not args.no_kernel_timing else {}
     # one instrumented encoder pass for the aggregation kernel's roofline -- on EVERY rank: a row-sharded encoder
@@ -576,7 +587,8 @@ def main():
                                         "replicated": "(every rank runs it, no exchange)"}[enc_plan["chosen"]])
                        if world > 1 else "single GPU",
                        "encoder_plan": enc_plan},
-            "encoder_ms": round(encoder_ms, 4), "value_incl_encoder": round(value_incl_encoder, 1),
+            "encoder_ms": round(encoder_ms, 4), "node_keys_ms": round(node_keys_ms, 4),
+            "value_incl_encoder": round(value_incl_encoder, 1),
             "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),
             "ms_per_step_repeats": {"n": len(rep_ms), "min": round(min(rep_ms), 4),
                                     "median": round(float(np.median(rep_ms)), 4), "max": round(max(rep_ms), 4)},

@@ -178,6 +178,8 @@ __global__ __launch_bounds__(GF_THREADS, 4) void gcn_fused_kernel(const GcnFused
                     for (int c = 0; c < 4; ++c)
                         if (c0_ + c < NT)
                             y[c0_ + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][u], acc[g][u], y[c0_ + c], 0, 0, 0);
+                // (keeps the operand reads of later blocks behind these MFMAs: hoisted together they spill)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #endif

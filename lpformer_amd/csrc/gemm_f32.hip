@@ -148,6 +148,151 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int N, int K, 
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ tall and skinny
+// M in the hundreds of thousands, K <= 128, N <= 256 (every GEMM of the encoder, the per-node projections of the
+// attention, most of the training step): the tiled kernel above runs at 0.39 of the matrix pipe there -- 128 x 128 x 32
+// tiles, two barriers per K block, four K blocks in all.  Here W^T stays in LDS for the life of a (persistent)
+// workgroup, in A-operand order of v_mfma_f32_16x16x4_f32 with the ROWS OF A ON THE MFMA COLUMNS (the layout of
+// gcn_fused.hip): a wavefront owns a tile of 16 rows, lane (j = lane % 16, q = lane / 16) loads row j's features
+// 16 g + 4 q .. + 3 -- a wavefront reads its 16 rows as one contiguous piece -- and those registers are the B operands
+// (k = 16 g + 4 q + u for the u-th MFMA of k-group g); the product leaves the lane with C[j][16 c + 4 q .. + 3]: bias,
+// addend, ReLU and the store are float4 operations.  No staging of A, no barrier after the fill; wavefronts in their
+// load phase cover the ones that multiply.  A row's result does not depend on M or on the tile it falls into.
+namespace {
+
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+
+struct RowsArgs {
+    int64_t M;
+    int N, K;
+    const float *A; int64_t lda;
+    const float *W; int64_t ldw;
+    const float *bias;
+    const float *addend; int64_t ldadd;
+    float *C; int64_t ldc;
+    uint32_t flags;
+};
+
+template <int NTI, int NTO, int NTH>
+__global__ __launch_bounds__(NTH, 4) void gemm_rows_kernel(const RowsArgs P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4r gr_lds[];   // [NTI][NTO][64]
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    for (int e = threadIdx.x; e < NTI * NTO * 64; e += NTH) {
+        const int l = e & 63, c = (e >> 6) % NTO, g = (e >> 6) / NTO;
+        const int n = 16 * c + (l & 15), k = 16 * g + 4 * (l >> 4);
+        f32x4r v = {0.f, 0.f, 0.f, 0.f};
+        if (n < P.N && k < P.K) v = *reinterpret_cast<const f32x4r *>(P.W + (int64_t)n * P.ldw + k);
+        gr_lds[e] = v;
+    }
+    __syncthreads();
+    const int64_t n_tiles = (P.M + 15) >> 4;
+    const int64_t n_waves = (int64_t)gridDim.x * (NTH / 64);
+    const bool relu = P.flags & LPF_FLAG_RELU;
+    for (int64_t tile = (int64_t)blockIdx.x * (NTH / 64) + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
+        const int64_t row = tile * 16 + j;
+        const bool live = row < P.M;
+        const float *ar = P.A + (live ? row : P.M - 1) * P.lda + 4 * q;
+        f32x4r b[NTI];
+#pragma unroll
+        for (int g = 0; g < NTI; ++g)
+#ifdef GR_NOLOAD
+            b[g] = (f32x4r){0.5f, 0.25f, (float)j, (float)g};
+#else
+            b[g] = (16 * g + 4 * q < P.K) ? *reinterpret_cast<const f32x4r *>(ar + 16 * g) : (f32x4r){0.f, 0.f, 0.f, 0.f};
+#endif
+        f32x4r y[NTO];
+#pragma unroll
+        for (int c = 0; c < NTO; ++c) y[c] = (f32x4r){0.f, 0.f, 0.f, 0.f};
+#ifdef GR_NOMFMA
+#pragma unroll
+        for (int c = 0; c < NTO; ++c) y[c] = b[c % NTI];
+#else
+#pragma unroll
+        for (int g = 0; g < NTI; ++g) {
+            const f32x4r *lg = gr_lds + g * NTO * 64 + lane;
+#pragma unroll
+            for (int c0 = 0; c0 < NTO; c0 += 4) {      // four tiles' operands at a time
+                f32x4r a[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = (c0 + c < NTO) ? lg[(c0 + c) * 64] : (f32x4r){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c0 + c < NTO)
+                            y[c0 + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][u], b[g][u], y[c0 + c], 0, 0, 0);
+                // (keeps the operand reads of later blocks behind these MFMAs: hoisted together they spill)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
+#ifdef GR_NOSTORE
+        if (live && y[0][0] == 123.456f) {
+#else
+        if (live) {
+#endif
+#pragma unroll
+            for (int c = 0; c < NTO; ++c) {
+                const int n0 = 16 * c + 4 * q;
+                if (n0 < P.N) {        // (N is a multiple of 4 on this path)
+                    f32x4r v = y[c];
+                    if (P.bias) v += *reinterpret_cast<const f32x4r *>(P.bias + n0);
+                    if (P.addend) v += *reinterpret_cast<const f32x4r *>(P.addend + row * P.ldadd + n0);
+                    if (relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    *reinterpret_cast<f32x4r *>(P.C + row * P.ldc + n0) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NTI, int NTO>
+int gemm_rows_go(const RowsArgs &a, hipStream_t s, int n_cu) {
+    constexpr size_t lds = (size_t)NTI * NTO * 64 * sizeof(f32x4r);
+    constexpr int NTH = lds > 64 * 1024 ? 1024 : 512;       // two workgroups per CU, or one around a big table
+    auto kern = gemm_rows_kernel<NTI, NTO, NTH>;
+    static bool lds_set = false;
+    if (lds > 64 * 1024 && !lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return LPF_ERR_LAUNCH;
+        lds_set = true;
+    }
+    const int64_t n_tiles = (a.M + 15) >> 4;
+    int64_t groups = (n_tiles + NTH / 64 - 1) / (NTH / 64);
+    const int64_t cap = (int64_t)n_cu * (NTH == 1024 ? 1 : 2);
+    if (groups > cap) groups = cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(NTH), lds, s, a);
+    return LPF_OK;
+}
+
+// returns LPF_ERR_UNSUPPORTED when the shape is not one of this path's
+int gemm_rows_launch(const RowsArgs &a, hipStream_t s) {
+    if (a.K > 128 || a.N > 256 || (a.K & 3) || (a.N & 3) || a.M < 4096) return LPF_ERR_UNSUPPORTED;
+    if ((a.ldc & 3) || !lpf_aligned16(a.C) || (a.bias && !lpf_aligned16(a.bias)) ||
+        (a.addend && ((a.ldadd & 3) || !lpf_aligned16(a.addend))))
+        return LPF_ERR_UNSUPPORTED;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
+        n_cu = prop.multiProcessorCount;
+    }
+    const int nti = a.K <= 32 ? 2 : (a.K <= 64 ? 4 : 8), nto = a.N <= 32 ? 2 : (a.N <= 64 ? 4 : (a.N <= 128 ? 8 : 16));
+#define LPF_ROWS(I, O) if (nti == I && nto == O) return gemm_rows_go<I, O>(a, s, n_cu)
+    LPF_ROWS(2, 2); LPF_ROWS(2, 4); LPF_ROWS(2, 8); LPF_ROWS(2, 16);
+    LPF_ROWS(4, 2); LPF_ROWS(4, 4); LPF_ROWS(4, 8); LPF_ROWS(4, 16);
+    LPF_ROWS(8, 2); LPF_ROWS(8, 4); LPF_ROWS(8, 8); LPF_ROWS(8, 16);
+#undef LPF_ROWS
+    return LPF_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
 namespace {
 template <bool OUT_BF16>
 int gemm_launch(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *W, int64_t ldw,
@@ -160,6 +305,15 @@ int gemm_launch(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, co
     LPF_REQUIRE(!addend || ldadd >= N);
     LPF_REQUIRE((M + BM - 1) / BM < (1ll << 31));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if constexpr (!OUT_BF16) {   // tall and skinny: the row-streaming kernel
+        const RowsArgs ra{M, N, K, A, lda, W, ldw, bias, addend, ldadd, C, ldc, flags};
+        const int rc = gemm_rows_launch(ra, s);
+        if (rc != LPF_ERR_UNSUPPORTED) {
+            if (rc != LPF_OK) return rc;
+            LPF_CHECK_LAUNCH();
+            return LPF_OK;
+        }
+    }
     // Column tile: the one that wastes fewer padded columns; and for small problems the narrow tile, so that the grid
     // has at least two workgroups per CU.
     const int pad128 = ((N + 127) / 128) * 128 - N, pad64 = ((N + 63) / 64) * 64 - N;

@@ -98,6 +98,8 @@ def fold_attention(state: dict, dim: int, n_types: int, prefix="att_layers.0.att
     return {
         "w_rx": w_rx.astype(np.float32), "b_r": b_r.astype(np.float32),
         "w_l": w_l.astype(np.float32), "b_l": b_l.astype(np.float32), "b_l2": (2.0 * b_l).astype(np.float32),
+        # both node-level projections as ONE [2D, D] product (Z | Y side by side: the node table is read once)
+        "w_zy": np.concatenate([w_rx, w_l]).astype(np.float32), "b_zy": np.concatenate([b_r, b_l]).astype(np.float32),
         "att": att.astype(np.float32), "wfold": wfold.astype(np.float32), "bfold": bfold.astype(np.float32),
         "wfold_packed": pack_wfold(wfold.astype(np.float32)),
         "wfold_packed_bf16": pack_wfold_bf16(wfold.astype(np.float32)).view(np.int16), "wcat": np.ascontiguousarray(wcat.astype(np.float32)),

@@ -690,8 +690,7 @@ class LinkTransformer(nn.Module):
                 d = self.dim
                 pack = torch.empty(hi - lo, 3 * d, dtype=torch.float32, device=self.device)
                 pack[:, :d] = x_rows
-                gemm(x_rows, w["w_rx"], w["b_r"], out=pack[:, d:2 * d], tag="gemm_node_keys")
-                gemm(x_rows, w["w_l"], w["b_l"], out=pack[:, 2 * d:], tag="gemm_node_keys")
+                gemm(x_rows, w["w_zy"], w["b_zy"], out=pack[:, d:], tag="gemm_node_keys")     # [Z | Y] in one product
                 full = lpf_dist.allgather_rows(pack, self.num_nodes)      # the all-gather of node embeddings
                 x = full[:, :d]
                 torch.cuda.current_stream(self.device).synchronize()      # other streams read Z, Y (as _node_keys)
@@ -843,10 +842,10 @@ class LinkTransformer(nn.Module):
         hit = self._z_cache
         if hit is None or hit[0]() is not x_node or hit[1] != x_node._version:
             xr = _as_f32_rows(x_node)
-            z = gemm(xr, w["w_rx"], w["b_r"], tag="gemm_node_keys")
-            y = gemm(xr, w["w_l"], w["b_l"], tag="gemm_node_keys")
+            d = self.dim
+            zy = gemm(xr, w["w_zy"], w["b_zy"], tag="gemm_node_keys")    # [N, 2D]: Z | Y, the node table read once
             torch.cuda.current_stream(self.device).synchronize()  # once per encoder output: other streams read Z, Y
-            hit = self._z_cache = (weakref.ref(x_node), x_node._version, z, y)
+            hit = self._z_cache = (weakref.ref(x_node), x_node._version, zy[:, :d], zy[:, d:])
         return hit[2], hit[3]
 
     def _z_bf16(self, z: torch.Tensor) -> torch.Tensor:

@@ -31,6 +31,38 @@ def test_gemm_f32(m, n, k, relu):
     assert (out.double() - ref).abs().max().item() <= 2e-5 * max(1.0, k ** 0.5)
 
 
+@pytest.mark.parametrize("m,n,k", [(5000, 128, 128), (4099, 256, 64), (70001, 36, 32), (4096, 132, 60), (9001, 64, 128),
+                                   (4097, 8, 4), (6000, 256, 128)])
+def test_gemm_rows_kernel(m, n, k):
+    """The tall-and-skinny path of lpf_gemm_f32 (gemm_rows_kernel: M >= 4096, K <= 128, N <= 256, both multiples of 4):
+    every epilogue combination against fp64 torch, strided inputs and output, a ragged last tile; a row's result does
+    not depend on the rows around it (row blocks are bitwise the rows of the whole product)."""
+    g = torch.Generator().manual_seed(m + 3 * n + k)
+    a_buf = torch.randn(m, k + 8, generator=g).to(DEV)
+    a = a_buf[:, 4:4 + k]                                  # row stride k + 8, 16-byte aligned start
+    w = torch.randn(n, k, generator=g).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    add = torch.randn(m, n, generator=g).to(DEV)
+    ref0 = a.double() @ w.double().T
+    tol = 2e-5 * max(1.0, k ** 0.5)
+    for use_bias, use_add, relu in ((False, False, False), (True, True, True), (True, False, False), (False, True, True)):
+        out_buf = torch.full((m, n + 4), 7.0, device=DEV)
+        out = gemm(a, w, bias if use_bias else None, addend=add if use_add else None, relu=relu, out=out_buf[:, :n])
+        ref = ref0 + (bias.double() if use_bias else 0) + (add.double() if use_add else 0)
+        if relu:
+            ref = ref.clamp_min(0)
+        assert (out.double() - ref).abs().max().item() <= tol
+        assert (out_buf[:, n:] == 7.0).all()               # nothing written past the N columns
+    whole = gemm(a, w, bias)
+    lo = 4100 if m > 9000 else 0
+    if m - lo >= 4096:
+        blk = gemm(a[lo:], w, bias)
+        assert torch.equal(blk, whole[lo:])
+    # the same rows through the tiled kernel (M < 4096 takes it) agree to rounding
+    small = gemm(a[:1000], w, bias)
+    assert (small - whole[:1000]).abs().max().item() <= tol
+
+
 def test_gemm_asymmetric_layout():
     """A = I against an asymmetric W catches a transposed accumulator map."""
     n = 64
