@@ -264,7 +264,9 @@ def main():
         model._node_keys(hh, model._fold())
         kt0 = KernelTimer.summary()
         KernelTimer.enabled = False
-        last_agg = LD.max_over_ranks(kt0["spmm_csr"][2] if "spmm_csr" in kt0 else enc1 / cfg["gnn_layers"], dev)
+        # (a fused layer -- one launch, csrc/gcn_fused.hip -- is row-sharded whole)
+        last_key = "gcn_layer_fused" if "gcn_layer_fused" in kt0 else "spmm_csr"
+        last_agg = LD.max_over_ranks(kt0[last_key][2] if last_key in kt0 else enc1 / cfg["gnn_layers"], dev)
         keys_ms = LD.max_over_ranks(kt0["gemm_node_keys"][1] if "gemm_node_keys" in kt0 else 0.0, dev)
         del hh
         ag = LD.measure_allgather_gbps(n, d, dev)
