@@ -19,7 +19,7 @@
 //
 // The 16 rows of a tile advance through their edge lists in lockstep, so tiles are cut from a DEGREE-SORTED row order
 // (lpformer_amd/graph.py fused_row_order; any permutation is correct, this one keeps the 16 rows equally long).  Hub
-// rows (> 128 entries) are cut into slices of 256 entries that spmm_row_parts_kernel (spmm_csr.hip) sums into a
+// rows (> 64 entries) are cut into slices of 256 entries that spmm_row_parts_kernel (spmm_csr.hip) sums into a
 // compact table, one workgroup per slice; here a hub row is a row whose "neighbours" are its slices, weight 1.
 #include "lpf_common.h"
 
@@ -45,13 +45,23 @@ struct GcnFusedArgs {
     const float *t_parts;        // [n_slices][D]: the slices' sums
 };
 
-constexpr int GF_THREADS = 512;
+constexpr int GF_THREADS = 512;   // threads of a workgroup
+constexpr int GF_NB = 4;          // neighbours of EACH row of a pair requested per step (x D/32 float4 per lane)
+// workgroups per CU (they share nothing but the CU): at D = 128 ONE, i.e. two wavefronts per SIMD with 256 registers
+// each -- 32 float4 of neighbour rows in flight per lane beside the accumulators (measured per layer on the
+// collab-like graph: 2 workgroups x 2 neighbours 230 us, 1 x 4: 217, 1 x 5: 216, 256 threads 2 x 4: 227,
+// 768 threads 1 x 3: 222, 1,024 threads 1 x 2: 231); two below, where the rows are short
+template <int NT> constexpr int gf_per_cu() { return NT == 8 ? 1 : 2; }
 constexpr int GF_STAGE = 512;    // float4 per packed stage (pack_dense pads a stage to 512)
 
 __device__ __forceinline__ float gf_row_sum(float v) {   // over the four lanes (q) of a row
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
+}
+
+__device__ __forceinline__ float gf_partner(float v) {   // the value lane ^ 1 holds (DPP quad_perm [1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
 }
 
 template <int NT>
@@ -79,7 +89,7 @@ __device__ __forceinline__ void gf_layernorm(f32x4 (&y)[NT], const float *g, con
 }
 
 template <int NT>
-__global__ __launch_bounds__(GF_THREADS, 4) void gcn_fused_kernel(const GcnFusedArgs A) {
+__global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) void gcn_fused_kernel(const GcnFusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) f32x4 gf_lds[];
     f32x4 *const lw = gf_lds;                                       // [NT][GF_STAGE]
     int *const lticket = reinterpret_cast<int *>(gf_lds + NT * GF_STAGE);
@@ -98,63 +108,117 @@ __global__ __launch_bounds__(GF_THREADS, 4) void gcn_fused_kernel(const GcnFused
     auto tile_of = [&](int k) __attribute__((always_inline)) { return (int64_t)k * gridDim.x + blockIdx.x; };
     int tk_next = draw();
     for (int64_t tile = tile_of(threadIdx.x >> 6); tile < A.n_tiles;) {
-        const int ro = A.row_order[tile * 16 + j];
-        const bool live = ro != -1, hub = ro < -1;
-        // the row's entry list: [e, e + n_total) of (col, w), or the hub's slices
-        int64_t row = live ? ro : 0, e = 0;
-        int n_total = 0;
-        int32_t hub_c = 0;
-        if (hub) {
-            const int32_t *hb = A.hubs + 3 * (int64_t)(-2 - ro);
-            row = hb[0];
-            hub_c = hb[1];
-            n_total = hb[2];
-        } else if (live) {
-            e = A.rowptr[row];
-            n_total = (int)(A.rowptr[row + 1] - e);
-        }
-        const float *tab = (hub ? A.t_parts : A.H) + 4 * q;
-        const int64_t ldt = hub ? 16 * NT : A.ldh;
+        // Rows are gathered in PAIRS: lanes (j, q) and (j ^ 1, q) together fetch whole 128-byte lines -- of row
+        // X = the even lane's row, then of row Y = the odd lane's -- the even lane the first 64 bytes of a line
+        // (k-group 2L), the odd lane the second (k-group 2L + 1).  With every lane fetching only its own row a request
+        // covered 16 rows x 64 bytes, half a cache line each, and the fabric moved 6.0 TB/s where the 256-byte pieces of
+        // spmm_csr.hip get 7.1.  Each lane therefore accumulates half of the k-groups of BOTH rows and the two lanes
+        // swap the foreign halves (one DPP move per register) before the product.
+        struct RowSrc {
+            int64_t e;            // first entry of the row's list in col / w (ordinary rows)
+            int n_total;          // entries, or slices of a hub row
+            int32_t hub_c;        // first slice of a hub row
+            bool hub;
+            const float *tab;     // table the entries point into (+ this lane's offset inside a 128-byte line)
+            int64_t ldt;
+        };
+        const int odd = j & 1;
+        auto source = [&](int code, int64_t &row_out) __attribute__((always_inline)) {
+            RowSrc r;
+            const bool lv = code != -1;
+            r.hub = code < -1;
+            r.e = 0;
+            r.n_total = 0;
+            r.hub_c = 0;
+            int64_t row = lv ? code : 0;
+            if (r.hub) {
+                const int32_t *hb = A.hubs + 3 * (int64_t)(-2 - code);
+                row = hb[0];
+                r.hub_c = hb[1];
+                r.n_total = hb[2];
+            } else if (lv) {
+                r.e = A.rowptr[row];
+                r.n_total = (int)(A.rowptr[row + 1] - r.e);
+            }
+            r.tab = (r.hub ? A.t_parts : A.H) + 16 * odd + 4 * q;
+            r.ldt = r.hub ? 16 * NT : A.ldh;
+            row_out = row;
+            return r;
+        };
+        const int roX = A.row_order[tile * 16 + (j & ~1)], roY = A.row_order[tile * 16 + (j | 1)];
+        int64_t rowX, rowY;
+        const RowSrc X = source(roX, rowX), Y = source(roY, rowY);
+        const int ro = odd ? roY : roX;
+        const bool live = ro != -1;
+        const int64_t row = odd ? rowY : rowX;      // the row this lane multiplies, normalises and stores
 
-        f32x4 acc[NT];
+        constexpr int NL = NT / 2;                   // 128-byte lines of a row
+        f32x4 accX[NL], accY[NL];
 #pragma unroll
-        for (int g = 0; g < NT; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < NL; ++l) accX[l] = accY[l] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifndef GF_NOGATHER
-        // The gather, two neighbours per step; the (col, weight) pairs of the NEXT step are requested before this
-        // step's rows are added.  Entries past the end of a row are (row 0, weight 0).
-        auto edge = [&](int k, int32_t &c, float &wv) __attribute__((always_inline)) {
+        // GF_NB neighbours of each of the two rows per step; the (col, weight) pairs of the NEXT step are requested
+        // before this step's rows are added.  Entries past the end of a row are (row 0, weight 0).
+        auto edge = [&](const RowSrc &r, int k, int32_t &c, float &wv) __attribute__((always_inline)) {
             c = 0;
             wv = 0.f;
-            if (k < n_total) {
-                if (hub) {
-                    c = hub_c + k;
+            if (k < r.n_total) {
+                if (r.hub) {
+                    c = r.hub_c + k;
                     wv = 1.0f;
                 } else {
-                    c = A.col[e + k];
-                    wv = A.w[e + k];
+                    c = A.col[r.e + k];
+                    wv = A.w[r.e + k];
                 }
             }
         };
-        int32_t c0, c1;
-        float w0, w1;
-        edge(0, c0, w0);
-        edge(1, c1, w1);
-        for (int k = 0; __any(k < n_total); k += 2) {
-            const float *p0 = tab + (int64_t)c0 * ldt, *p1 = tab + (int64_t)c1 * ldt;
-            const float u0 = w0, u1 = w1;
-            f32x4 h0[NT], h1[NT];
+        constexpr int NBP = NT == 8 ? GF_NB : GF_NB / 2;   // neighbours per step and row (128 registers below D = 128)
+        int32_t cx[NBP], cy[NBP];
+        float wx[NBP], wy[NBP];
 #pragma unroll
-            for (int g = 0; g < NT; ++g) h0[g] = *reinterpret_cast<const f32x4 *>(p0 + 16 * g);
+        for (int i = 0; i < NBP; ++i) {
+            edge(X, i, cx[i], wx[i]);
+            edge(Y, i, cy[i], wy[i]);
+        }
+        const int n_max = X.n_total > Y.n_total ? X.n_total : Y.n_total;
+        for (int k = 0; __any(k < n_max); k += NBP) {
+            f32x4 hx[NBP][NL], hy[NBP][NL];
+            float ux[NBP], uy[NBP];
 #pragma unroll
-            for (int g = 0; g < NT; ++g) h1[g] = *reinterpret_cast<const f32x4 *>(p1 + 16 * g);
-            edge(k + 2, c0, w0);
-            edge(k + 3, c1, w1);
+            for (int i = 0; i < NBP; ++i) {
+                const float *px = X.tab + (int64_t)cx[i] * X.ldt, *py = Y.tab + (int64_t)cy[i] * Y.ldt;
+                ux[i] = wx[i];
+                uy[i] = wy[i];
 #pragma unroll
-            for (int g = 0; g < NT; ++g) acc[g] += h0[g] * u0;
+                for (int l = 0; l < NL; ++l) hx[i][l] = *reinterpret_cast<const f32x4 *>(px + 32 * l);
 #pragma unroll
-            for (int g = 0; g < NT; ++g) acc[g] += h1[g] * u1;
+                for (int l = 0; l < NL; ++l) hy[i][l] = *reinterpret_cast<const f32x4 *>(py + 32 * l);
+            }
+#pragma unroll
+            for (int i = 0; i < NBP; ++i) {
+                edge(X, k + NBP + i, cx[i], wx[i]);
+                edge(Y, k + NBP + i, cy[i], wy[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NBP; ++i) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) accX[l] += hx[i][l] * ux[i];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) accY[l] += hy[i][l] * uy[i];
+            }
         }
 #endif
+        // the swap: an even lane keeps accX (its own row, k-groups 2L) and needs its partner's accX (k-groups 2L + 1);
+        // an odd lane keeps accY (its own row, k-groups 2L + 1) and needs its partner's accY (k-groups 2L)
+        f32x4 acc[NT];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const f32x4 send = odd ? accX[l] : accY[l];
+            const float s0 = send[0], s1 = send[1], s2 = send[2], s3 = send[3];
+            const f32x4 recv = {gf_partner(s0), gf_partner(s1), gf_partner(s2), gf_partner(s3)};
+            acc[2 * l] = odd ? recv : accX[l];
+            acc[2 * l + 1] = odd ? accY[l] : recv;
+        }
 
         // out^T tile = W . acc: NT output tiles x NT k-groups x 4 MFMAs
         f32x4 y[NT];
@@ -240,9 +304,8 @@ extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
         n_cu = prop.multiProcessorCount;
     }
-    // persistent workgroups, two of 512 threads per CU (64 KB of W^T each at D = 128)
-    int64_t groups = (n_tiles + GF_THREADS / 64 - 1) / (GF_THREADS / 64);
-    if (groups > 2ll * n_cu) groups = 2ll * n_cu;
+    // persistent workgroups
+    const int64_t want = (n_tiles + GF_THREADS / 64 - 1) / (GF_THREADS / 64);
 #define LPF_GF(NT)                                                                                                  \
     do {                                                                                                            \
         auto kern = gcn_fused_kernel<NT>;                                                                           \
@@ -254,7 +317,8 @@ extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t
                 return LPF_ERR_LAUNCH;                                                                              \
             lds_set = true;                                                                                         \
         }                                                                                                           \
-        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(GF_THREADS), lds, s, a);                              \
+        const int64_t cap = (int64_t)gf_per_cu<NT>() * n_cu;                                                        \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(want < cap ? want : cap)), dim3(GF_THREADS), lds, s, a);           \
     } while (0)
     switch (D) {
         case 32: LPF_GF(2); break;

@@ -67,10 +67,13 @@ class DeviceCSR:
         return self.host
 
 
-def fused_row_order(rowptr: torch.Tensor, lo: int, hi: int, long_threshold: int = 128, part: int = 256):
+def fused_row_order(rowptr: torch.Tensor, lo: int, hi: int, long_threshold: int = 64, part: int = 256):
     """Work order of rows [lo, hi) for ``lpf_gcn_layer_fused_f32`` (csrc/gcn_fused.hip).  Returns
     ``(order, hubs, parts)``: ``order`` int32 codes, 16 per tile -- hub rows first (more than ``long_threshold`` stored
-    entries; code -2 - k for the k-th one), then the other rows by falling degree (stable), padded with -1;
+    entries -- measured per layer, slice kernel + layer kernel, ppa-like graph (mean degree 74): 64: 843 + 740 us,
+    128: 476 + 1,168, 256: 266 + 1,420, 512: 150 + 1,575; collab-like (mean 11): 32: 53 + 186, 64: 38 + 197,
+    128: 27 + 217: the slice kernel moves an entry faster than a 16-row tile does --; code -2 - k for the k-th one),
+    then the other rows by falling degree (stable), padded with -1;
     ``hubs`` int32 [n_hub, 3] = (global row id, first slice, number of slices) and ``parts`` int64 [n_slices, 2] =
     the slices' entry ranges (``part`` entries each, ``lpf_spmm_row_parts_f32``), both None without hub rows.
     The 16 rows of a tile walk their entry lists in lockstep: sorted, they are equally long."""

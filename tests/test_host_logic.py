@@ -313,7 +313,7 @@ def test_fused_row_order_covers_rows_once_and_slices_hubs():
     deg[10] = 128
     rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)]).astype(np.int64))
     for lo, hi in ((0, 1000), (2, 779), (4, 500)):
-        order, hubs, parts = G.fused_row_order(rowptr, lo, hi)
+        order, hubs, parts = G.fused_row_order(rowptr, lo, hi, long_threshold=128)
         o = order.numpy()
         assert o.size % 16 == 0
         hub_rows = [r for r in (3, 500, 777) if lo <= r < hi]

@@ -12,6 +12,8 @@ data = D.build_data(ei, x, n, edge_weight=w, eps=1e-2)
 from lpformer_amd import graph as G
 _orig = G.fused_row_order
 def _patched(rowptr, lo, hi, *a, **k):
+    if os.environ.get("LPF_HUB_T"):
+        k["long_threshold"] = int(os.environ["LPF_HUB_T"])
     order, hubs, parts = _orig(rowptr, lo, hi, *a, **k)
     mode = os.environ.get("LPF_ORDER", "degree")
     nh = 0 if hubs is None else hubs.shape[0]
