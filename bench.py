@@ -399,9 +399,13 @@ def main():
         bf16 = {"value": round(world * bs * args.steps / el16, 1), "unit": "pairs/s",
                 "ms_per_step": round(el16 * 1e3 / args.steps, 4),
                 "max_abs_logit_diff_vs_f32": float((got_l - ref_l).abs().max()),
-                "what": "bf16 storage of the node table Z + v_mfma_f32_32x32x16_bf16 for Wfold h, bf16 weights and "
-                        "v_mfma_f32_16x16x16_bf16 for the two GEMMs of the dense tail (fp32 accumulate everywhere); "
-                        "selection, q, softmax, record merge, LayerNorms in fp32; selected index sets identical to fp32"}
+                "what": "bf16 storage of the node table Z; attention: "
+                        + ("the activation-pattern kernel on the bf16 table, fp32 arithmetic (no D x D product left "
+                           "to run in bf16)" if model.attention_kernel() == "flip" else
+                           "v_mfma_f32_32x32x16_bf16 for Wfold h")
+                        + "; bf16 weights and v_mfma_f32_16x16x16_bf16 for the two GEMMs of the dense tail (fp32 "
+                          "accumulate everywhere); selection, q, softmax, record merge, LayerNorms in fp32; selected "
+                          "index sets identical to fp32"}
         KernelTimer.reset()
         KernelTimer.enabled = True
         for i in range(args.steps):

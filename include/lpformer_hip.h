@@ -360,6 +360,15 @@ int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t *type_ptr, 
                                 const float *pe_stat, const float *base, const float *wfold_t, const float *att,
                                 float *part, float *bnd, int64_t units_cap, void *stream);
 
+/* The same with the node table Z stored in bf16 (Z_bf16: uint16 rows, ldz in elements, a multiple of 8): the attention
+ * kernel of the bf16 throughput mode for D >= 128.  Z is widened to fp32 on arrival; q, tables, arithmetic and records
+ * are those of lpf_pair_attention_flip_f32. */
+int lpf_pair_attention_flip_zbf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
+                                  const void *Z_bf16, int64_t ldz, const float *q, int64_t ldq,
+                                  const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                  const float *wfold_t, const float *att, float *part, float *bnd, int64_t units_cap,
+                                  void *stream);
+
 /* The attention OUTPUT of every pair from the records of lpf_pair_attention_fused_f32 (for callers that want
  * features, calc_pairwise link_transformer.py:132-178, rather than scores):
  *   out[p, :D] = post_att_norm( merged record of pair p + att_bias )   (layers.py:78,220; PyG softmax, +1e-16 once)

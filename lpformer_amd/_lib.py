@@ -50,6 +50,7 @@ HIP_PROTOTYPES = {
     "lpf_pair_attention_fused_f32": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_attention_fused_bf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_attention_flip_f32": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "lpf_pair_attention_flip_zbf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_attention_merge_f32": [i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_tail_chain_merge_f32": [i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
                                  vp, vp, vp],

@@ -21,6 +21,8 @@
 // walks one UNIT of 16 consecutive same-type entries with an online softmax and leaves exactly the records
 // pair_fused.hip leaves (part[t][pair] for a segment inside one unit, boundary records otherwise), so the consumers
 // (tail_chain.hip merge mode, pair_merge.hip) do not care which kernel ran.  64 / G units per wavefront at a time.
+#include <type_traits>
+
 #include "pe_common.h"
 
 namespace {
@@ -32,7 +34,7 @@ struct FlipArgs {
     const int32_t *type_ptr;   // [3][bs+1]
     const int4 *entries;       // [3][ent_cap]
     int64_t ent_cap;
-    const float *Z; uint32_t ldz;
+    const float *Z; uint32_t ldz;   // (ZB: bf16 rows, ldz in bf16 elements)
     const float *q; uint32_t ldq;
     const float *pe_tab;       // [3][D][4]   (ta, tc, td, beta) per hidden unit, times +1 (unit in S0) or -1
     const float *pe_stat;      // [3][8]
@@ -89,8 +91,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int WTL>
 __device__ __forceinline__ constexpr int fl_first_resident() { return WTL == 1 ? 1 : 0; }
 
-template <int G, int NTH, int WTL>
+// ZB: the node table Z is stored in bf16 (the bf16 throughput mode: 8 bytes per lane and entry instead of 16; widened to
+// fp32 on arrival, everything else as in the fp32 kernel)
+template <int G, int NTH, int WTL, bool ZB = false>
 __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(const FlipArgs A) {
+    using ZT = typename std::conditional<ZB, uint2, float4>::type;   // a lane's piece of a Z row as it travels
     constexpr int D = 4 * G, RS = D + 4, EPW = 64 / G, T_LO = fl_first_resident<WTL>();
     extern __shared__ __attribute__((aligned(16))) float4 fl_lds[];
     float4 *const ltab = fl_lds;                 // [4][3][G]: row j of hidden unit 4 lj + j, type t -> ((j * 3 + t) * G + lj)
@@ -181,7 +186,18 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
             if (lj == 0) *reinterpret_cast<float4 *>(dst + D) = make_float4(m, l, __int_as_float(pair), cback ? 0.f : 1.f);
         };
         auto z_row = [&](int node) __attribute__((always_inline)) {
-            return *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)node * A.ldz + off);
+            if constexpr (ZB)
+                return *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(A.Z) +
+                                                        (uint64_t)(uint32_t)node * A.ldz + off);
+            else
+                return *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)node * A.ldz + off);
+        };
+        auto z_wide = [&](const ZT &z) __attribute__((always_inline)) {
+            if constexpr (ZB)
+                return make_float4(__uint_as_float(z.x << 16), __uint_as_float(z.x & 0xffff0000u),
+                                   __uint_as_float(z.y << 16), __uint_as_float(z.y & 0xffff0000u));
+            else
+                return z;
         };
         auto q_row = [&](int pair) __attribute__((always_inline)) {
             return *reinterpret_cast<const float4 *>(A.q + (uint64_t)(uint32_t)pair * A.ldq + off);
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
         }
         int lro = 0;                 // (opaque zero: the record reads below must stay behind the stores above)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(lro) :: "memory");
-        float4 za[4], zb[4];
+        ZT za[4], zb[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) za[u] = z_row(lr[lro + u].y);
         {
@@ -225,7 +241,8 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lro) :: "memory");
 
         // one entry: i = its position in the unit, zc = its Z row (this lane's four features)
-        auto entry = [&](const int i, const float4 zc) __attribute__((always_inline)) {
+        auto entry = [&](const int i, const ZT zraw) __attribute__((always_inline)) {
+            const float4 zc = z_wide(zraw);
             const int4 rc = lr[lro + i];
             const f32x2 r12 = ls[lro + i];
             const int pair_n = (int)((uint32_t)lr[lro + (i < 15 ? i + 1 : 15)].x & FL_PAIR_MASK);
@@ -332,12 +349,12 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
             __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler hoists every load of the batch to its top)
         };
         // one batch: request the Z rows of the next one, then walk this one's four entries
-        auto batch = [&](const int qt, const float4 (&zc4)[4], float4 (&zn4)[4]) __attribute__((always_inline)) {
+        auto batch = [&](const int qt, const ZT (&zc4)[4], ZT (&zn4)[4]) __attribute__((always_inline)) {
             const int nb = qt < 3 ? 4 * qt + 4 : 12;        // (the last one re-requests itself: harmless)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #ifdef FL_NOZ
-                zn4[u] = make_float4(0.1f, 0.2f, 0.3f, 0.4f);
+                zn4[u] = ZT{};
 #else
                 zn4[u] = z_row(lr[lro + nb + u].y);
 #endif
@@ -366,19 +383,21 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_flip_kernel(cons
 
 }  // namespace
 
-extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
-                                           int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
-                                           const float *pe_tab_signed, const float *pe_stat, const float *base,
-                                           const float *wfold_t, const float *att, float *part,
-                                           float *bnd, int64_t units_cap, void *stream) {
+namespace {
+template <bool ZB>
+int flip_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap, const void *Z,
+                int64_t ldz, const float *q, int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
+                const float *base, const float *wfold_t, const float *att, float *part, float *bnd, int64_t units_cap,
+                void *stream) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && type_ptr && entries && ent_cap > 0 && Z && q && pe_tab_signed && pe_stat && base && wfold_t &&
                 att && part && bnd && units_cap >= (ent_cap + 15) / 16);
-    LPF_REQUIRE(ldz >= D && ldq >= D && ldz < (1ll << 31) && ldq < (1ll << 31) && (ldz & 3) == 0 && (ldq & 3) == 0 && lpf_aligned16(entries) && lpf_aligned16(Z) &&
-                lpf_aligned16(q) && lpf_aligned16(pe_tab_signed) && lpf_aligned16(base) &&
-                lpf_aligned16(wfold_t) && lpf_aligned16(att) && lpf_aligned16(part) && lpf_aligned16(bnd));
-    const FlipArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, Z, (uint32_t)ldz, q, (uint32_t)ldq, pe_tab_signed, pe_stat, base,
-                     wfold_t, att, part, bnd, units_cap};
+    LPF_REQUIRE(ldz >= D && ldq >= D && ldz < (1ll << 31) && ldq < (1ll << 31) && (ldz & (ZB ? 7 : 3)) == 0 &&
+                (ldq & 3) == 0 && lpf_aligned16(entries) && lpf_aligned16(Z) && lpf_aligned16(q) &&
+                lpf_aligned16(pe_tab_signed) && lpf_aligned16(base) && lpf_aligned16(wfold_t) && lpf_aligned16(att) &&
+                lpf_aligned16(part) && lpf_aligned16(bnd));
+    const FlipArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), (uint32_t)ldz,
+                     q, (uint32_t)ldq, pe_tab_signed, pe_stat, base, wfold_t, att, part, bnd, units_cap};
     hipStream_t s = static_cast<hipStream_t>(stream);
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -392,7 +411,7 @@ extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t 
     // Wfold^T tables of two types (128 of its 152 KB of LDS), two of 512 threads below, three of 256 at D = 256
 #define LPF_FLIP(GG, NTH, WTL, PER_CU)                                                                          \
     do {                                                                                                        \
-        auto kern = pair_flip_kernel<GG, NTH, WTL>;                                                             \
+        auto kern = pair_flip_kernel<GG, NTH, WTL, ZB>;                                                         \
         constexpr size_t lds = (size_t)(6 * 4 * GG + WTL * 4 * GG * GG + (NTH / 64) * (64 / GG) * 24 + 1) * sizeof(float4); \
         static bool lds_set = false;                                                                            \
         if (lds > 64 * 1024 && !lds_set) {                                                                      \
@@ -420,4 +439,23 @@ extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t 
 #undef LPF_FLIP
     LPF_CHECK_LAUNCH();
     return LPF_OK;
+}
+}  // namespace
+
+extern "C" int lpf_pair_attention_flip_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                           int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
+                                           const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                           const float *wfold_t, const float *att, float *part,
+                                           float *bnd, int64_t units_cap, void *stream) {
+    return flip_launch<false>(D, bs, type_ptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t, att,
+                              part, bnd, units_cap, stream);
+}
+
+extern "C" int lpf_pair_attention_flip_zbf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                             int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q, int64_t ldq,
+                                             const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                             const float *wfold_t, const float *att, float *part, float *bnd,
+                                             int64_t units_cap, void *stream) {
+    return flip_launch<true>(D, bs, type_ptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t,
+                             att, part, bnd, units_cap, stream);
 }

@@ -1103,7 +1103,13 @@ class LinkTransformer(nn.Module):
         part = self._workspace("att_part", 3 * bs * rs, torch.float32, st)
         bnd = self._workspace("att_bnd", 3 * units_cap * 2 * rs, torch.float32, st)
         with KernelTimer.span("pair_attention_fused"):
-            if self.precision == "bf16":
+            if self.precision == "bf16" and self.attention_kernel() == "flip":
+                zb = self._z_bf16(z)      # bf16 node table, fp32 arithmetic (no D x D product to run in bf16)
+                check(lib.lpf_pair_attention_flip_zbf16(
+                    d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zb), zb.stride(0), ptr(q), q.stride(0),
+                    ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["wfold_t"]),
+                    ptr(w["att"]), ptr(part), ptr(bnd), units_cap, st), "lpf_pair_attention_flip_zbf16")
+            elif self.precision == "bf16":
                 zb = self._z_bf16(z)
                 check(lib.lpf_pair_attention_fused_bf16(
                     d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zb), zb.stride(0), ptr(q),
