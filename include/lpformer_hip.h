@@ -81,14 +81,15 @@ int lpf_spmm_csr_f32(int64_t n, int32_t D, const int64_t *rowptr, const int32_t 
  * (row id, first slice, number of slices), the hub row's entry list being replaced by rows first .. first + number - 1
  * of t_parts (float[n_slices][D], lpf_spmm_row_parts_f32), each with weight 1.  rowptr is indexed by the global row
  * id; out / residual hold rows row_base...  w_packed = the weight image of lpformer_amd/fold.py pack_dense(W, 1)
- * (W = GCNConv.lin.weight, [D, D]).  Rounding order differs from transform-then-aggregate (A (X W^T) vs (A X) W^T);
- * identical from launch to launch. */
+ * (W = GCNConv.lin.weight, [D, D]).  pre_out (optional, training): receives the rows before the LayerNorm (product +
+ * bias), what a LayerNorm backward needs.  Rounding order differs from transform-then-aggregate (A (X W^T) vs
+ * (A X) W^T); identical from launch to launch. */
 int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
                             const int64_t *rowptr, const int32_t *col, const float *w, const float *H, int64_t ldh,
                             const float *w_packed, float *out, int64_t ldo, const float *bias, const float *ln_g,
                             const float *ln_b, const float *residual, int64_t ldr, const float *ln2_g,
                             const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
-                            void *stream);
+                            float *pre_out, int64_t ldpre, void *stream);
 
 /* Sums of slices of (hub) rows: out[p][:D] = sum over the stored entries e in [parts[2p], parts[2p+1]) of w_e H[col_e]
  * (one workgroup per slice, partial sums added in a fixed order).  D a multiple of 8, <= 128. */

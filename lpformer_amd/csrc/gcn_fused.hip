@@ -43,6 +43,7 @@ struct GcnFusedArgs {
     uint32_t flags;
     const int32_t *hubs;         // [n_hub][3]: row id, first slice, number of slices
     const float *t_parts;        // [n_slices][D]: the slices' sums
+    float *pre; int64_t ldpre;   // optional: the pre-normalisation rows (product + bias), for a LayerNorm backward
 };
 
 constexpr int GF_THREADS = 512;   // threads of a workgroup
@@ -253,6 +254,12 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
 #pragma unroll
             for (int c = 0; c < NT; ++c) y[c] += *reinterpret_cast<const f32x4 *>(A.bias + 16 * c + 4 * q);
         }
+        const int64_t orow = row - A.row_base;
+        if (A.pre && live) {
+            float *pp = A.pre + orow * A.ldpre + 4 * q;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) *reinterpret_cast<f32x4 *>(pp + 16 * c) = y[c];
+        }
         if (A.ln_g) gf_layernorm<NT>(y, A.ln_g, A.ln_b, q);
         if (A.flags & LPF_FLAG_RELU) {
 #pragma unroll
@@ -260,7 +267,6 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[c][r] = fmaxf(y[c][r], 0.f);
         }
-        const int64_t orow = row - A.row_base;
         if (A.residual && live) {
             const float *rp = A.residual + orow * A.ldr + 4 * q;
 #pragma unroll
@@ -284,18 +290,20 @@ extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t
                                        int64_t ldh, const float *w_packed, float *out, int64_t ldo, const float *bias,
                                        const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
                                        const float *ln2_g, const float *ln2_b, uint32_t flags,
-                                       const int32_t *hubs, const float *t_parts, void *stream) {
+                                       const int32_t *hubs, const float *t_parts, float *pre_out, int64_t ldpre,
+                                       void *stream) {
     if (n_tiles == 0) return LPF_OK;
     LPF_REQUIRE(n_tiles > 0 && row_order && rowptr && col && w && H && w_packed && out);
     if (D != 32 && D != 64 && D != 128) return LPF_ERR_UNSUPPORTED;
     LPF_REQUIRE(ldh >= D && ldo >= D && (ldh & 3) == 0 && (ldo & 3) == 0 && lpf_aligned16(H) && lpf_aligned16(out) &&
                 lpf_aligned16(w_packed));
     LPF_REQUIRE((!ln_g) == (!ln_b) && (!ln2_g) == (!ln2_b) && (!hubs) == (!t_parts));
+    LPF_REQUIRE(!pre_out || (ldpre >= D && (ldpre & 3) == 0 && lpf_aligned16(pre_out)));
     LPF_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= D && lpf_aligned16(residual)));
     LPF_REQUIRE((!bias || lpf_aligned16(bias)) && (!ln_g || (lpf_aligned16(ln_g) && lpf_aligned16(ln_b))) &&
                 (!ln2_g || (lpf_aligned16(ln2_g) && lpf_aligned16(ln2_b))) && (!t_parts || lpf_aligned16(t_parts)));
     const GcnFusedArgs a{n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
-                         residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts};
+                         residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre};
     hipStream_t s = static_cast<hipStream_t>(stream);
     static int n_cu = 0;
     if (n_cu == 0) {

@@ -133,8 +133,18 @@ class _PackedSquare:
     def get(self, weight: torch.Tensor) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, weight.device)
         if key != self._key:
-            img = fold.pack_dense(weight.detach().to(torch.float32).cpu().numpy(), 1)
-            self._w, self._key = torch.from_numpy(img).to(weight.device), key
+            # fold.pack_dense(w, 1) with torch operators on the weight's own device: in training the weight changes
+            # every step, and a host round trip per layer and step would cost more than the launch it feeds
+            w = weight.detach().to(torch.float32)
+            n, k = w.shape
+            nt, ng = ((n + 15) // 16 + 1) & ~1, (k + 15) // 16
+            wp = torch.zeros(nt * 16, ng * 16, dtype=torch.float32, device=w.device)
+            wp[:n, :k] = w
+            r = wp.view(nt, 16, ng, 4, 4).permute(2, 0, 3, 1, 4).reshape(ng, nt * 256)     # stage, c, q, i, u
+            per_stage = -(-(nt * 64) // 512) * 512 * 4
+            img = torch.zeros(ng, per_stage, dtype=torch.float32, device=w.device)
+            img[:, :nt * 256] = r
+            self._w, self._key = img.reshape(-1), key
         return self._w
 
 
@@ -759,7 +769,7 @@ class LinkTransformer(nn.Module):
                 ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
                 ptr(res), 0 if res is None else res.stride(0),
                 ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
-                FLAG_RELU if enc.relu else 0, ptr(hubs), ptr(t_parts), st), "lpf_gcn_layer_fused_f32")
+                FLAG_RELU if enc.relu else 0, ptr(hubs), ptr(t_parts), None, 0, st), "lpf_gcn_layer_fused_f32")
         return out
 
     def _layer_transform(self, i: int, x_rows: torch.Tensor) -> torch.Tensor:

@@ -52,8 +52,8 @@ def _rows4(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def _gemm(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """a [M, K] @ w[N, K]^T -> [M, N] through lpf_gemm_f32."""
+def _gemm(a: torch.Tensor, w: torch.Tensor, bias=None) -> torch.Tensor:
+    """a [M, K] @ w[N, K]^T (+ bias) -> [M, N] through lpf_gemm_f32 (the bias rides in the kernel's epilogue)."""
     a, w = _rows4(a), _rows4(w)
     m, k = a.shape
     n = w.shape[0]
@@ -61,8 +61,10 @@ def _gemm(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     if m == 0 or n == 0:
         return out
     if k == 0:
-        return out.zero_()
-    check(_lib.hip().lpf_gemm_f32(m, n, k, ptr(a), a.stride(0), ptr(w), w.stride(0), None, None, 0, ptr(out),
+        return out.zero_() if bias is None else out.copy_(bias.detach().expand(m, n))
+    if bias is not None:
+        bias = bias.detach().float().contiguous()
+    check(_lib.hip().lpf_gemm_f32(m, n, k, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), None, 0, ptr(out),
                                   out.stride(0), 0, _stream(a)), "lpf_gemm_f32")
     return out
 
@@ -99,8 +101,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        y = _gemm(x, weight)
-        return y + bias if bias is not None else y.clone()
+        return _gemm(x, weight, bias)      # a fresh tensor: nothing else holds it
 
     @staticmethod
     def backward(ctx, dy):
@@ -255,6 +256,47 @@ class GcnLayerFn(torch.autograd.Function):
         return dt, None, dbias, dg, db
 
 
+class GcnFusedFn(torch.autograd.Function):
+    """A square GCN layer WITH its Linear, r = ReLU(LN(A_hat (x W^T) + b)), forward in ONE launch
+    (lpf_gcn_layer_fused_f32, csrc/gcn_fused.hip: aggregate, then transform; the pre-norm rows are written beside the
+    result for the backward).  Backward = the chain of LinearFn and GcnLayerFn: fused LayerNorm/ReLU backward (+ bias
+    gradient), aggregation with A_hat^T, dW = dT^T x, dx = dT W."""
+
+    @staticmethod
+    def forward(ctx, model, i, x, weight, a_hat, conv_bias, ln_w, ln_b):
+        from . import graph
+        x2 = _rows4(x)
+        n, d = a_hat.n, x2.shape[1]
+        lib, st = _lib.hip(), _stream(x2)
+        cache = a_hat.__dict__.setdefault("_fused_order", {})
+        if (0, n) not in cache:
+            cache[(0, n)] = graph.fused_row_order(a_hat.rowptr, 0, n)
+        order, hubs, parts = cache[(0, n)]
+        t_parts = None
+        if hubs is not None:
+            t_parts = torch.empty(parts.shape[0], d, dtype=torch.float32, device=x2.device)
+            check(lib.lpf_spmm_row_parts_f32(d, ptr(parts), parts.shape[0], ptr(a_hat.col), ptr(a_hat.val), ptr(x2),
+                                             x2.stride(0), ptr(t_parts), st), "lpf_spmm_row_parts_f32")
+        r = torch.empty(n, d, dtype=torch.float32, device=x2.device)
+        u = torch.empty(n, d, dtype=torch.float32, device=x2.device)
+        check(lib.lpf_gcn_layer_fused_f32(
+            d, order.numel() // 16, ptr(order), 0, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x2), x2.stride(0),
+            ptr(model._conv_packs[i].get(weight)), ptr(r), d, ptr(conv_bias), ptr(ln_w), ptr(ln_b), None, 0, None, None,
+            _lib.FLAG_RELU, ptr(hubs), ptr(t_parts), ptr(u), d, st), "lpf_gcn_layer_fused_f32")
+        ctx.save_for_backward(x2, weight, u, ln_w, ln_b)
+        ctx.a_hat = a_hat
+        return r
+
+    @staticmethod
+    def backward(ctx, dr):
+        x2, weight, u, ln_w, ln_b = ctx.saved_tensors
+        du, dg, db, dbias = _ln_relu_bwd(u, dr.contiguous(), ln_w, ln_b)
+        dt = _spmm_plain(_transpose_csr(ctx.a_hat), du)
+        dx = _gemm(dt, weight.t().contiguous()).contiguous() if ctx.needs_input_grad[2] else None
+        dw = _gemm_tn(dt, x2)
+        return None, None, dx, dw, None, dbias, dg, db
+
+
 def layer_norm(x, weight, bias):
     """LayerNorm over the last dimension; the C-ABI kernels when the width allows (D % 4 == 0, D <= 256)."""
     d = x.shape[-1]
@@ -312,6 +354,12 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     x = model._features()
     x = F.dropout(x, p=model.node_encoder.feat_drop, training=True)
     for i, conv in enumerate(enc.convs):
+        if enc.lns is not None and enc.relu and model._fusable(i, x.shape[1]):
+            # a square layer: Linear + aggregation + bias + LayerNorm + ReLU forward in one launch
+            xi = GcnFusedFn.apply(model, i, x, conv.lin.weight, a_hat, conv.bias, enc.lns[i].weight, enc.lns[i].bias)
+            xi = F.dropout(xi, p=enc.dropout, training=True)
+            x = x + xi if (enc.residual and x.shape[-1] == xi.shape[-1]) else xi
+            continue
         t = linear(x, conv.lin.weight, None)
         if enc.lns is not None and enc.relu and t.shape[1] % 4 == 0 and t.shape[1] <= 256:
             # aggregation + bias, LayerNorm + ReLU: two forward and two backward kernels; the dropout (a non-negative

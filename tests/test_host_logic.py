@@ -336,3 +336,14 @@ def test_fused_row_order_covers_rows_once_and_slices_hubs():
         assert sorted(live.tolist() + hub_rows) == list(range(lo, hi))
         d = deg[live]
         assert (d[:-1] >= d[1:]).all() and d.max() <= 128
+
+
+def test_packed_square_weight_matches_pack_dense():
+    """The device-side packing of a GCN layer's weight (link_transformer._PackedSquare, torch operators) is the image
+    fold.pack_dense(w, 1) builds on the host."""
+    import torch
+    from lpformer_amd import fold
+    from lpformer_amd.link_transformer import _PackedSquare
+    for d in (32, 64, 128):
+        w = torch.randn(d, d)
+        assert np.array_equal(_PackedSquare().get(w).numpy(), fold.pack_dense(w.numpy(), 1))
