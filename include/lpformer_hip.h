@@ -91,6 +91,21 @@ int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order
                             const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
                             float *pre_out, int64_t ldpre, void *stream);
 
+/* The same layer gathering from a bf16 table (the bf16-table encoder mode; D = 64 or 128).  H_bf16p: uint16 rows, ldh in
+ * elements (a multiple of 8), in the PERMUTED order  element 32 i + 8 q + 4 h + u = feature 16 (2 i + h) + 4 q + u
+ * (i < D/32, q < 4, h < 2, u < 4) -- a lane's 16-byte load then holds two whole 16-feature k-groups.  out receives the
+ * fp32 rows in normal order; out_bf16p (optional, ldob in elements) the same rows as permuted bf16, i.e. the next
+ * layer's table.  Hub rows must sit in tiles of their own (fused_row_order(..., pad_hubs=True)); their slices come
+ * from lpf_spmm_row_parts_bf16p, which reads the permuted table and writes fp32 sums in normal order. */
+int lpf_gcn_layer_fused_bf16(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
+                             const int64_t *rowptr, const int32_t *col, const float *w, const void *H_bf16p,
+                             int64_t ldh, const float *w_packed, float *out, int64_t ldo, const float *bias,
+                             const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                             const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *hubs,
+                             const float *t_parts, void *out_bf16p, int64_t ldob, void *stream);
+int lpf_spmm_row_parts_bf16p(int32_t D, const int64_t *parts, int64_t n_parts, const int32_t *col, const float *w,
+                             const void *H_bf16p, int64_t ldh, float *out, void *stream);
+
 /* Sums of slices of (hub) rows: out[p][:D] = sum over the stored entries e in [parts[2p], parts[2p+1]) of w_e H[col_e]
  * (one workgroup per slice, partial sums added in a fixed order).  D a multiple of 8, <= 128. */
 int lpf_spmm_row_parts_f32(int32_t D, const int64_t *parts, int64_t n_parts, const int32_t *col, const float *w,

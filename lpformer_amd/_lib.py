@@ -35,6 +35,9 @@ HIP_PROTOTYPES = {
     "lpf_gcn_layer_fused_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,
                                 vp, vp, i64, vp],
     "lpf_spmm_row_parts_f32": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
+    "lpf_spmm_row_parts_bf16p": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
+    "lpf_gcn_layer_fused_bf16": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,
+                                 vp, vp, i64, vp],
     "lpf_spmm_csr_bf16": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],
     "lpf_layernorm_f32": [i64, i32, vp, i64, vp, vp, vp, i64, u32, vp],
     "lpf_pair_gather_f32": [i64, i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp],

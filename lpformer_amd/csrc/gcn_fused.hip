@@ -21,6 +21,13 @@
 // (lpformer_amd/graph.py fused_row_order; any permutation is correct, this one keeps the 16 rows equally long).  Hub
 // rows (> 64 entries) are cut into slices of 256 entries that spmm_row_parts_kernel (spmm_csr.hip) sums into a
 // compact table, one workgroup per slice; here a hub row is a row whose "neighbours" are its slices, weight 1.
+//
+// HB (the bf16-table encoder mode): the gathered table holds bf16 rows in the PERMUTED order this kernel's lanes want
+// -- element 32 i + 8 q + 4 h + u = feature 16 (2 i + h) + 4 q + u, so a lane's 16-byte load yields two whole
+// k-groups -- which is also the order a lane can store its own results in with 16-byte writes: the epilogue writes the
+// fp32 rows (normal order: residuals, the final output) AND, on request, that bf16 image for the next layer to gather.
+#include <type_traits>
+
 #include "lpf_common.h"
 
 namespace {
@@ -44,6 +51,7 @@ struct GcnFusedArgs {
     const int32_t *hubs;         // [n_hub][3]: row id, first slice, number of slices
     const float *t_parts;        // [n_slices][D]: the slices' sums
     float *pre; int64_t ldpre;   // optional: the pre-normalisation rows (product + bias), for a LayerNorm backward
+    uint16_t *out_b; int64_t ldob;   // optional (HB): the result rows as permuted bf16 (the next layer's table)
 };
 
 constexpr int GF_THREADS = 512;   // threads of a workgroup
@@ -89,7 +97,7 @@ __device__ __forceinline__ void gf_layernorm(f32x4 (&y)[NT], const float *g, con
     }
 }
 
-template <int NT>
+template <int NT, bool HB>
 __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) void gcn_fused_kernel(const GcnFusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) f32x4 gf_lds[];
     f32x4 *const lw = gf_lds;                                       // [NT][GF_STAGE]
@@ -120,8 +128,8 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
             int n_total;          // entries, or slices of a hub row
             int32_t hub_c;        // first slice of a hub row
             bool hub;
-            const float *tab;     // table the entries point into (+ this lane's offset inside a 128-byte line)
-            int64_t ldt;
+            const char *tab;      // table the entries point into (+ this lane's 16 bytes inside a 128-byte line)
+            int64_t ldb;          // bytes per table row
         };
         const int odd = j & 1;
         auto source = [&](int code, int64_t &row_out) __attribute__((always_inline)) {
@@ -141,8 +149,9 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
                 r.e = A.rowptr[row];
                 r.n_total = (int)(A.rowptr[row + 1] - r.e);
             }
-            r.tab = (r.hub ? A.t_parts : A.H) + 16 * odd + 4 * q;
-            r.ldt = r.hub ? 16 * NT : A.ldh;
+            // (slice sums are fp32 rows in normal order whatever the table is)
+            r.tab = reinterpret_cast<const char *>(r.hub ? A.t_parts : A.H) + 64 * odd + 16 * q;
+            r.ldb = r.hub ? 64 * NT : A.ldh * (HB ? 2 : 4);
             row_out = row;
             return r;
         };
@@ -153,72 +162,109 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
         const bool live = ro != -1;
         const int64_t row = odd ? rowY : rowX;      // the row this lane multiplies, normalises and stores
 
-        constexpr int NL = NT / 2;                   // 128-byte lines of a row
-        f32x4 accX[NL], accY[NL];
+        // The gather of one tile from a table of fp32 rows (B16 = false: a lane's 16 bytes of a line are ONE k-group,
+        // g = 2 l + odd) or of permuted bf16 rows (B16 = true: TWO k-groups, g = 4 l + 2 odd + h); then the swap: a
+        // lane keeps what it gathered of its own row and takes the other half from its partner.
+        f32x4 acc[NT];
+        auto gather = [&](auto kind) __attribute__((always_inline)) {
+            constexpr bool B16 = decltype(kind)::value;
+            constexpr int KP = B16 ? 2 : 1;              // k-groups a lane gets from its 16 bytes of a line
+            constexpr int NL = NT / (2 * KP);            // 128-byte lines of a row
+            f32x4 accX[NL][KP], accY[NL][KP];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) accX[l] = accY[l] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int h = 0; h < KP; ++h) accX[l][h] = accY[l][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifndef GF_NOGATHER
-        // GF_NB neighbours of each of the two rows per step; the (col, weight) pairs of the NEXT step are requested
-        // before this step's rows are added.  Entries past the end of a row are (row 0, weight 0).
-        auto edge = [&](const RowSrc &r, int k, int32_t &c, float &wv) __attribute__((always_inline)) {
-            c = 0;
-            wv = 0.f;
-            if (k < r.n_total) {
-                if (r.hub) {
-                    c = r.hub_c + k;
-                    wv = 1.0f;
+            // NBP neighbours of each of the two rows per step; the (col, weight) pairs of the NEXT step are requested
+            // before this step's rows are added.  Entries past the end of a row are (row 0, weight 0).
+            auto edge = [&](const RowSrc &r, int k, int32_t &c, float &wv) __attribute__((always_inline)) {
+                c = 0;
+                wv = 0.f;
+                if (k < r.n_total) {
+                    if (r.hub) {
+                        c = r.hub_c + k;
+                        wv = 1.0f;
+                    } else {
+                        c = A.col[r.e + k];
+                        wv = A.w[r.e + k];
+                    }
+                }
+            };
+            auto widen = [&](const uint4 raw, f32x4 (&v)[KP]) __attribute__((always_inline)) {
+                if constexpr (B16) {
+                    v[0] = (f32x4){__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
+                                   __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u)};
+                    v[1] = (f32x4){__uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
+                                   __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
                 } else {
-                    c = A.col[r.e + k];
-                    wv = A.w[r.e + k];
+                    v[0] = (f32x4){__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
+                                   __uint_as_float(raw.w)};
+                }
+            };
+            constexpr int NBP = (NT == 8 && !B16) ? GF_NB : (NT == 8 ? GF_NB + 2 : GF_NB / 2);   // neighbours per step and row
+            int32_t cx[NBP], cy[NBP];
+            float wx[NBP], wy[NBP];
+#pragma unroll
+            for (int i = 0; i < NBP; ++i) {
+                edge(X, i, cx[i], wx[i]);
+                edge(Y, i, cy[i], wy[i]);
+            }
+            const int n_max = X.n_total > Y.n_total ? X.n_total : Y.n_total;
+            for (int k = 0; __any(k < n_max); k += NBP) {
+                uint4 hx[NBP][NL], hy[NBP][NL];
+                float ux[NBP], uy[NBP];
+#pragma unroll
+                for (int i = 0; i < NBP; ++i) {
+                    const char *px = X.tab + (int64_t)cx[i] * X.ldb, *py = Y.tab + (int64_t)cy[i] * Y.ldb;
+                    ux[i] = wx[i];
+                    uy[i] = wy[i];
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) hx[i][l] = *reinterpret_cast<const uint4 *>(px + 128 * l);
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) hy[i][l] = *reinterpret_cast<const uint4 *>(py + 128 * l);
+                }
+#pragma unroll
+                for (int i = 0; i < NBP; ++i) {
+                    edge(X, k + NBP + i, cx[i], wx[i]);
+                    edge(Y, k + NBP + i, cy[i], wy[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < NBP; ++i) {
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) {
+                        f32x4 vx[KP], vy[KP];
+                        widen(hx[i][l], vx);
+                        widen(hy[i][l], vy);
+#pragma unroll
+                        for (int h = 0; h < KP; ++h) {
+                            accX[l][h] += vx[h] * ux[i];
+                            accY[l][h] += vy[h] * uy[i];
+                        }
+                    }
                 }
             }
-        };
-        constexpr int NBP = NT == 8 ? GF_NB : GF_NB / 2;   // neighbours per step and row (128 registers below D = 128)
-        int32_t cx[NBP], cy[NBP];
-        float wx[NBP], wy[NBP];
-#pragma unroll
-        for (int i = 0; i < NBP; ++i) {
-            edge(X, i, cx[i], wx[i]);
-            edge(Y, i, cy[i], wy[i]);
-        }
-        const int n_max = X.n_total > Y.n_total ? X.n_total : Y.n_total;
-        for (int k = 0; __any(k < n_max); k += NBP) {
-            f32x4 hx[NBP][NL], hy[NBP][NL];
-            float ux[NBP], uy[NBP];
-#pragma unroll
-            for (int i = 0; i < NBP; ++i) {
-                const float *px = X.tab + (int64_t)cx[i] * X.ldt, *py = Y.tab + (int64_t)cy[i] * Y.ldt;
-                ux[i] = wx[i];
-                uy[i] = wy[i];
-#pragma unroll
-                for (int l = 0; l < NL; ++l) hx[i][l] = *reinterpret_cast<const f32x4 *>(px + 32 * l);
-#pragma unroll
-                for (int l = 0; l < NL; ++l) hy[i][l] = *reinterpret_cast<const f32x4 *>(py + 32 * l);
-            }
-#pragma unroll
-            for (int i = 0; i < NBP; ++i) {
-                edge(X, k + NBP + i, cx[i], wx[i]);
-                edge(Y, k + NBP + i, cy[i], wy[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < NBP; ++i) {
-#pragma unroll
-                for (int l = 0; l < NL; ++l) accX[l] += hx[i][l] * ux[i];
-#pragma unroll
-                for (int l = 0; l < NL; ++l) accY[l] += hy[i][l] * uy[i];
-            }
-        }
 #endif
-        // the swap: an even lane keeps accX (its own row, k-groups 2L) and needs its partner's accX (k-groups 2L + 1);
-        // an odd lane keeps accY (its own row, k-groups 2L + 1) and needs its partner's accY (k-groups 2L)
-        f32x4 acc[NT];
+            // an even lane keeps accX (its own row) and needs its partner's accX; an odd lane keeps accY and needs its
+            // partner's accY: both send what they hold of the OTHER row
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const f32x4 send = odd ? accX[l] : accY[l];
-            const float s0 = send[0], s1 = send[1], s2 = send[2], s3 = send[3];
-            const f32x4 recv = {gf_partner(s0), gf_partner(s1), gf_partner(s2), gf_partner(s3)};
-            acc[2 * l] = odd ? recv : accX[l];
-            acc[2 * l + 1] = odd ? accY[l] : recv;
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int h = 0; h < KP; ++h) {
+                    const f32x4 send = odd ? accX[l][h] : accY[l][h];
+                    const float s0 = send[0], s1 = send[1], s2 = send[2], s3 = send[3];
+                    const f32x4 recv = {gf_partner(s0), gf_partner(s1), gf_partner(s2), gf_partner(s3)};
+                    const int g_even = 2 * KP * l + h, g_odd = 2 * KP * l + KP + h;     // k-groups of the two halves
+                    acc[g_even] = odd ? recv : accX[l][h];
+                    acc[g_odd] = odd ? accY[l][h] : recv;
+                }
+        };
+        if constexpr (HB) {
+            // (hub rows come first in the order, in tiles of their own: graph.fused_row_order pads them to 16)
+            if (__any(X.hub || Y.hub)) gather(std::false_type{});
+            else gather(std::true_type{});
+        } else {
+            gather(std::false_type{});
         }
 
         // out^T tile = W . acc: NT output tiles x NT k-groups x 4 MFMAs
@@ -277,6 +323,21 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
             float *op = A.out + orow * A.ldo + 4 * q;
 #pragma unroll
             for (int c = 0; c < NT; ++c) *reinterpret_cast<f32x4 *>(op + 16 * c) = y[c];
+            if constexpr (HB) {
+                if (A.out_b) {      // elements 32 i + 8 q .. + 7 = features 16 (2 i) + 4 q + u, 16 (2 i + 1) + 4 q + u
+                    uint16_t *ob = A.out_b + orow * A.ldob + 8 * q;
+#pragma unroll
+                    for (int i = 0; i < NT / 2; ++i) {
+                        const f32x4 lo = y[2 * i], hi = y[2 * i + 1];
+                        uint4 pk;
+                        pk.x = (uint32_t)lpf_f32_to_bf16(lo[0]) | ((uint32_t)lpf_f32_to_bf16(lo[1]) << 16);
+                        pk.y = (uint32_t)lpf_f32_to_bf16(lo[2]) | ((uint32_t)lpf_f32_to_bf16(lo[3]) << 16);
+                        pk.z = (uint32_t)lpf_f32_to_bf16(hi[0]) | ((uint32_t)lpf_f32_to_bf16(hi[1]) << 16);
+                        pk.w = (uint32_t)lpf_f32_to_bf16(hi[2]) | ((uint32_t)lpf_f32_to_bf16(hi[3]) << 16);
+                        *reinterpret_cast<uint4 *>(ob + 32 * i) = pk;
+                    }
+                }
+            }
         }
         tile = tile_of(GF_THREADS / 64 + __builtin_amdgcn_readfirstlane(tk_next));
         if (tile < A.n_tiles) tk_next = draw();
@@ -285,25 +346,28 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
 
 }  // namespace
 
-extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
-                                       const int64_t *rowptr, const int32_t *col, const float *w, const float *H,
-                                       int64_t ldh, const float *w_packed, float *out, int64_t ldo, const float *bias,
-                                       const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
-                                       const float *ln2_g, const float *ln2_b, uint32_t flags,
-                                       const int32_t *hubs, const float *t_parts, float *pre_out, int64_t ldpre,
-                                       void *stream) {
+namespace {
+template <bool HB>
+int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base, const int64_t *rowptr,
+              const int32_t *col, const float *w, const void *H, int64_t ldh, const float *w_packed, float *out,
+              int64_t ldo, const float *bias, const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+              const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
+              float *pre_out, int64_t ldpre, void *out_b, int64_t ldob, void *stream) {
     if (n_tiles == 0) return LPF_OK;
     LPF_REQUIRE(n_tiles > 0 && row_order && rowptr && col && w && H && w_packed && out);
     if (D != 32 && D != 64 && D != 128) return LPF_ERR_UNSUPPORTED;
-    LPF_REQUIRE(ldh >= D && ldo >= D && (ldh & 3) == 0 && (ldo & 3) == 0 && lpf_aligned16(H) && lpf_aligned16(out) &&
-                lpf_aligned16(w_packed));
+    if (HB && D == 32) return LPF_ERR_UNSUPPORTED;      // (a bf16 row of 64 bytes is half a line)
+    LPF_REQUIRE(ldh >= D && ldo >= D && (ldh & (HB ? 7 : 3)) == 0 && (ldo & 3) == 0 && lpf_aligned16(H) &&
+                lpf_aligned16(out) && lpf_aligned16(w_packed));
     LPF_REQUIRE((!ln_g) == (!ln_b) && (!ln2_g) == (!ln2_b) && (!hubs) == (!t_parts));
     LPF_REQUIRE(!pre_out || (ldpre >= D && (ldpre & 3) == 0 && lpf_aligned16(pre_out)));
+    LPF_REQUIRE(!out_b || (HB && ldob >= D && (ldob & 7) == 0 && lpf_aligned16(out_b)));
     LPF_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= D && lpf_aligned16(residual)));
     LPF_REQUIRE((!bias || lpf_aligned16(bias)) && (!ln_g || (lpf_aligned16(ln_g) && lpf_aligned16(ln_b))) &&
                 (!ln2_g || (lpf_aligned16(ln2_g) && lpf_aligned16(ln2_b))) && (!t_parts || lpf_aligned16(t_parts)));
-    const GcnFusedArgs a{n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
-                         residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre};
+    const GcnFusedArgs a{n_tiles, row_order, row_base, rowptr, col, w, static_cast<const float *>(H), ldh, w_packed, out,
+                         ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre,
+                         static_cast<uint16_t *>(out_b), ldob};
     hipStream_t s = static_cast<hipStream_t>(stream);
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -316,7 +380,7 @@ extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t
     const int64_t want = (n_tiles + GF_THREADS / 64 - 1) / (GF_THREADS / 64);
 #define LPF_GF(NT)                                                                                                  \
     do {                                                                                                            \
-        auto kern = gcn_fused_kernel<NT>;                                                                           \
+        auto kern = gcn_fused_kernel<NT, HB>;                                                                       \
         constexpr size_t lds = (size_t)(NT * GF_STAGE + 1) * sizeof(f32x4);                                         \
         static bool lds_set = false;                                                                                \
         if (lds > 64 * 1024 && !lds_set) {                                                                          \
@@ -329,11 +393,35 @@ extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t
         hipLaunchKernelGGL(kern, dim3((unsigned)(want < cap ? want : cap)), dim3(GF_THREADS), lds, s, a);           \
     } while (0)
     switch (D) {
-        case 32: LPF_GF(2); break;
+        case 32:
+            if constexpr (!HB) LPF_GF(2);
+            break;
         case 64: LPF_GF(4); break;
         default: LPF_GF(8); break;
     }
 #undef LPF_GF
     LPF_CHECK_LAUNCH();
     return LPF_OK;
+}
+}  // namespace
+
+extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
+                                       const int64_t *rowptr, const int32_t *col, const float *w, const float *H,
+                                       int64_t ldh, const float *w_packed, float *out, int64_t ldo, const float *bias,
+                                       const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                                       const float *ln2_g, const float *ln2_b, uint32_t flags,
+                                       const int32_t *hubs, const float *t_parts, float *pre_out, int64_t ldpre,
+                                       void *stream) {
+    return gf_launch<false>(D, n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
+                            residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre, nullptr, 0, stream);
+}
+
+extern "C" int lpf_gcn_layer_fused_bf16(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
+                                        const int64_t *rowptr, const int32_t *col, const float *w, const void *H_bf16p,
+                                        int64_t ldh, const float *w_packed, float *out, int64_t ldo, const float *bias,
+                                        const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
+                                        const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *hubs,
+                                        const float *t_parts, void *out_bf16p, int64_t ldob, void *stream) {
+    return gf_launch<true>(D, n_tiles, row_order, row_base, rowptr, col, w, H_bf16p, ldh, w_packed, out, ldo, bias, ln_g,
+                           ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, nullptr, 0, out_bf16p, ldob, stream);
 }

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void spmm_long_rows_kernel(
 // Slices of hub rows for gcn_fused.hip: workgroup p sums the stored entries [parts[2p], parts[2p+1]) of one row -- its
 // 256 / G lane groups take chunks of G entries round-robin, the partial sums are added in group order -- and writes the
 // plain sum (no epilogue) to row p of a compact table.
-template <int G, int V>
+// HB: the table holds bf16 rows in gcn_fused.hip's permuted order (element 32 i + 8 q + 4 h + u = feature
+// 16 (2 i + h) + 4 q + u); the sums are elementwise, and are stored as fp32 in NORMAL order.
+template <int G, int V, bool HB = false>
 __global__ __launch_bounds__(256) void spmm_row_parts_kernel(const int64_t *__restrict__ parts, int D,
                                                              const int32_t *__restrict__ col,
                                                              const float *__restrict__ w, const float *__restrict__ H,
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void spmm_row_parts_kernel(const int64_t *__re
     float4 acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    spmm_accumulate<G, V, false>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
+    spmm_accumulate<G, V, HB>(acc, e0, e1, grp, NG, col, w, H, ldh, off, act, gbase, lig);
 #pragma unroll
     for (int v = 0; v < V; ++v) part[grp][lig][v] = acc[v];
     __syncthreads();
@@ -249,7 +251,9 @@ __global__ __launch_bounds__(256) void spmm_row_parts_kernel(const int64_t *__re
                 const float4 x = part[g][lig][v];
                 y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
             }
-            *reinterpret_cast<float4 *>(out + (int64_t)blockIdx.x * D + off + 4 * v) = y;
+            // (HB: lane lig holds elements 8 lig .. + 7 = i = lig / 4, q = lig % 4, h = v)
+            const int dst = HB ? 32 * (lig >> 2) + 16 * v + 4 * (lig & 3) : off + 4 * v;
+            *reinterpret_cast<float4 *>(out + (int64_t)blockIdx.x * D + dst) = y;
         }
     }
 }
@@ -368,6 +372,24 @@ extern "C" int lpf_spmm_row_parts_f32(int32_t D, const int64_t *parts, int64_t n
     else
         hipLaunchKernelGGL((spmm_row_parts_kernel<16, 2>), dim3((unsigned)n_parts), dim3(256), 0, s, parts, D, col, w, H,
                            ldh, out);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+extern "C" int lpf_spmm_row_parts_bf16p(int32_t D, const int64_t *parts, int64_t n_parts, const int32_t *col,
+                                        const float *w, const void *H_bf16p, int64_t ldh, float *out, void *stream) {
+    if (n_parts == 0) return LPF_OK;
+    LPF_REQUIRE(n_parts > 0 && n_parts < (1ll << 31) && parts && col && w && H_bf16p && out);
+    if (D != 64 && D != 128) return LPF_ERR_UNSUPPORTED;
+    LPF_REQUIRE(ldh >= D && (ldh & 7) == 0 && lpf_aligned16(H_bf16p) && lpf_aligned16(out));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float *H = static_cast<const float *>(H_bf16p);
+    if (D == 64)
+        hipLaunchKernelGGL((spmm_row_parts_kernel<8, 2, true>), dim3((unsigned)n_parts), dim3(256), 0, s, parts, D, col, w,
+                           H, ldh, out);
+    else
+        hipLaunchKernelGGL((spmm_row_parts_kernel<16, 2, true>), dim3((unsigned)n_parts), dim3(256), 0, s, parts, D, col,
+                           w, H, ldh, out);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

@@ -67,7 +67,8 @@ class DeviceCSR:
         return self.host
 
 
-def fused_row_order(rowptr: torch.Tensor, lo: int, hi: int, long_threshold: int = 64, part: int = 256):
+def fused_row_order(rowptr: torch.Tensor, lo: int, hi: int, long_threshold: int = 64, part: int = 256,
+                    pad_hubs: bool = False):
     """Work order of rows [lo, hi) for ``lpf_gcn_layer_fused_f32`` (csrc/gcn_fused.hip).  Returns
     ``(order, hubs, parts)``: ``order`` int32 codes, 16 per tile -- hub rows first (more than ``long_threshold`` stored
     entries -- measured per layer, slice kernel + layer kernel, ppa-like graph (mean degree 74): 64: 843 + 740 us,
@@ -76,6 +77,7 @@ def fused_row_order(rowptr: torch.Tensor, lo: int, hi: int, long_threshold: int 
     then the other rows by falling degree (stable), padded with -1;
     ``hubs`` int32 [n_hub, 3] = (global row id, first slice, number of slices) and ``parts`` int64 [n_slices, 2] =
     the slices' entry ranges (``part`` entries each, ``lpf_spmm_row_parts_f32``), both None without hub rows.
+    ``pad_hubs``: pad the hub codes to a multiple of 16 so that no tile mixes hub and ordinary rows.
     The 16 rows of a tile walk their entry lists in lockstep: sorted, they are equally long."""
     dev = rowptr.device
     deg = rowptr[lo + 1:hi + 1] - rowptr[lo:hi]
@@ -84,7 +86,10 @@ def fused_row_order(rowptr: torch.Tensor, lo: int, hi: int, long_threshold: int 
     long_rows = rows[is_long]
     short = rows[~is_long]
     _, perm = torch.sort(deg[~is_long], descending=True, stable=True)
-    codes = torch.cat([-2 - torch.arange(long_rows.numel(), dtype=torch.int64, device=dev), short[perm]])
+    hub_codes = -2 - torch.arange(long_rows.numel(), dtype=torch.int64, device=dev)
+    if pad_hubs and hub_codes.numel() % 16:      # hub rows in tiles of their own (the bf16-table kernel wants that)
+        hub_codes = torch.cat([hub_codes, torch.full(((-hub_codes.numel()) % 16,), -1, dtype=torch.int64, device=dev)])
+    codes = torch.cat([hub_codes, short[perm]])
     pad = (-codes.numel()) % 16
     if pad:
         codes = torch.cat([codes, torch.full((pad,), -1, dtype=torch.int64, device=dev)])

@@ -736,41 +736,76 @@ class LinkTransformer(nn.Module):
         return self._layer_aggregate(i, a_hat, self._layer_transform(i, x), lo, hi, x[lo:hi])
 
     def _fusable(self, i: int, in_dim: int) -> bool:
-        """Layer i as ONE launch (csrc/gcn_fused.hip)?  fp32 table, square weight, D in {32, 64, 128}."""
+        """Layer i as ONE launch (csrc/gcn_fused.hip)?  Square weight, D in {32, 64, 128} (bf16 table: 64, 128)."""
         d_out, d_in = self.node_encoder.gnn_encoder.convs[i].lin.weight.shape
-        return (self.encoder_fused and self.encoder_precision != "bf16" and d_in == d_out and d_out in (32, 64, 128)
-                and in_dim == d_in)
+        ok = (32, 64, 128) if self.encoder_precision != "bf16" else (64, 128)   # (bf16 table: a row is >= one line)
+        return self.encoder_fused and d_in == d_out and d_out in ok and in_dim == d_in
 
     def _layer_fused(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
         """``lpf_gcn_layer_fused_f32``: out[r] = epilogue((sum_e w_e x[col_e]) W^T) for r in [lo, hi) -- the same layer
-        as ``_layer_transform`` + ``_layer_aggregate`` with the sum taken before the product."""
+        as ``_layer_transform`` + ``_layer_aggregate`` with the sum taken before the product.  With
+        ``encoder_precision == "bf16"`` the rows are gathered from a bf16 image of ``x`` (``lpf_gcn_layer_fused_bf16``;
+        sums, product and epilogue fp32) and a whole-graph layer also emits that image of its OUTPUT for the next one."""
         enc = self.node_encoder.gnn_encoder
         conv = enc.convs[i]
         d = x.shape[1]
         last = i == len(enc.convs) - 1
+        b16 = self.encoder_precision == "bf16"
         lib, st = _lib.hip(), _stream(self.device)
         cache = a_hat.__dict__.setdefault("_fused_order", {})
-        if (lo, hi) not in cache:
-            cache[(lo, hi)] = graph.fused_row_order(a_hat.rowptr, lo, hi)
-        order, hubs, parts = cache[(lo, hi)]
+        key = (lo, hi, b16)
+        if key not in cache:
+            cache[key] = graph.fused_row_order(a_hat.rowptr, lo, hi, pad_hubs=b16)
+        order, hubs, parts = cache[key]
         ln = enc.lns[i] if enc.lns is not None else None
         res = x[lo:hi] if enc.residual else None
         out = torch.empty(hi - lo, d, dtype=torch.float32, device=self.device)
+        xb = self._bf16p(x) if b16 else None
         t_parts = None
         if hubs is not None:   # hub rows: their slices are summed first, the layer kernel reads the sums
             t_parts = self._workspace("gcn_t_parts", parts.shape[0] * d, torch.float32, st)
             with KernelTimer.span("spmm_row_parts"):
-                check(lib.lpf_spmm_row_parts_f32(d, ptr(parts), parts.shape[0], ptr(a_hat.col), ptr(a_hat.val), ptr(x),
-                                                 x.stride(0), ptr(t_parts), st), "lpf_spmm_row_parts_f32")
+                if b16:
+                    check(lib.lpf_spmm_row_parts_bf16p(d, ptr(parts), parts.shape[0], ptr(a_hat.col), ptr(a_hat.val),
+                                                       ptr(xb), xb.stride(0), ptr(t_parts), st), "lpf_spmm_row_parts_bf16p")
+                else:
+                    check(lib.lpf_spmm_row_parts_f32(d, ptr(parts), parts.shape[0], ptr(a_hat.col), ptr(a_hat.val),
+                                                     ptr(x), x.stride(0), ptr(t_parts), st), "lpf_spmm_row_parts_f32")
+        common = (ptr(self._conv_packs[i].get(conv.lin.weight)), ptr(out), out.stride(0), ptr(conv.bias),
+                  ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
+                  ptr(res), 0 if res is None else res.stride(0),
+                  ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
+                  FLAG_RELU if enc.relu else 0, ptr(hubs), ptr(t_parts))
         with KernelTimer.span("gcn_layer_fused"):
-            check(lib.lpf_gcn_layer_fused_f32(
-                d, order.numel() // 16, ptr(order), lo, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x),
-                x.stride(0), ptr(self._conv_packs[i].get(conv.lin.weight)), ptr(out), out.stride(0), ptr(conv.bias),
-                ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
-                ptr(res), 0 if res is None else res.stride(0),
-                ptr(self.gnn_norm.weight) if last else None, ptr(self.gnn_norm.bias) if last else None,
-                FLAG_RELU if enc.relu else 0, ptr(hubs), ptr(t_parts), None, 0, st), "lpf_gcn_layer_fused_f32")
+            if b16:
+                whole = lo == 0 and hi == self.num_nodes and not last
+                out_b = torch.empty(hi - lo, d, dtype=torch.bfloat16, device=self.device) if whole else None
+                check(lib.lpf_gcn_layer_fused_bf16(
+                    d, order.numel() // 16, ptr(order), lo, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(xb),
+                    xb.stride(0), *common, ptr(out_b), d, st), "lpf_gcn_layer_fused_bf16")
+                if whole:
+                    self._xb_cache = (weakref.ref(out), out_b)
+            else:
+                check(lib.lpf_gcn_layer_fused_f32(
+                    d, order.numel() // 16, ptr(order), lo, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x),
+                    x.stride(0), *common, None, 0, st), "lpf_gcn_layer_fused_f32")
         return out
+
+    def _bf16p(self, x: torch.Tensor) -> torch.Tensor:
+        """The bf16 image of a [N, D] fp32 table in the order ``lpf_gcn_layer_fused_bf16`` gathers from (element
+        32 i + 8 q + 4 h + u = feature 16 (2 i + h) + 4 q + u): the one the previous fused layer wrote beside ``x``, or a
+        torch permute + cast (the feature table: once per model; an all-gathered layer input: once per layer)."""
+        hit = getattr(self, "_xb_cache", None)
+        if hit is not None and hit[0]() is x:
+            return hit[1]
+        feat = getattr(self, "_xb_feat", None)
+        if feat is not None and feat[0]() is x and feat[1] == x._version:
+            return feat[2]
+        n, d = x.shape
+        xb = x.reshape(n, d // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(n, d).to(torch.bfloat16).contiguous()
+        if x is self._features():
+            self._xb_feat = (weakref.ref(x), x._version, xb)
+        return xb
 
     def _layer_transform(self, i: int, x_rows: torch.Tensor) -> torch.Tensor:
         """GCNConv.lin of layer i on the given rows (other_models.py:66 -> PyG GCNConv: x W^T, no bias).  With

@@ -34,6 +34,7 @@ G.fused_row_order = _patched
 torch.manual_seed(0)
 model = lpformer_amd.LinkTransformer(D.train_args_for(cfg), data, device=dev).to(dev).eval()
 model.encoder_fused = os.environ.get("LPF_FUSED", "1") == "1"
+model.encoder_precision = os.environ.get("LPF_ENC_PREC", "f32")
 for _ in range(5): model.propagate()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): model.propagate()
