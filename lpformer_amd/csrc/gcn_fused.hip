@@ -55,7 +55,10 @@ struct GcnFusedArgs {
 };
 
 constexpr int GF_THREADS = 512;   // threads of a workgroup
-constexpr int GF_NB = 4;          // neighbours of EACH row of a pair requested per step (x D/32 float4 per lane)
+#ifndef LPF_GF_NB
+#define LPF_GF_NB 4
+#endif
+constexpr int GF_NB = LPF_GF_NB;  // neighbours of EACH row of a pair requested per step (x D/32 float4 per lane)
 // workgroups per CU (they share nothing but the CU): at D = 128 ONE, i.e. two wavefronts per SIMD with 256 registers
 // each -- 32 float4 of neighbour rows in flight per lane beside the accumulators (measured per layer on the
 // collab-like graph: 2 workgroups x 2 neighbours 230 us, 1 x 4: 217, 1 x 5: 216, 256 threads 2 x 4: 227,
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
                                    __uint_as_float(raw.w)};
                 }
             };
-            constexpr int NBP = (NT == 8 && !B16) ? GF_NB : (NT == 8 ? GF_NB + 2 : GF_NB / 2);   // neighbours per step and row
+            constexpr int NBP = NT == 8 ? GF_NB : GF_NB / 2;   // neighbours per step and row (bf16 table: 6 measured slower than 4)
             int32_t cx[NBP], cy[NBP];
             float wx[NBP], wy[NBP];
 #pragma unroll
