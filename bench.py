@@ -222,6 +222,12 @@ def main():
     ap.add_argument("--attention", default="auto", choices=("auto", "flip", "mfma"),
                     help="fp32 one-pass attention kernel: activation-pattern evaluation of the PE key projection "
                          "(pair_flip.hip, gather-bound) or the D x D product on the fp32 matrix cores (pair_fused.hip)")
+    ap.add_argument("--launch", default="auto", choices=("auto", "graph", "eager"),
+                    help="auto: whichever of the two is faster in an untimed probe before the windows (the choice and "
+                         "both probe times are reported in config); graph: every stream replays ONE captured HIP graph of the step (lpformer_amd.GraphedScorer: "
+                         "the same launches, bitwise the same scores; the host issues one graph launch instead of "
+                         "~10 kernel launches through Python: 0.15 ms of host time per step otherwise, which is more "
+                         "than the GPU time of the D = 64 configs); eager: LinkTransformer.score_pairs per step")
     ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
     args = ap.parse_args()
@@ -296,8 +302,19 @@ def main():
     # bound) run under the MFMA kernels of the previous one.  Every step still does all of its work.
     lanes = model.lanes(max(1, args.streams))
 
+    scorers = None
+    if args.launch in ("graph", "auto"):
+        # one captured step per stream; a scorer owns its workspaces (sized from the batch it is captured with, twice
+        # its entry counts) and re-captures by itself when the precision mode or a parameter changes
+        KernelTimer.enabled = False
+        scorers = [lpformer_amd.GraphedScorer(model, score, h, batches[k % len(batches)]) for k in range(len(lanes))]
+
+    use_graph = args.launch == "graph"
+
     def step_on(i):
         with torch.cuda.stream(lanes[i % len(lanes)]):
+            if use_graph:
+                return scorers[i % len(lanes)](batches[i % len(batches)])
             return step(i)
 
     for i in range(max(args.warmup, len(lanes))):
@@ -311,6 +328,28 @@ def main():
             step_on(i)
         torch.cuda.synchronize()
         n_spin += 16
+
+    launch_probe = None
+    if args.launch == "auto":
+        # untimed probe: the same K steps through both launch paths; the timed windows use the faster one.  (Eager
+        # costs ~0.15 ms of host time per step whatever the batch -- the D = 64 configs need less GPU time than that --
+        # while at D = 128 the replayed graphs run a few per cent behind the eager launches.)
+        probe = {}
+        for mode in ("eager", "graph"):
+            use_graph = mode == "graph"
+            for i in range(2 * len(lanes)):
+                step_on(i)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step_on(i)
+            torch.cuda.synchronize()
+            barrier()
+            probe[mode] = LD.max_over_ranks(time.perf_counter() - t0, dev) * 1e3 / args.steps
+        use_graph = probe["graph"] < probe["eager"]
+        launch_probe = {k: round(v, 4) for k, v in probe.items()}
+
 
     # ---- timed region: windows of EXACTLY `steps` steps, nothing but the scoring path (no event recording); each
     #      window is bracketed by a barrier + device synchronisation on both sides, time = max over ranks.
@@ -333,7 +372,10 @@ def main():
         assert torch.isfinite(out).all()
     # the steps never read the selection status back (nothing does while they are queued): read it once per lane now --
     # a batch that had outgrown its workspace would have come back as NaN and must not count as scored
-    overflows = sum(0 if model.check_selection(lane) else 1 for lane in lanes)
+    if use_graph:
+        overflows = sum(0 if sc.check() else 1 for sc in scorers)
+    else:
+        overflows = sum(0 if model.check_selection(lane) else 1 for lane in lanes)
     assert overflows == 0, "a timed step overflowed its selection workspace: the window is invalid"
     rep_ms = [e * 1e3 / args.steps for e in rep_s]
     elapsed = float(np.median(rep_s))   # `value`: the median window
@@ -592,7 +634,10 @@ def main():
                                    f"PPR eps={cfg['eps']}), {bs} candidate pairs per GPU per step, pair stage with "
                                    "encoder output resident",
                        "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
-                       "streams": len(lanes), "spinup_s": args.spinup, "attention_impl": model.attention_kernel(),
+                       "streams": len(lanes), "launch": ("one captured HIP graph of the step per stream, replayed"
+                                                         if use_graph else "eager (Python, ~10 launches per step)"),
+                       "launch_probe_ms_per_step": launch_probe,
+                       "spinup_s": args.spinup, "attention_impl": model.attention_kernel(),
                        "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']} " +
                                        {"sharded": "(rows + all-gather per layer)",
                                         "gather_once": "(last layer + Z / Y on row blocks, one all-gather of [X | Z | Y])",

@@ -11,21 +11,24 @@ sys.path.insert(0, ".")
 import lpformer_amd  # noqa: E402
 from lpformer_amd import data as D  # noqa: E402
 
-cfg = D.CONFIGS["collab"]
+import os
+cfg = dict(D.CONFIGS[os.environ.get("LPF_CFG", "collab")])
+if os.environ.get("LPF_BS"):
+    cfg["batch"] = int(os.environ["LPF_BS"])
 dev = torch.device("cuda:0")
 ei, w = D.chung_lu_graph(cfg["n"], cfg["edges"], gamma=cfg["gamma"], seed=0, max_weight=cfg["max_weight"])
 x = np.random.default_rng(1).standard_normal((cfg["n"], cfg["f_in"])).astype(np.float32)
-data = D.build_data(ei, x, cfg["n"], edge_weight=w, eps=cfg["eps"])
+data = D.build_data(ei, x, cfg["n"], edge_weight=w, eps=cfg["eps"], ppr_device=dev)
 model = lpformer_amd.LinkTransformer(D.train_args_for(cfg), data, device=dev).to(dev).eval()
 score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
 batches = [torch.from_numpy(D.sample_pairs(ei, cfg["n"], cfg["batch"], seed=i)).to(dev) for i in range(4)]
 h = model.propagate()
-lanes = [torch.cuda.Stream(dev) for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2)]
+lanes = model.lanes(int(sys.argv[1]) if len(sys.argv) > 1 else 6)
 
 
 def step(i):
     with torch.cuda.stream(lanes[i % len(lanes)]):
-        return score(model.pair_features(batches[i % 4], h))
+        return model.score_pairs(batches[i % 4], h, score)
 
 
 for i in range(8):
