@@ -209,8 +209,12 @@ def main():
                     help="PPR producer for the (untimed) setup: lpf_ppr_push_f64 on the GPU or the OpenMP host push")
     ap.add_argument("--spinup", type=float, default=1.0,
                     help="seconds of untimed steps after the W warm-up steps, so that the device holds its clocks")
-    ap.add_argument("--no-side-stream", action="store_true",
-                    help="keep the elementwise / q branches on the step's own stream (model.use_side_stream = False)")
+    ap.add_argument("--side-stream", default="auto", choices=("auto", "on", "off"),
+                    help="the elementwise / q branches of a step on a side stream of their own (model.use_side_stream). "
+                         "auto = off when the steps already rotate over several streams: the other streams' kernels "
+                         "fill the machine, and the fork / join events of a side stream cost more than the overlap "
+                         "inside one step gives (collab-like, 6 streams: 0.199 ms/step with, 0.192 without)")
+    ap.add_argument("--no-side-stream", action="store_true", help="= --side-stream off")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of K steps each; `value` / `ms_per_step` are the MEDIAN window, min/median/max of "
                          "all are reported")
@@ -228,8 +232,9 @@ def main():
                          "the same launches, bitwise the same scores; the host issues one graph launch instead of "
                          "~10 kernel launches through Python: 0.15 ms of host time per step otherwise, which is more "
                          "than the GPU time of the D = 64 configs); eager: LinkTransformer.score_pairs per step")
-    ap.add_argument("--streams", type=int, default=6,
-                    help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial)")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial); "
+                         "collab-like without a side stream: 3: 0.196, 4: 0.189, 6: 0.191, 8: 0.187, 12: 0.186 ms/step")
     args = ap.parse_args()
 
     rank, world, local = LD.init_from_env()
@@ -248,7 +253,8 @@ def main():
     torch.manual_seed(0)
     model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev).eval()
     score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
-    model.use_side_stream = not args.no_side_stream
+    side = "off" if args.no_side_stream else args.side_stream
+    model.use_side_stream = side == "on" or (side == "auto" and args.streams <= 1)
     model.attention_impl = args.attention
     enc_plan = None
     if world > 1:
@@ -634,7 +640,7 @@ def main():
                                    f"PPR eps={cfg['eps']}), {bs} candidate pairs per GPU per step, pair stage with "
                                    "encoder output resident",
                        "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
-                       "streams": len(lanes), "launch": ("one captured HIP graph of the step per stream, replayed"
+                       "streams": len(lanes), "side_stream": bool(model.use_side_stream), "launch": ("one captured HIP graph of the step per stream, replayed"
                                                          if use_graph else "eager (Python, ~10 launches per step)"),
                        "launch_probe_ms_per_step": launch_probe,
                        "spinup_s": args.spinup, "attention_impl": model.attention_kernel(),
