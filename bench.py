@@ -232,6 +232,8 @@ def main():
                          "the same launches, bitwise the same scores; the host issues one graph launch instead of "
                          "~10 kernel launches through Python: 0.15 ms of host time per step otherwise, which is more "
                          "than the GPU time of the D = 64 configs); eager: LinkTransformer.score_pairs per step")
+    ap.add_argument("--select-grid", type=int, default=0,
+                    help="(tuning) workgroups of the selection's run kernel; 0 = as many as are resident at once")
     ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial); "
                          "collab-like without a side stream: 3: 0.196, 4: 0.189, 6: 0.191, 8: 0.187, 12: 0.186 ms/step")
@@ -256,6 +258,7 @@ def main():
     side = "off" if args.no_side_stream else args.side_stream
     model.use_side_stream = side == "on" or (side == "auto" and args.streams <= 1)
     model.attention_impl = args.attention
+    model.select_grid = args.select_grid
     enc_plan = None
     if world > 1:
         # encoder layout: measure the whole encoder on one GPU (replicated mode) and the all-gather of an [N, D] fp32

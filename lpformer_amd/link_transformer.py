@@ -531,6 +531,7 @@ class LinkTransformer(nn.Module):
         self._shard = (0, 1)   # (rank, world)
         self.encoder_mode = "sharded"  # with world > 1: "sharded" (rows + all-gather per layer) or "replicated"
         self.use_select_index = True  # False: always run the general (PPR-streaming) selection kernel
+        self.select_grid = 0           # workgroups of lpf_select3_run (0 = as many as are resident at once)
         # the elementwise branch and the q projection only need X and the batch: they run on a second HIP stream
         # underneath the (latency/issue-bound) selection kernels.  False: everything on the caller's stream.
         self.use_side_stream = True
@@ -927,7 +928,7 @@ class LinkTransformer(nn.Module):
                 check(lib.lpf_select3_run(bs, ptr(ws.desc), ptr(ws.offs), ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl),
                                           ptr(ws.run_lb), ptr(wi.u.cv), float(self.thresh_cn), float(self.thresh_1hop),
                                           float(self.thresh_non1hop), cn, ptr(ws.type_ptr), ptr(ws.entries),
-                                          ws.ent_cap, 0, st), "lpf_select3_run")
+                                          ws.ent_cap, self.select_grid, st), "lpf_select3_run")
             return
         adj, adjx, val, t0 = graphs
         with KernelTimer.span("select_plan"):
