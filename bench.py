@@ -316,7 +316,14 @@ def main():
         # one captured step per stream; a scorer owns its workspaces (sized from the batch it is captured with, twice
         # its entry counts) and re-captures by itself when the precision mode or a parameter changes
         KernelTimer.enabled = False
-        scorers = [lpformer_amd.GraphedScorer(model, score, h, batches[k % len(batches)]) for k in range(len(lanes))]
+        try:
+            scorers = [lpformer_amd.GraphedScorer(model, score, h, batches[k % len(batches)]) for k in range(len(lanes))]
+        except RuntimeError as exc:   # a capture that fails leaves the eager path, which is the same work
+            if args.launch == "graph":
+                raise
+            print(f"[bench] graph capture failed ({exc}); timing eager launches", file=sys.stderr)
+            scorers, args.launch = None, "eager"
+            torch.cuda.synchronize()
 
     use_graph = args.launch == "graph"
 
