@@ -27,11 +27,15 @@ class GraphedScorer:
     comes back as NaN: call ``scorer.check()`` before using the scores of a sweep (it synchronises)."""
 
     def __init__(self, model, score_func, h: torch.Tensor, example_batch: torch.Tensor, test_set: bool = False,
-                 logits: bool = False):
+                 logits: bool = False, adopt_input: bool = False):
+        """``adopt_input``: the example batch (an int64 [2, BS] device tensor) IS the static input -- no private copy;
+        a later call with that very tensor replays without the device-to-device copy of the ids (the caller refills it
+        in place, or, like the bench, keeps one resident batch per scorer)."""
         self.model, self.score_func, self.h = model, score_func, h
         self.test_set, self.logits = test_set, logits
         dev = model.device
-        self.batch = model._prep_batch(example_batch).clone()
+        prepped = model._prep_batch(example_batch)
+        self.batch = prepped if (adopt_input and prepped is example_batch) else prepped.clone()
         self.stream = torch.cuda.Stream(dev)   # private: the model's workspaces of this stream belong to the scorer
         self.captures = 0
         self._capture()
@@ -69,7 +73,8 @@ class GraphedScorer:
             raise ValueError(f"this graph was captured for batches of shape {tuple(self.batch.shape)}")
         if self._param_key() != self._key:
             self._capture()
-        self.batch.copy_(batch, non_blocking=True)
+        if batch is not self.batch:
+            self.batch.copy_(batch, non_blocking=True)
         self.graph.replay()
         return self.out
 

@@ -236,6 +236,16 @@ def test_step_replays_from_a_captured_graph(mode):
         want = model.score_pairs(b, h, score, logits=True)
         assert torch.equal(got, want)
     assert model.check_selection(scorer.stream)
+    # a scorer that adopts its input reads the caller's tensor in place: no copy when called with that very tensor,
+    # an in-place refill is seen by the next replay, any other tensor is copied in as before
+    own = batches[1].clone()
+    adopted = lpformer_amd.GraphedScorer(model, score, h, own, logits=True, adopt_input=True)
+    assert adopted.batch is own
+    assert torch.equal(adopted(own), model.score_pairs(batches[1], h, score, logits=True))
+    own.copy_(batches[2])
+    assert torch.equal(adopted(own), model.score_pairs(batches[2], h, score, logits=True))
+    assert torch.equal(adopted(batches[3]), model.score_pairs(batches[3], h, score, logits=True))
+    assert torch.equal(own, batches[3]) and adopted.check()
 
 
 def test_selection_overflow_is_flagged_and_recovered():
