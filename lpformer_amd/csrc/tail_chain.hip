@@ -62,7 +62,12 @@ __device__ __forceinline__ void tc_load(T (&r)[P], const float *packed, int stag
 #pragma unroll
     for (int e = 0; e < P; ++e) {
         const int i = e * TC_THREADS + tid;
+#ifdef TC_NOWLOAD      /* (tuning builds: how much of the kernel is waiting for the weight stream?) */
+        r[e] = T{};
+        (void)src; (void)i;
+#else
         r[e] = src[i < tc_stage_stride(NTP) ? i : 0];   // (the last strip of a thread may lie past the stage's padding)
+#endif
     }
 }
 template <int P, typename T>
