@@ -11,6 +11,50 @@ void lpf_set_hip_error(hipError_t e) {
     g_hip_err[sizeof(g_hip_err) - 1] = 0;
 }
 
+int lpf_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LPF_MAX_DEVICES) return -1;
+    return dev;
+}
+
+int lpf_cu_count() {
+    static LpfPerDevice cus;
+    const int dev = lpf_current_device();
+    if (dev < 0) return 0;
+    int n = cus.v[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n = prop.multiProcessorCount;
+        cus.v[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+int lpf_set_max_lds(LpfPerDevice &once, const void *kern, int bytes) {
+    const int dev = lpf_current_device();
+    if (dev < 0) return LPF_ERR_NO_DEVICE;
+    if (once.v[dev].load(std::memory_order_relaxed)) return LPF_OK;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        lpf_set_hip_error(e);
+        return LPF_ERR_LAUNCH;
+    }
+    once.v[dev].store(1, std::memory_order_relaxed);
+    return LPF_OK;
+}
+
+int lpf_blocks_per_cu(LpfPerDevice &cache, const void *kern, int threads, size_t lds, int fallback) {
+    const int dev = lpf_current_device();
+    if (dev < 0) return fallback;
+    int occ = cache.v[dev].load(std::memory_order_relaxed);
+    if (occ == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds) != hipSuccess || occ < 1) occ = fallback;
+        cache.v[dev].store(occ, std::memory_order_relaxed);
+    }
+    return occ;
+}
+
 extern "C" int lpf_abi_version(void) { return LPF_ABI_VERSION; }
 
 extern "C" const char *lpf_last_hip_error(void) { return g_hip_err; }

@@ -350,16 +350,7 @@ int dc_launch(const DenseChainArgs &a, hipStream_t s) {
     constexpr int G = dc_groups(NTP1, NTP2);
     constexpr size_t lds = DcLds<NT1, NT2, G>::BYTES;
     auto kern = dense_chain_kernel<NT1, NT2, G, MODE, dc_min_waves<NT1, NT2, G>()>;
-    static bool lds_set = false;  // (per instantiation; the attribute is sticky, one call is enough)
-    if (lds > 64 * 1024 && !lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            lpf_set_hip_error(e);
-            return LPF_ERR_LAUNCH;
-        }
-        lds_set = true;
-    }
+    LPF_SET_MAX_LDS(kern, lds);  // (per instantiation and device; the attribute is sticky)
     const int64_t blocks = (a.M + 16 * DC_GROUPS - 1) / (16 * DC_GROUPS);
     if (blocks > 0x7fffffff) return LPF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(DC_THREADS), lds, s, a);

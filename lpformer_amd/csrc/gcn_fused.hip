@@ -372,26 +372,15 @@ int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_
                          ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre,
                          static_cast<uint16_t *>(out_b), ldob};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = lpf_cu_count();
+    if (n_cu == 0) return LPF_ERR_NO_DEVICE;
     // persistent workgroups
     const int64_t want = (n_tiles + GF_THREADS / 64 - 1) / (GF_THREADS / 64);
 #define LPF_GF(NT)                                                                                                  \
     do {                                                                                                            \
         auto kern = gcn_fused_kernel<NT, HB>;                                                                       \
         constexpr size_t lds = (size_t)(NT * GF_STAGE + 1) * sizeof(f32x4);                                         \
-        static bool lds_set = false;                                                                                \
-        if (lds > 64 * 1024 && !lds_set) {                                                                          \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds) != hipSuccess)                                                        \
-                return LPF_ERR_LAUNCH;                                                                              \
-            lds_set = true;                                                                                         \
-        }                                                                                                           \
+        LPF_SET_MAX_LDS(kern, lds);                                                            \
         const int64_t cap = (int64_t)gf_per_cu<NT>() * n_cu;                                                        \
         hipLaunchKernelGGL(kern, dim3((unsigned)(want < cap ? want : cap)), dim3(GF_THREADS), lds, s, a);           \
     } while (0)

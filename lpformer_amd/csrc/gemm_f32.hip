@@ -254,13 +254,7 @@ int gemm_rows_go(const RowsArgs &a, hipStream_t s, int n_cu) {
     constexpr size_t lds = (size_t)NTI * NTO * 64 * sizeof(f32x4r);
     constexpr int NTH = lds > 64 * 1024 ? 1024 : 512;       // two workgroups per CU, or one around a big table
     auto kern = gemm_rows_kernel<NTI, NTO, NTH>;
-    static bool lds_set = false;
-    if (lds > 64 * 1024 && !lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return LPF_ERR_LAUNCH;
-        lds_set = true;
-    }
+    LPF_SET_MAX_LDS(kern, lds);
     const int64_t n_tiles = (a.M + 15) >> 4;
     int64_t groups = (n_tiles + NTH / 64 - 1) / (NTH / 64);
     const int64_t cap = (int64_t)n_cu * (NTH == 1024 ? 1 : 2);
@@ -275,13 +269,8 @@ int gemm_rows_launch(const RowsArgs &a, hipStream_t s) {
     if ((a.ldc & 3) || !lpf_aligned16(a.C) || (a.bias && !lpf_aligned16(a.bias)) ||
         (a.addend && ((a.ldadd & 3) || !lpf_aligned16(a.addend))))
         return LPF_ERR_UNSUPPORTED;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = lpf_cu_count();
+    if (n_cu == 0) return LPF_ERR_NO_DEVICE;
     const int nti = a.K <= 32 ? 2 : (a.K <= 64 ? 4 : 8), nto = a.N <= 32 ? 2 : (a.N <= 64 ? 4 : (a.N <= 128 ? 8 : 16));
 #define LPF_ROWS(I, O) if (nti == I && nto == O) return gemm_rows_go<I, O>(a, s, n_cu)
     LPF_ROWS(2, 2); LPF_ROWS(2, 4); LPF_ROWS(2, 8); LPF_ROWS(2, 16);

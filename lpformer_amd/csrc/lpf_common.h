@@ -9,6 +9,29 @@
 
 void lpf_set_hip_error(hipError_t e);
 
+// Launch facts are cached PER DEVICE: one process may drive several GPUs, from several host threads.  The guarded
+// actions (hipFuncSetAttribute, an occupancy query) are idempotent, so relaxed atomics are enough -- two threads doing
+// one of them twice is harmless, launching without it is not (function-local `static bool` caches).
+#include <atomic>
+constexpr int LPF_MAX_DEVICES = 64;
+struct LpfPerDevice {
+    std::atomic<int> v[LPF_MAX_DEVICES];
+};
+int lpf_current_device();                                             // -1: none (or an ordinal beyond the cache)
+int lpf_cu_count();                                                   // CUs of the current device; 0: no device
+int lpf_set_max_lds(LpfPerDevice &once, const void *kern, int bytes);  // hipFuncAttributeMaxDynamicSharedMemorySize
+// resident workgroups per CU of `kern` (occupancy query, cached); `fallback` when the query fails
+int lpf_blocks_per_cu(LpfPerDevice &cache, const void *kern, int threads, size_t lds, int fallback);
+
+#define LPF_SET_MAX_LDS(kern, lds)                                                                       \
+    do {                                                                                                 \
+        static LpfPerDevice once__;                                                                      \
+        if ((lds) > 64 * 1024) {                                                                         \
+            const int rc__ = lpf_set_max_lds(once__, reinterpret_cast<const void *>(kern), (int)(lds));  \
+            if (rc__ != LPF_OK) return rc__;                                                             \
+        }                                                                                                \
+    } while (0)
+
 #define LPF_CHECK_LAUNCH()                      \
     do {                                        \
         hipError_t e__ = hipGetLastError();     \

@@ -459,13 +459,7 @@ extern "C" int lpf_pair_scores_f32(int32_t D, const int64_t *type_ptr, int64_t b
     do {                                                                                                           \
         auto kern = pair_scores_lds_kernel<NT>;                                                                    \
         const size_t lds = (size_t)(NT * (32 * NT / 8) * 64 + 3 * 32 * NT) * sizeof(float4);                       \
-        static bool lds_set = false;                                                                               \
-        if (lds > 64 * 1024 && !lds_set) {                                                                         \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
-                return LPF_ERR_LAUNCH;                                                                             \
-            lds_set = true;                                                                                        \
-        }                                                                                                          \
+        LPF_SET_MAX_LDS(kern, lds);                                                            \
         int64_t groups = (tiles + PSL_WAVES - 1) / PSL_WAVES + 3;                                                  \
         if (groups > 256) groups = 256; /* one 16-wave workgroup per CU: half the LDS of two 8-wave ones */       \
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * PSL_WAVES), lds, s, type_ptr, bs, sel_pair,     \

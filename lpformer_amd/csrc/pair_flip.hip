@@ -399,13 +399,8 @@ int flip_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
     const FlipArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), (uint32_t)ldz,
                      q, (uint32_t)ldq, pe_tab_signed, pe_stat, base, wfold_t, att, part, bnd, units_cap};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = lpf_cu_count();
+    if (n_cu == 0) return LPF_ERR_NO_DEVICE;
     const int64_t max_units = 3 * ((ent_cap + 15) / 16) + 3;
     // persistent workgroups (they stride over the units they find): at D = 128 one of 1024 threads per CU around the
     // Wfold^T tables of two types (128 of its 152 KB of LDS), two of 512 threads below, three of 256 at D = 256
@@ -413,13 +408,7 @@ int flip_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
     do {                                                                                                        \
         auto kern = pair_flip_kernel<GG, NTH, WTL, ZB>;                                                         \
         constexpr size_t lds = (size_t)(6 * 4 * GG + WTL * 4 * GG * GG + (NTH / 64) * (64 / GG) * 24 + 1) * sizeof(float4); \
-        static bool lds_set = false;                                                                            \
-        if (lds > 64 * 1024 && !lds_set) {                                                                      \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds) != hipSuccess)                                                    \
-                return LPF_ERR_LAUNCH;                                                                          \
-            lds_set = true;                                                                                     \
-        }                                                                                                       \
+        LPF_SET_MAX_LDS(kern, lds);                                                            \
         int64_t groups = (max_units + (NTH / 64) * (64 / GG) - 1) / ((NTH / 64) * (64 / GG));                   \
         if (groups > (int64_t)n_cu * PER_CU) groups = (int64_t)n_cu * PER_CU;                                   \
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(NTH), lds, s, a);                                 \

@@ -438,13 +438,8 @@ int fused_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *ent
     FusedArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), ldz, q, ldq,
                 pe_tab, pe_stat, static_cast<const float *>(wfold_packed), bfold, att, part, bnd, units_cap, dbg};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = lpf_cu_count();
+    if (n_cu == 0) return LPF_ERR_NO_DEVICE;
     const int64_t tiles = (3 * ent_cap + 31) / 32 + 3;
 #define LPF_FUSED(NT)                                                                                              \
     do {                                                                                                           \
@@ -452,18 +447,9 @@ int fused_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *ent
         constexpr int PF_WAVES = pf_waves<NT>();                                                                   \
         const size_t lds = (size_t)(3 * 32 * NT) * sizeof(float4) +                                                \
                            (size_t)PF_WAVES * 32 * 32 * NT * (BF16 ? 2 : 4);                                       \
-        static int per_cu = 0; /* resident workgroups per CU, queried once (also sets the LDS attribute) */        \
-        if (per_cu == 0) {                                                                                         \
-            if (lds > 64 * 1024 &&                                                                                 \
-                hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
-                return LPF_ERR_LAUNCH;                                                                             \
-            int occ = 1;                                                                                           \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * PF_WAVES, lds) != hipSuccess ||      \
-                occ < 1)                                                                                           \
-                occ = 1;                                                                                           \
-            per_cu = occ;                                                                                          \
-        }                                                                                                          \
+        LPF_SET_MAX_LDS(kern, lds);                                                                                \
+        static LpfPerDevice occ__; /* resident workgroups per CU, queried once per device */                       \
+        const int per_cu = lpf_blocks_per_cu(occ__, reinterpret_cast<const void *>(kern), 64 * PF_WAVES, lds, 1);  \
         int64_t groups = (tiles + PF_WAVES - 1) / PF_WAVES;                                                        \
         if (groups > (int64_t)n_cu * per_cu) groups = (int64_t)n_cu * per_cu; /* persistent: one resident round */ \
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * PF_WAVES), lds, s, a);                          \

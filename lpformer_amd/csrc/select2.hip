@@ -808,16 +808,11 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     a.type_ptr = type_ptr; a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
     // one resident round of workgroups (they are persistent; more than fit only queue up behind the others:
     // 1024 / 1280 / 2048 / 4096 workgroups measured 132 / 132 / 138 / 158 us on 256 CUs)
-    static int resident = 0;
-    if (resident == 0) {
-        int dev = 0, occ = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, select_run_kernel<false>, S2_THREADS, 0) != hipSuccess ||
-            occ < 1)
-            occ = 4;
-        resident = prop.multiProcessorCount * occ;
-    }
+    static LpfPerDevice occ_cache;
+    const int n_cu = lpf_cu_count();
+    if (n_cu == 0) return LPF_ERR_NO_DEVICE;
+    const int resident =
+        n_cu * lpf_blocks_per_cu(occ_cache, reinterpret_cast<const void *>(select_run_kernel<false>), S2_THREADS, 0, 4);
     int64_t blocks = grid_blocks > 0 ? grid_blocks : resident;
     if (blocks > item_cap) blocks = item_cap;
     hipStream_t s = static_cast<hipStream_t>(stream);

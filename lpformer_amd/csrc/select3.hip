@@ -504,15 +504,11 @@ extern "C" int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs
     // and at half the footprint it is faster by itself (collab-like 60.5 -> 55.9 us: fewer workgroups contend for the
     // same DRAM pages and the look-back chains are shorter) and leaves room for the kernels of other streams (pipelined
     // step 0.187 -> 0.181 ms; one per CU: 79 us by itself, the same pipelined step).
-    static int resident = 0;
-    if (resident == 0) {
-        int dev = 0, occ = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LPF_ERR_NO_DEVICE;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, select3_run_kernel, S3_THREADS, 0) != hipSuccess || occ < 1)
-            occ = 4;
-        resident = prop.multiProcessorCount * (occ < 2 ? occ : 2);
-    }
+    static LpfPerDevice occ_cache;
+    const int n_cu = lpf_cu_count();
+    if (n_cu == 0) return LPF_ERR_NO_DEVICE;
+    const int occ = lpf_blocks_per_cu(occ_cache, reinterpret_cast<const void *>(select3_run_kernel), S3_THREADS, 0, 4);
+    const int resident = n_cu * (occ < 2 ? occ : 2);
     int64_t blocks = grid_blocks > 0 ? grid_blocks : resident;
     if (blocks > item_cap) blocks = item_cap;
     hipLaunchKernelGGL(select3_run_kernel, dim3((unsigned)blocks), dim3(S3_THREADS), 0, static_cast<hipStream_t>(stream), a);

@@ -405,13 +405,7 @@ template <int NTA, int NTB, int NTC, bool WB = false>
 int tc_launch(const TailArgs &a, hipStream_t s) {
     constexpr size_t lds = TcShape<NTA, NTB, NTC>::BYTES;
     auto kern = tail_chain_kernel<NTA, NTB, NTC, WB>;
-    static bool lds_set = false;  // (per instantiation; the attribute is sticky, one call is enough)
-    if (lds > 64 * 1024 && !lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return LPF_ERR_LAUNCH;
-        lds_set = true;
-    }
+    LPF_SET_MAX_LDS(kern, lds);  // (per instantiation and device; the attribute is sticky)
     const int64_t blocks = (a.M + 16 * TC_GROUPS - 1) / (16 * TC_GROUPS);
     if (blocks > 0x7fffffff) return LPF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TC_THREADS), lds, s, a);

@@ -448,13 +448,25 @@ class _SelectWorkspace:
             self.entries = None  # release before allocating the new size
             self.entries = torch.empty(3 * self.ent_cap * 4, dtype=torch.int32, device=self.device)
 
-    def read_status(self):
-        """(error bits, [n_cn, n_1hop, n_non1hop]) of the last batch; synchronises the current stream."""
-        v = self.ctl.tolist()
+    def read_status(self, stream=None):
+        """(error bits, [n_cn, n_1hop, n_non1hop]) of the last batch.  The read is ordered after everything queued on
+        ``stream`` (a ``torch.cuda.Stream``; default: the current one): the copy is issued ON that stream and waited
+        for, so a selection kernel still in flight there cannot be read as "ok"."""
+        if stream is None:
+            v = self.ctl.tolist()
+        else:
+            with torch.cuda.stream(stream):
+                v = self.ctl.tolist()
         return int(v[3]), [int(v[4]), int(v[5]), int(v[6])]
 
-    def clear_errors(self):
-        self.ctl[3] = 0
+    def clear_errors(self, stream=None):
+        """Clears the sticky bits on ``stream`` (default: the current one) -- the stream whose kernels raise them, so
+        the write cannot race with a kernel's atomicOr."""
+        if stream is None:
+            self.ctl[3] = 0
+        else:
+            with torch.cuda.stream(stream):
+                self.ctl[3] = 0
 
 
 # ------------------------------------------------------------------------------------------ the model
@@ -1010,17 +1022,20 @@ class LinkTransformer(nn.Module):
         """Synchronising check of the sticky selection status of ``stream`` (default: the current one).  Returns True
         when every batch since the last check fitted its workspace; otherwise clears the status, marks the workspace
         for re-sizing and returns False (the caller re-scores those batches).  Node ids out of range raise
-        IndexError."""
-        st = _stream(self.device) if stream is None else stream.cuda_stream
+        IndexError.  The status is read (and cleared) ON ``stream`` itself, behind everything queued there, whatever
+        the caller's current stream is: a lane that has not run yet cannot be read as "ok"."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        st = stream.cuda_stream
         ok = True
         for key, ws in list(self._ws.items()):
             if not (isinstance(key, tuple) and key[0] == "sel2" and key[1] == st):
                 continue
-            err, _ = ws.read_status()
+            err, _ = ws.read_status(stream)
             if err == 0:
                 continue
             ok = False
-            ws.clear_errors()
+            ws.clear_errors(stream)
             if err & _lib.SELECT_ERR_NODE_RANGE:
                 raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
             ws.calibrated = False   # re-size on the next batch

@@ -278,6 +278,38 @@ def test_selection_overflow_is_flagged_and_recovered():
     assert torch.isfinite(out).all() and torch.equal(out, want)
 
 
+def test_check_selection_orders_its_read_behind_a_busy_lane():
+    """check_selection(lane) called from ANOTHER stream while the lane still has the overflowing batch queued behind
+    a long kernel: the status read must wait for the lane (never "ok" for a batch that has not run yet), and the
+    clear must not race with the kernel that raises the bit."""
+    cfg, n, ei, w, x, data, args, model, score, _ = _setup("collab", scale=0.05, bs=2048)
+    h = model.propagate()
+    rng = np.random.default_rng(1)
+    sparse, dense = _sparse_then_hub_edges(n, data, rng, 2048, 2048)
+    sparse, dense = (torch.from_numpy(e.T.copy()).to(DEV) for e in (sparse, dense))
+    lane = model.lanes(1)[0]
+    big = torch.randn(8192, 8192, device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(lane):
+        model.score_pairs(sparse, h, score)               # sizes the lane's workspace for the sparse batch
+    assert model.check_selection(lane)
+    for _ in range(3):
+        with torch.cuda.stream(lane):
+            for _ in range(6):
+                big = (big @ big).mul_(1e-4)              # tens of ms queued in front of the selection
+            bad = model.score_pairs(dense, h, score, logits=True)
+        assert not lane.query()                           # the lane is still busy when the check is made ...
+        assert not model.check_selection(lane)            # ... from the main stream: must report the overflow
+        assert torch.isnan(bad).all()
+        with torch.cuda.stream(lane):
+            good = model.score_pairs(dense, h, score, logits=True)
+        assert model.check_selection(lane) and torch.isfinite(good).all()
+        with torch.cuda.stream(lane):
+            model._ws.clear()
+            model.score_pairs(sparse, h, score)
+        assert model.check_selection(lane)
+
+
 def _sparse_then_hub_edges(n, data, rng, n_sparse, n_dense, n_hubs=64):
     deg = np.diff(data["adj_mask"].rowptr)
     hubs = np.argsort(deg)[-n_hubs:]
