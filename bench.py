@@ -76,14 +76,47 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 
 
-def build_problem(cfg, rank, world, threads, ppr_device=None):
+def build_problem(cfg, rank, world, threads, ppr_device=None, barrier=None):
+    """Synthetic graph, features and PPR matrix (untimed set-up).  With more than one rank only rank 0 generates the
+    graph and runs the PPR push; the others load what it wrote to a memory-backed cache (/dev/shm, removed again by
+    rank 0 once every rank has read it) -- the set-up is identical on every rank by construction, there is no point in
+    eight processes recomputing it on eight GPUs at once."""
+    from lpformer_amd import graph as G
     n = cfg["n"]
+    cache = None
+    if world > 1:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        import tempfile
+        cache = os.path.join(base or tempfile.gettempdir(),
+                             f"lpf_bench_setup_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}.npz")
     t0 = time.time()
-    ei, w = D.chung_lu_graph(n, cfg["edges"], gamma=cfg["gamma"], seed=0, max_weight=cfg["max_weight"])
-    x = np.random.default_rng(1).standard_normal((n, cfg["f_in"])).astype(np.float32)
-    t1 = time.time()
-    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr_threads=threads, ppr_device=ppr_device)
-    t2 = time.time()
+    if rank == 0 or cache is None:
+        ei, w = D.chung_lu_graph(n, cfg["edges"], gamma=cfg["gamma"], seed=0, max_weight=cfg["max_weight"])
+        x = np.random.default_rng(1).standard_normal((n, cfg["f_in"])).astype(np.float32)
+        t1 = time.time()
+        data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr_threads=threads, ppr_device=ppr_device)
+        t2 = time.time()
+        if cache is not None:
+            ppr = data["ppr"]
+            tmp = cache + ".tmp.npz"
+            np.savez(tmp, ei=ei, w=np.zeros(0, np.float32) if w is None else w, x=x, ppr_rowptr=ppr.rowptr,
+                     ppr_col=ppr.col, ppr_val=ppr.val)
+            os.replace(tmp, cache)
+    if cache is not None:
+        barrier()                       # the cache is complete
+        if rank != 0:
+            z = np.load(cache)
+            ei, w, x = z["ei"], (z["w"] if z["w"].size else None), z["x"]
+            t1 = time.time()
+            ppr = G.CSR(z["ppr_rowptr"], z["ppr_col"], z["ppr_val"], n)
+            data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr=ppr)
+            t2 = time.time()
+        barrier()                       # every rank has read it
+        if rank == 0:
+            try:
+                os.remove(cache)
+            except OSError:
+                pass
     return ei, w, x, data, {"graph_s": t1 - t0, "ppr_s": t2 - t1}
 
 
@@ -196,9 +229,17 @@ def main():
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="collab", choices=sorted(D.CONFIGS))
-    ap.add_argument("--batches", type=int, default=0,
-                    help="distinct candidate batches cycled through; 0 = one per stream (a stream then always scores the "
-                         "same resident batch, which a captured graph reads in place instead of through a copy)")
+    ap.add_argument("--batches", type=int, default=32,
+                    help="distinct candidate batches cycled through (resident in HBM before the timed region; a captured "
+                         "graph copies the ids of the step's batch into its static input).  0 = one per stream: a "
+                         "stream then always scores the same resident batch, read in place (round 3's default)")
+    ap.add_argument("--weights", default="both", choices=("random", "both"),
+                    help="both: after the headline (random-init weights, as the bench contract prescribes) the model is "
+                         "trained for --train-steps steps of the repo's own training step on the synthetic graph and "
+                         "the same timed window is run again (extra key `trained_weights`: flips per entry, the "
+                         "attention kernel `auto` then picks, ms per step)")
+    ap.add_argument("--train-steps", type=int, default=150)
+    ap.add_argument("--train-lr", type=float, default=1e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="pairs timed on the CPU oracle, taken from the bench's own batches (0 = 1,024 per worker process, "
@@ -251,7 +292,11 @@ def main():
     n, d, bs = cfg["n"], cfg["dim"], cfg["batch"]
     host_threads = max(1, (os.cpu_count() or 8) // world)
 
-    ei, w, x, data, setup = build_problem(cfg, rank, world, host_threads, dev if args.ppr == "gpu" else None)
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    ei, w, x, data, setup = build_problem(cfg, rank, world, host_threads, dev if args.ppr == "gpu" else None, barrier)
     targs = D.train_args_for(cfg)
     torch.manual_seed(0)
     model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev).eval()
@@ -298,9 +343,17 @@ def main():
     batches_np = [D.sample_pairs(ei, n, bs, seed=1000 * rank + i) for i in range(args.batches)]
     batches = [torch.from_numpy(b).to(dev) for b in batches_np]
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+    # ---- the selection's walk indexes (built once per (adjacency, PPR matrix, thresholds) on the device): timed and
+    #      sized here, because the selection's speed is bought with them
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wi = model._walk_index(model._data_obj("mask", False), model._data_obj("ppr", False))
+    torch.cuda.synchronize()
+    setup["index_s"] = time.perf_counter() - t0
+    idx_tensors = [wi.rec, wi.adj_cv, wi.a1_cv, wi.px_cv, wi.t0_cv, wi.u.cv, wi.u.rowptr, wi.u.len] + \
+        [getattr(wi, k) for k in ("bloom",) if getattr(wi, k, None) is not None]
+    index_bytes = int(sum(t.numel() * t.element_size() for t in idx_tensors if t is not None))
+    del wi, idx_tensors
 
     # ---- encoder output (resident for the pair stage; the encoder itself is timed after the pair stage, warm)
     for _ in range(2):
@@ -328,15 +381,19 @@ def main():
             if args.launch == "graph":
                 raise
             print(f"[bench] graph capture failed ({exc}); timing eager launches", file=sys.stderr)
-            scorers, args.launch = None, "eager"
+            scorers = None
             torch.cuda.synchronize()
+        # every rank must take the same path from here on (the probe below runs barriers and reductions): if the
+        # capture failed on ANY rank, all of them time eager launches
+        if LD.max_over_ranks(0.0 if scorers is not None else 1.0, dev) > 0.0:
+            scorers, args.launch = None, "eager"
 
     use_graph = args.launch == "graph"
 
     def step_on(i):
         with torch.cuda.stream(lanes[i % len(lanes)]):
-            if use_graph:
-                return scorers[i % len(lanes)](batches[i % len(batches)])
+            if use_graph:   # (validate=False: nothing changes a parameter inside a window; stale() is asked after it)
+                return scorers[i % len(lanes)](batches[i % len(batches)], validate=False)
             return step(i)
 
     for i in range(max(args.warmup, len(lanes))):
@@ -395,6 +452,7 @@ def main():
     # the steps never read the selection status back (nothing does while they are queued): read it once per lane now --
     # a batch that had outgrown its workspace would have come back as NaN and must not count as scored
     if use_graph:
+        assert not any(sc.stale() for sc in scorers), "a parameter changed inside the timed windows"
         overflows = sum(0 if sc.check() else 1 for sc in scorers)
     else:
         overflows = sum(0 if model.check_selection(lane) else 1 for lane in lanes)
@@ -503,6 +561,72 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     pairs_per_s = world * bs * args.steps / elapsed
+    flips_random = model.flips_per_entry() if d >= 128 else None
+    attention_random = model.attention_kernel()
+
+    # ---- the same window on TRAINED weights (extra keys): the activation-pattern attention
+    #      kernel's cost depends on how many hidden units of the PE MLPs leave the activation pattern of (0, 0), i.e. on
+    #      the ppr_encoder_* weights; the headline uses random-init weights as the bench contract prescribes.  A few
+    #      hundred steps of the repo's own training step (lpformer_amd/train.py: positives = existing edges, negatives =
+    #      uniform pairs, Adam) move them the way training does; `auto` then re-decides between the two kernels.
+    trained = None
+    if args.weights == "both":
+        saved = ({k: v.detach().clone() for k, v in model.state_dict().items()},
+                 {k: v.detach().clone() for k, v in score.state_dict().items()})
+        pos_e = torch.from_numpy(ei[:, ei[0] < ei[1]]).to(dev)
+        opt = torch.optim.Adam(list(model.parameters()) + list(score.parameters()), lr=args.train_lr)
+        tb, losses = 4096, []
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(4321)
+        model.train(); score.train()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(args.train_steps):
+            idx = torch.randint(0, pos_e.shape[1], (tb,), device=dev, generator=gen)
+            neg = torch.randint(0, n, (2, tb), device=dev, generator=gen)
+            loss = (-torch.log(score(model(pos_e[:, idx])) + 1e-6).mean()
+                    - torch.log(1 - score(model(neg)) + 1e-6).mean())
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            if it < 5 or it >= args.train_steps - 5:
+                losses.append(float(loss))
+        torch.cuda.synchronize()
+        train_s = time.perf_counter() - t0
+        model.eval(); score.eval()
+        del opt
+        h_rand, scorers_rand = h, scorers
+        h = model.propagate()
+        torch.cuda.synchronize()
+        if use_graph:
+            scorers = [lpformer_amd.GraphedScorer(model, score, h, batches[k % len(batches)]) for k in range(len(lanes))]
+        for i in range(max(args.warmup, 2 * len(lanes))):
+            step_on(i)
+        torch.cuda.synchronize()
+        tr_s = []
+        for _ in range(max(1, args.repeats)):
+            el, out = window()
+            tr_s.append(el)
+            assert torch.isfinite(out).all()
+        ok = all(sc.check() for sc in scorers) if use_graph else all(model.check_selection(lane) for lane in lanes)
+        assert ok, "a timed step of the trained-weights leg overflowed its selection workspace"
+        el_t = float(np.median(tr_s))
+        trained = {"train_steps": args.train_steps, "train_batch": f"{tb} positives + {tb} negatives", "lr": args.train_lr,
+                   "train_ms_per_step": round(train_s * 1e3 / max(1, args.train_steps), 2),
+                   "loss_first5_mean": round(float(np.mean(losses[:5])), 4) if losses else None,
+                   "loss_last5_mean": round(float(np.mean(losses[-5:])), 4) if losses else None,
+                   "flips_per_entry": None if d < 128 else round(model.flips_per_entry(), 3),
+                   "attention_impl": model.attention_kernel(),
+                   "ms_per_step": round(el_t * 1e3 / args.steps, 4),
+                   "value": round(world * bs * args.steps / el_t, 1), "unit": "pairs/s"}
+        # back to the random-init weights for everything below (kernel timings, CPU baseline)
+        model.load_state_dict(saved[0])
+        score.load_state_dict(saved[1])
+        scorers = scorers_rand
+        del h_rand, saved
+        h = model.propagate()
+        torch.cuda.synchronize()
     value_incl_encoder = world * bs / ((ms_per_step + encoder_ms + node_keys_ms) * 1e-3)
 
     kt = KernelTimer.summary() if not args.no_kernel_timing else {}
@@ -517,7 +641,7 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline: every modelled kernel, the dominant one of the timed region reported as "roofline"
-        roofline, rooflines, kernels = None, {}, {}
+        roofline, rooflines, kernels, pair_stage = None, {}, {}, None
         if kt:
             tot = sum(v[1] for v in kt.values())
             kernels = {k: {"launches": v[0], "ms_per_step": round(v[1] / args.steps, 4),
@@ -533,6 +657,12 @@ def main():
             # algorithmic work per launch: bytes for the HBM-bound kernels, FLOPs for MFMA ones
             slots = mean([s["slots"] for s in stats])
             c = model.count_dim
+            # the WHOLE pair stage against the HBM roof: SURVEY 8(d)'s B_pair summed over the batch (what a both-rows
+            # walk of the reference's algorithm must touch) / the measured step time
+            b_pair = 4.0 * sum_deg + 8.0 * sum_ppr + (32.0 + 16.0 + 4.0) * bs + 4.0 * d * (2.0 * bs + n_sel)
+            pair_stage = {"survey_8d_bytes_per_step": round(b_pair, 0),
+                          "hbm_frac_of_8TBs": round(b_pair / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                          "hbm_frac_of_6.3TBs": round(b_pair / (ms_per_step * 1e-3) / 6.3e12, 4)}
             work = {
                 # one-pass attention (score + segment softmax + weighted sum).  "mfma": SURVEY 8(d) n_sel * (2 D^2 +
                 # ~20 D) FLOP on the fp32 matrix cores.  "flip" (default): the D x D product is gone, what
@@ -659,7 +789,9 @@ def main():
                        "streams": len(lanes), "side_stream": bool(model.use_side_stream), "launch": ("one captured HIP graph of the step per stream, replayed"
                                                          if use_graph else "eager (Python, ~10 launches per step)"),
                        "launch_probe_ms_per_step": launch_probe,
-                       "spinup_s": args.spinup, "attention_impl": model.attention_kernel(),
+                       "spinup_s": args.spinup, "attention_impl": attention_random,
+                       "attention_impl_requested": args.attention, "flips_per_entry": flips_random,
+                       "flip_break_even": model.FLIP_BREAK_EVEN.get(d),
                        "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']} " +
                                        {"sharded": "(rows + all-gather per layer)",
                                         "gather_once": "(last layer + Z / Y on row blocks, one all-gather of [X | Z | Y])",
@@ -671,8 +803,12 @@ def main():
             "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),
             "ms_per_step_repeats": {"n": len(rep_ms), "min": round(min(rep_ms), 4),
                                     "median": round(float(np.median(rep_ms)), 4), "max": round(max(rep_ms), 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "bf16_mode": bf16, "kernels": kernels, "rooflines": rooflines,
-            "setup_s": dict({k: round(v, 2) for k, v in setup.items()}, ppr_producer=args.ppr),
+            "roofline": roofline, "cpu_baseline": cpu,
+            "pair_stage_hbm_frac": None if pair_stage is None else pair_stage["hbm_frac_of_8TBs"],
+            "pair_stage": pair_stage, "trained_weights": trained,
+            "bf16_mode": bf16, "kernels": kernels, "rooflines": rooflines,
+            "setup_s": dict({k: round(v, 2) for k, v in setup.items()}, ppr_producer=args.ppr,
+                            index_bytes=index_bytes),
         }
         print(json.dumps(result), flush=True)
     barrier()

@@ -22,12 +22,17 @@ import torch
 import torch.distributed as dist
 
 
+# Test knob: with a process group of ONE rank still issue the (then trivial) collectives and walk the sharded encoder
+# branches -- a 1-GPU box can load librccl and run the very call path the N > 1 runs take (tests/test_gpu_dist.py).
+FORCE_COLLECTIVES = False
+
+
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's environment; initialises the default group if world > 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("LPF_DIST_FORCE_INIT") == "1") and not dist.is_initialized():
         if backend is None:  # (LPF_DIST_BACKEND=gloo: functional runs of the N > 1 path with several ranks on ONE GPU)
             backend = os.environ.get("LPF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -53,7 +58,7 @@ def shard_pairs(batch: torch.Tensor, world: int, rank: int) -> torch.Tensor:
 
 def allgather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
     """Assemble the full [n, D] matrix from every rank's row block (blocks follow ``row_range``)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES):
         return local
     world = dist.get_world_size(group)
     d = local.shape[1]
@@ -80,7 +85,7 @@ def gather_scores(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
 
 
 def max_over_ranks(value: float, device=None) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_COLLECTIVES):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -92,7 +97,7 @@ def measure_allgather_gbps(n: int, d: int, device, reps: int = 3, group=None) ->
     group, measured: the one number the encoder plan needs."""
     import time
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (FORCE_COLLECTIVES and dist.is_initialized()):
         return float("inf")
     rank = dist.get_rank(group)
     lo, hi = row_range(n, world, rank)

@@ -41,11 +41,19 @@ class GraphedScorer:
         self._capture()
 
     def _param_key(self):
-        ps = list(self.model.parameters()) + list(self.score_func.parameters())
-        return tuple((p.data_ptr(), p._version) for p in ps) + (self.model.precision, self.model.tail_precision)
+        # (the module trees are walked once per capture, not per replay: a module gaining or losing a parameter goes
+        #  through __setattr__ / load_state_dict(assign=True), which the version / address pairs below also notice for
+        #  every parameter that existed at the capture)
+        return tuple((p.data_ptr(), p._version) for p in self._params) + (self.model.precision,
+                                                                           self.model.tail_precision)
+
+    def stale(self) -> bool:
+        """True when a parameter (storage or version) or a precision switch changed since the capture."""
+        return self._param_key() != self._key
 
     def _capture(self):
         model, dev = self.model, self.model.device
+        self._params = list(model.parameters()) + list(self.score_func.parameters())
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):
             for _ in range(2):  # sizes the per-stream workspaces and fills every parameter-derived cache
@@ -66,12 +74,14 @@ class GraphedScorer:
         self._key = self._param_key()
         self.captures += 1
 
-    def __call__(self, batch: torch.Tensor) -> torch.Tensor:
+    def __call__(self, batch: torch.Tensor, validate: bool = True) -> torch.Tensor:
         """Scores of ``batch`` ([2, BS] node ids, same BS as the example); the result tensor is reused by the next
-        call.  Re-captures first when a parameter changed since the capture."""
+        call.  Re-captures first when a parameter changed since the capture.  ``validate=False`` skips that check
+        (one pass over the parameters' version counters on the host): for sweeps in which the caller knows that no
+        parameter changes -- it then owes one ``stale()`` per sweep."""
         if batch.shape != self.batch.shape:
             raise ValueError(f"this graph was captured for batches of shape {tuple(self.batch.shape)}")
-        if self._param_key() != self._key:
+        if validate and self.stale():
             self._capture()
         if batch is not self.batch:
             self.batch.copy_(batch, non_blocking=True)

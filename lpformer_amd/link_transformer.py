@@ -690,7 +690,7 @@ class LinkTransformer(nn.Module):
             a_hat = self._device_graph("prop", self._data_obj("adj", test_set) if adj is None else adj)
             n_layers = len(self.node_encoder.gnn_encoder.convs)
             rank, world = self._shard
-            if world == 1 or self.encoder_mode == "replicated":
+            if (world == 1 and not lpf_dist.FORCE_COLLECTIVES) or self.encoder_mode == "replicated":
                 x = self._features()
                 for i in range(n_layers):
                     if _layers_out is not None:
@@ -1137,10 +1137,63 @@ class LinkTransformer(nn.Module):
         side.wait_stream(main)
         return side
 
+    # Measured break-even of the two fp32 one-pass attention kernels, in mean flipped hidden units per selected entry
+    # (tools/flip_breakeven.py, profiles/r04_flip_breakeven.txt): the cost of csrc/pair_flip.hip grows with the number
+    # of units of the PE hidden layer that leave the activation pattern of (0, 0), csrc/pair_fused.hip does the whole
+    # D x D product whatever the weights are.
+    FLIP_BREAK_EVEN = {128: 6.0, 256: 24.0}
+
+    @_on_device
+    def flips_per_entry(self, n_pairs: int = 4096, seed: int = 0) -> float:
+        """Mean number of hidden units of the PE MLPs (both argument orders, ``2 D`` per entry) whose ReLU state differs
+        from the one at (0, 0), over the selected entries of a sample batch drawn from the model's OWN graph and PPR
+        matrix (half existing edges, half uniform pairs -- the selection kernels run on it).  This is what the cost of
+        the activation-pattern attention kernel depends on; a property of the ``ppr_encoder_*`` weights
+        (reference link_transformer.py:67-76) and of the PPR values, evaluated once per parameter version."""
+        w = self._fold()
+        hit = getattr(self, "_flip_est", None)
+        if hit is not None and hit[0] is self._folded[0]:
+            return hit[1]
+        with torch.no_grad():
+            mask = self._device_graph("mask", self._data_obj("mask", False))
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(seed)
+            k = n_pairs // 2 if mask.nnz > 0 else 0
+            parts = []
+            if k:
+                e = torch.randint(0, mask.nnz, (k,), device=self.device, generator=gen)
+                rows = torch.searchsorted(mask.rowptr, e, right=True) - 1
+                parts.append(torch.stack([rows, mask.col[e].long()]))
+            parts.append(torch.randint(0, self.num_nodes, (2, n_pairs - k), device=self.device, generator=gen))
+            batch = torch.cat(parts, dim=1).contiguous()
+            sel = self._select(batch, False, None)
+            bs = sel["bs"]
+            tot = sel["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)[:, bs].tolist()
+            flips, base = 0.0, 0
+            for t in range({"all": 3, "1-hop": 2, "cn": 1}[self.mask]):
+                pa, pb = sel["sel_pa"][base:base + tot[t]], sel["sel_pb"][base:base + tot[t]]
+                base += tot[t]
+                if pa.numel() == 0:
+                    continue
+                tab, st = w["flip_tab"][t], w["pe_stat"][t]     # rows (ta, tc, td, beta) times the unit's sign at (0, 0)
+                for x, y in ((pa, pb), (pb, pa)):
+                    var = st[0] * x * x + st[1] * y * y + st[2] + 2.0 * (st[3] * x * y + st[4] * x + st[5] * y)
+                    r = torch.rsqrt(var.clamp_min(0.0) + 1e-5)
+                    z = r[:, None] * (x[:, None] * tab[:, 0] + y[:, None] * tab[:, 1] + tab[:, 2]) + tab[:, 3]
+                    flips += float((z < 0).sum().item())
+            est = flips / max(1, sum(tot))
+        self._flip_est = (self._folded[0], est)
+        return est
+
     def attention_kernel(self) -> str:
-        """The fp32 one-pass attention kernel this model runs: ``attention_impl`` with "auto" resolved."""
+        """The fp32 one-pass attention kernel this model runs: ``attention_impl`` with "auto" resolved.  Below D = 128
+        the matrix-core kernel always wins; from D = 128 on "auto" looks at the weights: the
+        activation-pattern kernel while ``flips_per_entry()`` is below the measured break-even, the matrix-core kernel
+        (whose cost does not depend on the weights) above it."""
         if self.attention_impl == "auto":
-            return "flip" if self.dim >= 128 else "mfma"
+            if self.dim < 128:
+                return "mfma"
+            return "flip" if self.flips_per_entry() <= self.FLIP_BREAK_EVEN.get(self.dim, 6.0) else "mfma"
         return self.attention_impl
 
     def _fused_attention(self, batch, x_node, test_set, adj_mask, side):

@@ -40,3 +40,16 @@ def test_encoder_layouts_under_a_process_group(world, ragged):
             raise
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_rccl_world_of_one():
+    """backend "nccl" (= RCCL), one rank, collectives forced: librccl is loaded and ``allgather_rows`` /
+    ``measure_allgather_gbps`` / ``max_over_ranks`` / every ``set_row_shard`` layout run the library's collective
+    calls on the device (tests/rccl_world1_worker.py).  The exchange over xGMI itself needs more than one GPU."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_worker.py")], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout
+    assert "rccl world-1 ok" in p.stdout, p.stdout

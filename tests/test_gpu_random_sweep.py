@@ -133,3 +133,41 @@ def test_flip_attention_with_weights_that_flip_most_units(dim, gain):
         assert model.check_selection()
         assert np.abs(lg.cpu().numpy() - ref["logit"]).max() <= TOL * max(1.0, float(np.abs(ref["logit"]).max())), impl
     assert (outs["flip"] - outs["mfma"]).abs().max().item() <= 1e-5 * max(1.0, outs["mfma"].abs().max().item())
+
+
+@pytest.mark.parametrize("dim", [128, 256])
+def test_auto_attention_choice_follows_the_weights(dim):
+    """``attention_impl = "auto"`` estimates the flipped units per entry on a sample of the model's own PPR matrix
+    (LinkTransformer.flips_per_entry) and takes the activation-pattern kernel below the measured break-even, the
+    matrix-core kernel above it.  Random-init weights: few flips -> "flip"; first PE layers scaled up: many -> "mfma";
+    the estimate follows a parameter update without being asked; both choices within 1e-4 of the oracle."""
+    seed = 33
+    rng = np.random.default_rng(seed)
+    n = 500
+    ei, w = D.chung_lu_graph(n, 6000, gamma=2.3, seed=seed, max_weight=0)
+    x = rng.standard_normal((n, 24)).astype(np.float32)
+    ppr = lpformer_amd.calc_ppr(ei, n, 0.15, 1e-4)
+    d = D.build_data(ei, x, n, edge_weight=w, ppr=ppr)
+    cfg = D.train_args_for(dict(thresholds=(0.0, 1e-3, 1e-2), dim=dim, gnn_layers=1, residual=False))
+    torch.manual_seed(seed)
+    model = lpformer_amd.LinkTransformer(cfg, d, device=DEV).to(DEV).eval()
+    score = lpformer_amd.mlp_score(2 * dim, 2 * dim, 1, 2).to(DEV).eval()
+    batch = D.sample_pairs(ei, n, 600, seed=seed + 1)
+    assert model.attention_impl == "auto"
+    chosen = []
+    for gain in (1.0, 200.0):
+        with torch.no_grad():
+            for enc in (model.ppr_encoder_cn, model.ppr_encoder_onehop, model.ppr_encoder_non1hop):
+                enc.linears[0].weight.mul_(gain)
+        P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
+        ref = O.forward(batch, x, O.gcn_norm(ei, w, n), O.symmetric_mask_csr(ei, n),
+                        (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P, dict(cfg, pred_layers=2))
+        flips = model.flips_per_entry()
+        chosen.append((model.attention_kernel(), flips))
+        assert (flips <= model.FLIP_BREAK_EVEN[dim]) == (chosen[-1][0] == "flip")
+        lg = model.score_pairs(torch.from_numpy(batch).to(DEV), model.propagate(), score, logits=True)
+        assert model.check_selection()
+        assert np.abs(lg.cpu().numpy() - ref["logit"]).max() <= TOL * max(1.0, float(np.abs(ref["logit"]).max()))
+    assert [c[0] for c in chosen] == ["flip", "mfma"], chosen
+    assert chosen[0][1] < 1.5 and chosen[1][1] > 30.0, chosen
