@@ -49,6 +49,9 @@ constexpr int S3_PAIRS = S3_ITEM / S3_MIN_SLOTS + 2;
 constexpr uint32_t S3_FROM_B = 0x80000000u;
 constexpr uint32_t S3_HASH_MUL = 2654435761u;
 constexpr int S3_BUCKET = 8;
+constexpr int S3_DESC_AHEAD = S3_THREADS / 8;        // descriptors copied before the window is known (one int4 per thread)
+// absence filter in front of a U row (lpformer_amd/graph.py BLOOM_*): 2 * buckets words, two bits of one word per key
+constexpr uint32_t S3_BLOOM_MUL1 = 0x85EBCA6Bu, S3_BLOOM_MUL2 = 0xC2B2AE35u;
 
 // walk kinds
 constexpr int K_FULL = 0, K_A1 = 1, K_PX = 2, K_T0 = 3;
@@ -74,6 +77,13 @@ struct alignas(16) PairDesc3 {
     int32_t total, a, b, pad[5];
 };
 static_assert(sizeof(Walk3) == 32 && sizeof(PairDesc3) == 128, "descriptor is one 128-byte line");
+
+__device__ __forceinline__ uint32_t s3_bloom_hash(uint32_t v) {
+    uint32_t h = v * S3_BLOOM_MUL1;
+    h ^= h >> 15;
+    h *= S3_BLOOM_MUL2;
+    return h ^ (h >> 13);
+}
 
 // fl32((fl32(fl32(p*t)+t)-t)/t) for t in {1,2}: p*1, p*2, x/1 and x/2 are exact, only the add and subtract round
 __device__ __forceinline__ float s3_rt1(float p) { return __fsub_rn(__fadd_rn(p, 1.0f), 1.0f); }
@@ -202,7 +212,8 @@ struct RunArgs3 {
     int64_t item_cap;
     int64_t *ctl;
     uint64_t *run_lb;   // [3][item_cap]
-    const int2 *u_cv;   // the hashed union index: buckets of 8 {node, value bits | adjacent << 31}
+    const int2 *u_cv;   // the hashed union index: per row its absence filter, then buckets of 8 {node, value bits |
+                        // adjacent << 31} (a Walk3's u0 points at the first bucket)
     float th_cn, th_1, th_n;
     int32_t mode_cn;
     int32_t *type_ptr;  // [3][bs+1]
@@ -218,7 +229,7 @@ struct RunLds3 {
     int32_t pre[S3_GROUPS];       // window pairs that start before group g (beyond the first)
     int32_t cnt[S3_GROUPS][4];    // kept entries per type of group g, then their exclusive scan
     int64_t base[3];
-    int64_t ticket;
+    int64_t nx_ticket, nx_pf;     // the NEXT item and its first pair, drawn while the current one is being typed
     int32_t n_pairs;
     int32_t run[3];               // kept entries per type of the item being built
     // the parked item: what its deferred write-out needs once the window belongs to the next item
@@ -274,7 +285,13 @@ __device__ __forceinline__ void s3_finish_parked(const RunArgs3 &A, RunLds3 &L, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(S3_THREADS, 4) void select3_run_kernel(const RunArgs3 A) {
+#ifndef S3_MIN_WAVES      // (tuning) resident wavefronts per SIMD the register budget allows: workgroups per CU
+#define S3_MIN_WAVES 2
+#endif
+#ifndef S3_PER_CU         // (tuning) persistent workgroups per CU the launch asks for
+#define S3_PER_CU 2
+#endif
+__global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(const RunArgs3 A) {
     __shared__ RunLds3 L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -283,25 +300,43 @@ __global__ __launch_bounds__(S3_THREADS, 4) void select3_run_kernel(const RunArg
     if (n_items > A.item_cap) n_items = A.item_cap;
     const int64_t bs = A.bs;
     const uint32_t epoch = (uint32_t)A.ctl[8];  // launch number, written by the plan kernel
-    if (tid == 0) L.p_live = 0;
+    // The ticket of an item and its first pair are drawn one item AHEAD (by the last wavefront, between the phases of
+    // the item being typed): at the top of the loop both are known and the window and the descriptors are requested
+    // at once -- ticket -> item_pair -> offsets -> descriptors used to be four dependent round trips per item.
+    const bool drawer = tid == S3_THREADS - 1;
+    if (tid == 0) {
+        L.p_live = 0;
+        const int64_t t = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 2), 1ull);
+        L.nx_ticket = t;
+        L.nx_pf = t < n_items ? A.item_pair[t] : 0;
+    }
 
     while (true) {
-        __syncthreads();  // the previous item's window is no longer needed
-        if (tid == 0) L.ticket = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 2), 1ull);
+        __syncthreads();  // the previous item's window is no longer needed; nx_* are the current item's
+        const int64_t it = L.nx_ticket;
+        const int64_t pf = L.nx_pf;
         if (tid < 2 * S3_GROUPS) L.bits[tid] = 0u;
-        __syncthreads();
-        const int64_t it = L.ticket;
         if (it >= n_items) break;
+        int64_t nx_t = 0;
+        if (drawer) nx_t = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 2), 1ull);
         const int64_t c0 = it * S3_ITEM;
         const int n_here = (int)((total - c0) < S3_ITEM ? (total - c0) : S3_ITEM);
-        const int64_t pf = A.item_pair[it];
+        // the first S3_DESC_AHEAD descriptors of the window (one int4 per thread), requested before the window is
+        // known -- an item of 1,024 slots rarely holds more pairs than that --, and the window itself: both in flight
+        // together, consumed behind the barrier
+        const int64_t avail = bs - pf;
+        const int n4a = (int)(avail < S3_DESC_AHEAD ? avail : S3_DESC_AHEAD) * 8;
+        int4 dreg = make_int4(0, 0, 0, 0);
+        if (tid < n4a) dreg = reinterpret_cast<const int4 *>(A.desc + pf)[tid];
+        int64_t v = n_here;
+        if (tid <= S3_PAIRS && pf + tid <= bs) v = A.offs[pf + tid] - c0;
 
         // ---- pair window: loc[i] = offs[pf + i] - c0, pairs past the item read n_here; a pair other than the first
         //      raises the bit of the slot it starts in (every pair owns >= S3_MIN_SLOTS slots: at most S3_PAIRS pairs,
         //      no two in one slot)
+        __syncthreads();  // (bits are zero)
+        if (tid < n4a) reinterpret_cast<int4 *>(L.dsc)[tid] = dreg;
         if (tid < 128) {
-            int64_t v = n_here;
-            if (tid <= S3_PAIRS && pf + tid <= bs) v = A.offs[pf + tid] - c0;
             if (v > n_here) v = n_here;
             if (tid <= S3_PAIRS) L.loc[tid] = (int32_t)v;
             const bool in = tid <= S3_PAIRS && v < n_here;
@@ -317,12 +352,15 @@ __global__ __launch_bounds__(S3_THREADS, 4) void select3_run_kernel(const RunArg
             for (int g = 0; g < tid; ++g) s += __popc(L.bits[2 * g]) + __popc(L.bits[2 * g + 1]);
             L.pre[tid] = s;
         }
-        {   // descriptors of the window pairs -> LDS (one coalesced copy; every slot reads its pair's walk from there)
+        {   // the rest of the window's descriptors (every slot reads its pair's walk from LDS)
             const int n4 = np * 8;
             const int4 *src = reinterpret_cast<const int4 *>(A.desc + pf);
             int4 *dst = reinterpret_cast<int4 *>(L.dsc);
-            for (int i = tid; i < n4; i += S3_THREADS) dst[i] = src[i];
+            for (int i = S3_DESC_AHEAD * 8 + tid; i < n4; i += S3_THREADS) dst[i] = src[i];
         }
+        // the next item's first pair: requested now, in flight beside this item's walked entries
+        int64_t nx_p = 0;
+        if (drawer && nx_t < n_items) nx_p = A.item_pair[nx_t];
         __syncthreads();
 
         // ---- typing: one slot per thread and round; everything a kept slot needs later stays in registers.  The rounds
@@ -358,11 +396,29 @@ __global__ __launch_bounds__(S3_THREADS, 4) void select3_run_kernel(const RunArg
                 }
             }
         }
+        // is x in the other endpoint's union row AT ALL?  One 4-byte word of the row's absence filter answers "no" for
+        // most candidates (collab-like: 3 of 4), and a candidate that is not there needs no bucket: "not found" is what
+        // the bucket would have said.  The filter words of a row are 1/8 of its buckets and the candidates of a pair
+        // all ask the same row, so these reads mostly hit in L2.
+        uint32_t bw[S3_ROUNDS], bh[S3_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < S3_ROUNDS; ++r) {
+            const bool look = act[r] && unbr[r] > 0;
+            bh[r] = s3_bloom_hash((uint32_t)cvr[r].x);
+            const uint32_t nb = (uint32_t)unbr[r];
+            const uint32_t *flt = reinterpret_cast<const uint32_t *>(A.u_cv + (look ? u0r[r] - (int64_t)((nb + 7u) & ~7u) : 0));
+            bw[r] = look ? flt[__umulhi(bh[r], 2u * nb)] : 0u;
+        }
+        if (drawer) { L.nx_ticket = nx_t; L.nx_pf = nx_p; }   // (read at the top of the next iteration, behind barriers)
         int4 bv[S3_ROUNDS][S3_BUCKET / 2];
 #pragma unroll
         for (int r = 0; r < S3_ROUNDS; ++r) {
             // what is x to the other endpoint?  one bucket of its hashed union row
+#ifdef S3_NO_BLOOM   // (tuning: every candidate fetches its bucket, as before the filter)
             const bool look = act[r] && unbr[r] > 0;
+#else
+            const bool look = act[r] && unbr[r] > 0 && ((bw[r] >> (bh[r] & 31u)) & (bw[r] >> ((bh[r] >> 5) & 31u)) & 1u);
+#endif
             const uint32_t b = look ? __umulhi((uint32_t)cvr[r].x * S3_HASH_MUL, (uint32_t)unbr[r]) : 0u;
             const int4 *blk = reinterpret_cast<const int4 *>(A.u_cv + (look ? u0r[r] + S3_BUCKET * (int64_t)b : 0));
 #pragma unroll
@@ -508,7 +564,7 @@ extern "C" int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs
     const int n_cu = lpf_cu_count();
     if (n_cu == 0) return LPF_ERR_NO_DEVICE;
     const int occ = lpf_blocks_per_cu(occ_cache, reinterpret_cast<const void *>(select3_run_kernel), S3_THREADS, 0, 4);
-    const int resident = n_cu * (occ < 2 ? occ : 2);
+    const int resident = n_cu * (occ < S3_PER_CU ? occ : S3_PER_CU);
     int64_t blocks = grid_blocks > 0 ? grid_blocks : resident;
     if (blocks > item_cap) blocks = item_cap;
     hipLaunchKernelGGL(select3_run_kernel, dim3((unsigned)blocks), dim3(S3_THREADS), 0, static_cast<hipStream_t>(stream), a);

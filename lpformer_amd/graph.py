@@ -341,6 +341,19 @@ def ppr_filter_device_blocked(ppr: DeviceCSR, mode: int, theta: float) -> Blocke
 
 HASH_MUL = 2654435761  # Fibonacci hashing constant (2^32 / golden ratio)
 HASH_BUCKET = 8        # entries per bucket of a hashed index (one 64-byte half line)
+# Absence filter in front of a hashed row (csrc/select3.hip, s3_bloom_*): a row of ``nb`` buckets owns 2 nb 32-bit words
+# (1/8 of the bucket bytes), a key sets TWO bits of ONE word: h = mix(key); word = (h * 2 nb) >> 32; bits h & 31 and
+# (h >> 5) & 31.  At one bucket per four entries that is ~2 keys per word, ~1.5-3 % false positives; a key that fails
+# the test is not in the row, so its 64-byte bucket is never fetched.
+BLOOM_MUL1, BLOOM_MUL2 = 0x85EBCA6B, 0xC2B2AE35
+
+
+def bloom_hash(key: torch.Tensor) -> torch.Tensor:
+    """The filter's 32-bit mix of a node id (int64 tensor in, int64 values < 2^32 out); select3.hip::s3_bloom_hash."""
+    h = (key * BLOOM_MUL1) & 0xFFFFFFFF
+    h = h ^ (h >> 15)
+    h = (h * BLOOM_MUL2) & 0xFFFFFFFF
+    return h ^ (h >> 13)
 
 
 @dataclass
@@ -354,6 +367,14 @@ class HashedIndex:
     cv: torch.Tensor       # int32 [HASH_BUCKET * buckets, 2] = 8 entries per bucket
     len: torch.Tensor      # int32 [n]: buckets per row
     n: int
+    # with an absence filter (``hash_index_device(..., bloom=True)``): row i's region starts with its filter words --
+    # 2 len[i] of them, padded to whole 64-byte lines = ``pad[i]`` entries of cv -- and its buckets follow at
+    # ``rowptr[i] + pad[i]`` (64-byte aligned).  None: buckets only.
+    pad: "Optional[torch.Tensor]" = None
+
+    def bucket_start(self) -> torch.Tensor:
+        """int64 [n]: entry offset of every row's first bucket."""
+        return self.rowptr[:-1] if self.pad is None else self.rowptr[:-1] + self.pad
 
     def to_host_compact(self) -> CSR:
         """The index as a plain sorted CSR (tests, statistics)."""
@@ -361,6 +382,8 @@ class HashedIndex:
         rp = self.rowptr.cpu().numpy()
         row = np.repeat(np.arange(self.n), np.diff(rp))
         live = cv[: row.size, 0] != 2**31 - 1
+        if self.pad is not None:   # the filter words in front of every row's buckets are not entries
+            live &= (np.arange(row.size) - rp[:-1][row]) >= self.pad.cpu().numpy()[row]
         row, col, val = row[live], cv[: row.size][live, 0], cv[: row.size][live, 1].copy().view(np.float32)
         order = np.lexsort((col, row))
         rowptr = np.zeros(self.n + 1, np.int64)
@@ -368,8 +391,9 @@ class HashedIndex:
         return CSR(rowptr, col[order].copy(), val[order].copy(), self.n)
 
 
-def hash_index_device(p: DeviceCSR) -> HashedIndex:
-    """Bucketised layout of a device-resident sorted CSR (see HashedIndex).  One-time, a few torch passes."""
+def hash_index_device(p: DeviceCSR, bloom: bool = False) -> HashedIndex:
+    """Bucketised layout of a device-resident sorted CSR (see HashedIndex).  One-time, a few torch passes.
+    ``bloom``: every row's buckets are preceded by its absence filter (BLOOM_* above)."""
     dev, n = p.rowptr.device, p.n
     ln = p.rowptr[1:] - p.rowptr[:-1]
     nnz = int(p.rowptr[-1].item())
@@ -390,18 +414,50 @@ def hash_index_device(p: DeviceCSR) -> HashedIndex:
         nbk[bad] = nbk[bad] * 3 // 2 + 1
     else:
         raise RuntimeError("hash_index_device: bucket sizes did not settle")
-    cv = torch.zeros((max(total, 1) * HASH_BUCKET, 2), dtype=torch.int32, device=dev)
-    cv[:, 0] = 2**31 - 1
+    pad = (nbk + HASH_BUCKET - 1) // HASH_BUCKET * HASH_BUCKET if bloom else torch.zeros_like(nbk)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(nbk * HASH_BUCKET + pad, 0, out=rowptr[1:])
+    n_ent = int(rowptr[-1].item())
+    cv = torch.zeros((max(n_ent, 1), 2), dtype=torch.int32, device=dev)
+    bstart = rowptr[:-1] + pad                          # first bucket entry of every row
+    if total:
+        bucket_row = torch.repeat_interleave(torch.arange(n, device=dev), nbk)
+        slot0 = (bstart[bucket_row] + (torch.arange(total, device=dev) - base[bucket_row]) * HASH_BUCKET)
+        empty = (slot0[:, None] + torch.arange(HASH_BUCKET, device=dev)[None, :]).reshape(-1)
+        cv[empty, 0] = 2**31 - 1
+        del empty, slot0
     if nnz:
         order = torch.argsort(key, stable=True)
         key_s = key[order]
         start = torch.cumsum(cnt, 0) - cnt
-        pos = key_s * HASH_BUCKET + (torch.arange(nnz, device=dev) - start[key_s])
+        row_s = row[order]
+        pos = bstart[row_s] + (key_s - base[row_s]) * HASH_BUCKET + (torch.arange(nnz, device=dev) - start[key_s])
         cv[pos, 0] = p.col[:nnz][order]
         cv[pos, 1] = p.val[:nnz].view(torch.int32)[order]
-    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(nbk * HASH_BUCKET, 0, out=rowptr[1:])
-    return HashedIndex(rowptr, cv.contiguous(), nbk.to(torch.int32), n)
+        if bloom:
+            # two bits of one word per key; the words of a row live in the int32 view of its first `pad` entries
+            h = bloom_hash(col)
+            word = 2 * rowptr[:-1][row] + ((h * (2 * nbk[row])) >> 32)
+            flat = cv.view(-1)
+            n_words = flat.numel()
+            bitpos = torch.cat([word * 32 + (h & 31), word * 32 + ((h >> 5) & 31)])
+            del h, word
+            # OR-scatter without atomics: mark the bits in chunks of words, pack 32 flags per word
+            chunk = 1 << 22
+            w2 = torch.tensor([1 << b for b in range(31)] + [-(1 << 31)], dtype=torch.int32, device=dev)
+            wlo_all = torch.div(bitpos, 32, rounding_mode="floor")
+            for lo in range(0, n_words, chunk):
+                hi = min(lo + chunk, n_words)
+                m = (wlo_all >= lo) & (wlo_all < hi)
+                if not bool(m.any().item()):
+                    continue
+                flags = torch.zeros((hi - lo) * 32, dtype=torch.bool, device=dev)
+                flags[bitpos[m] - lo * 32] = True
+                packed = (flags.view(-1, 32).to(torch.int32) * w2[None, :]).sum(dim=1, dtype=torch.int32)
+                nz = packed != 0
+                flat[lo:hi][nz] = packed[nz]
+            del bitpos, wlo_all
+    return HashedIndex(rowptr, cv.contiguous(), nbk.to(torch.int32), n, pad.to(torch.int64) if bloom else None)
 
 
 def self_ppr_device(adj: DeviceCSR, ppr: DeviceCSR) -> torch.Tensor:
@@ -514,14 +570,14 @@ def build_walk_index(adj, ppr, th_1hop: float, th_non1hop: float, want_t0: bool)
     urow = torch.div(ukey, n, rounding_mode="floor")
     u_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(torch.bincount(urow, minlength=n), 0, out=u_rowptr[1:])
-    u = hash_index_device(DeviceCSR(u_rowptr, (ukey - urow * n).to(torch.int32), ubits.view(f32), n, None))
+    u = hash_index_device(DeviceCSR(u_rowptr, (ukey - urow * n).to(torch.int32), ubits.view(f32), n, None), bloom=True)
 
     rec64 = torch.zeros((n, 8), dtype=torch.int64, device=dev)
     rec64[:, 0] = adj.rowptr[:-1]
     rec64[:, 1] = starts(n_a1)
     rec64[:, 2] = starts(n_px)
     rec64[:, 3] = starts(n_t0)
-    rec64[:, 4] = u.rowptr[:-1]
+    rec64[:, 4] = u.bucket_start()                       # (the row's absence filter sits right in front of it)
     rec = rec64.view(torch.int32)                      # [n, 16]; little endian: int64 field f = columns 2f, 2f+1
     for i, lens in enumerate((deg, n_a1, n_px, n_t0, u.len)):
         rec[:, 10 + i] = lens.to(torch.int32)

@@ -1141,7 +1141,7 @@ class LinkTransformer(nn.Module):
     # (tools/flip_breakeven.py, profiles/r04_flip_breakeven.txt): the cost of csrc/pair_flip.hip grows with the number
     # of units of the PE hidden layer that leave the activation pattern of (0, 0), csrc/pair_fused.hip does the whole
     # D x D product whatever the weights are.
-    FLIP_BREAK_EVEN = {128: 6.0, 256: 24.0}
+    FLIP_BREAK_EVEN = {128: 5.0, 256: 24.0}
 
     @_on_device
     def flips_per_entry(self, n_pairs: int = 4096, seed: int = 0) -> float:

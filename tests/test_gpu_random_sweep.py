@@ -170,4 +170,4 @@ def test_auto_attention_choice_follows_the_weights(dim):
         assert model.check_selection()
         assert np.abs(lg.cpu().numpy() - ref["logit"]).max() <= TOL * max(1.0, float(np.abs(ref["logit"]).max()))
     assert [c[0] for c in chosen] == ["flip", "mfma"], chosen
-    assert chosen[0][1] < 1.5 and chosen[1][1] > 30.0, chosen
+    assert chosen[0][1] < model.FLIP_BREAK_EVEN[dim] < chosen[1][1], chosen
