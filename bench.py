@@ -351,7 +351,7 @@ def main():
     torch.cuda.synchronize()
     setup["index_s"] = time.perf_counter() - t0
     idx_tensors = [wi.rec, wi.adj_cv, wi.a1_cv, wi.px_cv, wi.t0_cv, wi.u.cv, wi.u.rowptr, wi.u.len] + \
-        [getattr(wi, k) for k in ("bloom",) if getattr(wi, k, None) is not None]
+        [getattr(wi, k) for k in ("mini",) if getattr(wi, k, None) is not None]
     index_bytes = int(sum(t.numel() * t.element_size() for t in idx_tensors if t is not None))
     del wi, idx_tensors
 

@@ -34,7 +34,7 @@ extern "C" {
 #define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
 #define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
 
-#define LPF_ABI_VERSION 3
+#define LPF_ABI_VERSION 4
 
 /* GEMM / row-wise epilogue flags */
 #define LPF_FLAG_RELU 1u
@@ -238,6 +238,10 @@ int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int3
  *            (64 aligned bytes, unused entries node INT32_MAX), entry (i, v) in bucket
  *            mulhi_u32(v * 2654435761 mod 2^32, u_buckets[i]), value = P[i, v] with the SIGN BIT set when v is
  *            adjacent to i; no bucket overflows (the builder grows a row's bucket count until that holds)
+ *   mini     uint32 [n_nodes][32]: a fixed 1,024-bit absence filter of every union row -- key v sets bits h & 31 and
+ *            (h >> 5) & 31 of word h >> 27, h = mix32(v ^ 0x9E3779B9) (graph.py mini_filters / bloom_hash).  The run
+ *            kernel stages the filters of an item's endpoints in LDS and fetches a bucket only for candidates that
+ *            pass: random reads are what bounds it (profiles/r04_random_read_probe.txt)
  * mode_cn: mask mode "cn" -- common neighbours only, round trip with t = 1, thresh_cn filter (:232-247).
  * use_px:  0 when theta_1 <= 0 (absent PPR entries then pass the one-hop test and px rows cannot stand in for them). */
 int lpf_select3_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
@@ -245,9 +249,9 @@ int lpf_select3_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t
                      int32_t use_px, void *desc, int64_t *offs, int32_t *item_pair, int64_t item_cap, int64_t *ctl,
                      uint64_t *plan_lb, void *stream);
 int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair, int64_t item_cap,
-                    int64_t *ctl, uint64_t *run_lb, const void *u_cv, float th_cn, float th_1hop, float th_non1hop,
-                    int32_t mode_cn, int32_t *type_ptr, void *entries, int64_t ent_cap, int32_t grid_blocks,
-                    void *stream);
+                    int64_t *ctl, uint64_t *run_lb, const void *u_cv, const void *mini, float th_cn, float th_1hop,
+                    float th_non1hop, int32_t mode_cn, int32_t *type_ptr, void *entries, int64_t ent_cap,
+                    int32_t grid_blocks, void *stream);
 
 /* The reference's layout from the regions above: all CN entries sorted by (pair, node), then all 1-hop (the two runs
  * merged by node id), then all >1-hop (link_transformer.py:161-162); type_ptr64 int64[3*(bs+1)] relative per type,
@@ -413,6 +417,50 @@ int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts, const floa
                              const float *bB, const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre,
                              const void *wC_packed_bf16, const float *bC, const float *w_dot, const float *b_dot,
                              const int64_t *sel_ctl, float *logit, float *prob, void *stream);
+
+/* One-pass attention PAIR-MAJOR (pair_rows.hip; replaces lpf_pair_attention_flip_* + the record merge on the hot path):
+ * LinkAttention.message + PyG softmax + scatter-sum + LinkAttention.bias + post_att_norm (src/modules/layers.py:66-78,
+ * 193-224) and get_structure_cnts (src/models/link_transformer.py:340-356), with the positional encodings
+ * (link_transformer.py:182-211) folded in as in lpf_pair_attention_flip_f32 (same tables).  A group of D/4 lanes walks
+ * the entries PAIR-MAJOR -- a pair's three segments one after the other, found from type_ptr, 16 consecutive entries
+ * per work unit -- and the kernel writes every pair's finished row once:
+ *   out[p, :D]  = post_att_norm( sum_e alpha_e k_e + att_bias )          (no entry: post_att_norm(att_bias))
+ *   out[p, D..] = n_cn, n_1hop, [n_non1hop,] n_cn + n_1hop               (n_counts of them; n_counts = 0: none written)
+ * A pair inside one unit is finished in registers; one that crosses units leaves a partial state per unit in `pieces`,
+ * merged in unit order by the workgroup that owns the pair before the launch ends: nothing is left for the consumer.
+ * ldo >= D + n_counts, ldo % 4 == 0.  Rows are NaN when sel_ctl[3] != 0 (selection workspace overflow).
+ * pieces: scratch, float[units_cap * 2 * lpf_pair_rows_piece_floats(D)], units_cap >= ceil(3 * ent_cap / 16) + 1 -- the
+ * partial softmax states of the pairs that cross the 16-entry units of the pair-major order (written and merged inside
+ * the launch, by the workgroup that owns the pair; contents are meaningless afterwards).  D in {32, 64, 128, 256}. */
+int lpf_pair_attention_rows_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
+                                const float *Z, int64_t ldz, const float *q, int64_t ldq, const float *pe_tab_signed,
+                                const float *pe_stat, const float *base, const float *wfold_t, const float *att,
+                                const float *att_bias, const float *ln_g, const float *ln_b, int32_t n_counts,
+                                const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out, int64_t ldo,
+                                void *stream);
+int64_t lpf_pair_rows_piece_floats(int32_t D);
+/* The same with the node table Z stored in bf16 (uint16 rows, ldz in elements, a multiple of 8). */
+int lpf_pair_attention_rows_zbf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
+                                  const void *Z_bf16, int64_t ldz, const float *q, int64_t ldq,
+                                  const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                  const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
+                                  const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
+                                  int64_t units_cap, float *out, int64_t ldo, void *stream);
+
+/* lpf_tail_chain_f32 behind lpf_pair_attention_rows_*: stage A is a plain read of the pair's finished row
+ * rows[p] = [post_att_norm(attention output) (D) | count features, zero padded to 4] (ldrows >= D + 4); what is left is
+ * the first layer of pairwise_lin, its LayerNorm + ReLU, the folded score head and the sigmoid
+ * (other_models.py:80-179, link_transformer.py:170-177).  sel_ctl as for lpf_tail_chain_merge_f32.  D in {32, 64, 128}. */
+int lpf_tail_chain_rows_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                            const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
+                            const float *r_e, int64_t ldre, const float *wC_packed, const float *bC, const float *w_dot,
+                            const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob, void *stream);
+/* ... with bf16 weights and v_mfma_f32_16x16x16_bf16 for the two GEMMs (as lpf_tail_chain_merge_bf16). */
+int lpf_tail_chain_rows_bf16(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                             const void *wB_packed_bf16, const float *bB, const float *lnB_g, const float *lnB_b,
+                             const float *r_e, int64_t ldre, const void *wC_packed_bf16, const float *bC,
+                             const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob,
+                             void *stream);
 
 /* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
  * logit or prob may be NULL. */

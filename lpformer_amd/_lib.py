@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "liblpformer_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "liblpformer_host.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_RELU = 1
 SELECT_ERR_NODE_RANGE, SELECT_ERR_ITEM_CAP, SELECT_ERR_ENTRY_CAP = 1, 2, 4
 
@@ -46,7 +46,7 @@ HIP_PROTOTYPES = {
     "lpf_select_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, i64, i32,
                        vp],
     "lpf_select3_plan": [i64, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp],
-    "lpf_select3_run": [i64, vp, vp, vp, i64, vp, vp, vp, f32, f32, f32, i32, vp, vp, i64, i32, vp],
+    "lpf_select3_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, f32, f32, f32, i32, vp, vp, i64, i32, vp],
     "lpf_select_export": [i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp],
@@ -55,6 +55,13 @@ HIP_PROTOTYPES = {
     "lpf_pair_attention_flip_f32": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_attention_flip_zbf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_attention_merge_f32": [i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
+    "lpf_pair_attention_rows_f32": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp,
+                                    i64, vp, i64, vp],
+    "lpf_pair_attention_rows_zbf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp,
+                                      i64, vp, i64, vp],
+    "lpf_pair_rows_piece_floats": [i32],
+    "lpf_tail_chain_rows_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lpf_tail_chain_rows_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lpf_tail_chain_merge_f32": [i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
                                  vp, vp, vp],
     "lpf_tail_chain_merge_bf16": [i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
@@ -89,7 +96,7 @@ HOST_PROTOTYPES = {
 _RESTYPE = {"lpf_strerror": C.c_char_p, "lpf_last_hip_error": C.c_char_p, "lpf_host_free": None,
             "lpf_ppr_push_workspace_bytes": C.c_int64, "lpf_select_plan_blocks": C.c_int64, "lpf_ppr_pack_workspace_bytes": C.c_int64,
             "lpf_gemm_tn_workspace_floats": C.c_int64, "lpf_layernorm_bwd_workspace_floats": C.c_int64,
-            "lpf_train_partial_blocks": C.c_int64}
+            "lpf_train_partial_blocks": C.c_int64, "lpf_pair_rows_piece_floats": C.c_int64}
 
 
 class LpfError(RuntimeError):

@@ -1,0 +1,576 @@
+// Pairwise PPR-positional attention, PAIR-MAJOR: one finished feature row per candidate pair.
+//
+// Reference: LinkAttention.message + PyG softmax + scatter-sum + post_att_norm (src/modules/layers.py:66-78,193-224)
+// with get_pos_encodings (src/models/link_transformer.py:182-211) folded in, evaluated through the activation pattern
+// of the PE hidden layer exactly as in pair_flip.hip (same tables, same per-entry arithmetic).
+//
+// What is different from pair_flip.hip is the ORDER the entries are walked in and what leaves the kernel.  There a
+// group of G = D/4 lanes walks a unit of 16 consecutive entries of ONE TYPE REGION and leaves online-softmax records (one
+// per (pair, type) segment inside the unit, boundary records for segments that cross units) which the dense tail reads
+// back and merges -- on the collab-like batch half of the pairs have ~22 selected entries, two thirds of the segments
+// cross a unit, a pair costs 1.7 records of D + 4 floats written and re-read, and the tail spent a third of its time
+// chasing and merging them before its first matrix instruction.  Here the entries are walked PAIR-MAJOR -- a pair's
+// common-neighbour, one-hop and >1-hop segments one after the other: the three segment pointers are prefix sums, so
+// C[p] = sum_t ptr_t[p] IS the pair-major position of pair p's first entry -- and what leaves the kernel is the pair's
+// finished row
+//     out[p] = [ post_att_norm( sum_e alpha_e k_e + bias ) | n_cn, n_1hop, (n_non1hop,) n_cn + n_1hop ],
+// D + c floats written once, read once: no merge and no LayerNorm left for the consumer.
+//
+// Work: a workgroup owns a contiguous range of pairs holding 1/gridDim.x of (entries + pairs) -- found by a 64-ary
+// search over the pointers -- and stages the range's pointers in LDS (PR_CHUNK pairs at a time).  The unit of work stays
+// what it is in pair_flip.hip, 16 consecutive entries -- now of the pair-major order --, handed out inside the
+// workgroup by a ticket in LDS: a pair of 500 entries is 32 units on 32 groups, a round is always full, no lane waits
+// for a longer neighbour.  A pair that lies inside one unit is finished in registers (online softmax -> bias ->
+// LayerNorm -> row).  A pair that crosses unit boundaries leaves one partial state per unit it touches in a scratch
+// buffer (slot 1 of the unit it starts in, slot 0 of every later one); after the workgroup's units are done -- one
+// barrier -- its groups merge those pieces in unit order and finish the rows.  The pieces are written and read by the
+// same CU microseconds apart: they never leave L2.  A pair's row does not depend on the batch around it except through
+// where the 16-entry grid cuts it (the same dependence pair_flip.hip has).
+#include <type_traits>
+
+#include "pe_common.h"
+
+namespace {
+
+constexpr uint32_t PR_PAIR_MASK = 0x7fffffffu;
+constexpr int PR_CHUNK = 512;    // pairs of the workgroup's range staged in LDS at a time
+
+struct RowsArgs {
+    int64_t bs;
+    const int32_t *type_ptr;   // [3][bs+1]
+    const int4 *entries;       // [3][ent_cap]
+    int64_t ent_cap;
+    const float *Z; uint32_t ldz;   // (ZB: bf16 rows, ldz in bf16 elements)
+    const float *q; uint32_t ldq;
+    const float *pe_tab;       // [3][D][4]   (ta, tc, td, beta) per hidden unit, times +1 (unit in S0) or -1
+    const float *pe_stat;      // [3][8]
+    const float *base;         // [3][4][D]   P0, Q0, R0, C0 = 2 B0 + bfold
+    const float *wfoldT;       // [3][D][D]   wfoldT[t][k][c] = Wfold_t[c][k]
+    const float *att;          // [D]
+    const float *att_bias, *ln_g, *ln_b;   // [D] each: LinkAttention.bias, post_att_norm
+    float *out; int64_t ldo;   // [bs][ldo]: D features, then n_counts count features
+    int32_t n_counts;
+    const int64_t *sel_ctl;    // selection control block: word 3 != 0 => the batch did not fit its workspace, rows = NaN
+    float *pieces;             // [units_cap][2][RSP]: partial states of the pairs that cross 16-entry units
+    int64_t units_cap;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float pr_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the G lanes of a group, the same bits in every lane (pair_flip.hip::fl_group_sum)
+template <int G>
+__device__ __forceinline__ float pr_group_sum(float v) {
+    v += pr_dpp<0xB1>(v);
+    v += pr_dpp<0x4E>(v);
+    if constexpr (G >= 8) v += pr_dpp<0x141>(v);
+    if constexpr (G >= 16) v += pr_dpp<0x140>(v);
+    if constexpr (G >= 32)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f));
+    if constexpr (G >= 64) {
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+        const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+        v = a + b;
+    }
+    return v;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (tuning builds, -DPR_STAMPS: wall-clock marks -- 100 MHz -- of lane 0 of every wavefront; tools/rows_stamps.py)
+#ifdef PR_STAMPS
+__device__ uint64_t *pr_stamp_buf = nullptr;
+#define PR_STAMP(k) do { if (lane == 0) st_t[k] = wall_clock64(); } while (0)
+#else
+#define PR_STAMP(k) do { } while (0)
+#endif
+
+// floats of one piece record: D accumulators, m, l, padded to whole 128-byte lines (no line is shared by two records:
+// neighbouring units may belong to different workgroups)
+constexpr int pr_piece_floats(int D) { return (D + 4 + 31) / 32 * 32; }
+
+// LDS carve-up, shared by the kernel and the launcher (float4 units unless noted)
+template <int G, int NTH, int WTL>
+struct PrLds {
+    static constexpr int D = 4 * G, NG = (NTH / 64) * (64 / G);
+    static constexpr int TAB = 0, BASE = TAB + 3 * D, VEC = BASE + 3 * D, CONST_ROW = VEC + 3 * G, STAT = CONST_ROW + G;
+    static constexpr int WT = STAT + 6;                      // (pe_stat: 3 x 8 floats)
+    static constexpr int REC = WT + WTL * D * G;             // int4 [NG][16]
+    static constexpr int SC = REC + NG * 16;                 // f32x2 [NG][16]  (NG * 8 float4)
+    static constexpr int META = SC + NG * 8;                 // int [NG][16]    (NG * 4 float4)
+    static constexpr int TP = META + NG * 4;                 // int [3][PR_CHUNK + 4]
+    static constexpr int CUM = TP + 3 * (PR_CHUNK / 4 + 1);  // int [PR_CHUNK + 4]: pair-major start of every pair, chunk-relative
+    static constexpr int LISTS = CUM + (PR_CHUNK / 4 + 1);   // int [2][PR_CHUNK]: empty pairs, pairs in several pieces
+    static constexpr int CTL = LISTS + 2 * (PR_CHUNK / 4);   // int [16]: counters, ticket, range
+    static constexpr int TOTAL = CTL + 4;
+    static constexpr size_t BYTES = (size_t)TOTAL * 16;
+};
+
+// ZB: the node table Z is stored in bf16 (the bf16 throughput mode)
+template <int G, int NTH, int WTL, bool ZB = false>
+__global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(const RowsArgs A) {
+    using ZT = typename std::conditional<ZB, uint2, float4>::type;
+    using L = PrLds<G, NTH, WTL>;
+    constexpr int D = 4 * G, EPW = 64 / G, NG = L::NG, T_LO = WTL == 1 ? 1 : 0, TPS = PR_CHUNK + 4, RSP = pr_piece_floats(D);
+    extern __shared__ __attribute__((aligned(16))) float4 pr_lds[];
+    float4 *const ltab = pr_lds + L::TAB;        // [4][3][G]: row j of hidden unit 4 lj + j, type t -> ((j * 3 + t) * G + lj)
+    float4 *const lbase = pr_lds + L::BASE;      // [3][4][G]
+    float4 *const lvec = pr_lds + L::VEC;        // [3][G]: att_bias, ln_g, ln_b by feature quad
+    float4 *const lconst = pr_lds + L::CONST_ROW;   // [G]: the row of a pair without entries
+    float *const lstat = reinterpret_cast<float *>(pr_lds + L::STAT);   // [3][8]
+    float4 *const lwt = pr_lds + L::WT;          // [WTL][D][G]
+    int4 *const lrec = reinterpret_cast<int4 *>(pr_lds + L::REC);
+    f32x2 *const lsc = reinterpret_cast<f32x2 *>(pr_lds + L::SC);
+    int *const lmeta = reinterpret_cast<int *>(pr_lds + L::META);
+    int *const ltp = reinterpret_cast<int *>(pr_lds + L::TP);
+    int *const lcum = reinterpret_cast<int *>(pr_lds + L::CUM);
+    int *const llist = reinterpret_cast<int *>(pr_lds + L::LISTS);
+    int *const lctl = reinterpret_cast<int *>(pr_lds + L::CTL);   // 0: n_empty 1: n_multi 2: unit ticket 4,5: P0 6,7: P1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane / G, lj = lane % G, off = 4 * lj;
+    const int gid = wave * EPW + grp;            // this group among the workgroup's NG
+#ifdef PR_STAMPS
+    uint64_t st_t[8] = {0};
+    int st_rounds = 0;
+    PR_STAMP(0);
+#endif
+    int64_t n[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        n[t] = A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs];
+        if (n[t] > A.ent_cap) n[t] = A.ent_cap;   // (overflow: flagged by the selection kernel, stay inside the region)
+        if (n[t] < 0) n[t] = 0;
+    }
+    const bool bad = A.sel_ctl && A.sel_ctl[3] != 0;
+    for (int i = tid; i < 3 * D; i += NTH) {
+        const int t = i / D, k = i % D;
+        ltab[((k & 3) * 3 + t) * G + (k >> 2)] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
+        lbase[i] = reinterpret_cast<const float4 *>(A.base)[i];
+    }
+    for (int i = tid; i < 3 * G; i += NTH) {
+        const float *src = i < G ? A.att_bias : (i < 2 * G ? A.ln_g : A.ln_b);
+        lvec[i] = *reinterpret_cast<const float4 *>(src + 4 * (i % G));
+    }
+    if (tid < 24) lstat[tid] = A.pe_stat[tid];
+    if constexpr (WTL > 0) {
+        const float4 *src = reinterpret_cast<const float4 *>(A.wfoldT) + (int64_t)T_LO * D * G;
+        for (int i = tid; i < WTL * D * G; i += NTH) lwt[i] = src[i];
+    }
+
+    // pair-major position of pair p's first entry (the pointers clamped into their regions)
+    auto cum_at = [&](int64_t p) __attribute__((always_inline)) {
+        int64_t c = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int64_t v = A.type_ptr[(int64_t)t * (A.bs + 1) + p];
+            c += v < n[t] ? (v < 0 ? 0 : v) : n[t];
+        }
+        return c;
+    };
+    // ---- the workgroup's pair range: first pair p with  p + C[p]  >= b * (entries + pairs) / gridDim.x  (64-ary search,
+    //      three dependent rounds for 32 k pairs; wavefront 0 looks for the lower end, wavefront 1 for the upper one,
+    //      the others fill the tables above meanwhile)
+    if (wave < 2) {
+        const int64_t total = n[0] + n[1] + n[2] + A.bs;
+        const int64_t b = (int64_t)blockIdx.x + wave;
+        int64_t lo = 0, hi = A.bs;   // answer in [lo, hi]
+        if (b >= (int64_t)gridDim.x) {
+            lo = A.bs;
+        } else if (b > 0) {
+            const int64_t target = (total * b) / (int64_t)gridDim.x;
+            while (hi - lo > 64) {
+                const int64_t step = (hi - lo + 63) / 64;
+                const int64_t idx = lo + (int64_t)lane * step;
+                const bool below = idx < hi && idx + cum_at(idx < hi ? idx : 0) < target;
+                const int c = __popcll(__ballot(below));   // (monotone: the first c probes are below the target)
+                if (c == 0) { hi = lo; break; }
+                const int64_t nlo = lo + (int64_t)(c - 1) * step + 1;
+                const int64_t nhi = lo + (int64_t)c * step;
+                lo = nlo;
+                hi = nhi < hi ? nhi : hi;
+            }
+            if (hi > lo) {
+                const int64_t idx = lo + lane;
+                const bool below = idx < hi && idx + cum_at(idx < hi ? idx : 0) < target;
+                lo += __popcll(__ballot(below));
+            }
+        }
+        if (lane == 0) { lctl[4 + 2 * wave] = (int)(lo & 0xffffffff); lctl[5 + 2 * wave] = (int)(lo >> 32); }
+    }
+    __syncthreads();
+    PR_STAMP(1);
+    const int64_t P0 = (int64_t)(uint32_t)lctl[4] | ((int64_t)lctl[5] << 32);
+    const int64_t P1 = (int64_t)(uint32_t)lctl[6] | ((int64_t)lctl[7] << 32);
+
+    // finished row of a pair from its (merged) softmax state: post_att_norm(o / (l + 1e-16) + bias)
+    auto finish_row = [&](f32x2 o01, f32x2 o23, float l) __attribute__((always_inline)) {
+        const float4 vb = lvec[lj], vg = lvec[G + lj], vbeta = lvec[2 * G + lj];   // (once per pair: not worth registers)
+        const float inv = 1.0f / (l + 1e-16f);
+        const float4 y = make_float4(o01.x * inv + vb.x, o01.y * inv + vb.y, o23.x * inv + vb.z, o23.y * inv + vb.w);
+        const float mean = pr_group_sum<G>((y.x + y.y) + (y.z + y.w)) * (1.0f / (float)D);
+        const float4 d = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
+        const float var = pr_group_sum<G>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / (float)D);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        float4 r = make_float4(d.x * rstd * vg.x + vbeta.x, d.y * rstd * vg.y + vbeta.y, d.z * rstd * vg.z + vbeta.z,
+                               d.w * rstd * vg.w + vbeta.w);
+        if (bad) r = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+        return r;
+    };
+    if (wave == 0 && grp == 0) lconst[lj] = finish_row(f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, 0.f);
+
+    const float4 at = *reinterpret_cast<const float4 *>(A.att + off);
+    const f32x2 at01 = {at.x, at.y}, at23 = {at.z, at.w};
+    int4 *const lr = lrec + gid * 16;
+    f32x2 *const ls = lsc + gid * 16;
+    int *const lm = lmeta + gid * 16;
+
+    auto z_row = [&](int node) __attribute__((always_inline)) {
+        if constexpr (ZB)
+            return *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(A.Z) +
+                                                    (uint64_t)(uint32_t)node * A.ldz + off);
+        else
+            return *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)node * A.ldz + off);
+    };
+    auto z_wide = [&](const ZT &z) __attribute__((always_inline)) {
+        if constexpr (ZB)
+            return make_float4(__uint_as_float(z.x << 16), __uint_as_float(z.x & 0xffff0000u),
+                               __uint_as_float(z.y << 16), __uint_as_float(z.y & 0xffff0000u));
+        else
+            return z;
+    };
+    auto q_row = [&](int pair) __attribute__((always_inline)) {
+        return *reinterpret_cast<const float4 *>(A.q + (uint64_t)(uint32_t)pair * A.ldq + off);
+    };
+
+    for (int64_t c0 = P0; c0 < P1; c0 += PR_CHUNK) {
+        const int cn = (int)(P1 - c0 < PR_CHUNK ? P1 - c0 : PR_CHUNK);
+        __syncthreads();   // the previous chunk's lists and pointers are no longer needed
+        for (int i = tid; i < 3 * (cn + 1); i += NTH) {
+            const int t = i / (cn + 1), k = i % (cn + 1);
+            int64_t v = A.type_ptr[(int64_t)t * (A.bs + 1) + c0 + k];
+            v = v < n[t] ? (v < 0 ? 0 : v) : n[t];
+            ltp[t * TPS + k] = (int)v;
+        }
+        if (tid < 4) lctl[tid] = 0;
+        __syncthreads();
+        // pair-major base of the chunk, then every pair's start relative to it (fits 31 bits: ent_cap does)
+        const int64_t v0 = (int64_t)ltp[0] + ltp[TPS] + ltp[2 * TPS];
+        const int64_t v1 = (int64_t)ltp[cn] + ltp[TPS + cn] + ltp[2 * TPS + cn];
+        const int64_t u_first = v0 >> 4;
+        const int n_units = v1 > v0 ? (int)(((v1 - 1) >> 4) - u_first + 1) : 0;
+        for (int k = tid; k <= cn; k += NTH)
+            lcum[k] = (int)(((int64_t)ltp[k] + ltp[TPS + k] + ltp[2 * TPS + k]) - v0);
+        __syncthreads();
+        // ---- sort the chunk's pairs (empty / in several pieces); the count features go out at once
+        for (int k = tid; k < cn; k += NTH) {
+            const int n0 = ltp[k + 1] - ltp[k], n1 = ltp[TPS + k + 1] - ltp[TPS + k], n2 = ltp[2 * TPS + k + 1] - ltp[2 * TPS + k];
+            const int np = n0 + n1 + n2;
+            if (np == 0) {
+                llist[atomicAdd(&lctl[0], 1)] = k;
+            } else if (((v0 + lcum[k]) >> 4) != ((v0 + lcum[k + 1] - 1) >> 4)) {
+                llist[PR_CHUNK + atomicAdd(&lctl[1], 1)] = k;
+            }
+            if (A.n_counts > 0) {
+                float *o = A.out + (c0 + k) * A.ldo + D;
+                const float f0 = (float)n0, f1 = (float)n1, f2 = (float)n2;
+                if (A.n_counts == 4) { o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f0 + f1; }
+                else if (A.n_counts == 3) { o[0] = f0; o[1] = f1; o[2] = f0 + f1; }
+                else { o[0] = f0; }
+            }
+        }
+        __syncthreads();
+        PR_STAMP(2);
+        const int n_empty = lctl[0], n_multi = lctl[1];
+        // ---- pairs without entries: the constant row
+        {
+            const float4 cr = lconst[lj];
+            for (int k = gid; k < n_empty; k += NG)
+                *reinterpret_cast<float4 *>(A.out + (c0 + llist[k]) * A.ldo + off) = cr;
+        }
+        PR_STAMP(3);
+        // ---- the chunk's units: 16 consecutive entries of the pair-major order each, EPW of them per wavefront and
+        //      ticket.  Lane i < 16 of a group finds entry i of its unit (binary search in the chunk's starts), fetches
+        //      its record and computes its two 1 / std; then the walk of pair_flip.hip, four entries per batch with the Z
+        //      rows requested a batch ahead.  meta: bits 0-1 type, 2 first entry of a piece, 3 last one, 4 the piece is
+        //      not the whole pair, 5 head piece (the pair started in an earlier unit), 6 the slot holds an entry.
+        while (true) {
+            int tk = 0;
+            if (lane == 0) tk = atomicAdd(&lctl[2], 1);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+            if (tk * EPW >= n_units) break;
+            const int ul = tk * EPW + grp;                     // unit of this group, chunk-relative
+            const int64_t x0 = (u_first + ul) << 4;            // its first pair-major position (global)
+            for (int i = lj; i < 16; i += G) {
+                int4 rec = make_int4(0, 0, 0, 0);
+                int meta = 0;
+                f32x2 sc = {0.f, 0.f};
+                const int64_t x = x0 + i;
+                if (ul < n_units && x >= v0 && x < v1) {
+                    const int xr = (int)(x - v0);
+                    int lo = 0, hi = cn;                       // largest k with lcum[k] <= xr (skips the empty pairs)
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (lcum[mid] <= xr) lo = mid; else hi = mid;
+                    }
+                    const int k = lo, ps = lcum[k], pe = lcum[k + 1], j = xr - ps;
+                    const int *tp = ltp + k;
+                    const int lo0 = tp[0], n0 = tp[1] - lo0, lo1 = tp[TPS], n1 = tp[TPS + 1] - lo1, lo2 = tp[2 * TPS];
+                    const int t = (j >= n0) + (j >= n0 + n1);
+                    const int64_t idx = t == 0 ? lo0 + j : (t == 1 ? lo1 + (j - n0) : lo2 + (j - n0 - n1));
+                    rec = A.entries[(int64_t)t * A.ent_cap + idx];
+                    const int64_t ustart = x0 - v0, uend = ustart + 16;        // the unit in chunk-relative positions
+                    const bool head = ps < ustart, more = pe > uend;
+                    meta = t | ((j == 0 || i == 0) ? 4 : 0) | ((xr == pe - 1 || i == 15) ? 8 : 0) |
+                           ((head || more) ? 16 : 0) | (head ? 32 : 0) | 64;
+                    const float *st = lstat + 8 * t;
+                    const float pa = __int_as_float(rec.z), pb = __int_as_float(rec.w);
+                    const float vab = st[0] * pa * pa + st[1] * pb * pb + st[2] + 2.0f * (st[3] * pa * pb + st[4] * pa + st[5] * pb);
+                    const float vba = st[0] * pb * pb + st[1] * pa * pa + st[2] + 2.0f * (st[3] * pa * pb + st[4] * pb + st[5] * pa);
+                    sc = f32x2{__builtin_amdgcn_rsqf(fmaxf(vab, 0.0f) + 1e-5f), __builtin_amdgcn_rsqf(fmaxf(vba, 0.0f) + 1e-5f)};
+                }
+                lr[i] = rec;
+                lm[i] = meta;
+                ls[i] = sc;
+            }
+            int lro = 0;                 // (opaque zero: the reads below must stay behind the stores above)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(lro) :: "memory");
+            ZT za[4], zb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) za[u] = z_row(lr[lro + u].y);
+            float4 qc = q_row((int)((uint32_t)lr[lro].x & PR_PAIR_MASK));
+            float *const piece_u = A.pieces + (u_first + ul) * 2 * RSP;
+            float m = -INFINITY, l = 0.f;
+            f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
+
+            auto entry = [&](const int i, const ZT zraw) __attribute__((always_inline)) {
+                const float4 zc = z_wide(zraw);
+                const int4 rc = lr[lro + i];
+                const f32x2 r12 = ls[lro + i];
+                const int meta = lm[lro + i];
+                const int pair_n = (int)((uint32_t)lr[lro + (i < 15 ? i + 1 : 15)].x & PR_PAIR_MASK);
+                const float4 qn = q_row(pair_n);
+                const bool on = meta & 64;
+                const int t = meta & 3;
+                const float pa = __int_as_float(rc.z), pb = __int_as_float(rc.w);
+                const f32x2 pab = {pa, pb}, pba = {pb, pa};
+                const int pair_i = (int)((uint32_t)rc.x & PR_PAIR_MASK);
+                const float4 *tabl = ltab + t * G + lj, *basel = lbase + t * D + lj;
+                f32x2 zz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 tj = tabl[3 * G * j];
+                    zz[j] = r12 * (tj.x * pab + (tj.y * pba + tj.z)) + tj.w;
+                }
+                const float zmin = fminf(fminf(fminf(zz[0].x, zz[0].y), fminf(zz[1].x, zz[1].y)),
+                                         fminf(fminf(zz[2].x, zz[2].y), fminf(zz[3].x, zz[3].y)));
+                const bool fl = zmin < 0.f && on;
+                const f32x2 cab = r12.x * pab + r12.y * pba;
+                const float cr = r12.x + r12.y;
+                const float4 P0v = basel[0], Q0v = basel[G], R0v = basel[2 * G], C0v = basel[3 * G];
+                f32x2 k01 = f32x2{zc.x, zc.y} + (f32x2{P0v.x, P0v.y} * cab.x +
+                                                 (f32x2{Q0v.x, Q0v.y} * cab.y + (f32x2{R0v.x, R0v.y} * cr + f32x2{C0v.x, C0v.y})));
+                f32x2 k23 = f32x2{zc.z, zc.w} + (f32x2{P0v.z, P0v.w} * cab.x +
+                                                 (f32x2{Q0v.z, Q0v.w} * cab.y + (f32x2{R0v.z, R0v.w} * cr + f32x2{C0v.z, C0v.w})));
+                if (__ballot(fl)) {
+                    // some unit of some group left the pattern of (0, 0): every lane of that group owes Wfold[:, k] |y_k|
+                    // (pair_flip.hip: one pass over the eight (order, unit-of-the-lane) slots, flipped lanes one at a time)
+                    const bool wt_lds = t >= T_LO && t < T_LO + WTL;
+                    const float4 *lw = lwt + (wt_lds ? (t - T_LO) * D * G : 0) + lj;
+                    const float *wT = A.wfoldT + (int64_t)t * D * D + off;
+                    const bool all_lds = WTL == 3 || __all(wt_lds || !fl);
+                    f32x2 wp01 = {0.f, 0.f}, wp23 = {0.f, 0.f};
+                    float vp = 0.f;
+#pragma unroll
+                    for (int oj = 0; oj < 8; ++oj) {
+                        const float zv = (oj & 4) ? zz[oj & 3].y : zz[oj & 3].x;
+                        uint64_t bm = __ballot(zv < 0.f && on);
+                        while (bm) {
+                            const int b = __builtin_ctzll(bm);
+                            bm &= bm - 1;
+                            const float val = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zv), b));
+                            const bool mine = b / G == grp;
+                            const int kk = 4 * (b % G) + (oj & 3);
+                            float4 w = WTL > 0 ? lw[kk * G] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (!all_lds) {
+                                float4 wg = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (mine && !wt_lds) wg = *reinterpret_cast<const float4 *>(wT + (int64_t)kk * D);
+                                w.x = wt_lds ? w.x : wg.x; w.y = wt_lds ? w.y : wg.y;
+                                w.z = wt_lds ? w.z : wg.z; w.w = wt_lds ? w.w : wg.w;
+                            }
+                            k01 += wp01 * vp;
+                            k23 += wp23 * vp;
+                            wp01 = f32x2{w.x, w.y};
+                            wp23 = f32x2{w.z, w.w};
+                            vp = mine ? val : 0.f;
+                        }
+                    }
+                    k01 += wp01 * vp;
+                    k23 += wp23 * vp;
+                }
+                const f32x2 x01 = k01 * f32x2{qc.x, qc.y}, x23 = k23 * f32x2{qc.z, qc.w};
+                const f32x2 y01 = x01 * 0.2f, y23 = x23 * 0.2f;
+                const f32x2 l01 = {fmaxf(x01.x, y01.x), fmaxf(x01.y, y01.y)}, l23 = {fmaxf(x23.x, y23.x), fmaxf(x23.y, y23.y)};
+                const f32x2 sp = l01 * at01 + l23 * at23;
+                const float s = pr_group_sum<G>(sp.x + sp.y);
+                if (on) {
+                    if (meta & 4) {          // first entry of a piece: fresh state
+                        m = -INFINITY; l = 0.f;
+                        o01 = f32x2{0.f, 0.f};
+                        o23 = f32x2{0.f, 0.f};
+                    }
+                    const float d = s - m;
+                    const float e = __expf(-fabsf(d));
+                    const bool up = d > 0.f;
+                    const float sca = up ? e : 1.f, w = up ? 1.f : e;
+                    l = fmaf(l, sca, w);
+                    o01 = o01 * sca + k01 * w;
+                    o23 = o23 * sca + k23 * w;
+                    m = fmaxf(m, s);
+                    if (meta & 8) {          // last entry of the piece
+                        if (meta & 16) {     // ... of a pair in several pieces: its state waits for the merge
+                            float *dst = piece_u + ((meta & 32) ? 0 : RSP);
+                            *reinterpret_cast<float4 *>(dst + off) = make_float4(o01.x, o01.y, o23.x, o23.y);
+                            if (lj == 0) *reinterpret_cast<float2 *>(dst + D) = make_float2(m, l);
+                        } else {
+                            *reinterpret_cast<float4 *>(A.out + (int64_t)pair_i * A.ldo + off) = finish_row(o01, o23, l);
+                        }
+                    }
+                }
+                qc = qn;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto batch = [&](const int qt, const ZT (&zc4)[4], ZT (&zn4)[4]) __attribute__((always_inline)) {
+                const int nb = qt < 3 ? 4 * qt + 4 : 12;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) zn4[u] = z_row(lr[lro + nb + u].y);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) entry(4 * qt + u, zc4[u]);
+            };
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                batch(2 * h, za, zb);
+                batch(2 * h + 1, zb, za);
+            }
+#ifdef PR_STAMPS
+            ++st_rounds;
+#endif
+        }
+        PR_STAMP(4);
+        // ---- pairs in several pieces: merged in unit order (the pieces were written by this workgroup: one barrier)
+        __syncthreads();
+        for (int mk = gid; mk < n_multi; mk += NG) {
+            const int k = llist[PR_CHUNK + mk];
+            const int64_t ua = (v0 + lcum[k]) >> 4, ub = (v0 + lcum[k + 1] - 1) >> 4;
+            float mx = -INFINITY, den = 0.f;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t u = ua; u <= ub; u += 4) {   // (four pieces requested together: a hub pair has dozens)
+                float2 h[4];
+                float4 b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t uu = u + i <= ub ? u + i : ub;
+                    const float *rp = A.pieces + (uu * 2 + (uu == ua ? 1 : 0)) * RSP;
+                    h[i] = *reinterpret_cast<const float2 *>(rp + D);
+                    b[i] = *reinterpret_cast<const float4 *>(rp + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (u + i > ub) break;
+                    const float mn = fmaxf(mx, h[i].x);
+                    const float sa = __expf(mx - mn), sb = __expf(h[i].x - mn);
+                    den = fmaf(den, sa, h[i].y * sb);
+                    v.x = v.x * sa + b[i].x * sb; v.y = v.y * sa + b[i].y * sb;
+                    v.z = v.z * sa + b[i].z * sb; v.w = v.w * sa + b[i].w * sb;
+                    mx = mn;
+                }
+            }
+            *reinterpret_cast<float4 *>(A.out + (c0 + k) * A.ldo + off) = finish_row(f32x2{v.x, v.y}, f32x2{v.z, v.w}, den);
+        }
+        PR_STAMP(5);
+    }
+#ifdef PR_STAMPS
+    if (lane == 0 && pr_stamp_buf) {
+        uint64_t *o = pr_stamp_buf + ((int64_t)blockIdx.x * (NTH / 64) + wave) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = st_t[k];
+        o[6] = (uint64_t)st_rounds;
+        o[7] = (uint64_t)(P1 - P0) | ((uint64_t)lctl[1] << 32);
+    }
+#endif
+}
+
+template <bool ZB>
+int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap, const void *Z,
+                int64_t ldz, const float *q, int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
+                const float *base, const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
+                const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
+                int64_t ldo, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && type_ptr && entries && ent_cap > 0 && ent_cap < (1ll << 29) && Z && q &&
+                pe_tab_signed && pe_stat && base && wfold_t && att && att_bias && ln_g && ln_b && out && pieces &&
+                units_cap >= (3 * ent_cap + 15) / 16 + 1 && lpf_aligned16(pieces));
+    LPF_REQUIRE((n_counts == 0 || n_counts == 1 || n_counts == 3 || n_counts == 4) && ldo >= D + n_counts && (ldo & 3) == 0);
+    LPF_REQUIRE(ldz >= D && ldq >= D && ldz < (1ll << 31) && ldq < (1ll << 31) && (ldz & (ZB ? 7 : 3)) == 0 &&
+                (ldq & 3) == 0 && lpf_aligned16(entries) && lpf_aligned16(Z) && lpf_aligned16(q) &&
+                lpf_aligned16(pe_tab_signed) && lpf_aligned16(base) && lpf_aligned16(wfold_t) && lpf_aligned16(att) &&
+                lpf_aligned16(att_bias) && lpf_aligned16(ln_g) && lpf_aligned16(ln_b) && lpf_aligned16(out));
+    const RowsArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), (uint32_t)ldz,
+                     q, (uint32_t)ldq, pe_tab_signed, pe_stat, base, wfold_t, att, att_bias, ln_g, ln_b, out, ldo,
+                     n_counts, sel_ctl, pieces, units_cap};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n_cu = lpf_cu_count();
+    if (n_cu == 0) return LPF_ERR_NO_DEVICE;
+#define LPF_ROWS_GO(GG, NTH, WTL, PER_CU)                                                           \
+    do {                                                                                            \
+        auto kern = pair_rows_kernel<GG, NTH, WTL, ZB>;                                             \
+        constexpr size_t lds = PrLds<GG, NTH, WTL>::BYTES;                                          \
+        LPF_SET_MAX_LDS(kern, lds);                                                                 \
+        int64_t groups = (int64_t)n_cu * PER_CU;                                                    \
+        const int64_t most = (bs + 15) / 16;   /* (a workgroup per 16 pairs at the very least) */   \
+        if (groups > most) groups = most;                                                           \
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(NTH), lds, s, a);                     \
+    } while (0)
+    switch (D) {
+        case 32: LPF_ROWS_GO(8, 512, 3, 2); break;
+        case 64: LPF_ROWS_GO(16, 512, 3, 2); break;
+        case 128: LPF_ROWS_GO(32, 1024, 1, 1); break;
+        case 256: LPF_ROWS_GO(64, 256, 0, 3); break;
+        default: return LPF_ERR_UNSUPPORTED;
+    }
+#undef LPF_ROWS_GO
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+}  // namespace
+
+extern "C" int lpf_pair_attention_rows_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                           int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
+                                           const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                           const float *wfold_t, const float *att, const float *att_bias,
+                                           const float *ln_g, const float *ln_b, int32_t n_counts,
+                                           const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
+                                           int64_t ldo, void *stream) {
+    return rows_launch<false>(D, bs, type_ptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t, att,
+                              att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream);
+}
+
+extern "C" int lpf_pair_attention_rows_zbf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                             int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q, int64_t ldq,
+                                             const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                             const float *wfold_t, const float *att, const float *att_bias,
+                                             const float *ln_g, const float *ln_b, int32_t n_counts,
+                                             const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
+                                             int64_t ldo, void *stream) {
+    return rows_launch<true>(D, bs, type_ptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t,
+                             att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream);
+}
+
+#ifdef PR_STAMPS
+extern "C" int lpf_pair_rows_set_stamps(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(pr_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? LPF_OK : LPF_ERR_LAUNCH;
+}
+#endif
+
+/* floats of one piece record of lpf_pair_attention_rows_* (D accumulators, m, l, padded to whole 128-byte lines) */
+extern "C" int64_t lpf_pair_rows_piece_floats(int32_t D) { return pr_piece_floats(D); }

@@ -50,8 +50,10 @@ constexpr uint32_t S3_FROM_B = 0x80000000u;
 constexpr uint32_t S3_HASH_MUL = 2654435761u;
 constexpr int S3_BUCKET = 8;
 constexpr int S3_DESC_AHEAD = S3_THREADS / 8;        // descriptors copied before the window is known (one int4 per thread)
-// absence filter in front of a U row (lpformer_amd/graph.py BLOOM_*): 2 * buckets words, two bits of one word per key
-constexpr uint32_t S3_BLOOM_MUL1 = 0x85EBCA6Bu, S3_BLOOM_MUL2 = 0xC2B2AE35u;
+// mini filter of a node's union row (lpformer_amd/graph.py mini_filters): 32 words, two bits of one word per key
+constexpr uint32_t S3_BLOOM_MUL1 = 0x85EBCA6Bu, S3_BLOOM_MUL2 = 0xC2B2AE35u, S3_MINI_SALT = 0x9E3779B9u;
+constexpr int S3_MINI_WORDS = 32;
+constexpr int S3_FLT_LOADS = (2 * (LPF_SELECT_ITEM / 16 + 2) * (S3_MINI_WORDS / 4) + 255) / 256;   // int4 reads per thread
 
 // walk kinds
 constexpr int K_FULL = 0, K_A1 = 1, K_PX = 2, K_T0 = 3;
@@ -212,8 +214,8 @@ struct RunArgs3 {
     int64_t item_cap;
     int64_t *ctl;
     uint64_t *run_lb;   // [3][item_cap]
-    const int2 *u_cv;   // the hashed union index: per row its absence filter, then buckets of 8 {node, value bits |
-                        // adjacent << 31} (a Walk3's u0 points at the first bucket)
+    const int2 *u_cv;   // the hashed union index: buckets of 8 {node, value bits | adjacent << 31}
+    const uint32_t *mini;   // [n_nodes][32]: the union rows' mini filters
     float th_cn, th_1, th_n;
     int32_t mode_cn;
     int32_t *type_ptr;  // [3][bs+1]
@@ -236,8 +238,19 @@ struct RunLds3 {
     int64_t p_item, p_pf;
     int32_t p_run[3], p_np, p_last, p_live;
     int16_t ps[S3_PAIRS][4];      // {rank of the pair's first slot per type, pair starts in the item}
+    uint4 flt[S3_PAIRS][2][S3_MINI_WORDS / 4];   // mini filters of the window pairs' endpoints (a, b)
 };
-static_assert(sizeof(RunLds3) <= 32 * 1024, "four or five workgroups per CU");
+static_assert(sizeof(RunLds3) <= 48 * 1024, "three workgroups per CU");
+
+// Workgroup barrier that orders LDS ONLY.  __syncthreads() is a workgroup-scope fence + barrier, and the fence makes the
+// compiler drain the vector-memory counter -- loads included -- in front of every barrier: in the run kernel that turned
+// each of the item loop's thirteen barriers into a wait for whatever global reads were in flight (in-kernel stamps: ~2 us
+// per dependent round trip, seven of them per item).  Nothing global is handed from one wavefront of a workgroup to
+// another here -- what leaves a workgroup for others goes through agent-scope atomics --, so the barriers only have to
+// order LDS, and the loads requested ahead (next item's ticket, window, descriptors) stay in flight across them.
+__device__ __forceinline__ void s3_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // Entries of the parked item from L.pk to their final place, the segment starts of the pairs that begin in it and,
 // from the last item, the totals.  L.base holds the item's place per type.
@@ -248,7 +261,11 @@ __device__ __forceinline__ void s3_write_out(const RunArgs3 &A, RunLds3 &L, int6
     for (int g = tid; g < n; g += S3_THREADS) {
         const int t = g < r0 ? 0 : (g < r0 + r1 ? 1 : 2);
         const int64_t dst = t == 0 ? b0 + g : (t == 1 ? b1 + (g - r0) : b2 + (g - r0 - r1));
+#ifdef S3_ABL_NOWRITE
+        if (dst < 0) {
+#else
         if (dst < A.ent_cap) {
+#endif
             A.entries[(int64_t)t * A.ent_cap + dst] = L.pk[g];
         } else {
             atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + 3), (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
@@ -272,19 +289,33 @@ __device__ __forceinline__ void s3_write_out(const RunArgs3 &A, RunLds3 &L, int6
 // Write-out of the parked item, if there is one (whole workgroup; barriers at both ends).
 __device__ __forceinline__ void s3_finish_parked(const RunArgs3 &A, RunLds3 &L, uint32_t epoch, int64_t bs, int lane,
                                                  int wave, int tid) {
-    __syncthreads();
+    s3_lds_barrier();
     if (L.p_live) {
         if (wave < 3) {
+#ifdef S3_ABL_NOLB
+            const int64_t base = L.p_item * 300;
+#else
             const int64_t base = (int64_t)lb_lookback(A.run_lb + (int64_t)wave * A.item_cap, L.p_item, epoch,
                                                       (uint64_t)L.p_run[wave], lane);
+#endif
             if (lane == 0) L.base[wave] = base;
         }
-        __syncthreads();
+        s3_lds_barrier();
         s3_write_out(A, L, bs, tid);
     }
-    __syncthreads();
+    s3_lds_barrier();
 }
 
+// (tuning builds, -DS3_STAMPS: where does an item's time go?  Thread 0 of every workgroup accumulates the wall-clock
+//  ticks -- 100 MHz -- between the marks below and leaves them, with its item count, in a debug buffer.)
+#ifdef S3_STAMPS
+__device__ uint64_t *s3_stamp_buf = nullptr;
+#define S3_STAMP(k) do { if (tid == 0) { const uint64_t n__ = wall_clock64(); st_acc[k] += n__ - st_last; st_last = n__; } } while (0)
+#define S3_STAMP_WAIT(k) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); S3_STAMP(k); } while (0)
+#else
+#define S3_STAMP(k) do { } while (0)
+#define S3_STAMP_WAIT(k) do { } while (0)
+#endif
 #ifndef S3_MIN_WAVES      // (tuning) resident wavefronts per SIMD the register budget allows: workgroups per CU
 #define S3_MIN_WAVES 2
 #endif
@@ -304,37 +335,62 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
     // the item being typed): at the top of the loop both are known and the window and the descriptors are requested
     // at once -- ticket -> item_pair -> offsets -> descriptors used to be four dependent round trips per item.
     const bool drawer = tid == S3_THREADS - 1;
+#ifdef S3_STAMPS
+    uint64_t st_acc[16] = {0}, st_last = wall_clock64(), st_t0 = st_last;
+#endif
     if (tid == 0) {
         L.p_live = 0;
         const int64_t t = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 2), 1ull);
         L.nx_ticket = t;
         L.nx_pf = t < n_items ? A.item_pair[t] : 0;
     }
+    if (tid < 2 * S3_GROUPS) L.bits[tid] = 0u;
+    s3_lds_barrier();
+    // An item's window (slot offsets of its pairs) and its first S3_DESC_AHEAD descriptors (one int4 per thread; an item
+    // of 1,024 slots rarely holds more pairs) are REQUESTED as soon as the item is known -- for the first item here, for
+    // every other one behind the typing of the item before it -- and consumed at the top of the loop: they travel while
+    // the previous item is ranked, looked back and parked.
+    struct Req {
+        int64_t it, pf, c0, v;
+        int n_here, n4a;
+        int4 dreg;
+    };
+    auto request = [&]() __attribute__((always_inline)) {
+        Req q;
+        const int64_t t = L.nx_ticket, p = L.nx_pf;
+        q.it = ((int64_t)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(t & 0xffffffff));
+        q.pf = ((int64_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(p & 0xffffffff));
+        q.c0 = q.it * S3_ITEM;
+        q.n_here = (int)((total - q.c0) < S3_ITEM ? (total - q.c0) : S3_ITEM);
+        const int64_t avail = bs - q.pf;
+        q.n4a = (int)(avail < S3_DESC_AHEAD ? avail : S3_DESC_AHEAD) * 8;
+        q.dreg = make_int4(0, 0, 0, 0);
+        q.v = q.n_here;
+        if (q.it < n_items) {
+            if (tid < q.n4a) q.dreg = reinterpret_cast<const int4 *>(A.desc + q.pf)[tid];
+            if (tid <= S3_PAIRS && q.pf + tid <= bs) q.v = A.offs[q.pf + tid] - q.c0;
+        }
+        return q;
+    };
+    Req cur = request();
 
     while (true) {
-        __syncthreads();  // the previous item's window is no longer needed; nx_* are the current item's
-        const int64_t it = L.nx_ticket;
-        const int64_t pf = L.nx_pf;
-        if (tid < 2 * S3_GROUPS) L.bits[tid] = 0u;
+        const int64_t it = cur.it, pf = cur.pf, c0 = cur.c0;
+        const int n_here = cur.n_here, n4a = cur.n4a;
+        const int4 dreg = cur.dreg;
+        int64_t v = cur.v;
+        s3_lds_barrier();  // the previous item's window is no longer needed (and its bit map is zero again)
+        S3_STAMP(1);    // top barrier (waits for the slowest wavefront of the previous item)
         if (it >= n_items) break;
         int64_t nx_t = 0;
         if (drawer) nx_t = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + 2), 1ull);
-        const int64_t c0 = it * S3_ITEM;
-        const int n_here = (int)((total - c0) < S3_ITEM ? (total - c0) : S3_ITEM);
-        // the first S3_DESC_AHEAD descriptors of the window (one int4 per thread), requested before the window is
-        // known -- an item of 1,024 slots rarely holds more pairs than that --, and the window itself: both in flight
-        // together, consumed behind the barrier
-        const int64_t avail = bs - pf;
-        const int n4a = (int)(avail < S3_DESC_AHEAD ? avail : S3_DESC_AHEAD) * 8;
-        int4 dreg = make_int4(0, 0, 0, 0);
-        if (tid < n4a) dreg = reinterpret_cast<const int4 *>(A.desc + pf)[tid];
-        int64_t v = n_here;
-        if (tid <= S3_PAIRS && pf + tid <= bs) v = A.offs[pf + tid] - c0;
 
         // ---- pair window: loc[i] = offs[pf + i] - c0, pairs past the item read n_here; a pair other than the first
         //      raises the bit of the slot it starts in (every pair owns >= S3_MIN_SLOTS slots: at most S3_PAIRS pairs,
         //      no two in one slot)
-        __syncthreads();  // (bits are zero)
+        S3_STAMP(2);    // (the window / descriptor requests were made an item ago)
         if (tid < n4a) reinterpret_cast<int4 *>(L.dsc)[tid] = dreg;
         if (tid < 128) {
             if (v > n_here) v = n_here;
@@ -344,9 +400,10 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
             const int cntp = __popcll(__ballot(in));
             if (lane == 0) L.pre[wave] = cntp;       // (scratch: two partial counts)
         }
-        __syncthreads();
+        s3_lds_barrier();
         const int np = L.pre[0] + L.pre[1];  // pairs with at least one slot in this item (>= 1)
-        __syncthreads();
+        s3_lds_barrier();
+        S3_STAMP(3);    // window processed
         if (tid < S3_GROUPS) {               // exclusive popcount scan over the 64-slot groups
             int s = 0;
             for (int g = 0; g < tid; ++g) s += __popc(L.bits[2 * g]) + __popc(L.bits[2 * g + 1]);
@@ -361,7 +418,8 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
         // the next item's first pair: requested now, in flight beside this item's walked entries
         int64_t nx_p = 0;
         if (drawer && nx_t < n_items) nx_p = A.item_pair[nx_t];
-        __syncthreads();
+        s3_lds_barrier();
+        S3_STAMP(4);    // rest of the descriptors + barrier
 
         // ---- typing: one slot per thread and round; everything a kept slot needs later stays in registers.  The rounds
         //      are taken together, phase by phase, so that their memory round trips overlap: first every round's walked
@@ -373,6 +431,26 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
         int64_t u0r[S3_ROUNDS];
         int2 cvr[S3_ROUNDS];
         bool act[S3_ROUNDS];
+        // The mini filters of the window pairs' endpoints (one 128-byte line per node, eight lanes each) are requested
+        // first and land in LDS while the walked entries travel: "is x in the other endpoint's union row AT ALL?" is
+        // then answered from LDS for most candidates, and a candidate that is not there needs no bucket -- "not found"
+        // is what the bucket would have said.  (Random reads are what bounds this kernel: the chip retires ~54 G
+        // lane-reads of distinct lines per second whatever is in flight, tools/probe/random_read.hip.)
+        uint4 fr[S3_FLT_LOADS];
+#pragma unroll
+        for (int f = 0; f < S3_FLT_LOADS; ++f) {
+            const int i = f * S3_THREADS + tid;                    // (pair w, endpoint e, 16-byte piece q)
+            const int w = i / (2 * (S3_MINI_WORDS / 4));
+            fr[f] = make_uint4(0u, 0u, 0u, 0u);
+#ifdef S3_ABL_NOFLT
+            if (false) {
+#else
+            if (w < np) {
+#endif
+                const int node = (i & (S3_MINI_WORDS / 4)) ? L.dsc[w].b : L.dsc[w].a;
+                fr[f] = reinterpret_cast<const uint4 *>(A.mini + (int64_t)node * S3_MINI_WORDS)[i & (S3_MINI_WORDS / 4 - 1)];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < S3_ROUNDS; ++r) {
             const int g = S3_WAVES * r + wave;          // the wavefront's 64-slot group
@@ -390,40 +468,44 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
                 if (i < d.total) {
                     const int k = (i >= d.w[1].start) + (i >= d.w[2].start);
                     const Walk3 wk = d.w[k];
+#ifdef S3_ABL_NOWALK
+                    cvr[r] = make_int2(i, 0x3c000000);
+#else
                     cvr[r] = wk.src[i - wk.start];
+#endif
                     kindr[r] = wk.kind; unbr[r] = wk.unb; u0r[r] = wk.u0;
                     act[r] = true;
                 }
             }
         }
-        // is x in the other endpoint's union row AT ALL?  One 4-byte word of the row's absence filter answers "no" for
-        // most candidates (collab-like: 3 of 4), and a candidate that is not there needs no bucket: "not found" is what
-        // the bucket would have said.  The filter words of a row are 1/8 of its buckets and the candidates of a pair
-        // all ask the same row, so these reads mostly hit in L2.
-        uint32_t bw[S3_ROUNDS], bh[S3_ROUNDS];
 #pragma unroll
-        for (int r = 0; r < S3_ROUNDS; ++r) {
-            const bool look = act[r] && unbr[r] > 0;
-            bh[r] = s3_bloom_hash((uint32_t)cvr[r].x);
-            const uint32_t nb = (uint32_t)unbr[r];
-            const uint32_t *flt = reinterpret_cast<const uint32_t *>(A.u_cv + (look ? u0r[r] - (int64_t)((nb + 7u) & ~7u) : 0));
-            bw[r] = look ? flt[__umulhi(bh[r], 2u * nb)] : 0u;
+        for (int f = 0; f < S3_FLT_LOADS; ++f) {
+            const int i = f * S3_THREADS + tid;
+            if (i < np * 2 * (S3_MINI_WORDS / 4)) (&L.flt[0][0][0])[i] = fr[f];
         }
-        if (drawer) { L.nx_ticket = nx_t; L.nx_pf = nx_p; }   // (read at the top of the next iteration, behind barriers)
+        if (drawer) { L.nx_ticket = nx_t; L.nx_pf = nx_p; }   // (read behind the typing barrier below)
+        s3_lds_barrier();
+        S3_STAMP_WAIT(5);   // walked entries and mini filters arrived
         int4 bv[S3_ROUNDS][S3_BUCKET / 2];
 #pragma unroll
         for (int r = 0; r < S3_ROUNDS; ++r) {
-            // what is x to the other endpoint?  one bucket of its hashed union row
-#ifdef S3_NO_BLOOM   // (tuning: every candidate fetches its bucket, as before the filter)
+            // what is x to the other endpoint?  one bucket of its hashed union row -- if the endpoint's mini filter lets
+            // x through (the looked-up endpoint is b when the walked row is a's, and the other way round)
+#if defined(S3_ABL_NOBUCKET)   // (ablation builds: wrong results, what does the phase cost?)
+            const bool look = false;
+#elif defined(S3_NO_BLOOM)   // (tuning: every candidate fetches its bucket, as before the filter)
             const bool look = act[r] && unbr[r] > 0;
 #else
-            const bool look = act[r] && unbr[r] > 0 && ((bw[r] >> (bh[r] & 31u)) & (bw[r] >> ((bh[r] >> 5) & 31u)) & 1u);
+            const uint32_t mh = s3_bloom_hash((uint32_t)cvr[r].x ^ S3_MINI_SALT);
+            const uint32_t mw = reinterpret_cast<const uint32_t *>(&L.flt[win[r]][(kindr[r] & KF_SRC_A) ? 1 : 0][0])[mh >> 27];
+            const bool look = act[r] && unbr[r] > 0 && ((mw >> (mh & 31u)) & (mw >> ((mh >> 5) & 31u)) & 1u);
 #endif
             const uint32_t b = look ? __umulhi((uint32_t)cvr[r].x * S3_HASH_MUL, (uint32_t)unbr[r]) : 0u;
             const int4 *blk = reinterpret_cast<const int4 *>(A.u_cv + (look ? u0r[r] + S3_BUCKET * (int64_t)b : 0));
 #pragma unroll
             for (int q = 0; q < S3_BUCKET / 2; ++q) bv[r][q] = look ? blk[q] : make_int4(-1, 0, -1, 0);
         }
+        S3_STAMP_WAIT(7);   // buckets arrived
 #pragma unroll
         for (int r = 0; r < S3_ROUNDS; ++r) {
             const int g = S3_WAVES * r + wave;
@@ -464,7 +546,11 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
                 c[0] = __popcll(b0); c[1] = __popcll(b1); c[2] = __popcll(b2);
             }
         }
-        __syncthreads();
+        s3_lds_barrier();
+        S3_STAMP(8);    // arithmetic + ballots + barrier
+        // the bit map was read by the typing above only; the next item (drawn meanwhile) is requested now
+        if (tid < 2 * S3_GROUPS) L.bits[tid] = 0u;
+        const Req nxt = request();
 
         // ---- ranks inside the item; the item's totals go out to the chained scan at once
         if (wave < 3) {  // wavefront t: exclusive scan of type t over the groups in slot order
@@ -480,11 +566,13 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
             if (lane == 0) L.run[wave] = run;
             lb_publish(A.run_lb + (int64_t)wave * A.item_cap, it, epoch, (uint64_t)run, lane);
         }
+        S3_STAMP(9);    // rank scan + publish
         // ---- deferred write-out: the item's place in the output depends on every earlier item, and the slowest of the
         //      ones in flight decides when that is known.  So the kept entries are parked in LDS, the workgroup went on
         //      to type this item first, and only now asks for the PREVIOUS item's place (by now an answer that needs
         //      no waiting) and writes it out.
         s3_finish_parked(A, L, epoch, bs, lane, wave, tid);  // (starts and ends with a barrier)
+        S3_STAMP(10);   // look-back + write-out of the parked item
         const int run0 = L.run[0], run1 = L.run[1];
         if (tid == 0) {
             L.p_item = it; L.p_pf = pf; L.p_np = np; L.p_last = (c0 + n_here == total);
@@ -492,7 +580,7 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
             L.p_live = 1;
         }
         if (tid < S3_PAIRS) L.ps[tid][3] = 0;
-        __syncthreads();
+        s3_lds_barrier();
 #pragma unroll
         for (int r = 0; r < S3_ROUNDS; ++r) {
             const int g = S3_WAVES * r + wave;
@@ -514,11 +602,27 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
                 L.ps[w][0] = (int16_t)k0; L.ps[w][1] = (int16_t)k1; L.ps[w][2] = (int16_t)k2; L.ps[w][3] = 1;
             }
         }
+        S3_STAMP(11);   // parking
+        cur = nxt;
     }
     s3_finish_parked(A, L, epoch, bs, lane, wave, tid);
+#ifdef S3_STAMPS
+    if (tid == 0 && s3_stamp_buf) {
+        S3_STAMP(12);   // last look-back + write-out
+        uint64_t *o = s3_stamp_buf + (int64_t)blockIdx.x * 16;
+        for (int k = 0; k < 13; ++k) o[k] = st_acc[k];
+        o[13] = st_t0; o[14] = st_last;
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef S3_STAMPS
+extern "C" int lpf_select3_set_stamps(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(s3_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? LPF_OK : LPF_ERR_LAUNCH;
+}
+#endif
 
 /* ---- C ABI ---------------------------------------------------------------------------------------------------- */
 extern "C" int lpf_select3_plan(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
@@ -545,15 +649,18 @@ extern "C" int lpf_select3_plan(int64_t bs, const int64_t *batch, int64_t batch_
 }
 
 extern "C" int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int32_t *item_pair,
-                               int64_t item_cap, int64_t *ctl, uint64_t *run_lb, const void *u_cv, float th_cn,
+                               int64_t item_cap, int64_t *ctl, uint64_t *run_lb, const void *u_cv, const void *mini,
+                               float th_cn,
                                float th_1hop, float th_non1hop, int32_t mode_cn, int32_t *type_ptr, void *entries,
                                int64_t ent_cap, int32_t grid_blocks, void *stream) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && u_cv && type_ptr && entries &&
-                ent_cap > 0 && lpf_aligned16(entries) && lpf_aligned16(desc) && lpf_aligned16(u_cv));
+    LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && u_cv && mini && type_ptr &&
+                entries && ent_cap > 0 && lpf_aligned16(entries) && lpf_aligned16(desc) && lpf_aligned16(u_cv) &&
+                lpf_aligned16(mini));
     RunArgs3 a;
     a.bs = bs; a.desc = static_cast<const PairDesc3 *>(desc); a.offs = offs; a.item_pair = item_pair;
     a.item_cap = item_cap; a.ctl = ctl; a.run_lb = run_lb; a.u_cv = static_cast<const int2 *>(u_cv);
+    a.mini = static_cast<const uint32_t *>(mini);
     a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop; a.mode_cn = mode_cn;
     a.type_ptr = type_ptr; a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
     // Persistent workgroups: by default TWO per CU, half of what fits -- the kernel waits for memory, not for issue slots,

@@ -47,6 +47,9 @@ struct TailArgs {
     const float *att_bias;          // [NA]
     const int64_t *sel_ctl;         // selection control block: word 3 != 0 => the batch did not fit, scores = NaN
     int n_counts;
+    // rows mode (rows != nullptr): stage A is already done -- lpf_pair_attention_rows_* left one finished row per pair,
+    // [post_att_norm(attention output) (NA) | count features (4, zero padded)] -- and is a plain read
+    const float *rows; int64_t ldrows;
 };
 
 constexpr int tc_per_thread(int ntp) { return (ntp * 64 + TC_THREADS - 1) / TC_THREADS; }
@@ -162,8 +165,10 @@ struct TcShape {
     static constexpr size_t BYTES = (size_t)(2 * SLAB + HID) * sizeof(f32x4) + TC_WAVES * 16 * sizeof(float);
 };
 
-template <int NTA, int NTB, int NTC, bool WB = false>
-__global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_chain_kernel(const TailArgs A) {
+// (D = 256: 32 output tiles of the score head -- 16 accumulators per lane in stage C alone --, one workgroup per CU with
+//  twice the registers)
+template <int NTA, int NTB, int NTC, bool WB = false, bool ROWS = false>
+__global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 : 3)) void tail_chain_kernel(const TailArgs A) {
     using S = TcShape<NTA, NTB, NTC>;
     using WT = typename std::conditional<WB, uint2, f32x4>::type;  // weight element (WB: bf16 weights, merge mode only)
     constexpr int NTPA = S::NTPA, NTPB = S::NTPB, NTPC = S::NTPC;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_ch
 #pragma unroll
     for (int c = 0; c < TPWA; ++c) accA[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int seg_cnt[3] = {0, 0, 0};
-    if (!WB && A.part == nullptr) {
+    if (!WB && !ROWS && A.part == nullptr) {
         const float *xa = A.x + mm * A.ldx;
         const int ngA = (A.KA + 15) >> 4;
         f32x4 wr[S::PA];
@@ -213,7 +218,16 @@ __global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_ch
     }
     WT wrB[S::PB];
     tc_load<S::PB, NTPB>(wrB, A.wB, 0, tid);  // stage B's first weights fly during the epilogue
-    if (A.part == nullptr) {
+    if constexpr (ROWS) {
+        const int fbase = 16 * half * TPWA + 4 * q;
+        const float *row = A.rows + mm * A.ldrows;
+#pragma unroll
+        for (int c = 0; c < TPWA; ++c) {
+            const int f0 = fbase + 16 * c;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (f0 < A.NA ? f0 : 0));
+            accA[c] = f0 < A.NA ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    } else if (A.part == nullptr) {
         const int fbase = 16 * half * TPWA + 4 * q;
         f32x4 ad[TPWA];
 #pragma unroll
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_ch
     }
     {
         const int fbase = 16 * half * TPWA + 4 * q;
-        tc_layernorm<TPWA>(accA, fbase, A.NA, A.lnA_g, A.lnA_b, half, q, my_x, peer_x, false);
+        if constexpr (!ROWS) tc_layernorm<TPWA>(accA, fbase, A.NA, A.lnA_g, A.lnA_b, half, q, my_x, peer_x, false);
 #pragma unroll
         for (int c = 0; c < TPWA; ++c) my_hid[(half * TPWA + c) * 64] = accA[c];
     }
@@ -320,7 +334,9 @@ __global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_ch
         // the appended k-group: the count features (4 floats per sample) in lane quarter 0, zeros elsewhere
         f32x4 tailv = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (q == 0) {
-            if (A.part == nullptr) {
+            if constexpr (ROWS) {
+                tailv = *reinterpret_cast<const f32x4 *>(A.rows + mm * A.ldrows + A.NA);
+            } else if (A.part == nullptr) {
                 tailv = *reinterpret_cast<const f32x4 *>(A.tail + mm * A.ldtail);
             } else {  // get_structure_cnts (link_transformer.py:340-356): n_cn, n_1hop, [n_non1hop,] n_cn + n_1hop
                 const float n0 = (float)seg_cnt[0], n1 = (float)seg_cnt[1], n2 = (float)seg_cnt[2];
@@ -401,10 +417,10 @@ __global__ __launch_bounds__(TC_THREADS, TC_THREADS >= 512 ? 4 : 3) void tail_ch
     }
 }
 
-template <int NTA, int NTB, int NTC, bool WB = false>
+template <int NTA, int NTB, int NTC, bool WB = false, bool ROWS = false>
 int tc_launch(const TailArgs &a, hipStream_t s) {
     constexpr size_t lds = TcShape<NTA, NTB, NTC>::BYTES;
-    auto kern = tail_chain_kernel<NTA, NTB, NTC, WB>;
+    auto kern = tail_chain_kernel<NTA, NTB, NTC, WB, ROWS>;
     LPF_SET_MAX_LDS(kern, lds);  // (per instantiation and device; the attribute is sticky)
     const int64_t blocks = (a.M + 16 * TC_GROUPS - 1) / (16 * TC_GROUPS);
     if (blocks > 0x7fffffff) return LPF_ERR_UNSUPPORTED;
@@ -432,7 +448,7 @@ extern "C" int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const 
                 lpf_aligned16(w_dot));
     TailArgs a{M, G + D, ldg, 3 * D + 4, G, ldg, wA_packed, lnA_g, lnA_b, D, counts, ldc, wB_packed, bB, lnB_g,
                lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
-               nullptr, nullptr, 0, nullptr, nullptr, nullptr, n_counts};
+               nullptr, nullptr, 0, nullptr, nullptr, nullptr, n_counts, nullptr, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);
@@ -457,7 +473,7 @@ extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, 
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0, wB_packed, bB, lnB_g,
                lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
-               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts};
+               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);
@@ -485,7 +501,7 @@ extern "C" int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts,
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0,
                static_cast<const float *>(wB_packed_bf16), bB, lnB_g, lnB_b, D + n_counts, r_e, ldre,
                static_cast<const float *>(wC_packed_bf16), bC, 2 * D, w_dot, b_dot, logit, prob,
-               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts};
+               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4, true>(a, s);
@@ -493,4 +509,49 @@ extern "C" int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts,
         case 128: return tc_launch<8, 9, 16, true>(a, s);
         default: return LPF_ERR_UNSUPPORTED;
     }
+}
+
+// Rows mode: stage A was done by lpf_pair_attention_rows_* (one finished row per pair: post_att_norm(attention output)
+// followed by the count features, zero padded to 4); the tail is the two GEMMs, their LayerNorm and the score.
+namespace {
+template <bool WB>
+int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows, const void *wB, const float *bB,
+            const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre, const void *wC, const float *bC,
+            const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob, void *stream) {
+    if (M == 0) return LPF_OK;
+    LPF_REQUIRE(M > 0 && rows && wB && bB && lnB_g && lnB_b && r_e && wC && bC && w_dot && b_dot && (logit || prob));
+    LPF_REQUIRE((n_counts == 1 || n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D && (ldrows & 3) == 0 &&
+                ldrows >= D + 4);
+    LPF_REQUIRE(lpf_aligned16(rows) && lpf_aligned16(r_e) && lpf_aligned16(wB) && lpf_aligned16(wC) && lpf_aligned16(bB) &&
+                lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
+    TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, D, nullptr, 0, static_cast<const float *>(wB), bB,
+               lnB_g, lnB_b, D + n_counts, r_e, ldre, static_cast<const float *>(wC), bC, 2 * D, w_dot, b_dot, logit, prob,
+               nullptr, nullptr, 0, nullptr, nullptr, sel_ctl, n_counts, rows, ldrows};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (D) {
+        case 32: return tc_launch<2, 3, 4, WB, true>(a, s);
+        case 64: return tc_launch<4, 5, 8, WB, true>(a, s);
+        case 128: return tc_launch<8, 9, 16, WB, true>(a, s);
+        case 256: return tc_launch<16, 17, 32, WB, true>(a, s);
+        default: return LPF_ERR_UNSUPPORTED;
+    }
+}
+}  // namespace
+
+extern "C" int lpf_tail_chain_rows_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                                       const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
+                                       const float *r_e, int64_t ldre, const float *wC_packed, const float *bC,
+                                       const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit,
+                                       float *prob, void *stream) {
+    return tc_rows<false>(M, D, n_counts, rows, ldrows, wB_packed, bB, lnB_g, lnB_b, r_e, ldre, wC_packed, bC, w_dot, b_dot,
+                          sel_ctl, logit, prob, stream);
+}
+
+extern "C" int lpf_tail_chain_rows_bf16(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                                        const void *wB_packed_bf16, const float *bB, const float *lnB_g, const float *lnB_b,
+                                        const float *r_e, int64_t ldre, const void *wC_packed_bf16, const float *bC,
+                                        const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit,
+                                        float *prob, void *stream) {
+    return tc_rows<true>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
+                         b_dot, sel_ctl, logit, prob, stream);
 }

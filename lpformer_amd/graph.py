@@ -341,11 +341,45 @@ def ppr_filter_device_blocked(ppr: DeviceCSR, mode: int, theta: float) -> Blocke
 
 HASH_MUL = 2654435761  # Fibonacci hashing constant (2^32 / golden ratio)
 HASH_BUCKET = 8        # entries per bucket of a hashed index (one 64-byte half line)
-# Absence filter in front of a hashed row (csrc/select3.hip, s3_bloom_*): a row of ``nb`` buckets owns 2 nb 32-bit words
-# (1/8 of the bucket bytes), a key sets TWO bits of ONE word: h = mix(key); word = (h * 2 nb) >> 32; bits h & 31 and
-# (h >> 5) & 31.  At one bucket per four entries that is ~2 keys per word, ~1.5-3 % false positives; a key that fails
-# the test is not in the row, so its 64-byte bucket is never fetched.
-BLOOM_MUL1, BLOOM_MUL2 = 0x85EBCA6B, 0xC2B2AE35
+BLOOM_MUL1, BLOOM_MUL2 = 0x85EBCA6B, 0xC2B2AE35   # constants of ``bloom_hash`` (csrc/select3.hip::s3_bloom_hash)
+MINI_WORDS = 32          # 32-bit words of a node's MINI filter (1,024 bits = 128 bytes, one cache line)
+MINI_SALT = 0x9E3779B9   # the mini filter hashes key ^ MINI_SALT: independent of the row filter's bits
+
+
+def _pack_bits(n_words: int, bitpos: torch.Tensor, out: torch.Tensor, chunk: int = 1 << 22) -> None:
+    """OR the bits ``bitpos`` (int64 positions, word * 32 + bit) into the int32 words ``out`` (flat view, n_words long)
+    without atomics: mark them in chunks of words, pack 32 flags per word."""
+    dev = bitpos.device
+    w2 = torch.tensor([1 << b for b in range(31)] + [-(1 << 31)], dtype=torch.int32, device=dev)
+    word_of = torch.div(bitpos, 32, rounding_mode="floor")
+    for lo in range(0, n_words, chunk):
+        hi = min(lo + chunk, n_words)
+        m = (word_of >= lo) & (word_of < hi)
+        if not bool(m.any().item()):
+            continue
+        flags = torch.zeros((hi - lo) * 32, dtype=torch.bool, device=dev)
+        flags[bitpos[m] - lo * 32] = True
+        packed = (flags.view(-1, 32).to(torch.int32) * w2[None, :]).sum(dim=1, dtype=torch.int32)
+        nz = packed != 0
+        out[lo:hi][nz] |= packed[nz]
+
+
+def mini_filters(rowptr: torch.Tensor, col: torch.Tensor, n: int) -> torch.Tensor:
+    """int32 [n, MINI_WORDS]: a fixed 1,024-bit absence filter per row of a CSR (rows = nodes, ``col`` = the keys of the
+    row's hashed union): key c sets two bits of ONE word -- h = bloom_hash(c ^ MINI_SALT), word h >> 27, bits h & 31
+    and (h >> 5) & 31.  csrc/select3.hip stages the filters of an item's endpoints in LDS (one 128-byte line each, read
+    coalesced) and tests every candidate there: a candidate that fails is not in the row and costs no random read at
+    all.  Rows of a few hundred keys pass 10-20 % of the absent candidates, hub rows almost everything (they fall
+    through to the row's own filter in front of its buckets)."""
+    dev = rowptr.device
+    nnz = int(rowptr[-1].item())
+    out = torch.zeros(n * MINI_WORDS, dtype=torch.int32, device=dev)
+    if nnz:
+        row = torch.repeat_interleave(torch.arange(n, device=dev), rowptr[1:] - rowptr[:-1])
+        h = bloom_hash(col[:nnz].long() ^ MINI_SALT)
+        word = row * MINI_WORDS + (h >> 27)
+        _pack_bits(n * MINI_WORDS, torch.cat([word * 32 + (h & 31), word * 32 + ((h >> 5) & 31)]), out)
+    return out.view(n, MINI_WORDS)
 
 
 def bloom_hash(key: torch.Tensor) -> torch.Tensor:
@@ -367,14 +401,6 @@ class HashedIndex:
     cv: torch.Tensor       # int32 [HASH_BUCKET * buckets, 2] = 8 entries per bucket
     len: torch.Tensor      # int32 [n]: buckets per row
     n: int
-    # with an absence filter (``hash_index_device(..., bloom=True)``): row i's region starts with its filter words --
-    # 2 len[i] of them, padded to whole 64-byte lines = ``pad[i]`` entries of cv -- and its buckets follow at
-    # ``rowptr[i] + pad[i]`` (64-byte aligned).  None: buckets only.
-    pad: "Optional[torch.Tensor]" = None
-
-    def bucket_start(self) -> torch.Tensor:
-        """int64 [n]: entry offset of every row's first bucket."""
-        return self.rowptr[:-1] if self.pad is None else self.rowptr[:-1] + self.pad
 
     def to_host_compact(self) -> CSR:
         """The index as a plain sorted CSR (tests, statistics)."""
@@ -382,8 +408,6 @@ class HashedIndex:
         rp = self.rowptr.cpu().numpy()
         row = np.repeat(np.arange(self.n), np.diff(rp))
         live = cv[: row.size, 0] != 2**31 - 1
-        if self.pad is not None:   # the filter words in front of every row's buckets are not entries
-            live &= (np.arange(row.size) - rp[:-1][row]) >= self.pad.cpu().numpy()[row]
         row, col, val = row[live], cv[: row.size][live, 0], cv[: row.size][live, 1].copy().view(np.float32)
         order = np.lexsort((col, row))
         rowptr = np.zeros(self.n + 1, np.int64)
@@ -391,9 +415,8 @@ class HashedIndex:
         return CSR(rowptr, col[order].copy(), val[order].copy(), self.n)
 
 
-def hash_index_device(p: DeviceCSR, bloom: bool = False) -> HashedIndex:
-    """Bucketised layout of a device-resident sorted CSR (see HashedIndex).  One-time, a few torch passes.
-    ``bloom``: every row's buckets are preceded by its absence filter (BLOOM_* above)."""
+def hash_index_device(p: DeviceCSR) -> HashedIndex:
+    """Bucketised layout of a device-resident sorted CSR (see HashedIndex).  One-time, a few torch passes."""
     dev, n = p.rowptr.device, p.n
     ln = p.rowptr[1:] - p.rowptr[:-1]
     nnz = int(p.rowptr[-1].item())
@@ -414,50 +437,18 @@ def hash_index_device(p: DeviceCSR, bloom: bool = False) -> HashedIndex:
         nbk[bad] = nbk[bad] * 3 // 2 + 1
     else:
         raise RuntimeError("hash_index_device: bucket sizes did not settle")
-    pad = (nbk + HASH_BUCKET - 1) // HASH_BUCKET * HASH_BUCKET if bloom else torch.zeros_like(nbk)
-    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(nbk * HASH_BUCKET + pad, 0, out=rowptr[1:])
-    n_ent = int(rowptr[-1].item())
-    cv = torch.zeros((max(n_ent, 1), 2), dtype=torch.int32, device=dev)
-    bstart = rowptr[:-1] + pad                          # first bucket entry of every row
-    if total:
-        bucket_row = torch.repeat_interleave(torch.arange(n, device=dev), nbk)
-        slot0 = (bstart[bucket_row] + (torch.arange(total, device=dev) - base[bucket_row]) * HASH_BUCKET)
-        empty = (slot0[:, None] + torch.arange(HASH_BUCKET, device=dev)[None, :]).reshape(-1)
-        cv[empty, 0] = 2**31 - 1
-        del empty, slot0
+    cv = torch.zeros((max(total, 1) * HASH_BUCKET, 2), dtype=torch.int32, device=dev)
+    cv[:, 0] = 2**31 - 1
     if nnz:
         order = torch.argsort(key, stable=True)
         key_s = key[order]
         start = torch.cumsum(cnt, 0) - cnt
-        row_s = row[order]
-        pos = bstart[row_s] + (key_s - base[row_s]) * HASH_BUCKET + (torch.arange(nnz, device=dev) - start[key_s])
+        pos = key_s * HASH_BUCKET + (torch.arange(nnz, device=dev) - start[key_s])
         cv[pos, 0] = p.col[:nnz][order]
         cv[pos, 1] = p.val[:nnz].view(torch.int32)[order]
-        if bloom:
-            # two bits of one word per key; the words of a row live in the int32 view of its first `pad` entries
-            h = bloom_hash(col)
-            word = 2 * rowptr[:-1][row] + ((h * (2 * nbk[row])) >> 32)
-            flat = cv.view(-1)
-            n_words = flat.numel()
-            bitpos = torch.cat([word * 32 + (h & 31), word * 32 + ((h >> 5) & 31)])
-            del h, word
-            # OR-scatter without atomics: mark the bits in chunks of words, pack 32 flags per word
-            chunk = 1 << 22
-            w2 = torch.tensor([1 << b for b in range(31)] + [-(1 << 31)], dtype=torch.int32, device=dev)
-            wlo_all = torch.div(bitpos, 32, rounding_mode="floor")
-            for lo in range(0, n_words, chunk):
-                hi = min(lo + chunk, n_words)
-                m = (wlo_all >= lo) & (wlo_all < hi)
-                if not bool(m.any().item()):
-                    continue
-                flags = torch.zeros((hi - lo) * 32, dtype=torch.bool, device=dev)
-                flags[bitpos[m] - lo * 32] = True
-                packed = (flags.view(-1, 32).to(torch.int32) * w2[None, :]).sum(dim=1, dtype=torch.int32)
-                nz = packed != 0
-                flat[lo:hi][nz] = packed[nz]
-            del bitpos, wlo_all
-    return HashedIndex(rowptr, cv.contiguous(), nbk.to(torch.int32), n, pad.to(torch.int64) if bloom else None)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(nbk * HASH_BUCKET, 0, out=rowptr[1:])
+    return HashedIndex(rowptr, cv.contiguous(), nbk.to(torch.int32), n)
 
 
 def self_ppr_device(adj: DeviceCSR, ppr: DeviceCSR) -> torch.Tensor:
@@ -482,7 +473,8 @@ class WalkIndex:
     * ``px_cv``   PPR entries (i, v) with v NOT adjacent to i that pass the weaker of the one-hop / >1-hop tests;
     * ``t0_cv``   the px entries that pass the >1-hop test (``p > 0`` and round trip ``>= theta_n``), None without them;
     * ``u``       hashed union of adjacency row and px row (``HashedIndex``), the sign bit of a value = "adjacent";
-    * ``rec``     int32 [n, 16]: one 64-byte record per node with the five row starts (int64) and the five lengths.
+    * ``rec``     int32 [n, 16]: one 64-byte record per node with the five row starts (int64) and the five lengths;
+    * ``mini``    int32 [n, 32]: a fixed 1,024-bit absence filter of every union row (``mini_filters``).
     """
     rec: torch.Tensor
     adj_cv: torch.Tensor
@@ -492,6 +484,7 @@ class WalkIndex:
     u: "HashedIndex"
     n: int
     use_px: bool
+    mini: Optional[torch.Tensor] = None   # int32 [n, MINI_WORDS]: ``mini_filters`` of the union rows
 
     def lengths(self):
         """(deg, n_a1, n_px, n_t0, u_buckets) as int32 [n] views of ``rec`` (statistics, tests)."""
@@ -570,18 +563,20 @@ def build_walk_index(adj, ppr, th_1hop: float, th_non1hop: float, want_t0: bool)
     urow = torch.div(ukey, n, rounding_mode="floor")
     u_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(torch.bincount(urow, minlength=n), 0, out=u_rowptr[1:])
-    u = hash_index_device(DeviceCSR(u_rowptr, (ukey - urow * n).to(torch.int32), ubits.view(f32), n, None), bloom=True)
+    ucol = (ukey - urow * n).to(torch.int32)
+    u = hash_index_device(DeviceCSR(u_rowptr, ucol, ubits.view(f32), n, None))
+    mini = mini_filters(u_rowptr, ucol, n)
 
     rec64 = torch.zeros((n, 8), dtype=torch.int64, device=dev)
     rec64[:, 0] = adj.rowptr[:-1]
     rec64[:, 1] = starts(n_a1)
     rec64[:, 2] = starts(n_px)
     rec64[:, 3] = starts(n_t0)
-    rec64[:, 4] = u.bucket_start()                       # (the row's absence filter sits right in front of it)
+    rec64[:, 4] = u.rowptr[:-1]
     rec = rec64.view(torch.int32)                      # [n, 16]; little endian: int64 field f = columns 2f, 2f+1
     for i, lens in enumerate((deg, n_a1, n_px, n_t0, u.len)):
         rec[:, 10 + i] = lens.to(torch.int32)
     return WalkIndex(rec=rec.contiguous(), adj_cv=_cv(adj.col[:nnz_a], selfp),
                      a1_cv=_cv(adj.col[:nnz_a][strong], selfp[strong]), px_cv=_cv(px_col, px_val),
                      t0_cv=_cv(px_col[far], px_val[far]) if want_t0 else None, u=u, n=n,
-                     use_px=float(th_1hop) > 0.0)
+                     use_px=float(th_1hop) > 0.0, mini=mini.contiguous())

@@ -556,6 +556,10 @@ class LinkTransformer(nn.Module):
         # (csrc/pair_fused.hip; its cost does not depend on the weights).  Same records, same consumers.
         self.attention_impl = "auto"   # "auto": "flip" for D >= 128, "mfma" below (at D = 64 the matrix-core kernel's
         #                                2 D^2 FLOP per entry take 22 us on the ppa-like batch, the flip kernel 33)
+        # the "flip" arithmetic PAIR-MAJOR (csrc/pair_rows.hip): a group of lanes walks all entries of a pair and leaves
+        # its finished row [post_att_norm(attention output) | counts] -- no records for the tail to chase and merge.
+        # False: the unit-major kernel (csrc/pair_flip.hip) + record merge, as the matrix-core kernel always does.
+        self.attention_rows = True
         # "f32" (parity mode, logits within 1e-4 of the reference) or "bf16" (throughput mode of score_pairs: the node
         # table Z is stored in bf16 and Wfold h runs on the bf16 matrix cores; selection and everything else as in f32)
         self.precision = "f32"
@@ -658,6 +662,15 @@ class LinkTransformer(nn.Module):
             t = torch.empty(grow, dtype=dtype, device=self.device)
             self._ws[key] = t
         return t
+
+    def _zero_workspace(self, name: str, numel: int, st=None) -> torch.Tensor:
+        """``_workspace`` whose memory is zero when it is (re)allocated: for buffers with padding columns that the
+        kernels never write and the consumers read."""
+        key = (name, st if st is not None else _stream(self.device))
+        t = self._ws.get(key)
+        if t is None or t.numel() < numel:
+            t = self._ws[key] = torch.zeros(int(numel * 1.25) + 64, dtype=torch.float32, device=self.device)
+        return t[:numel]
 
     # ---------------------------------------------------------------------------------- folded weights
     def _fold(self):
@@ -938,7 +951,8 @@ class LinkTransformer(nn.Module):
                                            ptr(ws.plan_lb), st), "lpf_select3_plan")
             with KernelTimer.span("select_run"):
                 check(lib.lpf_select3_run(bs, ptr(ws.desc), ptr(ws.offs), ptr(ws.item_pair), ws.item_cap, ptr(ws.ctl),
-                                          ptr(ws.run_lb), ptr(wi.u.cv), float(self.thresh_cn), float(self.thresh_1hop),
+                                          ptr(ws.run_lb), ptr(wi.u.cv), ptr(wi.mini), float(self.thresh_cn),
+                                          float(self.thresh_1hop),
                                           float(self.thresh_non1hop), cn, ptr(ws.type_ptr), ptr(ws.entries),
                                           ws.ent_cap, self.select_grid, st), "lpf_select3_run")
             return
@@ -1196,6 +1210,39 @@ class LinkTransformer(nn.Module):
             return "flip" if self.flips_per_entry() <= self.FLIP_BREAK_EVEN.get(self.dim, 6.0) else "mfma"
         return self.attention_impl
 
+    def _uses_rows(self) -> bool:
+        """True when the one-pass attention runs pair-major and hands over finished rows (csrc/pair_rows.hip)."""
+        return self.attention_rows and self.attention_kernel() == "flip"
+
+    def _attention_rows(self, batch, x_node, test_set, adj_mask, side, out, n_counts):
+        """q gather -> selection -> pair-major one-pass attention writing ``out[p] = [post_att_norm(attention output) |
+        n_counts count features]`` (``out``: [BS, ld] fp32, ld % 4 == 0).  Returns the selection workspace."""
+        lib, st, d = _lib.hip(), _stream(self.device), self.dim
+        bs = batch.shape[1]
+        w = self._fold()
+        z, y = self._node_keys(x_node, w)
+        q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+            with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
+                check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0), None, 0,
+                                              ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
+        ws = self._select_device(batch, test_set, adj_mask)
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        layer = self.att_layers[0]
+        units_cap = (3 * ws.ent_cap + 15) // 16 + 1
+        pieces = self._workspace("att_pieces", units_cap * 2 * int(lib.lpf_pair_rows_piece_floats(d)), torch.float32, st)
+        with KernelTimer.span("pair_attention_fused"):
+            if self.precision == "bf16":
+                zt, fn, name = self._z_bf16(z), lib.lpf_pair_attention_rows_zbf16, "lpf_pair_attention_rows_zbf16"
+            else:
+                zt, fn, name = z, lib.lpf_pair_attention_rows_f32, "lpf_pair_attention_rows_f32"
+            check(fn(d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zt), zt.stride(0), ptr(q), q.stride(0),
+                     ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["wfold_t"]), ptr(w["att"]),
+                     ptr(layer.att.bias), ptr(layer.post_att_norm.weight), ptr(layer.post_att_norm.bias), n_counts,
+                     ptr(ws.ctl), ptr(pieces), units_cap, ptr(out), out.stride(0), st), name)
+        return ws
+
     def _fused_attention(self, batch, x_node, test_set, adj_mask, side):
         """q gather (side stream) -> selection (two launches, nothing read back) -> one-pass attention.  Returns the
         selection workspace and the record buffers (part, bnd, units_cap) for ``lpf_tail_chain_merge_*`` /
@@ -1263,6 +1310,10 @@ class LinkTransformer(nn.Module):
                     feats[:, d + self.count_dim:].zero_()
                 layer = self.att_layers[0]
                 side = self._fork()
+                if self._uses_rows():
+                    self._attention_rows(batch, x_node, test_set, adj_mask, side, feats, self.count_dim)
+                    self._last_att = feats[:, :d]
+                    return feats, None, True
                 ws, part, bnd, units_cap = self._fused_attention(batch, x_node, test_set, adj_mask, side)
                 with KernelTimer.span("pair_attention_merge"):
                     check(lib.lpf_pair_attention_merge_f32(
@@ -1423,8 +1474,26 @@ class LinkTransformer(nn.Module):
                                                              _stream(self.device)), "lpf_pair_gather_f32")
                     gemm(prod, ew._pads[0].get(ew.linears[0].weight), ew.linears[0].bias, out=r[:, :d])
                     layernorm_(r[:, :d], ew.norm.weight, ew.norm.bias, relu=True)
+            if (d in (32, 64, 128, 256) and self.use_tail_chain and self.use_fused_attention and bs > 0 and
+                    self._uses_rows()):
+                # hot path: 2 selection launches (nothing read back) -> pair-major attention (finished rows) -> the
+                # dense tail that is left: pairwise_lin's first layer, folded score head, sigmoid
+                lib, st = _lib.hip(), _stream(self.device)
+                rows = self._zero_workspace("att_rows", bs * (d + 4), st).view(bs, d + 4)   # (pad columns stay zero)
+                ws = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim)
+                tt = self._tail_tables(score_func, a, c)
+                res = torch.empty(bs, dtype=torch.float32, device=self.device)
+                with KernelTimer.span("tail_chain"):
+                    b16 = self.tail_precision == "bf16"
+                    fn = lib.lpf_tail_chain_rows_bf16 if b16 else lib.lpf_tail_chain_rows_f32
+                    check(fn(bs, d, self.count_dim, ptr(rows), rows.stride(0), ptr(tt["wB_bf16" if b16 else "wB"]),
+                             ptr(tt["bB"]), ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(r), r.stride(0),
+                             ptr(tt["wC_bf16" if b16 else "wC"]), ptr(tt["bC"]), ptr(tt["w_dot"]), ptr(tt["b_dot"]),
+                             ptr(ws.ctl), ptr(res) if logits else None, None if logits else ptr(res), st),
+                          "lpf_tail_chain_rows")
+                return res
             if d in (32, 64, 128) and self.use_tail_chain and self.use_fused_attention and bs > 0:
-                # hot path: 2 selection launches (nothing read back) -> one-pass attention -> merged dense tail
+                # 2 selection launches (nothing read back) -> one-pass attention (records) -> merged dense tail
                 lib, st = _lib.hip(), _stream(self.device)
                 ws, part, bnd, units_cap = self._fused_attention(batch, x_node, test_set, adj_mask, side)
                 tt = self._tail_tables(score_func, a, c)

@@ -327,3 +327,71 @@ def test_layernorm_backward_kernel():
         assert (x.grad.double() - xr.grad).abs().max().item() <= 1e-4 * max(1.0, float(xr.grad.abs().max()))
         for got, want in ((g.grad, gr.grad), (b.grad, br.grad)):
             assert (got.double() - want).abs().max().item() <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dim,mode", [(32, "all"), (64, "all"), (128, "all"), (256, "1-hop"), (128, "cn")])
+def test_pair_rows_kernel_matches_the_record_path(dim, mode):
+    """The pair-major attention kernel (csrc/pair_rows.hip: finished rows) against the unit-major kernel + record
+    merge (pair_flip.hip + pair_merge.hip / the merge stage of tail_chain.hip) it replaces on the hot path: same
+    features, same scores -- on a batch with hub pairs of hundreds of entries (dozens of 16-entry units, their pieces
+    merged inside the launch), empty pairs, a == b, and so many pairs that a workgroup's range is staged in several
+    chunks.  A row depends on its pair and on where the 16-entry grid of the pair-major order cuts it: the rows of a
+    PREFIX of the batch are bitwise the same, those of a permuted batch agree to rounding.  bf16 node table variant
+    within the mode's tolerance."""
+    import lpformer_amd
+    from lpformer_amd import data as D
+    rng = np.random.default_rng(dim)
+    n = 2500
+    ei, w = D.chung_lu_graph(n, 16000, gamma=2.1, seed=dim, max_weight=0)
+    star = np.stack([np.zeros(700, np.int64), rng.choice(np.arange(2, n), 700, replace=False)])   # two hubs
+    star2 = np.stack([np.ones(650, np.int64), rng.choice(np.arange(2, n), 650, replace=False)])
+    allp = np.concatenate([ei, star, star[::-1], star2, star2[::-1]], axis=1)
+    _, keep = np.unique(allp[0] * n + allp[1], return_index=True)
+    ei = allp[:, keep]
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    th = {"all": (0.0, 1e-4, 1e-3), "1-hop": (0.0, 1e-4, 1.0), "cn": (0.0, 1.0, 1.0)}[mode]
+    data = D.build_data(ei, x, n, ppr=lpformer_amd.calc_ppr(ei, n, 0.15, 1e-4))
+    args = D.train_args_for(dict(thresholds=th, dim=dim, gnn_layers=1, residual=False))
+    torch.manual_seed(dim)
+    model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
+    score = lpformer_amd.mlp_score(2 * dim, 2 * dim, 1, 2).to(DEV).eval()
+    with torch.no_grad():
+        for p in list(model.parameters()) + list(score.parameters()):
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    bs = 140_000 if dim == 128 and mode == "all" else 6_000      # 140 k: > 512 pairs per workgroup (chunked ranges)
+    batch = D.sample_pairs(ei, n, bs, seed=dim + 1, frac_edges=0.3)
+    batch[:, :8] = np.array([[0, 1, 0, 0, 1, 5, 7, 7], [1, 0, 0, 5, 9, 5, 9, 9]])          # hub pairs, a == b, duplicates
+    tb = torch.from_numpy(batch).to(DEV)
+    h = model.propagate()
+    model.attention_impl = "flip"
+    outs = {}
+    for rows in (True, False):
+        model.attention_rows = rows
+        feats, _ = model.calc_pairwise(tb, h)
+        lg = model.score_pairs(tb, h, score, logits=True)
+        assert model.check_selection()
+        outs[rows] = (feats.clone(), lg.clone())
+    sel = model.compute_node_mask(tb[:, :64])
+    assert sel[0][0].shape[1] > 0 if mode != "cn" else True
+    cnt = torch.zeros(bs, dtype=torch.long, device=DEV)
+    for t in model.compute_node_mask(tb):
+        if t is not None:
+            cnt += torch.bincount(t[0][0], minlength=bs)
+    assert int(cnt.max()) > 96 and int((cnt == 0).sum()) > 0 and int(((cnt > 0) & (cnt < 16)).sum()) > 0
+    scale = max(1.0, float(outs[False][0].abs().max()))
+    assert (outs[True][0] - outs[False][0]).abs().max().item() <= 2e-5 * scale
+    if dim <= 128:
+        assert (outs[True][1] - outs[False][1]).abs().max().item() <= 2e-5 * max(1.0, float(outs[False][1].abs().max()))
+    model.attention_rows = True
+    k = 1500
+    sub, _ = model.calc_pairwise(tb[:, :k].contiguous(), h)
+    assert torch.equal(sub, outs[True][0][:k])                     # same pairs in front of it: same cuts, same bits
+    perm = torch.randperm(bs, device=DEV)
+    pf, _ = model.calc_pairwise(tb[:, perm].contiguous(), h)
+    assert (pf - outs[True][0][perm]).abs().max().item() <= 2e-6 * scale
+    if dim <= 128:
+        model.precision = model.tail_precision = "bf16"
+        lg16 = model.score_pairs(tb, h, score, logits=True)
+        assert model.check_selection()
+        assert (lg16 - outs[True][1]).abs().max().item() <= 5e-3 * max(1.0, float(outs[True][1].abs().max()))

@@ -30,6 +30,13 @@ def _bloom_hash(v: int) -> int:
     return h ^ (h >> 13)
 
 
+def _mini_pass(mini_row, x: int) -> bool:
+    """The run kernel's test of candidate x against a node's 1,024-bit mini filter (staged in LDS there)."""
+    h = _bloom_hash(int(x) ^ graph.MINI_SALT)
+    w = int(mini_row[h >> 27]) & 0xFFFFFFFF
+    return bool((w >> (h & 31)) & (w >> ((h >> 5) & 31)) & 1)
+
+
 def _rt1(p):
     return F32(F32(F32(p) + F32(1)) - F32(1))
 
@@ -50,19 +57,17 @@ def emulate_select3(wi: graph.WalkIndex, batch, thresholds, mode):
     out = {1: [], 2: [], 3: []}
 
     def node(i):
-        return dict(adj0=r64[i, 0], a10=r64[i, 1], px0=r64[i, 2], t00=r64[i, 3], u0=r64[i, 4], deg=rec[i, 10],
+        return dict(id=i, adj0=r64[i, 0], a10=r64[i, 1], px0=r64[i, 2], t00=r64[i, 3], u0=r64[i, 4], deg=rec[i, 10],
                     n_a1=rec[i, 11], n_px=rec[i, 12], n_t0=rec[i, 13], unb=rec[i, 14])
 
-    uwords = wi.u.cv.view(-1).numpy().view(np.uint32)      # the same array as 32-bit words (absence filters)
+    mini = wi.mini.numpy()
 
-    def lookup(u0, unb, x):
+    def lookup(look, x):
+        u0, unb = look["u0"], look["unb"]
         if unb <= 0:
             return False, False, F32(0)
-        # the row's absence filter (2 unb words right in front of its buckets, padded to whole 64-byte lines): a key
-        # that fails it is not in the row and its bucket is never read
-        h = _bloom_hash(int(x))
-        w = int(uwords[2 * (int(u0) - ((int(unb) + 7) & ~7)) + ((h * 2 * int(unb)) >> 32)])
-        if not ((w >> (h & 31)) & (w >> ((h >> 5) & 31)) & 1):
+        # the looked-up endpoint's mini filter: a candidate that fails it is not in the row, its bucket is never read
+        if not _mini_pass(mini[look["id"]], x):
             return False, False, F32(0)
         b = ((int(x) * HASH_MUL % 2**32) * int(unb)) >> 32
         blk = ucv[u0 + 8 * b: u0 + 8 * b + 8]
@@ -94,7 +99,7 @@ def emulate_select3(wi: graph.WalkIndex, batch, thresholds, mode):
             for j in range(int(ln)):
                 x, bits = cvs[arr][src0 + j]
                 ws = np.array([bits], np.int32).view(F32)[0]
-                found, adj, lv = lookup(look["u0"], look["unb"], x)
+                found, adj, lv = lookup(look, x)
                 cn = kind == K_FULL and adj
                 hop = (kind in (K_FULL, K_A1) and not adj) or (kind == K_PX and adj)
                 far = kind == K_T0 and found and not adj
@@ -189,7 +194,8 @@ def test_walk_index_layout():
     selfp = graph.self_ppr(adj, ppr)
     assert np.array_equal(wi.adj_cv.numpy()[:, 0], adj.col) and np.array_equal(wi.adj_cv.numpy()[:, 1].view(F32), selfp)
     one = F32(1)
-    fp_total = [0, 0]
+    mini, fp_total = wi.mini.numpy(), [0, 0]
+    assert mini.shape == (n, graph.MINI_WORDS)
     for i in range(n):
         nb = adj.col[adj.rowptr[i]:adj.rowptr[i + 1]]
         sp = selfp[adj.rowptr[i]:adj.rowptr[i + 1]]
@@ -208,25 +214,14 @@ def test_walk_index_layout():
         row = ucv[r64[i, 4]: r64[i, 4] + 8 * rec[i, 14]]
         live = row[row[:, 0] != 2**31 - 1]
         assert live.shape[0] == len(want)
-        unb = int(rec[i, 14])
-        pad = (unb + 7) & ~7
-        flt = ucv[r64[i, 4] - pad: r64[i, 4]].reshape(-1).view(np.uint32)   # the row's absence filter: 2 unb words
-        assert int(wi.u.rowptr[i]) == r64[i, 4] - pad and not flt[2 * unb:].any()
         for c, bits in live:
-            b = ((int(c) * HASH_MUL % 2**32) * unb) >> 32
+            b = ((int(c) * HASH_MUL % 2**32) * int(rec[i, 14])) >> 32
             assert (row[8 * b: 8 * b + 8, 0] == c).sum() == 1          # in the bucket its hash names
             flag, v = want[int(c)]
             assert bool((int(bits) >> 31) & 1) == flag
             assert np.array([int(bits) & 0x7FFFFFFF], np.uint32).view(F32)[0] == v
-            h = _bloom_hash(int(c))
-            w = int(flt[(h * 2 * unb) >> 32])
-            assert (w >> (h & 31)) & (w >> ((h >> 5) & 31)) & 1          # no false negatives
+            assert _mini_pass(mini[i], int(c))                          # the mini filter has no false negatives
         absent = [c for c in range(n) if c not in want]
-        fp = 0
-        for c in absent:
-            h = _bloom_hash(c)
-            w = int(flt[(h * 2 * unb) >> 32]) if unb else 0
-            fp += (w >> (h & 31)) & (w >> ((h >> 5) & 31)) & 1
-        fp_total[0] += fp
+        fp_total[0] += sum(_mini_pass(mini[i], c) for c in absent)
         fp_total[1] += len(absent)
-    assert fp_total[0] <= 0.06 * fp_total[1], fp_total                   # ~2 keys per word: a few per cent
+    assert fp_total[0] <= 0.05 * fp_total[1], fp_total                  # rows of a few dozen keys in 1,024 bits

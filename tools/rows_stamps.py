@@ -1,0 +1,47 @@
+"""Tuning aid: phase marks of pair_rows_kernel (build with EXTRA=-DPR_STAMPS): per wavefront start / set-up done / chunk
+sorted / empties / heavy / light end, rounds walked."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lpformer_amd
+from lpformer_amd import data as D, _lib
+name = os.environ.get("LPF_CFG", "collab")
+cfg = D.CONFIGS[name]
+n = cfg["n"]; dev = torch.device("cuda:0")
+ei, w = D.chung_lu_graph(n, cfg["edges"], gamma=cfg["gamma"], seed=0, max_weight=cfg["max_weight"])
+x = np.random.default_rng(1).standard_normal((n, cfg["f_in"])).astype(np.float32)
+data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"], ppr_device=dev)
+torch.manual_seed(0)
+model = lpformer_amd.LinkTransformer(D.train_args_for(cfg), data, device=dev).to(dev).eval()
+score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
+model.use_side_stream = False
+model.attention_impl = "flip"
+batches = [torch.from_numpy(D.sample_pairs(ei, n, cfg["batch"], seed=1000 + i)).to(dev) for i in range(3)]
+h = model.propagate()
+lib = _lib.hip()
+fn = lib.lpf_pair_rows_set_stamps
+fn.argtypes = [ctypes.c_void_p]; fn.restype = ctypes.c_int
+buf = torch.zeros(1024 * 16 * 8, dtype=torch.int64, device=dev)
+for b in batches * 3:
+    model.score_pairs(b, h, score)
+torch.cuda.synchronize()
+assert fn(buf.data_ptr()) == 0
+names = ["start", "tables+range", "chunk sorted", "empties", "units done", "merge done"]
+for i, b in enumerate(batches):
+    buf.zero_()
+    model.score_pairs(b, h, score)
+    torch.cuda.synchronize()
+    v = buf.view(-1, 8).cpu().numpy().astype(np.float64)
+    v = v[v[:, 0] > 0]
+    t0 = v[:, 0].min()
+    rel = (v[:, :6] - t0) / 100.0
+    print(f"batch {i}: {len(v)} wavefronts; kernel span {rel[:, 5].max():.1f} us")
+    for k in range(6):
+        print(f"   {names[k]:14s} p10 {np.percentile(rel[:, k], 10):6.1f}  p50 {np.percentile(rel[:, k], 50):6.1f}  "
+              f"p90 {np.percentile(rel[:, k], 90):6.1f}  max {rel[:, k].max():6.1f}")
+    r = v[:, 6]
+    heavy = (v[:, 7].astype(np.int64) >> 32)
+    print(f"   unit rounds per wavefront: mean {r.mean():.2f} p50 {np.percentile(r, 50):.0f} max {r.max():.0f}; per round: "
+          f"{np.mean((rel[:, 4] - rel[:, 3])[r > 0] / r[r > 0]):.2f} us; pairs in several pieces per workgroup: mean "
+          f"{heavy.mean():.1f} max {heavy.max()}; merge phase mean {np.mean(rel[:, 5] - rel[:, 4]):.1f} us max "
+          f"{np.max(rel[:, 5] - rel[:, 4]):.1f}")

@@ -35,7 +35,7 @@ def digest(ws, bs):
 digs = []
 for b in batches:
     ws = model._select_device(b, False, None)
-    assert model.check_selection()
+    assert model.check_selection() or os.environ.get("LPF_ABLATE")
     digs.append(digest(ws, b.shape[1])[0])
 for _ in range(3):
     for b in batches:
