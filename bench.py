@@ -13,7 +13,7 @@ resident in HBM (the reference's HeaRT / citation2 evaluation pattern, src/train
 ``propagate()`` once, then per batch ``elementwise_lin(h[a]*h[b])``, ``calc_pairwise``, ``score_func``):
 endpoint gathers, q projection, PPR-thresholded node selection, PE + attention, count features, ``pairwise_lin``,
 ``elementwise_lin`` and the ``mlp_score`` head, scores landing in device memory.  The encoder (L x GEMM + CSR SpMM;
-N > 1: replicated, row-sharded with an RCCL all-gather per layer, or one all-gather of [X | Z | Y] after the last layer,
+N > 1: replicated, row-sharded with an RCCL all-gather per layer, or one all-gather of [X | Z] after the last layer,
 chosen by a measured cost model) is timed separately and reported as ``encoder_ms``; the
 throughput including one encoder pass per batch (the reference's ``test_edge`` pattern) is ``value_incl_encoder``.
 
@@ -262,12 +262,16 @@ def main():
                          "all are reported")
     ap.add_argument("--encoder", default="auto", choices=("auto", "replicated", "sharded", "gather_once"),
                     help="N > 1: every rank runs the whole encoder / rows sharded with an all-gather per layer / the last "
-                         "layer and the per-node attention projections sharded with ONE all-gather of [X | Z | Y]; "
+                         "layer and the per-node attention projections sharded with ONE all-gather of [X | Z]; "
                          "auto = the cheapest by lpformer_amd.dist.encoder_plan (measured encoder, last-layer and "
                          "projection times, measured all-gather rate)")
     ap.add_argument("--attention", default="auto", choices=("auto", "flip", "mfma"),
                     help="fp32 one-pass attention kernel: activation-pattern evaluation of the PE key projection "
                          "(pair_flip.hip, gather-bound) or the D x D product on the fp32 matrix cores (pair_fused.hip)")
+    ap.add_argument("--rows", default="auto", choices=("auto", "on", "off"),
+                    help="activation-pattern attention pair-major with finished rows (pair_rows.hip + the rows mode of the "
+                         "dense tail) or unit-major with records merged by the tail (pair_flip.hip); auto: whichever is "
+                         "faster in an untimed probe of the pipelined steps (both times are reported in config)")
     ap.add_argument("--launch", default="auto", choices=("auto", "graph", "eager"),
                     help="auto: whichever of the two is faster in an untimed probe before the windows (the choice and "
                          "both probe times are reported in config); graph: every stream replays ONE captured HIP graph of the step (lpformer_amd.GraphedScorer: "
@@ -323,12 +327,13 @@ def main():
         KernelTimer.enabled = True
         hh = model.propagate()
         model._node_keys(hh, model._fold())
+        model._node_y(hh, model._fold())
         kt0 = KernelTimer.summary()
         KernelTimer.enabled = False
         # (a fused layer -- one launch, csrc/gcn_fused.hip -- is row-sharded whole)
         last_key = "gcn_layer_fused" if "gcn_layer_fused" in kt0 else "spmm_csr"
         last_agg = LD.max_over_ranks(kt0[last_key][2] if last_key in kt0 else enc1 / cfg["gnn_layers"], dev)
-        keys_ms = LD.max_over_ranks(kt0["gemm_node_keys"][1] if "gemm_node_keys" in kt0 else 0.0, dev)
+        keys_ms = LD.max_over_ranks(sum(kt0[k][1] for k in ("gemm_node_keys", "gemm_node_query") if k in kt0), dev)
         del hh
         ag = LD.measure_allgather_gbps(n, d, dev)
         enc_plan = LD.encoder_plan(enc1, n, d, cfg["gnn_layers"], world, ag, last_agg_ms=last_agg,
@@ -366,6 +371,35 @@ def main():
     # consecutive steps rotate over `--streams` HIP streams: the selection kernels of one batch (latency / issue
     # bound) run under the MFMA kernels of the previous one.  Every step still does all of its work.
     lanes = model.lanes(max(1, args.streams))
+
+    # ---- which of the two forms of the activation-pattern attention?  (untimed probe, eager launches on the lanes)
+    rows_probe = None
+    if args.rows != "auto":
+        model.attention_rows = args.rows == "on"
+    elif model.attention_kernel() == "flip":
+        rows_probe = {}
+        t_spin = time.perf_counter()          # (a cold device ramps its clocks for ~0.5 s: not inside the comparison)
+        while time.perf_counter() - t_spin < 0.6:
+            for i in range(16):
+                with torch.cuda.stream(lanes[i % len(lanes)]):
+                    step(i)
+            torch.cuda.synchronize()
+        for mode in ("rows", "records"):
+            model.attention_rows = mode == "rows"
+            for i in range(2 * len(lanes)):
+                with torch.cuda.stream(lanes[i % len(lanes)]):
+                    step(i)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(max(args.steps, 40)):
+                with torch.cuda.stream(lanes[i % len(lanes)]):
+                    step(i)
+            torch.cuda.synchronize()
+            barrier()
+            rows_probe[mode] = LD.max_over_ranks(time.perf_counter() - t0, dev) * 1e3 / max(args.steps, 40)
+        model.attention_rows = rows_probe["rows"] <= rows_probe["records"]
+        rows_probe = {k: round(v, 4) for k, v in rows_probe.items()}
 
     scorers = None
     if args.launch in ("graph", "auto"):
@@ -478,6 +512,8 @@ def main():
     for _ in range(enc_reps):
         h2 = model.propagate()
         model._node_keys(h2, model._fold())
+        if model.query_from == "table":
+            model._node_y(h2, model._fold())
     torch.cuda.synchronize()
     barrier()
     node_keys_ms = max(0.0, LD.max_over_ranks((time.perf_counter() - t0) * 1e3 / enc_reps, dev) - encoder_ms)
@@ -681,7 +717,11 @@ def main():
                 # plan kernel: two node ids, two 64-byte node records, descriptor + offset per pair
                 "select_plan": ("hbm", (16.0 + 2 * 64.0 + 128.0 + 8.0) * bs),
                 "select_export": ("hbm", 2 * 16.0 * n_sel + 40.0 * bs),
-                # q = Y[a] + Y[b]: two gathered rows in, one row out per pair
+                # q = lin_l(x_a) + lin_l(x_b) = W_l (x_a + x_b) + 2 b_l: the endpoint rows gathered and added inside the
+                # first stage of a [BS, D] x [D, D] product
+                "pair_q": ("mfma", 2.0 * bs * d * d),
+                # ... or, with the per-node table Y = X W_l^T + b_l (model.query_from = "table", the default): two
+                # gathered rows in, one row out per pair
                 "pair_gather_q": ("hbm", 3.0 * 4.0 * d * bs + 16.0 * bs),
                 "dense_chain_score": ("mfma", 2.0 * bs * (2 * d) * (2 * d + c + 1)),  # folded first layer
                 "dense_chain_mlp": ("mfma", (2.0 * bs * (2 * d * d) + 2.0 * bs * (d + c) * (2 * d + c)) / 2.0),
@@ -791,10 +831,13 @@ def main():
                        "launch_probe_ms_per_step": launch_probe,
                        "spinup_s": args.spinup, "attention_impl": attention_random,
                        "attention_impl_requested": args.attention, "flips_per_entry": flips_random,
+                       "attention_form": ("pair-major, finished rows (pair_rows.hip)" if model._uses_rows() else
+                                          "unit-major, records merged by the tail (pair_flip.hip / pair_fused.hip)"),
+                       "attention_form_probe_ms_per_step": rows_probe,
                        "flip_break_even": model.FLIP_BREAK_EVEN.get(d),
                        "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']} " +
                                        {"sharded": "(rows + all-gather per layer)",
-                                        "gather_once": "(last layer + Z / Y on row blocks, one all-gather of [X | Z | Y])",
+                                        "gather_once": "(last layer + Z on row blocks, one all-gather of [X | Z])",
                                         "replicated": "(every rank runs it, no exchange)"}[enc_plan["chosen"]])
                        if world > 1 else "single GPU",
                        "encoder_plan": enc_plan},

@@ -90,6 +90,16 @@ int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order
                             const float *ln_b, const float *residual, int64_t ldr, const float *ln2_g,
                             const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
                             float *pre_out, int64_t ldpre, void *stream);
+/* The same with a SECOND D x D product chained to the finished rows while they are still in registers (the last layer
+ * of the encoder):  out2[r - row_base] = W2 out[r] + bias2,  w2_packed = pack_dense(W2, 1).  With W2 = lin_r.weight[:, :D]
+ * and bias2 = lin_r.bias this is Z = X_node W_rx^T + b_r, the per-node half of the attention's key projection
+ * (src/modules/layers.py:204) -- formerly an N x D x D lpf_gemm_f32 launch that re-read X_node from HBM. */
+int lpf_gcn_layer_fused_keys_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
+                                 const int64_t *rowptr, const int32_t *col, const float *w, const float *H, int64_t ldh,
+                                 const float *w_packed, float *out, int64_t ldo, const float *bias, const float *ln_g,
+                                 const float *ln_b, const float *residual, int64_t ldr, const float *ln2_g,
+                                 const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
+                                 const float *w2_packed, const float *bias2, float *out2, int64_t ldo2, void *stream);
 
 /* The same layer gathering from a bf16 table (the bf16-table encoder mode; D = 64 or 128).  H_bf16p: uint16 rows, ldh in
  * elements (a multiple of 8), in the PERMUTED order  element 32 i + 8 q + 4 h + u = feature 16 (2 i + h) + 4 q + u
@@ -204,7 +214,9 @@ int lpf_pair_gather_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t bat
  * Result: per type t a dense region entries[t*ent_cap ..) of {pair | from_N(b) << 31, node, pa, pb} records ordered by
  * (pair, candidate slot); segment of pair k = [type_ptr[t*(bs+1)+k], type_ptr[t*(bs+1)+k+1]); the one-hop segment
  * lists the kept nodes of N(a), then those of N(b).  Entries past ent_cap are dropped and LPF_SELECT_ERR_ENTRY_CAP is
- * raised; consumers clamp to ent_cap.  grid_blocks: persistent workgroups of the run kernel (0 = default). */
+ * raised; consumers clamp to ent_cap.  grid_blocks: persistent workgroups of the run kernel (0 = default).
+ * mode_cn (lpf_select_run): mask mode "cn" (link_transformer.py:39-44,232-247) -- common neighbours only, their round
+ * trip with t = 1, thresh_cn filter; pass t0_* = NULL with it (no >1-hop nodes). */
 #define LPF_SELECT_ITEM 1024
 #define LPF_SELECT_CTL_WORDS 16
 #define LPF_SELECT_ERR_NODE_RANGE 1 /* a node id of the batch is outside [0, n_nodes): the pair was treated as empty */
@@ -219,8 +231,8 @@ int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs, const int3
                    int64_t *ctl, uint64_t *run_lb, const int32_t *adj_col, const float *adj_selfp,
                    const int32_t *adjx_col, const int32_t *val_col, const float *val_val, const void *val_cv,
                    const void *t0_cv, const int32_t *t0_skip, float th_cn, float th_1hop,
-                   float th_non1hop, int32_t *type_ptr, void *entries, int64_t ent_cap, int32_t grid_blocks,
-                   void *stream);
+                   float th_non1hop, int32_t mode_cn, int32_t *type_ptr, void *entries, int64_t ent_cap,
+                   int32_t grid_blocks, void *stream);
 /* Selection over the per-model WALK INDEXES (select3.hip) -- the evaluation path: the typing adjacency is the model's
  * own adj_mask / full_adj_mask (link_transformer.py:226-227 with adj=None), mask modes "all", "1-hop" and "cn"
  * (:39-44).  Same control block, workspaces, result layout and error bits as lpf_select_plan / lpf_select_run above

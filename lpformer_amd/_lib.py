@@ -34,6 +34,8 @@ HIP_PROTOTYPES = {
     "lpf_gemm_f32_out_bf16": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
     "lpf_gcn_layer_fused_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,
                                 vp, vp, i64, vp],
+    "lpf_gcn_layer_fused_keys_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32,
+                                     vp, vp, vp, vp, vp, i64, vp],
     "lpf_spmm_row_parts_f32": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
     "lpf_spmm_row_parts_bf16p": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
     "lpf_gcn_layer_fused_bf16": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,
@@ -43,8 +45,8 @@ HIP_PROTOTYPES = {
     "lpf_pair_gather_f32": [i64, i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp],
     "lpf_select_plan_blocks": [i64],
     "lpf_select_plan": [i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
-    "lpf_select_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, i64, i32,
-                       vp],
+    "lpf_select_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, vp, vp, i64,
+                       i32, vp],
     "lpf_select3_plan": [i64, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp],
     "lpf_select3_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, f32, f32, f32, i32, vp, vp, i64, i32, vp],
     "lpf_select_export": [i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp],

@@ -34,6 +34,7 @@ namespace {
 
 constexpr uint32_t PR_PAIR_MASK = 0x7fffffffu;
 constexpr int PR_CHUNK = 512;    // pairs of the workgroup's range staged in LDS at a time
+constexpr int PR_FLAGS = 2048;   // units of a chunk whose completion is tracked in LDS (more: one barrier, then the merges)
 
 struct RowsArgs {
     int64_t bs;
@@ -103,7 +104,8 @@ struct PrLds {
     static constexpr int CUM = TP + 3 * (PR_CHUNK / 4 + 1);  // int [PR_CHUNK + 4]: pair-major start of every pair, chunk-relative
     static constexpr int LISTS = CUM + (PR_CHUNK / 4 + 1);   // int [2][PR_CHUNK]: empty pairs, pairs in several pieces
     static constexpr int CTL = LISTS + 2 * (PR_CHUNK / 4);   // int [16]: counters, ticket, range
-    static constexpr int TOTAL = CTL + 4;
+    static constexpr int FLAGS = CTL + 4;                    // int [PR_FLAGS]: unit u of the chunk is done
+    static constexpr int TOTAL = FLAGS + PR_FLAGS / 4;
     static constexpr size_t BYTES = (size_t)TOTAL * 16;
 };
 
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     int *const lcum = reinterpret_cast<int *>(pr_lds + L::CUM);
     int *const llist = reinterpret_cast<int *>(pr_lds + L::LISTS);
     int *const lctl = reinterpret_cast<int *>(pr_lds + L::CTL);   // 0: n_empty 1: n_multi 2: unit ticket 4,5: P0 6,7: P1
+    int *const lflag = reinterpret_cast<int *>(pr_lds + L::FLAGS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane / G, lj = lane % G, off = 4 * lj;
     const int gid = wave * EPW + grp;            // this group among the workgroup's NG
 #ifdef PR_STAMPS
@@ -260,6 +263,12 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         const int n_units = v1 > v0 ? (int)(((v1 - 1) >> 4) - u_first + 1) : 0;
         for (int k = tid; k <= cn; k += NTH)
             lcum[k] = (int)(((int64_t)ltp[k] + ltp[TPS + k] + ltp[2 * TPS + k]) - v0);
+        // A pair in several pieces is merged by the group that walks its LAST piece, right behind that unit, once the
+        // units in front of it are flagged done (they were drawn earlier: nobody waits for a later unit) -- no barrier,
+        // no separate merge phase.  Only a chunk of more than PR_FLAGS units falls back to barrier + merge list.
+        const bool inl = n_units <= PR_FLAGS;
+        if (inl)
+            for (int k = tid; k < n_units; k += NTH) lflag[k] = 0;
         __syncthreads();
         // ---- sort the chunk's pairs (empty / in several pieces); the count features go out at once
         for (int k = tid; k < cn; k += NTH) {
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     const int64_t ustart = x0 - v0, uend = ustart + 16;        // the unit in chunk-relative positions
                     const bool head = ps < ustart, more = pe > uend;
                     meta = t | ((j == 0 || i == 0) ? 4 : 0) | ((xr == pe - 1 || i == 15) ? 8 : 0) |
-                           ((head || more) ? 16 : 0) | (head ? 32 : 0) | 64;
+                           ((head || more) ? 16 : 0) | (head ? 32 : 0) | 64 | ((head && !more && inl) ? 128 : 0);
                     const float *st = lstat + 8 * t;
                     const float pa = __int_as_float(rec.z), pb = __int_as_float(rec.w);
                     const float vab = st[0] * pa * pa + st[1] * pb * pb + st[2] + 2.0f * (st[3] * pa * pb + st[4] * pa + st[5] * pb);
@@ -341,6 +350,10 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             float *const piece_u = A.pieces + (u_first + ul) * 2 * RSP;
             float m = -INFINITY, l = 0.f;
             f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
+            // the last piece of a pair that started in an earlier unit: kept here, merged behind the walk (bit 7 of meta)
+            float hm = 0.f, hl = 0.f;
+            f32x2 ho01 = {0.f, 0.f}, ho23 = {0.f, 0.f};
+            int hpair = -1;
 
             auto entry = [&](const int i, const ZT zraw) __attribute__((always_inline)) {
                 const float4 zc = z_wide(zraw);
@@ -427,7 +440,9 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     o23 = o23 * sca + k23 * w;
                     m = fmaxf(m, s);
                     if (meta & 8) {          // last entry of the piece
-                        if (meta & 16) {     // ... of a pair in several pieces: its state waits for the merge
+                        if (meta & 128) {    // ... the LAST piece of a pair in several pieces: merged behind the walk
+                            hm = m; hl = l; ho01 = o01; ho23 = o23; hpair = pair_i;
+                        } else if (meta & 16) {   // ... another piece of such a pair: its state waits for the merge
                             float *dst = piece_u + ((meta & 32) ? 0 : RSP);
                             *reinterpret_cast<float4 *>(dst + off) = make_float4(o01.x, o01.y, o23.x, o23.y);
                             if (lj == 0) *reinterpret_cast<float2 *>(dst + D) = make_float2(m, l);
@@ -452,14 +467,57 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 batch(2 * h, za, zb);
                 batch(2 * h + 1, zb, za);
             }
+            if (inl) {
+                // this unit's pieces are in L2: flag it; then the merge of the pair that ended in it, if there is one
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lj == 0 && ul < n_units) __hip_atomic_store(&lflag[ul], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hpair >= 0) {
+                    const int k = (int)(hpair - c0);
+                    const int ua_l = (int)(((v0 + lcum[k]) >> 4) - u_first);      // first unit of the pair, chunk-relative
+                    for (int u = ua_l + lj; u < ul; u += G)
+                        while (__hip_atomic_load(&lflag[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+                            __builtin_amdgcn_s_sleep(2);
+                    asm volatile("" ::: "memory");
+                    float mx = -INFINITY, den = 0.f;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = ua_l; u < ul; u += 4) {   // (four pieces requested together: a hub pair has dozens)
+                        float2 h[4];
+                        float4 b[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int uu = u + i < ul ? u + i : ul - 1;
+                            const float *rp = A.pieces + ((u_first + uu) * 2 + (uu == ua_l ? 1 : 0)) * RSP;
+                            h[i] = *reinterpret_cast<const float2 *>(rp + D);
+                            b[i] = *reinterpret_cast<const float4 *>(rp + off);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (u + i >= ul) break;
+                            const float mn = fmaxf(mx, h[i].x);
+                            const float sa = __expf(mx - mn), sb = __expf(h[i].x - mn);
+                            den = fmaf(den, sa, h[i].y * sb);
+                            v.x = v.x * sa + b[i].x * sb; v.y = v.y * sa + b[i].y * sb;
+                            v.z = v.z * sa + b[i].z * sb; v.w = v.w * sa + b[i].w * sb;
+                            mx = mn;
+                        }
+                    }
+                    const float mn = fmaxf(mx, hm);
+                    const float sa = __expf(mx - mn), sb = __expf(hm - mn);
+                    den = fmaf(den, sa, hl * sb);
+                    v.x = v.x * sa + ho01.x * sb; v.y = v.y * sa + ho01.y * sb;
+                    v.z = v.z * sa + ho23.x * sb; v.w = v.w * sa + ho23.y * sb;
+                    *reinterpret_cast<float4 *>(A.out + (int64_t)hpair * A.ldo + off) =
+                        finish_row(f32x2{v.x, v.y}, f32x2{v.z, v.w}, den);
+                }
+            }
 #ifdef PR_STAMPS
             ++st_rounds;
 #endif
         }
         PR_STAMP(4);
-        // ---- pairs in several pieces: merged in unit order (the pieces were written by this workgroup: one barrier)
-        __syncthreads();
-        for (int mk = gid; mk < n_multi; mk += NG) {
+        // ---- (chunks of more than PR_FLAGS units) pairs in several pieces: one barrier, then merged in unit order
+        if (!inl) __syncthreads();
+        for (int mk = gid; mk < (inl ? 0 : n_multi); mk += NG) {
             const int k = llist[PR_CHUNK + mk];
             const int64_t ua = (v0 + lcum[k]) >> 4, ub = (v0 + lcum[k + 1] - 1) >> 4;
             float mx = -INFINITY, den = 0.f;

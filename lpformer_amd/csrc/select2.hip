@@ -267,6 +267,7 @@ struct RunArgs {
     const int2 *t0_cv;         // T0 index, blocked layout (both paths)
     const int32_t *t0_skip;
     float th_cn, th_1, th_n;
+    int mode_cn;   // mask mode "cn" (link_transformer.py:232-247): common neighbours only, round trip with t = 1
     int32_t *type_ptr;         // [3][bs+1]
     int4 *entries;             // [3][ent_cap]
     int64_t ent_cap;
@@ -362,10 +363,11 @@ __device__ __forceinline__ bool s2_type_slot(const RunArgs &A, const RunLds &L, 
             if (idx >= 0) other = A.val_val[v0 + idx];
         }
     }
-    const float pa = s2_round_trip(from_a ? own : other, cn);
-    const float pb = s2_round_trip(from_a ? other : own, cn);
+    const bool two = cn && !A.mode_cn;   // (t = 2 for a common neighbour; mode "cn": t = 1, as in select3.hip)
+    const float pa = s2_round_trip(from_a ? own : other, two);
+    const float pb = s2_round_trip(from_a ? other : own, two);
     const float th = cn ? A.th_cn : A.th_1;
-    const bool keep = pa >= th && pb >= th;
+    const bool keep = pa >= th && pb >= th && (cn || !A.mode_cn);
     code = keep ? (cn ? 1 : 2) : 0;
     va = pa; vb = pb; fromb = !from_a;
     return false;
@@ -787,7 +789,7 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
                               const float *adj_selfp, const int32_t *adjx_col, const int32_t *val_col,
                               const float *val_val, const void *val_cv, const void *t0_cv,
                               const int32_t *t0_skip, float th_cn, float th_1hop,
-                              float th_non1hop, int32_t *type_ptr, void *entries, int64_t ent_cap,
+                              float th_non1hop, int32_t mode_cn, int32_t *type_ptr, void *entries, int64_t ent_cap,
                               int32_t grid_blocks, void *stream) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && desc && offs && item_pair && item_cap > 0 && ctl && run_lb && adj_col && type_ptr &&
@@ -804,7 +806,7 @@ extern "C" int lpf_select_run(int64_t bs, const void *desc, const int64_t *offs,
     a.val_col = val_col; a.val_val = val_val;
     a.val_cv = static_cast<const int2 *>(val_cv);
     a.t0_cv = static_cast<const int2 *>(t0_cv); a.t0_skip = t0_skip;
-    a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop;
+    a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop; a.mode_cn = mode_cn;
     a.type_ptr = type_ptr; a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
     // one resident round of workgroups (they are persistent; more than fit only queue up behind the others:
     // 1024 / 1280 / 2048 / 4096 workgroups measured 132 / 132 / 138 / 158 us on 256 CUs)

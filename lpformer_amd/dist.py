@@ -117,12 +117,12 @@ def measure_allgather_gbps(n: int, d: int, device, reps: int = 3, group=None) ->
 
 def encoder_plan(encoder_ms_one_gpu: float, n: int, d: int, n_layers: int, world: int, allgather_gbps: float,
                  last_agg_ms: float | None = None, node_keys_ms: float = 0.0) -> dict:
-    """Cost model for the encoder + the per-node attention projections (Z, Y) on ``world`` GPUs (all times in ms):
+    """Cost model for the encoder + the per-node attention projection (Z) on ``world`` GPUs (all times in ms):
          replicated:  every rank runs all of it, no exchange           = enc + keys
          sharded:     1/world of every layer + (L + 1) all-gathers of an [n, d] fp32 matrix, Z / Y on every rank
                                                                        = enc / world + (L + 1) * ag + keys
          gather_once: layers 1..L-1 replicated, the last layer's aggregation and Z / Y on the rank's rows, ONE
-                      all-gather of [X | Z | Y] (3 d floats per node)  = enc - (1 - 1/world) * (last_agg + keys) + 3 * ag
+                      all-gather of [X | Z] (2 d floats per node)  = enc - (1 - 1/world) * (last_agg + keys) + 2 * ag
     ``last_agg_ms``: the row-shardable part of the last layer on one GPU -- its aggregation (SpMM + epilogue), or the
     whole layer when it runs as one fused launch (default: 0.7 * enc / L).  A sharded encoder whose layers are all
     fused needs L all-gathers, not L + 1 (layer 0 reads the replicated features): the estimate is on the safe side;
@@ -136,6 +136,6 @@ def encoder_plan(encoder_ms_one_gpu: float, n: int, d: int, n_layers: int, world
                 "allgather_ms": 0.0}
     ag_ms = n * d * 4 / (allgather_gbps * 1e9) * 1e3
     sharded = encoder_ms_one_gpu / world + (n_layers + 1) * ag_ms + node_keys_ms
-    once = encoder_ms_one_gpu - (1.0 - 1.0 / world) * (last_agg_ms + node_keys_ms) + node_keys_ms + 3.0 * ag_ms
+    once = encoder_ms_one_gpu - (1.0 - 1.0 / world) * (last_agg_ms + node_keys_ms) + node_keys_ms + 2.0 * ag_ms
     best = min((repl, "replicated"), (sharded, "sharded"), (once, "gather_once"))[1]
     return {"mode": best, "replicated_ms": repl, "sharded_ms": sharded, "gather_once_ms": once, "allgather_ms": ag_ms}

@@ -7,7 +7,7 @@ launch.  Inputs and outputs are static tensors owned by the scorer.
 
 A captured graph holds RAW POINTERS.  Everything they point at is either allocated during capture (the graph's own
 memory pool) or held by this object: the scorer runs on a stream of its own, so the model's per-stream workspaces
-behind that stream are used by nobody else, and it keeps strong references to the per-encoder-output tables (Z, Y and
+behind that stream are used by nobody else, and it keeps strong references to the per-encoder-output tables (Z and
 the bf16 copy), the folded weight tables and the selection workspace it was captured with -- the model replacing its
 caches (another encoder output, an optimiser step) cannot free memory a replay reads.  Replays are refused to go stale:
 ``__call__`` compares the version key of every parameter with the one of the capture and captures again when it
@@ -67,7 +67,7 @@ class GraphedScorer:
                                          logits=self.logits)
         # strong references to everything the captured launches read or write outside the graph's own pool
         raw = self.stream.cuda_stream
-        self._keep = (model._z_cache, getattr(model, "_zb_cache", None), model._folded,
+        self._keep = (model._z_cache, getattr(model, "_y_cache", None), getattr(model, "_zb_cache", None), model._folded,
                       getattr(model, "_tail_cache", None), getattr(model, "_score_fold_cache", None),
                       [(k, w, getattr(w, "entries", None), getattr(w, "item_pair", None), getattr(w, "run_lb", None))
                        for k, w in model._ws.items() if isinstance(k, tuple) and raw in k])

@@ -534,8 +534,17 @@ class LinkTransformer(nn.Module):
         self._ws = {}          # named workspaces
         self._param_list = None  # cached list(self.parameters()) for the fold key
         self._chain_att = DenseChain("dense_chain_attn_out")   # attention output projection + post_att_norm
+        self._chain_q = DenseChain("pair_q")                   # q = lin_l(x_a) + lin_l(x_b)
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
         self._conv_packs = [_PackedSquare() for _ in self.node_encoder.gnn_encoder.convs]
+        self._keys_pack = _PackedSquare()      # W_rx for the Z product chained to the last fused layer
+        self._keys_written = False
+        # True: the node half of the attention's key projection (Z = X_node W_rx^T + b_r) inside the last GCN layer's
+        # launch when that layer runs fused (csrc/gcn_fused.hip KEYS).  Off by default: measured, the chained product
+        # costs what the separate lpf_gemm_f32 costs (collab-like: encoder 0.686 -> 0.783 ms with it, 0.092 ms for the
+        # product alone) -- fp32 MFMA and the gather's vector FMAs issue from the same ports, nothing hides
+        self.fuse_node_keys = False
+        self.query_from = "table"              # "table" or "gemm": see _pair_q
         # square GCN layers (in = out = D <= 128) in one launch, aggregate-then-transform (csrc/gcn_fused.hip); False:
         # always lpf_gemm_f32 + lpf_spmm_csr_f32
         self.encoder_fused = True
@@ -708,12 +717,18 @@ class LinkTransformer(nn.Module):
                 for i in range(n_layers):
                     if _layers_out is not None:
                         _layers_out.append(x)
-                    x = self._layer(i, a_hat, x, 0, self.num_nodes)
+                    z = None
+                    if i == n_layers - 1 and self.fuse_node_keys and self.att_layers[0].att.lin_r.weight.shape[1] == 2 * self.dim:
+                        z = torch.empty(self.num_nodes, self.dim, dtype=torch.float32, device=self.device)
+                    x = self._layer(i, a_hat, x, 0, self.num_nodes, keys_out=z)
+                    if z is not None and self._keys_written:
+                        torch.cuda.current_stream(self.device).synchronize()   # other streams read Z (as _node_keys)
+                        self._z_cache = (weakref.ref(x), x._version, z)
             elif self.encoder_mode == "gather_once":
                 # BASELINE.json's literal layout -- "a single RCCL all-gather of node embeddings after the encoder":
                 # layers 1..L-1 run on every rank (no exchange), the LAST layer's aggregation + epilogue and the two
-                # per-node projections of the attention (Z, Y: _node_keys) run on the rank's row block only, and ONE
-                # all-gather of [X_node | Z | Y] rows (3 D floats per node) hands every rank all three tables.  A fused
+                # per-node projection of the attention (Z: _node_keys) runs on the rank's row block only, and ONE
+                # all-gather of [X_node | Z] rows (2 D floats per node) hands every rank both tables.  A fused
                 # last layer (csrc/gcn_fused.hip) is row-sharded whole; an unfused one keeps its X W^T replicated (a
                 # row's aggregation reads the transformed rows of all its neighbours).  Every element stays bitwise
                 # equal to the unsharded encoder.
@@ -721,16 +736,17 @@ class LinkTransformer(nn.Module):
                 for i in range(n_layers - 1):
                     x = self._layer(i, a_hat, x, 0, self.num_nodes)
                 lo, hi = lpf_dist.row_range(self.num_nodes, world, rank)
-                x_rows = self._layer(n_layers - 1, a_hat, x, lo, hi)
                 w = self._fold()
                 d = self.dim
-                pack = torch.empty(hi - lo, 3 * d, dtype=torch.float32, device=self.device)
+                pack = torch.empty(hi - lo, 2 * d, dtype=torch.float32, device=self.device)
+                x_rows = self._layer(n_layers - 1, a_hat, x, lo, hi, keys_out=pack[:, d:])
                 pack[:, :d] = x_rows
-                gemm(x_rows, w["w_zy"], w["b_zy"], out=pack[:, d:], tag="gemm_node_keys")     # [Z | Y] in one product
+                if not self._keys_written:
+                    gemm(x_rows, w["w_rx"], w["b_r"], out=pack[:, d:], tag="gemm_node_keys")  # Z of the rank's rows
                 full = lpf_dist.allgather_rows(pack, self.num_nodes)      # the all-gather of node embeddings
                 x = full[:, :d]
-                torch.cuda.current_stream(self.device).synchronize()      # other streams read Z, Y (as _node_keys)
-                self._z_cache = (weakref.ref(x), x._version, full[:, d:2 * d], full[:, 2 * d:])
+                torch.cuda.current_stream(self.device).synchronize()      # other streams read Z (as _node_keys)
+                self._z_cache = (weakref.ref(x), x._version, full[:, d:])
             else:
                 # row-sharded: a rank produces its block of rows of every layer.  A fused layer (aggregate, then
                 # transform) reads the layer INPUT of all nodes -- the features for layer 0 (replicated: no exchange),
@@ -753,12 +769,15 @@ class LinkTransformer(nn.Module):
                 _layers_out.append(x)
             return x
 
-    def _layer(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+    def _layer(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int, keys_out=None) -> torch.Tensor:
         """Rows [lo, hi) of layer i's output from the layer input ``x`` of ALL nodes: one launch when the layer is
-        square and small enough for the fused kernel, transform + aggregate otherwise."""
+        square and small enough for the fused kernel, transform + aggregate otherwise.  ``keys_out`` ([hi - lo, D], last
+        layer only): also receives Z = X_node W_rx^T + b_r of those rows when the fused kernel can chain it
+        (``self._keys_written`` says whether it did)."""
         x = _as_f32_rows(x)
+        self._keys_written = False
         if self._fusable(i, x.shape[1]):
-            return self._layer_fused(i, a_hat, x, lo, hi)
+            return self._layer_fused(i, a_hat, x, lo, hi, keys_out)
         return self._layer_aggregate(i, a_hat, self._layer_transform(i, x), lo, hi, x[lo:hi])
 
     def _fusable(self, i: int, in_dim: int) -> bool:
@@ -767,7 +786,7 @@ class LinkTransformer(nn.Module):
         ok = (32, 64, 128) if self.encoder_precision != "bf16" else (64, 128)   # (bf16 table: a row is >= one line)
         return self.encoder_fused and d_in == d_out and d_out in ok and in_dim == d_in
 
-    def _layer_fused(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+    def _layer_fused(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int, keys_out=None) -> torch.Tensor:
         """``lpf_gcn_layer_fused_f32``: out[r] = epilogue((sum_e w_e x[col_e]) W^T) for r in [lo, hi) -- the same layer
         as ``_layer_transform`` + ``_layer_aggregate`` with the sum taken before the product.  With
         ``encoder_precision == "bf16"`` the rows are gathered from a bf16 image of ``x`` (``lpf_gcn_layer_fused_bf16``;
@@ -811,6 +830,14 @@ class LinkTransformer(nn.Module):
                     xb.stride(0), *common, ptr(out_b), d, st), "lpf_gcn_layer_fused_bf16")
                 if whole:
                     self._xb_cache = (weakref.ref(out), out_b)
+            elif keys_out is not None and last and self.fuse_node_keys:
+                # the last layer: Z = X_node W_rx^T + b_r chained to the finished rows inside the same launch
+                lin_r = self.att_layers[0].att.lin_r
+                check(lib.lpf_gcn_layer_fused_keys_f32(
+                    d, order.numel() // 16, ptr(order), lo, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x),
+                    x.stride(0), *common, ptr(self._keys_pack.get(lin_r.weight[:, :d])), ptr(lin_r.bias), ptr(keys_out),
+                    keys_out.stride(0), st), "lpf_gcn_layer_fused_keys_f32")
+                self._keys_written = True
             else:
                 check(lib.lpf_gcn_layer_fused_f32(
                     d, order.numel() // 16, ptr(order), lo, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x),
@@ -892,7 +919,7 @@ class LinkTransformer(nn.Module):
         """This process is rank ``rank`` of ``world`` (default process group, lpformer_amd/dist.py).  ``mode``:
         "sharded" = row-sharded encoder with an all-gather per layer (L + 1 collectives), "replicated" = every rank runs
         the whole encoder (no exchange), "gather_once" = layers 1..L-1 replicated, the last layer's aggregation and the
-        per-node attention projections row-sharded, ONE all-gather of [X_node | Z | Y]
+        per-node attention projections row-sharded, ONE all-gather of [X_node | Z]
         (``lpformer_amd.dist.encoder_plan`` prices the three)."""
         if not (0 <= rank < world):
             raise ValueError("need 0 <= rank < world")
@@ -902,22 +929,57 @@ class LinkTransformer(nn.Module):
         self.encoder_mode = mode
 
     def _node_keys(self, x_node: torch.Tensor, w):
-        """Per encoder output (cached on the tensor's identity and version), two node-level projections that the
-        reference recomputes per selected node / per pair:
-          Z = X_node W_rx^T + b_r   the node half of lin_r (k_e = Z[v] + ...),
-          Y = X_node W_l^T + b_l    lin_l per node, so that q_pair = lin_l(x_a) + lin_l(x_b) = Y[a] + Y[b] -- literally
-                                    the reference's expression (layers.py:212-215) -- is a gather-add, not a GEMM."""
+        """Per encoder output (cached on the tensor's identity and version), the node-level projection that the
+        reference recomputes per selected node:  Z = X_node W_rx^T + b_r, the node half of lin_r (k_e = Z[v] + ...).
+        (Until round 3 a second table Y = X_node W_l^T + b_l was kept for q_pair = Y[a] + Y[b]; the query is now one
+        [BS, D] x [D, D] product per batch, ``_pair_q`` -- half the per-encoder-output work, 0.1 ms on collab-like.)"""
         # Keyed on the IDENTITY of the encoder output (weak reference) + its version: the encoder writes its output
         # through raw pointers (no version bump) and the caching allocator hands the same address to the next
         # propagate(), so neither data_ptr nor _version alone can tell two encoder outputs apart; a tensor object can.
         hit = self._z_cache
         if hit is None or hit[0]() is not x_node or hit[1] != x_node._version:
             xr = _as_f32_rows(x_node)
-            d = self.dim
-            zy = gemm(xr, w["w_zy"], w["b_zy"], tag="gemm_node_keys")    # [N, 2D]: Z | Y, the node table read once
-            torch.cuda.current_stream(self.device).synchronize()  # once per encoder output: other streams read Z, Y
-            hit = self._z_cache = (weakref.ref(x_node), x_node._version, zy[:, :d], zy[:, d:])
-        return hit[2], hit[3]
+            z = gemm(xr, w["w_rx"], w["b_r"], tag="gemm_node_keys")    # [N, D]
+            torch.cuda.current_stream(self.device).synchronize()  # once per encoder output: other streams read Z
+            hit = self._z_cache = (weakref.ref(x_node), x_node._version, z)
+        return hit[2]
+
+    def _node_y(self, x_node: torch.Tensor, w) -> torch.Tensor:
+        """Y = X_node W_l^T + b_l, lin_l per node (cached like Z): with it q_pair = Y[a] + Y[b] -- literally the
+        reference's expression (layers.py:212-215) -- is a gather-add per batch instead of a product."""
+        hit = getattr(self, "_y_cache", None)
+        if hit is None or hit[0]() is not x_node or hit[1] != x_node._version:
+            y = gemm(_as_f32_rows(x_node), w["w_l"], w["b_l"], tag="gemm_node_query")
+            torch.cuda.current_stream(self.device).synchronize()  # once per encoder output: other streams read Y
+            hit = self._y_cache = (weakref.ref(x_node), x_node._version, y)
+        return hit[2]
+
+    def _pair_q(self, batch, x_node, w) -> torch.Tensor:
+        """q_pair = lin_l(x_a) + lin_l(x_b)  (layers.py:212-215) on the current stream.  ``query_from``:
+        "table" -- Y[a] + Y[b] from the per-node table ``_node_y`` (one N x D x D product per ENCODER OUTPUT, then 12 us
+        of gather per batch: the evaluation pattern, one encoder pass for thousands of batches);
+        "gemm"  -- W_l (x_a + x_b) + 2 b_l per batch, the endpoint rows gathered and added inside the first stage of
+        ``lpf_dense_chain_f32`` (in_mode 2; 19 us per collab-like batch, nothing per encoder output: the
+        ``test_edge`` pattern, one encoder pass per batch)."""
+        if self.query_from == "table":
+            y = self._node_y(x_node, w)
+            bs, d = batch.shape[1], self.dim
+            q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+            with KernelTimer.span("pair_gather_q"):
+                check(_lib.hip().lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0),
+                                                     None, 0, ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
+            return q
+        lin_l = self.att_layers[0].att.lin_l
+        t = self._chain_q.tables(lin_l.weight, w["b_l2"])
+        q = self._chain_q.run(t, x_node, relu=False, batch=batch, in_mode=2)
+        if q is None:   # (a shape without a fused instantiation: gather-add, then the plain product)
+            bs, d = batch.shape[1], x_node.shape[1]
+            xs = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+            check(_lib.hip().lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), x_node.shape[0], ptr(x_node),
+                                                 x_node.stride(0), None, 0, ptr(xs), d, _stream(self.device)),
+                  "lpf_pair_gather_f32")
+            q = gemm(xs, lin_l.weight, w["b_l2"], tag="pair_q")
+        return q
 
     def _z_bf16(self, z: torch.Tensor) -> torch.Tensor:
         """bf16 copy of the node table Z (once per encoder output; the storage format of the bf16 throughput mode)."""
@@ -971,8 +1033,8 @@ class LinkTransformer(nn.Module):
                                      ptr(adjx.col) if adjx is not adj else None, ptr(val.col), ptr(val.val), None,
                                      ptr(t0.cv) if t0 is not None else None,
                                      ptr(t0.skip) if t0 is not None else None, float(self.thresh_cn),
-                                     float(self.thresh_1hop), float(self.thresh_non1hop), ptr(ws.type_ptr),
-                                     ptr(ws.entries), ws.ent_cap, 0, st), "lpf_select_run")
+                                     float(self.thresh_1hop), float(self.thresh_non1hop), 1 if self.mask == "cn" else 0,
+                                     ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, 0, st), "lpf_select_run")
 
     def _walk_index(self, mask_obj, ppr_obj) -> graph.WalkIndex:
         """The per-model indexes of the walk-plan selection for this (adjacency, PPR matrix) pair of ``self.data``,
@@ -992,9 +1054,6 @@ class LinkTransformer(nn.Module):
         ppr_obj, mask_obj = self._data_obj("ppr", test_set), self._data_obj("mask", test_set)
         if adj_mask is None and self.use_select_index:
             return self._walk_index(mask_obj, ppr_obj)
-        if self.mask == "cn":
-            raise NotImplementedError("mask mode 'cn' runs on the walk indexes only (no adjacency override, "
-                                      "use_select_index = True)")
         ppr = self._device_graph("ppr", ppr_obj)
         adjx = self._device_graph("mask", mask_obj)
         adj = adjx if adj_mask is None else self._device_graph("mask", adj_mask)
@@ -1220,12 +1279,9 @@ class LinkTransformer(nn.Module):
         lib, st, d = _lib.hip(), _stream(self.device), self.dim
         bs = batch.shape[1]
         w = self._fold()
-        z, y = self._node_keys(x_node, w)
-        q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+        z = self._node_keys(x_node, w)
         with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
-            with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
-                check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0), None, 0,
-                                              ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
+            q = self._pair_q(batch, x_node, w)
         ws = self._select_device(batch, test_set, adj_mask)
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
@@ -1250,12 +1306,9 @@ class LinkTransformer(nn.Module):
         lib, st, d = _lib.hip(), _stream(self.device), self.dim
         bs = batch.shape[1]
         w = self._fold()
-        z, y = self._node_keys(x_node, w)
-        q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+        z = self._node_keys(x_node, w)
         with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
-            with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
-                check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0), None, 0,
-                                              ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
+            q = self._pair_q(batch, x_node, w)
         ws = self._select_device(batch, test_set, adj_mask)
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
@@ -1323,14 +1376,10 @@ class LinkTransformer(nn.Module):
                 self._last_att = feats[:, :d]
                 return feats, None, True   # (unchecked: calc_pairwise reads the status back after queueing its own work)
             w = self._fold()
-            z, y = self._node_keys(x_node, w)
-
-            q = torch.empty(bs, d, dtype=torch.float32, device=self.device)
+            z = self._node_keys(x_node, w)
             side = self._fork()
             with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
-                with KernelTimer.span("pair_gather_q"):  # q = Y[a] + Y[b]
-                    check(lib.lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), y.shape[0], ptr(y), y.stride(0), None, 0,
-                                                  ptr(q), d, _stream(self.device)), "lpf_pair_gather_f32")
+                q = self._pair_q(batch, x_node, w)
 
             s = self._select(batch, test_set, adj_mask)
             if side is not None:

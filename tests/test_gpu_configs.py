@@ -387,7 +387,8 @@ def test_graphed_scorer_survives_cache_replacement_staleness_and_overflow():
     # (c) overflow: workspace of s3 is sized from a sparse batch, the hub batch does not fit
     s3 = lpformer_amd.GraphedScorer(model, score, h, b0, logits=True)
     bad = s3(bd)
-    assert not s3.check() and torch.isnan(bad).all()
+    all_nan = bool(torch.isnan(bad).all().item())    # (read before check(): a re-capture recycles the result tensor)
+    assert not s3.check() and all_nan
     good = s3(bd).clone()
     assert s3.check() and torch.isfinite(good).all()
     assert torch.equal(good, model.score_pairs(bd, h, score, logits=True))
@@ -597,3 +598,39 @@ def test_fused_gcn_layer_matches_two_launches(dim, f_in):
     # launch-to-launch determinism
     again = model._layer(last, a_hat, plain_layers[last], lo, hi)
     assert torch.equal(blk, again)
+
+
+@pytest.mark.parametrize("dim,residual", [(32, False), (64, True), (128, False)])
+def test_node_keys_chained_to_the_last_layer_match_the_separate_product(dim, residual):
+    """Z = X_node W_rx^T + b_r computed inside the last fused GCN layer's launch (csrc/gcn_fused.hip KEYS: the finished
+    rows are the second product's operands as they stand) against the separate lpf_gemm_f32 it replaces: same table to
+    rounding, same encoder output bitwise, same scores; hub rows, isolated nodes and a ragged last tile included."""
+    cfg = dict(D.CONFIGS["tiny"], dim=dim, residual=residual, gnn_layers=2, f_in=dim)
+    n = 3001
+    ei, w = D.chung_lu_graph(n, 14000, gamma=2.1, seed=dim, max_weight=4)
+    x = np.random.default_rng(dim).standard_normal((n, dim)).astype(np.float32)
+    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"])
+    args = D.train_args_for(cfg)
+    torch.manual_seed(1)
+    model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
+    score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(DEV).eval()
+    with torch.no_grad():
+        model.att_layers[0].att.lin_r.bias.add_(0.2 * torch.randn(dim, device=DEV))
+    batch = torch.from_numpy(D.sample_pairs(ei, n, 2048, seed=3)).to(DEV)
+    out = {}
+    for fused in (True, False):
+        model.fuse_node_keys = fused
+        model._z_cache = model._enc_cache = None
+        h = model.propagate()
+        assert (model._z_cache is not None) == fused          # the table came with the encoder output, or not yet
+        z = model._node_keys(h, model._fold()).clone()
+        s = model.score_pairs(batch, h, score, logits=True).clone()
+        assert model.check_selection()
+        out[fused] = (h.clone(), z, s)
+    assert torch.equal(out[True][0], out[False][0])
+    zs = max(1.0, float(out[False][1].abs().max()))
+    assert (out[True][1] - out[False][1]).abs().max().item() <= 2e-5 * zs
+    assert (out[True][2] - out[False][2]).abs().max().item() <= 2e-5 * max(1.0, float(out[False][2].abs().max()))
+    lin_r = model.att_layers[0].att.lin_r
+    want = out[True][0].double() @ lin_r.weight[:, :dim].double().T + lin_r.bias.double()
+    assert (out[True][1].double() - want).abs().max().item() <= 2e-5 * zs

@@ -1,6 +1,6 @@
 """The N > 1 encoder layouts under a real process group on the GPU box: WORLD ranks (child processes, backend gloo, all
 on the one MI355X of the box) run every layout of ``set_row_shard`` -- replicated, row-sharded with an all-gather per
-layer, and the single all-gather of [X_node | Z | Y] -- through ``propagate()`` and the pair stage and compare with the
+layer, and the single all-gather of [X_node | Z] -- through ``propagate()`` and the pair stage and compare with the
 unsharded result bit for bit (tests/dist_gpu_worker.py).  RCCL over xGMI needs more than one GPU, which the build loop
 does not have; what this pins is everything around the collective: row blocks (even and ragged), the order of the
 per-layer exchanges, the Z / Y hand-over of the single-gather layout, pair shards."""

@@ -70,7 +70,7 @@ def test_random_config_matches_oracle(case):
     tags = {"all": ("cn", "onehop", "non1hop"), "1-hop": ("cn", "onehop"), "cn": ("cn",)}[model.mask]
     assert all(i is None for i in model.compute_node_mask(torch.from_numpy(batch))[len(tags):])
     assert sum(ref["sel"][t][0].shape[1] for t in tags) > 100
-    for indexed in ((True, False) if model.mask != "cn" else (True,)):  # (mode "cn": walk indexes only)
+    for indexed in (True, False):   # walk indexes (select3.hip) and the general path over the raw PPR rows (select2.hip)
         model.use_select_index = indexed
         infos = model.compute_node_mask(torch.from_numpy(batch))
         for tag, info in zip(tags, infos):

@@ -40,7 +40,10 @@ def _build(z, cfg):
     model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV)
     score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, cfg["pred_layers"], 0.0).to(DEV)
     params = make_state(cfg["param_shapes"], cfg["seed"])
-    model.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in params.items() if k.startswith("model.")})
+    have = set(model.state_dict())     # (mask modes "1-hop" / "cn" own fewer positional encoders and count columns)
+    model.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in params.items()
+                           if k.startswith("model.") and k[6:] in have
+                           and tuple(v.shape) == tuple(model.state_dict()[k[6:]].shape)}, strict=False)
     score.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in params.items() if k.startswith("score.")})
     return model, score
 
@@ -135,3 +138,82 @@ def test_train_epoch_shaped_loop_runs_and_learns():
     with torch.no_grad():
         p = score(model(train_pos[:64].t()))
     assert torch.isfinite(p).all() and p.shape == (64,)
+
+
+def test_cn_mode_training_step_with_masked_adjacency():
+    """Mask mode "cn" (thresh_1hop = thresh_non1hop = 1; the reference's HeaRT citeseer / pubmed runs,
+    scripts/replicate_heart.sh:7,10 -- both TRAINING commands) through the training step: the batch's positive edges are
+    masked out of the typing adjacency (train_model.py:40-46), so the selection runs on the general path
+    (csrc/select2.hip, mode_cn).  The reference itself crashes in this mode on torch >= 2.1, so the check is
+    against the oracle's restatement: train-mode features (dropouts 0) == oracle == eval-mode inference kernels; the
+    gradient agrees with a central finite difference of the loss along two parameter directions; a short training loop
+    with the dropouts on reduces the loss."""
+    from oracle import lpformer_oracle as O
+    z, cfg = _load("train_step_d64")
+    cfg = dict(cfg, thresh_cn=1e-3, thresh_1hop=1.0, thresh_non1hop=1.0)
+    model, score = _build(z, cfg)
+    assert model.mask == "cn" and model.count_dim == 1
+    n = cfg["n"]
+    ei = z["edge_index"].astype(np.int64)
+    keep = torch.from_numpy(z["keep_edges"].astype(np.int64))
+    masked = SparseTensor.from_edge_index(keep, sparse_sizes=(n, n)).to_symmetric()
+    masked_adj = masked.to_torch_sparse_coo_tensor().coalesce().bool().int()
+    edges = torch.from_numpy(z["pos_edges"]).to(DEV)
+    neg = torch.from_numpy(z["neg_edges"]).to(DEV)
+
+    def loss_of():
+        h = model(edges, adj_mask=masked_adj)
+        hn = model(neg)
+        return (-torch.log(score(h) + 1e-6).mean() - torch.log(1 - score(hn) + 1e-6).mean()), h
+
+    model.train(); score.train()
+    loss, h_train = loss_of()
+    loss.backward()
+    # oracle: the same features with the masked typing adjacency (the >1-hop exclusion plays no role in this mode)
+    P = {f"model.{k}": v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    P.update({f"score.{k}": v.detach().cpu().numpy() for k, v in score.state_dict().items()})
+    kp = keep.numpy()
+    both = np.concatenate([kp, kp[::-1]], axis=1)
+    ppr = (np.asarray(model.data["ppr"].rowptr), np.asarray(model.data["ppr"].col).astype(np.int64),
+           np.asarray(model.data["ppr"].val))
+    ref = O.forward(z["pos_edges"], z["x"], O.gcn_norm(ei, z["edge_weight"], n), O.symmetric_mask_csr(both, n), ppr, P,
+                    dict(cfg, pred_layers=cfg["pred_layers"]))
+    assert set(ref["sel"]) == {"cn"} and ref["sel"]["cn"][0].shape[1] > 20
+    scale = max(1.0, float(np.abs(ref["combined_feats"]).max()))
+    assert np.abs(h_train.detach().cpu().numpy() - ref["combined_feats"]).max() <= 1e-4 * scale
+    model.eval(); score.eval()
+    with torch.no_grad():
+        h_eval = model(edges, adj_mask=masked_adj)
+    assert (h_eval - h_train.detach()).abs().max().item() <= 1e-4 * scale
+    # finite differences along two parameter directions
+    model.train(); score.train()
+    for p in (model.ppr_encoder_cn.linears[1].weight, model.pairwise_lin.linears[0].weight):
+        g = p.grad.detach().clone()
+        d = torch.randn_like(p)
+        d /= d.norm()
+        eps = 2e-2
+        with torch.no_grad():
+            p.add_(eps * d)
+            lp, _ = loss_of()
+            p.sub_(2 * eps * d)
+            lm, _ = loss_of()
+            p.add_(eps * d)
+        fd = (lp.item() - lm.item()) / (2 * eps)
+        an = float((g * d).sum())
+        assert abs(fd - an) <= 5e-2 * max(abs(an), 1e-3) + 2e-4, (fd, an)
+    # a short loop with the dropouts on
+    cfg2 = dict(cfg, att_drop=0.1, dropout=0.1, gnn_drop=0.1, feat_drop=0.1)
+    model2, score2 = _build(z, cfg2)
+    opt = torch.optim.Adam(list(model2.parameters()) + list(score2.parameters()), lr=5e-3)
+    torch.manual_seed(0)
+    losses = []
+    for _ in range(6):
+        model2.train(); score2.train()
+        l2 = (-torch.log(score2(model2(edges, adj_mask=masked_adj)) + 1e-6).mean()
+              - torch.log(1 - score2(model2(neg)) + 1e-6).mean())
+        l2.backward()
+        torch.nn.utils.clip_grad_norm_(model2.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        losses.append(l2.item())
+    assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0]

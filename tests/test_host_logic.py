@@ -236,7 +236,7 @@ def test_encoder_plan_cost_model():
     assert LD.encoder_plan(10.0, 2_927_963, 64, 3, 8, allgather_gbps=1000.0)["mode"] == "sharded"
     assert LD.encoder_plan(10.0, 2_927_963, 64, 3, 8, allgather_gbps=200.0)["mode"] == "replicated"
     assert LD.encoder_plan(5.0, 1000, 64, 3, 1, allgather_gbps=1.0)["mode"] == "replicated"
-    # the single all-gather of [X | Z | Y] (3 d floats per node against (L + 1) x d) wins where the LAST layer's
+    # the single all-gather of [X | Z] (2 d floats per node against (L + 1) x d) wins where the LAST layer's
     # aggregation and the per-node projections are most of the work -- a one-layer encoder with costly projections --
     # because it shards the projections too; with three layers and a fast exchange plain row sharding is cheaper
     p = LD.encoder_plan(10.0, 2_927_963, 64, 1, 8, allgather_gbps=500.0, last_agg_ms=9.5, node_keys_ms=4.0)
