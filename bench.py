@@ -71,7 +71,7 @@ from lpformer_amd import data as D  # noqa: E402
 from lpformer_amd import dist as LD  # noqa: E402
 from lpformer_amd.profile import KernelTimer  # noqa: E402
 
-PMC_FILE = "r03_pmc_traffic.json"  # committed rocprofv3 PMC passes the `traffic` figures are read from
+PMC_FILE = "r04_pmc_traffic.json"  # committed rocprofv3 PMC passes the `traffic` figures are read from
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 
@@ -748,9 +748,12 @@ def main():
                     raise KeyError("the committed PMC passes were collected on the collab-like workload, one GPU")
                 pmc_file = os.path.join("profiles", PMC_FILE)
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
+                rows_form = model._uses_rows()
                 for name, r in rooflines.items():
-                    if name in pmc["kernels"]:
-                        r["traffic"] = pmc["kernels"][name]["hbm_bytes_per_launch_corrected"]
+                    key = {"pair_attention_fused": "pair_attention_rows", "tail_chain": "tail_chain_rows"}.get(name, name) \
+                        if rows_form else name
+                    if key in pmc["kernels"]:
+                        r["traffic"] = pmc["kernels"][key]["hbm_bytes_per_launch_corrected"]
                         r["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes at {pmc.get('commit', '?')})"
             except (OSError, KeyError, ValueError):
                 pass

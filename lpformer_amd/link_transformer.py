@@ -1524,12 +1524,18 @@ class LinkTransformer(nn.Module):
                     gemm(prod, ew._pads[0].get(ew.linears[0].weight), ew.linears[0].bias, out=r[:, :d])
                     layernorm_(r[:, :d], ew.norm.weight, ew.norm.bias, relu=True)
             if (d in (32, 64, 128, 256) and self.use_tail_chain and self.use_fused_attention and bs > 0 and
-                    self._uses_rows()):
-                # hot path: 2 selection launches (nothing read back) -> pair-major attention (finished rows) -> the
-                # dense tail that is left: pairwise_lin's first layer, folded score head, sigmoid
+                    (self._uses_rows() or d == 256)):
+                # hot path: 2 selection launches (nothing read back) -> attention leaving finished rows -> the dense
+                # tail that is left: pairwise_lin's first layer, folded score head, sigmoid.  The rows come from the
+                # pair-major kernel or (D = 256 without it: the record-merging tail has no instantiation that wide) from
+                # the unit-major kernel + lpf_pair_attention_merge_f32
                 lib, st = _lib.hip(), _stream(self.device)
-                rows = self._zero_workspace("att_rows", bs * (d + 4), st).view(bs, d + 4)   # (pad columns stay zero)
-                ws = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim)
+                if self._uses_rows():
+                    rows = self._zero_workspace("att_rows", bs * (d + 4), st).view(bs, d + 4)   # (pad columns stay zero)
+                    ws = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim)
+                else:
+                    rows, _, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False)   # [BS, D + 4]
+                    ws = self._sel_ws(st, bs)
                 tt = self._tail_tables(score_func, a, c)
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):

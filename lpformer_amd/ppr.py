@@ -131,16 +131,31 @@ def ppr_cache_path(root: str, dataset: str, alpha: float, eps: float, is_val: bo
     return os.path.join(root, "node_subsets", "ppr", dataset, name)
 
 
+def _edge_fingerprint(edge_index, num_nodes: int) -> np.ndarray:
+    """(edge count, order-independent 64-bit checksum of the (row, col) pairs): cheap identity of an edge set."""
+    ei = np.asarray(edge_index.cpu() if hasattr(edge_index, "cpu") else edge_index, dtype=np.int64).reshape(2, -1)
+    key = ei[0].astype(np.uint64) * np.uint64(num_nodes) + ei[1].astype(np.uint64)
+    mixed = (key * np.uint64(0x9E3779B97F4A7C15)) ^ (key >> np.uint64(29))
+    return np.array([ei.shape[1], int(np.bitwise_xor.reduce(mixed)) if key.size else 0, int(mixed.sum(dtype=np.uint64))],
+                    dtype=np.uint64)
+
+
 def load_or_calc_ppr(edge_index, num_nodes: int, alpha: float = 0.15, eps: float = 5e-5, *, cache_root=None,
                      dataset: str = "graph", is_val: bool = False, device=None, num_threads: int = 0) -> CSR:
     """``get_ppr`` of the reference (calc_ppr_scores.py:245-270): load the cached matrix if present, otherwise run the
     producer (the GPU one when ``device`` is given, else the host one) and store the result."""
     import os
     path = None if cache_root is None else ppr_cache_path(cache_root, dataset, alpha, eps, is_val)
+    fp = _edge_fingerprint(edge_index, num_nodes)
     if path is not None and os.path.isfile(path):
         z = np.load(path)
         if int(z["num_nodes"]) != int(num_nodes):
             raise _lib.LpfError(f"{path}: cached PPR is for {int(z['num_nodes'])} nodes, not {num_nodes}")
+        # a cache is matched by NAME (dataset, alpha, eps) like the reference's; the edge fingerprint catches a file
+        # that was computed on another edge set under the same name (files written before it existed are trusted)
+        if "edge_fp" in z.files and not np.array_equal(z["edge_fp"], fp):
+            raise _lib.LpfError(f"{path}: cached PPR was computed on a different edge set (fingerprint mismatch); "
+                                "delete the file or use another dataset name")
         return CSR(z["rowptr"], z["col"], z["val"], int(num_nodes))
     csr = calc_ppr_gpu(edge_index, num_nodes, alpha, eps, device=device) if device is not None else \
         calc_ppr(edge_index, num_nodes, alpha, eps, num_threads)
@@ -148,7 +163,7 @@ def load_or_calc_ppr(edge_index, num_nodes: int, alpha: float = 0.15, eps: float
         os.makedirs(os.path.dirname(path), exist_ok=True)
         tmp = path + ".tmp.npz"
         np.savez(tmp, rowptr=csr.rowptr, col=csr.col, val=csr.val, num_nodes=np.int64(num_nodes),
-                 alpha=np.float64(alpha), eps=np.float64(eps))
+                 alpha=np.float64(alpha), eps=np.float64(eps), edge_fp=fp)
         os.replace(tmp, path)
     return csr
 
@@ -176,7 +191,6 @@ def get_ppr(dataset, edge_index, num_nodes, alpha, eps, is_val, *, root_dir=None
     import os
     root_dir = os.getcwd() if root_dir is None else root_dir
     ref_path = ppr_reference_cache_path(root_dir, dataset, alpha, eps, is_val)
-    os.makedirs(os.path.dirname(ref_path), exist_ok=True)
     try:
         from torch_sparse import SparseTensor  # noqa: F401  (only to read / write the reference's own cache format)
         have_ts = True
@@ -184,7 +198,12 @@ def get_ppr(dataset, edge_index, num_nodes, alpha, eps, is_val, *, root_dir=None
         have_ts = False
     if have_ts and os.path.isfile(ref_path):
         print("PPR matrix exists. Loading from file...", flush=True)
-        return torch.load(ref_path, weights_only=False).to_torch_sparse_coo_tensor()
+        # the reference pickles a torch_sparse.SparseTensor: allow-list exactly that class (and its storage) instead of
+        # unpickling whatever the file holds
+        from torch_sparse import SparseTensor
+        from torch_sparse.storage import SparseStorage
+        with torch.serialization.safe_globals([SparseTensor, SparseStorage]):
+            return torch.load(ref_path, weights_only=True).to_torch_sparse_coo_tensor()
     csr = load_or_calc_ppr(edge_index, int(num_nodes), alpha, eps, cache_root=root_dir, dataset=dataset, is_val=is_val,
                            device=device, num_threads=num_threads)
     coo = csr.to_torch_sparse_coo()
@@ -192,6 +211,7 @@ def get_ppr(dataset, edge_index, num_nodes, alpha, eps, is_val, *, root_dir=None
         from torch_sparse import SparseTensor
         ix = coo.indices()
         print(f"Saving data to {ref_path}...", flush=True)
+        os.makedirs(os.path.dirname(ref_path), exist_ok=True)   # (only when a file is actually written)
         torch.save(SparseTensor(row=ix[0], col=ix[1], value=coo.values(), sparse_sizes=(int(num_nodes),) * 2), ref_path)
     return coo
 

@@ -190,7 +190,8 @@ def test_flip_tables_reproduce_the_key_projection():
 
 def test_ppr_cache_round_trip(tmp_path):
     """load_or_calc_ppr: first call computes and stores under the reference's directory / file naming, the second
-    call reads the same matrix back; a cache for another graph size is refused."""
+    call reads the same matrix back; a cache for another graph size, or one that was computed on a different edge set
+    under the same name (edge fingerprint in the file), is refused."""
     rng = np.random.default_rng(0)
     n = 120
     ei = rng.integers(0, n, size=(2, 500))
@@ -198,8 +199,10 @@ def test_ppr_cache_round_trip(tmp_path):
     path = lpformer_amd.ppr.ppr_cache_path(str(tmp_path), "toy", 0.15, 1e-3, True)
     assert path.endswith(os.path.join("node_subsets", "ppr", "toy", "sparse_adj-015_eps-0001_val.lpf.npz"))
     assert os.path.isfile(path)
-    b = lpformer_amd.ppr.load_or_calc_ppr(np.zeros((2, 0), np.int64), n, 0.15, 1e-3, cache_root=str(tmp_path),
-                                          dataset="toy", is_val=True)  # edges ignored: served from the cache
+    b = lpformer_amd.ppr.load_or_calc_ppr(ei[:, ::-1].copy(), n, 0.15, 1e-3, cache_root=str(tmp_path),
+                                          dataset="toy", is_val=True)  # same edge set (any order): served from the cache
+    with pytest.raises(_lib.LpfError):                                 # another edge set under the same name
+        lpformer_amd.ppr.load_or_calc_ppr(ei[:, :400], n, 0.15, 1e-3, cache_root=str(tmp_path), dataset="toy", is_val=True)
     np.testing.assert_array_equal(a.rowptr, b.rowptr)
     np.testing.assert_array_equal(a.col, b.col)
     np.testing.assert_array_equal(a.val.view(np.uint32), b.val.view(np.uint32))

@@ -13,7 +13,9 @@ SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
     ("select3_run_kernel", "select_run"), ("select3_plan_kernel", "select_plan"),
     ("select_run_kernel", "select_run_general"), ("select_plan_kernel", "select_plan"), ("select_export", "select_export"),
     ("pair_flip_kernel", "pair_attention_fused"), ("pair_fused_kernel", "pair_attention_fused_mfma"),
-    ("tail_chain_kernel", "tail_chain"), ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"),
+    ("pair_rows_kernel", "pair_attention_rows"),
+    ("tail_chain_kernel<8, 9, 16, false, true>", "tail_chain_rows"), ("tail_chain_kernel", "tail_chain"),
+    ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"),
     ("pair_scores_", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
     ("pair_softmax_gather_kernel", "pair_softmax_gather_light"),
     ("gcn_fused_kernel", "gcn_layer_fused"), ("spmm_row_parts", "spmm_row_parts"),
