@@ -14,7 +14,9 @@ targs = dict(D.train_args_for(cfg), att_drop=0.1, dropout=0.1, gnn_drop=0.1, fea
 torch.manual_seed(0)
 model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev)
 score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2, 0.1).to(dev)
-opt = torch.optim.Adam(list(model.parameters()) + list(score.parameters()), lr=1e-3)
+# (LPF_FUSED_ADAM=1: one multi-tensor launch per optimiser step instead of a dozen small kernels per parameter)
+opt = torch.optim.Adam(list(model.parameters()) + list(score.parameters()), lr=1e-3,
+                       fused=bool(os.environ.get("LPF_FUSED_ADAM")))
 pos = torch.from_numpy(ei[:, ei[0] < ei[1]]).to(dev)
 class _ST:  # torch_sparse.SparseTensor look-alike on the device (what the reference's loop builds per batch)
     def __init__(self, r, c, v, n): self._r, self._c, self._v, self._n = r, c, v, n
