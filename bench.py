@@ -374,6 +374,8 @@ def main():
 
     # ---- which of the two forms of the activation-pattern attention?  (untimed probe, eager launches on the lanes)
     rows_probe = None
+    if os.environ.get("LPF_TAIL_SKIP_EMPTY"):                    # A/B aid: "0" = the plain rows tail
+        model.tail_skip_empty = os.environ["LPF_TAIL_SKIP_EMPTY"] != "0"
     if args.rows != "auto":
         model.attention_rows = args.rows == "on"
     elif model.attention_kernel() == "flip":

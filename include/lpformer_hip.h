@@ -474,6 +474,46 @@ int lpf_tail_chain_rows_bf16(int64_t M, int32_t D, int32_t n_counts, const float
                              const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob,
                              void *stream);
 
+/* The pair of launches with the pairs WITHOUT selected nodes handled apart.  Such a pair's attention branch is a constant
+ * -- softmax over nothing, so the row is post_att_norm(att_bias) with zero counts (layers.py:66-78,
+ * link_transformer.py:340-356) -- and so is everything pairwise_lin makes of it: its score needs the elementwise half of
+ * the folded head only.  lpf_pair_attention_rows_perm_* additionally leaves the ORDER the tail walks the pairs in:
+ *   perm int32[bs]: the pairs with selected nodes in ascending order, then -- from the back, descending towards the
+ *                   front -- the ones without;  *n_nonempty: how many have selected nodes.  (Deterministic: a chained scan
+ *                   over the workgroups, no atomics on a counter.)
+ *   perm_lb uint64[LPF_ROWS_PERM_LB_WORDS]: the scan's words; zero before the first launch, then left alone (the
+ *                   kernel tags them with a launch number it keeps in the last word).  One buffer per stream.
+ * lpf_tail_chain_rows_perm_* walks the pairs in that order; a workgroup whose 64 pairs all lie behind *n_full computes
+ *   score = w_dot . ReLU(A_e r_e + bC_empty) + b_dot,    bC_empty [2 D] = bC + A_p r_p0
+ * with r_p0 the hidden activation of pairwise_lin for the constant row (lpformer_amd/fold.py empty_pair_head_bias); every
+ * other workgroup runs the full tail (a mixed workgroup reads the empty pairs' rows, which hold the constant).  Outputs
+ * are indexed by pair as before. */
+#define LPF_ROWS_PERM_LB_WORDS 1025
+int lpf_pair_attention_rows_perm_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
+                                     const float *Z, int64_t ldz, const float *q, int64_t ldq,
+                                     const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                     const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
+                                     const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
+                                     int64_t units_cap, float *out, int64_t ldo, int32_t *perm, uint64_t *perm_lb,
+                                     int64_t *n_nonempty, void *stream);
+int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                       int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q, int64_t ldq,
+                                       const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                       const float *wfold_t, const float *att, const float *att_bias,
+                                       const float *ln_g, const float *ln_b, int32_t n_counts, const int64_t *sel_ctl,
+                                       float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
+                                       uint64_t *perm_lb, int64_t *n_nonempty, void *stream);
+int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                                 const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
+                                 const float *r_e, int64_t ldre, const float *wC_packed, const float *bC,
+                                 const float *w_dot, const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
+                                 const int64_t *n_full, const float *bC_empty, float *logit, float *prob, void *stream);
+int lpf_tail_chain_rows_perm_bf16(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                                  const void *wB_packed_bf16, const float *bB, const float *lnB_g, const float *lnB_b,
+                                  const float *r_e, int64_t ldre, const void *wC_packed_bf16, const float *bC,
+                                  const float *w_dot, const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
+                                  const int64_t *n_full, const float *bC_empty, float *logit, float *prob, void *stream);
+
 /* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
  * logit or prob may be NULL. */
 int lpf_rowdot_sigmoid_f32(int64_t M, int32_t K, const float *A, int64_t lda, const float *w, float b,

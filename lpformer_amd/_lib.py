@@ -14,6 +14,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "liblpformer_host.so")
 ABI_VERSION = 4
 FLAG_RELU = 1
 SELECT_ERR_NODE_RANGE, SELECT_ERR_ITEM_CAP, SELECT_ERR_ENTRY_CAP = 1, 2, 4
+ROWS_PERM_LB_WORDS = 1025      # LPF_ROWS_PERM_LB_WORDS (include/lpformer_hip.h)
 
 i32, i64, f32, f64, u32, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32, C.c_void_p
 
@@ -61,6 +62,14 @@ HIP_PROTOTYPES = {
                                     i64, vp, i64, vp],
     "lpf_pair_attention_rows_zbf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp,
                                       i64, vp, i64, vp],
+    "lpf_pair_attention_rows_perm_f32": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp,
+                                         vp, i64, vp, i64, vp, vp, vp, vp],
+    "lpf_pair_attention_rows_perm_zbf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32,
+                                           vp, vp, i64, vp, i64, vp, vp, vp, vp],
+    "lpf_tail_chain_rows_perm_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                     vp, vp],
+    "lpf_tail_chain_rows_perm_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                      vp, vp],
     "lpf_pair_rows_piece_floats": [i32],
     "lpf_tail_chain_rows_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lpf_tail_chain_rows_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],

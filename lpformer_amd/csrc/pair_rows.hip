@@ -29,10 +29,12 @@
 #include <type_traits>
 
 #include "pe_common.h"
+#include "select_common.h"   // the chained scan (lb_*): start of every workgroup's pairs in the order of the dense tail
 
 namespace {
 
 constexpr uint32_t PR_PAIR_MASK = 0x7fffffffu;
+constexpr int PR_LB_WORDS = LPF_ROWS_PERM_LB_WORDS - 1;   // scan words of the perm order (>= the largest grid: 3 workgroups x 256+ CUs)
 constexpr int PR_CHUNK = 512;    // pairs of the workgroup's range staged in LDS at a time
 constexpr int PR_FLAGS = 2048;   // units of a chunk whose completion is tracked in LDS (more: one barrier, then the merges)
 
@@ -54,6 +56,13 @@ struct RowsArgs {
     const int64_t *sel_ctl;    // selection control block: word 3 != 0 => the batch did not fit its workspace, rows = NaN
     float *pieces;             // [units_cap][2][RSP]: partial states of the pairs that cross 16-entry units
     int64_t units_cap;
+    // optional: the order in which the dense tail takes the pairs -- those WITH selected nodes first (ascending), those
+    // without behind them (filled from the back) -- so that whole tiles of the tail hold pairs of one kind.  Deterministic
+    // (a chained scan over the workgroups' counts, not atomics): a replayed step stays bitwise the eager one.
+    int32_t *perm;             // [bs]
+    uint64_t *perm_lb;         // [PR_LB_WORDS + 1] chained-scan words (tagged with the launch number, never cleared) + the
+                               // launch counter
+    int64_t *n_nonempty;       // receives the number of pairs with selected nodes
 };
 
 template <int CTRL>
@@ -105,7 +114,8 @@ struct PrLds {
     static constexpr int LISTS = CUM + (PR_CHUNK / 4 + 1);   // int [2][PR_CHUNK]: empty pairs, pairs in several pieces
     static constexpr int CTL = LISTS + 2 * (PR_CHUNK / 4);   // int [16]: counters, ticket, range
     static constexpr int FLAGS = CTL + 4;                    // int [PR_FLAGS]: unit u of the chunk is done
-    static constexpr int TOTAL = FLAGS + PR_FLAGS / 4;
+    static constexpr int WCNT = FLAGS + PR_FLAGS / 4;        // int [32]: per-wavefront counts (ranks of the tail's order)
+    static constexpr int TOTAL = WCNT + 8;
     static constexpr size_t BYTES = (size_t)TOTAL * 16;
 };
 
@@ -128,8 +138,9 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     int *const ltp = reinterpret_cast<int *>(pr_lds + L::TP);
     int *const lcum = reinterpret_cast<int *>(pr_lds + L::CUM);
     int *const llist = reinterpret_cast<int *>(pr_lds + L::LISTS);
-    int *const lctl = reinterpret_cast<int *>(pr_lds + L::CTL);   // 0: n_empty 1: n_multi 2: unit ticket 4,5: P0 6,7: P1
+    int *const lctl = reinterpret_cast<int *>(pr_lds + L::CTL);   // 0: n_empty 1: n_multi 2: unit ticket 4,5: P0 6,7: P1 8-11: the order (base, own count, launch number)
     int *const lflag = reinterpret_cast<int *>(pr_lds + L::FLAGS);
+    int *const lwcnt = reinterpret_cast<int *>(pr_lds + L::WCNT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane / G, lj = lane % G, off = 4 * lj;
     const int gid = wave * EPW + grp;            // this group among the workgroup's NG
 #ifdef PR_STAMPS
@@ -204,6 +215,27 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     PR_STAMP(1);
     const int64_t P0 = (int64_t)(uint32_t)lctl[4] | ((int64_t)lctl[5] << 32);
     const int64_t P1 = (int64_t)(uint32_t)lctl[6] | ((int64_t)lctl[7] << 32);
+
+    // ---- the tail's order, first half: publish how many pairs of this workgroup's range select anything (word
+    //      blockIdx.x of perm_lb, tagged with this launch's number: word PR_LB_WORDS counts the launches).  The second half
+    //      -- the sum over the workgroups in front, then the order itself -- waits until the rows are done: by then every
+    //      predecessor's word has long been out, nobody spins on a workgroup that is not resident yet.
+    if (A.perm) {
+        int cnt = 0;
+        for (int64_t k = P0 + tid; k < P1; k += NTH) cnt += cum_at(k + 1) > cum_at(k) ? 1 : 0;
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) cnt += __shfl_xor(cnt, dlt, 64);
+        if (lane == 0) lwcnt[wave] = cnt;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < NTH / 64; ++w) tot += lwcnt[w];
+            const uint32_t epoch = (uint32_t)(A.perm_lb[PR_LB_WORDS] + 1ull) & ((1u << 22) - 1u);
+            lb_store(A.perm_lb + blockIdx.x, epoch, 1, (uint64_t)tot);
+            lctl[10] = tot;
+            lctl[11] = (int)epoch;
+        }
+    }
 
     // finished row of a pair from its (merged) softmax state: post_att_norm(o / (l + 1e-16) + bias)
     auto finish_row = [&](f32x2 o01, f32x2 o23, float l) __attribute__((always_inline)) {
@@ -547,6 +579,63 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         }
         PR_STAMP(5);
     }
+    // ---- the tail's order, second half: pairs with selected nodes in ascending order from the front, the others from
+    //      the back.  Deterministic (sums of published counts, ranks from ballots -- no atomics on a counter): a replayed
+    //      step stays bitwise the eager one.
+    if (A.perm) {
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t epoch = (uint32_t)lctl[11];
+            const int64_t nb = blockIdx.x;
+            uint64_t sum = 0;
+            for (int64_t j0 = 0; j0 < nb; j0 += 256) {   // four words per lane and round trip
+                uint64_t w[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t idx = j0 + 64 * b + lane;
+                    w[b] = idx < nb ? __hip_atomic_load(A.perm_lb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t idx = j0 + 64 * b + lane;
+                    if (idx < nb) {
+                        if (!((uint32_t)(w[b] >> 42) == epoch && ((w[b] >> 40) & 3ull) != 0ull))
+                            w[b] = lb_wait(A.perm_lb + idx, epoch);
+                        sum += w[b] & LB_VAL_MASK;
+                    }
+                }
+            }
+            sum = lb_wave_sum(sum);
+            if (lane == 0) {
+                lctl[8] = (int)(sum & 0xffffffff); lctl[9] = (int)(sum >> 32);
+                if (blockIdx.x == gridDim.x - 1) {   // (it has seen every other workgroup's word: they all read the counter)
+                    *A.n_nonempty = (int64_t)sum + lctl[10];
+                    A.perm_lb[PR_LB_WORDS] = (uint64_t)epoch;
+                }
+            }
+        }
+        __syncthreads();
+        int64_t ne_base = (int64_t)(uint32_t)lctl[8] | ((int64_t)lctl[9] << 32);   // pairs with entries in front
+        for (int64_t k0 = P0; k0 < P1; k0 += NTH) {
+            const int64_t k = k0 + tid;
+            const bool in = k < P1;
+            const bool ne = in && cum_at(k + 1) > cum_at(k);
+            const uint64_t b_ne = __ballot(ne), b_all = __ballot(in);
+            if (lane == 0) { lwcnt[wave] = __popcll(b_ne); lwcnt[16 + wave] = __popcll(b_all); }
+            __syncthreads();
+            int pre_ne = 0, pre_all = 0, tot_ne = 0;
+            for (int w = 0; w < NTH / 64; ++w) {
+                if (w < wave) { pre_ne += lwcnt[w]; pre_all += lwcnt[16 + w]; }
+                tot_ne += lwcnt[w];
+            }
+            const uint64_t lt = (1ull << lane) - 1ull;
+            const int r_ne = pre_ne + __popcll(b_ne & lt), r_all = pre_all + __popcll(b_all & lt);
+            if (ne) A.perm[ne_base + r_ne] = (int32_t)k;
+            else if (in) A.perm[A.bs - 1 - ((k0 - ne_base) + (r_all - r_ne))] = (int32_t)k;
+            __syncthreads();
+            ne_base += tot_ne;
+        }
+    }
 #ifdef PR_STAMPS
     if (lane == 0 && pr_stamp_buf) {
         uint64_t *o = pr_stamp_buf + ((int64_t)blockIdx.x * (NTH / 64) + wave) * 8;
@@ -562,11 +651,13 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
                 int64_t ldz, const float *q, int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
                 const float *base, const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
                 const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
-                int64_t ldo, void *stream) {
+                int64_t ldo, void *stream, int32_t *perm = nullptr, uint64_t *perm_lb = nullptr,
+                int64_t *n_nonempty = nullptr) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && type_ptr && entries && ent_cap > 0 && ent_cap < (1ll << 29) && Z && q &&
                 pe_tab_signed && pe_stat && base && wfold_t && att && att_bias && ln_g && ln_b && out && pieces &&
                 units_cap >= (3 * ent_cap + 15) / 16 + 1 && lpf_aligned16(pieces));
+    LPF_REQUIRE(!perm || (perm_lb && n_nonempty));
     LPF_REQUIRE((n_counts == 0 || n_counts == 1 || n_counts == 3 || n_counts == 4) && ldo >= D + n_counts && (ldo & 3) == 0);
     LPF_REQUIRE(ldz >= D && ldq >= D && ldz < (1ll << 31) && ldq < (1ll << 31) && (ldz & (ZB ? 7 : 3)) == 0 &&
                 (ldq & 3) == 0 && lpf_aligned16(entries) && lpf_aligned16(Z) && lpf_aligned16(q) &&
@@ -574,7 +665,7 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
                 lpf_aligned16(att_bias) && lpf_aligned16(ln_g) && lpf_aligned16(ln_b) && lpf_aligned16(out));
     const RowsArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), (uint32_t)ldz,
                      q, (uint32_t)ldq, pe_tab_signed, pe_stat, base, wfold_t, att, att_bias, ln_g, ln_b, out, ldo,
-                     n_counts, sel_ctl, pieces, units_cap};
+                     n_counts, sel_ctl, pieces, units_cap, perm, perm_lb, n_nonempty};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_cu = lpf_cu_count();
     if (n_cu == 0) return LPF_ERR_NO_DEVICE;
@@ -586,6 +677,7 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
         int64_t groups = (int64_t)n_cu * PER_CU;                                                    \
         const int64_t most = (bs + 15) / 16;   /* (a workgroup per 16 pairs at the very least) */   \
         if (groups > most) groups = most;                                                           \
+        if (groups > PR_LB_WORDS) groups = PR_LB_WORDS;                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(NTH), lds, s, a);                     \
     } while (0)
     switch (D) {
@@ -629,6 +721,38 @@ extern "C" int lpf_pair_rows_set_stamps(void *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(pr_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? LPF_OK : LPF_ERR_LAUNCH;
 }
 #endif
+
+/* lpf_pair_attention_rows_f32 / _zbf16 that also leave the ORDER for lpf_tail_chain_rows_perm_*: perm int32[bs] = the
+ * pairs with selected nodes in ascending order, then (from the back) those without; perm_lb: uint64 scratch of
+ * LPF_ROWS_PERM_LB_WORDS words, zero before the first launch and then left alone (chained-scan words tagged with a launch
+ * number the kernel keeps in the last word); *n_nonempty: the count. */
+extern "C" int lpf_pair_attention_rows_perm_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                                int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
+                                                const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                                const float *wfold_t, const float *att, const float *att_bias,
+                                                const float *ln_g, const float *ln_b, int32_t n_counts,
+                                                const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
+                                                int64_t ldo, int32_t *perm, uint64_t *perm_lb, int64_t *n_nonempty,
+                                                void *stream) {
+    LPF_REQUIRE(perm && perm_lb && n_nonempty);
+    return rows_launch<false>(D, bs, type_ptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t, att,
+                              att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream, perm, perm_lb,
+                              n_nonempty);
+}
+
+extern "C" int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries,
+                                                  int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q,
+                                                  int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
+                                                  const float *base, const float *wfold_t, const float *att,
+                                                  const float *att_bias, const float *ln_g, const float *ln_b,
+                                                  int32_t n_counts, const int64_t *sel_ctl, float *pieces,
+                                                  int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
+                                                  uint64_t *perm_lb, int64_t *n_nonempty, void *stream) {
+    LPF_REQUIRE(perm && perm_lb && n_nonempty);
+    return rows_launch<true>(D, bs, type_ptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t,
+                             att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream, perm, perm_lb,
+                             n_nonempty);
+}
 
 /* floats of one piece record of lpf_pair_attention_rows_* (D accumulators, m, l, padded to whole 128-byte lines) */
 extern "C" int64_t lpf_pair_rows_piece_floats(int32_t D) { return pr_piece_floats(D); }

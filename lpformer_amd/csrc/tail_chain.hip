@@ -50,6 +50,13 @@ struct TailArgs {
     // rows mode (rows != nullptr): stage A is already done -- lpf_pair_attention_rows_* left one finished row per pair,
     // [post_att_norm(attention output) (NA) | count features (4, zero padded)] -- and is a plain read
     const float *rows; int64_t ldrows;
+    // rows mode, optional: the pairs are taken in the order perm[] (lpf_pair_attention_rows_perm_*: those with selected
+    // nodes first, *n_full of them, the others behind).  A workgroup whose 64 pairs all lie behind *n_full skips stage
+    // A, stage B and the r_p half of stage C: the pairwise branch of a pair without selected nodes is a constant, folded
+    // into bC_empty on the host (fold.empty_pair_head_bias).
+    const int32_t *perm;
+    const int64_t *n_full;
+    const float *bC_empty;
 };
 
 constexpr int tc_per_thread(int ntp) { return (ntp * 64 + TC_THREADS - 1) / TC_THREADS; }
@@ -184,10 +191,67 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
     f32x4 *my_hid = hid + (grp * S::HT) * 64 + lane;
     int buf = 0;
 
-    const int64_t m = (int64_t)blockIdx.x * (16 * TC_GROUPS) + grp * 16 + j;
-    const bool live = m < A.M;
-    const int64_t mm = live ? m : A.M - 1;  // dead lanes compute on a valid row and store nothing
+    // (With an order the short workgroups are the LAST ones of the grid.  Dealing the tiles from both ends instead, a short
+    // workgroup next to every full one on a CU, measured worse: collab-like 0.205 against 0.186 ms per pipelined step, the
+    // launch alone unchanged at 55 us -- what the short workgroups buy is a grid that drains early for the next kernel.)
+    const int64_t tile = blockIdx.x;
+    const int64_t pos = tile * (16 * TC_GROUPS) + grp * 16 + j;
+    const bool live = pos < A.M;
+    bool lite = false;          // (rows mode with an order: every pair of this workgroup is one without selected nodes)
+    int64_t m = pos;
+    if constexpr (ROWS) {
+        if (A.perm) {
+            m = A.perm[live ? pos : A.M - 1];
+            lite = tile * (16 * TC_GROUPS) >= *A.n_full;
+        }
+    }
+    const int64_t mm = live ? m : (ROWS && A.perm ? m : A.M - 1);  // dead lanes compute on a valid row and store nothing
 
+    if constexpr (ROWS) {
+        if (lite) {
+            // ---- 64 pairs without selected nodes: score = w_dot . ReLU(A_e r_e + bC_empty) + b_dot -- stage C over the
+            //      r_e k-groups alone (35 % of the matrix work of a full workgroup), nothing else
+            f32x4 acc[TPWC];
+#pragma unroll
+            for (int c = 0; c < TPWC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            WT wr[S::PC];
+            tc_load<S::PC, NTPC>(wr, A.wC, 0, tid);
+            const float *rer = A.re + mm * A.ldre + 4 * q;
+            f32x4 xr = *reinterpret_cast<const f32x4 *>(rer);
+#pragma unroll 1
+            for (int kg = 0; kg < NGE; ++kg) {
+                const f32x4 bv = xr;
+                WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
+                tc_store<S::PC>(wr, lw, tid);
+                __syncthreads();
+                if (kg + 1 < NGE) {
+                    tc_load<S::PC, NTPC>(wr, A.wC, kg + 1, tid);
+                    xr = *reinterpret_cast<const f32x4 *>(rer + 16 * (kg + 1));
+                }
+                tc_mfma<TPWC>(acc, lw + (half * TPWC) * 64 + lane, bv);
+                buf ^= 1;
+            }
+            const int fbase = 16 * half * TPWC + 4 * q;
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < TPWC; ++c) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(A.bC_empty + fbase + 16 * c);
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(A.wdot + fbase + 16 * c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d = fmaf(fmaxf(acc[c][r] + b[r], 0.f), w[r], d);
+            }
+            d = tc_quad_sum(d);
+            if (q == 0) *my_x = d;
+            __syncthreads();
+            if (live && q == 0 && half == 0) {
+                d = d + *peer_x + A.bdot[0];
+                if (A.sel_ctl && A.sel_ctl[3] != 0) d = __builtin_nanf("");
+                if (A.logit) A.logit[m] = d;
+                if (A.prob) A.prob[m] = 1.0f / (1.0f + expf(-d));
+            }
+            return;
+        }
+    }
     // ------------------------------------------------------------------ stage A: attention output + post-norm
     f32x4 accA[TPWA];
 #pragma unroll
@@ -448,7 +512,7 @@ extern "C" int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const 
                 lpf_aligned16(w_dot));
     TailArgs a{M, G + D, ldg, 3 * D + 4, G, ldg, wA_packed, lnA_g, lnA_b, D, counts, ldc, wB_packed, bB, lnB_g,
                lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
-               nullptr, nullptr, 0, nullptr, nullptr, nullptr, n_counts, nullptr, 0};
+               nullptr, nullptr, 0, nullptr, nullptr, nullptr, n_counts, nullptr, 0, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);
@@ -473,7 +537,7 @@ extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, 
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0, wB_packed, bB, lnB_g,
                lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
-               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0};
+               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);
@@ -501,7 +565,7 @@ extern "C" int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts,
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0,
                static_cast<const float *>(wB_packed_bf16), bB, lnB_g, lnB_b, D + n_counts, r_e, ldre,
                static_cast<const float *>(wC_packed_bf16), bC, 2 * D, w_dot, b_dot, logit, prob,
-               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0};
+               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4, true>(a, s);
@@ -517,8 +581,10 @@ namespace {
 template <bool WB>
 int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows, const void *wB, const float *bB,
             const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre, const void *wC, const float *bC,
-            const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob, void *stream) {
+            const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob, void *stream,
+            const int32_t *perm = nullptr, const int64_t *n_full = nullptr, const float *bC_empty = nullptr) {
     if (M == 0) return LPF_OK;
+    LPF_REQUIRE(!perm || (n_full && bC_empty && lpf_aligned16(bC_empty)));
     LPF_REQUIRE(M > 0 && rows && wB && bB && lnB_g && lnB_b && r_e && wC && bC && w_dot && b_dot && (logit || prob));
     LPF_REQUIRE((n_counts == 1 || n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D && (ldrows & 3) == 0 &&
                 ldrows >= D + 4);
@@ -526,7 +592,7 @@ int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t l
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, D, nullptr, 0, static_cast<const float *>(wB), bB,
                lnB_g, lnB_b, D + n_counts, r_e, ldre, static_cast<const float *>(wC), bC, 2 * D, w_dot, b_dot, logit, prob,
-               nullptr, nullptr, 0, nullptr, nullptr, sel_ctl, n_counts, rows, ldrows};
+               nullptr, nullptr, 0, nullptr, nullptr, sel_ctl, n_counts, rows, ldrows, perm, n_full, bC_empty};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4, WB, true>(a, s);
@@ -554,4 +620,31 @@ extern "C" int lpf_tail_chain_rows_bf16(int64_t M, int32_t D, int32_t n_counts, 
                                         float *prob, void *stream) {
     return tc_rows<true>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
                          b_dot, sel_ctl, logit, prob, stream);
+}
+
+/* lpf_tail_chain_rows_* taking the pairs in the order lpf_pair_attention_rows_perm_* left: perm int32[M], *n_full = how
+ * many of them (the first ones) have selected nodes.  Workgroups whose 64 pairs all lie behind *n_full compute
+ * score = w_dot . ReLU(A_e r_e + bC_empty) + b_dot only -- bC_empty [2D] = bC + A_p r_p0 with r_p0 the (constant) hidden
+ * activation of pairwise_lin for a pair without selected nodes (lpformer_amd/fold.py empty_pair_head_bias). */
+extern "C" int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                                            const float *wB_packed, const float *bB, const float *lnB_g,
+                                            const float *lnB_b, const float *r_e, int64_t ldre, const float *wC_packed,
+                                            const float *bC, const float *w_dot, const float *b_dot,
+                                            const int64_t *sel_ctl, const int32_t *perm, const int64_t *n_full,
+                                            const float *bC_empty, float *logit, float *prob, void *stream) {
+    LPF_REQUIRE(perm && n_full && bC_empty);
+    return tc_rows<false>(M, D, n_counts, rows, ldrows, wB_packed, bB, lnB_g, lnB_b, r_e, ldre, wC_packed, bC, w_dot, b_dot,
+                          sel_ctl, logit, prob, stream, perm, n_full, bC_empty);
+}
+
+extern "C" int lpf_tail_chain_rows_perm_bf16(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                                             const void *wB_packed_bf16, const float *bB, const float *lnB_g,
+                                             const float *lnB_b, const float *r_e, int64_t ldre,
+                                             const void *wC_packed_bf16, const float *bC, const float *w_dot,
+                                             const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
+                                             const int64_t *n_full, const float *bC_empty, float *logit, float *prob,
+                                             void *stream) {
+    LPF_REQUIRE(perm && n_full && bC_empty);
+    return tc_rows<true>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
+                         b_dot, sel_ctl, logit, prob, stream, perm, n_full, bC_empty);
 }

@@ -186,9 +186,31 @@ def dense_chain_tables(w1, b1, ln_g=None, ln_b=None, w2=None, b2=None) -> dict:
     return out
 
 
-def tail_chain_tables(wcat, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b, a_fold, c_fold, w_dot, b_dot, dim: int) -> dict:
+def empty_pair_head_bias(att_bias, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b, a_fold, c_fold, dim: int) -> np.ndarray:
+    """Bias of the folded score head for a pair WITHOUT selected nodes, float64 on the host: its attention output is
+    post_att_norm(0 / (0 + 1e-16) + bias) (layers.py:78,220), its count features are zero
+    (link_transformer.py:340-356), so its whole pairwise branch is a constant vector
+        r_p0 = ReLU(LN_B(W_p0 [LN_A(att_bias) | 0] + b_p0))
+    and the head sees  A_e r_e + (c + A_p r_p0).  Returns c + A_p r_p0 (fp32, [2D])."""
+    f64 = lambda t: np.asarray(t, np.float64)  # noqa: E731
+
+    def ln(x, g, b):
+        mu = x.mean()
+        return (x - mu) / np.sqrt(((x - mu) ** 2).mean() + 1e-5) * f64(g)[:x.size] + f64(b)[:x.size]
+
+    w_p0 = f64(w_p0)
+    pd = w_p0.shape[0]
+    feats = np.zeros(w_p0.shape[1])
+    feats[:dim] = ln(f64(att_bias), lnA_g, lnA_b)
+    r_p0 = np.maximum(ln(w_p0 @ feats + f64(b_p0), lnB_g, lnB_b), 0.0)
+    return (f64(c_fold) + f64(a_fold)[:, dim:dim + pd] @ r_p0).astype(np.float32)
+
+
+def tail_chain_tables(wcat, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b, a_fold, c_fold, w_dot, b_dot, dim: int,
+                      att_bias=None) -> dict:
     """fp32 arrays of one lpf_tail_chain_f32 call.  ``a_fold`` [2D, D + pd] = [A_e | A_p] (LinkTransformer._score_fold);
-    its r_p columns are moved behind the D r_e columns on an even-tile boundary, as the kernel walks them."""
+    its r_p columns are moved behind the D r_e columns on an even-tile boundary, as the kernel walks them.
+    ``att_bias``: adds ``bC_empty`` (``empty_pair_head_bias``)."""
     wcat, w_p0, a_fold = (np.asarray(t, np.float32) for t in (wcat, w_p0, a_fold))
     pd = w_p0.shape[0]
     ntpb = ((pd + 15) // 16 + 1) & ~1
@@ -204,4 +226,6 @@ def tail_chain_tables(wcat, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b, a_fold, c_fo
         "wC": pack_dense(wc, 1), "bC": np.asarray(c_fold, np.float32).reshape(-1).copy(),
         "w_dot": np.asarray(w_dot, np.float32).reshape(-1).copy(),
         "b_dot": np.asarray(b_dot, np.float32).reshape(-1)[:1].copy(),
+        **({} if att_bias is None else {"bC_empty": empty_pair_head_bias(att_bias, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b,
+                                                                       a_fold, c_fold, dim)}),
     }

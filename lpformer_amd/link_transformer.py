@@ -569,6 +569,9 @@ class LinkTransformer(nn.Module):
         # its finished row [post_att_norm(attention output) | counts] -- no records for the tail to chase and merge.
         # False: the unit-major kernel (csrc/pair_flip.hip) + record merge, as the matrix-core kernel always does.
         self.attention_rows = True
+        # behind the pair-major kernel: hand the dense tail the pairs with selected nodes first and let the workgroups that
+        # see only pairs without any (their attention branch is a constant) run the elementwise half of the head alone
+        self.tail_skip_empty = True
         # "f32" (parity mode, logits within 1e-4 of the reference) or "bf16" (throughput mode of score_pairs: the node
         # table Z is stored in bf16 and Wfold h runs on the bf16 matrix cores; selection and everything else as in f32)
         self.precision = "f32"
@@ -1273,9 +1276,11 @@ class LinkTransformer(nn.Module):
         """True when the one-pass attention runs pair-major and hands over finished rows (csrc/pair_rows.hip)."""
         return self.attention_rows and self.attention_kernel() == "flip"
 
-    def _attention_rows(self, batch, x_node, test_set, adj_mask, side, out, n_counts):
+    def _attention_rows(self, batch, x_node, test_set, adj_mask, side, out, n_counts, order=False):
         """q gather -> selection -> pair-major one-pass attention writing ``out[p] = [post_att_norm(attention output) |
-        n_counts count features]`` (``out``: [BS, ld] fp32, ld % 4 == 0).  Returns the selection workspace."""
+        n_counts count features]`` (``out``: [BS, ld] fp32, ld % 4 == 0).  Returns the selection workspace; with
+        ``order`` also (perm int32[BS], n_nonempty int64[1]): the pairs with selected nodes first, for
+        ``lpf_tail_chain_rows_perm_*``."""
         lib, st, d = _lib.hip(), _stream(self.device), self.dim
         bs = batch.shape[1]
         w = self._fold()
@@ -1288,16 +1293,20 @@ class LinkTransformer(nn.Module):
         layer = self.att_layers[0]
         units_cap = (3 * ws.ent_cap + 15) // 16 + 1
         pieces = self._workspace("att_pieces", units_cap * 2 * int(lib.lpf_pair_rows_piece_floats(d)), torch.float32, st)
+        extra = ()
+        if order:
+            perm = self._workspace("att_perm", bs, torch.int32, st)
+            nfull = self._workspace("att_nfull", 1, torch.int64, st)
+            extra = (ptr(perm), ptr(self._zero_workspace("att_perm_lb", 2 * _lib.ROWS_PERM_LB_WORDS, st)), ptr(nfull))
         with KernelTimer.span("pair_attention_fused"):
-            if self.precision == "bf16":
-                zt, fn, name = self._z_bf16(z), lib.lpf_pair_attention_rows_zbf16, "lpf_pair_attention_rows_zbf16"
-            else:
-                zt, fn, name = z, lib.lpf_pair_attention_rows_f32, "lpf_pair_attention_rows_f32"
-            check(fn(d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zt), zt.stride(0), ptr(q), q.stride(0),
-                     ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["wfold_t"]), ptr(w["att"]),
-                     ptr(layer.att.bias), ptr(layer.post_att_norm.weight), ptr(layer.post_att_norm.bias), n_counts,
-                     ptr(ws.ctl), ptr(pieces), units_cap, ptr(out), out.stride(0), st), name)
-        return ws
+            name = "lpf_pair_attention_rows" + ("_perm" if order else "") + ("_zbf16" if self.precision == "bf16" else "_f32")
+            zt = self._z_bf16(z) if self.precision == "bf16" else z
+            check(getattr(lib, name)(
+                d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zt), zt.stride(0), ptr(q), q.stride(0),
+                ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["wfold_t"]), ptr(w["att"]),
+                ptr(layer.att.bias), ptr(layer.post_att_norm.weight), ptr(layer.post_att_norm.bias), n_counts,
+                ptr(ws.ctl), ptr(pieces), units_cap, ptr(out), out.stride(0), *extra, st), name)
+        return (ws, perm, nfull) if order else ws
 
     def _fused_attention(self, batch, x_node, test_set, adj_mask, side):
         """q gather (side stream) -> selection (two launches, nothing read back) -> one-pass attention.  Returns the
@@ -1470,7 +1479,7 @@ class LinkTransformer(nn.Module):
         """Device tables of ``lpf_tail_chain_f32`` (refreshed with the folds they are built from)."""
         layer, pw = self.att_layers[0], self.pairwise_lin
         ps = [layer.post_att_norm.weight, layer.post_att_norm.bias, pw.linears[0].weight, pw.linears[0].bias,
-              pw.norm.weight, pw.norm.bias, score_func.lins[1].weight, score_func.lins[1].bias]
+              pw.norm.weight, pw.norm.bias, score_func.lins[1].weight, score_func.lins[1].bias, layer.att.bias]
         self._fold()
         key = (tuple((p.data_ptr(), p._version) for p in ps), a.data_ptr(), self._folded[0])
         hit = getattr(self, "_tail_cache", None)
@@ -1480,7 +1489,7 @@ class LinkTransformer(nn.Module):
         npy = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
         tabs = fold.tail_chain_tables(npy(w["wcat"]), npy(ps[0]), npy(ps[1]), npy(ps[2]), npy(ps[3]), npy(ps[4]),
                                       npy(ps[5]), npy(a)[:, :self.dim + self.dim + self.count_dim], npy(c), npy(ps[6]),
-                                      npy(ps[7]), self.dim)
+                                      npy(ps[7]), self.dim, att_bias=npy(ps[8]))
         dev = {k: torch.from_numpy(v).to(self.device) for k, v in tabs.items()}
         # bf16 images of the two GEMM weights (same element order: a lane's four fp32 become its four bf16)
         for k in ("wB", "wC"):
@@ -1530,9 +1539,14 @@ class LinkTransformer(nn.Module):
                 # pair-major kernel or (D = 256 without it: the record-merging tail has no instantiation that wide) from
                 # the unit-major kernel + lpf_pair_attention_merge_f32
                 lib, st = _lib.hip(), _stream(self.device)
+                order = None
                 if self._uses_rows():
                     rows = self._zero_workspace("att_rows", bs * (d + 4), st).view(bs, d + 4)   # (pad columns stay zero)
-                    ws = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim)
+                    if self.tail_skip_empty:
+                        ws, *order = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim,
+                                                          order=True)
+                    else:
+                        ws = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim)
                 else:
                     rows, _, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False)   # [BS, D + 4]
                     ws = self._sel_ws(st, bs)
@@ -1540,12 +1554,13 @@ class LinkTransformer(nn.Module):
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):
                     b16 = self.tail_precision == "bf16"
-                    fn = lib.lpf_tail_chain_rows_bf16 if b16 else lib.lpf_tail_chain_rows_f32
-                    check(fn(bs, d, self.count_dim, ptr(rows), rows.stride(0), ptr(tt["wB_bf16" if b16 else "wB"]),
-                             ptr(tt["bB"]), ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(r), r.stride(0),
-                             ptr(tt["wC_bf16" if b16 else "wC"]), ptr(tt["bC"]), ptr(tt["w_dot"]), ptr(tt["b_dot"]),
-                             ptr(ws.ctl), ptr(res) if logits else None, None if logits else ptr(res), st),
-                          "lpf_tail_chain_rows")
+                    name = "lpf_tail_chain_rows" + ("_perm" if order else "") + ("_bf16" if b16 else "_f32")
+                    extra = (ptr(order[0]), ptr(order[1]), ptr(tt["bC_empty"])) if order else ()
+                    check(getattr(lib, name)(
+                        bs, d, self.count_dim, ptr(rows), rows.stride(0), ptr(tt["wB_bf16" if b16 else "wB"]),
+                        ptr(tt["bB"]), ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(r), r.stride(0),
+                        ptr(tt["wC_bf16" if b16 else "wC"]), ptr(tt["bC"]), ptr(tt["w_dot"]), ptr(tt["b_dot"]),
+                        ptr(ws.ctl), *extra, ptr(res) if logits else None, None if logits else ptr(res), st), name)
                 return res
             if d in (32, 64, 128) and self.use_tail_chain and self.use_fused_attention and bs > 0:
                 # 2 selection launches (nothing read back) -> one-pass attention (records) -> merged dense tail

@@ -190,11 +190,19 @@ def test_evaluation_sweep_matches_per_batch_loop():
     edges = torch.from_numpy(rng.integers(0, n, size=(5000, 2)))            # the reference's [P, 2] split layout
     loop = torch.cat([score(model(edges[i:i + 1024].t())) for i in range(0, 5000, 1024)])
     sweep = E.score_edges(model, score, edges, batch_size=1024, streams=3)
-    assert sweep.is_cuda and (loop - sweep).abs().max().item() <= 1e-6  # folded score head: re-associated Linears
+    bad = torch.nonzero((loop - sweep).abs() > 1e-6).flatten().tolist()   # folded score head: re-associated Linears
+    assert sweep.is_cuda and not bad, (bad[:16], sweep[bad[:16]].tolist())
     neg = torch.from_numpy(rng.integers(0, n, size=(40, 25, 2)))
     sn = E.score_negatives(model, score, neg, batch_size=300)
     assert sn.shape == (40, 25)
-    assert torch.equal(sn.reshape(-1), E.score_edges(model, score, neg.reshape(-1, 2), batch_size=1000, streams=1))
+    # (another split of the same pairs: a pair without selected nodes is scored by the short form of the head or, in a
+    # workgroup it shares with pairs that have some, by the full one -- equal up to rounding, not bit for bit)
+    other = E.score_edges(model, score, neg.reshape(-1, 2), batch_size=1000, streams=1)
+    assert (sn.reshape(-1) - other).abs().max().item() <= 5e-7
+    model.tail_skip_empty = False
+    assert torch.equal(E.score_negatives(model, score, neg, batch_size=300).reshape(-1),
+                       E.score_edges(model, score, neg.reshape(-1, 2), batch_size=1000, streams=1))
+    model.tail_skip_empty = True
     m = E.ranking_metrics(sweep[:40], sn)
     assert 0.0 < m["MRR"] <= 1.0 and 0.0 <= E.hits_at_k(sweep[:40], sn, 20) <= 1.0
 

@@ -390,6 +390,30 @@ def test_pair_rows_kernel_matches_the_record_path(dim, mode):
     perm = torch.randperm(bs, device=DEV)
     pf, _ = model.calc_pairwise(tb[:, perm].contiguous(), h)
     assert (pf - outs[True][0][perm]).abs().max().item() <= 2e-6 * scale
+    # the tail with the pairs that select nothing handled apart (lpf_pair_attention_rows_perm_* +
+    # lpf_tail_chain_rows_perm_*): the order it leaves, and the same scores as the plain rows tail
+    lscale = max(1.0, float(outs[True][1].abs().max()))
+    assert model.tail_skip_empty
+    ws = {k[0]: v for k, v in model._ws.items()}
+    n_full = int(ws["att_nfull"][0])
+    order = ws["att_perm"][:bs].long()
+    assert n_full == int((cnt > 0).sum())
+    assert torch.equal(order[:n_full], torch.nonzero(cnt > 0).flatten())
+    assert torch.equal(order[n_full:].flip(0), torch.nonzero(cnt == 0).flatten())
+    model.tail_skip_empty = False
+    plain = model.score_pairs(tb, h, score, logits=True)
+    model.tail_skip_empty = True
+    assert (plain - outs[True][1]).abs().max().item() <= 2e-6 * lscale
+    assert torch.equal(model.score_pairs(tb, h, score, logits=True), outs[True][1])           # replay: same bits
+    for sub in (torch.nonzero(cnt == 0).flatten()[:700], torch.nonzero(cnt > 0).flatten()[:700]):   # all / none empty
+        tsub = tb[:, sub].contiguous()
+        for _attempt in range(3):     # (far more entries per pair than the big batch: the workspace may have to grow once)
+            got = model.score_pairs(tsub, h, score, logits=True)
+            if model.check_selection():
+                break
+        else:
+            raise AssertionError("selection workspace did not settle")
+        assert (got - outs[True][1][sub]).abs().max().item() <= 2e-6 * lscale
     if dim <= 128:
         model.precision = model.tail_precision = "bf16"
         lg16 = model.score_pairs(tb, h, score, logits=True)
