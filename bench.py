@@ -272,12 +272,15 @@ def main():
                     help="activation-pattern attention pair-major with finished rows (pair_rows.hip + the rows mode of the "
                          "dense tail) or unit-major with records merged by the tail (pair_flip.hip); auto: whichever is "
                          "faster in an untimed probe of the pipelined steps (both times are reported in config)")
-    ap.add_argument("--launch", default="auto", choices=("auto", "graph", "eager"),
-                    help="auto: whichever of the two is faster in an untimed probe before the windows (the choice and "
-                         "both probe times are reported in config); graph: every stream replays ONE captured HIP graph of the step (lpformer_amd.GraphedScorer: "
-                         "the same launches, bitwise the same scores; the host issues one graph launch instead of "
-                         "~10 kernel launches through Python: 0.15 ms of host time per step otherwise, which is more "
-                         "than the GPU time of the D = 64 configs); eager: LinkTransformer.score_pairs per step")
+    ap.add_argument("--launch", default="auto", choices=("auto", "graph", "plan", "eager"),
+                    help="auto: whichever of the three is fastest in an untimed probe before the windows (the choice and "
+                         "all probe times are reported in config); eager: LinkTransformer.score_pairs per step (~0.15 ms "
+                         "of host time per step between its launches: the loop is bound by the host whenever the device "
+                         "needs less); graph: every stream replays ONE captured HIP graph of the step "
+                         "(lpformer_amd.GraphedScorer; 0.04 ms of host time, but replayed graphs overlap less between "
+                         "streams); plan: every stream replays the RECORDED C-ABI launches of the step, one plain launch "
+                         "after the other (lpformer_amd.PlannedScorer; 0.04 ms of host time, the overlap of eager "
+                         "launches).  The same launches and bitwise the same scores in all three")
     ap.add_argument("--select-grid", type=int, default=0,
                     help="(tuning) workgroups of the selection's run kernel; 0 = as many as are resident at once")
     ap.add_argument("--streams", type=int, default=8,
@@ -372,8 +375,24 @@ def main():
     # bound) run under the MFMA kernels of the previous one.  Every step still does all of its work.
     lanes = model.lanes(max(1, args.streams))
 
-    # ---- which of the two forms of the activation-pattern attention?  (untimed probe, eager launches on the lanes)
+    def record_plans():
+        """One recorded step per stream (None when the step cannot be recorded on some rank: all ranks agree)."""
+        try:
+            got = [lpformer_amd.PlannedScorer(model, score, h, batches[k % len(batches)], adopt_input=True)
+                   for k in range(len(lanes))]
+        except RuntimeError as exc:   # (a step that does work outside the C-ABI launches cannot be recorded)
+            if args.launch == "plan":
+                raise
+            print(f"[bench] recording the step failed ({exc})", file=sys.stderr)
+            got = None
+            torch.cuda.synchronize()
+        return None if LD.max_over_ranks(0.0 if got is not None else 1.0, dev) > 0.0 else got
+
+    # ---- which of the two forms of the activation-pattern attention?  (untimed probe of the pipelined steps; through
+    #      recorded plans when the timed windows may use them -- eager launches are bound by the host at D <= 128 and
+    #      would time Python, not the kernels)
     rows_probe = None
+    planned_by_form = {}
     if os.environ.get("LPF_TAIL_SKIP_EMPTY"):                    # A/B aid: "0" = the plain rows tail
         model.tail_skip_empty = os.environ["LPF_TAIL_SKIP_EMPTY"] != "0"
     if args.rows != "auto":
@@ -388,22 +407,30 @@ def main():
             torch.cuda.synchronize()
         for mode in ("rows", "records"):
             model.attention_rows = mode == "rows"
-            for i in range(2 * len(lanes)):
+            pl = planned_by_form[mode] = record_plans() if args.launch in ("plan", "auto") else None
+
+            def probe_step(i):
+                if pl is not None:
+                    return pl[i % len(lanes)](batches[i % len(batches)], validate=False, ordered=False)
                 with torch.cuda.stream(lanes[i % len(lanes)]):
-                    step(i)
+                    return step(i)
+            for i in range(2 * len(lanes)):
+                probe_step(i)
             torch.cuda.synchronize()
             barrier()
             t0 = time.perf_counter()
             for i in range(max(args.steps, 40)):
-                with torch.cuda.stream(lanes[i % len(lanes)]):
-                    step(i)
+                probe_step(i)
             torch.cuda.synchronize()
             barrier()
             rows_probe[mode] = LD.max_over_ranks(time.perf_counter() - t0, dev) * 1e3 / max(args.steps, 40)
         model.attention_rows = rows_probe["rows"] <= rows_probe["records"]
         rows_probe = {k: round(v, 4) for k, v in rows_probe.items()}
 
-    scorers = None
+    scorers = planned = None
+    if args.launch in ("plan", "auto"):
+        planned = planned_by_form.get("rows" if model.attention_rows else "records") or record_plans()
+        planned_by_form.clear()
     if args.launch in ("graph", "auto"):
         # one captured step per stream; a scorer owns its workspaces (sized from the batch it is captured with, twice
         # its entry counts) and re-captures by itself when the precision mode or a parameter changes
@@ -422,13 +449,18 @@ def main():
         # every rank must take the same path from here on (the probe below runs barriers and reductions): if the
         # capture failed on ANY rank, all of them time eager launches
         if LD.max_over_ranks(0.0 if scorers is not None else 1.0, dev) > 0.0:
-            scorers, args.launch = None, "eager"
+            scorers = None
+            if args.launch == "graph":
+                args.launch = "eager"
 
-    use_graph = args.launch == "graph"
+    launch = args.launch if args.launch != "auto" else "eager"
 
     def step_on(i):
+        # (validate=False: nothing changes a parameter inside a window; stale() is asked after it)
+        if launch == "plan":   # the plan's launches go to its own stream; the ids have been resident since set-up
+            return planned[i % len(lanes)](batches[i % len(batches)], validate=False, ordered=False)
         with torch.cuda.stream(lanes[i % len(lanes)]):
-            if use_graph:   # (validate=False: nothing changes a parameter inside a window; stale() is asked after it)
+            if launch == "graph":
                 return scorers[i % len(lanes)](batches[i % len(batches)], validate=False)
             return step(i)
 
@@ -450,8 +482,10 @@ def main():
         # costs ~0.15 ms of host time per step whatever the batch -- the D = 64 configs need less GPU time than that --
         # while at D = 128 the replayed graphs run a few per cent behind the eager launches.)
         probe = {}
-        for mode in ("eager", "graph"):
-            use_graph = mode == "graph"
+        for mode in ("eager", "graph", "plan"):
+            if (mode == "graph" and scorers is None) or (mode == "plan" and planned is None):
+                continue
+            launch = mode
             for i in range(2 * len(lanes)):
                 step_on(i)
             torch.cuda.synchronize()
@@ -462,7 +496,7 @@ def main():
             torch.cuda.synchronize()
             barrier()
             probe[mode] = LD.max_over_ranks(time.perf_counter() - t0, dev) * 1e3 / args.steps
-        use_graph = probe["graph"] < probe["eager"]
+        launch = min(probe, key=probe.get)
         launch_probe = {k: round(v, 4) for k, v in probe.items()}
 
 
@@ -487,9 +521,10 @@ def main():
         assert torch.isfinite(out).all()
     # the steps never read the selection status back (nothing does while they are queued): read it once per lane now --
     # a batch that had outgrown its workspace would have come back as NaN and must not count as scored
-    if use_graph:
-        assert not any(sc.stale() for sc in scorers), "a parameter changed inside the timed windows"
-        overflows = sum(0 if sc.check() else 1 for sc in scorers)
+    if launch != "eager":
+        used = scorers if launch == "graph" else planned
+        assert not any(sc.stale() for sc in used), "a parameter changed inside the timed windows"
+        overflows = sum(0 if sc.check() else 1 for sc in used)
     else:
         overflows = sum(0 if model.check_selection(lane) else 1 for lane in lanes)
     assert overflows == 0, "a timed step overflowed its selection workspace: the window is invalid"
@@ -634,11 +669,14 @@ def main():
         train_s = time.perf_counter() - t0
         model.eval(); score.eval()
         del opt
-        h_rand, scorers_rand = h, scorers
+        h_rand, scorers_rand, planned_rand = h, scorers, planned
         h = model.propagate()
         torch.cuda.synchronize()
-        if use_graph:
+        if launch == "graph":
             scorers = [lpformer_amd.GraphedScorer(model, score, h, batches[k % len(batches)]) for k in range(len(lanes))]
+        if launch == "plan":
+            planned = [lpformer_amd.PlannedScorer(model, score, h, batches[k % len(batches)], adopt_input=True)
+                       for k in range(len(lanes))]
         for i in range(max(args.warmup, 2 * len(lanes))):
             step_on(i)
         torch.cuda.synchronize()
@@ -647,7 +685,8 @@ def main():
             el, out = window()
             tr_s.append(el)
             assert torch.isfinite(out).all()
-        ok = all(sc.check() for sc in scorers) if use_graph else all(model.check_selection(lane) for lane in lanes)
+        ok = (all(sc.check() for sc in (scorers if launch == "graph" else planned)) if launch != "eager"
+              else all(model.check_selection(lane) for lane in lanes))
         assert ok, "a timed step of the trained-weights leg overflowed its selection workspace"
         el_t = float(np.median(tr_s))
         trained = {"train_steps": args.train_steps, "train_batch": f"{tb} positives + {tb} negatives", "lr": args.train_lr,
@@ -661,7 +700,7 @@ def main():
         # back to the random-init weights for everything below (kernel timings, CPU baseline)
         model.load_state_dict(saved[0])
         score.load_state_dict(saved[1])
-        scorers = scorers_rand
+        scorers, planned = scorers_rand, planned_rand
         del h_rand, saved
         h = model.propagate()
         torch.cuda.synchronize()
@@ -831,8 +870,9 @@ def main():
                                    f"PPR eps={cfg['eps']}), {bs} candidate pairs per GPU per step, pair stage with "
                                    "encoder output resident",
                        "pairs_per_step_per_gpu": bs, "distinct_batches": len(batches),
-                       "streams": len(lanes), "side_stream": bool(model.use_side_stream), "launch": ("one captured HIP graph of the step per stream, replayed"
-                                                         if use_graph else "eager (Python, ~10 launches per step)"),
+                       "streams": len(lanes), "side_stream": bool(model.use_side_stream), "launch": {"graph": "one captured HIP graph of the step per stream, replayed",
+                                  "plan": "the recorded C-ABI launches of the step per stream, replayed as plain launches",
+                                  "eager": "eager (LinkTransformer.score_pairs per step)"}[launch],
                        "launch_probe_ms_per_step": launch_probe,
                        "spinup_s": args.spinup, "attention_impl": attention_random,
                        "attention_impl_requested": args.attention, "flips_per_entry": flips_random,

@@ -329,6 +329,16 @@ int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx,
                         const float *addend, int64_t ldadd, const float *ln_g, const float *ln_b, uint32_t flags,
                         const float *w2_packed, int32_t N2, const float *b2, float *out, int64_t ldo, float *prob,
                         void *stream);
+/* lpf_dense_chain_f32 in a gather mode (in_mode 1 or 2) that ALSO leaves side_out[m, :side_dim] = S[a_m] + S[b_m] for a
+ * second per-node table S [n_rows, ld_side_tab] read with the same ids -- lpf_pair_gather_f32 (sum) without a launch of
+ * its own: the attention's per-pair query q = lin_l(x_a) + lin_l(x_b) from the table lin_l(X) (layers.py:212-215)
+ * beside the elementwise branch of the same batch.  side_dim % 4 == 0, rows 16-byte aligned, a + b in that order. */
+int lpf_dense_chain_side_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch,
+                             int64_t batch_ld, int64_t n_rows, int32_t K1, const float *w1_packed, int32_t N1,
+                             const float *b1, const float *addend, int64_t ldadd, const float *ln_g, const float *ln_b,
+                             uint32_t flags, const float *w2_packed, int32_t N2, const float *b2, float *out,
+                             int64_t ldo, float *prob, const float *side_tab, int64_t ld_side_tab, int32_t side_dim,
+                             float *side_out, int64_t ld_side_out, void *stream);
 
 /* The dense tail of the scoring path in one launch (what LinkTransformer.score_pairs runs after the softmax-gather):
  *   o   = post_att_norm( G[:, D:] Wcat^T + G[:, :D] )                        (layers.py:78; G from

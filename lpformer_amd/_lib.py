@@ -98,6 +98,8 @@ HIP_PROTOTYPES = {
     "lpf_pair_scatter_add_f32": [i64, i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lpf_dense_chain_f32": [i64, i32, vp, i64, vp, i64, i64, i32, vp, i32, vp, vp, i64, vp, vp, u32, vp, i32, vp, vp, i64,
                             vp, vp],
+    "lpf_dense_chain_side_f32": [i64, i32, vp, i64, vp, i64, i64, i32, vp, i32, vp, vp, i64, vp, vp, u32, vp, i32, vp, vp, i64,
+                            vp, vp, i64, i32, vp, i64, vp],
 }
 HOST_PROTOTYPES = {
     "lpf_ppr_push_cpu": [i64, vp, vp, f64, f64, vp, C.POINTER(vp), C.POINTER(vp), i32],

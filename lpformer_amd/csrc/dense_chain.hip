@@ -43,6 +43,10 @@ struct DenseChainArgs {
     const float *b2;
     float *out; int64_t ldo;     // [M, N2] (or [M, N1] for a single layer); dot mode: logit[M] (may be NULL)
     float *prob;                 // dot mode: sigmoid(logit) (may be NULL)
+    // gather modes, optional: a SECOND table read with the same ids -- side[m] = S[a] + S[b] (lpf_dense_chain_side_f32:
+    // the attention's per-pair query beside the elementwise branch, one launch for both)
+    const float *side_tab; int64_t ld_side_tab; int side_dim;
+    float *side_out; int64_t ld_side_out;
 };
 
 // k-groups (16 input features) per pipeline stage; fold.py::dense_stage_groups mirrors this.  One: with batches
@@ -203,6 +207,29 @@ __global__ __launch_bounds__(DC_THREADS, MINW) void dense_chain_kernel(const Den
             if ((uint64_t)rb >= (uint64_t)A.n_rows) rb = 0;
         }
         const float *xa = A.X + ra * A.ldx, *xb = A.X + rb * A.ldx;
+        // side gather (lpf_dense_chain_side_f32): the eight threads of a sample (two wavefronts x four quads) share its
+        // row S[a] + S[b] (that order, = lpf_pair_gather_f32).  Requested here, in front of the first operands; added and
+        // stored behind the first stage's input wait, which they have passed by then (same queue, issued earlier).
+        constexpr int SIDE_U = 4;
+        f32x4 sva[SIDE_U], svb[SIDE_U];
+        const bool side = MODE != 0 && A.side_out != nullptr;
+        const int side_n4 = A.side_dim >> 2, side_f0 = 4 * half + q;
+        auto side_load = [&](int f0) __attribute__((always_inline)) {
+            const float *sa = A.side_tab + ra * A.ld_side_tab, *sb = A.side_tab + rb * A.ld_side_tab;
+#pragma unroll
+            for (int u = 0; u < SIDE_U; ++u) {
+                const int f = f0 + 8 * u < side_n4 ? f0 + 8 * u : side_f0;
+                sva[u] = *reinterpret_cast<const f32x4 *>(sa + 4 * f);
+                svb[u] = *reinterpret_cast<const f32x4 *>(sb + 4 * f);
+            }
+        };
+        auto side_store = [&](int f0) __attribute__((always_inline)) {
+            float *so = A.side_out + mm * A.ld_side_out;
+#pragma unroll
+            for (int u = 0; u < SIDE_U; ++u)
+                if (live && f0 + 8 * u < side_n4) *reinterpret_cast<f32x4 *>(so + 4 * (f0 + 8 * u)) = sva[u] + svb[u];
+        };
+        if (side && side_f0 < side_n4) side_load(side_f0);
 
         // ---------------- layer 1: this wave's tiles half*TPW1 .. half*TPW1 + TPW1 - 1
         f32x4 acc1[TPW1];
@@ -217,6 +244,13 @@ __global__ __launch_bounds__(DC_THREADS, MINW) void dense_chain_kernel(const Den
                 const int cnt = ng1 - g0 < G ? ng1 - g0 : G;
                 f32x4 bv[G];
                 dc_input_combine<G, MODE>(xra, xrb, A, g0, q, bv);
+                if (side && g0 == 0) {
+                    if (side_f0 < side_n4) side_store(side_f0);
+                    for (int f0 = side_f0 + 8 * SIDE_U; f0 < side_n4; f0 += 8 * SIDE_U) {   // (tables wider than 128)
+                        side_load(f0);
+                        side_store(f0);
+                    }
+                }
                 f32x4 *lw = lds + buf * SLAB;
                 dc_stage_store<P1>(wr, lw, tid);
                 __syncthreads();
@@ -360,11 +394,12 @@ int dc_launch(const DenseChainArgs &a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch,
-                                   int64_t batch_ld, int64_t n_rows, int32_t K1, const float *w1_packed, int32_t N1, const float *b1,
-                                   const float *addend, int64_t ldadd, const float *ln_g, const float *ln_b,
-                                   uint32_t flags, const float *w2_packed, int32_t N2, const float *b2, float *out,
-                                   int64_t ldo, float *prob, void *stream) {
+namespace {
+int dc_entry(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch, int64_t batch_ld,
+             int64_t n_rows, int32_t K1, const float *w1_packed, int32_t N1, const float *b1, const float *addend,
+             int64_t ldadd, const float *ln_g, const float *ln_b, uint32_t flags, const float *w2_packed, int32_t N2,
+             const float *b2, float *out, int64_t ldo, float *prob, const float *side_tab, int64_t ld_side_tab,
+             int32_t side_dim, float *side_out, int64_t ld_side_out, void *stream) {
     if (M == 0) return LPF_OK;
     LPF_REQUIRE(M > 0 && X && w1_packed && b1 && K1 > 0 && N1 > 0 && (ldx & 3) == 0 && lpf_aligned16(X) &&
                 lpf_aligned16(w1_packed) && lpf_aligned16(b1));
@@ -380,8 +415,11 @@ extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, i
     LPF_REQUIRE(dot || ldo >= (two ? N2 : N1));
     LPF_REQUIRE(dot || !two || lpf_aligned16(b2));
     const int nt1 = (N1 + 15) / 16, nt2 = (two && !dot) ? (N2 + 15) / 16 : 0;
+    LPF_REQUIRE(!side_out || (in_mode != 0 && side_tab && side_dim > 0 && (side_dim & 3) == 0 && ld_side_tab >= side_dim &&
+                              ld_side_out >= side_dim && (ld_side_tab & 3) == 0 && (ld_side_out & 3) == 0 &&
+                              lpf_aligned16(side_tab) && lpf_aligned16(side_out)));
     DenseChainArgs a{M, in_mode, X, ldx, batch, batch_ld, n_rows, K1, w1_packed, N1, b1, addend, ldadd, ln_g, ln_b, flags,
-                     w2_packed, N2, b2, out, ldo, prob};
+                     w2_packed, N2, b2, out, ldo, prob, side_tab, ld_side_tab, side_dim, side_out, ld_side_out};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // in_mode 1 (gather-multiply) is built for the square two-layer chains (elementwise_lin) and the single-layer
     // ones (its first layer alone), in_mode 2 (gather-add) for the single-layer ones; plain rows for everything
@@ -410,4 +448,30 @@ extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, i
 #undef DC_SINGLE
 #undef DC_SQUARE
     return LPF_ERR_UNSUPPORTED;
+}
+}  // namespace
+
+extern "C" int lpf_dense_chain_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch,
+                                   int64_t batch_ld, int64_t n_rows, int32_t K1, const float *w1_packed, int32_t N1, const float *b1,
+                                   const float *addend, int64_t ldadd, const float *ln_g, const float *ln_b,
+                                   uint32_t flags, const float *w2_packed, int32_t N2, const float *b2, float *out,
+                                   int64_t ldo, float *prob, void *stream) {
+    return dc_entry(M, in_mode, X, ldx, batch, batch_ld, n_rows, K1, w1_packed, N1, b1, addend, ldadd, ln_g, ln_b, flags,
+                    w2_packed, N2, b2, out, ldo, prob, nullptr, 0, 0, nullptr, 0, stream);
+}
+
+/* lpf_dense_chain_f32 in a gather mode (in_mode 1 or 2) that ALSO leaves side_out[m, :side_dim] = S[a_m] + S[b_m] for a
+ * second table S [n_rows, ld_side_tab] read with the same ids -- lpf_pair_gather_f32(sum) without a launch of its own:
+ * the attention's per-pair query q = lin_l(x_a) + lin_l(x_b) from the per-node table lin_l(X) (layers.py:212-215) beside
+ * the elementwise branch of the same batch.  side_dim % 4 == 0; rows 16-byte aligned. */
+extern "C" int lpf_dense_chain_side_f32(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int64_t *batch,
+                                        int64_t batch_ld, int64_t n_rows, int32_t K1, const float *w1_packed, int32_t N1,
+                                        const float *b1, const float *addend, int64_t ldadd, const float *ln_g,
+                                        const float *ln_b, uint32_t flags, const float *w2_packed, int32_t N2,
+                                        const float *b2, float *out, int64_t ldo, float *prob, const float *side_tab,
+                                        int64_t ld_side_tab, int32_t side_dim, float *side_out, int64_t ld_side_out,
+                                        void *stream) {
+    LPF_REQUIRE(side_tab && side_out && in_mode != 0);
+    return dc_entry(M, in_mode, X, ldx, batch, batch_ld, n_rows, K1, w1_packed, N1, b1, addend, ldadd, ln_g, ln_b, flags,
+                    w2_packed, N2, b2, out, ldo, prob, side_tab, ld_side_tab, side_dim, side_out, ld_side_out, stream);
 }

@@ -669,12 +669,17 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_cu = lpf_cu_count();
     if (n_cu == 0) return LPF_ERR_NO_DEVICE;
+#ifdef PR_GRID2   /* tuning aid: twice the workgroups a CU holds at a time */
+#define PR_GRID_MUL 2
+#else
+#define PR_GRID_MUL 1
+#endif
 #define LPF_ROWS_GO(GG, NTH, WTL, PER_CU)                                                           \
     do {                                                                                            \
         auto kern = pair_rows_kernel<GG, NTH, WTL, ZB>;                                             \
         constexpr size_t lds = PrLds<GG, NTH, WTL>::BYTES;                                          \
         LPF_SET_MAX_LDS(kern, lds);                                                                 \
-        int64_t groups = (int64_t)n_cu * PER_CU;                                                    \
+        int64_t groups = (int64_t)n_cu * PER_CU * PR_GRID_MUL;                                      \
         const int64_t most = (bs + 15) / 16;   /* (a workgroup per 16 pairs at the very least) */   \
         if (groups > most) groups = most;                                                           \
         if (groups > PR_LB_WORDS) groups = PR_LB_WORDS;                                             \
@@ -683,7 +688,13 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
     switch (D) {
         case 32: LPF_ROWS_GO(8, 512, 3, 2); break;
         case 64: LPF_ROWS_GO(16, 512, 3, 2); break;
+#ifdef PR_CFG128   /* tuning aid: NTH, WTL, PER_CU of the D = 128 launch */
+#define LPF_ROWS_GO_(...) LPF_ROWS_GO(__VA_ARGS__)
+        case 128: LPF_ROWS_GO_(32, PR_CFG128); break;
+#undef LPF_ROWS_GO_
+#else
         case 128: LPF_ROWS_GO(32, 1024, 1, 1); break;
+#endif
         case 256: LPF_ROWS_GO(64, 256, 0, 3); break;
         default: return LPF_ERR_UNSUPPORTED;
     }

@@ -5,6 +5,8 @@
   testing.py:87 -> link_transformer.py:100);
 * batches are issued round-robin over a few HIP streams, so the selection kernels of one batch run underneath the
   matrix-core kernels of the previous one (per-stream workspaces in ``LinkTransformer``);
+* a long sweep replays RECORDED steps (``lpformer_amd.PlannedScorer``, one per stream): ``score_pairs`` spends ~0.15 ms of
+  host time per batch between its launches, more than the device needs at D <= 128;
 * scores stay on the device -- no ``.cpu()`` per batch (testing.py:88,117); the ranking metrics below
   (src/train/evaluation.py:23-50 and the OGB ``hits@K`` rule) are a few reductions over them.
 
@@ -24,13 +26,57 @@ def _as_2xp(edges: torch.Tensor) -> torch.Tensor:
     return edges.t() if edges.shape[1] == 2 and edges.shape[0] != 2 else edges
 
 
+PLAN_MIN_BATCHES = 6   # full batches per stream from which recording the step pays (a recording costs ~5 eager steps)
+
+
+def _planned_sweep(model, score_func, batch, out, h, batch_size, n_full, test_set, streams, logits) -> bool:
+    """The first ``n_full`` full batches of a sweep through recorded steps, one ``PlannedScorer`` per stream.  Returns
+    False (nothing written) when the step of this configuration cannot be recorded."""
+    from .graphed import PlannedScorer
+    nl = max(1, min(streams, n_full))
+    main = torch.cuda.current_stream(model.device)
+    try:
+        plans = [PlannedScorer(model, score_func, h, batch[:, k * batch_size:(k + 1) * batch_size], test_set=test_set,
+                               logits=logits, adopt_input=True) for k in range(nl)]
+    except RuntimeError:
+        return False
+    jobs = [[] for _ in plans]
+    for p in plans:
+        p.stream.wait_stream(main)   # h, batch and out are ready
+    for i in range(n_full):
+        lo, p = i * batch_size, plans[i % nl]
+        jobs[i % nl].append(lo)
+        res = p(batch[:, lo:lo + batch_size], validate=False, ordered=False)
+        with torch.cuda.stream(p.stream):
+            out[lo:lo + batch_size].copy_(res, non_blocking=True)
+    # as below: one status read per stream at the end; a stream that reports an overflow scores its batches again, one at
+    # a time with the status checked after each (check() re-records with a workspace sized for the offending batch)
+    for p, lane_jobs in zip(plans, jobs):
+        if p.check():
+            continue
+        for lo in lane_jobs:
+            for _attempt in range(4):
+                res = p(batch[:, lo:lo + batch_size], validate=False, ordered=False)
+                with torch.cuda.stream(p.stream):
+                    out[lo:lo + batch_size].copy_(res, non_blocking=True)
+                if p.check():
+                    break
+            else:
+                raise RuntimeError("score_edges: the selection workspace could not be sized")
+    for p in plans:
+        main.wait_stream(p.stream)
+    return True
+
+
 @torch.no_grad()
 def score_edges(model, score_func, edges, batch_size: int = 32768, *, h: Optional[torch.Tensor] = None,
-                test_set: bool = False, streams: int = 4, logits: bool = False) -> torch.Tensor:
+                test_set: bool = False, streams: int = 4, logits: bool = False, plans: Optional[bool] = None) -> torch.Tensor:
     """Probabilities (or pre-sigmoid logits) for every pair of ``edges``, as one device tensor of shape [P].
 
     Same arithmetic per pair as ``score_func(model(edge, test_set=test_set))`` of the reference loop; ``h`` (the encoder
-    output, ``model.propagate(test_set=...)``) is computed once if not given."""
+    output, ``model.propagate(test_set=...)``) is computed once if not given.  ``plans``: replay recorded steps for the
+    full batches (default: when the sweep has at least ``PLAN_MIN_BATCHES`` of them per stream); the scores are bitwise
+    the ones of the eager loop."""
     dev = model.device
     batch = _as_2xp(edges).to(dev)
     if batch.dtype != torch.int64:
@@ -43,11 +89,20 @@ def score_edges(model, score_func, edges, batch_size: int = 32768, *, h: Optiona
     if total == 0:
         return out
     main = torch.cuda.current_stream(dev)
-    lanes = model.lanes(max(1, min(streams, (total + batch_size - 1) // batch_size)))  # persistent: workspaces are per stream
+    start = 0
+    n_full = total // batch_size
+    if plans is None:
+        plans = n_full >= PLAN_MIN_BATCHES * max(1, min(streams, n_full))
+    if plans and n_full > 0 and _planned_sweep(model, score_func, batch, out, h, batch_size, n_full, test_set, streams,
+                                               logits):
+        start = n_full * batch_size
+        if start == total:
+            return out
+    lanes = model.lanes(max(1, min(streams, (total - start + batch_size - 1) // batch_size)))  # persistent: workspaces are per stream
     for s in lanes:
         s.wait_stream(main)  # h, batch and out are ready
     jobs = [[] for _ in lanes]
-    for i, lo in enumerate(range(0, total, batch_size)):
+    for i, lo in enumerate(range(start, total, batch_size)):
         hi = min(lo + batch_size, total)
         jobs[i % len(lanes)].append((lo, hi))
         with torch.cuda.stream(lanes[i % len(lanes)]):

@@ -96,3 +96,145 @@ class GraphedScorer:
             return True
         self._capture()
         return False
+
+
+class PlannedScorer(GraphedScorer):
+    """The same fixed-size step as a RECORDED LIST OF C-ABI LAUNCHES, replayed one ``hipLaunchKernel`` after the other.
+
+    Why beside the HIP graph: ``score_pairs`` spends ~0.15 ms of host time per step between its six launches (workspace
+    look-ups, cache keys, pointer conversions), more than the device needs at D <= 128 once batches are pipelined over
+    several streams -- the eager loop is bound by the host; and replayed graphs, which cost the host 0.04 ms per step,
+    run their nodes with less overlap between streams than plain launches do (measured: tools/host_floor.py,
+    tools/marginal_cost.py).  A plan keeps the launches plain and takes the host out: one recorded ``score_pairs`` call
+    gives the entry points, their argument tuples (workspaces, tables and temporaries of that call, all kept alive by
+    the plan) and the two stream hand-overs of the side stream; a replay calls them again, with the ids pointer
+    replaced by the new batch's -- ~0.03 ms of host time per step.
+
+    Same contract as ``GraphedScorer`` (fixed batch size and encoder output, ``check()`` before the scores of a sweep are
+    used, re-recorded when a parameter changed), except that the launches always go to ``scorer.stream`` (and the model's
+    side stream of it); ``__call__`` orders them against the caller's current stream unless told not to.  Only the C-ABI launches of the step
+    are replayed -- which is all a step consists of on the paths ``score_pairs`` takes for the two-layer score head;
+    the recording is checked against the eager result, bit for bit, before it is used."""
+
+    _SKIP = frozenset(("lpf_strerror", "lpf_last_hip_error", "lpf_pair_rows_piece_floats", "lpf_abi_version",
+                       "lpf_device_info", "lpf_select_plan_blocks", "lpf_train_partial_blocks"))
+
+    def _capture(self):
+        from . import _lib
+        from . import link_transformer as LT
+        model, dev = self.model, self.model.device
+        self._params = list(model.parameters()) + list(self.score_func.parameters())
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        kw = dict(test_set=self.test_set, logits=self.logits)
+        with torch.cuda.stream(self.stream):
+            for _ in range(2):  # sizes the per-stream workspaces and fills every parameter-derived cache
+                model.score_pairs(self.batch, self.h, self.score_func, **kw)
+            if not model.check_selection(self.stream):   # (first call of a stream sizes exactly: cannot overflow)
+                model.score_pairs(self.batch, self.h, self.score_func, **kw)
+            calls, keep = [], []
+            real_hip, real_ptr, real_wait = _lib.hip, LT.ptr, torch.cuda.Stream.wait_stream
+            lib = real_hip()
+
+            class _Recorder:
+                def __getattr__(rec, name):   # noqa: N805
+                    fn = getattr(lib, name)
+                    if name in self._SKIP or not name.startswith("lpf_"):
+                        return fn
+
+                    def call(*args):
+                        calls.append((name, fn, args))
+                        return fn(*args)
+                    return call
+
+            def rec_ptr(t):
+                if t is not None:
+                    keep.append(t)
+                return real_ptr(t)
+
+            def rec_wait(s, other):
+                calls.append((None, None, (s, other)))
+                return real_wait(s, other)
+
+            recorder = _Recorder()
+            _lib.hip, LT.ptr, torch.cuda.Stream.wait_stream = (lambda: recorder), rec_ptr, rec_wait
+            try:
+                self.out = model.score_pairs(self.batch, self.h, self.score_func, **kw)
+            finally:
+                _lib.hip, LT.ptr, torch.cuda.Stream.wait_stream = real_hip, real_ptr, real_wait
+            want = self.out.clone()
+        b = self.batch   # (its extent in memory: a [2, BS] window of a longer id list has its rows far apart)
+        base = b.data_ptr()
+        nbytes = (sum((n - 1) * st for n, st in zip(b.shape, b.stride())) + 1) * b.element_size()
+        # arguments that point INTO the ids (the tensor itself, its second row, ...) follow the batch of a replay; such a
+        # value can only sit in a pointer slot: ints of other meaning are far below any device address
+        self._plan = [(name, fn, args, tuple(i for i, a in enumerate(args)
+                                             if fn is not None and isinstance(a, int) and base <= a < base + nbytes))
+                      for name, fn, args in calls]
+        raw = self.stream.cuda_stream
+        self._keep = (keep, model._z_cache, getattr(model, "_y_cache", None), getattr(model, "_zb_cache", None),
+                      model._folded, getattr(model, "_tail_cache", None), getattr(model, "_score_fold_cache", None),
+                      [(k, w, getattr(w, "entries", None), getattr(w, "item_pair", None), getattr(w, "run_lb", None))
+                       for k, w in model._ws.items() if isinstance(k, tuple) and raw in k])
+        self._key = self._param_key()
+        self.captures += 1
+        self._replay(base)
+        self.stream.synchronize()
+        if not torch.equal(self.out, want):
+            raise RuntimeError("PlannedScorer: the recorded launches do not reproduce the eager step (the step of this "
+                               "configuration does work outside the C-ABI launches)")
+
+    def _replay(self, ids_ptr: int):
+        from ._lib import check
+        base = self.batch.data_ptr()
+        for name, fn, args, slots in self._plan:
+            if fn is None:
+                args[0].wait_stream(args[1])
+                continue
+            if slots and ids_ptr != base:
+                args = list(args)
+                for i in slots:
+                    args[i] += ids_ptr - base
+            rc = fn(*args)
+            if rc:
+                check(rc, name)
+
+    def __call__(self, batch: torch.Tensor, validate: bool = True, ordered: bool = True) -> torch.Tensor:
+        """Scores of ``batch`` ([2, BS] int64 node ids on the device, same BS as the example), queued on
+        ``scorer.stream``; the result tensor is reused by the next call.  ``ordered`` (default): the plan's stream first
+        waits for the caller's current stream (whatever produced ``batch`` there is complete before the ids are read) and
+        the caller's stream then waits for the plan's (the scores are complete for whatever the caller queues next) --
+        the call behaves like ``score_pairs`` on the current stream.  ``ordered=False`` drops both hand-overs: for
+        pipelines over several scorers whose ids have long been resident and whose consumer synchronises by itself."""
+        if batch.shape != self.batch.shape:
+            raise ValueError(f"this plan was recorded for batches of shape {tuple(self.batch.shape)}")
+        if validate and self.stale():
+            self._capture()
+        cur = torch.cuda.current_stream(self.model.device) if ordered else None
+        if ordered:
+            self.stream.wait_stream(cur)
+        self._last = batch
+        if batch is self.batch:
+            self._replay(self.batch.data_ptr())
+        elif (batch.dtype == self.batch.dtype and batch.device == self.batch.device and
+              batch.stride() == self.batch.stride()):
+            # the ids are read where they are: the plan's stream must see them complete
+            self._replay(batch.data_ptr())
+        else:
+            with torch.cuda.stream(self.stream):
+                self.batch.copy_(batch, non_blocking=True)
+            self._replay(self.batch.data_ptr())
+        if ordered:
+            cur.wait_stream(self.stream)
+        return self.out
+
+    def check(self) -> bool:
+        """As ``GraphedScorer.check``; after an overflow the step is recorded again with a workspace sized for the LAST
+        batch replayed (the plan takes a copy of it as its own ids; an adopted input tensor is left alone)."""
+        if self.model.check_selection(self.stream):
+            return True
+        last = getattr(self, "_last", None)
+        if last is not None and last is not self.batch:
+            with torch.cuda.stream(self.stream):
+                self.batch = self.model._prep_batch(last).clone()
+        self._capture()
+        return False

@@ -183,8 +183,10 @@ class DenseChain:
         return self._t
 
     def run(self, t: dict, x: torch.Tensor, relu: bool, batch=None, in_mode=0, addend=None, out=None, prob=None,
-            want_logit=True):
-        """x: [M, K1] rows (in_mode 0) or the node-feature matrix gathered through ``batch`` ([2, M] int64)."""
+            want_logit=True, side=None):
+        """x: [M, K1] rows (in_mode 0) or the node-feature matrix gathered through ``batch`` ([2, M] int64).
+        ``side = (S, out)`` (gather modes): the launch also leaves ``out[m] = S[a_m] + S[b_m]`` for a second per-node
+        table S (``lpf_dense_chain_side_f32``)."""
         k1, n1, n2 = t["shape"]
         nt1, dot = (n1 + 15) // 16, n2 == 1
         nt2 = 0 if (n2 == 0 or dot) else (n2 + 15) // 16
@@ -202,13 +204,20 @@ class DenseChain:
                 return None
             res = out if out is not None else torch.empty(m, width, dtype=torch.float32, device=dev)
             o, pr, ldo = ptr(res), None, res.stride(0)
+        extra, name = (), "lpf_dense_chain_f32"
+        if side is not None:
+            s_tab, s_out = side
+            if in_mode == 0 or s_tab.shape[0] != x.shape[0] or s_tab.shape[1] % 4 or s_tab.stride(0) % 4:
+                raise ValueError("side table: gather modes only, one row per row of x, a multiple of 4 wide")
+            extra = (ptr(s_tab), s_tab.stride(0), s_tab.shape[1], ptr(s_out), s_out.stride(0))
+            name = "lpf_dense_chain_side_f32"
         with KernelTimer.span(self.tag):
-            check(_lib.hip().lpf_dense_chain_f32(
+            check(getattr(_lib.hip(), name)(
                 m, in_mode, ptr(x), x.stride(0), ptr(batch), 0 if batch is None else batch.stride(0),
                 x.shape[0] if in_mode else 0, k1,
                 ptr(t["w1p"]), n1, ptr(t["b1"]), ptr(addend), 0 if addend is None else addend.stride(0),
                 ptr(t.get("ln_g")), ptr(t.get("ln_b")), FLAG_RELU if relu else 0, ptr(t.get("w2p")), n2,
-                ptr(t.get("b2")), o, ldo, pr, _stream(dev)), "lpf_dense_chain_f32")
+                ptr(t.get("b2")), o, ldo, pr, *extra, _stream(dev)), name)
         return res
 
 
@@ -1276,7 +1285,7 @@ class LinkTransformer(nn.Module):
         """True when the one-pass attention runs pair-major and hands over finished rows (csrc/pair_rows.hip)."""
         return self.attention_rows and self.attention_kernel() == "flip"
 
-    def _attention_rows(self, batch, x_node, test_set, adj_mask, side, out, n_counts, order=False):
+    def _attention_rows(self, batch, x_node, test_set, adj_mask, side, out, n_counts, order=False, q=None):
         """q gather -> selection -> pair-major one-pass attention writing ``out[p] = [post_att_norm(attention output) |
         n_counts count features]`` (``out``: [BS, ld] fp32, ld % 4 == 0).  Returns the selection workspace; with
         ``order`` also (perm int32[BS], n_nonempty int64[1]): the pairs with selected nodes first, for
@@ -1285,8 +1294,9 @@ class LinkTransformer(nn.Module):
         bs = batch.shape[1]
         w = self._fold()
         z = self._node_keys(x_node, w)
-        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
-            q = self._pair_q(batch, x_node, w)
+        if q is None:   # (score_pairs has it gathered by the elementwise branch's launch)
+            with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+                q = self._pair_q(batch, x_node, w)
         ws = self._select_device(batch, test_set, adj_mask)
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
@@ -1308,7 +1318,7 @@ class LinkTransformer(nn.Module):
                 ptr(ws.ctl), ptr(pieces), units_cap, ptr(out), out.stride(0), *extra, st), name)
         return (ws, perm, nfull) if order else ws
 
-    def _fused_attention(self, batch, x_node, test_set, adj_mask, side):
+    def _fused_attention(self, batch, x_node, test_set, adj_mask, side, q=None):
         """q gather (side stream) -> selection (two launches, nothing read back) -> one-pass attention.  Returns the
         selection workspace and the record buffers (part, bnd, units_cap) for ``lpf_tail_chain_merge_*`` /
         ``lpf_pair_attention_merge_f32``."""
@@ -1316,8 +1326,9 @@ class LinkTransformer(nn.Module):
         bs = batch.shape[1]
         w = self._fold()
         z = self._node_keys(x_node, w)
-        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
-            q = self._pair_q(batch, x_node, w)
+        if q is None:
+            with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+                q = self._pair_q(batch, x_node, w)
         ws = self._select_device(batch, test_set, adj_mask)
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
@@ -1518,13 +1529,18 @@ class LinkTransformer(nn.Module):
             x_node = _as_f32_rows(X_node)
             a, c, kpad = self._score_fold(score_func)
             r = torch.empty(bs, kpad, dtype=torch.float32, device=self.device)  # [r_e | r_p | pad]
-            if kpad > d + pd:
-                r[:, d + pd:].zero_()
             ew, pw = self.elementwise_lin, self.pairwise_lin
+            one_pass = d in (32, 64, 128, 256) and self.use_tail_chain and self.use_fused_attention and bs > 0
+            # the attention's query q = Y[a] + Y[b] is gathered by the launch of the elementwise branch (same ids, a
+            # second table): one launch less per step -- 19 us of a 193 us pipelined step as a launch of its own
+            q_side = None
+            if one_pass and self.query_from == "table" and (d < 256 or self._uses_rows()):
+                q_side = (self._node_y(x_node, self._fold()), torch.empty(bs, d, dtype=torch.float32, device=self.device))
             side = self._fork()
             with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
                 t = ew._chain1.tables(ew.linears[0].weight, ew.linears[0].bias, ew.norm.weight, ew.norm.bias)
-                if ew._chain1.run(t, x_node, relu=True, batch=batch, in_mode=1, out=r[:, :d]) is None:
+                if ew._chain1.run(t, x_node, relu=True, batch=batch, in_mode=1, out=r[:, :d], side=q_side) is None:
+                    q_side = None
                     prod = torch.empty(bs, d, dtype=torch.float32, device=self.device)
                     with KernelTimer.span("pair_gather"):
                         check(_lib.hip().lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), x_node.shape[0], ptr(x_node),
@@ -1544,9 +1560,10 @@ class LinkTransformer(nn.Module):
                     rows = self._zero_workspace("att_rows", bs * (d + 4), st).view(bs, d + 4)   # (pad columns stay zero)
                     if self.tail_skip_empty:
                         ws, *order = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim,
-                                                          order=True)
+                                                          order=True, q=q_side and q_side[1])
                     else:
-                        ws = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim)
+                        ws = self._attention_rows(batch, x_node, test_set, adj_mask, side, rows, self.count_dim,
+                                                  q=q_side and q_side[1])
                 else:
                     rows, _, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False)   # [BS, D + 4]
                     ws = self._sel_ws(st, bs)
@@ -1565,7 +1582,8 @@ class LinkTransformer(nn.Module):
             if d in (32, 64, 128) and self.use_tail_chain and self.use_fused_attention and bs > 0:
                 # 2 selection launches (nothing read back) -> one-pass attention (records) -> merged dense tail
                 lib, st = _lib.hip(), _stream(self.device)
-                ws, part, bnd, units_cap = self._fused_attention(batch, x_node, test_set, adj_mask, side)
+                ws, part, bnd, units_cap = self._fused_attention(batch, x_node, test_set, adj_mask, side,
+                                                                 q=q_side and q_side[1])
                 tt = self._tail_tables(score_func, a, c)
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):
@@ -1593,6 +1611,8 @@ class LinkTransformer(nn.Module):
                         _stream(self.device)), "lpf_tail_chain_f32")
                 return res
             feats, _, _ = self._pair_attention(batch, x_node, test_set, adj_mask, False)  # joins the side stream
+            if kpad > d + pd:
+                r[:, d + pd:].zero_()
             xin = feats[:, :pd]
             t = pw._chain1.tables(pw.linears[0].weight, pw.linears[0].bias, pw.norm.weight, pw.norm.bias)
             if pw._chain1.run(t, xin, relu=True, out=r[:, d:d + pd]) is None:

@@ -192,6 +192,10 @@ def test_evaluation_sweep_matches_per_batch_loop():
     sweep = E.score_edges(model, score, edges, batch_size=1024, streams=3)
     bad = torch.nonzero((loop - sweep).abs() > 1e-6).flatten().tolist()   # folded score head: re-associated Linears
     assert sweep.is_cuda and not bad, (bad[:16], sweep[bad[:16]].tolist())
+    # a long sweep replays recorded steps (one PlannedScorer per stream) for its full batches: the same bits
+    planned = E.score_edges(model, score, edges, batch_size=256, streams=3, plans=True)
+    assert torch.equal(planned, E.score_edges(model, score, edges, batch_size=256, streams=3, plans=False))
+    assert (planned - loop).abs().max().item() <= 1e-6
     neg = torch.from_numpy(rng.integers(0, n, size=(40, 25, 2)))
     sn = E.score_negatives(model, score, neg, batch_size=300)
     assert sn.shape == (40, 25)
@@ -254,6 +258,53 @@ def test_step_replays_from_a_captured_graph(mode):
     assert torch.equal(adopted(own), model.score_pairs(batches[2], h, score, logits=True))
     assert torch.equal(adopted(batches[3]), model.score_pairs(batches[3], h, score, logits=True))
     assert torch.equal(own, batches[3]) and adopted.check()
+
+
+@pytest.mark.parametrize("name,scale,mode", [("collab", 0.1, "f32"), ("collab", 0.1, "bf16"), ("ppa", 0.02, "f32"),
+                                             ("cora", 1.0, "f32")])
+def test_step_replays_from_a_recorded_plan(name, scale, mode):
+    """lpformer_amd.PlannedScorer: the C-ABI launches of one step, recorded and replayed as plain launches -- bitwise the
+    eager scores for other batches (ids pointer replaced in the recorded arguments), for a batch in another memory
+    layout (copied into the plan's own ids), across a parameter update (re-recorded) and an overflow (flagged, NaN,
+    re-recorded with a larger workspace); D = 128 (activation-pattern attention, rows), D = 64 (matrix-core attention,
+    records), D = 256."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale=scale, bs=4096)
+    model.precision = model.tail_precision = mode
+    h = model.propagate()
+    batches = [torch.from_numpy(D.sample_pairs(ei, n, 4096, seed=90 + i)).to(DEV) for i in range(4)]
+    plan = lpformer_amd.PlannedScorer(model, score, h, batches[0], logits=True)
+    n_launch = sum(1 for c in plan._plan if c[1] is not None)
+    assert 4 <= n_launch <= 8, [c[0] for c in plan._plan]
+    for b in batches + batches[:2]:
+        got = plan(b).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, model.score_pairs(b, h, score, logits=True))
+    assert plan.check()
+    strided = torch.zeros(2, 8192, dtype=torch.int64, device=DEV)[:, ::2]          # another layout: copied in
+    strided.copy_(batches[2])
+    got = plan(strided).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got, model.score_pairs(batches[2], h, score, logits=True))
+    caps = plan.captures
+    with torch.no_grad():
+        score.lins[1].bias.add_(0.25)
+    want = model.score_pairs(batches[1], h, score, logits=True).clone()
+    got = plan(batches[1]).clone()
+    torch.cuda.synchronize()
+    assert plan.captures == caps + 1 and torch.equal(got, want)
+    if name == "collab":
+        deg = np.diff(data["adj_mask"].rowptr)
+        hubs = np.argsort(deg)[-64:]
+        rng = np.random.default_rng(5)
+        bd = torch.from_numpy(np.stack([rng.choice(hubs, 4096), rng.choice(hubs, 4096)])).to(DEV)
+        sparse = torch.from_numpy(rng.integers(0, n, size=(2, 4096))).to(DEV)
+        p2 = lpformer_amd.PlannedScorer(model, score, h, sparse, logits=True)
+        bad = p2(bd)
+        torch.cuda.synchronize()
+        all_nan = bool(torch.isnan(bad).all().item())
+        assert not p2.check() and all_nan
+        good = p2(bd).clone()
+        assert p2.check() and torch.equal(good, model.score_pairs(bd, h, score, logits=True))
 
 
 def test_selection_overflow_is_flagged_and_recovered():
@@ -346,6 +397,9 @@ def test_sweep_with_late_hub_batches_is_finite_and_right():
         assert (sweep - loop).abs().max().item() <= 2e-6
         for lane in model.lanes(streams):
             assert model.check_selection(lane)                            # nothing left pending
+    # the same through recorded steps: a plan's workspace is sized from the batch it was recorded with (a sparse one)
+    planned = E.score_edges(model, score, edges, batch_size=512, h=h, streams=2, plans=True)
+    assert torch.isfinite(planned).all() and (planned - loop).abs().max().item() <= 2e-6
     # HeaRT layout: positives with K negatives each, the hub-heavy negatives at the end of the flattened list
     model._ws.clear()
     pos = torch.from_numpy(sparse[:64])

@@ -206,6 +206,31 @@ def test_dense_chain_gathered_inputs(in_mode, d):
     assert (out.double() - ref).abs().max().item() <= 3e-5
 
 
+@pytest.mark.parametrize("d,sd", [(32, 32), (64, 64), (128, 128), (256, 256), (128, 36)])
+def test_dense_chain_side_gather(d, sd):
+    """lpf_dense_chain_side_f32: the elementwise branch's launch also gathers side[m] = S[a] + S[b] from a second table
+    (the attention's query from lin_l(X)) -- bitwise lpf_pair_gather_f32's sum, main output bitwise unchanged; a ragged
+    last block, a side width that is not the model width, a strided output."""
+    g_ = torch.Generator().manual_seed(d + sd)
+    r = lambda *s: torch.randn(*s, generator=g_).to(DEV)  # noqa: E731
+    n, m = 700, 1111
+    xn, stab = r(n, d), r(n, sd + 4)[:, :sd]
+    batch = torch.randint(0, n, (2, m), generator=g_).to(DEV)
+    batch[:, :3] = torch.tensor([[0, n - 1, 5], [0, 0, 5]])
+    w1, b1, lg, lb = r(d, d) / d ** 0.5, r(d), r(d), r(d)
+    dc = DenseChain("t")
+    t = dc.tables(w1, b1, lg, lb)
+    plain = dc.run(t, xn, relu=True, batch=batch, in_mode=1)
+    side = torch.full((m, sd + 4), 7.0, device=DEV)
+    both = dc.run(t, xn, relu=True, batch=batch, in_mode=1, side=(stab, side[:, :sd]))
+    assert plain is not None and both is not None and torch.equal(plain, both)
+    want = torch.empty(m, sd, device=DEV)
+    _lib.check(_lib.hip().lpf_pair_gather_f32(m, sd, _lib.ptr(batch), batch.stride(0), n, _lib.ptr(stab), stab.stride(0),
+                                              None, 0, _lib.ptr(want), sd, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(side[:, :sd], want) and torch.equal(want, stab[batch[0]] + stab[batch[1]])
+    assert (side[:, sd:] == 7.0).all()
+
+
 def test_dense_chain_unsupported_shape_is_reported():
     x, w1, b1 = torch.randn(8, 96, device=DEV), torch.randn(96, 96, device=DEV), torch.randn(96, device=DEV)
     dc = DenseChain("t")

@@ -1,16 +1,12 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_configs.py -m gpu -q -k "pair_rows or sweep" 2>&1 | tail -3
-for ex in "" "-DTC_NO_DEAL"; do
-  touch lpformer_amd/csrc/tail_chain.hip
-  make -C lpformer_amd/csrc EXTRA="$ex" > /dev/null 2>&1 || { echo "[$ex] build failed"; continue; }
-  for cfgargs in "" "--config cora"; do
-  for i in 1 2; do
-    echo "[$ex] $cfgargs"
-    python3 bench.py --gpus 1 --steps 20 --warmup 5 --rows on $cfgargs > gpurun_out/r04n_bench.log 2>&1
-    tail -1 gpurun_out/r04n_bench.log | python3 tools/all_configs_fmt.py | head -2 | cut -c1-100
-  done
-  done
+timeout 2400 python -m pytest tests -m gpu -q -x > gpurun_out/r04n_tests.log 2>&1
+tail -5 gpurun_out/r04n_tests.log
+for c in collab; do
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 --config $c > gpurun_out/r04n_bench_$c.log 2>&1
+  tail -1 gpurun_out/r04n_bench_$c.log | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); c=d['config']
+print(d['value'], d['ms_per_step'], c['launch'][:40], c['launch_probe_ms_per_step'], c.get('attention_form_probe_ms_per_step'))"
 done
-touch lpformer_amd/csrc/tail_chain.hip; make -C lpformer_amd/csrc > /dev/null 2>&1
