@@ -726,14 +726,19 @@ def main():
             # structural totals over the batches actually timed
             tp = [model.compute_node_mask(b) for b in batches]
             nsel = [sum(int(t[0].shape[1]) for t in sel if t is not None) for sel in tp]
+            # pairs that select at least one node (the others take the short form of the score head)
+            nfull = [int(torch.unique(torch.cat([t[0][0] for t in sel if t is not None])).numel()) for sel in tp]
             stats = [dict(pair_stats(data, b), slots=slot_count(model, bt)) for b, bt in zip(batches_np, batches)]
             used = [i % len(batches) for i in range(args.steps)]
             mean = lambda arr: float(np.mean([arr[i] for i in used]))  # noqa: E731
             n_sel, sum_deg = mean(nsel), mean([s["sum_deg"] for s in stats])
+            n_full = mean(nfull)
             sum_ppr = mean([s["sum_ppr_len"] for s in stats])
             # algorithmic work per launch: bytes for the HBM-bound kernels, FLOPs for MFMA ones
             slots = mean([s["slots"] for s in stats])
             c = model.count_dim
+            tail_short = bool(model.tail_skip_empty and model._uses_rows())
+            q_rides = model.query_from == "table" and "pair_gather_q" not in kt
             # the WHOLE pair stage against the HBM roof: SURVEY 8(d)'s B_pair summed over the batch (what a both-rows
             # walk of the reference's algorithm must touch) / the measured step time
             b_pair = 4.0 * sum_deg + 8.0 * sum_ppr + (32.0 + 16.0 + 4.0) * bs + 4.0 * d * (2.0 * bs + n_sel)
@@ -768,9 +773,14 @@ def main():
                 "dense_chain_mlp": ("mfma", (2.0 * bs * (2 * d * d) + 2.0 * bs * (d + c) * (2 * d + c)) / 2.0),
                 "dense_chain_attn_out": ("mfma", 2.0 * bs * d * (3 * d + 4)),
                 # merged dense tail: record merge + post-norm (no GEMM), first layer of pairwise_lin, folded score head
-                "tail_chain": ("mfma", 2.0 * bs * ((d + c) ** 2 + 2 * d * (2 * d + c))),
-                # first layer of elementwise_lin alone (score_pairs): D x D
-                "dense_chain_mlp_hidden": ("mfma", 2.0 * bs * d * d),
+                # (pairs without selected nodes -- workgroups of 64 of them -- need the r_e half of the head only: the
+                #  FLOPs counted are the ones the launch has to do, not the ones the reference spends on constants)
+                "tail_chain": ("mfma", (2.0 * bs * ((d + c) ** 2 + 2 * d * (2 * d + c)) if not tail_short else
+                                        2.0 * (n_full * ((d + c) ** 2 + 2 * d * (2 * d + c)) + (bs - n_full) * 2 * d * d))),
+                # first layer of elementwise_lin alone (score_pairs): D x D -- and, in the same launch, the query gather
+                # q = Y[a] + Y[b]: two table rows per endpoint in, two rows out, 1.1 GFLOP beside them
+                "dense_chain_mlp_hidden": (("hbm", (6.0 * 4.0 * d + 16.0) * bs) if q_rides else
+                                           ("mfma", 2.0 * bs * d * d)),
             }
             for name, (bound, units) in work.items():
                 if name not in kt:
@@ -809,7 +819,8 @@ def main():
             modelled = [k for k in sorted(kt, key=lambda k: -kt[k][1]) if k in rooflines]
             if modelled:
                 roofline = dict(rooflines[modelled[0]])
-                roofline["batch_stats"] = {"n_sel": n_sel, "sum_deg": sum_deg, "sum_ppr_len": sum_ppr, "slots": slots}
+                roofline["batch_stats"] = {"n_sel": n_sel, "sum_deg": sum_deg, "sum_ppr_len": sum_ppr, "slots": slots,
+                                           "pairs_with_selected_nodes": n_full}
         # encoder aggregation kernel (outside the timed pair-stage region): SURVEY 8(d) bytes per layer.  A square layer
         # runs as ONE launch (gcn_layer_fused: aggregation + transform + epilogue, csrc/gcn_fused.hip) with the same
         # algorithmic bytes as the aggregation alone -- the D x D product adds no memory traffic

@@ -34,7 +34,7 @@ extern "C" {
 #define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
 #define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
 
-#define LPF_ABI_VERSION 4
+#define LPF_ABI_VERSION 5
 
 /* GEMM / row-wise epilogue flags */
 #define LPF_FLAG_RELU 1u

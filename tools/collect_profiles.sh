@@ -28,7 +28,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES
 python3 tools/pmc_summary.py $OUT/${TAG}_mfma pair_fused_kernel pair_flip_kernel pair_rows_kernel tail_chain_kernel dense_chain_kernel gcn_fused_kernel gemm_f32 > $OUT/${TAG}_pmc_mfma_util.txt 2>&1
 echo "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); collected at commit $COMMIT" >> $OUT/${TAG}_pmc_mfma_util.txt
 # 5. timeline of the pipelined run
-rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_tl -- python3 bench.py --launch eager --weights random --no-cpu-baseline --no-kernel-timing --no-bf16 --repeats 1 --steps 40 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_tl -- python3 bench.py --launch plan --weights random --no-cpu-baseline --no-kernel-timing --no-bf16 --repeats 1 --steps 40 > /dev/null 2>&1
 python3 tools/timeline.py $(find $OUT/${TAG}_tl -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_timeline_pipelined.txt 2>&1
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_tl $OUT/${TAG}_mfma
 ls -la $OUT | grep ${TAG}_
