@@ -407,23 +407,29 @@ def main():
             torch.cuda.synchronize()
         for mode in ("rows", "records"):
             model.attention_rows = mode == "rows"
-            pl = planned_by_form[mode] = record_plans() if args.launch in ("plan", "auto") else None
+            planned_by_form[mode] = record_plans() if args.launch in ("plan", "auto") else None
+        for rnd in range(2):   # rows, records, rows, records: the smaller of a form's two times counts (whatever ran
+            #                    first on a box that is still settling would otherwise lose)
+            for mode in ("rows", "records"):
+                model.attention_rows = mode == "rows"
+                pl = planned_by_form[mode]
 
-            def probe_step(i):
-                if pl is not None:
-                    return pl[i % len(lanes)](batches[i % len(batches)], validate=False, ordered=False)
-                with torch.cuda.stream(lanes[i % len(lanes)]):
-                    return step(i)
-            for i in range(2 * len(lanes)):
-                probe_step(i)
-            torch.cuda.synchronize()
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(max(args.steps, 40)):
-                probe_step(i)
-            torch.cuda.synchronize()
-            barrier()
-            rows_probe[mode] = LD.max_over_ranks(time.perf_counter() - t0, dev) * 1e3 / max(args.steps, 40)
+                def probe_step(i):
+                    if pl is not None:
+                        return pl[i % len(lanes)](batches[i % len(batches)], validate=False, ordered=False)
+                    with torch.cuda.stream(lanes[i % len(lanes)]):
+                        return step(i)
+                for i in range(2 * len(lanes)):
+                    probe_step(i)
+                torch.cuda.synchronize()
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(max(args.steps, 40)):
+                    probe_step(i)
+                torch.cuda.synchronize()
+                barrier()
+                t = LD.max_over_ranks(time.perf_counter() - t0, dev) * 1e3 / max(args.steps, 40)
+                rows_probe[mode] = min(t, rows_probe.get(mode, t))
         model.attention_rows = rows_probe["rows"] <= rows_probe["records"]
         rows_probe = {k: round(v, 4) for k, v in rows_probe.items()}
 
