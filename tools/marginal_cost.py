@@ -52,7 +52,8 @@ with torch.no_grad():
     print(f"all launches: {base:.4f} ms per step; host time per replay {np.median(host):.4f} ms")
     names = {"elementwise branch + q gather": ["lpf_dense_chain_side_f32"],
              "select run": ["lpf_select3_run"],
-             "attention (rows)": ["lpf_pair_attention_rows_perm_f32"], "dense tail": ["lpf_tail_chain_rows_perm_f32", "lpf_tail_chain_rows_perm_bf16"],
+             # (the attention alone cannot be left out: the tail walks the pairs in the order it leaves)
+             "dense tail": ["lpf_tail_chain_rows_perm_f32", "lpf_tail_chain_rows_perm_bf16"],
              "attention + tail": ["lpf_pair_attention_rows_perm_f32", "lpf_tail_chain_rows_perm_f32", "lpf_tail_chain_rows_perm_bf16"]}
     if os.environ.get("LPF_ONLY_BASE"):
         names = {}
