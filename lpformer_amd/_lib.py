@@ -118,6 +118,38 @@ class LpfError(RuntimeError):
 
 _hip = None
 _host = None
+_recorder = None   # set by `recording(...)`: the launches, pointers and stream hand-overs of the calls made meanwhile
+
+
+class recording:
+    """``with recording(rec):`` every entry point fetched through ``hip()`` is handed to ``rec.launch(name, fn)`` (which
+    returns what the caller calls instead), every tensor whose address ``ptr()`` hands out to ``rec.keep(t)``, every
+    ``stream_wait(a, b)`` to ``rec.wait(a, b)``.  ``lpformer_amd.PlannedScorer`` records one scoring step this way.  One
+    recording at a time, from one thread (the hooks are module state)."""
+
+    def __init__(self, rec):
+        self.rec = rec
+
+    def __enter__(self):
+        global _recorder
+        if _recorder is not None:
+            raise LpfError("a recording is already in progress")
+        _recorder = self.rec
+        return self.rec
+
+    def __exit__(self, *exc):
+        global _recorder
+        _recorder = None
+        return False
+
+
+class _RecordingLib:
+    def __init__(self, lib, rec):
+        self._lib, self._rec = lib, rec
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        return self._rec.launch(name, fn) if name.startswith("lpf_") else fn
 
 
 def _bind(lib, protos):
@@ -139,7 +171,7 @@ def hip():
         if lib.lpf_abi_version() != ABI_VERSION:
             raise LpfError("liblpformer_hip.so ABI version mismatch; rebuild")
         _hip = lib
-    return _hip
+    return _hip if _recorder is None else _RecordingLib(_hip, _recorder)
 
 
 def host():
@@ -157,7 +189,7 @@ def host():
 
 def check(rc: int, what: str = ""):
     if rc != 0:
-        lib = hip()
+        lib = _hip if _hip is not None else hip()
         msg = lib.lpf_strerror(rc).decode()
         extra = lib.lpf_last_hip_error().decode()
         raise LpfError(f"{what or 'lpformer_hip call'} failed: {msg}" + (f" [{extra}]" if extra else ""))
@@ -165,7 +197,19 @@ def check(rc: int, what: str = ""):
 
 def ptr(t):
     """Device/host pointer of a torch tensor (None -> NULL)."""
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if _recorder is not None:
+        _recorder.keep(t)
+    return t.data_ptr()
+
+
+def stream_wait(waiter, waited):
+    """``waiter.wait_stream(waited)`` -- the one way the scoring path hands work from one stream to another, so that a
+    recording sees it."""
+    if _recorder is not None:
+        _recorder.wait(waiter, waited)
+    waiter.wait_stream(waited)
 
 
 def device_info():

@@ -98,6 +98,29 @@ class GraphedScorer:
         return False
 
 
+class _StepRecorder:
+    """What ``_lib.recording`` reports while one ``score_pairs`` call runs: the C-ABI launches (entry point, arguments)
+    and stream hand-overs in issue order, and every tensor whose address went into an argument."""
+
+    def __init__(self, skip):
+        self.skip, self.calls, self.kept = skip, [], []
+
+    def launch(self, name, fn):
+        if name in self.skip:   # (pure queries: nothing to replay)
+            return fn
+
+        def call(*args):
+            self.calls.append((name, fn, args))
+            return fn(*args)
+        return call
+
+    def keep(self, t):
+        self.kept.append(t)
+
+    def wait(self, waiter, waited):
+        self.calls.append((None, None, (waiter, waited)))
+
+
 class PlannedScorer(GraphedScorer):
     """The same fixed-size step as a RECORDED LIST OF C-ABI LAUNCHES, replayed one ``hipLaunchKernel`` after the other.
 
@@ -121,7 +144,6 @@ class PlannedScorer(GraphedScorer):
 
     def _capture(self):
         from . import _lib
-        from . import link_transformer as LT
         model, dev = self.model, self.model.device
         self._params = list(model.parameters()) + list(self.score_func.parameters())
         self.stream.wait_stream(torch.cuda.current_stream(dev))
@@ -131,36 +153,9 @@ class PlannedScorer(GraphedScorer):
                 model.score_pairs(self.batch, self.h, self.score_func, **kw)
             if not model.check_selection(self.stream):   # (first call of a stream sizes exactly: cannot overflow)
                 model.score_pairs(self.batch, self.h, self.score_func, **kw)
-            calls, keep = [], []
-            real_hip, real_ptr, real_wait = _lib.hip, LT.ptr, torch.cuda.Stream.wait_stream
-            lib = real_hip()
-
-            class _Recorder:
-                def __getattr__(rec, name):   # noqa: N805
-                    fn = getattr(lib, name)
-                    if name in self._SKIP or not name.startswith("lpf_"):
-                        return fn
-
-                    def call(*args):
-                        calls.append((name, fn, args))
-                        return fn(*args)
-                    return call
-
-            def rec_ptr(t):
-                if t is not None:
-                    keep.append(t)
-                return real_ptr(t)
-
-            def rec_wait(s, other):
-                calls.append((None, None, (s, other)))
-                return real_wait(s, other)
-
-            recorder = _Recorder()
-            _lib.hip, LT.ptr, torch.cuda.Stream.wait_stream = (lambda: recorder), rec_ptr, rec_wait
-            try:
+            with _lib.recording(_StepRecorder(self._SKIP)) as rec:
                 self.out = model.score_pairs(self.batch, self.h, self.score_func, **kw)
-            finally:
-                _lib.hip, LT.ptr, torch.cuda.Stream.wait_stream = real_hip, real_ptr, real_wait
+            calls, keep = rec.calls, rec.kept
             want = self.out.clone()
         b = self.batch   # (its extent in memory: a [2, BS] window of a longer id list has its rows far apart)
         base = b.data_ptr()

@@ -350,3 +350,47 @@ def test_packed_square_weight_matches_pack_dense():
     for d in (32, 64, 128):
         w = torch.randn(d, d)
         assert np.array_equal(_PackedSquare().get(w).numpy(), fold.pack_dense(w.numpy(), 1))
+
+
+def test_recording_hooks_report_launches_pointers_and_hand_overs():
+    """_lib.recording: what lpformer_amd.PlannedScorer records a scoring step through -- entry points fetched from the
+    library handle, tensors whose address is taken, stream hand-overs; nothing is reported outside the block, and a
+    second recording inside one is refused."""
+    import torch
+    from lpformer_amd import _lib
+
+    class Rec:
+        def __init__(self):
+            self.names, self.kept, self.waits = [], [], []
+
+        def launch(self, name, fn):
+            self.names.append(name)
+            return fn
+
+        def keep(self, t):
+            self.kept.append(t)
+
+        def wait(self, a, b):
+            self.waits.append((a, b))
+
+    class FakeStream:
+        def __init__(self):
+            self.waited = []
+
+        def wait_stream(self, other):
+            self.waited.append(other)
+
+    t = torch.zeros(4)
+    a, b = FakeStream(), FakeStream()
+    with _lib.recording(Rec()) as rec:
+        assert _lib.hip().lpf_abi_version() == _lib.ABI_VERSION
+        assert _lib.ptr(t) == t.data_ptr() and _lib.ptr(None) is None
+        _lib.stream_wait(a, b)
+        with pytest.raises(_lib.LpfError):
+            with _lib.recording(Rec()):
+                pass
+    assert rec.names == ["lpf_abi_version"] and rec.kept == [t] and rec.waits == [(a, b)] and a.waited == [b]
+    _lib.hip().lpf_abi_version()
+    _lib.ptr(t)
+    _lib.stream_wait(a, b)
+    assert rec.names == ["lpf_abi_version"] and len(rec.kept) == 1 and len(rec.waits) == 1 and a.waited == [b, b]
