@@ -953,7 +953,8 @@ class LinkTransformer(nn.Module):
             xr = _as_f32_rows(x_node)
             if self.query_from == "table" and 2 * self.dim <= 256:
                 # the query table Y will be asked for next: ONE [N, D] x [D, 2D] product leaves both, Z and Y being the
-                # two halves of its rows (X is read once; 0.14 ms instead of 0.09 + 0.10 on collab-like)
+                # two halves of its rows (one launch and one pass over X; the time is the matrix pipe's either way:
+                # 0.20 ms on collab-like against 0.09 + 0.10)
                 zy = gemm(xr, w["w_zy"], w["b_zy"], tag="gemm_node_keys")
                 z, y = zy[:, :self.dim], zy[:, self.dim:]
             else:
