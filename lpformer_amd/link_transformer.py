@@ -542,6 +542,7 @@ class LinkTransformer(nn.Module):
         self._x_cache = None   # (key, padded features)
         self._ws = {}          # named workspaces
         self._param_list = None  # cached list(self.parameters()) for the fold key
+        self._fold_memo = None   # the folded tables for the duration of one score_pairs call
         self._chain_att = DenseChain("dense_chain_attn_out")   # attention output projection + post_att_norm
         self._chain_q = DenseChain("pair_q")                   # q = lin_l(x_a) + lin_l(x_b)
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
@@ -695,6 +696,8 @@ class LinkTransformer(nn.Module):
 
     # ---------------------------------------------------------------------------------- folded weights
     def _fold(self):
+        if self._fold_memo is not None:   # (inside one score_pairs call: the ~40 version counters were just walked)
+            return self._fold_memo
         if self._param_list is None:
             self._param_list = list(self.parameters())
         key = tuple((p.data_ptr(), p._version) for p in self._param_list)
@@ -1531,6 +1534,14 @@ class LinkTransformer(nn.Module):
         if not two_layer:
             feats = self.pair_features(batch, X_node, test_set=test_set, adj_mask=adj_mask)
             return score_func.logits(feats) if logits else score_func(feats)
+        self._fold_memo = None
+        self._fold_memo = self._fold()   # one walk over the parameters' version counters per call, not one per helper
+        try:
+            return self._score_pairs_folded(batch, X_node, score_func, test_set, adj_mask, logits)
+        finally:
+            self._fold_memo = None
+
+    def _score_pairs_folded(self, batch, X_node, score_func, test_set, adj_mask, logits):
         with torch.no_grad():
             d, pd = self.dim, self.dim + self.count_dim
             batch = self._prep_batch(batch)
