@@ -35,9 +35,10 @@ def _planned_sweep(model, score_func, batch, out, h, batch_size, n_full, test_se
     from .graphed import PlannedScorer
     nl = max(1, min(streams, n_full))
     main = torch.cuda.current_stream(model.device)
+    lanes = model.lanes(nl)   # the model's persistent streams: every sweep finds the workspaces of the one before
     try:
         plans = [PlannedScorer(model, score_func, h, batch[:, k * batch_size:(k + 1) * batch_size], test_set=test_set,
-                               logits=logits, adopt_input=True) for k in range(nl)]
+                               logits=logits, adopt_input=True, stream=lanes[k]) for k in range(nl)]
     except RuntimeError:
         return False
     jobs = [[] for _ in plans]

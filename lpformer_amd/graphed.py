@@ -27,16 +27,20 @@ class GraphedScorer:
     comes back as NaN: call ``scorer.check()`` before using the scores of a sweep (it synchronises)."""
 
     def __init__(self, model, score_func, h: torch.Tensor, example_batch: torch.Tensor, test_set: bool = False,
-                 logits: bool = False, adopt_input: bool = False):
+                 logits: bool = False, adopt_input: bool = False, stream: "torch.cuda.Stream | None" = None):
         """``adopt_input``: the example batch (an int64 [2, BS] device tensor) IS the static input -- no private copy;
         a later call with that very tensor replays without the device-to-device copy of the ids (the caller refills it
-        in place, or, like the bench, keeps one resident batch per scorer)."""
+        in place, or, like the bench, keeps one resident batch per scorer).  ``stream``: the stream the step lives on
+        (default: a new one).  The model's per-stream workspaces behind it are the scorer's: give it a stream nothing
+        else scores on while the scorer is in use (a caller that rebuilds scorers often hands the same few streams back
+        instead of leaving a set of workspaces behind for every new one)."""
         self.model, self.score_func, self.h = model, score_func, h
         self.test_set, self.logits = test_set, logits
         dev = model.device
         prepped = model._prep_batch(example_batch)
         self.batch = prepped if (adopt_input and prepped is example_batch) else prepped.clone()
-        self.stream = torch.cuda.Stream(dev)   # private: the model's workspaces of this stream belong to the scorer
+        # private: the model's workspaces of this stream belong to the scorer
+        self.stream = stream if stream is not None else torch.cuda.Stream(dev)
         self.captures = 0
         self._capture()
 
