@@ -5,8 +5,9 @@
   testing.py:87 -> link_transformer.py:100);
 * batches are issued round-robin over a few HIP streams, so the selection kernels of one batch run underneath the
   matrix-core kernels of the previous one (per-stream workspaces in ``LinkTransformer``);
-* a long sweep replays RECORDED steps (``lpformer_amd.PlannedScorer``, one per stream): ``score_pairs`` spends ~0.15 ms of
-  host time per batch between its launches, more than the device needs at D <= 128;
+* a very long sweep (hundreds of batches: HeaRT / citation2 negatives) replays RECORDED steps
+  (``lpformer_amd.PlannedScorer``, one per stream): ``score_pairs`` spends ~0.13 ms of host time per batch between its
+  launches, more than the device needs at D = 64;
 * scores stay on the device -- no ``.cpu()`` per batch (testing.py:88,117); the ranking metrics below
   (src/train/evaluation.py:23-50 and the OGB ``hits@K`` rule) are a few reductions over them.
 
@@ -26,7 +27,11 @@ def _as_2xp(edges: torch.Tensor) -> torch.Tensor:
     return edges.t() if edges.shape[1] == 2 and edges.shape[0] != 2 else edges
 
 
-PLAN_MIN_BATCHES = 6   # full batches per stream from which recording the step pays (a recording costs ~5 eager steps)
+# Full batches per stream from which recording the step pays.  Measured (tools/sweep_rate.py, 8 streams): recording the
+# eight plans costs ~10 ms per sweep; a replayed batch saves 0.015 ms (collab-like: the device needs 0.19 of the 0.206 ms
+# an eager batch takes), 0.04 ms (ppa-like), 0.08 ms (citation2-like) -- break-even at 700 / 260 / 130 batches.  Sweeps
+# of that length are the HeaRT and citation2 negatives (testing.py:95-121), not the few batches of an ogbl-collab split.
+PLAN_MIN_BATCHES = 64
 
 
 def _planned_sweep(model, score_func, batch, out, h, batch_size, n_full, test_set, streams, logits) -> bool:
