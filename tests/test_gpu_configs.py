@@ -272,7 +272,14 @@ def test_step_replays_from_a_recorded_plan(name, scale, mode):
     model.precision = model.tail_precision = mode
     h = model.propagate()
     batches = [torch.from_numpy(D.sample_pairs(ei, n, 4096, seed=90 + i)).to(DEV) for i in range(4)]
+    # without the side stream the recording is launches only; with it (the default) the two hand-overs are in it too
+    model.use_side_stream = False
+    serial = lpformer_amd.PlannedScorer(model, score, h, batches[0], logits=True)
+    assert all(c[1] is not None for c in serial._plan)
+    model.use_side_stream = True
     plan = lpformer_amd.PlannedScorer(model, score, h, batches[0], logits=True)
+    assert sum(1 for c in plan._plan if c[1] is None) == 2
+    assert torch.equal(serial(batches[1]).clone(), plan(batches[1]))
     n_launch = sum(1 for c in plan._plan if c[1] is not None)
     assert 4 <= n_launch <= 8, [c[0] for c in plan._plan]
     for b in batches + batches[:2]:
