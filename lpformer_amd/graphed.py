@@ -128,7 +128,7 @@ class _StepRecorder:
 class PlannedScorer(GraphedScorer):
     """The same fixed-size step as a RECORDED LIST OF C-ABI LAUNCHES, replayed one ``hipLaunchKernel`` after the other.
 
-    Why beside the HIP graph: ``score_pairs`` spends ~0.15 ms of host time per step between its six launches (workspace
+    Why beside the HIP graph: ``score_pairs`` spends 0.13-0.15 ms of host time per step between its five launches (workspace
     look-ups, cache keys, pointer conversions), more than the device needs at D <= 128 once batches are pipelined over
     several streams -- the eager loop is bound by the host; and replayed graphs, which cost the host 0.04 ms per step,
     run their nodes with less overlap between streams than plain launches do (measured: tools/host_floor.py,
