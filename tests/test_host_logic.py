@@ -394,3 +394,40 @@ def test_recording_hooks_report_launches_pointers_and_hand_overs():
     _lib.ptr(t)
     _lib.stream_wait(a, b)
     assert rec.names == ["lpf_abi_version"] and len(rec.kept) == 1 and len(rec.waits) == 1 and a.waited == [b, b]
+
+
+def test_short_form_of_the_head_for_pairs_without_selected_nodes():
+    """fold.empty_pair_head_bias (the short form the dense tail runs for pairs that select nothing) against
+    the oracle's module arithmetic: attention over an empty set = bias, post_att_norm, zero counts, pairwise_lin, the
+    concatenation with the elementwise branch and the score head -- logit = w_dot . ReLU(A_e r_e + bC_empty) + b_dot for
+    any elementwise hidden activation r_e."""
+    fx = Fixture("lp_all_d64")
+    P = fx.params
+    d = fx.cfg["dim"]
+    rng = np.random.default_rng(3)
+    n = 40
+    # the reference's way: pairwise branch of a pair whose three selected sets are empty
+    pre = np.zeros((n, d), np.float32) + P["model.att_layers.0.att.bias"]
+    post = O.layer_norm(pre, P["model.att_layers.0.post_att_norm.weight"], P["model.att_layers.0.post_att_norm.bias"])
+    pw = O.mlp2(np.concatenate([post, np.zeros((n, 4), np.float32)], axis=1), P, "model.pairwise_lin")
+    x_e = rng.standard_normal((n, d)).astype(np.float32)               # any elementwise product x_a * x_b
+    h = O.linear(x_e, P["model.elementwise_lin.linears.0.weight"], P["model.elementwise_lin.linears.0.bias"])
+    r_e = np.maximum(O.layer_norm(h, P["model.elementwise_lin.norm.weight"], P["model.elementwise_lin.norm.bias"]), 0)
+    ew = O.linear(r_e, P["model.elementwise_lin.linears.1.weight"], P["model.elementwise_lin.linears.1.bias"])
+    _, want = O.mlp_score(np.concatenate([ew, pw], axis=1).astype(np.float32), P, 2)
+    # the folded way (LinkTransformer._score_fold in float64, then the short form)
+    f64 = lambda k: P[k].astype(np.float64)   # noqa: E731
+    ws0, bs0 = f64("score.lins.0.weight"), f64("score.lins.0.bias")
+    a_e = ws0[:, :d] @ f64("model.elementwise_lin.linears.1.weight")
+    a_p = ws0[:, d:] @ f64("model.pairwise_lin.linears.1.weight")
+    c = bs0 + ws0[:, :d] @ f64("model.elementwise_lin.linears.1.bias") + ws0[:, d:] @ f64("model.pairwise_lin.linears.1.bias")
+    a_fold = np.concatenate([a_e, a_p], axis=1)
+    bc_empty = fold.empty_pair_head_bias(P["model.att_layers.0.att.bias"], P["model.att_layers.0.post_att_norm.weight"],
+                                         P["model.att_layers.0.post_att_norm.bias"],
+                                         P["model.pairwise_lin.linears.0.weight"], P["model.pairwise_lin.linears.0.bias"],
+                                         P["model.pairwise_lin.norm.weight"], P["model.pairwise_lin.norm.bias"],
+                                         a_fold, c, d)
+    assert bc_empty.shape == (2 * d,) and bc_empty.dtype == np.float32
+    hid = np.maximum(r_e.astype(np.float64) @ a_e.T + bc_empty, 0)
+    got = hid @ f64("score.lins.1.weight").reshape(-1) + f64("score.lins.1.bias")[0]
+    assert np.abs(got - want).max() < 2e-5

@@ -60,5 +60,5 @@ if os.environ.get("LPF_TRAIN_PROFILE"):
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         for i in range(3): step(i)
         torch.cuda.synchronize()
-    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=70, max_name_column_width=90))
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=15, max_name_column_width=60))
