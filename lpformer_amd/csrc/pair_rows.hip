@@ -264,7 +264,11 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             return *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(A.Z) +
                                                     (uint64_t)(uint32_t)node * A.ldz + off);
         else
+#ifdef PR_ABL_NOZ   /* (timing only, wrong results: every entry reads one of two rows of Z -- no random gather) */
+            return *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)(node & 1) * A.ldz + off);
+#else
             return *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)node * A.ldz + off);
+#endif
     };
     auto z_wide = [&](const ZT &z) __attribute__((always_inline)) {
         if constexpr (ZB)
@@ -416,7 +420,11 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                                                  (f32x2{Q0v.x, Q0v.y} * cab.y + (f32x2{R0v.x, R0v.y} * cr + f32x2{C0v.x, C0v.y})));
                 f32x2 k23 = f32x2{zc.z, zc.w} + (f32x2{P0v.z, P0v.w} * cab.x +
                                                  (f32x2{Q0v.z, Q0v.w} * cab.y + (f32x2{R0v.z, R0v.w} * cr + f32x2{C0v.z, C0v.w})));
+#ifdef PR_ABL_NOFLIP   /* (timing only, wrong results: what do the corrections for flipped units cost?) */
+                if (false) {
+#else
                 if (__ballot(fl)) {
+#endif
                     // some unit of some group left the pattern of (0, 0): every lane of that group owes Wfold[:, k] |y_k|
                     // (pair_flip.hip: one pass over the eight (order, unit-of-the-lane) slots, flipped lanes one at a time)
                     const bool wt_lds = t >= T_LO && t < T_LO + WTL;
