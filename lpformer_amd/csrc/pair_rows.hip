@@ -369,6 +369,9 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                            ((head || more) ? 16 : 0) | (head ? 32 : 0) | 64 | ((head && !more && inl) ? 128 : 0);
                     const float *st = lstat + 8 * t;
                     const float pa = __int_as_float(rec.z), pb = __int_as_float(rec.w);
+                    // pe_stat[t][7]: inside [0, c]^2 no hidden unit leaves the pattern of (0, 0), in either argument order
+                    // (fold.no_flip_radius): such an entry needs no look at its units at all
+                    if (!(fmaxf(pa, pb) <= st[7])) meta |= 256;
                     const float vab = st[0] * pa * pa + st[1] * pb * pb + st[2] + 2.0f * (st[3] * pa * pb + st[4] * pa + st[5] * pb);
                     const float vba = st[0] * pb * pb + st[1] * pa * pa + st[2] + 2.0f * (st[3] * pa * pb + st[4] * pb + st[5] * pa);
                     sc = f32x2{__builtin_amdgcn_rsqf(fmaxf(vab, 0.0f) + 1e-5f), __builtin_amdgcn_rsqf(fmaxf(vba, 0.0f) + 1e-5f)};
@@ -404,6 +407,20 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 const f32x2 pab = {pa, pb}, pba = {pb, pa};
                 const int pair_i = (int)((uint32_t)rc.x & PR_PAIR_MASK);
                 const float4 *tabl = ltab + t * G + lj, *basel = lbase + t * D + lj;
+                const f32x2 cab = r12.x * pab + r12.y * pba;
+                const float cr = r12.x + r12.y;
+                const float4 P0v = basel[0], Q0v = basel[G], R0v = basel[2 * G], C0v = basel[3 * G];
+                f32x2 k01 = f32x2{zc.x, zc.y} + (f32x2{P0v.x, P0v.y} * cab.x +
+                                                 (f32x2{Q0v.x, Q0v.y} * cab.y + (f32x2{R0v.x, R0v.y} * cr + f32x2{C0v.x, C0v.y})));
+                f32x2 k23 = f32x2{zc.z, zc.w} + (f32x2{P0v.z, P0v.w} * cab.x +
+                                                 (f32x2{Q0v.z, Q0v.w} * cab.y + (f32x2{R0v.z, R0v.w} * cr + f32x2{C0v.z, C0v.w})));
+#ifdef PR_ABL_NOFLIP   /* (timing only, wrong results: what do detection and corrections of flipped units cost?) */
+                if (false) {
+#elif defined(PR_ABL_ALLDETECT)   /* (timing only: every entry looks at its units, as before the no-flip box) */
+                if (true) {
+#else
+                if (__ballot((meta & 256) != 0)) {   // some entry of this wavefront lies outside its type's no-flip box
+#endif
                 f32x2 zz[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -413,18 +430,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 const float zmin = fminf(fminf(fminf(zz[0].x, zz[0].y), fminf(zz[1].x, zz[1].y)),
                                          fminf(fminf(zz[2].x, zz[2].y), fminf(zz[3].x, zz[3].y)));
                 const bool fl = zmin < 0.f && on;
-                const f32x2 cab = r12.x * pab + r12.y * pba;
-                const float cr = r12.x + r12.y;
-                const float4 P0v = basel[0], Q0v = basel[G], R0v = basel[2 * G], C0v = basel[3 * G];
-                f32x2 k01 = f32x2{zc.x, zc.y} + (f32x2{P0v.x, P0v.y} * cab.x +
-                                                 (f32x2{Q0v.x, Q0v.y} * cab.y + (f32x2{R0v.x, R0v.y} * cr + f32x2{C0v.x, C0v.y})));
-                f32x2 k23 = f32x2{zc.z, zc.w} + (f32x2{P0v.z, P0v.w} * cab.x +
-                                                 (f32x2{Q0v.z, Q0v.w} * cab.y + (f32x2{R0v.z, R0v.w} * cr + f32x2{C0v.z, C0v.w})));
-#ifdef PR_ABL_NOFLIP   /* (timing only, wrong results: what do the corrections for flipped units cost?) */
-                if (false) {
-#else
                 if (__ballot(fl)) {
-#endif
                     // some unit of some group left the pattern of (0, 0): every lane of that group owes Wfold[:, k] |y_k|
                     // (pair_flip.hip: one pass over the eight (order, unit-of-the-lane) slots, flipped lanes one at a time)
                     const bool wt_lds = t >= T_LO && t < T_LO + WTL;
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     }
                     k01 += wp01 * vp;
                     k23 += wp23 * vp;
+                }
                 }
                 const f32x2 x01 = k01 * f32x2{qc.x, qc.y}, x23 = k23 * f32x2{qc.z, qc.w};
                 const f32x2 y01 = x01 * 0.2f, y23 = x23 * 0.2f;

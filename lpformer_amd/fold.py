@@ -79,6 +79,35 @@ def flip_tables(state: dict, dim: int, n_types: int, prefix="att_layers.0.att"):
     return tabs.astype(np.float32), base.astype(np.float32), s0, np.ascontiguousarray(wt.astype(np.float32))
 
 
+def no_flip_radius(tab_signed: np.ndarray, stat: np.ndarray, grid: int = 41, c_max: float = 0.5) -> float:
+    """Largest c (bisection to 1e-4, then shrunk by 5 %) such that on [0, c]^2 NO hidden unit of one PE MLP leaves the
+    pattern of (0, 0): z_k(x, y) = r(x, y) (ta_k x + tc_k y + td_k) + beta_k > 0 for every unit k of ``tab_signed`` [D, 4]
+    (``flip_tables``: signed for that pattern) on a ``grid`` x ``grid`` lattice of the square, float64.  The square is
+    symmetric, so both argument orders of an entry (pa, pb) with max(pa, pb) <= c are inside it: the pair-major
+    attention kernel (csrc/pair_rows.hip) then takes the base vectors as they are and never looks at the entry's units.
+    (Between lattice points z moves by O((c / grid)^2) of its curvature -- a unit that dips below zero there does so by
+    ~1e-7 and owes a correction of that size, far below the fp32 noise of the sums it would join.)  0 when some unit is
+    already at or below zero at the origin."""
+    tab, st = np.asarray(tab_signed, np.float64), np.asarray(stat, np.float64)
+
+    def ok(c):
+        g = np.linspace(0.0, c, grid)
+        xx, yy = (a.ravel() for a in np.meshgrid(g, g, indexing="ij"))
+        var = st[0] * xx * xx + st[1] * yy * yy + st[2] + 2.0 * (st[3] * xx * yy + st[4] * xx + st[5] * yy)
+        r = 1.0 / np.sqrt(np.maximum(var, 0.0) + 1e-5)
+        z = r[:, None] * (xx[:, None] * tab[:, 0] + yy[:, None] * tab[:, 1] + tab[:, 2]) + tab[:, 3]
+        return bool(z.min() > 0.0)
+    if not ok(0.0):
+        return 0.0
+    lo, hi = 0.0, float(c_max)
+    if ok(hi):
+        return 0.95 * hi
+    while hi - lo > 1e-4:
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if ok(mid) else (lo, mid)
+    return 0.95 * lo
+
+
 def fold_attention(state: dict, dim: int, n_types: int, prefix="att_layers.0.att"):
     """Returns dict of fp32 arrays: w_rx [D,D], b_r [D], wfold [3,D,D], bfold [3,D], wfold_packed (MFMA A-operand
     order), wcat [D, 3D+4] = [Wfold_0 | Wfold_1 | Wfold_2 | bfold_0 bfold_1 bfold_2 | att bias], w_l, b_l2 = 2 b_l."""

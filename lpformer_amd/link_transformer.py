@@ -708,6 +708,11 @@ class LinkTransformer(nn.Module):
         out = fold.fold_attention(sd, self.dim, n_types)
         out["pe_tab"], out["pe_stat"] = fold.pe_tables(sd, self.dim, n_types)
         out["flip_tab"], out["flip_base"], _, out["wfold_t"] = fold.flip_tables(sd, self.dim, n_types)
+        # pe_stat[t][7]: the square of PPR value pairs inside which no unit flips (the pair-major kernel skips the look at
+        # an entry's units there; the unit-major kernels never read the slot)
+        out["pe_stat"] = out["pe_stat"].copy()
+        for t in range(n_types):
+            out["pe_stat"][t, 7] = fold.no_flip_radius(out["flip_tab"][t], out["pe_stat"][t])
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
         self._folded = (key, dev)
         self._z_cache = None

@@ -431,3 +431,34 @@ def test_short_form_of_the_head_for_pairs_without_selected_nodes():
     hid = np.maximum(r_e.astype(np.float64) @ a_e.T + bc_empty, 0)
     got = hid @ f64("score.lins.1.weight").reshape(-1) + f64("score.lins.1.bias")[0]
     assert np.abs(got - want).max() < 2e-5
+
+
+def test_no_flip_radius_is_a_square_without_flips():
+    """fold.no_flip_radius: inside [0, c]^2 no hidden unit of the PE MLP leaves the pattern of (0, 0) (checked on random
+    points of the square, float64, both argument orders by symmetry of the square); just outside it some unit does, or
+    the search stopped at its cap; a unit sitting at zero at the origin gives 0."""
+    fx = Fixture("lp_all_d64")
+    m_sd, _ = fx.state_dicts()
+    sd = {k: torch.from_numpy(v) for k, v in m_sd.items()}
+    d = fx.cfg["dim"]
+    tabs, _, _, _ = fold.flip_tables(sd, d, 3)
+    _, stat = fold.pe_tables(sd, d, 3)
+    rng = np.random.default_rng(0)
+
+    def zmin(t, xy):
+        st, tb = stat[t].astype(np.float64), tabs[t].astype(np.float64)
+        x, y = xy[:, 0], xy[:, 1]
+        var = st[0] * x * x + st[1] * y * y + st[2] + 2 * (st[3] * x * y + st[4] * x + st[5] * y)
+        r = 1 / np.sqrt(np.maximum(var, 0) + 1e-5)
+        return (r[:, None] * (x[:, None] * tb[:, 0] + y[:, None] * tb[:, 1] + tb[:, 2]) + tb[:, 3]).min()
+    for t in range(3):
+        c = fold.no_flip_radius(tabs[t], stat[t])
+        assert 0.0 < c <= 0.5
+        assert zmin(t, rng.uniform(0, c, (100_000, 2))) > 0
+        if c < 0.45:
+            edge = np.concatenate([np.stack([np.full(2000, 1.25 * c), np.linspace(0, 1.25 * c, 2000)], 1),
+                                   np.stack([np.linspace(0, 1.25 * c, 2000), np.full(2000, 1.25 * c)], 1)])
+            assert zmin(t, edge) < 0
+    bad = tabs[0].copy()
+    bad[5, 2:] = 0.0           # unit 5: exactly zero at the origin
+    assert fold.no_flip_radius(bad, stat[0]) == 0.0
