@@ -19,6 +19,8 @@ from __future__ import annotations
 
 import torch
 
+from ._lib import check
+
 
 class GraphedScorer:
     """``scorer(batch) -> scores`` for candidate batches of ONE fixed size against a fixed encoder output ``h``.
@@ -183,7 +185,6 @@ class PlannedScorer(GraphedScorer):
                                "configuration does work outside the C-ABI launches)")
 
     def _replay(self, ids_ptr: int):
-        from ._lib import check
         base = self.batch.data_ptr()
         for name, fn, args, slots in self._plan:
             if fn is None:
