@@ -314,6 +314,25 @@ def test_step_replays_from_a_recorded_plan(name, scale, mode):
         assert p2.check() and torch.equal(good, model.score_pairs(bd, h, score, logits=True))
 
 
+@pytest.mark.parametrize("name,scale", [("collab", 0.1), ("ppa", 0.02), ("cora", 1.0)])
+def test_query_from_table_and_gemm_agree(name, scale):
+    """q = lin_l(x_a) + lin_l(x_b) from the per-node table Y (gathered inside the elementwise branch's launch) and as one
+    [BS, D] x [D, D] product on x_a + x_b per batch (``query_from``): the same scores to rounding, through the scoring
+    path and through the module-by-module one; D = 128 (rows form), 64 (matrix-core attention), 256."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale=scale, bs=3000)
+    tb = torch.from_numpy(batch).to(DEV)
+    h = model.propagate()
+    outs = {}
+    for mode in ("table", "gemm"):
+        model.query_from = mode
+        outs[mode] = (model.score_pairs(tb, h, score, logits=True).clone(), model.calc_pairwise(tb, h)[0].clone())
+        assert model.check_selection()
+    for a, b in zip(outs["table"], outs["gemm"]):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, float(a.abs().max()))
+    sample, ref = _oracle_sample(model, score, data, args, batch, h, k=96)
+    assert np.abs(outs["gemm"][0][:96].cpu().numpy() - ref["logit"]).max() <= 1e-4
+
+
 def test_selection_overflow_is_flagged_and_recovered():
     """A batch with many more selected entries than the workspace was sized for: the scores come back as NaN (never
     silently wrong), check_selection() reports it once, and the re-scored batch is right."""
