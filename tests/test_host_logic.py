@@ -462,3 +462,38 @@ def test_no_flip_radius_is_a_square_without_flips():
     bad = tabs[0].copy()
     bad[5, 2:] = 0.0           # unit 5: exactly zero at the origin
     assert fold.no_flip_radius(bad, stat[0]) == 0.0
+
+
+def test_recorded_plan_moves_every_pointer_into_the_ids():
+    """PlannedScorer._replay: an argument that points INTO the ids tensor the step was recorded with (the tensor itself,
+    its second row) follows the ids of the replay; everything else -- workspaces, sizes, a value that merely lies near --
+    stays; stream hand-overs are replayed in place; a non-zero status raises."""
+    from lpformer_amd.graphed import PlannedScorer
+
+    ids = torch.zeros(2, 100, dtype=torch.int64)[:, 10:42]          # a [2, 32] window of a longer id list: rows 800 B apart
+    base = ids.data_ptr()
+    seen = []
+
+    class FakeStream:
+        def wait_stream(self, other):
+            seen.append(("wait", self, other))
+    a, b = FakeStream(), FakeStream()
+    ok = lambda *args: (seen.append(args), 0)[1]     # noqa: E731
+    bad = lambda *args: 3                              # noqa: E731
+    extent = (1 * 100 + 31 * 1 + 1) * 8
+    plan = PlannedScorer.__new__(PlannedScorer)
+    plan.batch = ids
+    calls = [("k1", ok, (32, base, 100, base + 800, 12345)), (None, None, (a, b)),
+             ("k2", ok, (base + extent, base - 8, None))]
+    plan._plan = [(n, f, args, tuple(i for i, v in enumerate(args)
+                                     if f is not None and isinstance(v, int) and base <= v < base + extent))
+                  for n, f, args in calls]
+    assert plan._plan[0][3] == (1, 3) and plan._plan[2][3] == ()
+    plan._replay(base)
+    assert seen == [(32, base, 100, base + 800, 12345), ("wait", a, b), (base + extent, base - 8, None)]
+    del seen[:]
+    plan._replay(base + 4096)
+    assert seen[0] == (32, base + 4096, 100, base + 4896, 12345) and seen[2] == (base + extent, base - 8, None)
+    plan._plan.append(("k3", bad, (1,), ()))
+    with pytest.raises(_lib.LpfError):
+        plan._replay(base)
