@@ -34,7 +34,7 @@ extern "C" {
 #define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
 #define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
 
-#define LPF_ABI_VERSION 5
+#define LPF_ABI_VERSION 6
 
 /* GEMM / row-wise epilogue flags */
 #define LPF_FLAG_RELU 1u
@@ -264,6 +264,32 @@ int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int
                     int64_t *ctl, uint64_t *run_lb, const void *u_cv, const void *mini, float th_cn, float th_1hop,
                     float th_non1hop, int32_t mode_cn, int32_t *type_ptr, void *entries, int64_t ent_cap,
                     int32_t grid_blocks, void *stream);
+
+/* The same selection in ONE launch with PAIR-MAJOR output (select4.hip) -- the form the hot
+ * path runs: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (link_transformer.py:214-319,434-481) for the model's
+ * own typing adjacency, same index arrays, same per-candidate arithmetic and therefore the same index sets and PPR
+ * values bit for bit as lpf_select3_*.  A workgroup owns a block of LPF_SELECT4_BLOCK consecutive pairs: it plans their
+ * walks itself (no plan launch, no descriptors in memory), types the block's candidate slots, and compacts the kept
+ * entries in slot order -- a pair's entries are contiguous -- with ballot ranks and one scan inside the workgroup (no
+ * chained scan over the batch).  Where a block lands in `entries` is one atomic add; consumers address entries through
+ * pair_tab only, so results do not depend on it.
+ *   entries   16-byte records {pair | type << 29 | from_N(b) << 31, node, pa, pb}, type 1 = common neighbour,
+ *             2 = one-hop, 3 = >1-hop; a pair's entries in candidate-slot order (neighbours of a, then of b, then
+ *             the >1-hop nodes), types mixed
+ *   pair_tab  int32[bs][4] = {first entry, n_cn, n_1hop, n_non1hop} per pair
+ *   blk_cnt   int32[ceil(bs / LPF_SELECT4_BLOCK)]: selected entries per block of pairs
+ *   ctl       int64[LPF_SELECT_CTL_WORDS], zero-initialised once by the caller, then owned by the library (one control
+ *             block per stream): [0] entries the last batch needed room for (its candidate slots, block by block rounded
+ *             up to 8: what ent_cap is sized from)  [3] STICKY error bits as above  [9], [10] allocation and completion
+ *             counters (zero between launches)
+ * A block that does not fit below ent_cap leaves empty pairs and raises LPF_SELECT_ERR_ENTRY_CAP (consumers write NaN
+ * rows while the bit is set).  threads: 0 (default), 512 or 1024 per workgroup. */
+#define LPF_SELECT4_BLOCK 64
+int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
+                const void *adj_cv, const void *a1_cv, const void *px_cv, const void *t0_cv, const void *u_cv,
+                const void *mini, int32_t mode_cn, int32_t use_px, float th_cn, float th_1hop, float th_non1hop,
+                int64_t *ctl, void *pair_tab, int32_t *blk_cnt, void *entries, int64_t ent_cap, int32_t threads,
+                void *stream);
 
 /* The reference's layout from the regions above: all CN entries sorted by (pair, node), then all 1-hop (the two runs
  * merged by node id), then all >1-hop (link_transformer.py:161-162); type_ptr64 int64[3*(bs+1)] relative per type,
@@ -513,6 +539,27 @@ int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const int32_t *typ
                                        const float *ln_g, const float *ln_b, int32_t n_counts, const int64_t *sel_ctl,
                                        float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
                                        uint64_t *perm_lb, int64_t *n_nonempty, void *stream);
+/* lpf_pair_attention_rows_perm_* behind lpf_select4: the entries are pair-major already (a pair's entries contiguous from
+ * pair_tab[p][0], the type in bits 29-30 of the record's pair word), so the kernel reads ONE region and needs no per-type
+ * pointers; its workgroups split the batch by blk_cnt (entries per LPF_SELECT4_BLOCK pairs) and the 64 table entries of the
+ * block a cut falls into.  units_cap >= ceil(ent_cap / 16) + 1.  perm / perm_lb / n_nonempty: all three, or all NULL (no
+ * order for the tail).  Everything else as lpf_pair_attention_rows_f32; the rows agree with that call's up to the order
+ * in which a pair's entries are summed. */
+int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt, const void *entries,
+                                 int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
+                                 const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                 const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
+                                 const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
+                                 int64_t units_cap, float *out, int64_t ldo, int32_t *perm, uint64_t *perm_lb,
+                                 int64_t *n_nonempty, void *stream);
+int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
+                                   const void *entries, int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q,
+                                   int64_t ldq, const float *pe_tab_signed, const float *pe_stat, const float *base,
+                                   const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
+                                   const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
+                                   int64_t units_cap, float *out, int64_t ldo, int32_t *perm, uint64_t *perm_lb,
+                                   int64_t *n_nonempty, void *stream);
+
 int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
                                  const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
                                  const float *r_e, int64_t ldre, const float *wC_packed, const float *bC,

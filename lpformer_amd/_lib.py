@@ -11,10 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "liblpformer_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "liblpformer_host.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_RELU = 1
 SELECT_ERR_NODE_RANGE, SELECT_ERR_ITEM_CAP, SELECT_ERR_ENTRY_CAP = 1, 2, 4
 ROWS_PERM_LB_WORDS = 1025      # LPF_ROWS_PERM_LB_WORDS (include/lpformer_hip.h)
+SELECT4_BLOCK = 64             # LPF_SELECT4_BLOCK
 
 i32, i64, f32, f64, u32, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32, C.c_void_p
 
@@ -50,6 +51,7 @@ HIP_PROTOTYPES = {
                        i32, vp],
     "lpf_select3_plan": [i64, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp],
     "lpf_select3_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, f32, f32, f32, i32, vp, vp, i64, i32, vp],
+    "lpf_select4": [i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp, i64, i32, vp],
     "lpf_select_export": [i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp],
@@ -66,6 +68,10 @@ HIP_PROTOTYPES = {
                                          vp, i64, vp, i64, vp, vp, vp, vp],
     "lpf_pair_attention_rows_perm_zbf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                            vp, vp, i64, vp, i64, vp, vp, vp, vp],
+    "lpf_pair_attention_rows4_f32": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp,
+                                     vp, i64, vp, i64, vp, vp, vp, vp],
+    "lpf_pair_attention_rows4_zbf16": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp,
+                                       vp, i64, vp, i64, vp, vp, vp, vp],
     "lpf_tail_chain_rows_perm_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp],
     "lpf_tail_chain_rows_perm_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,

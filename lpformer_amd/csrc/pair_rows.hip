@@ -63,6 +63,9 @@ struct RowsArgs {
     uint64_t *perm_lb;         // [PR_LB_WORDS + 1] chained-scan words (tagged with the launch number, never cleared) + the
                                // launch counter
     int64_t *n_nonempty;       // receives the number of pairs with selected nodes
+    // PT (pair-table) form -- the selection of select4.hip: entries pair-major already, the type in the record
+    const int4 *pair_tab;      // [bs] {first entry, n_cn, n_1hop, n_non1hop}
+    const int32_t *blk_cnt;    // [ceil(bs / LPF_SELECT4_BLOCK)] entries per block of pairs
 };
 
 template <int CTRL>
@@ -120,11 +123,14 @@ struct PrLds {
 };
 
 // ZB: the node table Z is stored in bf16 (the bf16 throughput mode)
-template <int G, int NTH, int WTL, bool ZB = false>
+// PT: the selection came from select4.hip (pair_tab / blk_cnt instead of the three type-major regions and type_ptr)
+template <int G, int NTH, int WTL, bool ZB = false, bool PT = false>
 __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(const RowsArgs A) {
     using ZT = typename std::conditional<ZB, uint2, float4>::type;
     using L = PrLds<G, NTH, WTL>;
     constexpr int D = 4 * G, EPW = 64 / G, NG = L::NG, T_LO = WTL == 1 ? 1 : 0, TPS = PR_CHUNK + 4, RSP = pr_piece_floats(D);
+    constexpr uint32_t PAIR_MASK = PT ? 0x1fffffffu : PR_PAIR_MASK;
+    constexpr int SB = LPF_SELECT4_BLOCK;
     extern __shared__ __attribute__((aligned(16))) float4 pr_lds[];
     float4 *const ltab = pr_lds + L::TAB;        // [4][3][G]: row j of hidden unit 4 lj + j, type t -> ((j * 3 + t) * G + lj)
     float4 *const lbase = pr_lds + L::BASE;      // [3][4][G]
@@ -148,13 +154,22 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     int st_rounds = 0;
     PR_STAMP(0);
 #endif
-    int64_t n[3];
+    int64_t n[3] = {0, 0, 0};
+    if constexpr (!PT) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        n[t] = A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs];
-        if (n[t] > A.ent_cap) n[t] = A.ent_cap;   // (overflow: flagged by the selection kernel, stay inside the region)
-        if (n[t] < 0) n[t] = 0;
+        for (int t = 0; t < 3; ++t) {
+            n[t] = A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs];
+            if (n[t] > A.ent_cap) n[t] = A.ent_cap;   // (overflow: flagged by the selection kernel, stay inside the region)
+            if (n[t] < 0) n[t] = 0;
+        }
     }
+    // PT: entries of pair p (a pair whose table entry does not lie inside the buffer counts as empty: nothing is read
+    // outside it whatever the table holds)
+    auto pt_count = [&](int64_t p) __attribute__((always_inline)) {
+        const int4 e = A.pair_tab[p];
+        const int64_t c = (int64_t)e.y + e.z + e.w;
+        return (e.x < 0 || e.y < 0 || e.z < 0 || e.w < 0 || e.x + c > A.ent_cap) ? 0 : (int)c;
+    };
     const bool bad = A.sel_ctl && A.sel_ctl[3] != 0;
     for (int i = tid; i < 3 * D; i += NTH) {
         const int t = i / D, k = i % D;
@@ -174,16 +189,104 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     // pair-major position of pair p's first entry (the pointers clamped into their regions)
     auto cum_at = [&](int64_t p) __attribute__((always_inline)) {
         int64_t c = 0;
+        if constexpr (!PT) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int64_t v = A.type_ptr[(int64_t)t * (A.bs + 1) + p];
-            c += v < n[t] ? (v < 0 ? 0 : v) : n[t];
+            for (int t = 0; t < 3; ++t) {
+                const int64_t v = A.type_ptr[(int64_t)t * (A.bs + 1) + p];
+                c += v < n[t] ? (v < 0 ? 0 : v) : n[t];
+            }
         }
         return c;
     };
-    // ---- the workgroup's pair range: first pair p with  p + C[p]  >= b * (entries + pairs) / gridDim.x  (64-ary search,
-    //      three dependent rounds for 32 k pairs; wavefront 0 looks for the lower end, wavefront 1 for the upper one,
-    //      the others fill the tables above meanwhile)
+    // does pair p select anything?
+    auto nonempty = [&](int64_t p) __attribute__((always_inline)) {
+        if constexpr (PT) return pt_count(p) > 0;
+        else return cum_at(p + 1) > cum_at(p);
+    };
+    // ---- the workgroup's pair range: first pair p with  p + C[p]  >= b * (entries + pairs) / gridDim.x
+    if constexpr (PT) {
+        // The selection left entries per BLOCK of 64 pairs: every thread sums the weights (entries + pairs) of its share of
+        // the blocks, one scan over the workgroup gives every share's place, the two threads whose share holds a target
+        // walk it; then wavefront 0 / 1 find the pair inside that block from its 64 table entries.
+        int64_t *const wtot = reinterpret_cast<int64_t *>(lwcnt);        // [NTH / 64] (LDS scratch, 16 words)
+        int64_t *const cut = reinterpret_cast<int64_t *>(lflag);         // [2][2]: block, weight in front of it
+        const int64_t nblk = (A.bs + SB - 1) / SB;
+        const int64_t per = (nblk + NTH - 1) / NTH;
+        auto blk_w = [&](int64_t B) __attribute__((always_inline)) {
+            const int c = A.blk_cnt[B];
+            const int64_t np = A.bs - B * SB < SB ? A.bs - B * SB : SB;
+            return (int64_t)(c < 0 ? 0 : c) + np;
+        };
+        int64_t own = 0;
+        for (int64_t i = 0; i < per; ++i) {
+            const int64_t B = (int64_t)tid * per + i;
+            if (B < nblk) own += blk_w(B);
+        }
+        int64_t x = own;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int64_t y = __shfl_up(x, dlt, 64);
+            if (lane >= dlt) x += y;
+        }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        int64_t pre = 0, total = 0;
+        for (int w = 0; w < NTH / 64; ++w) {
+            if (w < wave) pre += wtot[w];
+            total += wtot[w];
+        }
+        const int64_t ex = pre + x - own;    // weight in front of this thread's first block
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t b = (int64_t)blockIdx.x + e;
+            const int64_t target = (total * b) / (int64_t)gridDim.x;
+            // last block B with (weight in front of B) < target: it lies in the share with ex < target <= ex + own
+            if (b > 0 && b < (int64_t)gridDim.x && ex < target && target <= ex + own) {
+                int64_t B = (int64_t)tid * per, f = ex;
+                while (B + 1 < nblk && B + 1 < (int64_t)(tid + 1) * per) {
+                    const int64_t fn = f + blk_w(B);
+                    if (fn >= target) break;
+                    f = fn;
+                    ++B;
+                }
+                cut[2 * e] = B;
+                cut[2 * e + 1] = f;
+            }
+        }
+        __syncthreads();
+        if (wave < 2) {
+            const int64_t b = (int64_t)blockIdx.x + wave;
+            int64_t P = 0, C = 0;
+            if (b >= (int64_t)gridDim.x) {
+                P = A.bs; C = total - A.bs;
+            } else if (b > 0) {
+                const int64_t target = (total * b) / (int64_t)gridDim.x;
+                const bool any = target > 0;                     // (fewer entries + pairs than workgroups: nothing in front)
+                const int64_t B = any ? cut[2 * wave] : 0, f = any ? cut[2 * wave + 1] : 0;
+                const int64_t p = B * SB + lane;
+                const int cnt = p < A.bs ? pt_count(p) : 0;
+                int xs = cnt;     // inclusive scan of the entries
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                    const int y = __shfl_up(xs, dlt, 64);
+                    if (lane >= dlt) xs += y;
+                }
+                // f(p) = f + lane + (entries of the block's pairs in front of p)
+                const bool below = p < A.bs && f + lane + (xs - cnt) < target;
+                const uint64_t bm = __ballot(below);      // (monotone: the first c pairs are below the target)
+                const int c = __popcll(bm);
+                const int before = c == 0 ? 0 : __shfl(xs, c - 1, 64);
+                P = B * SB + c;
+                C = f - B * SB + before;
+            }
+            if (lane == 0) {
+                lctl[4 + 2 * wave] = (int)(P & 0xffffffff); lctl[5 + 2 * wave] = (int)(P >> 32);
+                lctl[12 + 2 * wave] = (int)(C & 0xffffffff); lctl[13 + 2 * wave] = (int)(C >> 32);
+            }
+        }
+    } else
+    // (type-major form: 64-ary search over the pointers, three dependent rounds for 32 k pairs; wavefront 0 looks for
+    //  the lower end, wavefront 1 for the upper one, the others fill the tables above meanwhile)
     if (wave < 2) {
         const int64_t total = n[0] + n[1] + n[2] + A.bs;
         const int64_t b = (int64_t)blockIdx.x + wave;
@@ -215,6 +318,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     PR_STAMP(1);
     const int64_t P0 = (int64_t)(uint32_t)lctl[4] | ((int64_t)lctl[5] << 32);
     const int64_t P1 = (int64_t)(uint32_t)lctl[6] | ((int64_t)lctl[7] << 32);
+    int64_t vpos = PT ? ((int64_t)(uint32_t)lctl[12] | ((int64_t)lctl[13] << 32)) : 0;   // PT: pair-major position of the chunk
 
     // ---- the tail's order, first half: publish how many pairs of this workgroup's range select anything (word
     //      blockIdx.x of perm_lb, tagged with this launch's number: word PR_LB_WORDS counts the launches).  The second half
@@ -222,7 +326,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     //      predecessor's word has long been out, nobody spins on a workgroup that is not resident yet.
     if (A.perm) {
         int cnt = 0;
-        for (int64_t k = P0 + tid; k < P1; k += NTH) cnt += cum_at(k + 1) > cum_at(k) ? 1 : 0;
+        for (int64_t k = P0 + tid; k < P1; k += NTH) cnt += nonempty(k) ? 1 : 0;
 #pragma unroll
         for (int dlt = 32; dlt > 0; dlt >>= 1) cnt += __shfl_xor(cnt, dlt, 64);
         if (lane == 0) lwcnt[wave] = cnt;
@@ -284,6 +388,52 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     for (int64_t c0 = P0; c0 < P1; c0 += PR_CHUNK) {
         const int cn = (int)(P1 - c0 < PR_CHUNK ? P1 - c0 : PR_CHUNK);
         __syncthreads();   // the previous chunk's lists and pointers are no longer needed
+        int64_t v0, v1;
+        if constexpr (PT) {
+            // the chunk's table entries: ltp[k] = first entry, ltp[TPS + k] / ltp[2 TPS + k] = common neighbours / one-hop
+            // nodes of pair k, lcum = the entries in front of pair k inside the chunk (a scan over the workgroup)
+            constexpr int PER = (PR_CHUNK + NTH - 1) / NTH;
+            int cnt[PER], own = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = tid * PER + i;
+                cnt[i] = 0;
+                if (k < cn) {
+                    const int4 e = A.pair_tab[c0 + k];
+                    const bool ok = pt_count(c0 + k) > 0;
+                    cnt[i] = ok ? e.y + e.z + e.w : 0;
+                    ltp[k] = ok ? e.x : 0;
+                    ltp[TPS + k] = ok ? e.y : 0;
+                    ltp[2 * TPS + k] = ok ? e.z : 0;
+                }
+                own += cnt[i];
+            }
+            int x = own;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int y = __shfl_up(x, dlt, 64);
+                if (lane >= dlt) x += y;
+            }
+            if (lane == 63) lwcnt[wave] = x;
+            if (tid < 4) lctl[tid] = 0;
+            __syncthreads();
+            int pre = 0, tot = 0;
+            for (int w = 0; w < NTH / 64; ++w) {
+                if (w < wave) pre += lwcnt[w];
+                tot += lwcnt[w];
+            }
+            int run = pre + x - own;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = tid * PER + i;
+                if (k < cn) lcum[k] = run;
+                run += cnt[i];
+            }
+            if (tid == 0) lcum[cn] = tot;
+            v0 = vpos;
+            v1 = vpos + tot;
+            vpos = v1;
+        } else {
         for (int i = tid; i < 3 * (cn + 1); i += NTH) {
             const int t = i / (cn + 1), k = i % (cn + 1);
             int64_t v = A.type_ptr[(int64_t)t * (A.bs + 1) + c0 + k];
@@ -293,12 +443,13 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         if (tid < 4) lctl[tid] = 0;
         __syncthreads();
         // pair-major base of the chunk, then every pair's start relative to it (fits 31 bits: ent_cap does)
-        const int64_t v0 = (int64_t)ltp[0] + ltp[TPS] + ltp[2 * TPS];
-        const int64_t v1 = (int64_t)ltp[cn] + ltp[TPS + cn] + ltp[2 * TPS + cn];
-        const int64_t u_first = v0 >> 4;
-        const int n_units = v1 > v0 ? (int)(((v1 - 1) >> 4) - u_first + 1) : 0;
+        v0 = (int64_t)ltp[0] + ltp[TPS] + ltp[2 * TPS];
+        v1 = (int64_t)ltp[cn] + ltp[TPS + cn] + ltp[2 * TPS + cn];
         for (int k = tid; k <= cn; k += NTH)
             lcum[k] = (int)(((int64_t)ltp[k] + ltp[TPS + k] + ltp[2 * TPS + k]) - v0);
+        }
+        const int64_t u_first = v0 >> 4;
+        const int n_units = v1 > v0 ? (int)(((v1 - 1) >> 4) - u_first + 1) : 0;
         // A pair in several pieces is merged by the group that walks its LAST piece, right behind that unit, once the
         // units in front of it are flagged done (they were drawn earlier: nobody waits for a later unit) -- no barrier,
         // no separate merge phase.  Only a chunk of more than PR_FLAGS units falls back to barrier + merge list.
@@ -308,7 +459,12 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         __syncthreads();
         // ---- sort the chunk's pairs (empty / in several pieces); the count features go out at once
         for (int k = tid; k < cn; k += NTH) {
-            const int n0 = ltp[k + 1] - ltp[k], n1 = ltp[TPS + k + 1] - ltp[TPS + k], n2 = ltp[2 * TPS + k + 1] - ltp[2 * TPS + k];
+            int n0, n1, n2;
+            if constexpr (PT) {
+                n0 = ltp[TPS + k]; n1 = ltp[2 * TPS + k]; n2 = lcum[k + 1] - lcum[k] - n0 - n1;
+            } else {
+                n0 = ltp[k + 1] - ltp[k]; n1 = ltp[TPS + k + 1] - ltp[TPS + k]; n2 = ltp[2 * TPS + k + 1] - ltp[2 * TPS + k];
+            }
             const int np = n0 + n1 + n2;
             if (np == 0) {
                 llist[atomicAdd(&lctl[0], 1)] = k;
@@ -358,11 +514,18 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                         if (lcum[mid] <= xr) lo = mid; else hi = mid;
                     }
                     const int k = lo, ps = lcum[k], pe = lcum[k + 1], j = xr - ps;
-                    const int *tp = ltp + k;
-                    const int lo0 = tp[0], n0 = tp[1] - lo0, lo1 = tp[TPS], n1 = tp[TPS + 1] - lo1, lo2 = tp[2 * TPS];
-                    const int t = (j >= n0) + (j >= n0 + n1);
-                    const int64_t idx = t == 0 ? lo0 + j : (t == 1 ? lo1 + (j - n0) : lo2 + (j - n0 - n1));
-                    rec = A.entries[(int64_t)t * A.ent_cap + idx];
+                    int t;
+                    if constexpr (PT) {      // the pair's entries are contiguous, the type travels in the record
+                        rec = A.entries[(int64_t)ltp[k] + j];
+                        t = (int)(((uint32_t)rec.x >> 29) & 3u) - 1;
+                        t = t < 0 ? 0 : t;
+                    } else {
+                        const int *tp = ltp + k;
+                        const int lo0 = tp[0], n0 = tp[1] - lo0, lo1 = tp[TPS], n1 = tp[TPS + 1] - lo1, lo2 = tp[2 * TPS];
+                        t = (j >= n0) + (j >= n0 + n1);
+                        const int64_t idx = t == 0 ? lo0 + j : (t == 1 ? lo1 + (j - n0) : lo2 + (j - n0 - n1));
+                        rec = A.entries[(int64_t)t * A.ent_cap + idx];
+                    }
                     const int64_t ustart = x0 - v0, uend = ustart + 16;        // the unit in chunk-relative positions
                     const bool head = ps < ustart, more = pe > uend;
                     meta = t | ((j == 0 || i == 0) ? 4 : 0) | ((xr == pe - 1 || i == 15) ? 8 : 0) |
@@ -385,7 +548,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             ZT za[4], zb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) za[u] = z_row(lr[lro + u].y);
-            float4 qc = q_row((int)((uint32_t)lr[lro].x & PR_PAIR_MASK));
+            float4 qc = q_row((int)((uint32_t)lr[lro].x & PAIR_MASK));
             float *const piece_u = A.pieces + (u_first + ul) * 2 * RSP;
             float m = -INFINITY, l = 0.f;
             f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
@@ -399,13 +562,13 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 const int4 rc = lr[lro + i];
                 const f32x2 r12 = ls[lro + i];
                 const int meta = lm[lro + i];
-                const int pair_n = (int)((uint32_t)lr[lro + (i < 15 ? i + 1 : 15)].x & PR_PAIR_MASK);
+                const int pair_n = (int)((uint32_t)lr[lro + (i < 15 ? i + 1 : 15)].x & PAIR_MASK);
                 const float4 qn = q_row(pair_n);
                 const bool on = meta & 64;
                 const int t = meta & 3;
                 const float pa = __int_as_float(rc.z), pb = __int_as_float(rc.w);
                 const f32x2 pab = {pa, pb}, pba = {pb, pa};
-                const int pair_i = (int)((uint32_t)rc.x & PR_PAIR_MASK);
+                const int pair_i = (int)((uint32_t)rc.x & PAIR_MASK);
                 const float4 *tabl = ltab + t * G + lj, *basel = lbase + t * D + lj;
                 const f32x2 cab = r12.x * pab + r12.y * pba;
                 const float cr = r12.x + r12.y;
@@ -634,7 +797,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         for (int64_t k0 = P0; k0 < P1; k0 += NTH) {
             const int64_t k = k0 + tid;
             const bool in = k < P1;
-            const bool ne = in && cum_at(k + 1) > cum_at(k);
+            const bool ne = in && nonempty(k);
             const uint64_t b_ne = __ballot(ne), b_all = __ballot(in);
             if (lane == 0) { lwcnt[wave] = __popcll(b_ne); lwcnt[16 + wave] = __popcll(b_all); }
             __syncthreads();
@@ -661,17 +824,18 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
 #endif
 }
 
-template <bool ZB>
+template <bool ZB, bool PT = false>
 int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap, const void *Z,
                 int64_t ldz, const float *q, int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
                 const float *base, const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
                 const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
                 int64_t ldo, void *stream, int32_t *perm = nullptr, uint64_t *perm_lb = nullptr,
-                int64_t *n_nonempty = nullptr) {
+                int64_t *n_nonempty = nullptr, const void *pair_tab = nullptr, const int32_t *blk_cnt = nullptr) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && bs < (1ll << 31) && type_ptr && entries && ent_cap > 0 && ent_cap < (1ll << 29) && Z && q &&
+    LPF_REQUIRE(bs > 0 && bs < (PT ? (1ll << 29) : (1ll << 31)) && (PT ? (pair_tab && blk_cnt && lpf_aligned16(pair_tab)) : type_ptr != nullptr) &&
+                entries && ent_cap > 0 && ent_cap < (PT ? (1ll << 31) : (1ll << 29)) && Z && q &&
                 pe_tab_signed && pe_stat && base && wfold_t && att && att_bias && ln_g && ln_b && out && pieces &&
-                units_cap >= (3 * ent_cap + 15) / 16 + 1 && lpf_aligned16(pieces));
+                units_cap >= ((PT ? 1 : 3) * ent_cap + 15) / 16 + 1 && lpf_aligned16(pieces));
     LPF_REQUIRE(!perm || (perm_lb && n_nonempty));
     LPF_REQUIRE((n_counts == 0 || n_counts == 1 || n_counts == 3 || n_counts == 4) && ldo >= D + n_counts && (ldo & 3) == 0);
     LPF_REQUIRE(ldz >= D && ldq >= D && ldz < (1ll << 31) && ldq < (1ll << 31) && (ldz & (ZB ? 7 : 3)) == 0 &&
@@ -680,7 +844,8 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
                 lpf_aligned16(att_bias) && lpf_aligned16(ln_g) && lpf_aligned16(ln_b) && lpf_aligned16(out));
     const RowsArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), (uint32_t)ldz,
                      q, (uint32_t)ldq, pe_tab_signed, pe_stat, base, wfold_t, att, att_bias, ln_g, ln_b, out, ldo,
-                     n_counts, sel_ctl, pieces, units_cap, perm, perm_lb, n_nonempty};
+                     n_counts, sel_ctl, pieces, units_cap, perm, perm_lb, n_nonempty,
+                     static_cast<const int4 *>(pair_tab), blk_cnt};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_cu = lpf_cu_count();
     if (n_cu == 0) return LPF_ERR_NO_DEVICE;
@@ -691,7 +856,7 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
 #endif
 #define LPF_ROWS_GO(GG, NTH, WTL, PER_CU)                                                           \
     do {                                                                                            \
-        auto kern = pair_rows_kernel<GG, NTH, WTL, ZB>;                                             \
+        auto kern = pair_rows_kernel<GG, NTH, WTL, ZB, PT>;                                             \
         constexpr size_t lds = PrLds<GG, NTH, WTL>::BYTES;                                          \
         LPF_SET_MAX_LDS(kern, lds);                                                                 \
         int64_t groups = (int64_t)n_cu * PER_CU * PR_GRID_MUL;                                      \
@@ -778,6 +943,34 @@ extern "C" int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const i
     return rows_launch<true>(D, bs, type_ptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t,
                              att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream, perm, perm_lb,
                              n_nonempty);
+}
+
+/* The same kernel behind lpf_select4 (pair-major entries, the type in the record; pair_tab / blk_cnt as that call leaves
+ * them).  perm / perm_lb / n_nonempty: all three or none (NULL). */
+extern "C" int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
+                                            const void *entries, int64_t ent_cap, const float *Z, int64_t ldz,
+                                            const float *q, int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
+                                            const float *base, const float *wfold_t, const float *att,
+                                            const float *att_bias, const float *ln_g, const float *ln_b, int32_t n_counts,
+                                            const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
+                                            int64_t ldo, int32_t *perm, uint64_t *perm_lb, int64_t *n_nonempty,
+                                            void *stream) {
+    return rows_launch<false, true>(D, bs, nullptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t,
+                                    att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream, perm,
+                                    perm_lb, n_nonempty, pair_tab, blk_cnt);
+}
+
+extern "C" int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
+                                              const void *entries, int64_t ent_cap, const void *Z_bf16, int64_t ldz,
+                                              const float *q, int64_t ldq, const float *pe_tab_signed,
+                                              const float *pe_stat, const float *base, const float *wfold_t,
+                                              const float *att, const float *att_bias, const float *ln_g,
+                                              const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
+                                              int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
+                                              uint64_t *perm_lb, int64_t *n_nonempty, void *stream) {
+    return rows_launch<true, true>(D, bs, nullptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, base,
+                                   wfold_t, att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream,
+                                   perm, perm_lb, n_nonempty, pair_tab, blk_cnt);
 }
 
 /* floats of one piece record of lpf_pair_attention_rows_* (D accumulators, m, l, padded to whole 128-byte lines) */

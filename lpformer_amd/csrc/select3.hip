@@ -32,12 +32,11 @@
 // one-hop segment the kept nodes of N(a) come before those of N(b) (flag bit 31 of the pair word) -- exactly the layout
 // select2.hip produces, so lpf_select_export and the attention kernels do not care which path ran.
 
-#include "select_common.h"
-
-// the reference's fp32 round trip must be evaluated op by op: no fused multiply-add in this file
-#pragma clang fp contract(off)
+#include "walk_common.h"   // node records, walk descriptors, the per-candidate typing (shared with select4.hip)
 
 namespace {
+
+using namespace walk;
 
 constexpr int S3_ITEM = LPF_SELECT_ITEM;             // candidate slots per work item
 constexpr int S3_THREADS = 256;
@@ -46,50 +45,11 @@ constexpr int S3_WAVES = S3_THREADS / 64;
 constexpr int S3_GROUPS = S3_ITEM / 64;              // 64-slot groups of an item (one per wavefront and round)
 constexpr int S3_MIN_SLOTS = 16;                     // slots a pair owns at least => at most S3_PAIRS pairs per item
 constexpr int S3_PAIRS = S3_ITEM / S3_MIN_SLOTS + 2;
-constexpr uint32_t S3_FROM_B = 0x80000000u;
-constexpr uint32_t S3_HASH_MUL = 2654435761u;
-constexpr int S3_BUCKET = 8;
+constexpr uint32_t S3_FROM_B = FROM_B;
+constexpr int S3_BUCKET = BUCKET;
 constexpr int S3_DESC_AHEAD = S3_THREADS / 8;        // descriptors copied before the window is known (one int4 per thread)
-// mini filter of a node's union row (lpformer_amd/graph.py mini_filters): 32 words, two bits of one word per key
-constexpr uint32_t S3_BLOOM_MUL1 = 0x85EBCA6Bu, S3_BLOOM_MUL2 = 0xC2B2AE35u, S3_MINI_SALT = 0x9E3779B9u;
-constexpr int S3_MINI_WORDS = 32;
+constexpr int S3_MINI_WORDS = MINI_WORDS;
 constexpr int S3_FLT_LOADS = (2 * (LPF_SELECT_ITEM / 16 + 2) * (S3_MINI_WORDS / 4) + 255) / 256;   // int4 reads per thread
-
-// walk kinds
-constexpr int K_FULL = 0, K_A1 = 1, K_PX = 2, K_T0 = 3;
-constexpr int KF_SRC_A = 4;    // the walked row belongs to endpoint a (its value is pa, the looked-up one pb)
-constexpr int KF_SIDE_B = 8;   // a one-hop node emitted by this walk is a neighbour of b (flag bit 31 of the pair word)
-
-struct alignas(16) NodeRec {   // lpformer_amd/graph.py WalkIndex.rec: where node i's rows start in the index arrays
-    int64_t adj0, a10, px0, t00, u0;   // element offsets into adj_cv / a1_cv / px_cv / t0_cv; entry offset into u_cv
-    int32_t deg, n_a1, n_px, n_t0, u_nb, pad;
-};
-static_assert(sizeof(NodeRec) == 64, "one 64-byte record per node");
-
-struct alignas(16) Walk3 {
-    const int2 *src;     // {node, value bits} entries of the walked row
-    int64_t u0;          // first entry of the looked-up endpoint's U row
-    int32_t unb;         // ... and its bucket count
-    int32_t start;       // slot (inside the pair) at which this walk starts
-    int32_t kind;        // K_* | KF_*
-    int32_t len;
-};
-struct alignas(16) PairDesc3 {
-    Walk3 w[3];
-    int32_t total, a, b, pad[5];
-};
-static_assert(sizeof(Walk3) == 32 && sizeof(PairDesc3) == 128, "descriptor is one 128-byte line");
-
-__device__ __forceinline__ uint32_t s3_bloom_hash(uint32_t v) {
-    uint32_t h = v * S3_BLOOM_MUL1;
-    h ^= h >> 15;
-    h *= S3_BLOOM_MUL2;
-    return h ^ (h >> 13);
-}
-
-// fl32((fl32(fl32(p*t)+t)-t)/t) for t in {1,2}: p*1, p*2, x/1 and x/2 are exact, only the add and subtract round
-__device__ __forceinline__ float s3_rt1(float p) { return __fsub_rn(__fadd_rn(p, 1.0f), 1.0f); }
-__device__ __forceinline__ float s3_rt2(float p) { return 0.5f * __fsub_rn(__fadd_rn(p * 2.0f, 2.0f), 2.0f); }
 
 // ------------------------------------------------------------------------------------------- plan
 struct PlanArgs {
@@ -130,38 +90,7 @@ __global__ __launch_bounds__(S3_THREADS) void select3_plan_kernel(const PlanArgs
             NodeRec r[2];
             __builtin_memcpy(&r[0], A.rec + a, sizeof(NodeRec));
             __builtin_memcpy(&r[1], A.rec + b, sizeof(NodeRec));
-            const int s = r[0].deg <= r[1].deg ? 0 : 1;   // the endpoint whose whole adjacency row is walked
-            int start = 0;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {                 // walk e: the nodes that are neighbours of endpoint e
-                const int o = 1 - e;
-                Walk3 &w = d.w[e];
-                const int side = e == 1 ? KF_SIDE_B : 0;
-                if (e == s) {          // common neighbours + this side's one-hop nodes
-                    w.src = A.adj_cv + r[e].adj0; w.len = r[e].deg; w.u0 = r[o].u0; w.unb = r[o].u_nb;
-                    w.kind = K_FULL | (e == 0 ? KF_SRC_A : 0) | side;
-                } else if (A.mode_cn) {
-                    w.len = 0;
-                } else if (A.use_px && r[o].n_px < r[e].n_a1) {   // walk the other endpoint's strong non-neighbours
-                    w.src = A.px_cv + r[o].px0; w.len = r[o].n_px; w.u0 = r[e].u0; w.unb = r[e].u_nb;
-                    w.kind = K_PX | (o == 0 ? KF_SRC_A : 0) | side;
-                } else {                                          // walk this endpoint's strong neighbours
-                    w.src = A.a1_cv + r[e].a10; w.len = r[e].n_a1; w.u0 = r[o].u0; w.unb = r[o].u_nb;
-                    w.kind = K_A1 | (e == 0 ? KF_SRC_A : 0) | side;
-                }
-                w.start = start;
-                start += w.len;
-            }
-            Walk3 &w = d.w[2];
-            w.start = start;
-            if (A.t0_cv) {
-                const int e = r[0].n_t0 <= r[1].n_t0 ? 0 : 1, o = 1 - e;
-                w.src = A.t0_cv + r[e].t00; w.len = r[e].n_t0; w.u0 = r[o].u0; w.unb = r[o].u_nb;
-                w.kind = K_T0 | (e == 0 ? KF_SRC_A : 0);
-                start += w.len;
-            }
-            d.total = start;
-            d.a = (int32_t)a; d.b = (int32_t)b;
+            build_desc(d, a, b, r, A.adj_cv, A.a1_cv, A.px_cv, A.t0_cv, A.mode_cn, A.use_px);
         }
         ub = d.total < S3_MIN_SLOTS ? S3_MIN_SLOTS : d.total;
         __builtin_memcpy(A.desc + k, &d, sizeof(PairDesc3));
@@ -496,11 +425,10 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
 #elif defined(S3_NO_BLOOM)   // (tuning: every candidate fetches its bucket, as before the filter)
             const bool look = act[r] && unbr[r] > 0;
 #else
-            const uint32_t mh = s3_bloom_hash((uint32_t)cvr[r].x ^ S3_MINI_SALT);
-            const uint32_t mw = reinterpret_cast<const uint32_t *>(&L.flt[win[r]][(kindr[r] & KF_SRC_A) ? 1 : 0][0])[mh >> 27];
-            const bool look = act[r] && unbr[r] > 0 && ((mw >> (mh & 31u)) & (mw >> ((mh >> 5) & 31u)) & 1u);
+            const bool look = act[r] && unbr[r] > 0 &&
+                              mini_pass(reinterpret_cast<const uint32_t *>(&L.flt[win[r]][(kindr[r] & KF_SRC_A) ? 1 : 0][0]), cvr[r].x);
 #endif
-            const uint32_t b = look ? __umulhi((uint32_t)cvr[r].x * S3_HASH_MUL, (uint32_t)unbr[r]) : 0u;
+            const uint32_t b = look ? bucket_of(cvr[r].x, unbr[r]) : 0u;
             const int4 *blk = reinterpret_cast<const int4 *>(A.u_cv + (look ? u0r[r] + S3_BUCKET * (int64_t)b : 0));
 #pragma unroll
             for (int q = 0; q < S3_BUCKET / 2; ++q) bv[r][q] = look ? blk[q] : make_int4(-1, 0, -1, 0);
@@ -510,34 +438,12 @@ __global__ __launch_bounds__(S3_THREADS, S3_MIN_WAVES) void select3_run_kernel(c
         for (int r = 0; r < S3_ROUNDS; ++r) {
             const int g = S3_WAVES * r + wave;
             if (act[r]) {
-                const int32_t x = cvr[r].x;
-                const float ws = __int_as_float(cvr[r].y);
-                bool found = false;
-                int bitsv = 0;
-#pragma unroll
-                for (int q = 0; q < S3_BUCKET / 2; ++q) {
-                    if (bv[r][q].x == x) { found = true; bitsv = bv[r][q].y; }
-                    if (bv[r][q].z == x) { found = true; bitsv = bv[r][q].w; }
-                }
-                const bool adj = found && bitsv < 0;                     // sign bit: x is adjacent to that endpoint
-                const float lv = __int_as_float(bitsv & 0x7fffffff);     // its PPR value (0: nothing stored)
-                const int kind = kindr[r] & 3;
-                const bool cn = kind == K_FULL && adj;
-                const bool hop = kind == K_FULL ? !adj : (kind == K_A1 ? !adj : (kind == K_PX ? adj : false));
-                const bool far = kind == K_T0 && found && !adj;
-                // the reference's round trips (t = 2 for a common neighbour, 1 otherwise; mode "cn": 1)
-                const bool two = cn && !A.mode_cn;
-                const float rs = two ? s3_rt2(ws) : s3_rt1(ws);
-                const float rl = two ? s3_rt2(lv) : s3_rt1(lv);
-                int c = 0;
-                if (cn) c = (rs >= A.th_cn && rl >= A.th_cn) ? 1 : 0;
-                else if (hop) c = (!A.mode_cn && rs >= A.th_1 && rl >= A.th_1) ? 2 : 0;
-                else if (far) c = (ws > 0.f && lv > 0.f && rs >= A.th_n && rl >= A.th_n) ? 3 : 0;
-                const bool src_a = kindr[r] & KF_SRC_A;
-                code[r] = c | ((c == 2 && (kindr[r] & KF_SIDE_B)) ? 4 : 0);
-                node[r] = x;
-                va[r] = src_a ? rs : rl;
-                vb[r] = src_a ? rl : rs;
+                const Typed ty = type_slot(cvr[r].x, __int_as_float(cvr[r].y), kindr[r], bv[r], A.th_cn, A.th_1, A.th_n,
+                                           A.mode_cn);
+                code[r] = ty.code;
+                node[r] = cvr[r].x;
+                va[r] = ty.va;
+                vb[r] = ty.vb;
             }
             const int c3 = code[r] & 3;
             const uint64_t b0 = __ballot(c3 == 1), b1 = __ballot(c3 == 2), b2 = __ballot(c3 == 3);

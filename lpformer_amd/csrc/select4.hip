@@ -1,0 +1,299 @@
+// PPR-thresholded node selection over the per-model WALK INDEXES, ONE launch, PAIR-MAJOR output, no chained scan.
+//
+// Reference: compute_node_mask + get_ppr_vals + get_non_1hop_ppr (src/models/link_transformer.py:214-319, 434-481), eval
+// mode, typing adjacency == the model's own adj_mask / full_adj_mask.  The sets, the walks and the per-candidate
+// arithmetic are select3.hip's (walk_common.h: every selected set an intersection evaluated from its shorter side, one
+// hashed look-up per candidate, the reference's fp32 round trip op for op) -- what is different is the SKELETON.
+//
+// select3.hip lays all candidates of a batch out in one flat slot space, which takes a plan launch (descriptors + a
+// chained scan over the pairs), a ticket, a window and eleven barriers per 1,024-slot item, and a second chained scan
+// that turns per-item totals into positions in three type-major regions: 34 of its 57 us are that skeleton
+// (DESIGN.md 5.2b), and the pair-major attention kernel then pays a search per entry to undo the type-major order.
+// Here a workgroup owns a BLOCK of 64 consecutive pairs, everything about the block is decided inside the workgroup,
+// and nothing is waited for that another workgroup produces:
+//
+//   plan      wavefront 0, one lane per pair: ids -> the two 64-byte node records -> the pair's three walks (LDS) and a
+//             wave scan of the slot counts; meanwhile every thread fetches one 16-byte piece of the endpoints' mini
+//             filters.  The block's place in the entry buffer is ONE atomic add of its slot count (an upper bound of
+//             what it keeps) on a counter -- where a block lands is irrelevant, its pairs say where they start.
+//   typing    the block's slots are dealt to the wavefronts 64 at a time, four rounds per thread in flight (walked
+//             entries, then buckets, then the arithmetic: two dependent round trips per 4 x NTH slots); the pair of a
+//             slot comes from a ballot over the pair starts.
+//   placing   kept entries are compacted IN SLOT ORDER -- which is pair-major, a pair's slots being contiguous -- by
+//             ballot ranks and one scan over the rounds of the block: a pair's entries end up contiguous, its start and
+//             its three counts go to pair_tab[pair], the type of an entry travels in its record.
+//
+// Result: entries {pair | type << 29 | from_N(b) << 31, node, pa, pb}; pair_tab[pair] = {start, n_cn, n_1hop, n_far};
+// blk_cnt[block] = entries of the block (the attention kernel splits its work by it).  Deterministic up to the block
+// bases: every consumer addresses entries through pair_tab, so scores do not depend on where a block landed.
+#include "walk_common.h"
+
+namespace {
+
+using namespace walk;
+
+constexpr int S4_PAIRS = LPF_SELECT4_BLOCK;   // pairs per workgroup: one lane of the planning wavefront each
+constexpr int S4_ROUNDS = 4;                  // slots per thread in flight
+constexpr int CTL_ERR = 3, CTL_ALLOC = 9, CTL_DONE = 10;
+
+struct Args4 {
+    int64_t bs;
+    const int64_t *batch;
+    int64_t batch_ld, n_nodes;
+    const NodeRec *rec;
+    const int2 *adj_cv, *a1_cv, *px_cv, *t0_cv;   // t0_cv NULL: no >1-hop walk (modes "1-hop", "cn")
+    const int2 *u_cv;
+    const uint32_t *mini;
+    int32_t mode_cn, use_px;
+    float th_cn, th_1, th_n;
+    int64_t *ctl;
+    int4 *pair_tab;      // [bs]
+    int32_t *blk_cnt;    // [ceil(bs / 64)]
+    int4 *entries;       // [ent_cap]
+    int64_t ent_cap;
+};
+
+template <int NTH>
+struct Lds4 {
+    static constexpr int WAVES = NTH / 64, NR = WAVES * S4_ROUNDS;
+    PairDesc3 dsc[S4_PAIRS];                     // the block's walk descriptors
+    uint4 flt[S4_PAIRS][2][MINI_WORDS / 4];      // mini filters of the endpoints (a, b)
+    int32_t sflag[WAVES][S4_ROUNDS][64];         // per wavefront and round: "a pair starts in this slot"
+    int32_t loc[S4_PAIRS + 1];                   // first slot of pair j (block-relative); pairs past the batch: S
+    int32_t pcnt[S4_PAIRS][4];                   // per pair: kept common neighbours, one-hop, >1-hop; start (block-relative)
+    int32_t rcnt[NR];                            // kept entries per round of the batch, then their exclusive scan
+    int64_t base;                                // the block's place in the entry buffer
+    int32_t S, run, ovf;
+};
+
+// Workgroup barrier that orders LDS only (select3.hip: __syncthreads() would drain the vector-memory counter -- here
+// the allocation atomic of wavefront 0 and the loads requested ahead stay in flight across it).  Nothing global is
+// handed between the wavefronts of a workgroup.
+__device__ __forceinline__ void s4_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NTH>
+__global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
+    using LT = Lds4<NTH>;
+    constexpr int WAVES = LT::WAVES, NR = LT::NR;
+    __shared__ LT L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
+    const int64_t p0 = (int64_t)blockIdx.x * S4_PAIRS;
+    const int np = (int)(A.bs - p0 < S4_PAIRS ? A.bs - p0 : S4_PAIRS);
+
+    // ---- the endpoints' mini filters: one 16-byte piece per thread and trip (id -> piece: two dependent reads, beside
+    //      the plan's id -> node record)
+    constexpr int FP = S4_PAIRS * 2 * (MINI_WORDS / 4), FL = (FP + NTH - 1) / NTH;
+    uint4 fr[FL];
+#pragma unroll
+    for (int f = 0; f < FL; ++f) {
+        const int i = f * NTH + tid, j = i / (2 * (MINI_WORDS / 4)), e = (i / (MINI_WORDS / 4)) & 1;
+        fr[f] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < FP && j < np) {
+            const int64_t id = A.batch[(int64_t)e * A.batch_ld + p0 + j];
+            if ((uint64_t)id < (uint64_t)A.n_nodes)
+                fr[f] = reinterpret_cast<const uint4 *>(A.mini + id * MINI_WORDS)[i & (MINI_WORDS / 4 - 1)];
+        }
+    }
+    // ---- plan (wavefront 0, lane = pair)
+    int64_t base_reg = 0;
+    if (wave == 0) {
+        PairDesc3 d;
+        __builtin_memset(&d, 0, sizeof(d));
+        int ub = 0;
+        if (lane < np) {
+            const int64_t a = A.batch[p0 + lane], b = A.batch[A.batch_ld + p0 + lane];
+            if ((uint64_t)a >= (uint64_t)A.n_nodes || (uint64_t)b >= (uint64_t)A.n_nodes) {
+                atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ERR), (unsigned long long)LPF_SELECT_ERR_NODE_RANGE);
+            } else {
+                NodeRec r[2];
+                __builtin_memcpy(&r[0], A.rec + a, sizeof(NodeRec));
+                __builtin_memcpy(&r[1], A.rec + b, sizeof(NodeRec));
+                build_desc(d, a, b, r, A.adj_cv, A.a1_cv, A.px_cv, A.t0_cv, A.mode_cn, A.use_px);
+            }
+            ub = d.total < 1 ? 1 : d.total;     // (every pair owns a slot: no two pairs start in the same one)
+        }
+        int x = ub;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int y = __shfl_up(x, dlt, 64);
+            if (lane >= dlt) x += y;
+        }
+        const int S = __shfl(x, 63, 64);
+        L.dsc[lane] = d;
+        L.loc[lane] = x - ub;
+        *reinterpret_cast<int4 *>(L.pcnt[lane]) = make_int4(0, 0, 0, 0);
+        if (lane == 0) {
+            L.loc[S4_PAIRS] = S;
+            L.S = S;
+            L.run = 0;
+            // the block's place: its slot count bounds what it keeps (rounded to whole 128-byte lines)
+            base_reg = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ALLOC),
+                                          (unsigned long long)((S + 7) & ~7));
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < FL; ++f) {
+        const int i = f * NTH + tid;
+        if (i < FP) (&L.flt[0][0][0])[i] = fr[f];
+    }
+    s4_lds_barrier();
+    const int S = L.S;
+    const int myloc = L.loc[lane < S4_PAIRS ? lane : S4_PAIRS];   // (S4_PAIRS == 64: lane j holds the start of pair j)
+    volatile int32_t *const sfw = &L.sflag[wave][0][0];
+
+    for (int s0 = 0; s0 < S; s0 += NTH * S4_ROUNDS) {
+        if (s0 > 0) s4_lds_barrier();   // (the previous batch's round offsets are no longer needed)
+        // ---- typing: one slot per thread and round; the rounds are taken together, phase by phase, so that their memory
+        //      round trips overlap -- every round's walked entry, then every round's bucket, then the arithmetic
+        int code[S4_ROUNDS], node[S4_ROUNDS], win[S4_ROUNDS];
+        float va[S4_ROUNDS], vb[S4_ROUNDS];
+        int kindr[S4_ROUNDS], unbr[S4_ROUNDS];
+        int64_t u0r[S4_ROUNDS];
+        int2 cvr[S4_ROUNDS];
+        bool act[S4_ROUNDS], first[S4_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < S4_ROUNDS; ++r) {
+            const int g = WAVES * r + wave;          // the wavefront's 64-slot round inside the batch
+            const int r0 = s0 + 64 * g, l = r0 + lane;
+            code[r] = 0; node[r] = 0; win[r] = 0; va[r] = 0.f; vb[r] = 0.f;
+            act[r] = false; first[r] = false; kindr[r] = 0; unbr[r] = 0; u0r[r] = 0; cvr[r] = make_int2(0, 0);
+            if (r0 < S) {                            // (wave-uniform)
+                // pair of slot l = pairs that start at or before it: those at or before the round's first slot by a
+                // ballot over the pairs, those inside the round by flags scattered to the slots they start in
+                volatile int32_t *sf = sfw + 64 * r;
+                sf[lane] = 0;
+                const int before = __popcll(__ballot(myloc <= r0));
+                if (myloc > r0 && myloc < r0 + 64) sf[myloc - r0] = 1;
+                const uint64_t starts = __ballot(sf[lane] != 0);
+                if (l < S) {
+                    const int w = before - 1 + __popcll(starts & le_mask);
+                    const PairDesc3 &d = L.dsc[w];
+                    const int i = l - L.loc[w];
+                    win[r] = w;
+                    first[r] = i == 0;
+                    if (i < d.total) {
+                        const int k = (i >= d.w[1].start) + (i >= d.w[2].start);
+                        const Walk3 wk = d.w[k];
+                        cvr[r] = wk.src[i - wk.start];
+                        kindr[r] = wk.kind; unbr[r] = wk.unb; u0r[r] = wk.u0;
+                        act[r] = true;
+                    }
+                }
+            }
+        }
+        int4 bv[S4_ROUNDS][BUCKET / 2];
+#pragma unroll
+        for (int r = 0; r < S4_ROUNDS; ++r) {
+            // what is x to the other endpoint?  one bucket of its hashed union row -- if the endpoint's mini filter lets
+            // x through (the looked-up endpoint is b when the walked row is a's, and the other way round)
+            const bool look = act[r] && unbr[r] > 0 &&
+                              mini_pass(reinterpret_cast<const uint32_t *>(&L.flt[win[r]][(kindr[r] & KF_SRC_A) ? 1 : 0][0]), cvr[r].x);
+            const uint32_t b = look ? bucket_of(cvr[r].x, unbr[r]) : 0u;
+            const int4 *blk = reinterpret_cast<const int4 *>(A.u_cv + (look ? u0r[r] + BUCKET * (int64_t)b : 0));
+#pragma unroll
+            for (int q = 0; q < BUCKET / 2; ++q) bv[r][q] = look ? blk[q] : make_int4(-1, 0, -1, 0);
+        }
+        uint64_t keptb[S4_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < S4_ROUNDS; ++r) {
+            const int g = WAVES * r + wave;
+            if (act[r]) {
+                const Typed ty = type_slot(cvr[r].x, __int_as_float(cvr[r].y), kindr[r], bv[r], A.th_cn, A.th_1, A.th_n,
+                                           A.mode_cn);
+                code[r] = ty.code;
+                node[r] = cvr[r].x;
+                va[r] = ty.va;
+                vb[r] = ty.vb;
+            }
+            const int c3 = code[r] & 3;
+            keptb[r] = __ballot(c3 != 0);
+            if (c3) atomicAdd(&L.pcnt[win[r]][c3 - 1], 1);
+            if (lane == 0) L.rcnt[g] = __popcll(keptb[r]);
+        }
+        s4_lds_barrier();
+        // ---- the rounds' places inside the block: one scan over the rounds of the batch (wavefront 0)
+        if (wave == 0) {
+            const int v = lane < NR ? L.rcnt[lane] : 0;
+            int x = v;
+#pragma unroll
+            for (int dlt = 1; dlt < NR; dlt <<= 1) {
+                const int y = __shfl_up(x, dlt, 64);
+                if (lane >= dlt) x += y;
+            }
+            const int run = L.run;
+            if (lane < NR) L.rcnt[lane] = run + x - v;
+            if (lane == NR - 1) L.run = run + x;
+            if (lane == 0 && s0 == 0) {
+                L.base = base_reg;
+                L.ovf = base_reg + ((S + 7) & ~7) > A.ent_cap ? 1 : 0;
+            }
+        }
+        s4_lds_barrier();
+        const int64_t base = L.base;
+        const bool ovf = L.ovf != 0;
+#pragma unroll
+        for (int r = 0; r < S4_ROUNDS; ++r) {
+            const int g = WAVES * r + wave;
+            const int c3 = code[r] & 3;
+            const int pos = L.rcnt[g < NR ? g : 0] + __popcll(keptb[r] & lt_mask);
+            if (c3 && !ovf)
+                A.entries[base + pos] = make_int4((int32_t)((uint32_t)(p0 + win[r]) | ((uint32_t)c3 << 29) |
+                                                            ((code[r] & 4) ? FROM_B : 0u)),
+                                                  node[r], __float_as_int(va[r]), __float_as_int(vb[r]));
+            if (first[r]) L.pcnt[win[r]][3] = pos;   // first slot of the pair: where its entries start
+        }
+    }
+    s4_lds_barrier();
+    const bool ovf = S > 0 && L.ovf != 0;
+    if (tid < np) {
+        const int4 c = *reinterpret_cast<const int4 *>(L.pcnt[tid]);
+        // (a block that does not fit leaves empty pairs -- nothing is read past the buffer -- and raises the sticky bit:
+        //  the scores of the batch come out as NaN and the caller sizes the workspace again)
+        A.pair_tab[p0 + tid] = ovf ? make_int4(0, 0, 0, 0) : make_int4((int32_t)(L.base + c.w), c.x, c.y, c.z);
+    }
+    if (tid == 0) {
+        A.blk_cnt[blockIdx.x] = ovf ? 0 : L.run;
+        if (ovf) atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ERR), (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
+        // the last workgroup leaves the counters as the next launch on this control block wants them (stream order)
+        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + CTL_DONE), 1ull);
+        if (done == (unsigned long long)gridDim.x - 1ull) {
+            const unsigned long long total = atomicExch(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ALLOC), 0ull);
+            atomicExch(reinterpret_cast<unsigned long long *>(A.ctl + CTL_DONE), 0ull);
+            A.ctl[0] = (int64_t)total;   // entries the batch needs room for (what ent_cap is sized from)
+        }
+    }
+}
+
+}  // namespace
+
+/* ---- C ABI ---------------------------------------------------------------------------------------------------- */
+extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
+                           const void *adj_cv, const void *a1_cv, const void *px_cv, const void *t0_cv, const void *u_cv,
+                           const void *mini, int32_t mode_cn, int32_t use_px, float th_cn, float th_1hop,
+                           float th_non1hop, int64_t *ctl, void *pair_tab, int32_t *blk_cnt, void *entries,
+                           int64_t ent_cap, int32_t threads, void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && bs < (1ll << 29) && batch && batch_ld >= bs && n_nodes > 0 && node_rec && adj_cv && a1_cv &&
+                (px_cv || !use_px) && u_cv && mini && ctl && pair_tab && blk_cnt && entries && ent_cap > 0 &&
+                ent_cap < (1ll << 31) && lpf_aligned16(node_rec) && lpf_aligned16(u_cv) && lpf_aligned16(mini) &&
+                lpf_aligned16(pair_tab) && lpf_aligned16(entries));
+    Args4 a;
+    a.bs = bs; a.batch = batch; a.batch_ld = batch_ld; a.n_nodes = n_nodes;
+    a.rec = static_cast<const NodeRec *>(node_rec);
+    a.adj_cv = static_cast<const int2 *>(adj_cv); a.a1_cv = static_cast<const int2 *>(a1_cv);
+    a.px_cv = static_cast<const int2 *>(px_cv); a.t0_cv = static_cast<const int2 *>(t0_cv);
+    a.u_cv = static_cast<const int2 *>(u_cv); a.mini = static_cast<const uint32_t *>(mini);
+    a.mode_cn = mode_cn; a.use_px = use_px; a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop;
+    a.ctl = ctl; a.pair_tab = static_cast<int4 *>(pair_tab); a.blk_cnt = blk_cnt;
+    a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
+    const int64_t nb = (bs + S4_PAIRS - 1) / S4_PAIRS;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (threads == 512) hipLaunchKernelGGL(select4_kernel<512>, dim3((unsigned)nb), dim3(512), 0, s, a);
+    else if (threads == 0 || threads == 1024) hipLaunchKernelGGL(select4_kernel<1024>, dim3((unsigned)nb), dim3(1024), 0, s, a);
+    else return LPF_ERR_INVALID;
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}

@@ -478,6 +478,49 @@ class _SelectWorkspace:
                 self.ctl[3] = 0
 
 
+class _Select4Workspace:
+    """Per (stream, batch size) buffers of the one-launch, pair-major selection (``lpf_select4``,
+    include/lpformer_hip.h): ``pair_tab`` int32 [bs, 4] = {first entry, n_cn, n_1hop, n_non1hop}, ``blk_cnt`` int32
+    [ceil(bs / 64)], ``entries`` 16-byte records.  ``ctl`` persists across launches (word 3: sticky error bits; word 0:
+    the room the last batch needed)."""
+
+    def __init__(self, device, bs: int):
+        self.device, self.bs = device, bs
+        self.ctl = torch.zeros(16, dtype=torch.int64, device=device)  # LPF_SELECT_CTL_WORDS
+        self.pair_tab = torch.zeros(4 * max(bs, 1), dtype=torch.int32, device=device)
+        self.blk_cnt = torch.zeros((bs + _lib.SELECT4_BLOCK - 1) // _lib.SELECT4_BLOCK + 1, dtype=torch.int32, device=device)
+        self.ent_cap = 0
+        self.entries = None
+        self.calibrated = False
+
+    def ensure(self, ent_cap: int, shrink: bool = False):
+        if ent_cap > self.ent_cap or (shrink and ent_cap < self.ent_cap // 2):
+            self.ent_cap = int(ent_cap)
+            self.entries = None  # release before allocating the new size
+            self.entries = torch.empty(self.ent_cap * 4, dtype=torch.int32, device=self.device)
+
+    def read_status(self, stream=None):
+        """(error bits, [entries the last batch needed room for]); the read is ordered behind ``stream`` (see
+        ``_SelectWorkspace.read_status``)."""
+        if stream is None:
+            v = self.ctl.tolist()
+        else:
+            with torch.cuda.stream(stream):
+                v = self.ctl.tolist()
+        return int(v[3]), [int(v[0])]
+
+    def clear_errors(self, stream=None):
+        if stream is None:
+            self.ctl[3] = 0
+        else:
+            with torch.cuda.stream(stream):
+                self.ctl[3] = 0
+
+    def kept(self) -> int:
+        """Selected entries of the last batch (synchronises)."""
+        return int(self.blk_cnt[:-1].sum().item())
+
+
 # ------------------------------------------------------------------------------------------ the model
 class LinkTransformer(nn.Module):
     """LPFormer link-representation model on MI355X.
@@ -563,6 +606,11 @@ class LinkTransformer(nn.Module):
         self.encoder_mode = "sharded"  # with world > 1: "sharded" (rows + all-gather per layer) or "replicated"
         self.use_select_index = True  # False: always run the general (PPR-streaming) selection kernel
         self.select_grid = 0           # workgroups of lpf_select3_run (0 = as many as are resident at once)
+        # the selection in front of the pair-major attention: True = ONE launch leaving pair-major entries + a table entry
+        # per pair (csrc/select4.hip: blocks of 64 pairs, no plan launch, no chained scan); False = lpf_select3_plan / _run
+        # (type-major regions, which lpf_select_export and the record-writing attention kernels keep using)
+        self.select_blocks = True
+        self.select4_threads = 0       # threads per workgroup of lpf_select4 (0 = default)
         # the elementwise branch and the q projection only need X and the batch: they run on a second HIP stream
         # underneath the (latency/issue-bound) selection kernels.  False: everything on the caller's stream.
         self.use_side_stream = True
@@ -1120,6 +1168,46 @@ class LinkTransformer(nn.Module):
         self._select_launch(ws, batch, graphs)
         return ws
 
+    def _uses_select4(self, adj_mask=None) -> bool:
+        """True when the hot path's selection is the one-launch, pair-major kernel (csrc/select4.hip): the model's own
+        typing adjacency through the walk indexes, feeding the pair-major attention."""
+        return self.select_blocks and adj_mask is None and self.use_select_index
+
+    def _select4_launch(self, ws, batch, wi):
+        lib, st = _lib.hip(), _stream(self.device)
+        cn = 1 if self.mask == "cn" else 0
+        with KernelTimer.span("select_run"):
+            check(lib.lpf_select4(batch.shape[1], ptr(batch), batch.stride(0), self.num_nodes, ptr(wi.rec), ptr(wi.adj_cv),
+                                  ptr(wi.a1_cv), ptr(wi.px_cv), ptr(wi.t0_cv), ptr(wi.u.cv), ptr(wi.mini), cn,
+                                  1 if wi.use_px else 0, float(self.thresh_cn), float(self.thresh_1hop),
+                                  float(self.thresh_non1hop), ptr(ws.ctl), ptr(ws.pair_tab), ptr(ws.blk_cnt),
+                                  ptr(ws.entries), ws.ent_cap, self.select4_threads, st), "lpf_select4")
+
+    def _select4_device(self, batch: torch.Tensor, test_set: bool) -> "_Select4Workspace":
+        """The one-launch selection for the hot path (``lpf_select4``): pair-major entries, a table entry per pair,
+        nothing read back.  The entry buffer is sized from earlier batches (a batch needs room for its candidate
+        slots, which the kernel reports in ``ctl[0]``); a batch that does not fit raises the sticky error bits, its
+        scores come out as NaN and ``check_selection()`` sizes the buffer again.  The first batch of a (stream, batch
+        size) is sized exactly, with one synchronisation."""
+        st = _stream(self.device)
+        bs = batch.shape[1]
+        key = ("sel4", st, bs)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = _Select4Workspace(self.device, bs)
+        wi = self._select_graphs(test_set, None)
+        if not ws.calibrated:
+            ws.ensure(ent_cap=16)
+            self._select4_launch(ws, batch, wi)      # (token buffer: the kernel still reports the room it needs)
+            err, need = ws.read_status()
+            ws.clear_errors()
+            if err & _lib.SELECT_ERR_NODE_RANGE:
+                raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
+            ws.ensure(ent_cap=need[0] + need[0] // 2 + 4096, shrink=True)
+            ws.calibrated = True
+        self._select4_launch(ws, batch, wi)
+        return ws
+
     def check_selection(self, stream=None) -> bool:
         """Synchronising check of the sticky selection status of ``stream`` (default: the current one).  Returns True
         when every batch since the last check fitted its workspace; otherwise clears the status, marks the workspace
@@ -1131,7 +1219,7 @@ class LinkTransformer(nn.Module):
         st = stream.cuda_stream
         ok = True
         for key, ws in list(self._ws.items()):
-            if not (isinstance(key, tuple) and key[0] == "sel2" and key[1] == st):
+            if not (isinstance(key, tuple) and key[0] in ("sel2", "sel4") and key[1] == st):
                 continue
             err, _ = ws.read_status(stream)
             if err == 0:
@@ -1314,25 +1402,31 @@ class LinkTransformer(nn.Module):
         if q is None:   # (score_pairs has it gathered by the elementwise branch's launch)
             with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
                 q = self._pair_q(batch, x_node, w)
-        ws = self._select_device(batch, test_set, adj_mask)
+        four = self._uses_select4(adj_mask)
+        ws = self._select4_device(batch, test_set) if four else self._select_device(batch, test_set, adj_mask)
         if side is not None:
             _lib.stream_wait(torch.cuda.current_stream(self.device), side)
         layer = self.att_layers[0]
-        units_cap = (3 * ws.ent_cap + 15) // 16 + 1
+        units_cap = ((1 if four else 3) * ws.ent_cap + 15) // 16 + 1
         pieces = self._workspace("att_pieces", units_cap * 2 * int(lib.lpf_pair_rows_piece_floats(d)), torch.float32, st)
         extra = ()
         if order:
             perm = self._workspace("att_perm", bs, torch.int32, st)
             nfull = self._workspace("att_nfull", 1, torch.int64, st)
             extra = (ptr(perm), ptr(self._zero_workspace("att_perm_lb", 2 * _lib.ROWS_PERM_LB_WORDS, st)), ptr(nfull))
-        with KernelTimer.span("pair_attention_fused"):
-            name = "lpf_pair_attention_rows" + ("_perm" if order else "") + ("_zbf16" if self.precision == "bf16" else "_f32")
-            zt = self._z_bf16(z) if self.precision == "bf16" else z
-            check(getattr(lib, name)(
-                d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(zt), zt.stride(0), ptr(q), q.stride(0),
-                ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]), ptr(w["wfold_t"]), ptr(w["att"]),
-                ptr(layer.att.bias), ptr(layer.post_att_norm.weight), ptr(layer.post_att_norm.bias), n_counts,
-                ptr(ws.ctl), ptr(pieces), units_cap, ptr(out), out.stride(0), *extra, st), name)
+        zt = self._z_bf16(z) if self.precision == "bf16" else z
+        tabs = (ptr(zt), zt.stride(0), ptr(q), q.stride(0), ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]),
+                ptr(w["wfold_t"]), ptr(w["att"]), ptr(layer.att.bias), ptr(layer.post_att_norm.weight),
+                ptr(layer.post_att_norm.bias), n_counts, ptr(ws.ctl), ptr(pieces), units_cap, ptr(out), out.stride(0))
+        with KernelTimer.span("pair_attention_rows"):
+            if four:
+                name = "lpf_pair_attention_rows4" + ("_zbf16" if self.precision == "bf16" else "_f32")
+                check(getattr(lib, name)(d, bs, ptr(ws.pair_tab), ptr(ws.blk_cnt), ptr(ws.entries), ws.ent_cap, *tabs,
+                                         *(extra or (None, None, None)), st), name)
+            else:
+                name = ("lpf_pair_attention_rows" + ("_perm" if order else "") +
+                        ("_zbf16" if self.precision == "bf16" else "_f32"))
+                check(getattr(lib, name)(d, bs, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, *tabs, *extra, st), name)
         return (ws, perm, nfull) if order else ws
 
     def _fused_attention(self, batch, x_node, test_set, adj_mask, side, q=None):
