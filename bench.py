@@ -71,7 +71,12 @@ from lpformer_amd import data as D  # noqa: E402
 from lpformer_amd import dist as LD  # noqa: E402
 from lpformer_amd.profile import KernelTimer  # noqa: E402
 
-PMC_FILE = "r04_pmc_traffic.json"  # committed rocprofv3 PMC passes the `traffic` figures are read from
+PMC_FILE = "r05_pmc_traffic.json"  # committed rocprofv3 PMC passes the `traffic` figures are read from
+# timing span (KernelTimer) -> the HIP kernel that runs under it (what `roofline.kernel` names)
+KERNEL_NAMES = {"pair_attention_rows": "pair_rows_kernel", "pair_attention_fused": "pair_flip_kernel / pair_fused_kernel",
+                "tail_chain": "tail_chain_kernel", "select_run": "select_run", "select_plan": "select3_plan_kernel",
+                "dense_chain_mlp_hidden": "dense_chain_kernel (+ q gather)", "pair_gather_q": "pair_gather_kernel",
+                "pair_attention_merge": "pair_merge_kernel"}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 
@@ -132,7 +137,10 @@ def pair_stats(data, batch):
 def slot_count(model, batch_t):
     """Candidate slots of one batch as the plan kernel lays them out (a-side walk | b-side walk | >1-hop walk, at
     least 16 per pair)."""
-    ws = model._select_device(batch_t, False, None)
+    if model._uses_select4() and model._uses_rows():   # the one-launch form: ctl[0] = slots, block by block rounded to 8
+        ws = model._select4_device(batch_t, False)
+    else:
+        ws = model._select_device(batch_t, False, None)
     return int(ws.ctl[0].item())
 
 
@@ -617,8 +625,11 @@ def main():
             step(i)
         kt16 = KernelTimer.summary()
         KernelTimer.enabled = False
-        if "pair_attention_fused" in kt16:
-            bf16["pair_attention_fused_ms"] = round(kt16["pair_attention_fused"][2], 4)
+        for att_name in ("pair_attention_rows", "pair_attention_fused"):
+            if att_name in kt16:
+                bf16["pair_attention_fused_ms"] = round(kt16[att_name][2], 4)
+                bf16["attention_kernel"] = KERNEL_NAMES[att_name]
+                break
         if "tail_chain" in kt16:
             bf16["tail_chain_ms"] = round(kt16["tail_chain"][2], 4)
         model.precision = model.tail_precision = "f32"
@@ -748,6 +759,7 @@ def main():
             slots = mean([s["slots"] for s in stats])
             c = model.count_dim
             tail_short = bool(model.tail_skip_empty and model._uses_rows())
+            four = bool(model._uses_select4() and model._uses_rows())
             q_rides = model.query_from == "table" and "pair_gather_q" not in kt
             # the WHOLE pair stage against the HBM roof: SURVEY 8(d)'s B_pair summed over the batch (what a both-rows
             # walk of the reference's algorithm must touch) / the measured step time
@@ -763,13 +775,17 @@ def main():
                 "pair_attention_fused": (("hbm", n_sel * (4.0 * d + 16.0) + bs * (4.0 * d + 4.0 * (d + 4)))
                                          if model.attention_kernel() == "flip" else
                                          ("mfma", n_sel * (2.0 * d * d + 20.0 * d))),
+                # the pair-major form of the same arithmetic (pair_rows.hip): a finished row per pair instead of records
+                "pair_attention_rows": ("hbm", n_sel * (4.0 * d + 16.0) + bs * (4.0 * d + 4.0 * (d + 4))),
                 # legacy two-pass kernels (D = 256 and the module-by-module API)
                 "pair_scores": ("mfma", n_sel * (2.0 * d * d + 20.0 * d)),
                 "pair_softmax_gather": ("hbm", n_sel * (4.0 * d + 16.0) + bs * (4.0 * (4 * d + 4) + 48.0)),
                 # selection, run kernel (walk plan): per candidate slot the walked {node, value} entry (8 B) and the
                 # answer of its one look-up ({node, value | adjacent}: 8 B of a 64-byte bucket), 148 B per pair
                 # (descriptor, offset, three segment starts), one 16-byte record per selected entry
-                "select_run": ("hbm", 16.0 * slots + 148.0 * bs + 16.0 * n_sel),
+                # (one-launch form, select4.hip: no descriptors or offsets in memory -- per pair two ids, two 64-byte node
+                #  records, two 128-byte filters and a 16-byte table entry)
+                "select_run": ("hbm", 16.0 * slots + ((16.0 + 128.0 + 256.0 + 16.0) if four else 148.0) * bs + 16.0 * n_sel),
                 # plan kernel: two node ids, two 64-byte node records, descriptor + offset per pair
                 "select_plan": ("hbm", (16.0 + 2 * 64.0 + 128.0 + 8.0) * bs),
                 "select_export": ("hbm", 2 * 16.0 * n_sel + 40.0 * bs),
@@ -798,7 +814,12 @@ def main():
                 dur_s = kt[name][2] * 1e-3
                 peak = HBM_PEAK_GBS if bound == "hbm" else F32_MFMA_PEAK_TFLOPS
                 ach = units / dur_s / (1e9 if bound == "hbm" else 1e12)
-                rooflines[name] = {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak,
+                kname = KERNEL_NAMES.get(name, name)
+                if name == "select_run":
+                    kname = "select4_kernel" if four else "select3_run_kernel"
+                if name == "pair_attention_fused":
+                    kname = "pair_flip_kernel" if model.attention_kernel() == "flip" else "pair_fused_kernel"
+                rooflines[name] = {"kernel": kname, "span": name, "bound": bound, "achieved": round(ach, 2), "peak": peak,
                                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4),
                                    "traffic": None, "launch_ms": round(kt[name][2], 4),
                                    "launches_per_step": kt[name][0] / args.steps}
@@ -811,8 +832,7 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
                 rows_form = model._uses_rows()
                 for name, r in rooflines.items():
-                    key = {"pair_attention_fused": "pair_attention_rows", "tail_chain": "tail_chain_rows"}.get(name, name) \
-                        if rows_form else name
+                    key = {"tail_chain": "tail_chain_rows"}.get(name, name) if rows_form else name
                     if key in pmc["kernels"]:
                         r["traffic"] = pmc["kernels"][key]["hbm_bytes_per_launch_corrected"]
                         r["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes at {pmc.get('commit', '?')})"
@@ -823,7 +843,7 @@ def main():
                 # entry, one fp32 q row read and about one fp32 record written per pair
                 byts = n_sel * (2.0 * d + 16.0) + bs * (4.0 * d + 4.0 * d + 16.0)
                 ach = byts / (bf16["pair_attention_fused_ms"] * 1e-3) / 1e9
-                bf16["roofline"] = {"kernel": "pair_attention_fused (bf16)", "bound": "hbm", "achieved": round(ach, 1),
+                bf16["roofline"] = {"kernel": bf16.get("attention_kernel", "pair_fused_kernel") + " (bf16 node table)", "bound": "hbm", "achieved": round(ach, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                     "traffic": None, "launch_ms": bf16["pair_attention_fused_ms"]}
             modelled = [k for k in sorted(kt, key=lambda k: -kt[k][1]) if k in rooflines]
@@ -900,6 +920,9 @@ def main():
                        "attention_form": ("pair-major, finished rows (pair_rows.hip)" if model._uses_rows() else
                                           "unit-major, records merged by the tail (pair_flip.hip / pair_fused.hip)"),
                        "attention_form_probe_ms_per_step": rows_probe,
+                       "selection_form": ("one launch, pair-major entries + a table entry per pair (select4.hip)"
+                                          if model._uses_select4() and model._uses_rows() else
+                                          "plan + run launches, type-major regions (select3.hip)"),
                        "flip_break_even": model.FLIP_BREAK_EVEN.get(d),
                        "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']} " +
                                        {"sharded": "(rows + all-gather per layer)",

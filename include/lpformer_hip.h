@@ -277,7 +277,7 @@ int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int
  *             2 = one-hop, 3 = >1-hop; a pair's entries in candidate-slot order (neighbours of a, then of b, then
  *             the >1-hop nodes), types mixed
  *   pair_tab  int32[bs][4] = {first entry, n_cn, n_1hop, n_non1hop} per pair
- *   blk_cnt   int32[ceil(bs / LPF_SELECT4_BLOCK)]: selected entries per block of pairs
+ *   blk_cnt   int32[ceil(bs / LPF_SELECT4_BLOCK)][2]: {selected entries, pairs with selected entries} per block of pairs
  *   ctl       int64[LPF_SELECT_CTL_WORDS], zero-initialised once by the caller, then owned by the library (one control
  *             block per stream): [0] entries the last batch needed room for (its candidate slots, block by block rounded
  *             up to 8: what ent_cap is sized from)  [3] STICKY error bits as above  [9], [10] allocation and completion
@@ -542,23 +542,25 @@ int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const int32_t *typ
 /* lpf_pair_attention_rows_perm_* behind lpf_select4: the entries are pair-major already (a pair's entries contiguous from
  * pair_tab[p][0], the type in bits 29-30 of the record's pair word), so the kernel reads ONE region and needs no per-type
  * pointers; its workgroups split the batch by blk_cnt (entries per LPF_SELECT4_BLOCK pairs) and the 64 table entries of the
- * block a cut falls into.  units_cap >= ceil(ent_cap / 16) + 1.  perm / perm_lb / n_nonempty: all three, or all NULL (no
- * order for the tail).  Everything else as lpf_pair_attention_rows_f32; the rows agree with that call's up to the order
- * in which a pair's entries are summed. */
+ * block a cut falls into.  units_cap: 16-entry units the `pieces` scratch has room for -- it bounds the SELECTED entries
+ * of a batch (16 * (units_cap - 1)), not the entry buffer; a batch with more leaves NaN rows and raises
+ * LPF_SELECT_ERR_ENTRY_CAP in sel_ctl[3].  perm / n_nonempty: both, or both NULL (no order for the
+ * tail; the order needs no scan words here: the selection counted the pairs with entries per block).  Everything else as
+ * lpf_pair_attention_rows_f32; the rows agree with that call's up to the order in which a pair's entries are summed. */
 int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt, const void *entries,
                                  int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
                                  const float *pe_tab_signed, const float *pe_stat, const float *base,
                                  const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
                                  const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
-                                 int64_t units_cap, float *out, int64_t ldo, int32_t *perm, uint64_t *perm_lb,
-                                 int64_t *n_nonempty, void *stream);
+                                 int64_t units_cap, float *out, int64_t ldo, int32_t *perm, int64_t *n_nonempty,
+                                 void *stream);
 int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
                                    const void *entries, int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q,
                                    int64_t ldq, const float *pe_tab_signed, const float *pe_stat, const float *base,
                                    const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
                                    const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
-                                   int64_t units_cap, float *out, int64_t ldo, int32_t *perm, uint64_t *perm_lb,
-                                   int64_t *n_nonempty, void *stream);
+                                   int64_t units_cap, float *out, int64_t ldo, int32_t *perm, int64_t *n_nonempty,
+                                   void *stream);
 
 int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
                                  const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,

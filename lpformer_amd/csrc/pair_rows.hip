@@ -91,6 +91,14 @@ __device__ __forceinline__ float pr_group_sum(float v) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Workgroup barrier that orders LDS only.  __syncthreads() is a workgroup fence + barrier and the fence drains the
+// vector-memory counter: behind a loop of global stores (count features, constant rows, finished rows) every barrier of
+// the set-up would wait out a store round trip.  The wavefronts of a workgroup hand each other nothing through global
+// memory here except the pieces, which have their own wait + flag.
+__device__ __forceinline__ void pr_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // (tuning builds, -DPR_STAMPS: wall-clock marks -- 100 MHz -- of lane 0 of every wavefront; tools/rows_stamps.py)
 #ifdef PR_STAMPS
 __device__ uint64_t *pr_stamp_buf = nullptr;
@@ -131,6 +139,10 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     constexpr int D = 4 * G, EPW = 64 / G, NG = L::NG, T_LO = WTL == 1 ? 1 : 0, TPS = PR_CHUNK + 4, RSP = pr_piece_floats(D);
     constexpr uint32_t PAIR_MASK = PT ? 0x1fffffffu : PR_PAIR_MASK;
     constexpr int SB = LPF_SELECT4_BLOCK;
+    // PT: what a workgroup's share is balanced by is  EW * entries + pairs  -- the units of 16 entries are what takes time
+    // (a workgroup walks them in rounds of NG: one unit more than a multiple of NG is a whole round more), a pair without
+    // entries costs a row store
+    constexpr int EW = 4;
     extern __shared__ __attribute__((aligned(16))) float4 pr_lds[];
     float4 *const ltab = pr_lds + L::TAB;        // [4][3][G]: row j of hidden unit 4 lj + j, type t -> ((j * 3 + t) * G + lj)
     float4 *const lbase = pr_lds + L::BASE;      // [3][4][G]
@@ -170,20 +182,88 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         const int64_t c = (int64_t)e.y + e.z + e.w;
         return (e.x < 0 || e.y < 0 || e.z < 0 || e.w < 0 || e.x + c > A.ent_cap) ? 0 : (int)c;
     };
-    const bool bad = A.sel_ctl && A.sel_ctl[3] != 0;
-    for (int i = tid; i < 3 * D; i += NTH) {
-        const int t = i / D, k = i % D;
-        ltab[((k & 3) * 3 + t) * G + (k >> 2)] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
-        lbase[i] = reinterpret_cast<const float4 *>(A.base)[i];
+    bool bad = A.sel_ctl && A.sel_ctl[3] != 0;
+    // PT, wavefronts 0 / 1 (lower / upper end of the workgroup's range): the blocks' {entries, pairs with entries} are
+    // requested first -- lane l owns the blocks [l per, (l + 1) per) -- and travel beside the table fill below
+    const int64_t nblk = (A.bs + SB - 1) / SB, per = (nblk + 63) / 64;
+    auto blk_at = [&](int64_t B) __attribute__((always_inline)) {
+        int2 c = reinterpret_cast<const int2 *>(A.blk_cnt)[B];
+        const int np = (int)(A.bs - B * SB < SB ? A.bs - B * SB : SB);
+        c.x = c.x < 0 ? 0 : c.x;
+        c.y = c.y < 0 ? 0 : (c.y > np ? np : c.y);
+        return make_int4(c.x, c.y, np, 0);
+    };
+    int64_t own_w = 0;
+    int own_ne = 0;
+    if constexpr (PT) {
+        if (wave < 2) {
+            for (int64_t i = 0; i < per; ++i) {
+                const int64_t B = (int64_t)lane * per + i;
+                if (B < nblk) {
+                    const int4 c = blk_at(B);
+                    own_w += (int64_t)EW * c.x + c.z;
+                    own_ne += c.y;
+                }
+            }
+        }
     }
-    for (int i = tid; i < 3 * G; i += NTH) {
-        const float *src = i < G ? A.att_bias : (i < 2 * G ? A.ln_g : A.ln_b);
-        lvec[i] = *reinterpret_cast<const float4 *>(src + 4 * (i % G));
-    }
-    if (tid < 24) lstat[tid] = A.pe_stat[tid];
-    if constexpr (WTL > 0) {
-        const float4 *src = reinterpret_cast<const float4 *>(A.wfoldT) + (int64_t)T_LO * D * G;
-        for (int i = tid; i < WTL * D * G; i += NTH) lwt[i] = src[i];
+    {   // the tables: every load of a thread in flight before its first store (filling them with the wavefronts that do
+        // not look for the range only was measured: 9.4 us to the first barrier against 7.6)
+        constexpr int FT = NTH;
+        const int ft = tid;
+        constexpr int N3 = (3 * D + FT - 1) / FT;
+        float4 ta[N3], tb[N3];
+#pragma unroll
+        for (int u = 0; u < N3; ++u) {
+            const int i = u * FT + ft;
+            if (i < 3 * D) {
+                ta[u] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
+                tb[u] = reinterpret_cast<const float4 *>(A.base)[i];
+            }
+        }
+        constexpr int NW = WTL > 0 ? (WTL * D * G + FT - 1) / FT : 1;
+        float4 tw[NW];
+        if constexpr (WTL > 0) {
+            const float4 *src = reinterpret_cast<const float4 *>(A.wfoldT) + (int64_t)T_LO * D * G;
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                const int i = u * FT + ft;
+                if (i < WTL * D * G) tw[u] = src[i];
+            }
+        }
+        constexpr int NV = (3 * G + FT - 1) / FT;
+        float4 tv[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = u * FT + ft;
+            if (i < 3 * G) {
+                const float *src = i < G ? A.att_bias : (i < 2 * G ? A.ln_g : A.ln_b);
+                tv[u] = *reinterpret_cast<const float4 *>(src + 4 * (i % G));
+            }
+        }
+        const float ts = ft < 24 ? A.pe_stat[ft] : 0.f;
+#pragma unroll
+        for (int u = 0; u < N3; ++u) {
+            const int i = u * FT + ft;
+            if (i < 3 * D) {
+                const int t = i / D, k = i % D;
+                ltab[((k & 3) * 3 + t) * G + (k >> 2)] = ta[u];
+                lbase[i] = tb[u];
+            }
+        }
+        if constexpr (WTL > 0) {
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                const int i = u * FT + ft;
+                if (i < WTL * D * G) lwt[i] = tw[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = u * FT + ft;
+            if (i < 3 * G) lvec[i] = tv[u];
+        }
+        if (ft < 24) lstat[ft] = ts;
     }
 
     // pair-major position of pair p's first entry (the pointers clamped into their regions)
@@ -205,64 +285,46 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     };
     // ---- the workgroup's pair range: first pair p with  p + C[p]  >= b * (entries + pairs) / gridDim.x
     if constexpr (PT) {
-        // The selection left entries per BLOCK of 64 pairs: every thread sums the weights (entries + pairs) of its share of
-        // the blocks, one scan over the workgroup gives every share's place, the two threads whose share holds a target
-        // walk it; then wavefront 0 / 1 find the pair inside that block from its 64 table entries.
-        int64_t *const wtot = reinterpret_cast<int64_t *>(lwcnt);        // [NTH / 64] (LDS scratch, 16 words)
-        int64_t *const cut = reinterpret_cast<int64_t *>(lflag);         // [2][2]: block, weight in front of it
-        const int64_t nblk = (A.bs + SB - 1) / SB;
-        const int64_t per = (nblk + NTH - 1) / NTH;
-        auto blk_w = [&](int64_t B) __attribute__((always_inline)) {
-            const int c = A.blk_cnt[B];
-            const int64_t np = A.bs - B * SB < SB ? A.bs - B * SB : SB;
-            return (int64_t)(c < 0 ? 0 : c) + np;
-        };
-        int64_t own = 0;
-        for (int64_t i = 0; i < per; ++i) {
-            const int64_t B = (int64_t)tid * per + i;
-            if (B < nblk) own += blk_w(B);
-        }
-        int64_t x = own;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const int64_t y = __shfl_up(x, dlt, 64);
-            if (lane >= dlt) x += y;
-        }
-        if (lane == 63) wtot[wave] = x;
-        __syncthreads();
-        int64_t pre = 0, total = 0;
-        for (int w = 0; w < NTH / 64; ++w) {
-            if (w < wave) pre += wtot[w];
-            total += wtot[w];
-        }
-        const int64_t ex = pre + x - own;    // weight in front of this thread's first block
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int64_t b = (int64_t)blockIdx.x + e;
-            const int64_t target = (total * b) / (int64_t)gridDim.x;
-            // last block B with (weight in front of B) < target: it lies in the share with ex < target <= ex + own
-            if (b > 0 && b < (int64_t)gridDim.x && ex < target && target <= ex + own) {
-                int64_t B = (int64_t)tid * per, f = ex;
-                while (B + 1 < nblk && B + 1 < (int64_t)(tid + 1) * per) {
-                    const int64_t fn = f + blk_w(B);
-                    if (fn >= target) break;
-                    f = fn;
-                    ++B;
-                }
-                cut[2 * e] = B;
-                cut[2 * e + 1] = f;
-            }
-        }
-        __syncthreads();
+        // The selection left {entries, pairs with entries} per BLOCK of 64 pairs.  One wavefront per end, no LDS and no
+        // barrier: a scan over the lanes' shares of the blocks finds the share a target falls into, its lane walks it,
+        // then the pair inside that block comes from the block's 64 table entries -- two dependent round trips.
         if (wave < 2) {
+            int64_t x = own_w;
+            int xn = own_ne;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int64_t y = __shfl_up(x, dlt, 64);
+                const int yn = __shfl_up(xn, dlt, 64);
+                if (lane >= dlt) { x += y; xn += yn; }
+            }
+            const int64_t total = __shfl(x, 63, 64);
+            const int total_ne = __shfl(xn, 63, 64);
             const int64_t b = (int64_t)blockIdx.x + wave;
+            const int64_t target = (total * b) / (int64_t)gridDim.x;
             int64_t P = 0, C = 0;
+            int NE = 0;
             if (b >= (int64_t)gridDim.x) {
-                P = A.bs; C = total - A.bs;
-            } else if (b > 0) {
-                const int64_t target = (total * b) / (int64_t)gridDim.x;
-                const bool any = target > 0;                     // (fewer entries + pairs than workgroups: nothing in front)
-                const int64_t B = any ? cut[2 * wave] : 0, f = any ? cut[2 * wave + 1] : 0;
+                P = A.bs; C = (total - A.bs) / EW; NE = total_ne;
+            } else if (b > 0 && target > 0) {   // (target 0: fewer entries + pairs than workgroups, nothing in front)
+                // last block B with (weight in front of B) < target: it lies in the share with ex < target <= ex + own
+                const int64_t ex = x - own_w;
+                const uint64_t holder = __ballot(ex < target && target <= x);
+                const int hl = holder ? __builtin_ctzll(holder) : 0;
+                int64_t B = (int64_t)lane * per, f = ex;
+                int nef = xn - own_ne;
+                if (lane == hl) {
+                    while (B + 1 < nblk && B + 1 < (int64_t)(lane + 1) * per) {
+                        const int4 c = blk_at(B);
+                        const int64_t fn = f + (int64_t)EW * c.x + c.z;
+                        if (fn >= target) break;
+                        f = fn;
+                        nef += c.y;
+                        ++B;
+                    }
+                }
+                B = __shfl(B, hl, 64);
+                f = __shfl(f, hl, 64);
+                nef = __shfl(nef, hl, 64);
                 const int64_t p = B * SB + lane;
                 const int cnt = p < A.bs ? pt_count(p) : 0;
                 int xs = cnt;     // inclusive scan of the entries
@@ -271,17 +333,29 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     const int y = __shfl_up(xs, dlt, 64);
                     if (lane >= dlt) xs += y;
                 }
-                // f(p) = f + lane + (entries of the block's pairs in front of p)
-                const bool below = p < A.bs && f + lane + (xs - cnt) < target;
+                // f(p) = f + lane + EW * (entries of the block's pairs in front of p)
+                const bool below = p < A.bs && f + lane + (int64_t)EW * (xs - cnt) < target;
                 const uint64_t bm = __ballot(below);      // (monotone: the first c pairs are below the target)
                 const int c = __popcll(bm);
                 const int before = c == 0 ? 0 : __shfl(xs, c - 1, 64);
                 P = B * SB + c;
-                C = f - B * SB + before;
+                // entries in front of P: in front of block B (f = EW * entries + pairs = EW * entries + B * SB) + inside it
+                C = (f - B * SB) / EW + before;
+                NE = nef + __popcll(__ballot(below && cnt > 0));
             }
             if (lane == 0) {
                 lctl[4 + 2 * wave] = (int)(P & 0xffffffff); lctl[5 + 2 * wave] = (int)(P >> 32);
                 lctl[12 + 2 * wave] = (int)(C & 0xffffffff); lctl[13 + 2 * wave] = (int)(C >> 32);
+                if (wave == 0) {
+                    lctl[8] = NE; lctl[9] = 0; lctl[10] = total_ne;   // pairs with entries in front of the range, in all
+                    // more entries than the scratch for the pieces has units for: nothing is walked, the rows are NaN and
+                    // the sticky bit tells the caller to size the workspace again (as when the selection does not fit)
+                    const bool over = (total - A.bs) / EW > 16 * (A.units_cap - 1);
+                    lctl[11] = over ? 1 : 0;
+                    if (over && blockIdx.x == 0 && A.sel_ctl)
+                        atomicOr(reinterpret_cast<unsigned long long *>(const_cast<int64_t *>(A.sel_ctl) + 3),
+                                 (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
+                }
             }
         }
     } else
@@ -319,12 +393,14 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     const int64_t P0 = (int64_t)(uint32_t)lctl[4] | ((int64_t)lctl[5] << 32);
     const int64_t P1 = (int64_t)(uint32_t)lctl[6] | ((int64_t)lctl[7] << 32);
     int64_t vpos = PT ? ((int64_t)(uint32_t)lctl[12] | ((int64_t)lctl[13] << 32)) : 0;   // PT: pair-major position of the chunk
+    const bool over = PT && lctl[11] != 0;
+    bad = bad || over;
 
     // ---- the tail's order, first half: publish how many pairs of this workgroup's range select anything (word
     //      blockIdx.x of perm_lb, tagged with this launch's number: word PR_LB_WORDS counts the launches).  The second half
     //      -- the sum over the workgroups in front, then the order itself -- waits until the rows are done: by then every
     //      predecessor's word has long been out, nobody spins on a workgroup that is not resident yet.
-    if (A.perm) {
+    if (!PT && A.perm) {
         int cnt = 0;
         for (int64_t k = P0 + tid; k < P1; k += NTH) cnt += nonempty(k) ? 1 : 0;
 #pragma unroll
@@ -387,7 +463,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
 
     for (int64_t c0 = P0; c0 < P1; c0 += PR_CHUNK) {
         const int cn = (int)(P1 - c0 < PR_CHUNK ? P1 - c0 : PR_CHUNK);
-        __syncthreads();   // the previous chunk's lists and pointers are no longer needed
+        pr_lds_barrier();   // the previous chunk's lists and pointers are no longer needed
         int64_t v0, v1;
         if constexpr (PT) {
             // the chunk's table entries: ltp[k] = first entry, ltp[TPS + k] / ltp[2 TPS + k] = common neighbours / one-hop
@@ -400,7 +476,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 cnt[i] = 0;
                 if (k < cn) {
                     const int4 e = A.pair_tab[c0 + k];
-                    const bool ok = pt_count(c0 + k) > 0;
+                    const bool ok = !over && pt_count(c0 + k) > 0;
                     cnt[i] = ok ? e.y + e.z + e.w : 0;
                     ltp[k] = ok ? e.x : 0;
                     ltp[TPS + k] = ok ? e.y : 0;
@@ -416,7 +492,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             }
             if (lane == 63) lwcnt[wave] = x;
             if (tid < 4) lctl[tid] = 0;
-            __syncthreads();
+            pr_lds_barrier();
             int pre = 0, tot = 0;
             for (int w = 0; w < NTH / 64; ++w) {
                 if (w < wave) pre += lwcnt[w];
@@ -441,7 +517,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             ltp[t * TPS + k] = (int)v;
         }
         if (tid < 4) lctl[tid] = 0;
-        __syncthreads();
+        pr_lds_barrier();
         // pair-major base of the chunk, then every pair's start relative to it (fits 31 bits: ent_cap does)
         v0 = (int64_t)ltp[0] + ltp[TPS] + ltp[2 * TPS];
         v1 = (int64_t)ltp[cn] + ltp[TPS + cn] + ltp[2 * TPS + cn];
@@ -456,7 +532,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         const bool inl = n_units <= PR_FLAGS;
         if (inl)
             for (int k = tid; k < n_units; k += NTH) lflag[k] = 0;
-        __syncthreads();
+        pr_lds_barrier();
         // ---- sort the chunk's pairs (empty / in several pieces); the count features go out at once
         for (int k = tid; k < cn; k += NTH) {
             int n0, n1, n2;
@@ -479,7 +555,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 else { o[0] = f0; }
             }
         }
-        __syncthreads();
+        pr_lds_barrier();
         PR_STAMP(2);
         const int n_empty = lctl[0], n_multi = lctl[1];
         // ---- pairs without entries: the constant row
@@ -760,9 +836,10 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     // ---- the tail's order, second half: pairs with selected nodes in ascending order from the front, the others from
     //      the back.  Deterministic (sums of published counts, ranks from ballots -- no atomics on a counter): a replayed
     //      step stays bitwise the eager one.
+    if (PT && A.perm && tid == 0 && blockIdx.x == gridDim.x - 1) *A.n_nonempty = (int64_t)lctl[10];
     if (A.perm) {
-        __syncthreads();
-        if (wave == 0) {
+        pr_lds_barrier();
+        if (!PT && wave == 0) {   // (PT: the selection counted the pairs with entries per block -- known since the set-up)
             const uint32_t epoch = (uint32_t)lctl[11];
             const int64_t nb = blockIdx.x;
             uint64_t sum = 0;
@@ -792,7 +869,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 }
             }
         }
-        __syncthreads();
+        pr_lds_barrier();
         int64_t ne_base = (int64_t)(uint32_t)lctl[8] | ((int64_t)lctl[9] << 32);   // pairs with entries in front
         for (int64_t k0 = P0; k0 < P1; k0 += NTH) {
             const int64_t k = k0 + tid;
@@ -800,7 +877,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             const bool ne = in && nonempty(k);
             const uint64_t b_ne = __ballot(ne), b_all = __ballot(in);
             if (lane == 0) { lwcnt[wave] = __popcll(b_ne); lwcnt[16 + wave] = __popcll(b_all); }
-            __syncthreads();
+            pr_lds_barrier();
             int pre_ne = 0, pre_all = 0, tot_ne = 0;
             for (int w = 0; w < NTH / 64; ++w) {
                 if (w < wave) { pre_ne += lwcnt[w]; pre_all += lwcnt[16 + w]; }
@@ -810,7 +887,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             const int r_ne = pre_ne + __popcll(b_ne & lt), r_all = pre_all + __popcll(b_all & lt);
             if (ne) A.perm[ne_base + r_ne] = (int32_t)k;
             else if (in) A.perm[A.bs - 1 - ((k0 - ne_base) + (r_all - r_ne))] = (int32_t)k;
-            __syncthreads();
+            pr_lds_barrier();
             ne_base += tot_ne;
         }
     }
@@ -835,8 +912,8 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
     LPF_REQUIRE(bs > 0 && bs < (PT ? (1ll << 29) : (1ll << 31)) && (PT ? (pair_tab && blk_cnt && lpf_aligned16(pair_tab)) : type_ptr != nullptr) &&
                 entries && ent_cap > 0 && ent_cap < (PT ? (1ll << 31) : (1ll << 29)) && Z && q &&
                 pe_tab_signed && pe_stat && base && wfold_t && att && att_bias && ln_g && ln_b && out && pieces &&
-                units_cap >= ((PT ? 1 : 3) * ent_cap + 15) / 16 + 1 && lpf_aligned16(pieces));
-    LPF_REQUIRE(!perm || (perm_lb && n_nonempty));
+                units_cap >= (PT ? 2 : (3 * ent_cap + 15) / 16 + 1) && lpf_aligned16(pieces));
+    LPF_REQUIRE(!perm || ((PT || perm_lb) && n_nonempty));
     LPF_REQUIRE((n_counts == 0 || n_counts == 1 || n_counts == 3 || n_counts == 4) && ldo >= D + n_counts && (ldo & 3) == 0);
     LPF_REQUIRE(ldz >= D && ldq >= D && ldz < (1ll << 31) && ldq < (1ll << 31) && (ldz & (ZB ? 7 : 3)) == 0 &&
                 (ldq & 3) == 0 && lpf_aligned16(entries) && lpf_aligned16(Z) && lpf_aligned16(q) &&
@@ -946,18 +1023,17 @@ extern "C" int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const i
 }
 
 /* The same kernel behind lpf_select4 (pair-major entries, the type in the record; pair_tab / blk_cnt as that call leaves
- * them).  perm / perm_lb / n_nonempty: all three or none (NULL). */
+ * them).  perm / n_nonempty: both or none (NULL); no scan words -- the selection counted the pairs with entries. */
 extern "C" int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
                                             const void *entries, int64_t ent_cap, const float *Z, int64_t ldz,
                                             const float *q, int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
                                             const float *base, const float *wfold_t, const float *att,
                                             const float *att_bias, const float *ln_g, const float *ln_b, int32_t n_counts,
                                             const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
-                                            int64_t ldo, int32_t *perm, uint64_t *perm_lb, int64_t *n_nonempty,
-                                            void *stream) {
+                                            int64_t ldo, int32_t *perm, int64_t *n_nonempty, void *stream) {
     return rows_launch<false, true>(D, bs, nullptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t,
                                     att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream, perm,
-                                    perm_lb, n_nonempty, pair_tab, blk_cnt);
+                                    nullptr, n_nonempty, pair_tab, blk_cnt);
 }
 
 extern "C" int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
@@ -967,10 +1043,10 @@ extern "C" int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void 
                                               const float *att, const float *att_bias, const float *ln_g,
                                               const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
                                               int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
-                                              uint64_t *perm_lb, int64_t *n_nonempty, void *stream) {
+                                              int64_t *n_nonempty, void *stream) {
     return rows_launch<true, true>(D, bs, nullptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, base,
                                    wfold_t, att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream,
-                                   perm, perm_lb, n_nonempty, pair_tab, blk_cnt);
+                                   perm, nullptr, n_nonempty, pair_tab, blk_cnt);
 }
 
 /* floats of one piece record of lpf_pair_attention_rows_* (D accumulators, m, l, padded to whole 128-byte lines) */

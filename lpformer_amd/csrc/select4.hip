@@ -24,7 +24,7 @@
 //             its three counts go to pair_tab[pair], the type of an entry travels in its record.
 //
 // Result: entries {pair | type << 29 | from_N(b) << 31, node, pa, pb}; pair_tab[pair] = {start, n_cn, n_1hop, n_far};
-// blk_cnt[block] = entries of the block (the attention kernel splits its work by it).  Deterministic up to the block
+// blk_cnt[block] = {entries, pairs with entries} of the block (the attention kernel splits its work by it).  Deterministic up to the block
 // bases: every consumer addresses entries through pair_tab, so scores do not depend on where a block landed.
 #include "walk_common.h"
 
@@ -48,7 +48,7 @@ struct Args4 {
     float th_cn, th_1, th_n;
     int64_t *ctl;
     int4 *pair_tab;      // [bs]
-    int32_t *blk_cnt;    // [ceil(bs / 64)]
+    int32_t *blk_cnt;    // [ceil(bs / 64)][2]: entries, pairs with entries
     int4 *entries;       // [ent_cap]
     int64_t ent_cap;
 };
@@ -73,6 +73,17 @@ __device__ __forceinline__ void s4_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// (tuning builds, -DS4_STAMPS: thread 0 of every workgroup leaves the wall clock -- 100 MHz -- at the marks below in a
+//  debug buffer; tools/select4_stamps.py)
+#ifdef S4_STAMPS
+__device__ uint64_t *s4_stamp_buf = nullptr;
+#define S4_STAMP(k) do { if (tid == 0) st_t[k] = wall_clock64(); } while (0)
+#define S4_STAMP_WAIT(k) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); S4_STAMP(k); } while (0)
+#else
+#define S4_STAMP(k) do { } while (0)
+#define S4_STAMP_WAIT(k) do { } while (0)
+#endif
+
 template <int NTH>
 __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
     using LT = Lds4<NTH>;
@@ -82,6 +93,10 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
     const uint64_t lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
     const int64_t p0 = (int64_t)blockIdx.x * S4_PAIRS;
     const int np = (int)(A.bs - p0 < S4_PAIRS ? A.bs - p0 : S4_PAIRS);
+#ifdef S4_STAMPS
+    uint64_t st_t[16] = {0};
+    S4_STAMP(0);
+#endif
 
     // ---- the endpoints' mini filters: one 16-byte piece per thread and trip (id -> piece: two dependent reads, beside
     //      the plan's id -> node record)
@@ -139,7 +154,9 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
         const int i = f * NTH + tid;
         if (i < FP) (&L.flt[0][0][0])[i] = fr[f];
     }
+    S4_STAMP(1);    // plan issued (wavefront 0: ids -> node records -> descriptors; the others: ids -> filter pieces)
     s4_lds_barrier();
+    S4_STAMP(2);    // plan barrier
     const int S = L.S;
     const int myloc = L.loc[lane < S4_PAIRS ? lane : S4_PAIRS];   // (S4_PAIRS == 64: lane j holds the start of pair j)
     volatile int32_t *const sfw = &L.sflag[wave][0][0];
@@ -184,6 +201,7 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
                 }
             }
         }
+        if (s0 == 0) S4_STAMP_WAIT(3);    // walked entries arrived
         int4 bv[S4_ROUNDS][BUCKET / 2];
 #pragma unroll
         for (int r = 0; r < S4_ROUNDS; ++r) {
@@ -196,6 +214,7 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
 #pragma unroll
             for (int q = 0; q < BUCKET / 2; ++q) bv[r][q] = look ? blk[q] : make_int4(-1, 0, -1, 0);
         }
+        if (s0 == 0) S4_STAMP_WAIT(4);    // buckets arrived
         uint64_t keptb[S4_ROUNDS];
 #pragma unroll
         for (int r = 0; r < S4_ROUNDS; ++r) {
@@ -213,7 +232,9 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
             if (c3) atomicAdd(&L.pcnt[win[r]][c3 - 1], 1);
             if (lane == 0) L.rcnt[g] = __popcll(keptb[r]);
         }
+        if (s0 == 0) S4_STAMP(5);         // arithmetic + ballots
         s4_lds_barrier();
+        if (s0 == 0) S4_STAMP(6);         // typing barrier
         // ---- the rounds' places inside the block: one scan over the rounds of the batch (wavefront 0)
         if (wave == 0) {
             const int v = lane < NR ? L.rcnt[lane] : 0;
@@ -232,6 +253,7 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
             }
         }
         s4_lds_barrier();
+        if (s0 == 0) S4_STAMP(7);         // scan + barrier
         const int64_t base = L.base;
         const bool ovf = L.ovf != 0;
 #pragma unroll
@@ -246,8 +268,15 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
             if (first[r]) L.pcnt[win[r]][3] = pos;   // first slot of the pair: where its entries start
         }
     }
+    S4_STAMP(8);    // entries written (issued), further batches
     s4_lds_barrier();
+    S4_STAMP(9);
     const bool ovf = S > 0 && L.ovf != 0;
+    if (wave == 0) {    // (S4_PAIRS == 64: lane = pair)
+        const int4 cc = *reinterpret_cast<const int4 *>(L.pcnt[lane]);
+        const int ne = __popcll(__ballot(lane < np && !ovf && cc.x + cc.y + cc.z > 0));
+        if (lane == 0) reinterpret_cast<int2 *>(A.blk_cnt)[blockIdx.x] = make_int2(ovf ? 0 : L.run, ne);
+    }
     if (tid < np) {
         const int4 c = *reinterpret_cast<const int4 *>(L.pcnt[tid]);
         // (a block that does not fit leaves empty pairs -- nothing is read past the buffer -- and raises the sticky bit:
@@ -255,7 +284,6 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
         A.pair_tab[p0 + tid] = ovf ? make_int4(0, 0, 0, 0) : make_int4((int32_t)(L.base + c.w), c.x, c.y, c.z);
     }
     if (tid == 0) {
-        A.blk_cnt[blockIdx.x] = ovf ? 0 : L.run;
         if (ovf) atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ERR), (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
         // the last workgroup leaves the counters as the next launch on this control block wants them (stream order)
         const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + CTL_DONE), 1ull);
@@ -265,9 +293,23 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
             A.ctl[0] = (int64_t)total;   // entries the batch needs room for (what ent_cap is sized from)
         }
     }
+#ifdef S4_STAMPS
+    if (tid == 0 && s4_stamp_buf) {
+        S4_STAMP(10);
+        uint64_t *o = s4_stamp_buf + (int64_t)blockIdx.x * 16;
+        for (int k = 0; k < 11; ++k) o[k] = st_t[k];
+        o[11] = (uint64_t)S;
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef S4_STAMPS
+extern "C" int lpf_select4_set_stamps(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(s4_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? LPF_OK : LPF_ERR_LAUNCH;
+}
+#endif
 
 /* ---- C ABI ---------------------------------------------------------------------------------------------------- */
 extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,

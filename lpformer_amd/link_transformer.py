@@ -488,8 +488,10 @@ class _Select4Workspace:
         self.device, self.bs = device, bs
         self.ctl = torch.zeros(16, dtype=torch.int64, device=device)  # LPF_SELECT_CTL_WORDS
         self.pair_tab = torch.zeros(4 * max(bs, 1), dtype=torch.int32, device=device)
-        self.blk_cnt = torch.zeros((bs + _lib.SELECT4_BLOCK - 1) // _lib.SELECT4_BLOCK + 1, dtype=torch.int32, device=device)
+        self.blk_cnt = torch.zeros(2 * ((bs + _lib.SELECT4_BLOCK - 1) // _lib.SELECT4_BLOCK) + 2, dtype=torch.int32,
+                                   device=device)   # {entries, pairs with entries} per block
         self.ent_cap = 0
+        self.kept_cap = 0       # selected entries the attention's scratch is sized for (its units of 16)
         self.entries = None
         self.calibrated = False
 
@@ -518,7 +520,7 @@ class _Select4Workspace:
 
     def kept(self) -> int:
         """Selected entries of the last batch (synchronises)."""
-        return int(self.blk_cnt[:-1].sum().item())
+        return int(self.blk_cnt[:-2:2].sum().item())
 
 
 # ------------------------------------------------------------------------------------------ the model
@@ -1203,7 +1205,11 @@ class LinkTransformer(nn.Module):
             ws.clear_errors()
             if err & _lib.SELECT_ERR_NODE_RANGE:
                 raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
-            ws.ensure(ent_cap=need[0] + need[0] // 2 + 4096, shrink=True)
+            # a block's place is reserved for its candidate SLOTS (an upper bound of what it keeps): three times the
+            # first batch's, hub-heavy batches need several times the room of sparse ones
+            ws.ensure(ent_cap=3 * need[0] + 65536, shrink=True)
+            self._select4_launch(ws, batch, wi)
+            ws.kept_cap = 2 * ws.kept() + 65536
             ws.calibrated = True
         self._select4_launch(ws, batch, wi)
         return ws
@@ -1407,13 +1413,14 @@ class LinkTransformer(nn.Module):
         if side is not None:
             _lib.stream_wait(torch.cuda.current_stream(self.device), side)
         layer = self.att_layers[0]
-        units_cap = ((1 if four else 3) * ws.ent_cap + 15) // 16 + 1
+        units_cap = (ws.kept_cap + 15) // 16 + 1 if four else (3 * ws.ent_cap + 15) // 16 + 1
         pieces = self._workspace("att_pieces", units_cap * 2 * int(lib.lpf_pair_rows_piece_floats(d)), torch.float32, st)
         extra = ()
         if order:
             perm = self._workspace("att_perm", bs, torch.int32, st)
             nfull = self._workspace("att_nfull", 1, torch.int64, st)
-            extra = (ptr(perm), ptr(self._zero_workspace("att_perm_lb", 2 * _lib.ROWS_PERM_LB_WORDS, st)), ptr(nfull))
+            extra = (ptr(perm), ptr(nfull)) if four else \
+                (ptr(perm), ptr(self._zero_workspace("att_perm_lb", 2 * _lib.ROWS_PERM_LB_WORDS, st)), ptr(nfull))
         zt = self._z_bf16(z) if self.precision == "bf16" else z
         tabs = (ptr(zt), zt.stride(0), ptr(q), q.stride(0), ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]),
                 ptr(w["wfold_t"]), ptr(w["att"]), ptr(layer.att.bias), ptr(layer.post_att_norm.weight),
@@ -1422,7 +1429,7 @@ class LinkTransformer(nn.Module):
             if four:
                 name = "lpf_pair_attention_rows4" + ("_zbf16" if self.precision == "bf16" else "_f32")
                 check(getattr(lib, name)(d, bs, ptr(ws.pair_tab), ptr(ws.blk_cnt), ptr(ws.entries), ws.ent_cap, *tabs,
-                                         *(extra or (None, None, None)), st), name)
+                                         *(extra or (None, None)), st), name)
             else:
                 name = ("lpf_pair_attention_rows" + ("_perm" if order else "") +
                         ("_zbf16" if self.precision == "bf16" else "_f32"))

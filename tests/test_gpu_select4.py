@@ -29,11 +29,11 @@ def sel4_sets(model, batch, test_set=False, threads=0):
     bs = batch.shape[1]
     tab = ws.pair_tab[:4 * bs].view(bs, 4).cpu().numpy().astype(np.int64)
     ent = ws.entries.view(-1, 4).cpu().numpy()
-    blk = ws.blk_cnt.cpu().numpy()
+    blk = ws.blk_cnt.cpu().numpy().reshape(-1, 2)
     cnt = tab[:, 1:].sum(1)
-    # the table is consistent with itself and with the block counts
+    # the table is consistent with itself and with the block counts {entries, pairs with entries}
     for b in range((bs + 63) // 64):
-        assert blk[b] == cnt[64 * b: 64 * b + 64].sum()
+        assert blk[b, 0] == cnt[64 * b: 64 * b + 64].sum() and blk[b, 1] == (cnt[64 * b: 64 * b + 64] > 0).sum()
     assert (tab[:, 0] >= 0).all() and (tab[:, 0] + cnt <= ws.ent_cap).all()
     idx = np.concatenate([np.arange(s, s + c) for s, c in zip(tab[:, 0], cnt)]) if cnt.sum() else np.zeros(0, np.int64)
     rec = ent[idx]

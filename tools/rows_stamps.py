@@ -16,6 +16,7 @@ model = lpformer_amd.LinkTransformer(D.train_args_for(cfg), data, device=dev).to
 score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
 model.use_side_stream = False
 model.attention_impl = "flip"
+model.select_blocks = os.environ.get("LPF_SELECT_BLOCKS", "1") == "1"
 batches = [torch.from_numpy(D.sample_pairs(ei, n, cfg["batch"], seed=1000 + i)).to(dev) for i in range(3)]
 h = model.propagate()
 lib = _lib.hip()
@@ -39,6 +40,22 @@ for i, b in enumerate(batches):
     for k in range(6):
         print(f"   {names[k]:14s} p10 {np.percentile(rel[:, k], 10):6.1f}  p50 {np.percentile(rel[:, k], 50):6.1f}  "
               f"p90 {np.percentile(rel[:, k], 90):6.1f}  max {rel[:, k].max():6.1f}")
+    if os.environ.get("LPF_STAMP_WG"):   # per workgroup: when its last wavefront finished, tickets drawn, pairs in its range
+        nw = len(v) // (v[:, 7].astype(np.int64) & 0xffffffff > -1).sum() if False else 16
+        wg = v.reshape(-1, nw, 8)
+        end = (wg[:, :, 4].max(1) - t0) / 100.0
+        beg = (wg[:, :, 3].min(1) - t0) / 100.0
+        tickets = wg[:, :, 6].sum(1)
+        pairs = (wg[:, 0, 7].astype(np.int64) & 0xffffffff)
+        multi = (wg[:, 0, 7].astype(np.int64) >> 32)
+        order = np.argsort(end)
+        print("   slowest workgroups (index, units start, units end, tickets, max rounds of a wavefront, pairs, pairs in pieces):")
+        for j in order[-8:]:
+            print(f"     {j:4d} {beg[j]:6.1f} {end[j]:6.1f} {tickets[j]:4.0f} {wg[j, :, 6].max():3.0f} {pairs[j]:5d} {multi[j]:4d}")
+        print("   median ones:")
+        for j in order[len(order) // 2 - 3: len(order) // 2 + 3]:
+            print(f"     {j:4d} {beg[j]:6.1f} {end[j]:6.1f} {tickets[j]:4.0f} {wg[j, :, 6].max():3.0f} {pairs[j]:5d} {multi[j]:4d}")
+        print(f"   corr(end, tickets) {np.corrcoef(end, tickets)[0, 1]:.2f}  corr(end, pairs) {np.corrcoef(end, pairs)[0, 1]:.2f}  tickets p10 {np.percentile(tickets, 10):.0f} p50 {np.percentile(tickets, 50):.0f} p90 {np.percentile(tickets, 90):.0f} max {tickets.max():.0f}")
     r = v[:, 6]
     heavy = (v[:, 7].astype(np.int64) >> 32)
     print(f"   unit rounds per wavefront: mean {r.mean():.2f} p50 {np.percentile(r, 50):.0f} max {r.max():.0f}; per round: "
