@@ -584,6 +584,7 @@ class LinkTransformer(nn.Module):
         self._override = {}    # kind -> (obj, DeviceCSR): the LAST caller-supplied override only
         self._folded = None    # (param version key, dict of device tensors)
         self._z_cache = None   # (key, Z)
+        self._y_cache = None   # (key, Y): the per-node query table, built lazily (query_from = "table")
         self._x_cache = None   # (key, padded features)
         self._ws = {}          # named workspaces
         self._param_list = None  # cached list(self.parameters()) for the fold key
@@ -766,6 +767,8 @@ class LinkTransformer(nn.Module):
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
         self._folded = (key, dev)
         self._z_cache = None
+        self._y_cache = None      # (Y = X W_l^T + b_l is parameter-derived too: a stale Y would give stale queries)
+        self._zb_cache = None
         self._chain_att._key = None
         return dev
 

@@ -65,6 +65,7 @@ class LPFormer(nn.Module):
         self.core._override.clear()
         self.core._x_cache = None
         self.core._z_cache = None
+        self.core._y_cache = None
         self.core._enc_cache = None
         self._bound = key
 

@@ -733,3 +733,30 @@ def test_node_keys_chained_to_the_last_layer_match_the_separate_product(dim, res
     lin_r = model.att_layers[0].att.lin_r
     want = out[True][0].double() @ lin_r.weight[:, :dim].double().T + lin_r.bias.double()
     assert (out[True][1].double() - want).abs().max().item() <= 2e-5 * zs
+
+
+@pytest.mark.parametrize("name,scale", [("collab", 0.1), ("cora", 1.0)])
+def test_query_table_follows_an_in_place_update_of_lin_l(name, scale):
+    """The per-node query table Y = X W_l^T + b_l (``query_from = "table"``) is parameter-derived: an in-place change of
+    ``att.lin_l`` with the SAME encoder output reused (a frozen encoder with a trained head, an in-place
+    ``load_state_dict``) must rebuild it -- eager and through a recorded plan, D = 128 and D = 256 -- or the queries are
+    silently those of the old weights."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale=scale, bs=2048)
+    tb = torch.from_numpy(batch).to(DEV)
+    h = model.propagate()
+    plan = lpformer_amd.PlannedScorer(model, score, h, tb, logits=True)
+    before = model.score_pairs(tb, h, score, logits=True).clone()
+    assert model.check_selection() and torch.equal(before, plan(tb))
+    with torch.no_grad():
+        lin_l = model.att_layers[0].att.lin_l
+        lin_l.weight.add_(0.05 * torch.randn_like(lin_l.weight))
+        lin_l.bias.add_(0.1)
+    after = model.score_pairs(tb, h, score, logits=True).clone()
+    assert model.check_selection()
+    assert (after - before).abs().max().item() > 1e-3, "the update must move the scores"
+    sample, ref = _oracle_sample(model, score, data, args, batch, h)
+    k = sample.shape[1]
+    assert np.abs(after[:k].cpu().numpy() - ref["logit"]).max() <= 1e-4 * max(1.0, float(np.abs(ref["logit"]).max()))
+    got = plan(tb).clone()                      # re-records: a parameter's version changed
+    torch.cuda.synchronize()
+    assert torch.equal(got, after)
