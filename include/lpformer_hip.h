@@ -278,13 +278,15 @@ int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int
  *             the >1-hop nodes), types mixed
  *   pair_tab  int32[bs][4] = {first entry, n_cn, n_1hop, n_non1hop} per pair
  *   blk_cnt   int32[ceil(bs / LPF_SELECT4_BLOCK)][2]: {selected entries, pairs with selected entries} per block of pairs
- *   ctl       int64[LPF_SELECT_CTL_WORDS], zero-initialised once by the caller, then owned by the library (one control
- *             block per stream): [0] entries the last batch needed room for (its candidate slots, block by block rounded
- *             up to 8: what ent_cap is sized from)  [3] STICKY error bits as above  [9], [10] allocation and completion
- *             counters (zero between launches)
+ *   ctl       int64[LPF_SELECT4_CTL_WORDS], zero-initialised once by the caller, then owned by the library (one control
+ *             block per stream): [0] entries the last batch needed room for (the buffer is cut into 8 regions, workgroup
+ *             g allocates its candidate slots -- rounded up to 8 -- in region g % 8: 8 x the fullest region)  [3] STICKY
+ *             error bits as above  [10] completion counter, [16..23] allocation counters (zero between launches)
  * A block that does not fit below ent_cap leaves empty pairs and raises LPF_SELECT_ERR_ENTRY_CAP (consumers write NaN
- * rows while the bit is set).  threads: 0 (default), 512 or 1024 per workgroup. */
+ * rows while the bit is set).  threads: launch shape, workgroup size (512 or 1024) + 4096 * (blocks of 64 pairs a workgroup
+ * takes together - 1); 0 = the default (1024 threads, 2 blocks). */
 #define LPF_SELECT4_BLOCK 64
+#define LPF_SELECT4_CTL_WORDS 32
 int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
                 const void *adj_cv, const void *a1_cv, const void *px_cv, const void *t0_cv, const void *u_cv,
                 const void *mini, int32_t mode_cn, int32_t use_px, float th_cn, float th_1hop, float th_non1hop,

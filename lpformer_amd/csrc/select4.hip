@@ -34,7 +34,12 @@ using namespace walk;
 
 constexpr int S4_PAIRS = LPF_SELECT4_BLOCK;   // pairs per workgroup: one lane of the planning wavefront each
 constexpr int S4_ROUNDS = 4;                  // slots per thread in flight
-constexpr int CTL_ERR = 3, CTL_ALLOC = 9, CTL_DONE = 10;
+constexpr int CTL_ERR = 3, CTL_DONE = 10, CTL_ALLOC = 16;   // CTL_ALLOC: first of S4_SHARDS allocation counters
+// The entry buffer is cut into S4_SHARDS equal regions, a workgroup allocates in region blockIdx.x % S4_SHARDS: all
+// workgroups of a launch reach their allocation within a microsecond of each other, and 256 returning atomics on ONE
+// word take ~3 us to drain (~12 ns each) -- the wavefront that issued one waits that long at its next load.
+constexpr int S4_SHARDS = 8;
+static_assert(CTL_ALLOC + S4_SHARDS <= LPF_SELECT4_CTL_WORDS, "control block too small");
 
 struct Args4 {
     int64_t bs;
@@ -53,17 +58,20 @@ struct Args4 {
     int64_t ent_cap;
 };
 
-template <int NTH>
+// NB: blocks of 64 pairs a workgroup takes together (one planning wavefront each; their slots form one space, their
+// entries one contiguous run): the plan's two round trips are paid once per NB blocks and a workgroup's batches are fuller
+template <int NTH, int NB>
 struct Lds4 {
-    static constexpr int WAVES = NTH / 64, NR = WAVES * S4_ROUNDS;
-    PairDesc3 dsc[S4_PAIRS];                     // the block's walk descriptors
-    uint4 flt[S4_PAIRS][2][MINI_WORDS / 4];      // mini filters of the endpoints (a, b)
+    static constexpr int WAVES = NTH / 64, NR = WAVES * S4_ROUNDS, PAIRS = S4_PAIRS * NB;
+    PairDesc3 dsc[PAIRS];                        // the walk descriptors
+    uint4 flt[PAIRS][2][MINI_WORDS / 4];         // mini filters of the endpoints (a, b)
     int32_t sflag[WAVES][S4_ROUNDS][64];         // per wavefront and round: "a pair starts in this slot"
-    int32_t loc[S4_PAIRS + 1];                   // first slot of pair j (block-relative); pairs past the batch: S
-    int32_t pcnt[S4_PAIRS][4];                   // per pair: kept common neighbours, one-hop, >1-hop; start (block-relative)
+    int32_t loc[PAIRS];                          // first slot of pair j, relative to its block of 64; pairs past the batch: the block's slots
+    int32_t pcnt[PAIRS][4];                      // per pair: kept common neighbours, one-hop, >1-hop; start (workgroup-relative)
     int32_t rcnt[NR];                            // kept entries per round of the batch, then their exclusive scan
-    int64_t base;                                // the block's place in the entry buffer
-    int32_t S, run, ovf;
+    int32_t sub[NB];                             // slots of every block
+    int64_t base;                                // the workgroup's place in the entry buffer
+    int32_t run, ovf;
 };
 
 // Workgroup barrier that orders LDS only (select3.hip: __syncthreads() would drain the vector-memory counter -- here
@@ -84,15 +92,16 @@ __device__ uint64_t *s4_stamp_buf = nullptr;
 #define S4_STAMP_WAIT(k) do { } while (0)
 #endif
 
-template <int NTH>
+template <int NTH, int NB>
 __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
-    using LT = Lds4<NTH>;
-    constexpr int WAVES = LT::WAVES, NR = LT::NR;
+    using LT = Lds4<NTH, NB>;
+    constexpr int WAVES = LT::WAVES, NR = LT::NR, PAIRS = LT::PAIRS;
+    static_assert(NB <= WAVES && NB <= 4, "one planning wavefront per block of 64 pairs");
     __shared__ LT L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
-    const int64_t p0 = (int64_t)blockIdx.x * S4_PAIRS;
-    const int np = (int)(A.bs - p0 < S4_PAIRS ? A.bs - p0 : S4_PAIRS);
+    const int64_t p0 = (int64_t)blockIdx.x * PAIRS;
+    const int np = (int)(A.bs - p0 < PAIRS ? A.bs - p0 : PAIRS);
 #ifdef S4_STAMPS
     uint64_t st_t[16] = {0};
     S4_STAMP(0);
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
 
     // ---- the endpoints' mini filters: one 16-byte piece per thread and trip (id -> piece: two dependent reads, beside
     //      the plan's id -> node record)
-    constexpr int FP = S4_PAIRS * 2 * (MINI_WORDS / 4), FL = (FP + NTH - 1) / NTH;
+    constexpr int FP = PAIRS * 2 * (MINI_WORDS / 4), FL = (FP + NTH - 1) / NTH;
     uint4 fr[FL];
 #pragma unroll
     for (int f = 0; f < FL; ++f) {
@@ -112,14 +121,14 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
                 fr[f] = reinterpret_cast<const uint4 *>(A.mini + id * MINI_WORDS)[i & (MINI_WORDS / 4 - 1)];
         }
     }
-    // ---- plan (wavefront 0, lane = pair)
-    int64_t base_reg = 0;
-    if (wave == 0) {
+    // ---- plan (wavefront q < NB: block q of 64 pairs, lane = pair)
+    if (wave < NB) {
+        const int j = S4_PAIRS * wave + lane;
         PairDesc3 d;
         __builtin_memset(&d, 0, sizeof(d));
         int ub = 0;
-        if (lane < np) {
-            const int64_t a = A.batch[p0 + lane], b = A.batch[A.batch_ld + p0 + lane];
+        if (j < np) {
+            const int64_t a = A.batch[p0 + j], b = A.batch[A.batch_ld + p0 + j];
             if ((uint64_t)a >= (uint64_t)A.n_nodes || (uint64_t)b >= (uint64_t)A.n_nodes) {
                 atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ERR), (unsigned long long)LPF_SELECT_ERR_NODE_RANGE);
             } else {
@@ -136,18 +145,11 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
             const int y = __shfl_up(x, dlt, 64);
             if (lane >= dlt) x += y;
         }
-        const int S = __shfl(x, 63, 64);
-        L.dsc[lane] = d;
-        L.loc[lane] = x - ub;
-        *reinterpret_cast<int4 *>(L.pcnt[lane]) = make_int4(0, 0, 0, 0);
-        if (lane == 0) {
-            L.loc[S4_PAIRS] = S;
-            L.S = S;
-            L.run = 0;
-            // the block's place: its slot count bounds what it keeps (rounded to whole 128-byte lines)
-            base_reg = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ALLOC),
-                                          (unsigned long long)((S + 7) & ~7));
-        }
+        L.dsc[j] = d;
+        L.loc[j] = x - ub;
+        *reinterpret_cast<int4 *>(L.pcnt[j]) = make_int4(0, 0, 0, 0);
+        if (lane == 63) L.sub[wave] = x;
+        if (tid == 0) L.run = 0;
     }
 #pragma unroll
     for (int f = 0; f < FL; ++f) {
@@ -157,8 +159,22 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
     S4_STAMP(1);    // plan issued (wavefront 0: ids -> node records -> descriptors; the others: ids -> filter pieces)
     s4_lds_barrier();
     S4_STAMP(2);    // plan barrier
-    const int S = L.S;
-    const int myloc = L.loc[lane < S4_PAIRS ? lane : S4_PAIRS];   // (S4_PAIRS == 64: lane j holds the start of pair j)
+    // the blocks' slots one after the other: lane j holds the first slot of pair j of every block
+    int off[NB], myloc[NB], S = 0;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        off[q] = S;
+        myloc[q] = L.loc[S4_PAIRS * q + lane] + S;
+        S += L.sub[q];
+    }
+    // the workgroup's place in the entry buffer: its slot count bounds what it keeps (rounded to whole 128-byte lines);
+    // requested now, needed when the first entries are written
+    const int shard = (int)(blockIdx.x % S4_SHARDS);
+    const int64_t shard_cap = (A.ent_cap / S4_SHARDS) & ~7ll;
+    int64_t base_reg = 0;
+    if (tid == 0)
+        base_reg = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ALLOC + shard),
+                                      (unsigned long long)((S + 7) & ~7));
     volatile int32_t *const sfw = &L.sflag[wave][0][0];
 
     for (int s0 = 0; s0 < S; s0 += NTH * S4_ROUNDS) {
@@ -182,13 +198,19 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
                 // ballot over the pairs, those inside the round by flags scattered to the slots they start in
                 volatile int32_t *sf = sfw + 64 * r;
                 sf[lane] = 0;
-                const int before = __popcll(__ballot(myloc <= r0));
-                if (myloc > r0 && myloc < r0 + 64) sf[myloc - r0] = 1;
+                int before = 0;
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    before += __popcll(__ballot(myloc[q] <= r0));
+                    if (myloc[q] > r0 && myloc[q] < r0 + 64) sf[myloc[q] - r0] = 1;
+                }
                 const uint64_t starts = __ballot(sf[lane] != 0);
                 if (l < S) {
                     const int w = before - 1 + __popcll(starts & le_mask);
                     const PairDesc3 &d = L.dsc[w];
-                    const int i = l - L.loc[w];
+                    int i = l - L.loc[w];
+#pragma unroll
+                    for (int q = 1; q < NB; ++q) i -= (w >> 6) == q ? off[q] : 0;
                     win[r] = w;
                     first[r] = i == 0;
                     if (i < d.total) {
@@ -211,8 +233,16 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
                               mini_pass(reinterpret_cast<const uint32_t *>(&L.flt[win[r]][(kindr[r] & KF_SRC_A) ? 1 : 0][0]), cvr[r].x);
             const uint32_t b = look ? bucket_of(cvr[r].x, unbr[r]) : 0u;
             const int4 *blk = reinterpret_cast<const int4 *>(A.u_cv + (look ? u0r[r] + BUCKET * (int64_t)b : 0));
+#if defined(S4_ABL_ONEPIECE)   // (timing only, wrong results: one 16-byte piece of the bucket instead of four)
+#pragma unroll
+            for (int q = 0; q < BUCKET / 2; ++q) bv[r][q] = (look && q == 0) ? blk[q] : make_int4(-1, 0, -1, 0);
+#elif defined(S4_ABL_NOBUCKET)
+#pragma unroll
+            for (int q = 0; q < BUCKET / 2; ++q) bv[r][q] = make_int4(-1, (int)b, -1, 0);
+#else
 #pragma unroll
             for (int q = 0; q < BUCKET / 2; ++q) bv[r][q] = look ? blk[q] : make_int4(-1, 0, -1, 0);
+#endif
         }
         if (s0 == 0) S4_STAMP_WAIT(4);    // buckets arrived
         uint64_t keptb[S4_ROUNDS];
@@ -248,8 +278,8 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
             if (lane < NR) L.rcnt[lane] = run + x - v;
             if (lane == NR - 1) L.run = run + x;
             if (lane == 0 && s0 == 0) {
-                L.base = base_reg;
-                L.ovf = base_reg + ((S + 7) & ~7) > A.ent_cap ? 1 : 0;
+                L.base = (int64_t)shard * shard_cap + base_reg;
+                L.ovf = base_reg + ((S + 7) & ~7) > shard_cap ? 1 : 0;
             }
         }
         s4_lds_barrier();
@@ -272,14 +302,19 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
     s4_lds_barrier();
     S4_STAMP(9);
     const bool ovf = S > 0 && L.ovf != 0;
-    if (wave == 0) {    // (S4_PAIRS == 64: lane = pair)
-        const int4 cc = *reinterpret_cast<const int4 *>(L.pcnt[lane]);
-        const int ne = __popcll(__ballot(lane < np && !ovf && cc.x + cc.y + cc.z > 0));
-        if (lane == 0) reinterpret_cast<int2 *>(A.blk_cnt)[blockIdx.x] = make_int2(ovf ? 0 : L.run, ne);
+    if (wave < NB) {    // block q's {entries, pairs with entries}: lane = pair
+        const int j = S4_PAIRS * wave + lane;
+        const int4 cc = *reinterpret_cast<const int4 *>(L.pcnt[j]);
+        int kept = (j < np && !ovf) ? cc.x + cc.y + cc.z : 0;
+        const int ne = __popcll(__ballot(kept > 0));
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) kept += __shfl_xor(kept, dlt, 64);
+        const int64_t blk = (int64_t)blockIdx.x * NB + wave;
+        if (lane == 0 && blk * S4_PAIRS < A.bs) reinterpret_cast<int2 *>(A.blk_cnt)[blk] = make_int2(kept, ne);
     }
     if (tid < np) {
         const int4 c = *reinterpret_cast<const int4 *>(L.pcnt[tid]);
-        // (a block that does not fit leaves empty pairs -- nothing is read past the buffer -- and raises the sticky bit:
+        // (a workgroup that does not fit leaves empty pairs -- nothing is read past the buffer -- and raises the sticky bit:
         //  the scores of the batch come out as NaN and the caller sizes the workspace again)
         A.pair_tab[p0 + tid] = ovf ? make_int4(0, 0, 0, 0) : make_int4((int32_t)(L.base + c.w), c.x, c.y, c.z);
     }
@@ -288,9 +323,13 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
         // the last workgroup leaves the counters as the next launch on this control block wants them (stream order)
         const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + CTL_DONE), 1ull);
         if (done == (unsigned long long)gridDim.x - 1ull) {
-            const unsigned long long total = atomicExch(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ALLOC), 0ull);
+            unsigned long long most = 0ull;
+            for (int sh = 0; sh < S4_SHARDS; ++sh) {
+                const unsigned long long v = atomicExch(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ALLOC + sh), 0ull);
+                most = v > most ? v : most;
+            }
             atomicExch(reinterpret_cast<unsigned long long *>(A.ctl + CTL_DONE), 0ull);
-            A.ctl[0] = (int64_t)total;   // entries the batch needs room for (what ent_cap is sized from)
+            A.ctl[0] = (int64_t)(most * S4_SHARDS);   // entries the batch needs room for (what ent_cap is sized from)
         }
     }
 #ifdef S4_STAMPS
@@ -333,8 +372,14 @@ extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, i
     a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
     const int64_t nb = (bs + S4_PAIRS - 1) / S4_PAIRS;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (threads == 512) hipLaunchKernelGGL(select4_kernel<512>, dim3((unsigned)nb), dim3(512), 0, s, a);
-    else if (threads == 0 || threads == 1024) hipLaunchKernelGGL(select4_kernel<1024>, dim3((unsigned)nb), dim3(1024), 0, s, a);
+    // threads = workgroup size + 4096 * (blocks of 64 pairs per workgroup - 1); 0: the default
+    const int nth = threads & 4095, per = threads / 4096 + 1;
+    const dim3 grid((unsigned)((nb + per - 1) / per));
+    if (threads == 0 || (nth == 1024 && per == 2)) hipLaunchKernelGGL((select4_kernel<1024, 2>), dim3((unsigned)((nb + 1) / 2)), dim3(1024), 0, s, a);
+    else if (nth == 1024 && per == 1) hipLaunchKernelGGL((select4_kernel<1024, 1>), grid, dim3(1024), 0, s, a);
+    else if (nth == 1024 && per == 4) hipLaunchKernelGGL((select4_kernel<1024, 4>), grid, dim3(1024), 0, s, a);
+    else if (nth == 512 && per == 1) hipLaunchKernelGGL((select4_kernel<512, 1>), grid, dim3(512), 0, s, a);
+    else if (nth == 512 && per == 2) hipLaunchKernelGGL((select4_kernel<512, 2>), grid, dim3(512), 0, s, a);
     else return LPF_ERR_INVALID;
     LPF_CHECK_LAUNCH();
     return LPF_OK;

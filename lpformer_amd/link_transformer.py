@@ -486,7 +486,7 @@ class _Select4Workspace:
 
     def __init__(self, device, bs: int):
         self.device, self.bs = device, bs
-        self.ctl = torch.zeros(16, dtype=torch.int64, device=device)  # LPF_SELECT_CTL_WORDS
+        self.ctl = torch.zeros(32, dtype=torch.int64, device=device)  # LPF_SELECT4_CTL_WORDS
         self.pair_tab = torch.zeros(4 * max(bs, 1), dtype=torch.int32, device=device)
         self.blk_cnt = torch.zeros(2 * ((bs + _lib.SELECT4_BLOCK - 1) // _lib.SELECT4_BLOCK) + 2, dtype=torch.int32,
                                    device=device)   # {entries, pairs with entries} per block

@@ -35,6 +35,9 @@ def sel4_sets(model, batch, test_set=False, threads=0):
     for b in range((bs + 63) // 64):
         assert blk[b, 0] == cnt[64 * b: 64 * b + 64].sum() and blk[b, 1] == (cnt[64 * b: 64 * b + 64] > 0).sum()
     assert (tab[:, 0] >= 0).all() and (tab[:, 0] + cnt <= ws.ent_cap).all()
+    order = np.argsort(tab[:, 0], kind="stable")     # no two pairs' entries overlap
+    nz = order[cnt[order] > 0]
+    assert (tab[nz[1:], 0] >= tab[nz[:-1], 0] + cnt[nz[:-1]]).all()
     idx = np.concatenate([np.arange(s, s + c) for s, c in zip(tab[:, 0], cnt)]) if cnt.sum() else np.zeros(0, np.int64)
     rec = ent[idx]
     word = rec[:, 0].view(np.uint32) if rec.size else np.zeros(0, np.uint32)
@@ -62,8 +65,12 @@ def _assert_sets_equal(got, want, tags):
             assert got[tag][0].shape[1] == 0
 
 
+# launch shapes: workgroup size + 4096 * (blocks of 64 pairs per workgroup - 1); 0 = the default (1,024 threads, 2 blocks)
+SHAPES = [0, 1024, 512, 4096 + 512, 3 * 4096 + 1024]
+
+
 @pytest.mark.parametrize("case", LP_CASES)
-@pytest.mark.parametrize("threads", [1024, 512])
+@pytest.mark.parametrize("threads", SHAPES)
 def test_select4_bit_exact_vs_reference_fixtures(case, threads):
     fx = Fixture(case)
     model, _ = _build(fx)
@@ -123,7 +130,7 @@ def test_select4_matches_oracle_and_the_type_major_path(case):
     # the oracle's sets (CPU restatement of the reference) ...
     ref = O.select_nodes(batch, O.symmetric_mask_csr(ei, n), (ppr.rowptr, ppr.col.astype(np.int64), ppr.val),
                          (cfg["thresh_cn"], cfg["thresh_1hop"], cfg["thresh_non1hop"]), n=n)
-    for threads in (1024, 512):
+    for threads in SHAPES:
         got, ws = sel4_sets(model, bt, threads=threads)
         _assert_sets_equal(got, ref, tags)
     # ... and the two-launch type-major path (select3.hip + lpf_select_export) say the same
