@@ -71,7 +71,7 @@ from lpformer_amd import data as D  # noqa: E402
 from lpformer_amd import dist as LD  # noqa: E402
 from lpformer_amd.profile import KernelTimer  # noqa: E402
 
-PMC_FILE = "r05_pmc_traffic.json"  # committed rocprofv3 PMC passes the `traffic` figures are read from
+PMC_FILE = "r05_pmc_traffic_{config}.json"  # committed rocprofv3 PMC passes (one file per config) `traffic` is read from
 # timing span (KernelTimer) -> the HIP kernel that runs under it (what `roofline.kernel` names)
 KERNEL_NAMES = {"pair_attention_rows": "pair_rows_kernel", "pair_attention_fused": "pair_flip_kernel / pair_fused_kernel",
                 "tail_chain": "tail_chain_kernel", "select_run": "select_run", "select_plan": "select3_plan_kernel",
@@ -289,6 +289,9 @@ def main():
                          "streams); plan: every stream replays the RECORDED C-ABI launches of the step, one plain launch "
                          "after the other (lpformer_amd.PlannedScorer; 0.04 ms of host time, the overlap of eager "
                          "launches).  The same launches and bitwise the same scores in all three")
+    ap.add_argument("--tail", default="f32", choices=("split", "f32"),
+                    help="the dense tail's two GEMMs in the fp32 parity mode: fp32 MFMAs (default) or split-bf16 products "
+                         "on the bf16 matrix cores (within 2e-5 of fp32; measured 6 %% slower per pipelined step)")
     ap.add_argument("--select-grid", type=int, default=0,
                     help="(tuning) workgroups of the selection's run kernel; 0 = as many as are resident at once")
     ap.add_argument("--streams", type=int, default=8,
@@ -320,6 +323,7 @@ def main():
     model.use_side_stream = side == "on" or (side == "auto" and args.streams <= 1)
     model.attention_impl = args.attention
     model.select_grid = args.select_grid
+    model.tail_split = args.tail == "split"
     enc_plan = None
     if world > 1:
         # encoder layout: measure the whole encoder on one GPU (replicated mode) and the all-gather of an [N, D] fp32
@@ -386,6 +390,8 @@ def main():
     def record_plans():
         """One recorded step per stream (None when the step cannot be recorded on some rank: all ranks agree)."""
         try:
+            if os.environ.get("LPF_BENCH_FAIL_CAPTURE_RANK") == str(rank):   # (test switch: tests/test_gpu_dist.py)
+                raise RuntimeError("capture failure injected on this rank")
             got = [lpformer_amd.PlannedScorer(model, score, h, batches[k % len(batches)], adopt_input=True)
                    for k in range(len(lanes))]
         except RuntimeError as exc:   # (a step that does work outside the C-ABI launches cannot be recorded)
@@ -452,6 +458,8 @@ def main():
         try:
             # (a scorer whose stream always sees the same batch adopts it as its static input: no copy per replay)
             fixed = len(lanes) % len(batches) == 0
+            if os.environ.get("LPF_BENCH_FAIL_CAPTURE_RANK") == str(rank):   # (test switch)
+                raise RuntimeError("capture failure injected on this rank")
             scorers = [lpformer_amd.GraphedScorer(model, score, h, batches[k % len(batches)], adopt_input=fixed)
                        for k in range(len(lanes))]
         except RuntimeError as exc:   # a capture that fails leaves the eager path, which is the same work
@@ -826,13 +834,17 @@ def main():
             # HBM traffic per launch: NOT measured in this run -- read from the committed rocprofv3 PMC passes
             # (FETCH_SIZE / WRITE_SIZE, gfx950-corrected; tools/collect_profiles.sh) and tagged with that file
             try:
-                if args.config != "collab" or world > 1:
-                    raise KeyError("the committed PMC passes were collected on the collab-like workload, one GPU")
-                pmc_file = os.path.join("profiles", PMC_FILE)
+                if world > 1:
+                    raise KeyError("the committed PMC passes were collected on one GPU")
+                pmc_file = os.path.join("profiles", PMC_FILE.format(config=args.config))
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
                 rows_form = model._uses_rows()
                 for name, r in rooflines.items():
                     key = {"tail_chain": "tail_chain_rows"}.get(name, name) if rows_form else name
+                    if name == "select_run":
+                        key = "select4" if four else "select3_run"
+                    if name == "pair_attention_fused" and model.attention_kernel() != "flip":
+                        key = "pair_attention_fused_mfma"
                     if key in pmc["kernels"]:
                         r["traffic"] = pmc["kernels"][key]["hbm_bytes_per_launch_corrected"]
                         r["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes at {pmc.get('commit', '?')})"
@@ -883,9 +895,9 @@ def main():
                                 "achieved_compulsory_floor": round(ach_floor, 1),
                                 "frac_compulsory_floor": round(ach_floor / HBM_PEAK_GBS, 4)}
             try:
-                pmc_file = os.path.join("profiles", PMC_FILE)
+                pmc_file = os.path.join("profiles", PMC_FILE.format(config=args.config))
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
-                if args.config == "collab" and world == 1 and ename in pmc["kernels"]:
+                if world == 1 and ename in pmc["kernels"]:
                     rooflines[ename]["traffic"] = pmc["kernels"][ename]["hbm_bytes_per_launch_corrected"] + (
                         pmc["kernels"].get("spmm_row_parts", {}).get("hbm_bytes_per_launch_corrected", 0)
                         if ename == "gcn_layer_fused" else 0)

@@ -541,6 +541,19 @@ int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const int32_t *typ
                                        const float *ln_g, const float *ln_b, int32_t n_counts, const int64_t *sel_ctl,
                                        float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
                                        uint64_t *perm_lb, int64_t *n_nonempty, void *stream);
+/* lpf_tail_chain_rows_f32 / lpf_tail_chain_rows_perm_f32 with the two GEMMs on the bf16 matrix cores at fp32 accuracy
+ * (other_models.py:80-179, link_transformer.py:170-177 as above): wB / wC are SPLIT images of the same packed weights
+ * -- per packed element four hi = bf16(w) followed by four lo = bf16(w - hi), 16 bytes like an fp32 element
+ * (lpformer_amd/fold.py split_bf16_planes) --, the activations are split the same way in registers, a product is three
+ * v_mfma_f32_16x16x16_bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate).  Dropped: lo*lo and the rounding of the lo planes,
+ * <= 3 * 2^-18 |w| |x| per term; logits within ~1e-5 of the fp32 launch.  perm / n_full / bC_empty: all three (the
+ * order lpf_pair_attention_rows*_ left) or all NULL. */
+int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                              const void *wB_split, const float *bB, const float *lnB_g, const float *lnB_b,
+                              const float *r_e, int64_t ldre, const void *wC_split, const float *bC, const float *w_dot,
+                              const float *b_dot, const int64_t *sel_ctl, const int32_t *perm, const int64_t *n_full,
+                              const float *bC_empty, float *logit, float *prob, void *stream);
+
 /* lpf_pair_attention_rows_perm_* behind lpf_select4: the entries are pair-major already (a pair's entries contiguous from
  * pair_tab[p][0], the type in bits 29-30 of the record's pair word), so the kernel reads ONE region and needs no per-type
  * pointers; its workgroups split the batch by blk_cnt (entries per LPF_SELECT4_BLOCK pairs) and the 64 table entries of the

@@ -117,6 +117,40 @@ __device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint2 *lw, cons
     }
 }
 
+// SPLIT variant: fp32 results from the bf16 matrix cores.  Every weight travels as two bf16 planes (hi = bf16(w), lo =
+// bf16(w - hi), split on the host: the weights are constants; one uint4 = four hi + four lo, the 16 bytes an fp32 element
+// takes), every activation is split the same way in registers, and a product is three v_mfma_f32_16x16x16_bf16 --
+// hi*hi + lo*hi + hi*lo, fp32 accumulate -- instead of four fp32 MFMAs: what is dropped is lo*lo and the rounding of the
+// two lo planes, <= 3 * 2^-18 |w| |x| per term (a bf16 product is exact in fp32).  24 matrix-pipe cycles per k-group and
+// tile instead of 128.
+template <int TPW>
+__device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint4 *lw, const f32x4 bv, bool last = true) {
+    bf16x4_bits bh, bl;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint16_t h = lpf_f32_to_bf16(bv[u]);
+        bh[u] = (short)h;
+        bl[u] = (short)lpf_f32_to_bf16(bv[u] - lpf_bf16_to_f32(h));
+    }
+    bf16x4_bits ah[TPW], al[TPW];
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const uint4 w = lw[c * 64];
+        ah[c] = (bf16x4_bits){(short)(w.x & 0xffffu), (short)(w.x >> 16), (short)(w.y & 0xffffu), (short)(w.y >> 16)};
+        al[c] = (bf16x4_bits){(short)(w.z & 0xffffu), (short)(w.z >> 16), (short)(w.w & 0xffffu), (short)(w.w >> 16)};
+    }
+    const int n = last ? TPW : TPW - 1;   // consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int c = 0; c < TPW; ++c)
+        if (c < n) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[c], bh, acc[c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < TPW; ++c)
+        if (c < n) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[c], bh, acc[c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < TPW; ++c)
+        if (c < n) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[c], bl, acc[c], 0, 0, 0);
+}
+
 __device__ __forceinline__ float tc_quad_sum(float v) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -174,10 +208,14 @@ struct TcShape {
 
 // (D = 256: 32 output tiles of the score head -- 16 accumulators per lane in stage C alone --, one workgroup per CU with
 //  twice the registers)
-template <int NTA, int NTB, int NTC, bool WB = false, bool ROWS = false>
+// WM: how the two GEMMs run -- 0 fp32 weights and MFMAs, 1 bf16 weights and activations (throughput mode), 2 fp32 from
+// split bf16 planes (rows mode)
+template <int NTA, int NTB, int NTC, int WM = 0, bool ROWS = false>
 __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 : 3)) void tail_chain_kernel(const TailArgs A) {
     using S = TcShape<NTA, NTB, NTC>;
-    using WT = typename std::conditional<WB, uint2, f32x4>::type;  // weight element (WB: bf16 weights, merge mode only)
+    constexpr bool WB = WM != 0;
+    // weight element: four fp32, four bf16, or four hi + four lo bf16
+    using WT = typename std::conditional<WM == 1, uint2, typename std::conditional<WM == 2, uint4, f32x4>::type>::type;
     constexpr int NTPA = S::NTPA, NTPB = S::NTPB, NTPC = S::NTPC;
     constexpr int TPWA = NTPA / 2, TPWB = NTPB / 2, TPWC = NTPC / 2;
     constexpr int NGE = NTA;  // k-groups of r_e
@@ -481,10 +519,10 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
     }
 }
 
-template <int NTA, int NTB, int NTC, bool WB = false, bool ROWS = false>
+template <int NTA, int NTB, int NTC, int WM = 0, bool ROWS = false>
 int tc_launch(const TailArgs &a, hipStream_t s) {
     constexpr size_t lds = TcShape<NTA, NTB, NTC>::BYTES;
-    auto kern = tail_chain_kernel<NTA, NTB, NTC, WB, ROWS>;
+    auto kern = tail_chain_kernel<NTA, NTB, NTC, WM, ROWS>;
     LPF_SET_MAX_LDS(kern, lds);  // (per instantiation and device; the attribute is sticky)
     const int64_t blocks = (a.M + 16 * TC_GROUPS - 1) / (16 * TC_GROUPS);
     if (blocks > 0x7fffffff) return LPF_ERR_UNSUPPORTED;
@@ -568,9 +606,9 @@ extern "C" int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts,
                part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
-        case 32: return tc_launch<2, 3, 4, true>(a, s);
-        case 64: return tc_launch<4, 5, 8, true>(a, s);
-        case 128: return tc_launch<8, 9, 16, true>(a, s);
+        case 32: return tc_launch<2, 3, 4, 1>(a, s);
+        case 64: return tc_launch<4, 5, 8, 1>(a, s);
+        case 128: return tc_launch<8, 9, 16, 1>(a, s);
         default: return LPF_ERR_UNSUPPORTED;
     }
 }
@@ -578,7 +616,7 @@ extern "C" int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts,
 // Rows mode: stage A was done by lpf_pair_attention_rows_* (one finished row per pair: post_att_norm(attention output)
 // followed by the count features, zero padded to 4); the tail is the two GEMMs, their LayerNorm and the score.
 namespace {
-template <bool WB>
+template <int WM>
 int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows, const void *wB, const float *bB,
             const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre, const void *wC, const float *bC,
             const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob, void *stream,
@@ -595,10 +633,10 @@ int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t l
                nullptr, nullptr, 0, nullptr, nullptr, sel_ctl, n_counts, rows, ldrows, perm, n_full, bC_empty};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
-        case 32: return tc_launch<2, 3, 4, WB, true>(a, s);
-        case 64: return tc_launch<4, 5, 8, WB, true>(a, s);
-        case 128: return tc_launch<8, 9, 16, WB, true>(a, s);
-        case 256: return tc_launch<16, 17, 32, WB, true>(a, s);
+        case 32: return tc_launch<2, 3, 4, WM, true>(a, s);
+        case 64: return tc_launch<4, 5, 8, WM, true>(a, s);
+        case 128: return tc_launch<8, 9, 16, WM, true>(a, s);
+        case 256: return tc_launch<16, 17, 32, WM, true>(a, s);
         default: return LPF_ERR_UNSUPPORTED;
     }
 }
@@ -609,7 +647,7 @@ extern "C" int lpf_tail_chain_rows_f32(int64_t M, int32_t D, int32_t n_counts, c
                                        const float *r_e, int64_t ldre, const float *wC_packed, const float *bC,
                                        const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit,
                                        float *prob, void *stream) {
-    return tc_rows<false>(M, D, n_counts, rows, ldrows, wB_packed, bB, lnB_g, lnB_b, r_e, ldre, wC_packed, bC, w_dot, b_dot,
+    return tc_rows<0>(M, D, n_counts, rows, ldrows, wB_packed, bB, lnB_g, lnB_b, r_e, ldre, wC_packed, bC, w_dot, b_dot,
                           sel_ctl, logit, prob, stream);
 }
 
@@ -618,7 +656,7 @@ extern "C" int lpf_tail_chain_rows_bf16(int64_t M, int32_t D, int32_t n_counts, 
                                         const float *r_e, int64_t ldre, const void *wC_packed_bf16, const float *bC,
                                         const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit,
                                         float *prob, void *stream) {
-    return tc_rows<true>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
+    return tc_rows<1>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
                          b_dot, sel_ctl, logit, prob, stream);
 }
 
@@ -633,7 +671,7 @@ extern "C" int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_coun
                                             const int64_t *sel_ctl, const int32_t *perm, const int64_t *n_full,
                                             const float *bC_empty, float *logit, float *prob, void *stream) {
     LPF_REQUIRE(perm && n_full && bC_empty);
-    return tc_rows<false>(M, D, n_counts, rows, ldrows, wB_packed, bB, lnB_g, lnB_b, r_e, ldre, wC_packed, bC, w_dot, b_dot,
+    return tc_rows<0>(M, D, n_counts, rows, ldrows, wB_packed, bB, lnB_g, lnB_b, r_e, ldre, wC_packed, bC, w_dot, b_dot,
                           sel_ctl, logit, prob, stream, perm, n_full, bC_empty);
 }
 
@@ -645,6 +683,21 @@ extern "C" int lpf_tail_chain_rows_perm_bf16(int64_t M, int32_t D, int32_t n_cou
                                              const int64_t *n_full, const float *bC_empty, float *logit, float *prob,
                                              void *stream) {
     LPF_REQUIRE(perm && n_full && bC_empty);
-    return tc_rows<true>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
+    return tc_rows<1>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
                          b_dot, sel_ctl, logit, prob, stream, perm, n_full, bC_empty);
+}
+
+/* lpf_tail_chain_rows_f32 / _perm_f32 with the two GEMMs on the bf16 matrix cores at fp32 accuracy: wB / wC as SPLIT images
+ * (lpformer_amd/fold.py split_bf16_planes: per packed element four hi = bf16(w) then four lo = bf16(w - hi), 16 bytes), the
+ * activations split in registers, three MFMAs per product (hi*hi + lo*hi + hi*lo).  Logits within ~1e-5 of the fp32
+ * launch (the parity mode of the scoring path); perm / n_full / bC_empty: all three or all NULL. */
+extern "C" int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                                         const void *wB_split, const float *bB, const float *lnB_g, const float *lnB_b,
+                                         const float *r_e, int64_t ldre, const void *wC_split, const float *bC,
+                                         const float *w_dot, const float *b_dot, const int64_t *sel_ctl,
+                                         const int32_t *perm, const int64_t *n_full, const float *bC_empty, float *logit,
+                                         float *prob, void *stream) {
+    LPF_REQUIRE((perm != nullptr) == (n_full != nullptr) && (perm != nullptr) == (bC_empty != nullptr));
+    return tc_rows<2>(M, D, n_counts, rows, ldrows, wB_split, bB, lnB_g, lnB_b, r_e, ldre, wC_split, bC, w_dot, b_dot,
+                      sel_ctl, logit, prob, stream, perm, n_full, bC_empty);
 }

@@ -646,6 +646,12 @@ class LinkTransformer(nn.Module):
         # on the bf16 matrix cores with bf16 weights and activations rounded to bf16 (fp32 accumulate; record merge,
         # LayerNorms, dot product and sigmoid stay fp32); logits within 5e-3 of fp32 (observed <= 1e-3).
         self.tail_precision = "f32"
+        # tail_precision "f32", rows form: the tail's two GEMMs as split-bf16 products on the bf16 matrix cores (weights as
+        # hi | lo planes, three MFMAs per product, fp32 accumulate: within 2e-5 of the fp32 MFMA result at a fifth of its
+        # matrix-pipe time).  Off: measured, the launch does not get shorter (57 us against 55: with the matrix time
+        # gone the one-k-group-ahead weight stream is what a workgroup waits for) and the pipelined step gets 6 % LONGER
+        # (0.173-0.176 against 0.163-0.167 ms: splitting the activations is vector work beside a vector-bound attention)
+        self.tail_split = False
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self, train_ok: bool = False):
@@ -1626,6 +1632,8 @@ class LinkTransformer(nn.Module):
         # bf16 images of the two GEMM weights (same element order: a lane's four fp32 become its four bf16)
         for k in ("wB", "wC"):
             dev[k + "_bf16"] = torch.from_numpy(fold.to_bf16_bits(tabs[k]).view(np.int16)).to(self.device)
+            # ... and the split images (hi | lo planes): fp32 accuracy from the bf16 matrix cores
+            dev[k + "_split"] = torch.from_numpy(fold.split_bf16_planes(tabs[k]).view(np.int16)).to(self.device)
         self._tail_cache = (key, dev)
         return dev
 
@@ -1700,12 +1708,17 @@ class LinkTransformer(nn.Module):
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):
                     b16 = self.tail_precision == "bf16"
-                    name = "lpf_tail_chain_rows" + ("_perm" if order else "") + ("_bf16" if b16 else "_f32")
                     extra = (ptr(order[0]), ptr(order[1]), ptr(tt["bC_empty"])) if order else ()
+                    if self.tail_precision == "f32" and self.tail_split:
+                        name, sfx = "lpf_tail_chain_rows_split", "_split"
+                        extra = extra or (None, None, None)
+                    else:
+                        name = "lpf_tail_chain_rows" + ("_perm" if order else "") + ("_bf16" if b16 else "_f32")
+                        sfx = "_bf16" if b16 else ""
                     check(getattr(lib, name)(
-                        bs, d, self.count_dim, ptr(rows), rows.stride(0), ptr(tt["wB_bf16" if b16 else "wB"]),
+                        bs, d, self.count_dim, ptr(rows), rows.stride(0), ptr(tt["wB" + sfx]),
                         ptr(tt["bB"]), ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(r), r.stride(0),
-                        ptr(tt["wC_bf16" if b16 else "wC"]), ptr(tt["bC"]), ptr(tt["w_dot"]), ptr(tt["b_dot"]),
+                        ptr(tt["wC" + sfx]), ptr(tt["bC"]), ptr(tt["w_dot"]), ptr(tt["b_dot"]),
                         ptr(ws.ctl), *extra, ptr(res) if logits else None, None if logits else ptr(res), st), name)
                 return res
             if d in (32, 64, 128) and self.use_tail_chain and self.use_fused_attention and bs > 0:

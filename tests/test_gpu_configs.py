@@ -760,3 +760,32 @@ def test_query_table_follows_an_in_place_update_of_lin_l(name, scale):
     got = plan(tb).clone()                      # re-records: a parameter's version changed
     torch.cuda.synchronize()
     assert torch.equal(got, after)
+
+
+@pytest.mark.parametrize("name,scale,dim", [("collab", 0.1, 128), ("cora", 1.0, 256), ("ppa", 0.02, 64), ("tiny", 1.0, 32)])
+def test_split_bf16_tail_keeps_fp32_accuracy(name, scale, dim):
+    """The dense tail's two GEMMs as split-bf16 products (``tail_split``, the default of the parity mode: weights as
+    hi | lo bf16 planes, three MFMAs per product) against the fp32-MFMA tail and the oracle: logits within 2e-5 of the
+    fp32 launch's and of the oracle's (stated bar 1e-4: five times the margin), with and without the tail's order."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale=scale, bs=3000)
+    if model.dim != dim:
+        args = dict(args, dim=dim)
+        torch.manual_seed(3)
+        model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
+        score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(DEV).eval()
+    model.attention_impl = "flip"           # the rows form at every D
+    tb = torch.from_numpy(batch).to(DEV)
+    h = model.propagate()
+    outs = {}
+    for split in (True, False):
+        for skip in (True, False):
+            model.tail_split, model.tail_skip_empty = split, skip
+            outs[split, skip] = model.score_pairs(tb, h, score, logits=True).clone()
+            assert model.check_selection()
+    scale_l = max(1.0, float(outs[False, True].abs().max()))
+    for skip in (True, False):
+        assert (outs[True, skip] - outs[False, skip]).abs().max().item() <= 2e-5 * scale_l
+    sample, ref = _oracle_sample(model, score, data, args, batch, h)
+    k = sample.shape[1]
+    err = np.abs(outs[True, True][:k].cpu().numpy() - ref["logit"]).max()
+    assert err <= 2e-5 * max(1.0, float(np.abs(ref["logit"]).max())), err

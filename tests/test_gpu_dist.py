@@ -53,3 +53,49 @@ def test_rccl_world_of_one():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout
     assert "rccl world-1 ok" in p.stdout, p.stdout
+
+
+def _bench(args, extra_env=None, timeout=900):
+    env = dict(os.environ, LPF_DIST_BACKEND="gloo", LPF_LOCAL_DEVICE="0")
+    env.pop("WORLD_SIZE", None)      # bench.py starts its own ranks
+    env.pop("RANK", None)
+    env.update(extra_env or {})
+    before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    after = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    left = [f for f in after - before if f.startswith("lpf_bench_setup")]
+    return p, left
+
+
+@pytest.mark.parametrize("encoder", ["replicated", "sharded", "gather_once"])
+def test_bench_dress_rehearsal_eight_ranks_on_one_gpu(encoder):
+    """``bench.py --gpus 8`` end to end on the box's ONE GPU (eight ranks under gloo, all on cuda:0): the self-launch, the
+    set-up shared through /dev/shm (and removed again), the encoder layout, the rank-agreed launch path, the max-over-ranks
+    timing and the one JSON line of rank 0 -- everything of an N = 8 run but the exchange over xGMI."""
+    import json
+    p, left = _bench(["--gpus", "8", "--config", "tiny", "--steps", "4", "--warmup", "2", "--repeats", "2", "--encoder",
+                      encoder, "--no-cpu-baseline", "--weights", "random", "--no-bf16", "--spinup", "0"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert "pairs sharded x8" in d["config"]["parallelism"] and encoder in d["config"]["parallelism"]
+    assert d["config"]["encoder_plan"]["chosen"] == encoder
+    assert not left, f"set-up files left in /dev/shm: {left}"
+
+
+def test_bench_capture_failure_on_one_rank_falls_back_everywhere():
+    """A recording / capture that fails on ONE rank (injected) must put ALL ranks on the eager path -- the probes run
+    barriers and reductions, a rank on another path would wait for ever -- and the run still ends with one JSON line."""
+    import json
+    p, left = _bench(["--gpus", "4", "--config", "tiny", "--steps", "4", "--warmup", "2", "--repeats", "2",
+                      "--no-cpu-baseline", "--weights", "random", "--no-bf16", "--spinup", "0"],
+                     {"LPF_BENCH_FAIL_CAPTURE_RANK": "2"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["launch"].startswith("eager"), d["config"]["launch"]
+    assert not left

@@ -10,11 +10,11 @@ import sys
 from collections import defaultdict
 
 SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
-    ("select3_run_kernel", "select_run"), ("select3_plan_kernel", "select_plan"),
+    ("select4_kernel", "select4"), ("select3_run_kernel", "select3_run"), ("select3_plan_kernel", "select_plan"),
     ("select_run_kernel", "select_run_general"), ("select_plan_kernel", "select_plan"), ("select_export", "select_export"),
     ("pair_flip_kernel", "pair_attention_fused"), ("pair_fused_kernel", "pair_attention_fused_mfma"),
     ("pair_rows_kernel", "pair_attention_rows"),
-    ("tail_chain_kernel<8, 9, 16, false, true>", "tail_chain_rows"), ("tail_chain_kernel", "tail_chain"),
+    ("tail_chain_kernel", "tail_chain"),   # (rows / merge form: told apart below by the last template argument)
     ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"),
     ("pair_scores_", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
     ("pair_softmax_gather_kernel", "pair_softmax_gather_light"),
@@ -35,6 +35,8 @@ def collect(d, counter):
                 continue
             for frag, short in SHORT:
                 if frag in r["Kernel_Name"]:
+                    if short == "tail_chain" and r["Kernel_Name"].rstrip().rstrip(")").split("(")[0].rstrip().endswith("true>"):
+                        short = "tail_chain_rows"
                     acc[short].append(float(r["Counter_Value"]))
                     break
     return {k: v[len(v) // 2:] for k, v in acc.items()}
@@ -42,7 +44,8 @@ def collect(d, counter):
 
 def main():
     fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on the collab-like bench "
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on the " +
+                   (sys.argv[5] if len(sys.argv) > 5 else "collab") + "-like bench "
                    "workload, serial single-stream steps; bytes = 2 x FETCH_SIZE_KB x 1024 (gfx950 correction, "
                    "MI355X_MICROARCH.md) + WRITE_SIZE_KB x 1024, mean per launch after warm-up",
            "commit": sys.argv[4] if len(sys.argv) > 4 else "?", "kernels": {}}

@@ -55,6 +55,12 @@ for i, b in enumerate(batches):
         print("   median ones:")
         for j in order[len(order) // 2 - 3: len(order) // 2 + 3]:
             print(f"     {j:4d} {beg[j]:6.1f} {end[j]:6.1f} {tickets[j]:4.0f} {wg[j, :, 6].max():3.0f} {pairs[j]:5d} {multi[j]:4d}")
+        j = order[-1]
+        print("   slowest workgroup, per wavefront (units start, units end, rounds):",
+              " ".join(f"{(wg[j, w, 3] - t0) / 100:.0f}-{(wg[j, w, 4] - t0) / 100:.0f}/{wg[j, w, 6]:.0f}" for w in range(nw)))
+        j = order[len(order) // 2]
+        print("   a median workgroup:", " ".join(f"{(wg[j, w, 3] - t0) / 100:.0f}-{(wg[j, w, 4] - t0) / 100:.0f}/{wg[j, w, 6]:.0f}" for w in range(nw)))
+        print("   workgroup end times, top 20:", " ".join(f"{e:.0f}" for e in np.sort(end)[-20:]))
         print(f"   corr(end, tickets) {np.corrcoef(end, tickets)[0, 1]:.2f}  corr(end, pairs) {np.corrcoef(end, pairs)[0, 1]:.2f}  tickets p10 {np.percentile(tickets, 10):.0f} p50 {np.percentile(tickets, 50):.0f} p90 {np.percentile(tickets, 90):.0f} max {tickets.max():.0f}")
     r = v[:, 6]
     heavy = (v[:, 7].astype(np.int64) >> 32)
