@@ -348,12 +348,15 @@ def main():
         # (a fused layer -- one launch, csrc/gcn_fused.hip -- is row-sharded whole)
         last_key = "gcn_layer_fused" if "gcn_layer_fused" in kt0 else "spmm_csr"
         last_agg = LD.max_over_ranks(kt0[last_key][2] if last_key in kt0 else enc1 / cfg["gnn_layers"], dev)
-        keys_ms = LD.max_over_ranks(sum(kt0[k][1] for k in ("gemm_node_keys", "gemm_node_query") if k in kt0), dev)
+        # Z is row-shardable in gather_once; the query table Y is computed in full by every rank in every layout
+        keys_ms = LD.max_over_ranks(kt0["gemm_node_keys"][1] if "gemm_node_keys" in kt0 else 0.0, dev)
+        y_ms = LD.max_over_ranks(kt0["gemm_node_query"][1] if "gemm_node_query" in kt0 else 0.0, dev)
         del hh
         ag = LD.measure_allgather_gbps(n, d, dev)
         enc_plan = LD.encoder_plan(enc1, n, d, cfg["gnn_layers"], world, ag, last_agg_ms=last_agg,
-                                   node_keys_ms=keys_ms)
-        enc_plan.update(allgather_gbps=round(ag, 1), last_agg_ms=round(last_agg, 4), node_keys_ms=round(keys_ms, 4))
+                                   node_keys_ms=keys_ms, replicated_ms=y_ms)
+        enc_plan.update(allgather_gbps=round(ag, 1), last_agg_ms=round(last_agg, 4), node_keys_ms=round(keys_ms, 4),
+                        node_query_ms=round(y_ms, 4))
         enc_plan["chosen"] = enc_plan["mode"] if args.encoder == "auto" else args.encoder
         model.set_row_shard(rank, world, enc_plan["chosen"])
 

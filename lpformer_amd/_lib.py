@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "liblpformer_hip.so")
@@ -127,6 +128,11 @@ class LpfError(RuntimeError):
 _hip = None
 _host = None
 _recorder = None   # set by `recording(...)`: the launches, pointers and stream hand-overs of the calls made meanwhile
+_recorder_thread = None   # ... by THIS thread only: a concurrent sweep or PPR producer on another thread is not captured
+
+
+def _recording():
+    return _recorder if (_recorder is not None and _recorder_thread == threading.get_ident()) else None
 
 
 class recording:
@@ -139,15 +145,15 @@ class recording:
         self.rec = rec
 
     def __enter__(self):
-        global _recorder
+        global _recorder, _recorder_thread
         if _recorder is not None:
             raise LpfError("a recording is already in progress")
-        _recorder = self.rec
+        _recorder, _recorder_thread = self.rec, threading.get_ident()
         return self.rec
 
     def __exit__(self, *exc):
-        global _recorder
-        _recorder = None
+        global _recorder, _recorder_thread
+        _recorder = _recorder_thread = None
         return False
 
 
@@ -179,7 +185,8 @@ def hip():
         if lib.lpf_abi_version() != ABI_VERSION:
             raise LpfError("liblpformer_hip.so ABI version mismatch; rebuild")
         _hip = lib
-    return _hip if _recorder is None else _RecordingLib(_hip, _recorder)
+    rec = _recording()
+    return _hip if rec is None else _RecordingLib(_hip, rec)
 
 
 def host():
@@ -207,16 +214,18 @@ def ptr(t):
     """Device/host pointer of a torch tensor (None -> NULL)."""
     if t is None:
         return None
-    if _recorder is not None:
-        _recorder.keep(t)
+    rec = _recording()
+    if rec is not None:
+        rec.keep(t)
     return t.data_ptr()
 
 
 def stream_wait(waiter, waited):
     """``waiter.wait_stream(waited)`` -- the one way the scoring path hands work from one stream to another, so that a
     recording sees it."""
-    if _recorder is not None:
-        _recorder.wait(waiter, waited)
+    rec = _recording()
+    if rec is not None:
+        rec.wait(waiter, waited)
     waiter.wait_stream(waited)
 
 

@@ -123,21 +123,20 @@ __device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint2 *lw, cons
 // hi*hi + lo*hi + hi*lo, fp32 accumulate -- instead of four fp32 MFMAs: what is dropped is lo*lo and the rounding of the
 // two lo planes, <= 3 * 2^-18 |w| |x| per term (a bf16 product is exact in fp32).  24 matrix-pipe cycles per k-group and
 // tile instead of 128.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 template <int TPW>
 __device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint4 *lw, const f32x4 bv, bool last = true) {
-    bf16x4_bits bh, bl;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint16_t h = lpf_f32_to_bf16(bv[u]);
-        bh[u] = (short)h;
-        bl[u] = (short)lpf_f32_to_bf16(bv[u] - lpf_bf16_to_f32(h));
-    }
+    // the activations' planes: hardware conversions (v_cvt_pk_bf16_f32, round to nearest even), hi widened back by shifts
+    const bf16x4_t h4 = __builtin_convertvector(bv, bf16x4_t);
+    const f32x4 hf = __builtin_convertvector(h4, f32x4);
+    const bf16x4_t l4 = __builtin_convertvector(bv - hf, bf16x4_t);
+    const bf16x4_bits bh = __builtin_bit_cast(bf16x4_bits, h4), bl = __builtin_bit_cast(bf16x4_bits, l4);
     bf16x4_bits ah[TPW], al[TPW];
 #pragma unroll
     for (int c = 0; c < TPW; ++c) {
         const uint4 w = lw[c * 64];
-        ah[c] = (bf16x4_bits){(short)(w.x & 0xffffu), (short)(w.x >> 16), (short)(w.y & 0xffffu), (short)(w.y >> 16)};
-        al[c] = (bf16x4_bits){(short)(w.z & 0xffffu), (short)(w.z >> 16), (short)(w.w & 0xffffu), (short)(w.w >> 16)};
+        ah[c] = __builtin_bit_cast(bf16x4_bits, make_uint2(w.x, w.y));
+        al[c] = __builtin_bit_cast(bf16x4_bits, make_uint2(w.z, w.w));
     }
     const int n = last ? TPW : TPW - 1;   // consecutive MFMAs go to different accumulators
 #pragma unroll

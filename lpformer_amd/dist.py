@@ -116,7 +116,7 @@ def measure_allgather_gbps(n: int, d: int, device, reps: int = 3, group=None) ->
 
 
 def encoder_plan(encoder_ms_one_gpu: float, n: int, d: int, n_layers: int, world: int, allgather_gbps: float,
-                 last_agg_ms: float | None = None, node_keys_ms: float = 0.0) -> dict:
+                 last_agg_ms: float | None = None, node_keys_ms: float = 0.0, replicated_ms: float = 0.0) -> dict:
     """Cost model for the encoder + the per-node attention projection (Z) on ``world`` GPUs (all times in ms):
          replicated:  every rank runs all of it, no exchange           = enc + keys
          sharded:     1/world of every layer + (L + 1) all-gathers of an [n, d] fp32 matrix, Z / Y on every rank
@@ -126,16 +126,20 @@ def encoder_plan(encoder_ms_one_gpu: float, n: int, d: int, n_layers: int, world
     ``last_agg_ms``: the row-shardable part of the last layer on one GPU -- its aggregation (SpMM + epilogue), or the
     whole layer when it runs as one fused launch (default: 0.7 * enc / L).  A sharded encoder whose layers are all
     fused needs L all-gathers, not L + 1 (layer 0 reads the replicated features): the estimate is on the safe side;
-    ``node_keys_ms``: the two N x D x D projections.  Returns the estimates and the cheapest mode.
+    ``node_keys_ms``: the per-node projection(s) ``gather_once`` runs on the rank's row block (Z);  ``replicated_ms``:
+    per-node work EVERY rank does in full whatever the layout (the query table Y = X W_l^T + b_l with
+    ``query_from = "table"``: only [X | Z] travels in the one all-gather) -- a constant of all three estimates.
+    Returns the estimates and the cheapest mode.
     The reference has no counterpart (single device)."""
     if last_agg_ms is None:
         last_agg_ms = 0.7 * encoder_ms_one_gpu / max(n_layers, 1)
-    repl = encoder_ms_one_gpu + node_keys_ms
+    repl = encoder_ms_one_gpu + node_keys_ms + replicated_ms
     if world <= 1:
         return {"mode": "replicated", "replicated_ms": repl, "sharded_ms": repl, "gather_once_ms": repl,
                 "allgather_ms": 0.0}
     ag_ms = n * d * 4 / (allgather_gbps * 1e9) * 1e3
-    sharded = encoder_ms_one_gpu / world + (n_layers + 1) * ag_ms + node_keys_ms
-    once = encoder_ms_one_gpu - (1.0 - 1.0 / world) * (last_agg_ms + node_keys_ms) + node_keys_ms + 2.0 * ag_ms
+    sharded = encoder_ms_one_gpu / world + (n_layers + 1) * ag_ms + node_keys_ms + replicated_ms
+    once = (encoder_ms_one_gpu - (1.0 - 1.0 / world) * (last_agg_ms + node_keys_ms) + node_keys_ms + 2.0 * ag_ms +
+            replicated_ms)
     best = min((repl, "replicated"), (sharded, "sharded"), (once, "gather_once"))[1]
     return {"mode": best, "replicated_ms": repl, "sharded_ms": sharded, "gather_once_ms": once, "allgather_ms": ag_ms}

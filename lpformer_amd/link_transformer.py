@@ -630,6 +630,8 @@ class LinkTransformer(nn.Module):
         # its finished row [post_att_norm(attention output) | counts] -- no records for the tail to chase and merge.
         # False: the unit-major kernel (csrc/pair_flip.hip) + record merge, as the matrix-core kernel always does.
         self.attention_rows = True
+        self.flip_recheck_every = 16   # "auto": parameter versions between two looks at the weights (attention_kernel)
+        self._refolds = 0
         # behind the pair-major kernel: hand the dense tail the pairs with selected nodes first and let the workgroups that
         # see only pairs without any (their attention branch is a constant) run the elementwise half of the head alone
         self.tail_skip_empty = True
@@ -772,6 +774,7 @@ class LinkTransformer(nn.Module):
             out["pe_stat"][t, 7] = fold.no_flip_radius(out["flip_tab"][t], out["pe_stat"][t])
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in out.items()}
         self._folded = (key, dev)
+        self._refolds = getattr(self, "_refolds", 0) + 1
         self._z_cache = None
         self._y_cache = None      # (Y = X W_l^T + b_l is parameter-derived too: a stale Y would give stale queries)
         self._zb_cache = None
@@ -1398,7 +1401,19 @@ class LinkTransformer(nn.Module):
         if self.attention_impl == "auto":
             if self.dim < 128:
                 return "mfma"
-            return "flip" if self.flips_per_entry() <= self.FLIP_BREAK_EVEN.get(self.dim, 6.0) else "mfma"
+            # The estimate runs a 4,096-pair selection and reads counts back (host synchronisations): it is made once per
+            # parameter version in evaluation mode -- but not inside a loop that alternates optimiser steps with scoring
+            # (at most once per `flip_recheck_every` parameter versions), and never while training.
+            self._fold()
+            last = getattr(self, "_auto_choice", None)      # (parameter key, choice, refolds at the time)
+            if last is not None and (last[0] is self._folded[0] or self.training or
+                                     self._refolds - last[2] < self.flip_recheck_every):
+                return last[1]
+            if self.training:
+                return "flip"
+            choice = "flip" if self.flips_per_entry() <= self.FLIP_BREAK_EVEN.get(self.dim, 6.0) else "mfma"
+            self._auto_choice = (self._folded[0], choice, self._refolds)
+            return choice
         return self.attention_impl
 
     def _uses_rows(self) -> bool:

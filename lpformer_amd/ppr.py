@@ -200,10 +200,16 @@ def get_ppr(dataset, edge_index, num_nodes, alpha, eps, is_val, *, root_dir=None
         print("PPR matrix exists. Loading from file...", flush=True)
         # the reference pickles a torch_sparse.SparseTensor: allow-list exactly that class (and its storage) instead of
         # unpickling whatever the file holds
+        import pickle
         from torch_sparse import SparseTensor
         from torch_sparse.storage import SparseStorage
-        with torch.serialization.safe_globals([SparseTensor, SparseStorage]):
-            return torch.load(ref_path, weights_only=True).to_torch_sparse_coo_tensor()
+        try:
+            with torch.serialization.safe_globals([SparseTensor, SparseStorage]):
+                return torch.load(ref_path, weights_only=True).to_torch_sparse_coo_tensor()
+        except (AttributeError, pickle.UnpicklingError, RuntimeError) as exc:
+            # (torch < 2.5 has no safe_globals; the restricted unpickler may refuse the TorchScript storage class): the
+            # cache is an optimisation -- recompute instead of failing, and say so
+            print(f"could not load {ref_path} with the restricted unpickler ({exc}); recomputing", flush=True)
     csr = load_or_calc_ppr(edge_index, int(num_nodes), alpha, eps, cache_root=root_dir, dataset=dataset, is_val=is_val,
                            device=device, num_threads=num_threads)
     coo = csr.to_torch_sparse_coo()

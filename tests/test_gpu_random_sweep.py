@@ -154,6 +154,7 @@ def test_auto_attention_choice_follows_the_weights(dim):
     score = lpformer_amd.mlp_score(2 * dim, 2 * dim, 1, 2).to(DEV).eval()
     batch = D.sample_pairs(ei, n, 600, seed=seed + 1)
     assert model.attention_impl == "auto"
+    model.flip_recheck_every = 1      # look at the weights at every parameter version (the default amortises: below)
     chosen = []
     for gain in (1.0, 200.0):
         with torch.no_grad():
@@ -171,3 +172,13 @@ def test_auto_attention_choice_follows_the_weights(dim):
         assert np.abs(lg.cpu().numpy() - ref["logit"]).max() <= TOL * max(1.0, float(np.abs(ref["logit"]).max()))
     assert [c[0] for c in chosen] == ["flip", "mfma"], chosen
     assert chosen[0][1] < model.FLIP_BREAK_EVEN[dim] < chosen[1][1], chosen
+    # a loop that alternates optimiser steps with scoring does not pay the estimate (a selection + host reads) per step:
+    # with the default spacing the last choice stands until enough parameter versions have gone by, and training never asks
+    model.flip_recheck_every = 16
+    with torch.no_grad():
+        model.ppr_encoder_onehop.linears[0].weight.mul_(1.0 / 200.0)
+    est = model._flip_est
+    assert model.attention_kernel() == "mfma" and model._flip_est is est       # (no new estimate yet)
+    model.train()
+    assert model.attention_kernel() == "mfma" and model._flip_est is est
+    model.eval()
