@@ -524,8 +524,10 @@ int lpf_tail_chain_rows_bf16(int64_t M, int32_t D, int32_t n_counts, const float
  * lpf_tail_chain_rows_perm_* walks the pairs in that order; a workgroup whose 64 pairs all lie behind *n_full computes
  *   score = w_dot . ReLU(A_e r_e + bC_empty) + b_dot,    bC_empty [2 D] = bC + A_p r_p0
  * with r_p0 the hidden activation of pairwise_lin for the constant row (lpformer_amd/fold.py empty_pair_head_bias); every
- * other workgroup runs the full tail (a mixed workgroup reads the empty pairs' rows, which hold the constant).  Outputs
- * are indexed by pair as before. */
+ * other workgroup runs the full tail.  In a MIXED workgroup a pair without selected nodes takes its row from row_empty
+ * [D] = post_att_norm(att_bias) (lpformer_amd/fold.py empty_pair_row) and zero counts; row_empty NULL: it reads rows[] like
+ * any other pair (lpf_pair_attention_rows_perm_* writes the constant row there; lpf_pair_attention_rows4_* with an order
+ * does NOT write rows or counts of such pairs: pass row_empty behind it).  Outputs are indexed by pair as before. */
 #define LPF_ROWS_PERM_LB_WORDS 1025
 int lpf_pair_attention_rows_perm_f32(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entries, int64_t ent_cap,
                                      const float *Z, int64_t ldz, const float *q, int64_t ldq,
@@ -552,7 +554,7 @@ int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const floa
                               const void *wB_split, const float *bB, const float *lnB_g, const float *lnB_b,
                               const float *r_e, int64_t ldre, const void *wC_split, const float *bC, const float *w_dot,
                               const float *b_dot, const int64_t *sel_ctl, const int32_t *perm, const int64_t *n_full,
-                              const float *bC_empty, float *logit, float *prob, void *stream);
+                              const float *bC_empty, const float *row_empty, float *logit, float *prob, void *stream);
 
 /* lpf_pair_attention_rows_perm_* behind lpf_select4: the entries are pair-major already (a pair's entries contiguous from
  * pair_tab[p][0], the type in bits 29-30 of the record's pair word), so the kernel reads ONE region and needs no per-type
@@ -560,8 +562,10 @@ int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const floa
  * block a cut falls into.  units_cap: 16-entry units the `pieces` scratch has room for -- it bounds the SELECTED entries
  * of a batch (16 * (units_cap - 1)), not the entry buffer; a batch with more leaves NaN rows and raises
  * LPF_SELECT_ERR_ENTRY_CAP in sel_ctl[3].  perm / n_nonempty: both, or both NULL (no order for the
- * tail; the order needs no scan words here: the selection counted the pairs with entries per block).  Everything else as
- * lpf_pair_attention_rows_f32; the rows agree with that call's up to the order in which a pair's entries are summed. */
+ * tail; the order needs no scan words here: the selection counted the pairs with entries per block; WITH an order the
+ * rows and count features of pairs without entries are not written -- lpf_tail_chain_rows_perm_* takes row_empty for
+ * them).  Everything else as lpf_pair_attention_rows_f32; the rows agree with that call's up to the order in which a
+ * pair's entries are summed. */
 int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt, const void *entries,
                                  int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
                                  const float *pe_tab_signed, const float *pe_stat, const float *base,
@@ -581,12 +585,14 @@ int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_counts, const f
                                  const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
                                  const float *r_e, int64_t ldre, const float *wC_packed, const float *bC,
                                  const float *w_dot, const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
-                                 const int64_t *n_full, const float *bC_empty, float *logit, float *prob, void *stream);
+                                 const int64_t *n_full, const float *bC_empty, const float *row_empty, float *logit,
+                                 float *prob, void *stream);
 int lpf_tail_chain_rows_perm_bf16(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
                                   const void *wB_packed_bf16, const float *bB, const float *lnB_g, const float *lnB_b,
                                   const float *r_e, int64_t ldre, const void *wC_packed_bf16, const float *bC,
                                   const float *w_dot, const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
-                                  const int64_t *n_full, const float *bC_empty, float *logit, float *prob, void *stream);
+                                  const int64_t *n_full, const float *bC_empty, const float *row_empty, float *logit,
+                                  float *prob, void *stream);
 
 /* logit[i] = dot(A[i,:], w) + b ; prob[i] = sigmoid(logit[i])  (mlp_score last layer, other_models.py:178-179).
  * logit or prob may be NULL. */

@@ -74,11 +74,11 @@ HIP_PROTOTYPES = {
     "lpf_pair_attention_rows4_zbf16": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp,
                                        vp, i64, vp, i64, vp, vp, vp],
     "lpf_tail_chain_rows_perm_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                     vp, vp],
+                                     vp, vp, vp],
     "lpf_tail_chain_rows_perm_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                      vp, vp],
+                                      vp, vp, vp],
     "lpf_tail_chain_rows_split": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                  vp, vp],
+                                  vp, vp, vp],
     "lpf_pair_rows_piece_floats": [i32],
     "lpf_tail_chain_rows_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lpf_tail_chain_rows_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -542,6 +542,10 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 n0 = ltp[k + 1] - ltp[k]; n1 = ltp[TPS + k + 1] - ltp[TPS + k]; n2 = ltp[2 * TPS + k + 1] - ltp[2 * TPS + k];
             }
             const int np = n0 + n1 + n2;
+            // PT with an order for the tail: a pair without entries gets neither row nor counts -- the tail knows the
+            // constant row (lpf_tail_chain_rows_perm_*: row_empty) and never reads them
+            const bool skip = PT && A.perm != nullptr && np == 0;
+            if (skip) continue;
             if (np == 0) {
                 llist[atomicAdd(&lctl[0], 1)] = k;
             } else if (((v0 + lcum[k]) >> 4) != ((v0 + lcum[k + 1] - 1) >> 4)) {

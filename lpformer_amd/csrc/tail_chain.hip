@@ -57,6 +57,9 @@ struct TailArgs {
     const int32_t *perm;
     const int64_t *n_full;
     const float *bC_empty;
+    // ... and a pair without selected nodes in a MIXED workgroup takes its (constant) row from here and zero counts: the
+    // attention kernel that leaves the order does not write rows for such pairs
+    const float *row_empty;         // [NA]
 };
 
 constexpr int tc_per_thread(int ntp) { return (ntp * 64 + TC_THREADS - 1) / TC_THREADS; }
@@ -243,6 +246,8 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
         }
     }
     const int64_t mm = live ? m : (ROWS && A.perm ? m : A.M - 1);  // dead lanes compute on a valid row and store nothing
+    bool no_sel = false;        // (rows mode with an order: this pair has no selected nodes)
+    if constexpr (ROWS) no_sel = A.perm && A.row_empty && (live ? pos : A.M - 1) >= *A.n_full;
 
     if constexpr (ROWS) {
         if (lite) {
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
     tc_load<S::PB, NTPB>(wrB, A.wB, 0, tid);  // stage B's first weights fly during the epilogue
     if constexpr (ROWS) {
         const int fbase = 16 * half * TPWA + 4 * q;
-        const float *row = A.rows + mm * A.ldrows;
+        const float *row = no_sel ? A.row_empty : A.rows + mm * A.ldrows;
 #pragma unroll
         for (int c = 0; c < TPWA; ++c) {
             const int f0 = fbase + 16 * c;
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
         f32x4 tailv = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (q == 0) {
             if constexpr (ROWS) {
-                tailv = *reinterpret_cast<const f32x4 *>(A.rows + mm * A.ldrows + A.NA);
+                if (!no_sel) tailv = *reinterpret_cast<const f32x4 *>(A.rows + mm * A.ldrows + A.NA);
             } else if (A.part == nullptr) {
                 tailv = *reinterpret_cast<const f32x4 *>(A.tail + mm * A.ldtail);
             } else {  // get_structure_cnts (link_transformer.py:340-356): n_cn, n_1hop, [n_non1hop,] n_cn + n_1hop
@@ -549,7 +554,7 @@ extern "C" int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const 
                 lpf_aligned16(w_dot));
     TailArgs a{M, G + D, ldg, 3 * D + 4, G, ldg, wA_packed, lnA_g, lnA_b, D, counts, ldc, wB_packed, bB, lnB_g,
                lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
-               nullptr, nullptr, 0, nullptr, nullptr, nullptr, n_counts, nullptr, 0, nullptr, nullptr, nullptr};
+               nullptr, nullptr, 0, nullptr, nullptr, nullptr, n_counts, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);
@@ -574,7 +579,7 @@ extern "C" int lpf_tail_chain_merge_f32(int64_t M, int32_t D, int32_t n_counts, 
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0, wB_packed, bB, lnB_g,
                lnB_b, D + n_counts, r_e, ldre, wC_packed, bC, 2 * D, w_dot, b_dot, logit, prob,
-               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0, nullptr, nullptr, nullptr};
+               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4>(a, s);
@@ -602,7 +607,7 @@ extern "C" int lpf_tail_chain_merge_bf16(int64_t M, int32_t D, int32_t n_counts,
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, lnA_g, lnA_b, D, nullptr, 0,
                static_cast<const float *>(wB_packed_bf16), bB, lnB_g, lnB_b, D + n_counts, r_e, ldre,
                static_cast<const float *>(wC_packed_bf16), bC, 2 * D, w_dot, b_dot, logit, prob,
-               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0, nullptr, nullptr, nullptr};
+               part, bnd, units_cap, type_ptr, att_bias, sel_ctl, n_counts, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4, 1>(a, s);
@@ -619,9 +624,11 @@ template <int WM>
 int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows, const void *wB, const float *bB,
             const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre, const void *wC, const float *bC,
             const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob, void *stream,
-            const int32_t *perm = nullptr, const int64_t *n_full = nullptr, const float *bC_empty = nullptr) {
+            const int32_t *perm = nullptr, const int64_t *n_full = nullptr, const float *bC_empty = nullptr,
+            const float *row_empty = nullptr) {
     if (M == 0) return LPF_OK;
     LPF_REQUIRE(!perm || (n_full && bC_empty && lpf_aligned16(bC_empty)));
+    LPF_REQUIRE(!row_empty || (perm && lpf_aligned16(row_empty)));
     LPF_REQUIRE(M > 0 && rows && wB && bB && lnB_g && lnB_b && r_e && wC && bC && w_dot && b_dot && (logit || prob));
     LPF_REQUIRE((n_counts == 1 || n_counts == 3 || n_counts == 4) && (ldre & 3) == 0 && ldre >= D && (ldrows & 3) == 0 &&
                 ldrows >= D + 4);
@@ -629,7 +636,7 @@ int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t l
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, D, nullptr, 0, static_cast<const float *>(wB), bB,
                lnB_g, lnB_b, D + n_counts, r_e, ldre, static_cast<const float *>(wC), bC, 2 * D, w_dot, b_dot, logit, prob,
-               nullptr, nullptr, 0, nullptr, nullptr, sel_ctl, n_counts, rows, ldrows, perm, n_full, bC_empty};
+               nullptr, nullptr, 0, nullptr, nullptr, sel_ctl, n_counts, rows, ldrows, perm, n_full, bC_empty, row_empty};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4, WM, true>(a, s);
@@ -668,10 +675,11 @@ extern "C" int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_coun
                                             const float *lnB_b, const float *r_e, int64_t ldre, const float *wC_packed,
                                             const float *bC, const float *w_dot, const float *b_dot,
                                             const int64_t *sel_ctl, const int32_t *perm, const int64_t *n_full,
-                                            const float *bC_empty, float *logit, float *prob, void *stream) {
+                                            const float *bC_empty, const float *row_empty, float *logit, float *prob,
+                                            void *stream) {
     LPF_REQUIRE(perm && n_full && bC_empty);
     return tc_rows<0>(M, D, n_counts, rows, ldrows, wB_packed, bB, lnB_g, lnB_b, r_e, ldre, wC_packed, bC, w_dot, b_dot,
-                          sel_ctl, logit, prob, stream, perm, n_full, bC_empty);
+                          sel_ctl, logit, prob, stream, perm, n_full, bC_empty, row_empty);
 }
 
 extern "C" int lpf_tail_chain_rows_perm_bf16(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
@@ -679,11 +687,11 @@ extern "C" int lpf_tail_chain_rows_perm_bf16(int64_t M, int32_t D, int32_t n_cou
                                              const float *lnB_b, const float *r_e, int64_t ldre,
                                              const void *wC_packed_bf16, const float *bC, const float *w_dot,
                                              const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
-                                             const int64_t *n_full, const float *bC_empty, float *logit, float *prob,
-                                             void *stream) {
+                                             const int64_t *n_full, const float *bC_empty, const float *row_empty,
+                                             float *logit, float *prob, void *stream) {
     LPF_REQUIRE(perm && n_full && bC_empty);
     return tc_rows<1>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
-                         b_dot, sel_ctl, logit, prob, stream, perm, n_full, bC_empty);
+                         b_dot, sel_ctl, logit, prob, stream, perm, n_full, bC_empty, row_empty);
 }
 
 /* lpf_tail_chain_rows_f32 / _perm_f32 with the two GEMMs on the bf16 matrix cores at fp32 accuracy: wB / wC as SPLIT images
@@ -694,9 +702,9 @@ extern "C" int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts,
                                          const void *wB_split, const float *bB, const float *lnB_g, const float *lnB_b,
                                          const float *r_e, int64_t ldre, const void *wC_split, const float *bC,
                                          const float *w_dot, const float *b_dot, const int64_t *sel_ctl,
-                                         const int32_t *perm, const int64_t *n_full, const float *bC_empty, float *logit,
-                                         float *prob, void *stream) {
+                                         const int32_t *perm, const int64_t *n_full, const float *bC_empty,
+                                         const float *row_empty, float *logit, float *prob, void *stream) {
     LPF_REQUIRE((perm != nullptr) == (n_full != nullptr) && (perm != nullptr) == (bC_empty != nullptr));
     return tc_rows<2>(M, D, n_counts, rows, ldrows, wB_split, bB, lnB_g, lnB_b, r_e, ldre, wC_split, bC, w_dot, b_dot,
-                      sel_ctl, logit, prob, stream, perm, n_full, bC_empty);
+                      sel_ctl, logit, prob, stream, perm, n_full, bC_empty, row_empty);
 }

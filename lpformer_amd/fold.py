@@ -246,6 +246,17 @@ def empty_pair_head_bias(att_bias, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b, a_fol
     return (f64(c_fold) + f64(a_fold)[:, dim:dim + pd] @ r_p0).astype(np.float32)
 
 
+def empty_pair_row(att_bias, lnA_g, lnA_b, dim: int) -> np.ndarray:
+    """The attention branch's output row of a pair WITHOUT selected nodes, post_att_norm(0 / (0 + 1e-16) + bias)
+    (layers.py:78,220), float64 on the host -> fp32 [D]: with an order for the tail the pair-major attention kernel does
+    not write such a pair's row at all, the tail takes this one."""
+    x = np.asarray(att_bias, np.float64)[:dim]
+    mu = x.mean()
+    y = (x - mu) / np.sqrt(((x - mu) ** 2).mean() + 1e-5) * np.asarray(lnA_g, np.float64)[:dim] + \
+        np.asarray(lnA_b, np.float64)[:dim]
+    return y.astype(np.float32)
+
+
 def tail_chain_tables(wcat, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b, a_fold, c_fold, w_dot, b_dot, dim: int,
                       att_bias=None) -> dict:
     """fp32 arrays of one lpf_tail_chain_f32 call.  ``a_fold`` [2D, D + pd] = [A_e | A_p] (LinkTransformer._score_fold);
@@ -267,5 +278,6 @@ def tail_chain_tables(wcat, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b, a_fold, c_fo
         "w_dot": np.asarray(w_dot, np.float32).reshape(-1).copy(),
         "b_dot": np.asarray(b_dot, np.float32).reshape(-1)[:1].copy(),
         **({} if att_bias is None else {"bC_empty": empty_pair_head_bias(att_bias, lnA_g, lnA_b, w_p0, b_p0, lnB_g, lnB_b,
-                                                                       a_fold, c_fold, dim)}),
+                                                                       a_fold, c_fold, dim),
+                                        "row_empty": empty_pair_row(att_bias, lnA_g, lnA_b, dim)}),
     }

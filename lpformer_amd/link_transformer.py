@@ -1723,10 +1723,13 @@ class LinkTransformer(nn.Module):
                 res = torch.empty(bs, dtype=torch.float32, device=self.device)
                 with KernelTimer.span("tail_chain"):
                     b16 = self.tail_precision == "bf16"
-                    extra = (ptr(order[0]), ptr(order[1]), ptr(tt["bC_empty"])) if order else ()
+                    # (behind select4 the attention kernel leaves no rows for pairs without selected nodes: the tail
+                    #  takes the constant row itself; behind select3 the rows are there and row_empty stays NULL)
+                    row0 = ptr(tt["row_empty"]) if (order and self._uses_select4(adj_mask)) else None
+                    extra = (ptr(order[0]), ptr(order[1]), ptr(tt["bC_empty"]), row0) if order else ()
                     if self.tail_precision == "f32" and self.tail_split:
                         name, sfx = "lpf_tail_chain_rows_split", "_split"
-                        extra = extra or (None, None, None)
+                        extra = extra or (None, None, None, None)
                     else:
                         name = "lpf_tail_chain_rows" + ("_perm" if order else "") + ("_bf16" if b16 else "_f32")
                         sfx = "_bf16" if b16 else ""

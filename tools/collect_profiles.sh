@@ -2,7 +2,7 @@
 # Round profile collection on the GPU box (run through gpurun from the repo root):
 #   tools/collect_profiles.sh r02 <commit>   ->   gpurun_out/<tag>_*  (copy the summaries into profiles/ afterwards)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
@@ -22,7 +22,7 @@ for ROWS in on off; do
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch/$ROWS -- python3 bench.py --launch eager --streams 1 --rows $ROWS --weights random --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-timing --no-bf16 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write/$ROWS -- python3 bench.py --launch eager --streams 1 --rows $ROWS --weights random --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-timing --no-bf16 > /dev/null 2>&1
 done
-python3 tools/pmc_traffic.py $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_pmc_traffic.json $COMMIT
+python3 tools/pmc_traffic.py $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_pmc_traffic_collab.json $COMMIT collab
 # 4. matrix-core utilisation of the shipped MFMA kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/${TAG}_mfma -- python3 bench.py --launch eager --streams 1 --rows on --weights random --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-timing --no-bf16 > /dev/null 2>&1
 python3 tools/pmc_summary.py $OUT/${TAG}_mfma pair_fused_kernel pair_flip_kernel pair_rows_kernel tail_chain_kernel dense_chain_kernel gcn_fused_kernel gemm_f32 > $OUT/${TAG}_pmc_mfma_util.txt 2>&1

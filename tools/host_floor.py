@@ -16,8 +16,8 @@ score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval(
 batches = [torch.from_numpy(D.sample_pairs(ei, n, cfg["batch"], seed=1000 + i)).to(dev) for i in range(16)]
 h = model.propagate()
 lib = _lib.hip()
-fns = ["lpf_pair_gather_f32", "lpf_dense_chain_f32", "lpf_select3_plan", "lpf_select3_run",
-       "lpf_pair_attention_rows_perm_f32", "lpf_tail_chain_rows_perm_f32"]
+fns = ["lpf_pair_gather_f32", "lpf_dense_chain_f32", "lpf_dense_chain_side_f32", "lpf_select3_plan", "lpf_select3_run",
+       "lpf_select4", "lpf_pair_attention_rows_perm_f32", "lpf_pair_attention_rows4_f32", "lpf_tail_chain_rows_perm_f32"]
 with torch.no_grad():
     for nl in (1, 4, 8, 12):
         lanes = model.lanes(nl)

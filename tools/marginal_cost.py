@@ -51,10 +51,11 @@ with torch.no_grad():
     base = measure()
     print(f"all launches: {base:.4f} ms per step; host time per replay {np.median(host):.4f} ms")
     names = {"elementwise branch + q gather": ["lpf_dense_chain_side_f32"],
-             "select run": ["lpf_select3_run"],
+             "select run": ["lpf_select3_run", "lpf_select4"],
              # (the attention alone cannot be left out: the tail walks the pairs in the order it leaves)
              "dense tail": ["lpf_tail_chain_rows_perm_f32", "lpf_tail_chain_rows_perm_bf16"],
-             "attention + tail": ["lpf_pair_attention_rows_perm_f32", "lpf_tail_chain_rows_perm_f32", "lpf_tail_chain_rows_perm_bf16"]}
+             "attention + tail": ["lpf_pair_attention_rows_perm_f32", "lpf_pair_attention_rows4_f32",
+                                  "lpf_tail_chain_rows_perm_f32", "lpf_tail_chain_rows_perm_bf16"]}
     if os.environ.get("LPF_ONLY_BASE"):
         names = {}
     names.pop("select run", None)   # (a selection that does not run leaves garbage counts to size the next workspace from)
