@@ -33,7 +33,10 @@ namespace {
 using namespace walk;
 
 constexpr int S4_PAIRS = LPF_SELECT4_BLOCK;   // pairs per workgroup: one lane of the planning wavefront each
-constexpr int S4_ROUNDS = 4;                  // slots per thread in flight
+#ifndef S4_ROUNDS_N       // (tuning: slots per thread in flight)
+#define S4_ROUNDS_N 4
+#endif
+constexpr int S4_ROUNDS = S4_ROUNDS_N;        // slots per thread in flight
 constexpr int CTL_ERR = 3, CTL_DONE = 10, CTL_ALLOC = 16;   // CTL_ALLOC: first of S4_SHARDS allocation counters
 // The entry buffer is cut into S4_SHARDS equal regions, a workgroup allocates in region blockIdx.x % S4_SHARDS: all
 // workgroups of a launch reach their allocation within a microsecond of each other, and 256 returning atomics on ONE

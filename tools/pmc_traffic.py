@@ -15,7 +15,8 @@ SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
     ("pair_flip_kernel", "pair_attention_fused"), ("pair_fused_kernel", "pair_attention_fused_mfma"),
     ("pair_rows_kernel", "pair_attention_rows"),
     ("tail_chain_kernel", "tail_chain"),   # (rows / merge form: told apart below by the last template argument)
-    ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"),
+    ("dense_chain_kernel<8, 0, 1, 1", "dense_chain_mlp_hidden"), ("dense_chain_kernel<4, 0, 1, 1", "dense_chain_mlp_hidden"),
+    ("dense_chain_kernel<16, 0, 1, 1", "dense_chain_mlp_hidden"), ("dense_chain_kernel<2, 0, 1, 1", "dense_chain_mlp_hidden"),
     ("pair_scores_", "pair_scores"), ("pair_softmax_gather_heavy", "pair_softmax_gather_heavy"),
     ("pair_softmax_gather_kernel", "pair_softmax_gather_light"),
     ("gcn_fused_kernel", "gcn_layer_fused"), ("spmm_row_parts", "spmm_row_parts"),
