@@ -33,4 +33,4 @@ mkdir -p $O
 for t in split f32 split f32; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --tail $t --no-cpu-baseline --weights random --no-bf16 --no-kernel-timing 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); c=d['config']; print('tail=$t', d['value'], d['ms_per_step'], d['ms_per_step_repeats'], c['launch_probe_ms_per_step'])"; done > $O/r05_tail_split_ab.txt 2>&1
-tail -3 $O/r05_select4_stamps.txt $O/r05_select4_shapes.txt $O/r05_rows_stamps.txt $O/r05_tail_split_ab.txt
+tail -n 3 $O/r05_select4_stamps.txt $O/r05_select4_shapes.txt $O/r05_rows_stamps.txt $O/r05_tail_split_ab.txt
