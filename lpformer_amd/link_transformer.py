@@ -650,9 +650,10 @@ class LinkTransformer(nn.Module):
         self.tail_precision = "f32"
         # tail_precision "f32", rows form: the tail's two GEMMs as split-bf16 products on the bf16 matrix cores (weights as
         # hi | lo planes, three MFMAs per product, fp32 accumulate: within 2e-5 of the fp32 MFMA result at a fifth of its
-        # matrix-pipe time).  Off: measured, the launch does not get shorter (57 us against 55: with the matrix time
-        # gone the one-k-group-ahead weight stream is what a workgroup waits for) and the pipelined step gets 6 % LONGER
-        # (0.173-0.176 against 0.163-0.167 ms: splitting the activations is vector work beside a vector-bound attention)
+        # matrix-pipe time).  Off: measured, the launch gets 3.7 us shorter (51.3 against 55.0: with the matrix time
+        # gone the one-k-group-ahead weight stream is what a workgroup waits for) and the pipelined step does not move
+        # (0.165-0.168 against 0.163-0.166 ms: splitting the activations is vector work beside a vector-bound attention);
+        # the parity mode keeps the fp32 MFMAs
         self.tail_split = False
 
     # ---------------------------------------------------------------------------------- support checks
