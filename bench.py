@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--tail", default="f32", choices=("split", "f32"),
                     help="the dense tail's two GEMMs in the fp32 parity mode: fp32 MFMAs (default) or split-bf16 products "
                          "on the bf16 matrix cores (within 2e-5 of fp32; measured 6 %% slower per pipelined step)")
+    ap.add_argument("--select4-threads", type=int, default=0,
+                    help="(tuning) launch shape of lpf_select4: workgroup size + 4096 * (blocks per workgroup - 1); 0 = default")
     ap.add_argument("--select-grid", type=int, default=0,
                     help="(tuning) workgroups of the selection's run kernel; 0 = as many as are resident at once")
     ap.add_argument("--streams", type=int, default=8,
@@ -324,6 +326,7 @@ def main():
     model.attention_impl = args.attention
     model.select_grid = args.select_grid
     model.tail_split = args.tail == "split"
+    model.select4_threads = args.select4_threads
     enc_plan = None
     if world > 1:
         # encoder layout: measure the whole encoder on one GPU (replicated mode) and the all-gather of an [N, D] fp32
