@@ -45,8 +45,10 @@ def _rt2(p):
     return F32(F32(0.5) * F32(F32(F32(p) * F32(2) + F32(2)) - F32(2)))
 
 
-def emulate_select3(wi: graph.WalkIndex, batch, thresholds, mode):
-    """The plan kernel's walk choice and the run kernel's slot typing (select3.hip), one slot at a time."""
+def emulate_select3(wi: graph.WalkIndex, batch, thresholds, mode, slot_order=None):
+    """The plan kernel's walk choice and the run kernel's slot typing (select3.hip / walk_common.h), one slot at a time.
+    ``slot_order``: a list that receives every kept slot as (pair, code, node, pa, pb, from_N(b)) in candidate-slot
+    order -- the order lpf_select4 compacts in."""
     th_cn, th_1, th_n = (F32(t) for t in thresholds)
     rec = wi.rec.numpy()
     r64 = wi.rec.view(torch.int64).numpy()
@@ -114,6 +116,8 @@ def emulate_select3(wi: graph.WalkIndex, batch, thresholds, mode):
                     c = 3 if (ws > 0 and lv > 0 and rs >= th_n and rl >= th_n) else 0
                 if c:
                     out[c].append((k, int(x), rs if src_a else rl, rl if src_a else rs, side_b))
+                    if slot_order is not None:
+                        slot_order.append((k, c, int(x), rs if src_a else rl, rl if src_a else rs, side_b))
     res = {}
     for c, tag in ((1, "cn"), (2, "onehop"), (3, "non1hop")):
         ent = out[c]
@@ -122,6 +126,33 @@ def emulate_select3(wi: graph.WalkIndex, batch, thresholds, mode):
         ix = np.array([[t[0] for t in ent], [t[1] for t in ent]], np.int64).reshape(2, -1)
         res[tag] = (ix, np.array([t[2] for t in ent], F32), np.array([t[3] for t in ent], F32))
     return res
+
+
+def emulate_select4(wi: graph.WalkIndex, batch, thresholds, mode, blocks_per_wg=2):
+    """What lpf_select4 (csrc/select4.hip) leaves, restated on the host: the kept slots of a workgroup's blocks of 64
+    pairs compacted in candidate-slot order (pair-major: a pair's slots are contiguous), the type and the from-N(b) flag
+    in the record's pair word, a table entry {first entry, n_cn, n_1hop, n_non1hop} per pair, {entries, pairs with
+    entries} per block of 64 pairs.  Where a workgroup's run lands is an atomic add on the device; here the runs
+    simply follow each other, rounded up to 8 entries like there."""
+    kept = []
+    emulate_select3(wi, batch, thresholds, mode, slot_order=kept)
+    bs = batch.shape[1]
+    per_pair = [[] for _ in range(bs)]
+    for k, c, x, pa, pb, side_b in kept:      # (slot order inside every pair; pairs in batch order)
+        per_pair[k].append((c, x, pa, pb, side_b))
+    entries, tab = [], np.zeros((bs, 4), np.int64)
+    blk = np.zeros(((bs + 63) // 64, 2), np.int64)
+    wg_pairs = 64 * blocks_per_wg
+    for w0 in range(0, bs, wg_pairs):
+        for k in range(w0, min(w0 + wg_pairs, bs)):
+            tab[k] = [len(entries)] + [sum(1 for e in per_pair[k] if e[0] == t) for t in (1, 2, 3)]
+            for c, x, pa, pb, side_b in per_pair[k]:
+                word = (k | (c << 29) | ((1 << 31) if (c == 2 and side_b) else 0)) & 0xFFFFFFFF
+                entries.append((word, x, pa, pb))
+            blk[k // 64, 0] += len(per_pair[k])
+            blk[k // 64, 1] += 1 if per_pair[k] else 0
+        entries.extend([(0, 0, F32(0), F32(0))] * (-len(entries) % 8))     # (the next run starts on a 128-byte line)
+    return entries, tab, blk
 
 
 def _case(seed, n, m, thresholds, jitter=True):
@@ -182,6 +213,44 @@ def test_walk_plan_matches_oracle(mode, thresholds, seed):
         assert np.array_equal(got[tag][1].view(np.uint32), ref[tag][1].view(np.uint32)), (mode, tag, "pa")
         assert np.array_equal(got[tag][2].view(np.uint32), ref[tag][2].view(np.uint32)), (mode, tag, "pb")
     assert sum(ref[t][0].shape[1] for t in ref) > 10  # the case selects something
+
+
+@pytest.mark.parametrize("mode,thresholds", [CASES[0], CASES[3], CASES[5], CASES[7]])
+def test_pair_major_layout_matches_oracle(mode, thresholds):
+    """The pair-major layout of lpf_select4, restated on the host (``emulate_select4``): every pair's entries
+    contiguous from its table entry, per-type counts and block counts consistent, the 1-hop entries of N(a) in front of
+    those of N(b) -- and, regrouped by type and sorted by (pair, node), exactly the oracle's sets with the oracle's
+    values.  (The device kernel is checked against the same oracle in tests/test_gpu_select4.py.)"""
+    n = 220
+    adj, ppr, batch = _case(1, n, 900, thresholds)
+    wi = graph.build_walk_index(_dev(adj), _dev(ppr), thresholds[1], thresholds[2], want_t0=(mode == "all"))
+    entries, tab, blk = emulate_select4(wi, batch, thresholds, mode)
+    ref = O.select_nodes(batch, (adj.rowptr, adj.col.astype(np.int64)),
+                         (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), thresholds, n=n)
+    bs = batch.shape[1]
+    got = {t: [] for t in (1, 2, 3)}
+    for k in range(bs):
+        s0, cnt = tab[k, 0], tab[k, 1:].sum()
+        seen_b = False
+        for word, x, pa, pb in entries[s0:s0 + cnt]:
+            assert (word & 0x1FFFFFFF) == k                       # the pair's own entries, nothing else
+            t = (word >> 29) & 3
+            got[t].append((k, x, pa, pb))
+            if t == 2:                                            # N(a)'s one-hop nodes before N(b)'s
+                assert not (seen_b and not (word >> 31))
+                seen_b = seen_b or bool(word >> 31)
+        for t in (1, 2, 3):
+            assert sum(1 for e in entries[s0:s0 + cnt] if ((e[0] >> 29) & 3) == t) == tab[k, t]
+    for b in range(blk.shape[0]):
+        assert blk[b, 0] == tab[64 * b:64 * b + 64, 1:].sum() and blk[b, 1] == (tab[64 * b:64 * b + 64, 1:].sum(1) > 0).sum()
+    for t, tag in ((1, "cn"), (2, "onehop"), (3, "non1hop")):
+        ent = sorted(got[t], key=lambda e: (e[0], e[1]))
+        if tag not in ref:
+            assert not ent
+            continue
+        assert np.array_equal(np.array([[e[0] for e in ent], [e[1] for e in ent]], np.int64).reshape(2, -1), ref[tag][0])
+        assert np.array_equal(np.array([e[2] for e in ent], F32).view(np.uint32), ref[tag][1].view(np.uint32))
+        assert np.array_equal(np.array([e[3] for e in ent], F32).view(np.uint32), ref[tag][2].view(np.uint32))
 
 
 def test_walk_index_layout():
