@@ -327,6 +327,8 @@ def main():
     model.select_grid = args.select_grid
     model.tail_split = args.tail == "split"
     model.select4_threads = args.select4_threads
+    if os.environ.get("LPF_SELECT_BLOCKS"):                      # A/B aid: "0" = lpf_select3_plan / _run on every path
+        model.select_blocks = os.environ["LPF_SELECT_BLOCKS"] != "0"
     enc_plan = None
     if world > 1:
         # encoder layout: measure the whole encoder on one GPU (replicated mode) and the all-gather of an [N, D] fp32
