@@ -284,7 +284,7 @@ int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int
  *             error bits as above  [10] completion counter, [16..23] allocation counters (zero between launches)
  * A block that does not fit below ent_cap leaves empty pairs and raises LPF_SELECT_ERR_ENTRY_CAP (consumers write NaN
  * rows while the bit is set).  threads: launch shape, workgroup size (512 or 1024) + 4096 * (blocks of 64 pairs a workgroup
- * takes together - 1); 0 = the default (1024 threads, 2 blocks). */
+ * takes together - 1); 0 = the default (1024 threads; 2 blocks while that gives every CU a workgroup, else 1). */
 #define LPF_SELECT4_BLOCK 64
 #define LPF_SELECT4_CTL_WORDS 32
 int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,

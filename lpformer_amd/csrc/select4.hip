@@ -375,10 +375,17 @@ extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, i
     a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
     const int64_t nb = (bs + S4_PAIRS - 1) / S4_PAIRS;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // threads = workgroup size + 4096 * (blocks of 64 pairs per workgroup - 1); 0: the default
+    // threads = workgroup size + 4096 * (blocks of 64 pairs per workgroup - 1); 0: the default -- 1,024 threads and two
+    // blocks per workgroup while that still gives every CU a workgroup, one block otherwise (a batch of 8,192 pairs of a
+    // dense graph -- ddi-like, ~1,000 slots per pair -- is 64 workgroups of 32 batches each with two: 127 us against 69)
+    if (threads == 0) {
+        const int n_cu = lpf_cu_count();
+        if (n_cu == 0) return LPF_ERR_NO_DEVICE;
+        threads = 1024 + ((nb + 1) / 2 >= n_cu ? 4096 : 0);
+    }
     const int nth = threads & 4095, per = threads / 4096 + 1;
     const dim3 grid((unsigned)((nb + per - 1) / per));
-    if (threads == 0 || (nth == 1024 && per == 2)) hipLaunchKernelGGL((select4_kernel<1024, 2>), dim3((unsigned)((nb + 1) / 2)), dim3(1024), 0, s, a);
+    if (nth == 1024 && per == 2) hipLaunchKernelGGL((select4_kernel<1024, 2>), grid, dim3(1024), 0, s, a);
     else if (nth == 1024 && per == 1) hipLaunchKernelGGL((select4_kernel<1024, 1>), grid, dim3(1024), 0, s, a);
     else if (nth == 1024 && per == 4) hipLaunchKernelGGL((select4_kernel<1024, 4>), grid, dim3(1024), 0, s, a);
     else if (nth == 512 && per == 1) hipLaunchKernelGGL((select4_kernel<512, 1>), grid, dim3(512), 0, s, a);
