@@ -671,7 +671,7 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     pairs_per_s = world * bs * args.steps / elapsed
-    flips_random = model.flips_per_entry() if d >= 128 else None
+    flips_random = model.flips_per_entry(raw=True) if d >= 128 else None
     attention_random = model.attention_kernel()
 
     # ---- the same window on TRAINED weights (extra keys): the activation-pattern attention
@@ -730,7 +730,8 @@ def main():
                    "train_ms_per_step": round(train_s * 1e3 / max(1, args.train_steps), 2),
                    "loss_first5_mean": round(float(np.mean(losses[:5])), 4) if losses else None,
                    "loss_last5_mean": round(float(np.mean(losses[-5:])), 4) if losses else None,
-                   "flips_per_entry": None if d < 128 else round(model.flips_per_entry(), 3),
+                   "flips_per_entry": None if d < 128 else round(model.flips_per_entry(raw=True), 3),
+                   "flips_per_entry_not_tabulated": None if d < 128 else round(model.flips_per_entry(), 3),
                    "attention_impl": model.attention_kernel(),
                    "ms_per_step": round(el_t * 1e3 / args.steps, 4),
                    "value": round(world * bs * args.steps / el_t, 1), "unit": "pairs/s"}

@@ -34,7 +34,7 @@ extern "C" {
 #define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
 #define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
 
-#define LPF_ABI_VERSION 6
+#define LPF_ABI_VERSION 7
 
 /* GEMM / row-wise epilogue flags */
 #define LPF_FLAG_RELU 1u
@@ -564,22 +564,41 @@ int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const floa
  * LPF_SELECT_ERR_ENTRY_CAP in sel_ctl[3].  perm / n_nonempty: both, or both NULL (no order for the
  * tail; the order needs no scan words here: the selection counted the pairs with entries per block; WITH an order the
  * rows and count features of pairs without entries are not written -- lpf_tail_chain_rows_perm_* takes row_empty for
- * them).  Everything else as lpf_pair_attention_rows_f32; the rows agree with that call's up to the order in which a
- * pair's entries are summed. */
+ * them).
+ * ACTIVATION PATTERNS BY TABLE (link_transformer.py:67-76,182-211 -- the PE MLPs' hidden ReLU -- layers.py:193-224): the
+ * type-major calls know the base vectors of ONE activation pattern of the PE hidden layer, the one of (pa, pb) = (0, 0),
+ * and pay per entry for finding and correcting the units that left it (`base`, `wfold_t`).  Here the plane of PPR value
+ * pairs is cut into grid_n x grid_n cells, cell(v) = clamp((bits(fp32(v + grid_ofs)) >> grid_shift) - grid_base, 0,
+ * grid_n - 1) on either axis, and
+ *   pat_grid uint8 [3][grid_n][grid_n]: per type, cell (cell(x), cell(y)) -> id s < LPF_ROWS_PATTERNS of the pattern
+ *       that is the pattern of EVERY point (x, y) of the cell, or >= 0x80 (a boundary may cross the cell, or its
+ *       pattern is not tabulated: the entry then takes the exact detect-and-correct path against pattern 0, for which
+ *       pe_tab_signed / wfold_t are still read); the last cell of either axis (values > 1, NaN, negative) must be 0x80;
+ *   pat_base float [3][LPF_ROWS_PATTERNS][4][D]: (P_s, Q_s, R_s, B_s + bfold / 2) with X_s = sum over the units k active
+ *       in pattern s of Wfold[:, k] * (ta_k, tc_k, td_k, beta_k); id 0 = the pattern of (0, 0).
+ * An entry's key is Z[v] + [P r1 pa + Q r1 pb + R r1 + B](pattern of (pa, pb)) + [P r2 pb + Q r2 pa + R r2 + B](pattern
+ * of (pb, pa)): no look at its 2 D units at all.  Built by lpformer_amd/patterns.py (a per-cell proof by convexity;
+ * which patterns are tabulated only decides how many entries take the slower path, never a result).  A kernel that
+ * cannot hold LPF_ROWS_PATTERNS patterns per type in LDS (D = 256) keeps the first half and treats higher ids as 0x80.
+ * Everything else as lpf_pair_attention_rows_f32; the rows agree with that call's up to rounding (the order in which a
+ * pair's entries are summed, the association of the base vectors). */
+#define LPF_ROWS_PATTERNS 16
 int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt, const void *entries,
                                  int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
-                                 const float *pe_tab_signed, const float *pe_stat, const float *base,
-                                 const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
-                                 const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
-                                 int64_t units_cap, float *out, int64_t ldo, int32_t *perm, int64_t *n_nonempty,
-                                 void *stream);
+                                 const float *pe_tab_signed, const float *pe_stat, const float *pat_base,
+                                 const void *pat_grid, int32_t grid_n, int32_t grid_shift, int32_t grid_base,
+                                 float grid_ofs, const float *wfold_t, const float *att, const float *att_bias,
+                                 const float *ln_g, const float *ln_b, int32_t n_counts, const int64_t *sel_ctl,
+                                 float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
+                                 int64_t *n_nonempty, void *stream);
 int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
                                    const void *entries, int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q,
-                                   int64_t ldq, const float *pe_tab_signed, const float *pe_stat, const float *base,
-                                   const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
-                                   const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
-                                   int64_t units_cap, float *out, int64_t ldo, int32_t *perm, int64_t *n_nonempty,
-                                   void *stream);
+                                   int64_t ldq, const float *pe_tab_signed, const float *pe_stat, const float *pat_base,
+                                   const void *pat_grid, int32_t grid_n, int32_t grid_shift, int32_t grid_base,
+                                   float grid_ofs, const float *wfold_t, const float *att, const float *att_bias,
+                                   const float *ln_g, const float *ln_b, int32_t n_counts, const int64_t *sel_ctl,
+                                   float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
+                                   int64_t *n_nonempty, void *stream);
 
 int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
                                  const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,

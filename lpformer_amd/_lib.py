@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "liblpformer_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "liblpformer_host.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 FLAG_RELU = 1
 SELECT_ERR_NODE_RANGE, SELECT_ERR_ITEM_CAP, SELECT_ERR_ENTRY_CAP = 1, 2, 4
 ROWS_PERM_LB_WORDS = 1025      # LPF_ROWS_PERM_LB_WORDS (include/lpformer_hip.h)
@@ -69,10 +69,10 @@ HIP_PROTOTYPES = {
                                          vp, i64, vp, i64, vp, vp, vp, vp],
     "lpf_pair_attention_rows_perm_zbf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                            vp, vp, i64, vp, i64, vp, vp, vp, vp],
-    "lpf_pair_attention_rows4_f32": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp,
-                                     vp, i64, vp, i64, vp, vp, vp],
-    "lpf_pair_attention_rows4_zbf16": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp,
-                                       vp, i64, vp, i64, vp, vp, vp],
+    "lpf_pair_attention_rows4_f32": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, f32, vp,
+                                     vp, vp, vp, vp, i32, vp, vp, i64, vp, i64, vp, vp, vp],
+    "lpf_pair_attention_rows4_zbf16": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, f32, vp,
+                                       vp, vp, vp, vp, i32, vp, vp, i64, vp, i64, vp, vp, vp],
     "lpf_tail_chain_rows_perm_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp, vp],
     "lpf_tail_chain_rows_perm_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,

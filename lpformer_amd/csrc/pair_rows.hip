@@ -66,6 +66,14 @@ struct RowsArgs {
     // PT (pair-table) form -- the selection of select4.hip: entries pair-major already, the type in the record
     const int4 *pair_tab;      // [bs] {first entry, n_cn, n_1hop, n_non1hop}
     const int32_t *blk_cnt;    // [ceil(bs / LPF_SELECT4_BLOCK)] entries per block of pairs
+    // PT form: activation patterns by table (lpformer_amd/patterns.py).  The plane of PPR value pairs is cut into
+    // grid_n x grid_n cells, cell(v) = (bits(v + grid_ofs) >> grid_shift) - grid_base; a cell holds the id of the pattern
+    // that is provably the pattern of every point of the cell or 0x80 (then the entry takes the exact detect-and-correct
+    // path against pattern 0, as every entry outside the no-flip square does in the type-major form)
+    const float *pat_base;     // [3][LPF_ROWS_PATTERNS][4][D]: (P, Q, R, B + bfold / 2) of pattern s of type t
+    const uint8_t *pat_grid;   // [3][grid_n][grid_n]
+    int32_t grid_n, grid_shift, grid_base;
+    float grid_ofs;
 };
 
 template <int CTRL>
@@ -112,12 +120,15 @@ __device__ uint64_t *pr_stamp_buf = nullptr;
 constexpr int pr_piece_floats(int D) { return (D + 4 + 31) / 32 * 32; }
 
 // LDS carve-up, shared by the kernel and the launcher (float4 units unless noted)
-template <int G, int NTH, int WTL>
+// (PT form: NP patterns per type instead of one, and no copy of Wfold^T -- its corrections are the exception there)
+constexpr int pr_patterns(int G, bool PT) { return !PT ? 1 : (G >= 64 ? LPF_ROWS_PATTERNS / 2 : LPF_ROWS_PATTERNS); }
+
+template <int G, int NTH, int WTL, bool PT = false>
 struct PrLds {
-    static constexpr int D = 4 * G, NG = (NTH / 64) * (64 / G);
-    static constexpr int TAB = 0, BASE = TAB + 3 * D, VEC = BASE + 3 * D, CONST_ROW = VEC + 3 * G, STAT = CONST_ROW + G;
+    static constexpr int D = 4 * G, NG = (NTH / 64) * (64 / G), NP = pr_patterns(G, PT);
+    static constexpr int TAB = 0, BASE = TAB + 3 * D, VEC = BASE + 3 * NP * D, CONST_ROW = VEC + 3 * G, STAT = CONST_ROW + G;
     static constexpr int WT = STAT + 6;                      // (pe_stat: 3 x 8 floats)
-    static constexpr int REC = WT + WTL * D * G;             // int4 [NG][16]
+    static constexpr int REC = WT + (PT ? 0 : WTL) * D * G;  // int4 [NG][16]
     static constexpr int SC = REC + NG * 16;                 // f32x2 [NG][16]  (NG * 8 float4)
     static constexpr int META = SC + NG * 8;                 // int [NG][16]    (NG * 4 float4)
     static constexpr int TP = META + NG * 4;                 // int [3][PR_CHUNK + 4]
@@ -132,10 +143,11 @@ struct PrLds {
 
 // ZB: the node table Z is stored in bf16 (the bf16 throughput mode)
 // PT: the selection came from select4.hip (pair_tab / blk_cnt instead of the three type-major regions and type_ptr)
-template <int G, int NTH, int WTL, bool ZB = false, bool PT = false>
+template <int G, int NTH, int WTL_, bool ZB = false, bool PT = false>
 __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(const RowsArgs A) {
     using ZT = typename std::conditional<ZB, uint2, float4>::type;
-    using L = PrLds<G, NTH, WTL>;
+    using L = PrLds<G, NTH, WTL_, PT>;
+    constexpr int WTL = PT ? 0 : WTL_, NP = L::NP;
     constexpr int D = 4 * G, EPW = 64 / G, NG = L::NG, T_LO = WTL == 1 ? 1 : 0, TPS = PR_CHUNK + 4, RSP = pr_piece_floats(D);
     constexpr uint32_t PAIR_MASK = PT ? 0x1fffffffu : PR_PAIR_MASK;
     constexpr int SB = LPF_SELECT4_BLOCK;
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     constexpr int EW = 4;
     extern __shared__ __attribute__((aligned(16))) float4 pr_lds[];
     float4 *const ltab = pr_lds + L::TAB;        // [4][3][G]: row j of hidden unit 4 lj + j, type t -> ((j * 3 + t) * G + lj)
-    float4 *const lbase = pr_lds + L::BASE;      // [3][4][G]
+    float4 *const lbase = pr_lds + L::BASE;      // [3][NP][4][G]
     float4 *const lvec = pr_lds + L::VEC;        // [3][G]: att_bias, ln_g, ln_b by feature quad
     float4 *const lconst = pr_lds + L::CONST_ROW;   // [G]: the row of a pair without entries
     float *const lstat = reinterpret_cast<float *>(pr_lds + L::STAT);   // [3][8]
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             const int i = u * FT + ft;
             if (i < 3 * D) {
                 ta[u] = reinterpret_cast<const float4 *>(A.pe_tab)[i];
-                tb[u] = reinterpret_cast<const float4 *>(A.base)[i];
+                if constexpr (!PT) tb[u] = reinterpret_cast<const float4 *>(A.base)[i];
             }
         }
         constexpr int NW = WTL > 0 ? (WTL * D * G + FT - 1) / FT : 1;
@@ -248,7 +260,25 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             if (i < 3 * D) {
                 const int t = i / D, k = i % D;
                 ltab[((k & 3) * 3 + t) * G + (k >> 2)] = ta[u];
-                lbase[i] = tb[u];
+                if constexpr (!PT) lbase[i] = tb[u];
+            }
+        }
+        if constexpr (PT) {
+            // the pattern tables: [3][LPF_ROWS_PATTERNS][4][G] float4 in memory, the first NP patterns of every type kept
+            constexpr int PB = 3 * NP * D, PBU = 6;   // (six loads of a thread in flight at a time)
+            const float4 *src = reinterpret_cast<const float4 *>(A.pat_base);
+            for (int i0 = 0; i0 < PB; i0 += PBU * FT) {
+                float4 tp[PBU];
+#pragma unroll
+                for (int u = 0; u < PBU; ++u) {
+                    const int i = i0 + u * FT + ft;
+                    if (i < PB) tp[u] = src[(i / (NP * D)) * (LPF_ROWS_PATTERNS * D) + i % (NP * D)];
+                }
+#pragma unroll
+                for (int u = 0; u < PBU; ++u) {
+                    const int i = i0 + u * FT + ft;
+                    if (i < PB) lbase[i] = tp[u];
+                }
             }
         }
         if constexpr (WTL > 0) {
@@ -457,6 +487,11 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         else
             return z;
     };
+    // PT: the cell of a PPR value on either axis of the pattern grid (NaN, negative, > 1: the last cell, never tabulated)
+    auto grid_cell = [&](float v) __attribute__((always_inline)) {
+        const int c = (int)(__float_as_uint(v + A.grid_ofs) >> A.grid_shift) - A.grid_base;
+        return c < 0 ? A.grid_n - 1 : (c < A.grid_n ? c : A.grid_n - 1);
+    };
     auto q_row = [&](int pair) __attribute__((always_inline)) {
         return *reinterpret_cast<const float4 *>(A.q + (uint64_t)(uint32_t)pair * A.ldq + off);
     };
@@ -614,7 +649,22 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     const float pa = __int_as_float(rec.z), pb = __int_as_float(rec.w);
                     // pe_stat[t][7]: inside [0, c]^2 no hidden unit leaves the pattern of (0, 0), in either argument order
                     // (fold.no_flip_radius): such an entry needs no look at its units at all
-                    if (!(fmaxf(pa, pb) <= st[7])) meta |= 256;
+                    if constexpr (PT) {
+                        // bits 9-14 / 15-20: row t * NP + s of the pattern table for (pa, pb) / (pb, pa).  Outside the
+                        // square the two cells of the grid say which patterns these are -- or that a boundary may cross
+                        // one of them (bit 8: the exact path against pattern 0)
+                        int i1 = t * NP, i2 = t * NP;
+                        if (!(fmaxf(pa, pb) <= st[7])) {
+                            const int ia = grid_cell(pa), ib = grid_cell(pb);
+                            const uint8_t *gt = A.pat_grid + (int64_t)t * A.grid_n * A.grid_n;
+                            const int g1 = gt[ia * A.grid_n + ib], g2 = gt[ib * A.grid_n + ia];
+                            if (g1 >= NP || g2 >= NP) meta |= 256;
+                            else { i1 += g1; i2 += g2; }
+                        }
+                        meta |= (i1 << 9) | (i2 << 15);
+                    } else {
+                        if (!(fmaxf(pa, pb) <= st[7])) meta |= 256;
+                    }
                     const float vab = st[0] * pa * pa + st[1] * pb * pb + st[2] + 2.0f * (st[3] * pa * pb + st[4] * pa + st[5] * pb);
                     const float vba = st[0] * pb * pb + st[1] * pa * pa + st[2] + 2.0f * (st[3] * pa * pb + st[4] * pb + st[5] * pa);
                     sc = f32x2{__builtin_amdgcn_rsqf(fmaxf(vab, 0.0f) + 1e-5f), __builtin_amdgcn_rsqf(fmaxf(vba, 0.0f) + 1e-5f)};
@@ -642,21 +692,50 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 const int4 rc = lr[lro + i];
                 const f32x2 r12 = ls[lro + i];
                 const int meta = lm[lro + i];
+                // the query row of the NEXT entry's pair: fetched only where the pair changes -- the next step waits for
+                // whatever this one requested, and most steps stay inside a pair
                 const int pair_n = (int)((uint32_t)lr[lro + (i < 15 ? i + 1 : 15)].x & PAIR_MASK);
-                const float4 qn = q_row(pair_n);
+                float4 qn = qc;
+                if (pair_n != (int)((uint32_t)rc.x & PAIR_MASK)) qn = q_row(pair_n);
                 const bool on = meta & 64;
                 const int t = meta & 3;
                 const float pa = __int_as_float(rc.z), pb = __int_as_float(rc.w);
                 const f32x2 pab = {pa, pb}, pba = {pb, pa};
                 const int pair_i = (int)((uint32_t)rc.x & PAIR_MASK);
-                const float4 *tabl = ltab + t * G + lj, *basel = lbase + t * D + lj;
-                const f32x2 cab = r12.x * pab + r12.y * pba;
-                const float cr = r12.x + r12.y;
-                const float4 P0v = basel[0], Q0v = basel[G], R0v = basel[2 * G], C0v = basel[3 * G];
-                f32x2 k01 = f32x2{zc.x, zc.y} + (f32x2{P0v.x, P0v.y} * cab.x +
-                                                 (f32x2{Q0v.x, Q0v.y} * cab.y + (f32x2{R0v.x, R0v.y} * cr + f32x2{C0v.x, C0v.y})));
-                f32x2 k23 = f32x2{zc.z, zc.w} + (f32x2{P0v.z, P0v.w} * cab.x +
-                                                 (f32x2{Q0v.z, Q0v.w} * cab.y + (f32x2{R0v.z, R0v.w} * cr + f32x2{C0v.z, C0v.w})));
+                const float4 *tabl = ltab + t * G + lj;
+                f32x2 k01, k23;
+                if constexpr (PT) {
+                    // the base vectors of the pattern of (pa, pb) and of the pattern of (pb, pa), one order after the
+                    // other (one association whatever the neighbours in the wavefront are: a pair's row depends on its
+                    // own entries only)
+                    const int i1 = (meta >> 9) & 63, i2 = (meta >> 15) & 63;
+                    const float4 *b1 = lbase + i1 * D + lj, *b2 = lbase + i2 * D + lj;
+                    const f32x2 c1 = r12.x * pab, c2 = r12.y * pba;
+                    {
+                        const float4 P1 = b1[0], Q1 = b1[G], R1 = b1[2 * G], B1 = b1[3 * G];
+                        k01 = f32x2{zc.x, zc.y} + (f32x2{P1.x, P1.y} * c1.x + (f32x2{Q1.x, Q1.y} * c1.y +
+                                                   (f32x2{R1.x, R1.y} * r12.x + f32x2{B1.x, B1.y})));
+                        k23 = f32x2{zc.z, zc.w} + (f32x2{P1.z, P1.w} * c1.x + (f32x2{Q1.z, Q1.w} * c1.y +
+                                                   (f32x2{R1.z, R1.w} * r12.x + f32x2{B1.z, B1.w})));
+                    }
+                    {
+                        const float4 P2 = b2[0], Q2 = b2[G], R2 = b2[2 * G], B2 = b2[3 * G];
+                        k01 += f32x2{P2.x, P2.y} * c2.x + (f32x2{Q2.x, Q2.y} * c2.y + (f32x2{R2.x, R2.y} * r12.y + f32x2{B2.x, B2.y}));
+                        k23 += f32x2{P2.z, P2.w} * c2.x + (f32x2{Q2.z, Q2.w} * c2.y + (f32x2{R2.z, R2.w} * r12.y + f32x2{B2.z, B2.w}));
+                    }
+                } else {
+                    const float4 *basel = lbase + t * D + lj;
+                    const f32x2 cab = r12.x * pab + r12.y * pba;
+                    const float cr = r12.x + r12.y;
+                    const float4 P0v = basel[0], Q0v = basel[G], R0v = basel[2 * G], C0v = basel[3 * G];
+                    k01 = f32x2{zc.x, zc.y} + (f32x2{P0v.x, P0v.y} * cab.x +
+                                               (f32x2{Q0v.x, Q0v.y} * cab.y + (f32x2{R0v.x, R0v.y} * cr + f32x2{C0v.x, C0v.y})));
+                    k23 = f32x2{zc.z, zc.w} + (f32x2{P0v.z, P0v.w} * cab.x +
+                                               (f32x2{Q0v.z, Q0v.w} * cab.y + (f32x2{R0v.z, R0v.w} * cr + f32x2{C0v.z, C0v.w})));
+                }
+                // whose units are looked at: PT -- only the entries of cells without a tabulated pattern (the others
+                // already carry the vectors of their own patterns: a correction against pattern 0 would count twice)
+                const bool det = PT ? (on && (meta & 256) != 0) : on;
 #ifdef PR_ABL_NOFLIP   /* (timing only, wrong results: what do detection and corrections of flipped units cost?) */
                 if (false) {
 #elif defined(PR_ABL_ALLDETECT)   /* (timing only: every entry looks at its units, as before the no-flip box) */
@@ -672,7 +751,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 }
                 const float zmin = fminf(fminf(fminf(zz[0].x, zz[0].y), fminf(zz[1].x, zz[1].y)),
                                          fminf(fminf(zz[2].x, zz[2].y), fminf(zz[3].x, zz[3].y)));
-                const bool fl = zmin < 0.f && on;
+                const bool fl = zmin < 0.f && det;
                 if (__ballot(fl)) {
                     // some unit of some group left the pattern of (0, 0): every lane of that group owes Wfold[:, k] |y_k|
                     // (pair_flip.hip: one pass over the eight (order, unit-of-the-lane) slots, flipped lanes one at a time)
@@ -685,7 +764,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
 #pragma unroll
                     for (int oj = 0; oj < 8; ++oj) {
                         const float zv = (oj & 4) ? zz[oj & 3].y : zz[oj & 3].x;
-                        uint64_t bm = __ballot(zv < 0.f && on);
+                        uint64_t bm = __ballot(zv < 0.f && det);
                         while (bm) {
                             const int b = __builtin_ctzll(bm);
                             bm &= bm - 1;
@@ -911,22 +990,27 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
                 const float *base, const float *wfold_t, const float *att, const float *att_bias, const float *ln_g,
                 const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
                 int64_t ldo, void *stream, int32_t *perm = nullptr, uint64_t *perm_lb = nullptr,
-                int64_t *n_nonempty = nullptr, const void *pair_tab = nullptr, const int32_t *blk_cnt = nullptr) {
+                int64_t *n_nonempty = nullptr, const void *pair_tab = nullptr, const int32_t *blk_cnt = nullptr,
+                const float *pat_base = nullptr, const uint8_t *pat_grid = nullptr, int32_t grid_n = 0,
+                int32_t grid_shift = 0, int32_t grid_base = 0, float grid_ofs = 0.f) {
     if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(!PT || (pat_base && pat_grid && lpf_aligned16(pat_base) && grid_n >= 2 && grid_n <= 4096 &&
+                        grid_shift >= 0 && grid_shift <= 23 && grid_base >= 0 && grid_ofs >= 0.f));
     LPF_REQUIRE(bs > 0 && bs < (PT ? (1ll << 29) : (1ll << 31)) && (PT ? (pair_tab && blk_cnt && lpf_aligned16(pair_tab)) : type_ptr != nullptr) &&
                 entries && ent_cap > 0 && ent_cap < (PT ? (1ll << 31) : (1ll << 29)) && Z && q &&
-                pe_tab_signed && pe_stat && base && wfold_t && att && att_bias && ln_g && ln_b && out && pieces &&
+                pe_tab_signed && pe_stat && (PT || base) && wfold_t && att && att_bias && ln_g && ln_b && out && pieces &&
                 units_cap >= (PT ? 2 : (3 * ent_cap + 15) / 16 + 1) && lpf_aligned16(pieces));
     LPF_REQUIRE(!perm || ((PT || perm_lb) && n_nonempty));
     LPF_REQUIRE((n_counts == 0 || n_counts == 1 || n_counts == 3 || n_counts == 4) && ldo >= D + n_counts && (ldo & 3) == 0);
     LPF_REQUIRE(ldz >= D && ldq >= D && ldz < (1ll << 31) && ldq < (1ll << 31) && (ldz & (ZB ? 7 : 3)) == 0 &&
                 (ldq & 3) == 0 && lpf_aligned16(entries) && lpf_aligned16(Z) && lpf_aligned16(q) &&
-                lpf_aligned16(pe_tab_signed) && lpf_aligned16(base) && lpf_aligned16(wfold_t) && lpf_aligned16(att) &&
+                lpf_aligned16(pe_tab_signed) && (PT || lpf_aligned16(base)) && lpf_aligned16(wfold_t) && lpf_aligned16(att) &&
                 lpf_aligned16(att_bias) && lpf_aligned16(ln_g) && lpf_aligned16(ln_b) && lpf_aligned16(out));
     const RowsArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), (uint32_t)ldz,
                      q, (uint32_t)ldq, pe_tab_signed, pe_stat, base, wfold_t, att, att_bias, ln_g, ln_b, out, ldo,
                      n_counts, sel_ctl, pieces, units_cap, perm, perm_lb, n_nonempty,
-                     static_cast<const int4 *>(pair_tab), blk_cnt};
+                     static_cast<const int4 *>(pair_tab), blk_cnt, pat_base, pat_grid, grid_n, grid_shift, grid_base,
+                     grid_ofs};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_cu = lpf_cu_count();
     if (n_cu == 0) return LPF_ERR_NO_DEVICE;
@@ -938,7 +1022,7 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
 #define LPF_ROWS_GO(GG, NTH, WTL, PER_CU)                                                           \
     do {                                                                                            \
         auto kern = pair_rows_kernel<GG, NTH, WTL, ZB, PT>;                                             \
-        constexpr size_t lds = PrLds<GG, NTH, WTL>::BYTES;                                          \
+        constexpr size_t lds = PrLds<GG, NTH, WTL, PT>::BYTES;                                      \
         LPF_SET_MAX_LDS(kern, lds);                                                                 \
         int64_t groups = (int64_t)n_cu * PER_CU * PR_GRID_MUL;                                      \
         const int64_t most = (bs + 15) / 16;   /* (a workgroup per 16 pairs at the very least) */   \
@@ -1031,26 +1115,30 @@ extern "C" int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const i
 extern "C" int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
                                             const void *entries, int64_t ent_cap, const float *Z, int64_t ldz,
                                             const float *q, int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
-                                            const float *base, const float *wfold_t, const float *att,
-                                            const float *att_bias, const float *ln_g, const float *ln_b, int32_t n_counts,
-                                            const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
-                                            int64_t ldo, int32_t *perm, int64_t *n_nonempty, void *stream) {
-    return rows_launch<false, true>(D, bs, nullptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, base, wfold_t,
+                                            const float *pat_base, const void *pat_grid, int32_t grid_n,
+                                            int32_t grid_shift, int32_t grid_base, float grid_ofs, const float *wfold_t,
+                                            const float *att, const float *att_bias, const float *ln_g, const float *ln_b,
+                                            int32_t n_counts, const int64_t *sel_ctl, float *pieces, int64_t units_cap,
+                                            float *out, int64_t ldo, int32_t *perm, int64_t *n_nonempty, void *stream) {
+    return rows_launch<false, true>(D, bs, nullptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, nullptr, wfold_t,
                                     att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream, perm,
-                                    nullptr, n_nonempty, pair_tab, blk_cnt);
+                                    nullptr, n_nonempty, pair_tab, blk_cnt, pat_base, static_cast<const uint8_t *>(pat_grid),
+                                    grid_n, grid_shift, grid_base, grid_ofs);
 }
 
 extern "C" int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
                                               const void *entries, int64_t ent_cap, const void *Z_bf16, int64_t ldz,
                                               const float *q, int64_t ldq, const float *pe_tab_signed,
-                                              const float *pe_stat, const float *base, const float *wfold_t,
-                                              const float *att, const float *att_bias, const float *ln_g,
-                                              const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces,
-                                              int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
-                                              int64_t *n_nonempty, void *stream) {
-    return rows_launch<true, true>(D, bs, nullptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, base,
+                                              const float *pe_stat, const float *pat_base, const void *pat_grid,
+                                              int32_t grid_n, int32_t grid_shift, int32_t grid_base, float grid_ofs,
+                                              const float *wfold_t, const float *att, const float *att_bias,
+                                              const float *ln_g, const float *ln_b, int32_t n_counts,
+                                              const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
+                                              int64_t ldo, int32_t *perm, int64_t *n_nonempty, void *stream) {
+    return rows_launch<true, true>(D, bs, nullptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, nullptr,
                                    wfold_t, att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream,
-                                   perm, nullptr, n_nonempty, pair_tab, blk_cnt);
+                                   perm, nullptr, n_nonempty, pair_tab, blk_cnt, pat_base,
+                                   static_cast<const uint8_t *>(pat_grid), grid_n, grid_shift, grid_base, grid_ofs);
 }
 
 /* floats of one piece record of lpf_pair_attention_rows_* (D accumulators, m, l, padded to whole 128-byte lines) */

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, fold, graph
+from . import _lib, fold, graph, patterns
 from . import dist as lpf_dist
 from ._lib import FLAG_RELU, check, ptr
 from .profile import KernelTimer
@@ -1353,16 +1353,14 @@ class LinkTransformer(nn.Module):
     FLIP_BREAK_EVEN = {128: 5.0, 256: 24.0}
 
     @_on_device
-    def flips_per_entry(self, n_pairs: int = 4096, seed: int = 0) -> float:
-        """Mean number of hidden units of the PE MLPs (both argument orders, ``2 D`` per entry) whose ReLU state differs
-        from the one at (0, 0), over the selected entries of a sample batch drawn from the model's OWN graph and PPR
-        matrix (half existing edges, half uniform pairs -- the selection kernels run on it).  This is what the cost of
-        the activation-pattern attention kernel depends on; a property of the ``ppr_encoder_*`` weights
-        (reference link_transformer.py:67-76) and of the PPR values, evaluated once per parameter version."""
-        w = self._fold()
-        hit = getattr(self, "_flip_est", None)
-        if hit is not None and hit[0] is self._folded[0]:
-            return hit[1]
+    def _entry_sample(self, n_pairs: int = 4096, seed: int = 0):
+        """Per type the (pa, pb) values of the entries a sample batch selects -- half existing edges, half uniform
+        pairs of the model's OWN graph and PPR matrix, the selection kernels run on it.  A property of the graph, the
+        PPR matrix and the thresholds, not of the weights: drawn once per model.  It decides which activation patterns
+        are tabulated (``patterns.build``) and feeds ``flips_per_entry``; results never depend on it."""
+        hit = getattr(self, "_sample_cache", None)
+        if hit is not None:
+            return hit
         with torch.no_grad():
             mask = self._device_graph("mask", self._data_obj("mask", False))
             gen = torch.Generator(device=self.device)
@@ -1378,20 +1376,61 @@ class LinkTransformer(nn.Module):
             sel = self._select(batch, False, None)
             bs = sel["bs"]
             tot = sel["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)[:, bs].tolist()
-            flips, base = 0.0, 0
+            out, base = [None, None, None], 0
             for t in range({"all": 3, "1-hop": 2, "cn": 1}[self.mask]):
-                pa, pb = sel["sel_pa"][base:base + tot[t]], sel["sel_pb"][base:base + tot[t]]
+                out[t] = (sel["sel_pa"][base:base + tot[t]].clone(), sel["sel_pb"][base:base + tot[t]].clone())
                 base += tot[t]
+        self._sample_cache = out
+        return out
+
+    def _pattern_tables(self, w: dict) -> dict:
+        """Activation-pattern tables of the pair-major attention behind select4 (``lpformer_amd/patterns.py``), built on
+        the device once per parameter version and kept with the folded weights (one lifetime: recorded plans and
+        captured graphs hold pointers into both)."""
+        pt = w.get("patterns")
+        if pt is None:
+            n_types = {"all": 3, "1-hop": 2, "cn": 1}[self.mask]
+            sd = {k: v for k, v in self.state_dict().items()}
+            pt = w["patterns"] = patterns.build(sd, self.dim, n_types, self._entry_sample(), device=self.device)
+        return pt
+
+    @_on_device
+    def flips_per_entry(self, raw: bool = False) -> float:
+        """Mean number of hidden units of the PE MLPs (both argument orders, ``2 D`` per entry) whose ReLU state differs
+        from the one at (0, 0) and that the attention kernel has to find and correct one by one, over the entries of
+        ``_entry_sample()``.  Behind select4 the pair-major kernel reads the patterns of most entries from a table
+        (``_pattern_tables``): only entries in cells without a tabulated pattern count, unless ``raw``.  This is what the
+        cost of the activation-pattern kernels depends on; a property of the ``ppr_encoder_*`` weights
+        (reference link_transformer.py:67-76) and of the PPR values, evaluated once per parameter version."""
+        w = self._fold()
+        tabled = not raw and self._uses_select4() and self.attention_rows
+        hit = getattr(self, "_flip_est", None)
+        if hit is not None and hit[0] is self._folded[0] and hit[2] == tabled:
+            return hit[1]
+        with torch.no_grad():
+            sample = self._entry_sample()
+            pt = self._pattern_tables(w) if tabled else None
+            flips, total = 0.0, 0
+            for t in range({"all": 3, "1-hop": 2, "cn": 1}[self.mask]):
+                pa, pb = sample[t]
+                total += pa.numel()
                 if pa.numel() == 0:
                     continue
                 tab, st = w["flip_tab"][t], w["pe_stat"][t]     # rows (ta, tc, td, beta) times the unit's sign at (0, 0)
+                slow = None
+                if pt is not None:
+                    ia, ib = patterns.cell_index(pa, pt["geo"]), patterns.cell_index(pb, pt["geo"])
+                    g = pt["grid"][t]
+                    slow = ((g[ia, ib] >= patterns.AMBIGUOUS) | (g[ib, ia] >= patterns.AMBIGUOUS)) & \
+                        (torch.maximum(pa, pb) > st[7])
                 for x, y in ((pa, pb), (pb, pa)):
                     var = st[0] * x * x + st[1] * y * y + st[2] + 2.0 * (st[3] * x * y + st[4] * x + st[5] * y)
                     r = torch.rsqrt(var.clamp_min(0.0) + 1e-5)
                     z = r[:, None] * (x[:, None] * tab[:, 0] + y[:, None] * tab[:, 1] + tab[:, 2]) + tab[:, 3]
-                    flips += float((z < 0).sum().item())
-            est = flips / max(1, sum(tot))
-        self._flip_est = (self._folded[0], est)
+                    fl = (z < 0).sum(dim=1)
+                    flips += float((fl if slow is None else fl * slow).sum().item())
+            est = flips / max(1, total)
+        self._flip_est = (self._folded[0], est, tabled)
         return est
 
     def attention_kernel(self) -> str:
@@ -1447,7 +1486,13 @@ class LinkTransformer(nn.Module):
             extra = (ptr(perm), ptr(nfull)) if four else \
                 (ptr(perm), ptr(self._zero_workspace("att_perm_lb", 2 * _lib.ROWS_PERM_LB_WORDS, st)), ptr(nfull))
         zt = self._z_bf16(z) if self.precision == "bf16" else z
-        tabs = (ptr(zt), zt.stride(0), ptr(q), q.stride(0), ptr(w["flip_tab"]), ptr(w["pe_stat"]), ptr(w["flip_base"]),
+        if four:    # (the base vectors of the tabulated activation patterns + the grid that finds an entry's two)
+            pt = self._pattern_tables(w)
+            geo = pt["geo"]
+            bases = (ptr(pt["base"]), ptr(pt["grid"]), geo["n"], geo["shift"], geo["base"], geo["ofs"])
+        else:       # (the one pattern of (0, 0))
+            bases = (ptr(w["flip_base"]),)
+        tabs = (ptr(zt), zt.stride(0), ptr(q), q.stride(0), ptr(w["flip_tab"]), ptr(w["pe_stat"]), *bases,
                 ptr(w["wfold_t"]), ptr(w["att"]), ptr(layer.att.bias), ptr(layer.post_att_norm.weight),
                 ptr(layer.post_att_norm.bias), n_counts, ptr(ws.ctl), ptr(pieces), units_cap, ptr(out), out.stride(0))
         with KernelTimer.span("pair_attention_rows"):
