@@ -207,9 +207,22 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     };
     int64_t own_w = 0;
     int own_ne = 0;
+    constexpr int BLK_KEEP = 8;          // the first blocks of a lane's share stay in registers for the walk below
+    int2 kept_blk[BLK_KEEP];             // {weight, pairs with entries}
     if constexpr (PT) {
         if (wave < 2) {
-            for (int64_t i = 0; i < per; ++i) {
+#pragma unroll
+            for (int i = 0; i < BLK_KEEP; ++i) {
+                const int64_t B = (int64_t)lane * per + i;
+                kept_blk[i] = make_int2(0, 0);
+                if (i < per && B < nblk) {
+                    const int4 c = blk_at(B);
+                    kept_blk[i] = make_int2(EW * c.x + c.z, c.y);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BLK_KEEP; ++i) { own_w += kept_blk[i].x; own_ne += kept_blk[i].y; }
+            for (int64_t i = BLK_KEEP; i < per; ++i) {
                 const int64_t B = (int64_t)lane * per + i;
                 if (B < nblk) {
                     const int4 c = blk_at(B);
@@ -343,7 +356,18 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 int64_t B = (int64_t)lane * per, f = ex;
                 int nef = xn - own_ne;
                 if (lane == hl) {
-                    while (B + 1 < nblk && B + 1 < (int64_t)(lane + 1) * per) {
+                    // (the share's first blocks from registers -- no round trip per step; the rest, if any, from memory)
+                    const int64_t lim = (int64_t)(lane + 1) * per < nblk ? (int64_t)(lane + 1) * per : nblk;
+                    bool stop = false;
+#pragma unroll
+                    for (int i = 0; i < BLK_KEEP; ++i) {
+                        if (!stop && B + 1 < lim) {
+                            const int64_t fn = f + kept_blk[i].x;
+                            if (fn >= target) stop = true;
+                            else { f = fn; nef += kept_blk[i].y; ++B; }
+                        }
+                    }
+                    while (!stop && B + 1 < lim) {
                         const int4 c = blk_at(B);
                         const int64_t fn = f + (int64_t)EW * c.x + c.z;
                         if (fn >= target) break;
@@ -450,12 +474,12 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     // finished row of a pair from its (merged) softmax state: post_att_norm(o / (l + 1e-16) + bias)
     auto finish_row = [&](f32x2 o01, f32x2 o23, float l) __attribute__((always_inline)) {
         const float4 vb = lvec[lj], vg = lvec[G + lj], vbeta = lvec[2 * G + lj];   // (once per pair: not worth registers)
-        const float inv = 1.0f / (l + 1e-16f);
+        const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);   // (1 ulp: v_rcp_f32, not the IEEE division sequence)
         const float4 y = make_float4(o01.x * inv + vb.x, o01.y * inv + vb.y, o23.x * inv + vb.z, o23.y * inv + vb.w);
         const float mean = pr_group_sum<G>((y.x + y.y) + (y.z + y.w)) * (1.0f / (float)D);
         const float4 d = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
         const float var = pr_group_sum<G>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / (float)D);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
         float4 r = make_float4(d.x * rstd * vg.x + vbeta.x, d.y * rstd * vg.y + vbeta.y, d.z * rstd * vg.z + vbeta.z,
                                d.w * rstd * vg.w + vbeta.w);
         if (bad) r = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
