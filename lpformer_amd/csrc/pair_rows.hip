@@ -123,12 +123,12 @@ constexpr int pr_piece_floats(int D) { return (D + 4 + 31) / 32 * 32; }
 // (PT form: NP patterns per type instead of one, and no copy of Wfold^T -- its corrections are the exception there)
 constexpr int pr_patterns(int G, bool PT) { return !PT ? 1 : (G >= 64 ? LPF_ROWS_PATTERNS / 2 : LPF_ROWS_PATTERNS); }
 
-template <int G, int NTH, int WTL, bool PT = false>
+template <int G, int NTH, int WTL, bool PT = false, int NV = 1>
 struct PrLds {
-    static constexpr int D = 4 * G, NG = (NTH / 64) * (64 / G), NP = pr_patterns(G, PT);
-    static constexpr int TAB = 0, BASE = TAB + 3 * D, VEC = BASE + 3 * NP * D, CONST_ROW = VEC + 3 * G, STAT = CONST_ROW + G;
+    static constexpr int GG = G * NV, D = 4 * GG, NG = (NTH / 64) * (64 / G), NP = pr_patterns(GG, PT);
+    static constexpr int TAB = 0, BASE = TAB + 3 * D, VEC = BASE + 3 * NP * D, CONST_ROW = VEC + 3 * GG, STAT = CONST_ROW + GG;
     static constexpr int WT = STAT + 6;                      // (pe_stat: 3 x 8 floats)
-    static constexpr int REC = WT + (PT ? 0 : WTL) * D * G;  // int4 [NG][16]
+    static constexpr int REC = WT + (PT ? 0 : WTL) * D * GG; // int4 [NG][16]
     static constexpr int SC = REC + NG * 16;                 // f32x2 [NG][16]  (NG * 8 float4)
     static constexpr int META = SC + NG * 8;                 // int [NG][16]    (NG * 4 float4)
     static constexpr int TP = META + NG * 4;                 // int [3][PR_CHUNK + 4]
@@ -143,12 +143,15 @@ struct PrLds {
 
 // ZB: the node table Z is stored in bf16 (the bf16 throughput mode)
 // PT: the selection came from select4.hip (pair_tab / blk_cnt instead of the three type-major regions and type_ptr)
-template <int G, int NTH, int WTL_, bool ZB = false, bool PT = false>
+// NV: float4 vectors per lane -- a group of G lanes owns an entry, lane j its features (and hidden units) 4 (j + v G) ...
+//     + 3, v < NV; D = 4 G NV.  NV = 2 at D = 128 behind select4: four entries per wavefront step instead of two, i.e.
+//     half the per-entry work that does not depend on the feature (records, softmax scalars, reductions, branches)
+template <int G, int NTH, int WTL_, bool ZB = false, bool PT = false, int NV = 1>
 __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(const RowsArgs A) {
     using ZT = typename std::conditional<ZB, uint2, float4>::type;
-    using L = PrLds<G, NTH, WTL_, PT>;
-    constexpr int WTL = PT ? 0 : WTL_, NP = L::NP;
-    constexpr int D = 4 * G, EPW = 64 / G, NG = L::NG, T_LO = WTL == 1 ? 1 : 0, TPS = PR_CHUNK + 4, RSP = pr_piece_floats(D);
+    using L = PrLds<G, NTH, WTL_, PT, NV>;
+    constexpr int WTL = PT ? 0 : WTL_, NP = L::NP, GG = L::GG;
+    constexpr int D = 4 * GG, EPW = 64 / G, NG = L::NG, T_LO = WTL == 1 ? 1 : 0, TPS = PR_CHUNK + 4, RSP = pr_piece_floats(D);
     constexpr uint32_t PAIR_MASK = PT ? 0x1fffffffu : PR_PAIR_MASK;
     constexpr int SB = LPF_SELECT4_BLOCK;
     // PT: what a workgroup's share is balanced by is  EW * entries + pairs  -- the units of 16 entries are what takes time
@@ -156,12 +159,12 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     // entries costs a row store
     constexpr int EW = 4;
     extern __shared__ __attribute__((aligned(16))) float4 pr_lds[];
-    float4 *const ltab = pr_lds + L::TAB;        // [4][3][G]: row j of hidden unit 4 lj + j, type t -> ((j * 3 + t) * G + lj)
-    float4 *const lbase = pr_lds + L::BASE;      // [3][NP][4][G]
-    float4 *const lvec = pr_lds + L::VEC;        // [3][G]: att_bias, ln_g, ln_b by feature quad
-    float4 *const lconst = pr_lds + L::CONST_ROW;   // [G]: the row of a pair without entries
+    float4 *const ltab = pr_lds + L::TAB;        // [4][3][GG]: row j of hidden unit 4 q + j, type t -> ((j * 3 + t) * GG + q)
+    float4 *const lbase = pr_lds + L::BASE;      // [3][NP][4][GG]
+    float4 *const lvec = pr_lds + L::VEC;        // [3][GG]: att_bias, ln_g, ln_b by feature quad
+    float4 *const lconst = pr_lds + L::CONST_ROW;   // [GG]: the row of a pair without entries
     float *const lstat = reinterpret_cast<float *>(pr_lds + L::STAT);   // [3][8]
-    float4 *const lwt = pr_lds + L::WT;          // [WTL][D][G]
+    float4 *const lwt = pr_lds + L::WT;          // [WTL][D][GG]
     int4 *const lrec = reinterpret_cast<int4 *>(pr_lds + L::REC);
     f32x2 *const lsc = reinterpret_cast<f32x2 *>(pr_lds + L::SC);
     int *const lmeta = reinterpret_cast<int *>(pr_lds + L::META);
@@ -246,24 +249,24 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                 if constexpr (!PT) tb[u] = reinterpret_cast<const float4 *>(A.base)[i];
             }
         }
-        constexpr int NW = WTL > 0 ? (WTL * D * G + FT - 1) / FT : 1;
+        constexpr int NW = WTL > 0 ? (WTL * D * GG + FT - 1) / FT : 1;
         float4 tw[NW];
         if constexpr (WTL > 0) {
-            const float4 *src = reinterpret_cast<const float4 *>(A.wfoldT) + (int64_t)T_LO * D * G;
+            const float4 *src = reinterpret_cast<const float4 *>(A.wfoldT) + (int64_t)T_LO * D * GG;
 #pragma unroll
             for (int u = 0; u < NW; ++u) {
                 const int i = u * FT + ft;
-                if (i < WTL * D * G) tw[u] = src[i];
+                if (i < WTL * D * GG) tw[u] = src[i];
             }
         }
-        constexpr int NV = (3 * G + FT - 1) / FT;
-        float4 tv[NV];
+        constexpr int NVF = (3 * GG + FT - 1) / FT;
+        float4 tv[NVF];
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
+        for (int u = 0; u < NVF; ++u) {
             const int i = u * FT + ft;
-            if (i < 3 * G) {
-                const float *src = i < G ? A.att_bias : (i < 2 * G ? A.ln_g : A.ln_b);
-                tv[u] = *reinterpret_cast<const float4 *>(src + 4 * (i % G));
+            if (i < 3 * GG) {
+                const float *src = i < GG ? A.att_bias : (i < 2 * GG ? A.ln_g : A.ln_b);
+                tv[u] = *reinterpret_cast<const float4 *>(src + 4 * (i % GG));
             }
         }
         const float ts = ft < 24 ? A.pe_stat[ft] : 0.f;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             const int i = u * FT + ft;
             if (i < 3 * D) {
                 const int t = i / D, k = i % D;
-                ltab[((k & 3) * 3 + t) * G + (k >> 2)] = ta[u];
+                ltab[((k & 3) * 3 + t) * GG + (k >> 2)] = ta[u];
                 if constexpr (!PT) lbase[i] = tb[u];
             }
         }
@@ -298,13 +301,13 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
 #pragma unroll
             for (int u = 0; u < NW; ++u) {
                 const int i = u * FT + ft;
-                if (i < WTL * D * G) lwt[i] = tw[u];
+                if (i < WTL * D * GG) lwt[i] = tw[u];
             }
         }
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
+        for (int u = 0; u < NVF; ++u) {
             const int i = u * FT + ft;
-            if (i < 3 * G) lvec[i] = tv[u];
+            if (i < 3 * GG) lvec[i] = tv[u];
         }
         if (ft < 24) lstat[ft] = ts;
     }
@@ -471,38 +474,78 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         }
     }
 
-    // finished row of a pair from its (merged) softmax state: post_att_norm(o / (l + 1e-16) + bias)
-    auto finish_row = [&](f32x2 o01, f32x2 o23, float l) __attribute__((always_inline)) {
-        const float4 vb = lvec[lj], vg = lvec[G + lj], vbeta = lvec[2 * G + lj];   // (once per pair: not worth registers)
-        const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);   // (1 ulp: v_rcp_f32, not the IEEE division sequence)
-        const float4 y = make_float4(o01.x * inv + vb.x, o01.y * inv + vb.y, o23.x * inv + vb.z, o23.y * inv + vb.w);
-        const float mean = pr_group_sum<G>((y.x + y.y) + (y.z + y.w)) * (1.0f / (float)D);
-        const float4 d = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
-        const float var = pr_group_sum<G>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / (float)D);
-        const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-        float4 r = make_float4(d.x * rstd * vg.x + vbeta.x, d.y * rstd * vg.y + vbeta.y, d.z * rstd * vg.z + vbeta.z,
-                               d.w * rstd * vg.w + vbeta.w);
-        if (bad) r = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-        return r;
+    // a lane's NV feature quads as pairs of packed floats
+    struct Q4 { f32x2 a, b; };
+    auto q4_zero = [&](Q4 (&x)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) x[v] = Q4{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
     };
-    if (wave == 0 && grp == 0) lconst[lj] = finish_row(f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, 0.f);
+    // finished row of a pair from its (merged) softmax state: post_att_norm(o / (l + 1e-16) + bias); quad v of the lane
+    // goes to  out + row * ldo + 4 (lj + v G)
+    auto finish_row = [&](const Q4 (&o)[NV], float l, float4 (&r)[NV]) __attribute__((always_inline)) {
+        const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);   // (1 ulp: v_rcp_f32, not the IEEE division sequence)
+        float4 y[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 vb = lvec[lj + v * G];                // (once per pair: not worth registers)
+            y[v] = make_float4(o[v].a.x * inv + vb.x, o[v].a.y * inv + vb.y, o[v].b.x * inv + vb.z, o[v].b.y * inv + vb.w);
+            sum += (y[v].x + y[v].y) + (y[v].z + y[v].w);
+        }
+        const float mean = pr_group_sum<G>(sum) * (1.0f / (float)D);
+        float sq = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            y[v] = make_float4(y[v].x - mean, y[v].y - mean, y[v].z - mean, y[v].w - mean);
+            sq += (y[v].x * y[v].x + y[v].y * y[v].y) + (y[v].z * y[v].z + y[v].w * y[v].w);
+        }
+        const float var = pr_group_sum<G>(sq) * (1.0f / (float)D);
+        const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 vg = lvec[GG + lj + v * G], vbeta = lvec[2 * GG + lj + v * G];
+            r[v] = make_float4(y[v].x * rstd * vg.x + vbeta.x, y[v].y * rstd * vg.y + vbeta.y,
+                               y[v].z * rstd * vg.z + vbeta.z, y[v].w * rstd * vg.w + vbeta.w);
+            if (bad) r[v] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+        }
+    };
+    auto store_row = [&](int64_t pair, const float4 (&r)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(A.out + pair * A.ldo + off + 4 * G * v) = r[v];
+    };
+    if (wave == 0 && grp == 0) {
+        Q4 zero[NV];
+        q4_zero(zero);
+        float4 r[NV];
+        finish_row(zero, 0.f, r);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) lconst[lj + v * G] = r[v];
+    }
 
-    const float4 at = *reinterpret_cast<const float4 *>(A.att + off);
-    const f32x2 at01 = {at.x, at.y}, at23 = {at.z, at.w};
+    f32x2 at01[NV], at23[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float4 at = *reinterpret_cast<const float4 *>(A.att + off + 4 * G * v);
+        at01[v] = f32x2{at.x, at.y};
+        at23[v] = f32x2{at.z, at.w};
+    }
     int4 *const lr = lrec + gid * 16;
     f32x2 *const ls = lsc + gid * 16;
     int *const lm = lmeta + gid * 16;
 
-    auto z_row = [&](int node) __attribute__((always_inline)) {
-        if constexpr (ZB)
-            return *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(A.Z) +
-                                                    (uint64_t)(uint32_t)node * A.ldz + off);
-        else
+    auto z_row = [&](int node, ZT (&z)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if constexpr (ZB)
+                z[v] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(A.Z) +
+                                                        (uint64_t)(uint32_t)node * A.ldz + off + 4 * G * v);
+            else
 #ifdef PR_ABL_NOZ   /* (timing only, wrong results: every entry reads one of two rows of Z -- no random gather) */
-            return *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)(node & 1) * A.ldz + off);
+                z[v] = *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)(node & 1) * A.ldz + off + 4 * G * v);
 #else
-            return *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)node * A.ldz + off);
+                z[v] = *reinterpret_cast<const float4 *>(A.Z + (uint64_t)(uint32_t)node * A.ldz + off + 4 * G * v);
 #endif
+        }
     };
     auto z_wide = [&](const ZT &z) __attribute__((always_inline)) {
         if constexpr (ZB)
@@ -516,8 +559,10 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         const int c = (int)(__float_as_uint(v + A.grid_ofs) >> A.grid_shift) - A.grid_base;
         return c < 0 ? A.grid_n - 1 : (c < A.grid_n ? c : A.grid_n - 1);
     };
-    auto q_row = [&](int pair) __attribute__((always_inline)) {
-        return *reinterpret_cast<const float4 *>(A.q + (uint64_t)(uint32_t)pair * A.ldq + off);
+    auto q_row = [&](int pair, float4 (&q)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            q[v] = *reinterpret_cast<const float4 *>(A.q + (uint64_t)(uint32_t)pair * A.ldq + off + 4 * G * v);
     };
 
     for (int64_t c0 = P0; c0 < P1; c0 += PR_CHUNK) {
@@ -623,9 +668,10 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         const int n_empty = lctl[0], n_multi = lctl[1];
         // ---- pairs without entries: the constant row
         {
-            const float4 cr = lconst[lj];
-            for (int k = gid; k < n_empty; k += NG)
-                *reinterpret_cast<float4 *>(A.out + (c0 + llist[k]) * A.ldo + off) = cr;
+            float4 cr[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) cr[v] = lconst[lj + v * G];
+            for (int k = gid; k < n_empty; k += NG) store_row(c0 + llist[k], cr);
         }
         PR_STAMP(3);
         // ---- the chunk's units: 16 consecutive entries of the pair-major order each, EPW of them per wavefront and
@@ -699,35 +745,32 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             }
             int lro = 0;                 // (opaque zero: the reads below must stay behind the stores above)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(lro) :: "memory");
-            ZT za[4], zb[4];
+            constexpr int ZBATCH = NV == 1 ? 4 : 1;     // entries whose Z rows are requested together, a batch ahead
+            ZT za[ZBATCH][NV], zb[ZBATCH][NV];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) za[u] = z_row(lr[lro + u].y);
-            float4 qc = q_row((int)((uint32_t)lr[lro].x & PAIR_MASK));
+            for (int u = 0; u < ZBATCH; ++u) z_row(lr[lro + u].y, za[u]);
+            float4 qc[NV];
+            q_row((int)((uint32_t)lr[lro].x & PAIR_MASK), qc);
             float *const piece_u = A.pieces + (u_first + ul) * 2 * RSP;
             float m = -INFINITY, l = 0.f;
-            f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
-            // the last piece of a pair that started in an earlier unit: kept here, merged behind the walk (bit 7 of meta)
-            float hm = 0.f, hl = 0.f;
-            f32x2 ho01 = {0.f, 0.f}, ho23 = {0.f, 0.f};
+            Q4 o[NV];
+            q4_zero(o);
+            // the pair that started in an earlier unit and ends in this one (bit 7 of meta): merged behind the walk
             int hpair = -1;
 
-            auto entry = [&](const int i, const ZT zraw) __attribute__((always_inline)) {
-                const float4 zc = z_wide(zraw);
+            auto entry = [&](const int i, const ZT (&zraw)[NV]) __attribute__((always_inline)) {
                 const int4 rc = lr[lro + i];
                 const f32x2 r12 = ls[lro + i];
                 const int meta = lm[lro + i];
-                // the query row of the NEXT entry's pair: fetched only where the pair changes -- the next step waits for
-                // whatever this one requested, and most steps stay inside a pair
+                // (the NEXT entry's pair: its query row is fetched at the end of this step, and only where the pair changes)
                 const int pair_n = (int)((uint32_t)lr[lro + (i < 15 ? i + 1 : 15)].x & PAIR_MASK);
-                float4 qn = qc;
-                if (pair_n != (int)((uint32_t)rc.x & PAIR_MASK)) qn = q_row(pair_n);
+                const int pair_i = (int)((uint32_t)rc.x & PAIR_MASK);
                 const bool on = meta & 64;
                 const int t = meta & 3;
                 const float pa = __int_as_float(rc.z), pb = __int_as_float(rc.w);
                 const f32x2 pab = {pa, pb}, pba = {pb, pa};
-                const int pair_i = (int)((uint32_t)rc.x & PAIR_MASK);
-                const float4 *tabl = ltab + t * G + lj;
-                f32x2 k01, k23;
+                const float4 *tabl = ltab + t * GG + lj;
+                Q4 k[NV];
                 if constexpr (PT) {
                     // the base vectors of the pattern of (pa, pb) and of the pattern of (pb, pa), one order after the
                     // other (one association whatever the neighbours in the wavefront are: a pair's row depends on its
@@ -735,27 +778,34 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     const int i1 = (meta >> 9) & 63, i2 = (meta >> 15) & 63;
                     const float4 *b1 = lbase + i1 * D + lj, *b2 = lbase + i2 * D + lj;
                     const f32x2 c1 = r12.x * pab, c2 = r12.y * pba;
-                    {
-                        const float4 P1 = b1[0], Q1 = b1[G], R1 = b1[2 * G], B1 = b1[3 * G];
-                        k01 = f32x2{zc.x, zc.y} + (f32x2{P1.x, P1.y} * c1.x + (f32x2{Q1.x, Q1.y} * c1.y +
-                                                   (f32x2{R1.x, R1.y} * r12.x + f32x2{B1.x, B1.y})));
-                        k23 = f32x2{zc.z, zc.w} + (f32x2{P1.z, P1.w} * c1.x + (f32x2{Q1.z, Q1.w} * c1.y +
-                                                   (f32x2{R1.z, R1.w} * r12.x + f32x2{B1.z, B1.w})));
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const float4 zc = z_wide(zraw[v]);
+                        const float4 P1 = b1[v * G], Q1 = b1[GG + v * G], R1 = b1[2 * GG + v * G], B1 = b1[3 * GG + v * G];
+                        k[v].a = f32x2{zc.x, zc.y} + (f32x2{P1.x, P1.y} * c1.x + (f32x2{Q1.x, Q1.y} * c1.y +
+                                                      (f32x2{R1.x, R1.y} * r12.x + f32x2{B1.x, B1.y})));
+                        k[v].b = f32x2{zc.z, zc.w} + (f32x2{P1.z, P1.w} * c1.x + (f32x2{Q1.z, Q1.w} * c1.y +
+                                                      (f32x2{R1.z, R1.w} * r12.x + f32x2{B1.z, B1.w})));
                     }
-                    {
-                        const float4 P2 = b2[0], Q2 = b2[G], R2 = b2[2 * G], B2 = b2[3 * G];
-                        k01 += f32x2{P2.x, P2.y} * c2.x + (f32x2{Q2.x, Q2.y} * c2.y + (f32x2{R2.x, R2.y} * r12.y + f32x2{B2.x, B2.y}));
-                        k23 += f32x2{P2.z, P2.w} * c2.x + (f32x2{Q2.z, Q2.w} * c2.y + (f32x2{R2.z, R2.w} * r12.y + f32x2{B2.z, B2.w}));
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const float4 P2 = b2[v * G], Q2 = b2[GG + v * G], R2 = b2[2 * GG + v * G], B2 = b2[3 * GG + v * G];
+                        k[v].a += f32x2{P2.x, P2.y} * c2.x + (f32x2{Q2.x, Q2.y} * c2.y + (f32x2{R2.x, R2.y} * r12.y + f32x2{B2.x, B2.y}));
+                        k[v].b += f32x2{P2.z, P2.w} * c2.x + (f32x2{Q2.z, Q2.w} * c2.y + (f32x2{R2.z, R2.w} * r12.y + f32x2{B2.z, B2.w}));
                     }
                 } else {
                     const float4 *basel = lbase + t * D + lj;
                     const f32x2 cab = r12.x * pab + r12.y * pba;
                     const float cr = r12.x + r12.y;
-                    const float4 P0v = basel[0], Q0v = basel[G], R0v = basel[2 * G], C0v = basel[3 * G];
-                    k01 = f32x2{zc.x, zc.y} + (f32x2{P0v.x, P0v.y} * cab.x +
-                                               (f32x2{Q0v.x, Q0v.y} * cab.y + (f32x2{R0v.x, R0v.y} * cr + f32x2{C0v.x, C0v.y})));
-                    k23 = f32x2{zc.z, zc.w} + (f32x2{P0v.z, P0v.w} * cab.x +
-                                               (f32x2{Q0v.z, Q0v.w} * cab.y + (f32x2{R0v.z, R0v.w} * cr + f32x2{C0v.z, C0v.w})));
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const float4 zc = z_wide(zraw[v]);
+                        const float4 P0v = basel[v * G], Q0v = basel[GG + v * G], R0v = basel[2 * GG + v * G], C0v = basel[3 * GG + v * G];
+                        k[v].a = f32x2{zc.x, zc.y} + (f32x2{P0v.x, P0v.y} * cab.x +
+                                                      (f32x2{Q0v.x, Q0v.y} * cab.y + (f32x2{R0v.x, R0v.y} * cr + f32x2{C0v.x, C0v.y})));
+                        k[v].b = f32x2{zc.z, zc.w} + (f32x2{P0v.z, P0v.w} * cab.x +
+                                                      (f32x2{Q0v.z, Q0v.w} * cab.y + (f32x2{R0v.z, R0v.w} * cr + f32x2{C0v.z, C0v.w})));
+                    }
                 }
                 // whose units are looked at: PT -- only the entries of cells without a tabulated pattern (the others
                 // already carry the vectors of their own patterns: a correction against pattern 0 would count twice)
@@ -767,96 +817,122 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
 #else
                 if (__ballot((meta & 256) != 0)) {   // some entry of this wavefront lies outside its type's no-flip box
 #endif
-                f32x2 zz[4];
+                // one feature quad's four units (both orders) at a time: a unit that left the pattern of (0, 0) owes every
+                // lane of its group Wfold[:, k] |y_k| (pair_flip.hip: flipped lanes one at a time, the weights a step ahead)
+                const bool wt_lds = t >= T_LO && t < T_LO + WTL;
+                const float4 *lw = lwt + (wt_lds ? (t - T_LO) * D * GG : 0) + lj;
+                const float *wT = A.wfoldT + (int64_t)t * D * D + off;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 tj = tabl[3 * G * j];
-                    zz[j] = r12 * (tj.x * pab + (tj.y * pba + tj.z)) + tj.w;
-                }
-                const float zmin = fminf(fminf(fminf(zz[0].x, zz[0].y), fminf(zz[1].x, zz[1].y)),
-                                         fminf(fminf(zz[2].x, zz[2].y), fminf(zz[3].x, zz[3].y)));
-                const bool fl = zmin < 0.f && det;
-                if (__ballot(fl)) {
-                    // some unit of some group left the pattern of (0, 0): every lane of that group owes Wfold[:, k] |y_k|
-                    // (pair_flip.hip: one pass over the eight (order, unit-of-the-lane) slots, flipped lanes one at a time)
-                    const bool wt_lds = t >= T_LO && t < T_LO + WTL;
-                    const float4 *lw = lwt + (wt_lds ? (t - T_LO) * D * G : 0) + lj;
-                    const float *wT = A.wfoldT + (int64_t)t * D * D + off;
-                    const bool all_lds = WTL == 3 || __all(wt_lds || !fl);
-                    f32x2 wp01 = {0.f, 0.f}, wp23 = {0.f, 0.f};
-                    float vp = 0.f;
+                for (int vu = 0; vu < NV; ++vu) {
+                    f32x2 zz[4];
 #pragma unroll
-                    for (int oj = 0; oj < 8; ++oj) {
-                        const float zv = (oj & 4) ? zz[oj & 3].y : zz[oj & 3].x;
-                        uint64_t bm = __ballot(zv < 0.f && det);
-                        while (bm) {
-                            const int b = __builtin_ctzll(bm);
-                            bm &= bm - 1;
-                            const float val = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zv), b));
-                            const bool mine = b / G == grp;
-                            const int kk = 4 * (b % G) + (oj & 3);
-                            float4 w = WTL > 0 ? lw[kk * G] : make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (!all_lds) {
-                                float4 wg = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (mine && !wt_lds) wg = *reinterpret_cast<const float4 *>(wT + (int64_t)kk * D);
-                                w.x = wt_lds ? w.x : wg.x; w.y = wt_lds ? w.y : wg.y;
-                                w.z = wt_lds ? w.z : wg.z; w.w = wt_lds ? w.w : wg.w;
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 tj = tabl[3 * GG * j + vu * G];
+                        zz[j] = r12 * (tj.x * pab + (tj.y * pba + tj.z)) + tj.w;
+                    }
+                    const float zmin = fminf(fminf(fminf(zz[0].x, zz[0].y), fminf(zz[1].x, zz[1].y)),
+                                             fminf(fminf(zz[2].x, zz[2].y), fminf(zz[3].x, zz[3].y)));
+                    const bool fl = zmin < 0.f && det;
+                    if (__ballot(fl)) {
+                        const bool all_lds = WTL == 3 || __all(wt_lds || !fl);
+                        Q4 wp[NV];
+                        q4_zero(wp);
+                        float vp = 0.f;
+#pragma unroll
+                        for (int oj = 0; oj < 8; ++oj) {
+                            const float zv = (oj & 4) ? zz[oj & 3].y : zz[oj & 3].x;
+                            uint64_t bm = __ballot(zv < 0.f && det);
+                            while (bm) {
+                                const int b = __builtin_ctzll(bm);
+                                bm &= bm - 1;
+                                const float val = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zv), b));
+                                const bool mine = b / G == grp;
+                                const int kk = 4 * (b % G + vu * G) + (oj & 3);
+                                float4 w[NV];
+#pragma unroll
+                                for (int v = 0; v < NV; ++v)
+                                    w[v] = WTL > 0 ? lw[kk * GG + v * G] : make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (!all_lds) {
+#pragma unroll
+                                    for (int v = 0; v < NV; ++v) {
+                                        float4 wg = make_float4(0.f, 0.f, 0.f, 0.f);
+                                        if (mine && !wt_lds) wg = *reinterpret_cast<const float4 *>(wT + (int64_t)kk * D + 4 * G * v);
+                                        w[v].x = wt_lds ? w[v].x : wg.x; w[v].y = wt_lds ? w[v].y : wg.y;
+                                        w[v].z = wt_lds ? w[v].z : wg.z; w[v].w = wt_lds ? w[v].w : wg.w;
+                                    }
+                                }
+#pragma unroll
+                                for (int v = 0; v < NV; ++v) {
+                                    k[v].a += wp[v].a * vp;
+                                    k[v].b += wp[v].b * vp;
+                                    wp[v] = Q4{f32x2{w[v].x, w[v].y}, f32x2{w[v].z, w[v].w}};
+                                }
+                                vp = mine ? val : 0.f;
                             }
-                            k01 += wp01 * vp;
-                            k23 += wp23 * vp;
-                            wp01 = f32x2{w.x, w.y};
-                            wp23 = f32x2{w.z, w.w};
-                            vp = mine ? val : 0.f;
+                        }
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            k[v].a += wp[v].a * vp;
+                            k[v].b += wp[v].b * vp;
                         }
                     }
-                    k01 += wp01 * vp;
-                    k23 += wp23 * vp;
                 }
                 }
-                const f32x2 x01 = k01 * f32x2{qc.x, qc.y}, x23 = k23 * f32x2{qc.z, qc.w};
-                const f32x2 y01 = x01 * 0.2f, y23 = x23 * 0.2f;
-                const f32x2 l01 = {fmaxf(x01.x, y01.x), fmaxf(x01.y, y01.y)}, l23 = {fmaxf(x23.x, y23.x), fmaxf(x23.y, y23.y)};
-                const f32x2 sp = l01 * at01 + l23 * at23;
+                f32x2 sp = {0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const f32x2 x01 = k[v].a * f32x2{qc[v].x, qc[v].y}, x23 = k[v].b * f32x2{qc[v].z, qc[v].w};
+                    const f32x2 y01 = x01 * 0.2f, y23 = x23 * 0.2f;
+                    const f32x2 l01 = {fmaxf(x01.x, y01.x), fmaxf(x01.y, y01.y)}, l23 = {fmaxf(x23.x, y23.x), fmaxf(x23.y, y23.y)};
+                    if (v == 0) sp = l01 * at01[v] + l23 * at23[v];
+                    else sp += l01 * at01[v] + l23 * at23[v];
+                }
                 const float s = pr_group_sum<G>(sp.x + sp.y);
                 if (on) {
                     if (meta & 4) {          // first entry of a piece: fresh state
                         m = -INFINITY; l = 0.f;
-                        o01 = f32x2{0.f, 0.f};
-                        o23 = f32x2{0.f, 0.f};
+                        q4_zero(o);
                     }
                     const float d = s - m;
                     const float e = __expf(-fabsf(d));
                     const bool up = d > 0.f;
                     const float sca = up ? e : 1.f, w = up ? 1.f : e;
                     l = fmaf(l, sca, w);
-                    o01 = o01 * sca + k01 * w;
-                    o23 = o23 * sca + k23 * w;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        o[v].a = o[v].a * sca + k[v].a * w;
+                        o[v].b = o[v].b * sca + k[v].b * w;
+                    }
                     m = fmaxf(m, s);
                     if (meta & 8) {          // last entry of the piece
-                        if (meta & 128) {    // ... the LAST piece of a pair in several pieces: merged behind the walk
-                            hm = m; hl = l; ho01 = o01; ho23 = o23; hpair = pair_i;
-                        } else if (meta & 16) {   // ... another piece of such a pair: its state waits for the merge
+                        if (meta & 128) hpair = pair_i;   // ... the LAST piece of a pair in several pieces: merged behind the walk
+                        if (meta & 16) {     // ... a piece of such a pair: its state waits for the merge
                             float *dst = piece_u + ((meta & 32) ? 0 : RSP);
-                            *reinterpret_cast<float4 *>(dst + off) = make_float4(o01.x, o01.y, o23.x, o23.y);
+#pragma unroll
+                            for (int v = 0; v < NV; ++v)
+                                *reinterpret_cast<float4 *>(dst + off + 4 * G * v) = make_float4(o[v].a.x, o[v].a.y, o[v].b.x, o[v].b.y);
                             if (lj == 0) *reinterpret_cast<float2 *>(dst + D) = make_float2(m, l);
                         } else {
-                            *reinterpret_cast<float4 *>(A.out + (int64_t)pair_i * A.ldo + off) = finish_row(o01, o23, l);
+                            float4 r[NV];
+                            finish_row(o, l, r);
+                            store_row(pair_i, r);
                         }
                     }
                 }
-                qc = qn;
+                if (pair_n != pair_i) q_row(pair_n, qc);   // (behind the last use of this entry's row; most steps stay inside a pair)
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto batch = [&](const int qt, const ZT (&zc4)[4], ZT (&zn4)[4]) __attribute__((always_inline)) {
-                const int nb = qt < 3 ? 4 * qt + 4 : 12;
+            auto batch = [&](const int qt, const ZT (&zc4)[ZBATCH][NV], ZT (&zn4)[ZBATCH][NV]) __attribute__((always_inline)) {
+                constexpr int NQ = 16 / ZBATCH;
+                const int nb = qt < NQ - 1 ? ZBATCH * qt + ZBATCH : 16 - ZBATCH;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) zn4[u] = z_row(lr[lro + nb + u].y);
+                for (int u = 0; u < ZBATCH; ++u) z_row(lr[lro + nb + u].y, zn4[u]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) entry(4 * qt + u, zc4[u]);
+                for (int u = 0; u < ZBATCH; ++u) entry(ZBATCH * qt + u, zc4[u]);
             };
 #pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 8 / ZBATCH; ++h) {
                 batch(2 * h, za, zb);
                 batch(2 * h + 1, zb, za);
             }
@@ -872,35 +948,36 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                             __builtin_amdgcn_s_sleep(2);
                     asm volatile("" ::: "memory");
                     float mx = -INFINITY, den = 0.f;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int u = ua_l; u < ul; u += 4) {   // (four pieces requested together: a hub pair has dozens)
+                    Q4 acc[NV];
+                    q4_zero(acc);
+                    for (int u = ua_l; u <= ul; u += 4) {   // (four pieces requested together: a hub pair has dozens)
                         float2 h[4];
-                        float4 b[4];
+                        float4 b[4][NV];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const int uu = u + i < ul ? u + i : ul - 1;
+                            const int uu = u + i <= ul ? u + i : ul;
                             const float *rp = A.pieces + ((u_first + uu) * 2 + (uu == ua_l ? 1 : 0)) * RSP;
                             h[i] = *reinterpret_cast<const float2 *>(rp + D);
-                            b[i] = *reinterpret_cast<const float4 *>(rp + off);
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) b[i][v] = *reinterpret_cast<const float4 *>(rp + off + 4 * G * v);
                         }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            if (u + i >= ul) break;
+                            if (u + i > ul) break;
                             const float mn = fmaxf(mx, h[i].x);
                             const float sa = __expf(mx - mn), sb = __expf(h[i].x - mn);
                             den = fmaf(den, sa, h[i].y * sb);
-                            v.x = v.x * sa + b[i].x * sb; v.y = v.y * sa + b[i].y * sb;
-                            v.z = v.z * sa + b[i].z * sb; v.w = v.w * sa + b[i].w * sb;
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) {
+                                acc[v].a = acc[v].a * sa + f32x2{b[i][v].x, b[i][v].y} * sb;
+                                acc[v].b = acc[v].b * sa + f32x2{b[i][v].z, b[i][v].w} * sb;
+                            }
                             mx = mn;
                         }
                     }
-                    const float mn = fmaxf(mx, hm);
-                    const float sa = __expf(mx - mn), sb = __expf(hm - mn);
-                    den = fmaf(den, sa, hl * sb);
-                    v.x = v.x * sa + ho01.x * sb; v.y = v.y * sa + ho01.y * sb;
-                    v.z = v.z * sa + ho23.x * sb; v.w = v.w * sa + ho23.y * sb;
-                    *reinterpret_cast<float4 *>(A.out + (int64_t)hpair * A.ldo + off) =
-                        finish_row(f32x2{v.x, v.y}, f32x2{v.z, v.w}, den);
+                    float4 r[NV];
+                    finish_row(acc, den, r);
+                    store_row(hpair, r);
                 }
             }
 #ifdef PR_STAMPS
@@ -914,16 +991,18 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             const int k = llist[PR_CHUNK + mk];
             const int64_t ua = (v0 + lcum[k]) >> 4, ub = (v0 + lcum[k + 1] - 1) >> 4;
             float mx = -INFINITY, den = 0.f;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            Q4 acc[NV];
+            q4_zero(acc);
             for (int64_t u = ua; u <= ub; u += 4) {   // (four pieces requested together: a hub pair has dozens)
                 float2 h[4];
-                float4 b[4];
+                float4 b[4][NV];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int64_t uu = u + i <= ub ? u + i : ub;
                     const float *rp = A.pieces + (uu * 2 + (uu == ua ? 1 : 0)) * RSP;
                     h[i] = *reinterpret_cast<const float2 *>(rp + D);
-                    b[i] = *reinterpret_cast<const float4 *>(rp + off);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) b[i][v] = *reinterpret_cast<const float4 *>(rp + off + 4 * G * v);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -931,12 +1010,17 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     const float mn = fmaxf(mx, h[i].x);
                     const float sa = __expf(mx - mn), sb = __expf(h[i].x - mn);
                     den = fmaf(den, sa, h[i].y * sb);
-                    v.x = v.x * sa + b[i].x * sb; v.y = v.y * sa + b[i].y * sb;
-                    v.z = v.z * sa + b[i].z * sb; v.w = v.w * sa + b[i].w * sb;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        acc[v].a = acc[v].a * sa + f32x2{b[i][v].x, b[i][v].y} * sb;
+                        acc[v].b = acc[v].b * sa + f32x2{b[i][v].z, b[i][v].w} * sb;
+                    }
                     mx = mn;
                 }
             }
-            *reinterpret_cast<float4 *>(A.out + (c0 + k) * A.ldo + off) = finish_row(f32x2{v.x, v.y}, f32x2{v.z, v.w}, den);
+            float4 r[NV];
+            finish_row(acc, den, r);
+            store_row(c0 + k, r);
         }
         PR_STAMP(5);
     }
@@ -1043,10 +1127,10 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
 #else
 #define PR_GRID_MUL 1
 #endif
-#define LPF_ROWS_GO(GG, NTH, WTL, PER_CU)                                                           \
+#define LPF_ROWS_GO(GQ, NTH, WTL, PER_CU, NVV)                                                      \
     do {                                                                                            \
-        auto kern = pair_rows_kernel<GG, NTH, WTL, ZB, PT>;                                             \
-        constexpr size_t lds = PrLds<GG, NTH, WTL, PT>::BYTES;                                      \
+        auto kern = pair_rows_kernel<GQ, NTH, WTL, ZB, PT, NVV>;                                        \
+        constexpr size_t lds = PrLds<GQ, NTH, WTL, PT, NVV>::BYTES;                                 \
         LPF_SET_MAX_LDS(kern, lds);                                                                 \
         int64_t groups = (int64_t)n_cu * PER_CU * PR_GRID_MUL;                                      \
         const int64_t most = (bs + 15) / 16;   /* (a workgroup per 16 pairs at the very least) */   \
@@ -1055,16 +1139,20 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
         hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(NTH), lds, s, a);                     \
     } while (0)
     switch (D) {
-        case 32: LPF_ROWS_GO(8, 512, 3, 2); break;
-        case 64: LPF_ROWS_GO(16, 512, 3, 2); break;
-#ifdef PR_CFG128   /* tuning aid: NTH, WTL, PER_CU of the D = 128 launch */
+        case 32: LPF_ROWS_GO(8, 512, 3, 2, 1); break;
+        case 64: LPF_ROWS_GO(16, 512, 3, 2, 1); break;
+#ifdef PR_CFG128   /* tuning aid: G, NTH, WTL, PER_CU, NV of the D = 128 launch */
 #define LPF_ROWS_GO_(...) LPF_ROWS_GO(__VA_ARGS__)
-        case 128: LPF_ROWS_GO_(32, PR_CFG128); break;
+        case 128: LPF_ROWS_GO_(PR_CFG128); break;
 #undef LPF_ROWS_GO_
 #else
-        case 128: LPF_ROWS_GO(32, 1024, 1, 1); break;
+        case 128:
+            // behind select4 (patterns by table): 16 lanes x 8 features per entry, four entries per wavefront step
+            if constexpr (PT) LPF_ROWS_GO(16, 1024, 0, 1, 2);
+            else LPF_ROWS_GO(32, 1024, 1, 1, 1);
+            break;
 #endif
-        case 256: LPF_ROWS_GO(64, 256, 0, 3); break;
+        case 256: LPF_ROWS_GO(64, 256, 0, 3, 1); break;
         default: return LPF_ERR_UNSUPPORTED;
     }
 #undef LPF_ROWS_GO

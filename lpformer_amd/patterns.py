@@ -76,6 +76,25 @@ def _pack(bits: torch.Tensor) -> torch.Tensor:
     return (bits.view(c, w, 32).to(torch.int64) << sh).sum(-1)
 
 
+def _unique_rows(rows: torch.Tensor):
+    """``torch.unique(rows, dim=0, return_inverse=True)`` through a 64-bit hash of every row (the row-wise unique sorts
+    with a lexicographic comparator: ~100 s for 6e5 rows of 8 words on the device, the hashed one milliseconds); the hash
+    is checked -- every row must equal the representative of its key -- and the slow form is the fallback."""
+    mult = torch.tensor([0x9E3779B97F4A7C15 - (1 << 64), 0xC2B2AE3D27D4EB4F - (1 << 64), 0x165667B19E3779F9,
+                         0x27D4EB2F165667C5, 0x85EBCA77C2B2AE63 - (1 << 64), 0x2545F4914F6CDD1D, 0x5851F42D4C957F2D,
+                         0x14057B7EF767814F], dtype=torch.int64, device=rows.device)
+    w = rows.shape[1]
+    mult = mult.repeat((w + 7) // 8)[:w] + 2 * torch.arange(w, device=rows.device, dtype=torch.int64)
+    key = ((rows ^ (rows >> 29)) * mult).sum(dim=1)
+    ukey, inv = torch.unique(key, return_inverse=True)
+    first = torch.full((ukey.numel(),), rows.shape[0], dtype=torch.int64, device=rows.device)
+    first.scatter_reduce_(0, inv, torch.arange(rows.shape[0], device=rows.device), reduce="amin")
+    uniq = rows[first]
+    if not bool((uniq[inv] == rows).all()):      # (a collision of the hash)
+        return torch.unique(rows, dim=0, return_inverse=True)
+    return uniq, inv
+
+
 def classify(tab: torch.Tensor, st: torch.Tensor, geo: dict, chunk: int = 1 << 15):
     """tab float64 [D, 4] = (ta, tc, td, beta) of one PE MLP (unsigned), st float64 [6] (``fold.pe_tables``).  Returns
     (words int64 [n * n, W]: the pattern at every cell's centre, clean bool [n * n]); cell (i, j) = x in cell i, y in
@@ -149,9 +168,11 @@ def build(state: dict, dim: int, n_types: int, sample=None, device=None, m: int 
         # pattern 0: the one of the point (0, 0) itself (``fold.flip_tables``: r0 td + beta > 0)
         r0 = 1.0 / np.sqrt((bc * bc).mean() + 1e-5)
         s0 = _pack(torch.from_numpy((tab_h[:, 2] * r0 + be) > 0)[None, :].to(device))
-        uniq, inv = torch.unique(torch.cat([s0, words[clean]]), dim=0, return_inverse=True)
-        wsum = torch.zeros(uniq.shape[0], dtype=torch.float64, device=device)
-        wsum.index_add_(0, inv[1:], weight[clean])
+        uniq, inv = _unique_rows(torch.cat([s0, words[clean]]))
+        # (fp32 sums: they only rank the patterns, and an fp64 index_add_ is a compare-and-swap loop per element on the
+        #  device -- most cells share a few patterns: ~30 s per type at D = 256)
+        wsum = torch.zeros(uniq.shape[0], dtype=torch.float32, device=device)
+        wsum.index_add_(0, inv[1:], weight[clean].to(torch.float32))
         wsum[inv[0]] = float("inf")                       # id 0
         order = torch.argsort(wsum, descending=True)[:npat]
         ident = torch.full((uniq.shape[0],), AMBIGUOUS, dtype=torch.int64, device=device)
