@@ -637,42 +637,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         if (inl)
             for (int k = tid; k < n_units; k += NTH) lflag[k] = 0;
         pr_lds_barrier();
-        // ---- sort the chunk's pairs (empty / in several pieces); the count features go out at once
-        for (int k = tid; k < cn; k += NTH) {
-            int n0, n1, n2;
-            if constexpr (PT) {
-                n0 = ltp[TPS + k]; n1 = ltp[2 * TPS + k]; n2 = lcum[k + 1] - lcum[k] - n0 - n1;
-            } else {
-                n0 = ltp[k + 1] - ltp[k]; n1 = ltp[TPS + k + 1] - ltp[TPS + k]; n2 = ltp[2 * TPS + k + 1] - ltp[2 * TPS + k];
-            }
-            const int np = n0 + n1 + n2;
-            // PT with an order for the tail: a pair without entries gets neither row nor counts -- the tail knows the
-            // constant row (lpf_tail_chain_rows_perm_*: row_empty) and never reads them
-            const bool skip = PT && A.perm != nullptr && np == 0;
-            if (skip) continue;
-            if (np == 0) {
-                llist[atomicAdd(&lctl[0], 1)] = k;
-            } else if (((v0 + lcum[k]) >> 4) != ((v0 + lcum[k + 1] - 1) >> 4)) {
-                llist[PR_CHUNK + atomicAdd(&lctl[1], 1)] = k;
-            }
-            if (A.n_counts > 0) {
-                float *o = A.out + (c0 + k) * A.ldo + D;
-                const float f0 = (float)n0, f1 = (float)n1, f2 = (float)n2;
-                if (A.n_counts == 4) { o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f0 + f1; }
-                else if (A.n_counts == 3) { o[0] = f0; o[1] = f1; o[2] = f0 + f1; }
-                else { o[0] = f0; }
-            }
-        }
-        pr_lds_barrier();
         PR_STAMP(2);
-        const int n_empty = lctl[0], n_multi = lctl[1];
-        // ---- pairs without entries: the constant row
-        {
-            float4 cr[NV];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) cr[v] = lconst[lj + v * G];
-            for (int k = gid; k < n_empty; k += NG) store_row(c0 + llist[k], cr);
-        }
         PR_STAMP(3);
         // ---- the chunk's units: 16 consecutive entries of the pair-major order each, EPW of them per wavefront and
         //      ticket.  Lane i < 16 of a group finds entry i of its unit (binary search in the chunk's starts), fetches
@@ -985,6 +950,48 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
 #endif
         }
         PR_STAMP(4);
+        // ---- the chunk's count features, and its pairs sorted (empty / in several pieces) -- BEHIND the units: nothing of
+        //      this is needed to walk them, and the wavefronts that run out of units early do their share meanwhile.  PT
+        //      with an order for the tail and a chunk whose pieces are merged inline: no list is read at all
+        const bool lists = !(PT && A.perm != nullptr) || !inl;
+        for (int k = tid; k < cn; k += NTH) {
+            int n0, n1, n2;
+            if constexpr (PT) {
+                n0 = ltp[TPS + k]; n1 = ltp[2 * TPS + k]; n2 = lcum[k + 1] - lcum[k] - n0 - n1;
+            } else {
+                n0 = ltp[k + 1] - ltp[k]; n1 = ltp[TPS + k + 1] - ltp[TPS + k]; n2 = ltp[2 * TPS + k + 1] - ltp[2 * TPS + k];
+            }
+            const int np = n0 + n1 + n2;
+            // PT with an order for the tail: a pair without entries gets neither row nor counts -- the tail knows the
+            // constant row (lpf_tail_chain_rows_perm_*: row_empty) and never reads them
+            const bool skip = PT && A.perm != nullptr && np == 0;
+            if (skip) continue;
+            if (lists) {
+                if (np == 0) {
+                    llist[atomicAdd(&lctl[0], 1)] = k;
+                } else if (((v0 + lcum[k]) >> 4) != ((v0 + lcum[k + 1] - 1) >> 4)) {
+                    llist[PR_CHUNK + atomicAdd(&lctl[1], 1)] = k;
+                }
+            }
+            if (A.n_counts > 0) {
+                float *o = A.out + (c0 + k) * A.ldo + D;
+                const float f0 = (float)n0, f1 = (float)n1, f2 = (float)n2;
+                if (A.n_counts == 4) { o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f0 + f1; }
+                else if (A.n_counts == 3) { o[0] = f0; o[1] = f1; o[2] = f0 + f1; }
+                else { o[0] = f0; }
+            }
+        }
+        int n_multi = 0;
+        if (lists) {
+            pr_lds_barrier();
+            const int n_empty = lctl[0];
+            n_multi = lctl[1];
+            // ---- pairs without entries: the constant row
+            float4 cr[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) cr[v] = lconst[lj + v * G];
+            for (int k = gid; k < n_empty; k += NG) store_row(c0 + llist[k], cr);
+        }
         // ---- (chunks of more than PR_FLAGS units) pairs in several pieces: one barrier, then merged in unit order
         if (!inl) __syncthreads();
         for (int mk = gid; mk < (inl ? 0 : n_multi); mk += NG) {
