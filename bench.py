@@ -329,6 +329,8 @@ def main():
     model.select4_threads = args.select4_threads
     if os.environ.get("LPF_SELECT_BLOCKS"):                      # A/B aid: "0" = lpf_select3_plan / _run on every path
         model.select_blocks = os.environ["LPF_SELECT_BLOCKS"] != "0"
+    if os.environ.get("LPF_TAIL_FOLD_E"):                        # A/B aid: "0" = the tail multiplies A_e r_e itself
+        model.tail_fold_e = os.environ["LPF_TAIL_FOLD_E"] != "0"
     enc_plan = None
     if world > 1:
         # encoder layout: measure the whole encoder on one GPU (replicated mode) and the all-gather of an [N, D] fp32

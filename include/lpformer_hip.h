@@ -600,6 +600,19 @@ int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, 
                                    float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
                                    int64_t *n_nonempty, void *stream);
 
+/* lpf_tail_chain_rows_perm_f32 (other_models.py:80-179, link_transformer.py:101-105,170-177 as there) with the elementwise
+ * branch's share of the folded score head done already: t_e [M, ldte >= 2 D] = A_e r_e -- lpf_dense_chain_side_f32 run with
+ * A_e (the first D columns of the fold lins0([ew | pw]) = A_e r_e + A_p r_p + c, no bias) as its second layer.  Stage C
+ * starts from t_e and runs the r_p k-groups of wC_packed only (the same image; its A_e k-groups are skipped); workgroups
+ * of pairs without selected nodes compute w_dot . ReLU(t_e + bC_empty) + b_dot without a matrix instruction.  The product
+ * A_e r_e is the same fp32 MFMA product either way -- it moves from the launch that is bound by the matrix pipe into the
+ * one that is bound by its gather. */
+int lpf_tail_chain_rows_perm_te_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
+                                    const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
+                                    const float *t_e, int64_t ldte, const float *wC_packed, const float *bC,
+                                    const float *w_dot, const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
+                                    const int64_t *n_full, const float *bC_empty, const float *row_empty, float *logit,
+                                    float *prob, void *stream);
 int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
                                  const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
                                  const float *r_e, int64_t ldre, const float *wC_packed, const float *bC,

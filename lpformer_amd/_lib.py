@@ -75,6 +75,8 @@ HIP_PROTOTYPES = {
                                        vp, vp, vp, vp, i32, vp, vp, i64, vp, i64, vp, vp, vp],
     "lpf_tail_chain_rows_perm_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp, vp],
+    "lpf_tail_chain_rows_perm_te_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                        vp, vp, vp],
     "lpf_tail_chain_rows_perm_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, vp],
     "lpf_tail_chain_rows_split": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,

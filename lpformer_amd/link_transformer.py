@@ -155,7 +155,7 @@ class DenseChain:
 
     BUILT = {(2, 0), (3, 0), (4, 0), (5, 0), (8, 0), (9, 0), (16, 0), (17, 0), (32, 0), (2, 2), (4, 4), (8, 8),
              (16, 16), (3, 2), (5, 4), (9, 8), (17, 16)}
-    BUILT_GATHER = {1: {(2, 0), (4, 0), (8, 0), (16, 0), (2, 2), (4, 4), (8, 8), (16, 16)},
+    BUILT_GATHER = {1: {(2, 0), (4, 0), (8, 0), (16, 0), (2, 2), (4, 4), (8, 8), (16, 16), (8, 16)},
                     2: {(2, 0), (4, 0), (8, 0), (16, 0)}}
 
     def __init__(self, tag: str):
@@ -244,6 +244,7 @@ class MLP(nn.Module):
         self._pads = [_PaddedLinear() for _ in self.linears]
         self._chain = DenseChain("dense_chain_mlp")
         self._chain1 = DenseChain("dense_chain_mlp_hidden")  # first layer alone (LinkTransformer.score_pairs)
+        self._chain_e = DenseChain("dense_chain_mlp_hidden")  # first layer + the folded score head's columns for this branch
 
     def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, batch=None, in_mode=0) -> torch.Tensor:
         """x: [M, K] fp32 device rows (16-byte aligned).  Optionally writes the result into ``out`` (a strided view).
@@ -655,6 +656,12 @@ class LinkTransformer(nn.Module):
         # (0.165-0.168 against 0.163-0.166 ms: splitting the activations is vector work beside a vector-bound attention);
         # the parity mode keeps the fp32 MFMAs
         self.tail_split = False
+        # D = 128 behind the pair-major attention with an order: the elementwise branch's launch also multiplies its hidden
+        # activation by the folded score head's columns (t_e = A_e r_e, lpf_dense_chain_side_f32 with a second layer) and
+        # the tail starts stage C from that (lpf_tail_chain_rows_perm_te_f32).  Off: measured, the tail gets 16 us shorter
+        # (55.3 -> 39.6) and the other launch 18 us longer (30.9 -> 49.3: its second layer is not hidden under its
+        # gather), the pipelined step 0.1465-0.148 against 0.1443 ms -- the product costs the same wherever it runs
+        self.tail_fold_e = False
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self, train_ok: bool = False):
@@ -1671,7 +1678,8 @@ class LinkTransformer(nn.Module):
         a[:, d:d + pd] = ws0[:, d:] @ wp1
         c = bs0 + ws0[:, :d] @ be1 + ws0[:, d:] @ bp1
         out = (a.float().to(self.device), c.float().to(self.device), kpad)
-        self._score_fold_cache = (key, out)
+        # (A_e as a tensor of its own: the second layer of the elementwise branch's launch when the tail takes t_e)
+        self._score_fold_cache = (key, out, a[:, :d].float().contiguous().to(self.device))
         return out
 
     def _tail_tables(self, score_func, a, c):
@@ -1735,9 +1743,22 @@ class LinkTransformer(nn.Module):
             if one_pass and self.query_from == "table" and (d < 256 or self._uses_rows()):
                 q_side = (self._node_y(x_node, self._fold()), torch.empty(bs, d, dtype=torch.float32, device=self.device))
             side = self._fork()
+            # t_e = A_e r_e by the elementwise branch's own launch (second layer of its chain) where the pair-major tail
+            # with an order runs behind it: a third of that tail's matrix work moves into a launch bound by its gather
+            t_e = None
+            a_e = self._score_fold_cache[2]
+            fold_e = (self.tail_fold_e and one_pass and d == 128 and a_e.shape[0] == 2 * d and self._uses_rows() and
+                      self.tail_skip_empty and self.tail_precision == "f32" and not self.tail_split)
             with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
+                if fold_e:
+                    t = ew._chain_e.tables(ew.linears[0].weight, ew.linears[0].bias, ew.norm.weight, ew.norm.bias, a_e, None)
+                    t_e = torch.empty(bs, a_e.shape[0], dtype=torch.float32, device=self.device)
+                    if ew._chain_e.run(t, x_node, relu=True, batch=batch, in_mode=1, out=t_e, side=q_side) is None:
+                        t_e = None
                 t = ew._chain1.tables(ew.linears[0].weight, ew.linears[0].bias, ew.norm.weight, ew.norm.bias)
-                if ew._chain1.run(t, x_node, relu=True, batch=batch, in_mode=1, out=r[:, :d], side=q_side) is None:
+                if t_e is not None:
+                    pass
+                elif ew._chain1.run(t, x_node, relu=True, batch=batch, in_mode=1, out=r[:, :d], side=q_side) is None:
                     q_side = None
                     prod = torch.empty(bs, d, dtype=torch.float32, device=self.device)
                     with KernelTimer.span("pair_gather"):
@@ -1776,12 +1797,15 @@ class LinkTransformer(nn.Module):
                     if self.tail_precision == "f32" and self.tail_split:
                         name, sfx = "lpf_tail_chain_rows_split", "_split"
                         extra = extra or (None, None, None, None)
+                    elif t_e is not None and order:
+                        name, sfx = "lpf_tail_chain_rows_perm_te_f32", ""
                     else:
                         name = "lpf_tail_chain_rows" + ("_perm" if order else "") + ("_bf16" if b16 else "_f32")
                         sfx = "_bf16" if b16 else ""
+                    re_in = t_e if name.endswith("_te_f32") else r
                     check(getattr(lib, name)(
                         bs, d, self.count_dim, ptr(rows), rows.stride(0), ptr(tt["wB" + sfx]),
-                        ptr(tt["bB"]), ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(r), r.stride(0),
+                        ptr(tt["bB"]), ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(re_in), re_in.stride(0),
                         ptr(tt["wC" + sfx]), ptr(tt["bC"]), ptr(tt["w_dot"]), ptr(tt["b_dot"]),
                         ptr(ws.ctl), *extra, ptr(res) if logits else None, None if logits else ptr(res), st), name)
                 return res

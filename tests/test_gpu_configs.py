@@ -762,6 +762,31 @@ def test_query_table_follows_an_in_place_update_of_lin_l(name, scale):
     assert torch.equal(got, after)
 
 
+
+def test_elementwise_share_of_the_score_head_in_the_side_launch():
+    """``tail_fold_e`` (D = 128): the elementwise branch's launch multiplies its hidden activation by the folded score
+    head's columns (``lpf_dense_chain_side_f32`` with a second layer) and ``lpf_tail_chain_rows_perm_te_f32`` starts its
+    last stage from that product -- the same fp32 products in another launch: logits within 2e-5 of the default form's and
+    of the oracle's, pairs without selected nodes (no matrix instruction left for them) included."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup("collab", scale=0.1, bs=3000)
+    assert model.dim == 128
+    model.attention_impl = "flip"
+    tb = torch.from_numpy(batch).to(DEV)
+    h = model.propagate()
+    outs = {}
+    for fold_e in (False, True):
+        model.tail_fold_e = fold_e
+        outs[fold_e] = model.score_pairs(tb, h, score, logits=True).clone()
+        assert model.check_selection()
+    scale_l = max(1.0, float(outs[False].abs().max()))
+    assert (outs[True] - outs[False]).abs().max().item() <= 2e-5 * scale_l
+    assert not torch.equal(outs[True], outs[False]) or True     # (different launches: equal bits are not required)
+    sample, ref = _oracle_sample(model, score, data, args, batch, h)
+    k = sample.shape[1]
+    err = np.abs(outs[True][:k].cpu().numpy() - ref["logit"]).max()
+    assert err <= 2e-5 * max(1.0, float(np.abs(ref["logit"]).max())), err
+
+
 @pytest.mark.parametrize("name,scale,dim", [("collab", 0.1, 128), ("cora", 1.0, 256), ("ppa", 0.02, 64), ("tiny", 1.0, 32)])
 def test_split_bf16_tail_keeps_fp32_accuracy(name, scale, dim):
     """The dense tail's two GEMMs as split-bf16 products (``tail_split``, the default of the parity mode: weights as
