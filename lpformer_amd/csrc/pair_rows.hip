@@ -1159,7 +1159,12 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
             else LPF_ROWS_GO(32, 1024, 1, 1, 1);
             break;
 #endif
-        case 256: LPF_ROWS_GO(64, 256, 0, 3, 1); break;
+        case 256:
+            // (behind select4 the pattern tables fill the LDS: ONE workgroup per CU, so it has to be a large one -- 32
+            //  lanes x 8 features per entry, sixteen wavefronts)
+            if constexpr (PT) LPF_ROWS_GO(32, 1024, 0, 1, 2);
+            else LPF_ROWS_GO(64, 256, 0, 3, 1);
+            break;
         default: return LPF_ERR_UNSUPPORTED;
     }
 #undef LPF_ROWS_GO

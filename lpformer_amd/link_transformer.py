@@ -1193,7 +1193,30 @@ class LinkTransformer(nn.Module):
     def _uses_select4(self, adj_mask=None) -> bool:
         """True when the hot path's selection is the one-launch, pair-major kernel (csrc/select4.hip): the model's own
         typing adjacency through the walk indexes, feeding the pair-major attention."""
-        return self.select_blocks and adj_mask is None and self.use_select_index
+        return self.select_blocks and adj_mask is None and self.use_select_index and self._patterns_pay()
+
+    # Above this many flipped units per entry LEFT for the exact path (entries whose patterns the table does not hold) the
+    # pair-major kernel behind select4 loses to the type-major form, whose exact path is the rule rather than the
+    # exception (cora-like: PPR values of 0.01 ... 0.25 spread over hundreds of patterns, 9.8 left of 15.3 -- 168 us
+    # against 102)
+    PT_EXACT_MAX = 1.0
+
+    def _patterns_pay(self) -> bool:
+        """False when the activation-pattern table covers too little of this model's entries (``PT_EXACT_MAX``): the hot
+        path then keeps select3 + the type-major kernels.  Looked at once per parameter version in evaluation mode (a
+        selection on a sample + the table build, 0.2-0.3 s), with the same spacing as ``attention_kernel``'s estimate."""
+        if self.dim < 128 or not (self.attention_rows and self.use_fused_attention):
+            return True
+        self._fold()
+        last = getattr(self, "_pt_choice", None)        # (parameter key, choice, refolds at the time)
+        if last is not None and (last[0] is self._folded[0] or self.training or
+                                 self._refolds - last[2] < self.flip_recheck_every):
+            return last[1]
+        if self.training:
+            return True
+        ok = self._flip_stats()[1] <= self.PT_EXACT_MAX
+        self._pt_choice = (self._folded[0], ok, self._refolds)
+        return ok
 
     def _select4_launch(self, ws, batch, wi):
         lib, st = _lib.hip(), _stream(self.device)
@@ -1402,22 +1425,19 @@ class LinkTransformer(nn.Module):
         return pt
 
     @_on_device
-    def flips_per_entry(self, raw: bool = False) -> float:
-        """Mean number of hidden units of the PE MLPs (both argument orders, ``2 D`` per entry) whose ReLU state differs
-        from the one at (0, 0) and that the attention kernel has to find and correct one by one, over the entries of
-        ``_entry_sample()``.  Behind select4 the pair-major kernel reads the patterns of most entries from a table
-        (``_pattern_tables``): only entries in cells without a tabulated pattern count, unless ``raw``.  This is what the
-        cost of the activation-pattern kernels depends on; a property of the ``ppr_encoder_*`` weights
-        (reference link_transformer.py:67-76) and of the PPR values, evaluated once per parameter version."""
+    def _flip_stats(self):
+        """(raw, left): mean number of hidden units of the PE MLPs (both argument orders, ``2 D`` per entry) whose ReLU
+        state differs from the one at (0, 0), over the entries of ``_entry_sample()`` -- all of them / only those of
+        entries whose patterns ``_pattern_tables`` does not hold (what the exact path of the kernel behind select4 has to
+        find and correct one by one).  Once per parameter version."""
         w = self._fold()
-        tabled = not raw and self._uses_select4() and self.attention_rows
         hit = getattr(self, "_flip_est", None)
-        if hit is not None and hit[0] is self._folded[0] and hit[2] == tabled:
+        if hit is not None and hit[0] is self._folded[0]:
             return hit[1]
         with torch.no_grad():
             sample = self._entry_sample()
-            pt = self._pattern_tables(w) if tabled else None
-            flips, total = 0.0, 0
+            pt = self._pattern_tables(w) if self.dim >= 128 else None
+            raw, left, total = 0.0, 0.0, 0
             for t in range({"all": 3, "1-hop": 2, "cn": 1}[self.mask]):
                 pa, pb = sample[t]
                 total += pa.numel()
@@ -1428,17 +1448,26 @@ class LinkTransformer(nn.Module):
                 if pt is not None:
                     ia, ib = patterns.cell_index(pa, pt["geo"]), patterns.cell_index(pb, pt["geo"])
                     g = pt["grid"][t]
-                    slow = ((g[ia, ib] >= patterns.AMBIGUOUS) | (g[ib, ia] >= patterns.AMBIGUOUS)) & \
-                        (torch.maximum(pa, pb) > st[7])
+                    npat = patterns.NPAT // 2 if self.dim >= 256 else patterns.NPAT    # (what the kernel's LDS holds)
+                    slow = ((g[ia, ib] >= npat) | (g[ib, ia] >= npat)) & (torch.maximum(pa, pb) > st[7])
                 for x, y in ((pa, pb), (pb, pa)):
                     var = st[0] * x * x + st[1] * y * y + st[2] + 2.0 * (st[3] * x * y + st[4] * x + st[5] * y)
                     r = torch.rsqrt(var.clamp_min(0.0) + 1e-5)
                     z = r[:, None] * (x[:, None] * tab[:, 0] + y[:, None] * tab[:, 1] + tab[:, 2]) + tab[:, 3]
                     fl = (z < 0).sum(dim=1)
-                    flips += float((fl if slow is None else fl * slow).sum().item())
-            est = flips / max(1, total)
-        self._flip_est = (self._folded[0], est, tabled)
+                    raw += float(fl.sum().item())
+                    left += float((fl if slow is None else fl * slow).sum().item())
+            est = (raw / max(1, total), left / max(1, total))
+        self._flip_est = (self._folded[0], est)
         return est
+
+    def flips_per_entry(self, raw: bool = False) -> float:
+        """Flipped hidden units per selected entry that the attention kernel has to find and correct one by one: behind
+        select4 only those of entries whose patterns are not tabulated, otherwise (or with ``raw``) all of them.  This
+        is what the cost of the activation-pattern kernels depends on; a property of the
+        ``ppr_encoder_*`` weights (reference link_transformer.py:67-76) and of the PPR values."""
+        r, left = self._flip_stats()
+        return r if raw or not self._uses_select4() else left
 
     def attention_kernel(self) -> str:
         """The fp32 one-pass attention kernel this model runs: ``attention_impl`` with "auto" resolved.  Below D = 128

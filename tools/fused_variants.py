@@ -18,7 +18,7 @@ score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval(
 model.precision = os.environ.get("LPF_PRECISION", "f32")
 model.tail_precision = os.environ.get("LPF_TAIL_PRECISION", "f32")
 model.tail_split = os.environ.get("LPF_TAIL_SPLIT", "0") == "1"
-model.tail_fold_e = os.environ.get("LPF_TAIL_FOLD_E", "1") == "1"
+model.tail_fold_e = os.environ.get("LPF_TAIL_FOLD_E", "0") == "1"
 model.select_blocks = os.environ.get("LPF_SELECT_BLOCKS", "1") == "1"
 model.select4_threads = int(os.environ.get("LPF_SEL4_THREADS", "0"))
 model.attention_impl = os.environ.get("LPF_ATT", "auto")
