@@ -570,12 +570,16 @@ int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const floa
  * and pay per entry for finding and correcting the units that left it (`base`, `wfold_t`).  Here the plane of PPR value
  * pairs is cut into grid_n x grid_n cells, cell(v) = clamp((bits(fp32(v + grid_ofs)) >> grid_shift) - grid_base, 0,
  * grid_n - 1) on either axis, and
- *   pat_grid uint8 [3][grid_n][grid_n]: per type, cell (cell(x), cell(y)) -> id s < LPF_ROWS_PATTERNS of the pattern
- *       that is the pattern of EVERY point (x, y) of the cell, or >= 0x80 (a boundary may cross the cell, or its
- *       pattern is not tabulated: the entry then takes the exact detect-and-correct path against pattern 0, for which
- *       pe_tab_signed / wfold_t are still read); the last cell of either axis (values > 1, NaN, negative) must be 0x80;
+ *   pat_grid uint8 [3][grid_n][grid_n]: per type, cell (cell(x), cell(y)) -> bits 0-4: id s < LPF_ROWS_PATTERNS of a
+ *       tabulated pattern, bit 7 clear: s is the pattern of EVERY point (x, y) of the cell; bit 7 set (a boundary may
+ *       cross the cell, or its pattern is not tabulated): s is the tabulated pattern nearest to the pattern of the cell's
+ *       centre, and the entry takes the exact path -- the units whose state differs from pattern s are found
+ *       (pe_tab_signed, signed for pattern 0, with pat_sign) and corrected (wfold_t) one by one; the last cell of either
+ *       axis (values > 1, NaN, negative) must be 0x80;
  *   pat_base float [3][LPF_ROWS_PATTERNS][4][D]: (P_s, Q_s, R_s, B_s + bfold / 2) with X_s = sum over the units k active
- *       in pattern s of Wfold[:, k] * (ta_k, tc_k, td_k, beta_k); id 0 = the pattern of (0, 0).
+ *       in pattern s of Wfold[:, k] * (ta_k, tc_k, td_k, beta_k); id 0 = the pattern of (0, 0);
+ *   pat_sign uint32 [3][LPF_ROWS_PATTERNS][D / 32]: bit k of pattern s = unit k is active in exactly one of pattern s and
+ *       pattern 0.
  * An entry's key is Z[v] + [P r1 pa + Q r1 pb + R r1 + B](pattern of (pa, pb)) + [P r2 pb + Q r2 pa + R r2 + B](pattern
  * of (pb, pa)): no look at its 2 D units at all.  Built by lpformer_amd/patterns.py (a per-cell proof by convexity;
  * which patterns are tabulated only decides how many entries take the slower path, never a result).  A kernel that
@@ -586,16 +590,16 @@ int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const floa
 int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt, const void *entries,
                                  int64_t ent_cap, const float *Z, int64_t ldz, const float *q, int64_t ldq,
                                  const float *pe_tab_signed, const float *pe_stat, const float *pat_base,
-                                 const void *pat_grid, int32_t grid_n, int32_t grid_shift, int32_t grid_base,
-                                 float grid_ofs, const float *wfold_t, const float *att, const float *att_bias,
+                                 const void *pat_grid, const void *pat_sign, int32_t grid_n, int32_t grid_shift,
+                                 int32_t grid_base, float grid_ofs, const float *wfold_t, const float *att, const float *att_bias,
                                  const float *ln_g, const float *ln_b, int32_t n_counts, const int64_t *sel_ctl,
                                  float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
                                  int64_t *n_nonempty, void *stream);
 int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
                                    const void *entries, int64_t ent_cap, const void *Z_bf16, int64_t ldz, const float *q,
                                    int64_t ldq, const float *pe_tab_signed, const float *pe_stat, const float *pat_base,
-                                   const void *pat_grid, int32_t grid_n, int32_t grid_shift, int32_t grid_base,
-                                   float grid_ofs, const float *wfold_t, const float *att, const float *att_bias,
+                                   const void *pat_grid, const void *pat_sign, int32_t grid_n, int32_t grid_shift,
+                                   int32_t grid_base, float grid_ofs, const float *wfold_t, const float *att, const float *att_bias,
                                    const float *ln_g, const float *ln_b, int32_t n_counts, const int64_t *sel_ctl,
                                    float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
                                    int64_t *n_nonempty, void *stream);

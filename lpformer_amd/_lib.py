@@ -69,9 +69,9 @@ HIP_PROTOTYPES = {
                                          vp, i64, vp, i64, vp, vp, vp, vp],
     "lpf_pair_attention_rows_perm_zbf16": [i32, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                                            vp, vp, i64, vp, i64, vp, vp, vp, vp],
-    "lpf_pair_attention_rows4_f32": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, f32, vp,
+    "lpf_pair_attention_rows4_f32": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp,
                                      vp, vp, vp, vp, i32, vp, vp, i64, vp, i64, vp, vp, vp],
-    "lpf_pair_attention_rows4_zbf16": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, f32, vp,
+    "lpf_pair_attention_rows4_zbf16": [i32, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp,
                                        vp, vp, vp, vp, i32, vp, vp, i64, vp, i64, vp, vp, vp],
     "lpf_tail_chain_rows_perm_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp, vp],

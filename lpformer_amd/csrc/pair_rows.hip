@@ -71,7 +71,9 @@ struct RowsArgs {
     // that is provably the pattern of every point of the cell or 0x80 (then the entry takes the exact detect-and-correct
     // path against pattern 0, as every entry outside the no-flip square does in the type-major form)
     const float *pat_base;     // [3][LPF_ROWS_PATTERNS][4][D]: (P, Q, R, B + bfold / 2) of pattern s of type t
-    const uint8_t *pat_grid;   // [3][grid_n][grid_n]
+    const uint8_t *pat_grid;   // [3][grid_n][grid_n]: pattern id (bits 0-4); bit 7: a boundary may cross the cell or its
+                               // pattern is not tabulated -- the exact path, starting from the NAMED (nearest) pattern
+    const uint32_t *pat_sign;  // [3][LPF_ROWS_PATTERNS][D / 32]: bit k = unit k's state in the pattern differs from pattern 0
     int32_t grid_n, grid_shift, grid_base;
     float grid_ofs;
 };
@@ -137,7 +139,8 @@ struct PrLds {
     static constexpr int CTL = LISTS + 2 * (PR_CHUNK / 4);   // int [16]: counters, ticket, range
     static constexpr int FLAGS = CTL + 4;                    // int [PR_FLAGS]: unit u of the chunk is done
     static constexpr int WCNT = FLAGS + PR_FLAGS / 4;        // int [32]: per-wavefront counts (ranks of the tail's order)
-    static constexpr int TOTAL = WCNT + 8;
+    static constexpr int SIGN = WCNT + 8;                    // PT: uint32 [3][NP][D / 32] (pat_sign)
+    static constexpr int TOTAL = SIGN + (PT ? (3 * NP * ((D + 31) / 32) + 3) / 4 : 0);
     static constexpr size_t BYTES = (size_t)TOTAL * 16;
 };
 
@@ -174,6 +177,8 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     int *const lctl = reinterpret_cast<int *>(pr_lds + L::CTL);   // 0: n_empty 1: n_multi 2: unit ticket 4,5: P0 6,7: P1 8-11: the order (base, own count, launch number)
     int *const lflag = reinterpret_cast<int *>(pr_lds + L::FLAGS);
     int *const lwcnt = reinterpret_cast<int *>(pr_lds + L::WCNT);
+    uint32_t *const lsign = reinterpret_cast<uint32_t *>(pr_lds + L::SIGN);
+    constexpr int SW = (D + 31) / 32;            // words of a pattern's sign vector
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane / G, lj = lane % G, off = 4 * lj;
     const int gid = wave * EPW + grp;            // this group among the workgroup's NG
 #ifdef PR_STAMPS
@@ -280,6 +285,8 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
             }
         }
         if constexpr (PT) {
+            if (ft < 3 * NP * SW)
+                lsign[ft] = A.pat_sign[((ft / (NP * SW)) * LPF_ROWS_PATTERNS + (ft / SW) % NP) * SW + ft % SW];
             // the pattern tables: [3][LPF_ROWS_PATTERNS][4][G] float4 in memory, the first NP patterns of every type kept
             constexpr int PB = 3 * NP * D, PBU = 6;   // (six loads of a thread in flight at a time)
             const float4 *src = reinterpret_cast<const float4 *>(A.pat_base);
@@ -686,15 +693,18 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     // (fold.no_flip_radius): such an entry needs no look at its units at all
                     if constexpr (PT) {
                         // bits 9-14 / 15-20: row t * NP + s of the pattern table for (pa, pb) / (pb, pa).  Outside the
-                        // square the two cells of the grid say which patterns these are -- or that a boundary may cross
-                        // one of them (bit 8: the exact path against pattern 0)
+                        // square the two cells of the grid say which patterns these are -- or (bit 8: the exact path)
+                        // which tabulated patterns come nearest where a boundary may cross a cell or its pattern is not
+                        // tabulated
                         int i1 = t * NP, i2 = t * NP;
                         if (!(fmaxf(pa, pb) <= st[7])) {
                             const int ia = grid_cell(pa), ib = grid_cell(pb);
                             const uint8_t *gt = A.pat_grid + (int64_t)t * A.grid_n * A.grid_n;
                             const int g1 = gt[ia * A.grid_n + ib], g2 = gt[ib * A.grid_n + ia];
-                            if (g1 >= NP || g2 >= NP) meta |= 256;
-                            else { i1 += g1; i2 += g2; }
+                            const int s1 = g1 & 31, s2 = g2 & 31;
+                            if (((g1 | g2) & 0x80) || s1 >= NP || s2 >= NP) meta |= 256;   // the exact path, from (i1, i2)
+                            i1 += s1 < NP ? s1 : 0;
+                            i2 += s2 < NP ? s2 : 0;
                         }
                         meta |= (i1 << 9) | (i2 << 15);
                     } else {
@@ -794,6 +804,18 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     for (int j = 0; j < 4; ++j) {
                         const float4 tj = tabl[3 * GG * j + vu * G];
                         zz[j] = r12 * (tj.x * pab + (tj.y * pba + tj.z)) + tj.w;
+                    }
+                    if constexpr (PT) {
+                        // the table is signed for pattern 0, the entry starts from the patterns its cells name: a unit
+                        // whose state differs between the two changes sign (.x: the order (pa, pb), .y: (pb, pa))
+                        const int qd = lj + vu * G;
+                        const uint32_t w1 = lsign[((meta >> 9) & 63) * SW + (qd >> 3)] >> (4 * (qd & 7));
+                        const uint32_t w2 = lsign[((meta >> 15) & 63) * SW + (qd >> 3)] >> (4 * (qd & 7));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            zz[j].x = __uint_as_float(__float_as_uint(zz[j].x) ^ ((w1 >> j) << 31));
+                            zz[j].y = __uint_as_float(__float_as_uint(zz[j].y) ^ ((w2 >> j) << 31));
+                        }
                     }
                     const float zmin = fminf(fminf(fminf(zz[0].x, zz[0].y), fminf(zz[1].x, zz[1].y)),
                                              fminf(fminf(zz[2].x, zz[2].y), fminf(zz[3].x, zz[3].y)));
@@ -1106,10 +1128,11 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
                 const float *ln_b, int32_t n_counts, const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
                 int64_t ldo, void *stream, int32_t *perm = nullptr, uint64_t *perm_lb = nullptr,
                 int64_t *n_nonempty = nullptr, const void *pair_tab = nullptr, const int32_t *blk_cnt = nullptr,
-                const float *pat_base = nullptr, const uint8_t *pat_grid = nullptr, int32_t grid_n = 0,
+                const float *pat_base = nullptr, const uint8_t *pat_grid = nullptr, const uint32_t *pat_sign = nullptr,
+                int32_t grid_n = 0,
                 int32_t grid_shift = 0, int32_t grid_base = 0, float grid_ofs = 0.f) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(!PT || (pat_base && pat_grid && lpf_aligned16(pat_base) && grid_n >= 2 && grid_n <= 4096 &&
+    LPF_REQUIRE(!PT || (pat_base && pat_grid && pat_sign && lpf_aligned16(pat_base) && grid_n >= 2 && grid_n <= 4096 &&
                         grid_shift >= 0 && grid_shift <= 23 && grid_base >= 0 && grid_ofs >= 0.f));
     LPF_REQUIRE(bs > 0 && bs < (PT ? (1ll << 29) : (1ll << 31)) && (PT ? (pair_tab && blk_cnt && lpf_aligned16(pair_tab)) : type_ptr != nullptr) &&
                 entries && ent_cap > 0 && ent_cap < (PT ? (1ll << 31) : (1ll << 29)) && Z && q &&
@@ -1124,7 +1147,7 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
     const RowsArgs a{bs, type_ptr, static_cast<const int4 *>(entries), ent_cap, static_cast<const float *>(Z), (uint32_t)ldz,
                      q, (uint32_t)ldq, pe_tab_signed, pe_stat, base, wfold_t, att, att_bias, ln_g, ln_b, out, ldo,
                      n_counts, sel_ctl, pieces, units_cap, perm, perm_lb, n_nonempty,
-                     static_cast<const int4 *>(pair_tab), blk_cnt, pat_base, pat_grid, grid_n, grid_shift, grid_base,
+                     static_cast<const int4 *>(pair_tab), blk_cnt, pat_base, pat_grid, pat_sign, grid_n, grid_shift, grid_base,
                      grid_ofs};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_cu = lpf_cu_count();
@@ -1239,22 +1262,24 @@ extern "C" int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const i
 extern "C" int lpf_pair_attention_rows4_f32(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
                                             const void *entries, int64_t ent_cap, const float *Z, int64_t ldz,
                                             const float *q, int64_t ldq, const float *pe_tab_signed, const float *pe_stat,
-                                            const float *pat_base, const void *pat_grid, int32_t grid_n,
-                                            int32_t grid_shift, int32_t grid_base, float grid_ofs, const float *wfold_t,
+                                            const float *pat_base, const void *pat_grid, const void *pat_sign,
+                                            int32_t grid_n, int32_t grid_shift, int32_t grid_base, float grid_ofs,
+                                            const float *wfold_t,
                                             const float *att, const float *att_bias, const float *ln_g, const float *ln_b,
                                             int32_t n_counts, const int64_t *sel_ctl, float *pieces, int64_t units_cap,
                                             float *out, int64_t ldo, int32_t *perm, int64_t *n_nonempty, void *stream) {
     return rows_launch<false, true>(D, bs, nullptr, entries, ent_cap, Z, ldz, q, ldq, pe_tab_signed, pe_stat, nullptr, wfold_t,
                                     att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream, perm,
                                     nullptr, n_nonempty, pair_tab, blk_cnt, pat_base, static_cast<const uint8_t *>(pat_grid),
-                                    grid_n, grid_shift, grid_base, grid_ofs);
+                                    static_cast<const uint32_t *>(pat_sign), grid_n, grid_shift, grid_base, grid_ofs);
 }
 
 extern "C" int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, const int32_t *blk_cnt,
                                               const void *entries, int64_t ent_cap, const void *Z_bf16, int64_t ldz,
                                               const float *q, int64_t ldq, const float *pe_tab_signed,
                                               const float *pe_stat, const float *pat_base, const void *pat_grid,
-                                              int32_t grid_n, int32_t grid_shift, int32_t grid_base, float grid_ofs,
+                                              const void *pat_sign, int32_t grid_n, int32_t grid_shift, int32_t grid_base,
+                                              float grid_ofs,
                                               const float *wfold_t, const float *att, const float *att_bias,
                                               const float *ln_g, const float *ln_b, int32_t n_counts,
                                               const int64_t *sel_ctl, float *pieces, int64_t units_cap, float *out,
@@ -1262,7 +1287,8 @@ extern "C" int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void 
     return rows_launch<true, true>(D, bs, nullptr, entries, ent_cap, Z_bf16, ldz, q, ldq, pe_tab_signed, pe_stat, nullptr,
                                    wfold_t, att, att_bias, ln_g, ln_b, n_counts, sel_ctl, pieces, units_cap, out, ldo, stream,
                                    perm, nullptr, n_nonempty, pair_tab, blk_cnt, pat_base,
-                                   static_cast<const uint8_t *>(pat_grid), grid_n, grid_shift, grid_base, grid_ofs);
+                                   static_cast<const uint8_t *>(pat_grid), static_cast<const uint32_t *>(pat_sign), grid_n,
+                                   grid_shift, grid_base, grid_ofs);
 }
 
 /* floats of one piece record of lpf_pair_attention_rows_* (D accumulators, m, l, padded to whole 128-byte lines) */

@@ -1195,11 +1195,12 @@ class LinkTransformer(nn.Module):
         typing adjacency through the walk indexes, feeding the pair-major attention."""
         return self.select_blocks and adj_mask is None and self.use_select_index and self._patterns_pay()
 
-    # Above this many flipped units per entry LEFT for the exact path (entries whose patterns the table does not hold) the
-    # pair-major kernel behind select4 loses to the type-major form, whose exact path is the rule rather than the
-    # exception (cora-like: PPR values of 0.01 ... 0.25 spread over hundreds of patterns, 9.8 left of 15.3 -- 168 us
-    # against 102)
-    PT_EXACT_MAX = 1.0
+    # Above this many flipped units per entry LEFT for the exact path (entries in flagged cells, counted against the
+    # tabulated patterns their cells name) the pair-major kernel behind select4 is taken to lose to the type-major form,
+    # whose exact path is the rule rather than the exception.  Measured point (cora-like, D = 256: PPR values of 0.01 ...
+    # 0.25 spread over hundreds of patterns, 8 tabulated): 3.0 left of 15.3 -- attention 96.6 us + selection 13.5 against
+    # 100.1 + 34.2 for select3 + the type-major kernel; counted against the pattern of (0, 0) it was 9.8 left and 168 us
+    PT_EXACT_MAX = 4.0
 
     def _patterns_pay(self) -> bool:
         """False when the activation-pattern table covers too little of this model's entries (``PT_EXACT_MAX``): the hot
@@ -1444,19 +1445,27 @@ class LinkTransformer(nn.Module):
                 if pa.numel() == 0:
                     continue
                 tab, st = w["flip_tab"][t], w["pe_stat"][t]     # rows (ta, tc, td, beta) times the unit's sign at (0, 0)
-                slow = None
+                slow, named = None, (None, None)
                 if pt is not None:
+                    # entries outside the no-flip square whose cells are flagged: the exact path, which starts from the
+                    # tabulated patterns the two cells name
                     ia, ib = patterns.cell_index(pa, pt["geo"]), patterns.cell_index(pb, pt["geo"])
                     g = pt["grid"][t]
-                    npat = patterns.NPAT // 2 if self.dim >= 256 else patterns.NPAT    # (what the kernel's LDS holds)
-                    slow = ((g[ia, ib] >= npat) | (g[ib, ia] >= npat)) & (torch.maximum(pa, pb) > st[7])
-                for x, y in ((pa, pb), (pb, pa)):
+                    g1, g2 = g[ia, ib].long(), g[ib, ia].long()
+                    slow = (((g1 | g2) & patterns.AMBIGUOUS) != 0) & (torch.maximum(pa, pb) > st[7])
+                    sh = torch.arange(32, device=self.device)
+                    sgn = pt["sign"][t].long() & 0xffffffff        # [NPAT, D / 32]: units that differ from pattern 0
+                    bits = lambda ids: ((sgn[ids & 31][:, :, None] >> sh) & 1).reshape(ids.numel(), -1)[:, :self.dim].bool()
+                    named = (bits(g1), bits(g2))
+                for (x, y), ref in zip(((pa, pb), (pb, pa)), named):
                     var = st[0] * x * x + st[1] * y * y + st[2] + 2.0 * (st[3] * x * y + st[4] * x + st[5] * y)
                     r = torch.rsqrt(var.clamp_min(0.0) + 1e-5)
                     z = r[:, None] * (x[:, None] * tab[:, 0] + y[:, None] * tab[:, 1] + tab[:, 2]) + tab[:, 3]
-                    fl = (z < 0).sum(dim=1)
-                    raw += float(fl.sum().item())
-                    left += float((fl if slow is None else fl * slow).sum().item())
+                    raw += float((z < 0).sum().item())
+                    if slow is None:
+                        left += float((z < 0).sum().item())
+                    else:
+                        left += float((((z < 0) ^ ref).sum(dim=1) * slow).sum().item())
             est = (raw / max(1, total), left / max(1, total))
         self._flip_est = (self._folded[0], est)
         return est
@@ -1525,7 +1534,7 @@ class LinkTransformer(nn.Module):
         if four:    # (the base vectors of the tabulated activation patterns + the grid that finds an entry's two)
             pt = self._pattern_tables(w)
             geo = pt["geo"]
-            bases = (ptr(pt["base"]), ptr(pt["grid"]), geo["n"], geo["shift"], geo["base"], geo["ofs"])
+            bases = (ptr(pt["base"]), ptr(pt["grid"]), ptr(pt["sign"]), geo["n"], geo["shift"], geo["base"], geo["ofs"])
         else:       # (the one pattern of (0, 0))
             bases = (ptr(w["flip_base"]),)
         tabs = (ptr(zt), zt.stride(0), ptr(q), q.stride(0), ptr(w["flip_tab"]), ptr(w["pe_stat"]), *bases,

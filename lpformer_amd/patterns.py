@@ -13,8 +13,12 @@ no-flip square then).  But the selected entries of a batch only ever see a few d
 
 * ``grid``  uint8 [3, n, n]: the plane cut into n x n cells, logarithmic in both coordinates (cell of a value v: the
   upper bits of the fp32 number v + 2^-12, ``cell_index``); a cell holds the id of the pattern that is PROVABLY the
-  pattern of every point of the cell, or ``AMBIGUOUS`` (a boundary may cross it / its pattern is not among the
-  tabulated ones): such entries take the kernel's exact detect-and-correct path against pattern 0 as before;
+  pattern of every point of the cell, or -- flag ``AMBIGUOUS`` set: a boundary may cross it / its pattern is not among
+  the tabulated ones -- the id of the tabulated pattern NEAREST to the pattern of its centre (fewest differing units):
+  such entries take the kernel's exact path, which finds and corrects the units that differ from THAT pattern (one or
+  two instead of the many that differ from the pattern of (0, 0) far from the origin);
+* ``sign``  int32 [3, NPAT, D / 32]: bit k of pattern s = unit k's state differs from its state in pattern 0 (the exact
+  path's hidden-layer table is signed for pattern 0);
 * ``base``  float32 [3, NPAT, 4, D]: (P_S, Q_S, R_S, B_S + bfold / 2) of the tabulated patterns, id 0 = the pattern
   of (0, 0).  An entry in clean cells adds the four vectors of the pattern of (pa, pb) and those of (pb, pa).
 
@@ -33,7 +37,7 @@ from . import fold
 
 GRID_M = 6            # cells per octave = 2^GRID_M
 GRID_OFS_EXP = -12    # v + 2^GRID_OFS_EXP: values below ~2^-12 share the first cells (linear there, logarithmic above)
-NPAT = 16             # patterns per type in ``base`` (the kernel keeps min(NPAT, what its LDS holds) of them)
+NPAT = 16             # pattern slots per type in ``base`` / ``sign``; D >= 256: the first half is used (the kernel's LDS)
 AMBIGUOUS = 0x80
 
 
@@ -95,6 +99,25 @@ def _unique_rows(rows: torch.Tensor):
     return uniq, inv
 
 
+def _popcount32(x: torch.Tensor) -> torch.Tensor:
+    """Set bits of the low 32 bits of every int64 element."""
+    x = x - ((x >> 1) & 0x55555555)
+    x = (x & 0x33333333) + ((x >> 2) & 0x33333333)
+    x = (x + (x >> 4)) & 0x0F0F0F0F
+    return ((x * 0x01010101) >> 24) & 0xFF
+
+
+def nearest_pattern(words: torch.Tensor, chosen: torch.Tensor, chunk: int = 1 << 16) -> torch.Tensor:
+    """For every row of ``words`` [C, W] the index of the row of ``chosen`` [S, W] with the fewest differing bits (ties:
+    the lowest index) -- int64 [C]."""
+    out = torch.empty(words.shape[0], dtype=torch.int64, device=words.device)
+    for a in range(0, words.shape[0], chunk):
+        w = words[a:a + chunk]
+        dist = _popcount32(w[:, None, :] ^ chosen[None, :, :]).sum(-1)
+        out[a:a + chunk] = torch.argmin(dist, dim=1)
+    return out
+
+
 def classify(tab: torch.Tensor, st: torch.Tensor, geo: dict, chunk: int = 1 << 15):
     """tab float64 [D, 4] = (ta, tc, td, beta) of one PE MLP (unsigned), st float64 [6] (``fold.pe_tables``).  Returns
     (words int64 [n * n, W]: the pattern at every cell's centre, clean bool [n * n]); cell (i, j) = x in cell i, y in
@@ -139,7 +162,9 @@ def build(state: dict, dim: int, n_types: int, sample=None, device=None, m: int 
     geo = grid_geometry(m, ofs_exp)
     n = geo["n"]
     grid = torch.full((3, n * n), AMBIGUOUS, dtype=torch.uint8, device=device)
+    npat_k = npat // 2 if dim >= 256 else npat       # what the kernel's LDS holds (csrc/pair_rows.hip pr_patterns)
     base = np.zeros((3, npat, 4, dim), np.float64)
+    sign = np.zeros((3, npat, (dim + 31) // 32), np.int64)
     stats = []
     # parameter-only algebra in float64 numpy on the host (as fold.py; small), the per-cell work on ``device``
     f64 = lambda name: state[name].detach().cpu().double().numpy()
@@ -174,19 +199,30 @@ def build(state: dict, dim: int, n_types: int, sample=None, device=None, m: int 
         wsum = torch.zeros(uniq.shape[0], dtype=torch.float32, device=device)
         wsum.index_add_(0, inv[1:], weight[clean].to(torch.float32))
         wsum[inv[0]] = float("inf")                       # id 0
-        order = torch.argsort(wsum, descending=True)[:npat]
+        order = torch.argsort(wsum, descending=True)[:npat_k]
         ident = torch.full((uniq.shape[0],), AMBIGUOUS, dtype=torch.int64, device=device)
         ident[order] = torch.arange(order.numel(), device=device)
+        # every cell: the nearest tabulated pattern, flagged -- then the clean cells of tabulated patterns: their own, unflagged
         gt = grid[t]
-        gt[clean] = ident[inv[1:]].to(torch.uint8)
+        gt[:] = (nearest_pattern(words, uniq[order]) | AMBIGUOUS).to(torch.uint8)
+        own = ident[inv[1:]]
+        cidx = torch.nonzero(clean)[:, 0]
+        keep = own < AMBIGUOUS
+        gt[cidx[keep]] = own[keep].to(torch.uint8)
+        g2 = gt.view(n, n)                                 # (out of range on either axis: the exact path against pattern 0)
+        g2[n - 1, :] = AMBIGUOUS
+        g2[:, n - 1] = AMBIGUOUS
         chosen = uniq[order].cpu().numpy()                 # [<= npat, W] int64
+        sign[t, :chosen.shape[0]] = (chosen ^ chosen[0:1]).astype(np.int64)
         for s in range(chosen.shape[0]):
             on = ((chosen[s][:, None] >> np.arange(32, dtype=np.int64)) & 1).reshape(-1)[:dim].astype(np.float64)
             ws = wfold * on[None, :]
             base[t, s, 0], base[t, s, 1], base[t, s, 2] = ws @ tab_h[:, 0], ws @ tab_h[:, 1], ws @ tab_h[:, 2]
             base[t, s, 3] = ws @ be + 0.5 * bfold
-        covered = float((gt[cells] != AMBIGUOUS).double().mean()) if n_sample else None
+        covered = float((gt[cells] < AMBIGUOUS).double().mean()) if n_sample else None
         stats.append({"n_patterns": int(uniq.shape[0]), "clean": float(clean.double().mean()), "covered": covered,
                       "sample_points": n_sample})
     base = torch.from_numpy(base.astype(np.float32)).to(device)
-    return {"grid": grid.view(3, n, n).contiguous(), "base": base.contiguous(), "geo": geo, "stats": stats}
+    sign_t = torch.from_numpy((sign & 0xffffffff).astype(np.uint32).view(np.int32)).to(device)
+    return {"grid": grid.view(3, n, n).contiguous(), "base": base.contiguous(), "sign": sign_t.contiguous(), "geo": geo,
+            "stats": stats}

@@ -68,6 +68,8 @@ def test_a_clean_cell_holds_one_pattern_and_its_vectors_give_the_key(dim, seed, 
     for t in range(3):
         grid = out["grid"][t]
         assert (grid[n - 1, :] == patterns.AMBIGUOUS).all() and (grid[:, n - 1] == patterns.AMBIGUOUS).all()
+        # flagged cells name a tabulated pattern too (the one the exact path starts from)
+        assert int((grid & 0x7f).max()) < patterns.NPAT
         assert int((grid < patterns.AMBIGUOUS).sum()) > 0
         # id 0 is the pattern of the point (0, 0)
         zero = torch.zeros(1, dtype=torch.float64)
@@ -101,6 +103,32 @@ def test_a_clean_cell_holds_one_pattern_and_its_vectors_give_the_key(dim, seed, 
         table = b[:, 0] * (r * x)[:, None] + b[:, 1] * (r * y)[:, None] + b[:, 2] * r[:, None] + b[:, 3]
         scale = max(1.0, float(direct.abs().max()))
         assert float((direct - table).abs().max()) <= 2e-6 * scale
+        # (c) flagged cells (a boundary may cross them / pattern not tabulated): the kernel's exact path starts from the
+        #     tabulated pattern the cell names and adds Wfold[:, k] |y_k| for every unit whose state differs from it
+        fi, fj = torch.nonzero(grid[: n - 1, : n - 1] >= patterns.AMBIGUOUS, as_tuple=True)
+        if fi.numel():
+            pick = torch.randperm(fi.numel(), generator=rng)[:400]
+            fi, fj = fi[pick], fj[pick]
+            fx = e[fi] + (e[fi + 1] - e[fi]) * torch.rand(fi.numel(), generator=rng, dtype=torch.float64)
+            fy = e[fj] + (e[fj + 1] - e[fj]) * torch.rand(fj.numel(), generator=rng, dtype=torch.float64)
+            fid = (grid[fi, fj] & 0x7f).long()
+            hid_f = _hidden(st, t, fx, fy)
+            sgn = out["sign"][t].long() & 0xffffffff                      # [NPAT, D / 32]
+            sh = torch.arange(32)
+            differs0 = ((sgn[fid][:, :, None] >> sh) & 1).reshape(fid.numel(), -1)[:, :dim].bool()
+            on_ref = (_hidden(st, t, zero, zero) > 0) ^ differs0          # the named pattern's active units
+            flipped = (hid_f > 0) ^ on_ref
+            hl = torch.stack([fx, fy], dim=1) @ st[f"{k}.linears.0.weight"].double().T + st[f"{k}.linears.0.bias"].double()
+            rf = 1.0 / torch.sqrt(hl.var(1, unbiased=False) + 1e-5)
+            bf = out["base"][t].double()[fid]
+            tab_f = bf[:, 0] * (rf * fx)[:, None] + bf[:, 1] * (rf * fy)[:, None] + bf[:, 2] * rf[:, None] + bf[:, 3]
+            corr = (hid_f.abs() * flipped) @ (w_rp @ w2).T
+            direct_f = torch.relu(hid_f) @ (w_rp @ w2).T + w_rp @ b2
+            assert float((direct_f - (tab_f + corr)).abs().max()) <= 2e-6 * max(1.0, float(direct_f.abs().max()))
+            # ... and the named pattern is a near one: fewer differing units than against the pattern of (0, 0) on average
+            d_ref = flipped.sum(1).double().mean()
+            d_0 = ((hid_f > 0) ^ (_hidden(st, t, zero, zero) > 0)).sum(1).double().mean()
+            assert d_ref <= d_0 + 1e-9
 
 
 def test_the_sample_decides_which_patterns_are_tabulated():

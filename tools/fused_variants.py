@@ -19,6 +19,8 @@ model.precision = os.environ.get("LPF_PRECISION", "f32")
 model.tail_precision = os.environ.get("LPF_TAIL_PRECISION", "f32")
 model.tail_split = os.environ.get("LPF_TAIL_SPLIT", "0") == "1"
 model.tail_fold_e = os.environ.get("LPF_TAIL_FOLD_E", "0") == "1"
+if os.environ.get("LPF_PT_EXACT_MAX"):
+    model.PT_EXACT_MAX = float(os.environ["LPF_PT_EXACT_MAX"])
 model.select_blocks = os.environ.get("LPF_SELECT_BLOCKS", "1") == "1"
 model.select4_threads = int(os.environ.get("LPF_SEL4_THREADS", "0"))
 model.attention_impl = os.environ.get("LPF_ATT", "auto")

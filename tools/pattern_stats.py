@@ -30,4 +30,5 @@ for name in sys.argv[1:] or ["collab", "cora", "ddi"]:
                 print(f"    entries with both orders among the first {npk} patterns: {float(ok.double().mean()):.4f}")
             q = [0.1, 0.5, 0.9, 0.99]
             print("    pa quantiles", np.quantile(smp[t][0].cpu().numpy(), q).round(4).tolist())
-    print("  flips per entry raw", round(model.flips_per_entry(raw=True), 3), "left for the exact path", round(model.flips_per_entry(), 3))
+    fr, fl = model._flip_stats()
+    print("  flips per entry raw", round(fr, 3), "left for the exact path (against the named patterns)", round(fl, 3), "patterns pay:", model._patterns_pay())
