@@ -907,9 +907,9 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
                     }
                 }
                 if (pair_n != pair_i) q_row(pair_n, qc);   // (behind the last use of this entry's row; most steps stay inside a pair)
-#ifndef PR_NO_ENTRY_FENCE   /* (tuning aid: let the scheduler interleave consecutive entries) */
+                // (consecutive entries are kept apart.  Without the fence a ticket of the 8-feature form takes 25.5 us
+                //  instead of 26.8 alone -- and the pipelined step 0.144 ms instead of 0.1415: six more registers spilled)
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             };
             auto batch = [&](const int qt, const ZT (&zc4)[ZBATCH][NV], ZT (&zn4)[ZBATCH][NV]) __attribute__((always_inline)) {
                 constexpr int NQ = 16 / ZBATCH;
