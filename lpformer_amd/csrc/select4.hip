@@ -109,6 +109,10 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
     uint64_t st_t[16] = {0};
     S4_STAMP(0);
 #endif
+#ifdef S4_STAGGER   /* (tuning aid: every other workgroup of an XCD starts S4_STAGGER x 3.9 us late -- phases out of lockstep) */
+    if (blockIdx.x & 8)
+        for (int i = 0; i < S4_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
     // ---- the endpoints' mini filters: one 16-byte piece per thread and trip (id -> piece: two dependent reads, beside
     //      the plan's id -> node record)

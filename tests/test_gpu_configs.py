@@ -763,6 +763,27 @@ def test_query_table_follows_an_in_place_update_of_lin_l(name, scale):
 
 
 
+def test_models_the_pattern_table_covers_badly_keep_the_type_major_path():
+    """``_patterns_pay``: above ``PT_EXACT_MAX`` flipped units per entry left for the exact path the hot path goes back to
+    select3 + the type-major attention kernel -- the same scores (within the bar of two kernel forms), checked on the same
+    model by moving the threshold."""
+    cfg, n, ei, w, x, data, args, model, score, batch = _setup("collab", scale=0.1, bs=3000)
+    model.attention_impl = "flip"
+    tb = torch.from_numpy(batch).to(DEV)
+    h = model.propagate()
+    assert model._patterns_pay() and model._uses_select4()
+    a = model.score_pairs(tb, h, score, logits=True).clone()
+    assert model.check_selection()
+    model.PT_EXACT_MAX = -1.0
+    model._pt_choice = None
+    assert not model._patterns_pay() and not model._uses_select4()
+    b = model.score_pairs(tb, h, score, logits=True).clone()
+    assert model.check_selection()
+    assert (a - b).abs().max().item() <= 2e-5 * max(1.0, float(a.abs().max()))
+    raw, left = model._flip_stats()
+    assert 0.0 <= left <= raw
+
+
 def test_elementwise_share_of_the_score_head_in_the_side_launch():
     """``tail_fold_e`` (D = 128): the elementwise branch's launch multiplies its hidden activation by the folded score
     head's columns (``lpf_dense_chain_side_f32`` with a second layer) and ``lpf_tail_chain_rows_perm_te_f32`` starts its

@@ -153,3 +153,14 @@ def test_the_sample_decides_which_patterns_are_tabulated():
             va = a["base"][t][a["grid"][t][ii, jj].long()]
             vb = b["base"][t][b["grid"][t][ii, jj].long()]
             assert torch.equal(va, vb)
+
+
+def test_nearest_pattern_is_the_hamming_nearest():
+    g = torch.Generator().manual_seed(7)
+    words = torch.randint(0, 1 << 32, (500, 4), generator=g, dtype=torch.int64)
+    chosen = torch.randint(0, 1 << 32, (8, 4), generator=g, dtype=torch.int64)
+    got = patterns.nearest_pattern(words, chosen, chunk=128)
+    bits = lambda x: ((x[..., None] >> torch.arange(32)) & 1).reshape(*x.shape[:-1], -1)
+    dist = (bits(words)[:, None, :] != bits(chosen)[None, :, :]).sum(-1)
+    assert torch.equal(got, dist.argmin(dim=1))
+    assert int(patterns._popcount32(torch.tensor([0, 1, 0xffffffff, 0x80000001])).sum()) == 0 + 1 + 32 + 2
