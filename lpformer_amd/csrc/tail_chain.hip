@@ -200,6 +200,17 @@ __device__ __forceinline__ void tc_layernorm(f32x4 (&acc)[TPW], int fbase, int n
     }
 }
 
+// (tuning builds, -DTC_STAMPS: wall-clock marks -- 100 MHz -- of lane 0 of every wavefront; tools/tail_stamps.py)
+#ifdef TC_STAMPS
+__device__ uint64_t *tc_stamp_buf = nullptr;
+#define TC_STAMP(k) do { if (lane == 0) st_t[k] = wall_clock64(); } while (0)
+#define TC_STAMPS_OUT(kind) do { if (lane == 0 && tc_stamp_buf) { uint64_t *o__ = tc_stamp_buf + ((int64_t)blockIdx.x * TC_WAVES + wave) * 8; \
+        for (int k__ = 0; k__ < 7; ++k__) o__[k__] = st_t[k__]; o__[7] = (kind); } } while (0)
+#else
+#define TC_STAMP(k) do { } while (0)
+#define TC_STAMPS_OUT(kind) do { } while (0)
+#endif
+
 // NTA / NTB / NTC: 16-feature tiles of the three stages' outputs (NTA = NGE = D/16)
 template <int NTA, int NTB, int NTC>
 struct TcShape {
@@ -234,6 +245,10 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
     const float *peer_x = xch + (wave ^ 1) * 16 + j;
     f32x4 *my_hid = hid + (grp * S::HT) * 64 + lane;
     int buf = 0;
+#ifdef TC_STAMPS
+    uint64_t st_t[8] = {0};
+    TC_STAMP(0);
+#endif
 
     // (With an order the short workgroups are the LAST ones of the grid.  Dealing the tiles from both ends instead, a short
     // workgroup next to every full one on a CU, measured worse: collab-like 0.205 against 0.186 ms per pipelined step, the
@@ -305,6 +320,8 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
                 if (A.logit) A.logit[m] = d;
                 if (A.prob) A.prob[m] = 1.0f / (1.0f + expf(-d));
             }
+            TC_STAMP(6);
+            TC_STAMPS_OUT(1);
             return;
         }
     }
@@ -446,6 +463,7 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
         for (int c = 0; c < TPWA; ++c) my_hid[(half * TPWA + c) * 64] = accA[c];
     }
 
+    TC_STAMP(1);
     // ------------------------------------------------------------------ stage B: first layer of pairwise_lin
     f32x4 accB[TPWB];
 #pragma unroll
@@ -476,6 +494,7 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
             buf ^= 1;
         }
     }
+    TC_STAMP(2);
     WT wrC[S::PC];
     const bool te = ROWS && A.re_folded;
     tc_load<S::PC, NTPC>(wrC, A.wC, te ? NGE : 0, tid);
@@ -492,6 +511,7 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
         for (int c = 0; c < TPWB; ++c) my_hid[(half * TPWB + c) * 64] = accB[c];
     }
 
+    TC_STAMP(3);
     // ------------------------------------------------------------------ stage C: folded score head
     f32x4 accC[TPWC];
     if (te) {   // the elementwise branch's share of the sum is there already (accumulator layout: rows 4 q .. + 3 of tile c)
@@ -513,6 +533,7 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
         tc_mfma<TPWC>(accC, lw + (half * TPWC) * 64 + lane, bv);
         buf ^= 1;
     }
+    TC_STAMP(4);
 #pragma unroll
     for (int kg = 0; kg < NTB; ++kg) {  // r_p, straight from LDS (its padding tile, all zeros, is no k-group worth running)
         WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
@@ -522,6 +543,7 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
         tc_mfma<TPWC>(accC, lw + (half * TPWC) * 64 + lane, my_hid[kg * 64]);
         buf ^= 1;
     }
+    TC_STAMP(5);
     {
         const int fbase = 16 * half * TPWC + 4 * q;
         float d = 0.f;
@@ -543,6 +565,8 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
             if (A.prob) A.prob[m] = 1.0f / (1.0f + expf(-d));
         }
     }
+    TC_STAMP(6);
+    TC_STAMPS_OUT(0);
 }
 
 template <int NTA, int NTB, int NTC, int WM = 0, bool ROWS = false>
@@ -558,6 +582,13 @@ int tc_launch(const TailArgs &a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef TC_STAMPS
+extern "C" int lpf_tail_chain_set_stamps(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(tc_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? LPF_OK : LPF_ERR_LAUNCH;
+}
+#endif
+
 
 extern "C" int lpf_tail_chain_f32(int64_t M, int32_t D, int32_t n_counts, const float *G, int64_t ldg,
                                   const float *wA_packed, const float *lnA_g, const float *lnA_b, const float *counts,
