@@ -452,6 +452,9 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
         }
         if (lane == 0) { lctl[4 + 2 * wave] = (int)(lo & 0xffffffff); lctl[5 + 2 * wave] = (int)(lo >> 32); }
     }
+#ifdef PR_STAMPS
+    if (lane == 0) st_t[7] = wall_clock64();      // this wavefront's own work before the first barrier is done
+#endif
     __syncthreads();
     PR_STAMP(1);
     const int64_t P0 = (int64_t)(uint32_t)lctl[4] | ((int64_t)lctl[5] << 32);
@@ -1117,6 +1120,7 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     if (lane == 0 && pr_stamp_buf) {
         uint64_t *o = pr_stamp_buf + ((int64_t)blockIdx.x * (NTH / 64) + wave) * 8;
         for (int k = 0; k < 6; ++k) o[k] = st_t[k];
+        o[3] = st_t[7];                           // (mark 3 -- the empties -- coincides with mark 2 since the lists moved)
         o[6] = (uint64_t)st_rounds;
         o[7] = (uint64_t)(P1 - P0) | ((uint64_t)lctl[1] << 32);
     }

@@ -27,7 +27,7 @@ for b in batches * 3:
     model.score_pairs(b, h, score)
 torch.cuda.synchronize()
 assert fn(buf.data_ptr()) == 0
-names = ["start", "tables+range", "chunk sorted", "empties", "units done", "merge done"]
+names = ["start", "tables+range", "chunk staged", "own set-up", "units done", "merge done"]
 for i, b in enumerate(batches):
     buf.zero_()
     model.score_pairs(b, h, score)
@@ -37,6 +37,11 @@ for i, b in enumerate(batches):
     t0 = v[:, 0].min()
     rel = (v[:, :6] - t0) / 100.0
     print(f"batch {i}: {len(v)} wavefronts; kernel span {rel[:, 5].max():.1f} us")
+    nw_ = 16
+    own = (v[:, 3] - t0) / 100.0
+    wv = np.arange(len(v)) % nw_
+    print(f"   before the first barrier, own work done: searching wavefronts (0, 1) p50 {np.median(own[wv < 2]):.1f} max {own[wv < 2].max():.1f}; "
+          f"table-filling wavefronts p50 {np.median(own[wv >= 2]):.1f} max {own[wv >= 2].max():.1f}")
     for k in range(6):
         print(f"   {names[k]:14s} p10 {np.percentile(rel[:, k], 10):6.1f}  p50 {np.percentile(rel[:, k], 50):6.1f}  "
               f"p90 {np.percentile(rel[:, k], 90):6.1f}  max {rel[:, k].max():6.1f}")
