@@ -219,14 +219,21 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
     int2 kept_blk[BLK_KEEP];             // {weight, pairs with entries}
     if constexpr (PT) {
         if (wave < 2) {
+            // (all of them requested before the first is looked at: inside their own branches the compiler waited for
+            //  every one in turn -- eight round trips in front of the search)
+            int2 raw_blk[BLK_KEEP];
 #pragma unroll
             for (int i = 0; i < BLK_KEEP; ++i) {
                 const int64_t B = (int64_t)lane * per + i;
-                kept_blk[i] = make_int2(0, 0);
-                if (i < per && B < nblk) {
-                    const int4 c = blk_at(B);
-                    kept_blk[i] = make_int2(EW * c.x + c.z, c.y);
-                }
+                raw_blk[i] = reinterpret_cast<const int2 *>(A.blk_cnt)[B < nblk ? B : nblk - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < BLK_KEEP; ++i) {
+                const int64_t B = (int64_t)lane * per + i;
+                const int np = (int)(A.bs - B * SB < SB ? A.bs - B * SB : SB);
+                const int cx = raw_blk[i].x < 0 ? 0 : raw_blk[i].x;
+                const int cy = raw_blk[i].y < 0 ? 0 : (raw_blk[i].y > np ? np : raw_blk[i].y);
+                kept_blk[i] = (i < per && B < nblk) ? make_int2(EW * cx + np, cy) : make_int2(0, 0);
             }
 #pragma unroll
             for (int i = 0; i < BLK_KEEP; ++i) { own_w += kept_blk[i].x; own_ne += kept_blk[i].y; }
