@@ -530,7 +530,8 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
 #pragma unroll
         for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(A.out + pair * A.ldo + off + 4 * G * v) = r[v];
     };
-    if (wave == 0 && grp == 0) {
+    // (the constant row of a pair without entries; PT with an order for the tail never writes it -- the tail has row_empty)
+    if (!(PT && A.perm != nullptr) && wave == 0 && grp == 0) {
         Q4 zero[NV];
         q4_zero(zero);
         float4 r[NV];
@@ -584,20 +585,31 @@ __global__ __launch_bounds__(NTH, NTH >= 512 ? 4 : 3) void pair_rows_kernel(cons
 
     for (int64_t c0 = P0; c0 < P1; c0 += PR_CHUNK) {
         const int cn = (int)(P1 - c0 < PR_CHUNK ? P1 - c0 : PR_CHUNK);
+        // PT: the chunk's table entries are requested in front of the barrier (they travel while the last wavefront
+        // arrives; the barrier guards LDS, not them)
+        constexpr int PER = (PR_CHUNK + NTH - 1) / NTH;
+        int4 e_pre[PER];
+        if constexpr (PT) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = tid * PER + i;
+                e_pre[i] = A.pair_tab[c0 + (k < cn ? k : cn - 1)];
+            }
+        }
         pr_lds_barrier();   // the previous chunk's lists and pointers are no longer needed
         int64_t v0, v1;
         if constexpr (PT) {
-            // the chunk's table entries: ltp[k] = first entry, ltp[TPS + k] / ltp[2 TPS + k] = common neighbours / one-hop
-            // nodes of pair k, lcum = the entries in front of pair k inside the chunk (a scan over the workgroup)
-            constexpr int PER = (PR_CHUNK + NTH - 1) / NTH;
+            // ltp[k] = first entry, ltp[TPS + k] / ltp[2 TPS + k] = common neighbours / one-hop nodes of pair k, lcum = the
+            // entries in front of pair k inside the chunk (a scan over the workgroup)
             int cnt[PER], own = 0;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int k = tid * PER + i;
                 cnt[i] = 0;
                 if (k < cn) {
-                    const int4 e = A.pair_tab[c0 + k];
-                    const bool ok = !over && pt_count(c0 + k) > 0;
+                    const int4 e = e_pre[i];
+                    const int64_t ce = (int64_t)e.y + e.z + e.w;   // (as pt_count: an entry outside the buffer counts as empty)
+                    const bool ok = !over && !(e.x < 0 || e.y < 0 || e.z < 0 || e.w < 0 || e.x + ce > A.ent_cap) && ce > 0;
                     cnt[i] = ok ? e.y + e.z + e.w : 0;
                     ltp[k] = ok ? e.x : 0;
                     ltp[TPS + k] = ok ? e.y : 0;
