@@ -26,6 +26,14 @@
 // barrier -- its groups merge those pieces in unit order and finish the rows.  The pieces are written and read by the
 // same CU microseconds apart: they never leave L2.  A pair's row does not depend on the batch around it except through
 // where the 16-entry grid cuts it (the same dependence pair_flip.hip has).
+//
+// Two forms share the kernel.  Type-major (behind select3): three entry regions + type_ptr, the base vectors of ONE
+// activation pattern (the one of (0, 0)), every entry outside the no-flip square looks at its 2 D hidden units and
+// corrects the flipped ones from an LDS copy of Wfold^T.  PT (behind select4, the hot path): entries pair-major already
+// (pair_tab / blk_cnt), the activation patterns of an entry's two argument orders come from a TABLE over the plane of PPR
+// value pairs (lpformer_amd/patterns.py: a log grid whose cells are proven to hold one pattern; the base vectors of
+// the tabulated patterns in LDS; only entries of flagged cells look at their units, starting from the pattern the cell
+// names), and at D >= 128 a lane holds two feature quads (NV = 2: 16 / 32 lanes per entry).
 #include <type_traits>
 
 #include "pe_common.h"
