@@ -296,9 +296,11 @@ def main():
                     help="(tuning) launch shape of lpf_select4: workgroup size + 4096 * (blocks per workgroup - 1); 0 = default")
     ap.add_argument("--select-grid", type=int, default=0,
                     help="(tuning) workgroups of the selection's run kernel; 0 = as many as are resident at once")
-    ap.add_argument("--streams", type=int, default=8,
-                    help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial); "
-                         "collab-like without a side stream: 3: 0.196, 4: 0.189, 6: 0.191, 8: 0.187, 12: 0.186 ms/step")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams the timed steps rotate over (consecutive batches overlap; 1 = strictly serial).  "
+                         "Round 5, collab-like, same lease, ms/step at 20 / 40 / 120 steps per window: 4 streams 0.139 / "
+                         "0.1355 / 0.135, 8 streams 0.142 / 0.136 / 0.135 (every kernel fills the chip by itself now: more "
+                         "streams only lengthen the fill and drain of a window); 2: 0.144, 16: 0.145 at 20 steps")
     args = ap.parse_args()
 
     rank, world, local = LD.init_from_env()
