@@ -949,6 +949,13 @@ def main():
                                           if model._uses_select4() and model._uses_rows() else
                                           "plan + run launches, type-major regions (select3.hip)"),
                        "flip_break_even": model.FLIP_BREAK_EVEN.get(d),
+                       # the activation-pattern table of the attention behind select4 (random-init weights): share of a
+                       # sample's ordered (pa, pb) points per type whose cell holds a tabulated pattern, and the flipped
+                       # units per entry left for the exact path (lpformer_amd/patterns.py)
+                       "pattern_table": (None if not (d >= 128 and model._uses_select4() and model._uses_rows()) else
+                                         {"covered_per_type": [s_["covered"] for s_ in model._pattern_tables(model._fold())["stats"]],
+                                          "flips_per_entry_left": round(model._flip_stats()[1], 4),
+                                          "grid_cells_per_axis": model._pattern_tables(model._fold())["geo"]["n"]}),
                        "parallelism": (f"pairs sharded x{world}, encoder {enc_plan['chosen']} " +
                                        {"sharded": "(rows + all-gather per layer)",
                                         "gather_once": "(last layer + Z on row blocks, one all-gather of [X | Z])",
