@@ -137,10 +137,10 @@ def pair_stats(data, batch):
 def slot_count(model, batch_t):
     """Candidate slots of one batch as the plan kernel lays them out (a-side walk | b-side walk | >1-hop walk, at
     least 16 per pair)."""
-    if model._uses_select4() and model._uses_rows():   # the one-launch form: ctl[0] = slots, block by block rounded to 8
-        ws = model._select4_device(batch_t, False)
-    else:
-        ws = model._select_device(batch_t, False, None)
+    if model._uses_select4() and model._uses_rows():   # the one-launch form: ctl[1] = slots, block by block rounded to 8
+        ws = model._select4_device(batch_t, False)     # (ctl[0] is 8 x the fullest allocation region: an upper bound)
+        return int(ws.ctl[1].item())
+    ws = model._select_device(batch_t, False, None)
     return int(ws.ctl[0].item())
 
 

@@ -34,7 +34,7 @@ extern "C" {
 #define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
 #define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
 
-#define LPF_ABI_VERSION 7
+#define LPF_ABI_VERSION 8
 
 /* GEMM / row-wise epilogue flags */
 #define LPF_FLAG_RELU 1u
@@ -277,11 +277,14 @@ int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int
  *             2 = one-hop, 3 = >1-hop; a pair's entries in candidate-slot order (neighbours of a, then of b, then
  *             the >1-hop nodes), types mixed
  *   pair_tab  int32[bs][4] = {first entry, n_cn, n_1hop, n_non1hop} per pair
- *   blk_cnt   int32[ceil(bs / LPF_SELECT4_BLOCK)][2]: {selected entries, pairs with selected entries} per block of pairs
+ *   blk_cnt   int32[ceil(bs / LPF_SELECT4_BLOCK)][2]: {selected entries, pairs with selected entries} per block of pairs;
+ *             8-byte aligned (written and read as 8-byte pairs)
  *   ctl       int64[LPF_SELECT4_CTL_WORDS], zero-initialised once by the caller, then owned by the library (one control
  *             block per stream): [0] entries the last batch needed room for (the buffer is cut into 8 regions, workgroup
- *             g allocates its candidate slots -- rounded up to 8 -- in region g % 8: 8 x the fullest region)  [3] STICKY
- *             error bits as above  [10] completion counter, [16..23] allocation counters (zero between launches)
+ *             g allocates its candidate slots -- rounded up to 8 -- in region g % 8: 8 x the fullest region -- an upper
+ *             bound)  [1] the candidate slots of the last batch (every workgroup's rounded up to 8: the true sum over the
+ *             regions)  [3] STICKY error bits as above  [10] completion counter, [16..23] allocation counters (zero
+ *             between launches)
  * A block that does not fit below ent_cap leaves empty pairs and raises LPF_SELECT_ERR_ENTRY_CAP (consumers write NaN
  * rows while the bit is set).  threads: launch shape, workgroup size (512 or 1024) + 4096 * (blocks of 64 pairs a workgroup
  * takes together - 1); 0 = the default (1024 threads; 2 blocks while that gives every CU a workgroup, else 1). */
@@ -677,6 +680,14 @@ int lpf_ppr_filter_fill(int64_t n, const int64_t *rowptr, const int32_t *col, co
  * to its own neighbours, aligned with the adjacency CSR (the adj_selfp argument of lpf_select_run). */
 int lpf_self_ppr(int64_t n, const int64_t *adj_rowptr, const int32_t *adj_col, const int64_t *ppr_rowptr,
                  const int32_t *ppr_col, const float *ppr_val, float *selfp, void *stream);
+
+/* out[q] = M[rows[q], cols[q]] of a CSR matrix with sorted int32 columns (0 where nothing is stored or an id lies outside
+ * [0, n)).  Used for the raw PPR values of the few selected entries whose TYPE changes when the training loop removes
+ * the batch's positive edges from the typing adjacency (src/train/train_model.py:40-46; a common neighbour of (a, b)
+ * that loses its edge to a becomes a one-hop node and its values are the other type's round trip of the raw value,
+ * src/models/link_transformer.py:229-237,290-291): lpformer_amd.LinkTransformer._patch_removed. */
+int lpf_csr_lookup_f32(int64_t nq, int64_t n, const int64_t *rows, const int64_t *cols, const int64_t *rowptr,
+                       const int32_t *col, const float *val, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step of the pair stage (pair_train.hip): the forward of get_pos_encodings

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "liblpformer_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "liblpformer_host.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 FLAG_RELU = 1
 SELECT_ERR_NODE_RANGE, SELECT_ERR_ITEM_CAP, SELECT_ERR_ENTRY_CAP = 1, 2, 4
 ROWS_PERM_LB_WORDS = 1025      # LPF_ROWS_PERM_LB_WORDS (include/lpformer_hip.h)
@@ -94,6 +94,7 @@ HIP_PROTOTYPES = {
     "lpf_ppr_filter_count": [i64, vp, vp, i32, f32, vp, vp],
     "lpf_ppr_filter_fill": [i64, vp, vp, vp, i32, f32, vp, vp, vp, vp],
     "lpf_self_ppr": [i64, vp, vp, vp, vp, vp, vp, vp],
+    "lpf_csr_lookup_f32": [i64, i64, vp, vp, vp, vp, vp, vp, vp],
     "lpf_ppr_push_workspace_bytes": [i64, i64, C.c_double, C.c_double],
     "lpf_ppr_push_f64": [i64, vp, vp, C.c_double, C.c_double, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp],
     "lpf_ppr_pack_workspace_bytes": [i64, i64],

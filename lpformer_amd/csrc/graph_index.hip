@@ -71,7 +71,39 @@ __global__ __launch_bounds__(256) void self_ppr_kernel(int64_t n, const int64_t 
     }
 }
 
+// out[q] = M[rows[q], cols[q]] of a CSR matrix with sorted columns, 0 where nothing is stored: one thread per query
+__global__ __launch_bounds__(256) void csr_lookup_kernel(int64_t nq, int64_t n, const int64_t *__restrict__ rows,
+                                                         const int64_t *__restrict__ cols,
+                                                         const int64_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                         float *__restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int64_t r = rows[q], c = cols[q];
+    float v = 0.f;
+    if ((uint64_t)r < (uint64_t)n && (uint64_t)c < (uint64_t)n) {
+        const int64_t p0 = rowptr[r], p1 = rowptr[r + 1];
+        const int64_t i = lpf_lower_bound(col, p0, p1, (int32_t)c);
+        if (i < p1 && col[i] == (int32_t)c) v = val[i];
+    }
+    out[q] = v;
+}
+
 }  // namespace
+
+/* out[q] = M[rows[q], cols[q]] (0 where nothing is stored; ids outside [0, n) give 0) for a CSR matrix with sorted
+ * columns: the raw PPR values of a handful of (endpoint, node) pairs -- the entries whose type changes when the training
+ * loop removes the batch's positive edges from the typing adjacency (src/train/train_model.py:40-46 ->
+ * src/models/link_transformer.py:229-237,290-291: their values are re-derived with the other type's round trip). */
+extern "C" int lpf_csr_lookup_f32(int64_t nq, int64_t n, const int64_t *rows, const int64_t *cols, const int64_t *rowptr,
+                                  const int32_t *col, const float *val, float *out, void *stream) {
+    if (nq == 0) return LPF_OK;
+    LPF_REQUIRE(nq > 0 && n > 0 && rows && cols && rowptr && col && val && out);
+    hipLaunchKernelGGL(csr_lookup_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), nq, n, rows, cols, rowptr, col, val, out);
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
 
 extern "C" int lpf_ppr_filter_count(int64_t n, const int64_t *rowptr, const float *val, int32_t mode, float theta,
                                     int64_t *out_len, void *stream) {

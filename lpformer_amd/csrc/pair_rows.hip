@@ -43,8 +43,14 @@ namespace {
 
 constexpr uint32_t PR_PAIR_MASK = 0x7fffffffu;
 constexpr int PR_LB_WORDS = LPF_ROWS_PERM_LB_WORDS - 1;   // scan words of the perm order (>= the largest grid: 3 workgroups x 256+ CUs)
-constexpr int PR_CHUNK = 512;    // pairs of the workgroup's range staged in LDS at a time
-constexpr int PR_FLAGS = 2048;   // units of a chunk whose completion is tracked in LDS (more: one barrier, then the merges)
+#ifndef PR_CHUNK_N    /* (tuning aids: -DPR_CHUNK_N / -DPR_FLAGS_N / -DPR_NP shrink the LDS image -- co-residency probes) */
+#define PR_CHUNK_N 512
+#endif
+#ifndef PR_FLAGS_N
+#define PR_FLAGS_N 2048
+#endif
+constexpr int PR_CHUNK = PR_CHUNK_N;   // pairs of the workgroup's range staged in LDS at a time
+constexpr int PR_FLAGS = PR_FLAGS_N;   // units of a chunk whose completion is tracked in LDS (more: one barrier, then the merges)
 
 struct RowsArgs {
     int64_t bs;
@@ -131,7 +137,11 @@ constexpr int pr_piece_floats(int D) { return (D + 4 + 31) / 32 * 32; }
 
 // LDS carve-up, shared by the kernel and the launcher (float4 units unless noted)
 // (PT form: NP patterns per type instead of one, and no copy of Wfold^T -- its corrections are the exception there)
+#ifdef PR_NP
+constexpr int pr_patterns(int G, bool PT) { return !PT ? 1 : (PR_NP); }
+#else
 constexpr int pr_patterns(int G, bool PT) { return !PT ? 1 : (G >= 64 ? LPF_ROWS_PATTERNS / 2 : LPF_ROWS_PATTERNS); }
+#endif
 
 template <int G, int NTH, int WTL, bool PT = false, int NV = 1>
 struct PrLds {
@@ -1167,7 +1177,9 @@ int rows_launch(int32_t D, int64_t bs, const int32_t *type_ptr, const void *entr
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(!PT || (pat_base && pat_grid && pat_sign && lpf_aligned16(pat_base) && grid_n >= 2 && grid_n <= 4096 &&
                         grid_shift >= 0 && grid_shift <= 23 && grid_base >= 0 && grid_ofs >= 0.f));
-    LPF_REQUIRE(bs > 0 && bs < (PT ? (1ll << 29) : (1ll << 31)) && (PT ? (pair_tab && blk_cnt && lpf_aligned16(pair_tab)) : type_ptr != nullptr) &&
+    LPF_REQUIRE(bs > 0 && bs < (PT ? (1ll << 29) : (1ll << 31)) &&
+                (PT ? (pair_tab && blk_cnt && lpf_aligned16(pair_tab) && (reinterpret_cast<uintptr_t>(blk_cnt) & 7) == 0)
+                    : type_ptr != nullptr) &&
                 entries && ent_cap > 0 && ent_cap < (PT ? (1ll << 31) : (1ll << 29)) && Z && q &&
                 pe_tab_signed && pe_stat && (PT || base) && wfold_t && att && att_bias && ln_g && ln_b && out && pieces &&
                 units_cap >= (PT ? 2 : (3 * ent_cap + 15) / 16 + 1) && lpf_aligned16(pieces));

@@ -37,7 +37,7 @@ constexpr int S4_PAIRS = LPF_SELECT4_BLOCK;   // pairs per workgroup: one lane o
 #define S4_ROUNDS_N 4
 #endif
 constexpr int S4_ROUNDS = S4_ROUNDS_N;        // slots per thread in flight
-constexpr int CTL_ERR = 3, CTL_DONE = 10, CTL_ALLOC = 16;   // CTL_ALLOC: first of S4_SHARDS allocation counters
+constexpr int CTL_SLOTS = 1, CTL_ERR = 3, CTL_DONE = 10, CTL_ALLOC = 16;   // CTL_ALLOC: first of S4_SHARDS allocation counters
 // The entry buffer is cut into S4_SHARDS equal regions, a workgroup allocates in region blockIdx.x % S4_SHARDS: all
 // workgroups of a launch reach their allocation within a microsecond of each other, and 256 returning atomics on ONE
 // word take ~3 us to drain (~12 ns each) -- the wavefront that issued one waits that long at its next load.
@@ -330,13 +330,15 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
         // the last workgroup leaves the counters as the next launch on this control block wants them (stream order)
         const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(A.ctl + CTL_DONE), 1ull);
         if (done == (unsigned long long)gridDim.x - 1ull) {
-            unsigned long long most = 0ull;
+            unsigned long long most = 0ull, sum = 0ull;
             for (int sh = 0; sh < S4_SHARDS; ++sh) {
                 const unsigned long long v = atomicExch(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ALLOC + sh), 0ull);
                 most = v > most ? v : most;
+                sum += v;
             }
             atomicExch(reinterpret_cast<unsigned long long *>(A.ctl + CTL_DONE), 0ull);
             A.ctl[0] = (int64_t)(most * S4_SHARDS);   // entries the batch needs room for (what ent_cap is sized from)
+            A.ctl[CTL_SLOTS] = (int64_t)sum;          // its candidate slots (block by block rounded to 8)
         }
     }
 #ifdef S4_STAMPS
@@ -367,7 +369,7 @@ extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, i
     LPF_REQUIRE(bs > 0 && bs < (1ll << 29) && batch && batch_ld >= bs && n_nodes > 0 && node_rec && adj_cv && a1_cv &&
                 (px_cv || !use_px) && u_cv && mini && ctl && pair_tab && blk_cnt && entries && ent_cap > 0 &&
                 ent_cap < (1ll << 31) && lpf_aligned16(node_rec) && lpf_aligned16(u_cv) && lpf_aligned16(mini) &&
-                lpf_aligned16(pair_tab) && lpf_aligned16(entries));
+                lpf_aligned16(pair_tab) && lpf_aligned16(entries) && (reinterpret_cast<uintptr_t>(blk_cnt) & 7) == 0);
     Args4 a;
     a.bs = bs; a.batch = batch; a.batch_ld = batch_ld; a.n_nodes = n_nodes;
     a.rec = static_cast<const NodeRec *>(node_rec);

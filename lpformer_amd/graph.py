@@ -188,6 +188,20 @@ def self_ppr(adj: CSR, ppr: CSR) -> np.ndarray:
     return out
 
 
+class RemovedEdges:
+    """An adjacency override stated as a DIFFERENCE: the model's own typing adjacency minus these undirected edges.
+
+    The reference's training loop rebuilds the masked adjacency of every batch from all training edges
+    (src/train/train_model.py:38-46: ``adjmask[perm] = 0; SparseTensor.from_edge_index(train_pos[adjmask])...``).
+    ``model(edges, adj_mask=masked_adj)`` accepts that tensor as it is -- the difference to the resident adjacency is then
+    found on the device --; a loop that knows which edges it removed can say so directly,
+    ``model(edges, adj_mask=lpformer_amd.RemovedEdges(edges))``, and skip building the tensor.
+    ``edges``: [2, K] node ids (either direction; edges the adjacency does not hold are ignored)."""
+
+    def __init__(self, edges):
+        self.edges = edges
+
+
 def as_coo_numpy(obj):
     """(row, col, val|None, n) from the graph objects the reference's data dict may hold:
     torch sparse COO/CSR tensors, scipy matrices, torch_sparse.SparseTensor-like objects (``.coo()``), or CSR."""

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, fold, graph, patterns
+from . import _lib, fold, graph, mask_delta, patterns
 from . import dist as lpf_dist
 from ._lib import FLAG_RELU, check, ptr
 from .profile import KernelTimer
@@ -609,6 +609,13 @@ class LinkTransformer(nn.Module):
         self._shard = (0, 1)   # (rank, world)
         self.encoder_mode = "sharded"  # with world > 1: "sharded" (rows + all-gather per layer) or "replicated"
         self.use_select_index = True  # False: always run the general (PPR-streaming) selection kernel
+        # an adjacency override that is the model's own typing adjacency minus a few edges (the training loop's masked
+        # adjacency, src/train/train_model.py:38-46) is taken as that DIFFERENCE: selection over the resident walk indexes,
+        # then a patch over the entries that touch a removed edge (lpformer_amd/mask_delta.py) -- no CSR is built from the
+        # override.  False: every override becomes a graph of its own on the general selection path (rounds 2-5)
+        self.use_mask_delta = True
+        self.mask_delta_limit = 1 << 20     # removed directed edges above which an override is a graph of its own
+        self._delta_cache = None            # (override object, test_set, removed keys or None): the LAST override only
         self.select_grid = 0           # workgroups of lpf_select3_run (0 = as many as are resident at once)
         # the selection in front of the pair-major attention: True = ONE launch leaving pair-major entries + a table entry
         # per pair (csrc/select4.hip: blocks of 64 pairs, no plan launch, no chained scan); False = lpf_select3_plan / _run
@@ -702,6 +709,8 @@ class LinkTransformer(nn.Module):
         if hit is not None and hit[0] is obj:
             return hit[1]
         dev = self.device
+        if isinstance(obj, graph.RemovedEdges):
+            raise TypeError("RemovedEdges describes a typing adjacency (the adj_mask argument), nothing else")
         if kind == "t0":    # per-model indexes: filtered on the device from the resident PPR matrix
             g = graph.ppr_filter_device_blocked(self._device_graph("ppr", obj), 0, self.thresh_non1hop)
         elif isinstance(obj, graph.CSR) and kind in ("mask", "ppr"):
@@ -1155,7 +1164,20 @@ class LinkTransformer(nn.Module):
             return self._walk_index(mask_obj, ppr_obj)
         ppr = self._device_graph("ppr", ppr_obj)
         adjx = self._device_graph("mask", mask_obj)
-        adj = adjx if adj_mask is None else self._device_graph("mask", adj_mask)
+        if isinstance(adj_mask, graph.RemovedEdges):
+            # a consumer on the general path (the fused evaluation kernels behind an override): the own adjacency without
+            # the removed edges as a CSR of its own (one slot, like every override)
+            hit = self._override.get("mask")
+            if hit is None or hit[0] is not adj_mask:
+                own = self._own_mask_keys(test_set)
+                rk = mask_delta.removed_from_edges(own, torch.as_tensor(adj_mask.edges).to(self.device), self.num_nodes)
+                keep = own[~mask_delta._member(rk, own)]
+                r = torch.div(keep, self.num_nodes, rounding_mode="floor")
+                hit = self._override["mask"] = (adj_mask, graph.csr_from_coo_device(r, keep - r * self.num_nodes, None,
+                                                                                    self.num_nodes))
+            adj = hit[1]
+        else:
+            adj = adjx if adj_mask is None else self._device_graph("mask", adj_mask)
         t0 = self._device_graph("t0", ppr_obj) if self.mask == "all" else None
         return adj, adjx, ppr, t0
 
@@ -1281,10 +1303,79 @@ class LinkTransformer(nn.Module):
             ws.calibrated = False   # re-size on the next batch
         return ok
 
+    def _own_mask_keys(self, test_set: bool) -> torch.Tensor:
+        """Sorted int64 keys row * N + col of the model's own typing adjacency (kept with its device graph)."""
+        g = self._device_graph("mask", self._data_obj("mask", test_set))
+        k = g.__dict__.get("_edge_keys")
+        if k is None:
+            k = g.__dict__["_edge_keys"] = mask_delta.edge_keys(g.rowptr, g.col, g.n)
+        return k
+
+    def _mask_delta(self, adj_mask, test_set: bool):
+        """The override as a difference to the model's own typing adjacency: sorted directed keys of the removed edges, or
+        None (not a subset of the own adjacency / too many edges removed / a model whose common-neighbour threshold is
+        positive, lpformer_amd/mask_delta.py).  The last override's answer is kept (the training loop passes a fresh
+        object per batch; ``compute_node_mask`` and ``forward`` of one batch share theirs)."""
+        if not (self.use_mask_delta and self.use_select_index) or self.thresh_cn > 0:
+            return None
+        hit = self._delta_cache
+        if hit is not None and hit[0] is adj_mask and hit[1] == test_set:
+            return hit[2]
+        n, dev = self.num_nodes, self.device
+        own = self._own_mask_keys(test_set)
+        if isinstance(adj_mask, graph.RemovedEdges):
+            rk = mask_delta.removed_from_edges(own, torch.as_tensor(adj_mask.edges).to(dev), n)
+        else:
+            coo = graph.as_coo_device(adj_mask, dev)
+            if coo is None:     # (a host-side container: its indices go to the device once, nothing is sorted there)
+                row, col, _, nn = graph.as_coo_numpy(adj_mask)
+                coo = (torch.from_numpy(np.ascontiguousarray(row)).to(dev), torch.from_numpy(np.ascontiguousarray(col)).to(dev),
+                       None, nn)
+            if coo[3] != n:
+                raise ValueError(f"graph has {coo[3]} nodes, the model {n}")
+            rk = mask_delta.removed_from_coo(own, coo[0], coo[1], n, self.mask_delta_limit)
+        self._delta_cache = (adj_mask, test_set, rk)
+        return rk
+
+    def _ppr_lookup(self, test_set: bool):
+        """rows, cols -> raw PPR values (0 where nothing is stored) through ``lpf_csr_lookup_f32``."""
+        ppr = self._device_graph("ppr", self._data_obj("ppr", test_set))
+
+        def lookup(rows, cols):
+            out = torch.empty(rows.numel(), dtype=torch.float32, device=self.device)
+            rows, cols = rows.contiguous(), cols.contiguous()
+            check(_lib.hip().lpf_csr_lookup_f32(rows.numel(), ppr.n, ptr(rows), ptr(cols), ptr(ppr.rowptr), ptr(ppr.col),
+                                                ptr(ppr.val), ptr(out), _stream(self.device)), "lpf_csr_lookup_f32")
+            return out
+        return lookup
+
+    def _select_patched(self, batch: torch.Tensor, test_set: bool, rk: torch.Tensor):
+        """``_select`` for an override given as removed edges: the resident-index selection, then the patch."""
+        s = self._select(batch, test_set, None)
+        bs = s["bs"]
+        if bs == 0 or rk.numel() == 0:
+            return s
+        pair, node, pa, pb, tp, counts = mask_delta.patch_selection(s, batch, rk, self.num_nodes, self.mask,
+                                                                    self.thresh_1hop, self._ppr_lookup(test_set))
+        feats, d = s["feats"], self.dim
+        c = counts.to(torch.float32)
+        if self.count_dim == 4:
+            feats[:, d:d + 4] = torch.stack([c[0], c[1], c[2], c[0] + c[1]], dim=1)
+        elif self.count_dim == 3:
+            feats[:, d:d + 3] = torch.stack([c[0], c[1], c[0] + c[1]], dim=1)
+        else:
+            feats[:, d] = c[0]
+        return {"bs": bs, "cap": max(int(pair.numel()), 1), "type_ptr": tp, "sel_pair": pair, "sel_node": node,
+                "sel_pa": pa, "sel_pb": pb, "feats": feats, "ldf": s["ldf"]}
+
     def _select(self, batch: torch.Tensor, test_set: bool, adj_mask=None):
         """Selection in the REFERENCE layout (module-by-module path, compute_node_mask, attention weights): the two
         selection launches, a status check (this path synchronises), then lpf_select_export.  Returns a dict of device
         arrays (type-major entries sorted by (pair, node), int64 segment pointers, float count features)."""
+        if adj_mask is not None:
+            rk = self._mask_delta(adj_mask, test_set)
+            if rk is not None:
+                return self._select_patched(batch, test_set, rk)
         lib, st = _lib.hip(), _stream(self.device)
         bs = batch.shape[1]
         ldf = _pad4(self.dim + self.count_dim)
@@ -1389,11 +1480,14 @@ class LinkTransformer(nn.Module):
         pairs of the model's OWN graph and PPR matrix, the selection kernels run on it.  A property of the graph, the
         PPR matrix and the thresholds, not of the weights: drawn once per model.  It decides which activation patterns
         are tabulated (``patterns.build``) and feeds ``flips_per_entry``; results never depend on it."""
+        mask_obj, ppr_obj = self._data_obj("mask", False), self._data_obj("ppr", False)
         hit = getattr(self, "_sample_cache", None)
-        if hit is not None:
-            return hit
+        if hit is not None and hit[0] is mask_obj and hit[1] is ppr_obj:
+            return hit[2]
+        if hit is not None:     # another graph / PPR matrix was bound: everything derived from the old sample goes with it
+            self._drop_sample_state()
         with torch.no_grad():
-            mask = self._device_graph("mask", self._data_obj("mask", False))
+            mask = self._device_graph("mask", mask_obj)
             gen = torch.Generator(device=self.device)
             gen.manual_seed(seed)
             k = n_pairs // 2 if mask.nnz > 0 else 0
@@ -1411,8 +1505,16 @@ class LinkTransformer(nn.Module):
             for t in range({"all": 3, "1-hop": 2, "cn": 1}[self.mask]):
                 out[t] = (sel["sel_pa"][base:base + tot[t]].clone(), sel["sel_pb"][base:base + tot[t]].clone())
                 base += tot[t]
-        self._sample_cache = out
+        self._sample_cache = (mask_obj, ppr_obj, out)
         return out
+
+    def _drop_sample_state(self):
+        """Forget the entry sample and what was decided from it (the select4 / select3 gate, the `auto` attention choice,
+        the tabulated patterns): called when the graph or the PPR matrix the sample was drawn from is replaced."""
+        self._sample_cache = None
+        self._flip_est = self._pt_choice = self._auto_choice = self._pt_cache = None
+        if self._folded is not None:
+            self._folded[1].pop("patterns", None)
 
     def _pattern_tables(self, w: dict) -> dict:
         """Activation-pattern tables of the pair-major attention behind select4 (``lpformer_amd/patterns.py``), built on
@@ -1420,10 +1522,35 @@ class LinkTransformer(nn.Module):
         captured graphs hold pointers into both)."""
         pt = w.get("patterns")
         if pt is None:
-            n_types = {"all": 3, "1-hop": 2, "cn": 1}[self.mask]
-            sd = {k: v for k, v in self.state_dict().items()}
-            pt = w["patterns"] = patterns.build(sd, self.dim, n_types, self._entry_sample(), device=self.device)
+            # keyed on the versions of the tensors the tables are built from (the PE MLPs and lin_r), not on the whole
+            # fold: an optimiser step that leaves them alone (frozen encoders, a score-head-only fine-tune) keeps them
+            sample = self._entry_sample()
+            key = self._pattern_key()
+            hit = getattr(self, "_pt_cache", None)
+            if hit is not None and hit[0] == key:
+                pt = hit[1]
+            else:
+                n_types = {"all": 3, "1-hop": 2, "cn": 1}[self.mask]
+                sd = {k: v for k, v in self.state_dict().items()}
+                pt = patterns.build(sd, self.dim, n_types, sample, device=self.device)
+                self._pt_cache = (key, pt)
+            w["patterns"] = pt
         return pt
+
+    def _pattern_key(self):
+        ps = [self.att_layers[0].att.lin_r.weight]
+        for name in ("ppr_encoder_cn", "ppr_encoder_onehop", "ppr_encoder_non1hop"):
+            mod = getattr(self, name, None)
+            if mod is not None:
+                ps += list(mod.parameters())
+        return tuple((p.data_ptr(), p._version) for p in ps)
+
+    def _prepare_pair_major(self, adj_mask=None):
+        """Everything the pair-major attention decides or builds on the host -- the select4 / select3 gate (a 4,096-pair
+        selection + the table build, once per parameter version) and the activation-pattern tables -- BEFORE a side
+        stream is forked: none of it may run between the fork and the join of a step."""
+        if self.dim >= 128 and self.use_fused_attention and self._uses_rows() and self._uses_select4(adj_mask):
+            self._pattern_tables(self._fold())
 
     @_on_device
     def _flip_stats(self):
@@ -1615,6 +1742,7 @@ class LinkTransformer(nn.Module):
                 if ld > d + self.count_dim:
                     feats[:, d + self.count_dim:].zero_()
                 layer = self.att_layers[0]
+                self._prepare_pair_major(adj_mask)
                 side = self._fork()
                 if self._uses_rows():
                     self._attention_rows(batch, x_node, test_set, adj_mask, side, feats, self.count_dim)
@@ -1780,6 +1908,8 @@ class LinkTransformer(nn.Module):
             q_side = None
             if one_pass and self.query_from == "table" and (d < 256 or self._uses_rows()):
                 q_side = (self._node_y(x_node, self._fold()), torch.empty(bs, d, dtype=torch.float32, device=self.device))
+            if one_pass:
+                self._prepare_pair_major(adj_mask)
             side = self._fork()
             # t_e = A_e r_e by the elementwise branch's own launch (second layer of its chain) where the pair-major tail
             # with an order runs behind it: a third of that tail's matrix work moves into a launch bound by its gather

@@ -1,0 +1,133 @@
+"""An adjacency override as a DIFFERENCE to the resident adjacency (the training step).
+
+The reference's training loop hands ``model(edges, adj_mask=masked_adj)`` a fresh sparse tensor per batch: every training
+edge except the batch's own positives (src/train/train_model.py:38-46).  ``compute_node_mask`` types a candidate node v
+of pair (a, b) by t = A'[a, v] + A'[b, v] over that masked adjacency A' (src/models/link_transformer.py:229-237) while the
+>1-hop set keeps excluding the neighbours of the UNMASKED adjacency A (:438-443).  Round 2-5 turned every such tensor into
+a CSR of its own (a device sort + unique over all 2 E edges, 4 ms per batch on the collab-like graph) and ran the general
+selection kernels over it.  But A' = A minus a handful of edges R, and only entries (k, v) with (a_k, v) or (b_k, v) in R
+can differ between the two selections:
+
+  D_a = {v : (a, v) in R} is a subset of N(a); for v in D_a or D_b the type drops by one per removed side,
+    t = 2 (common neighbour), one side removed  -> t' = 1: a one-hop node, values ((p * 1 + 1) - 1) / 1 of the RAW PPR
+                                                   values (:290-291,316-317 -- not the t = 2 round trip the unmasked
+                                                   selection stored), kept iff both >= thresh_1hop (:241-250)
+    t = 2, both sides removed                   -> t' = 0: gone (it is adjacent in A, so it is no >1-hop node either)
+    t = 1 (one-hop), its one side removed       -> t' = 0: gone
+    t = 0 (>1-hop)                               -> never in D_a or D_b: unchanged
+
+so the masked selection is the resident-index selection (``lpf_select3_*`` over the walk indexes, no graph rebuilt)
+followed by this patch over the few entries that touch R.  Requires thresh_cn <= 0 (every shipped script): then every
+common neighbour is IN the unmasked result and can be re-typed; with thresh_cn > 0 a common neighbour that failed its
+own test could still pass the one-hop test after losing an edge -- such models keep the general path.
+
+Everything here is torch index arithmetic on whatever device the tensors live on (the CPU tests run it against the oracle);
+the one data-sized look-up -- raw PPR values of the re-typed entries -- is passed in (``lpf_csr_lookup_f32`` on the GPU).
+"""
+from __future__ import annotations
+
+import torch
+
+
+def edge_keys(rowptr: torch.Tensor, col: torch.Tensor, n: int) -> torch.Tensor:
+    """Sorted int64 keys row * n + col of a CSR pattern with sorted columns."""
+    rows = torch.repeat_interleave(torch.arange(n, device=rowptr.device), rowptr[1:] - rowptr[:-1])
+    return rows * n + col.long()
+
+
+def _member(sorted_keys: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    if sorted_keys.numel() == 0:
+        return torch.zeros_like(q, dtype=torch.bool)
+    pos = torch.searchsorted(sorted_keys, q).clamp_(max=sorted_keys.numel() - 1)
+    return sorted_keys[pos] == q
+
+
+def removed_from_edges(own: torch.Tensor, edges: torch.Tensor, n: int) -> torch.Tensor:
+    """Directed keys of the undirected ``edges`` [2, K] that the adjacency ``own`` (sorted keys) holds: sorted, unique."""
+    e = edges.long().reshape(2, -1)
+    ok = (e[0] >= 0) & (e[0] < n) & (e[1] >= 0) & (e[1] < n)
+    e = e[:, ok]
+    q = torch.unique(torch.cat([e[0] * n + e[1], e[1] * n + e[0]]))
+    return q[_member(own, q)]
+
+
+def removed_from_coo(own: torch.Tensor, row: torch.Tensor, col: torch.Tensor, n: int, limit: int):
+    """The override (row, col) as a difference to ``own``: sorted directed keys own holds and the override does not -- or
+    None when the override is not a subset of ``own`` or differs by more than ``limit`` directed edges (it is then a
+    graph of its own).  One host synchronisation."""
+    mk = row.long() * n + col.long()
+    if mk.numel() == 0:
+        return own if own.numel() <= limit else None
+    inc = (mk[1:] > mk[:-1]).all() if mk.numel() > 1 else torch.ones((), dtype=torch.bool, device=mk.device)
+    hit = _member(mk, own)                     # (meaningful only when mk is sorted and duplicate-free: checked below)
+    n_hit, is_sorted = (int(v) for v in torch.stack([hit.sum(), inc.long()]).tolist())
+    if not is_sorted:                          # (a SparseTensor-like object may hand its entries over in any order)
+        mk = torch.unique(mk)
+        hit = _member(mk, own)
+        n_hit = int(hit.sum())
+    if n_hit != mk.numel() or own.numel() - n_hit > limit:
+        return None
+    return own[~hit]
+
+
+def round_trip1(v: torch.Tensor) -> torch.Tensor:
+    """((v * 1 + 1) - 1) / 1 in separately rounded fp32 operations (link_transformer.py:290-291,316-317 with t = 1)."""
+    one = torch.ones((), dtype=torch.float32, device=v.device)
+    return (v * one + one) - one
+
+
+def patch_selection(sel: dict, batch: torch.Tensor, rk: torch.Tensor, n: int, mode: str, th_1hop: float, lookup):
+    """The selection of the MASKED adjacency from the selection ``sel`` of the resident one.
+
+    sel: type-major arrays ``sel_pair`` / ``sel_node`` (int32), ``sel_pa`` / ``sel_pb`` (fp32) -- CN, then one-hop, then
+    >1-hop entries, each run sorted by (pair, node) -- and ``type_ptr`` int64 [3 * (bs + 1)] of per-type segment pointers
+    (``lpf_select_export``'s layout).  rk: sorted directed keys of the removed edges.  lookup(rows, cols) -> raw PPR
+    values P[rows, cols] (fp32, 0 where nothing is stored).  Returns (pair, node, pa, pb, type_ptr, counts int64 [3, bs])
+    in the same layout, new tensors."""
+    bs = batch.shape[1]
+    dev = batch.device
+    tp = sel["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)
+    n0, n1, n2 = (int(v) for v in tp[:, bs].tolist())
+    m, tot = n0 + n1, n0 + n1 + n2
+    pair_i, node_i = sel["sel_pair"][:tot], sel["sel_node"][:tot]
+    pa, pb = sel["sel_pa"][:tot], sel["sel_pb"][:tot]
+    pair, node = pair_i[:m].long(), node_i[:m].long()
+    a, b = batch[0][pair], batch[1][pair]
+    in_a, in_b = _member(rk, a * n + node), _member(rk, b * n + node)
+    touched = in_a | in_b
+    idx = torch.arange(m, device=dev)
+    if mode == "cn":            # pair_adj = src * tgt (:232-234): common neighbours of the masked adjacency only
+        keep0 = ~touched
+        parts = [(pair_i[:m][keep0], node_i[:m][keep0], pa[:m][keep0], pb[:m][keep0])]
+        p1 = None
+    else:
+        is_cn = idx < n0
+        keep0 = is_cn & ~touched
+        keep1 = ~is_cn & ~touched
+        dem = is_cn & (in_a ^ in_b)
+        parts = [(pair_i[:m][keep0], node_i[:m][keep0], pa[:m][keep0], pb[:m][keep0])]
+        p1 = (pair_i[:m][keep1], node_i[:m][keep1], pa[:m][keep1], pb[:m][keep1])
+        di = torch.nonzero(dem).flatten()
+        if di.numel() > 0:      # common neighbours that lost ONE of their two edges: one-hop candidates now
+            dn = node[di]
+            raw = lookup(torch.cat([a[di], b[di]]), torch.cat([dn, dn]))
+            va, vb = round_trip1(raw[:di.numel()]), round_trip1(raw[di.numel():])
+            ok = (va >= th_1hop) & (vb >= th_1hop)
+            if bool(ok.any()):
+                dk = di[ok]
+                cat = [torch.cat([p1[0], pair_i[:m][dk]]), torch.cat([p1[1], node_i[:m][dk]]),
+                       torch.cat([p1[2], va[ok]]), torch.cat([p1[3], vb[ok]])]
+                order = torch.argsort(cat[0].long() * n + cat[1].long())
+                p1 = tuple(t[order] for t in cat)
+        parts.append(p1)
+        parts.append((pair_i[m:tot], node_i[m:tot], pa[m:tot], pb[m:tot]))
+    counts = torch.zeros(3, bs, dtype=torch.int64, device=dev)
+    for t, part in enumerate(parts):
+        if t < 2:
+            counts[t] = torch.bincount(part[0].long(), minlength=bs)
+        else:
+            counts[t] = tp[2, 1:] - tp[2, :-1]
+    new_tp = torch.zeros(3, bs + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, dim=1, out=new_tp[:, 1:])
+    out = [torch.cat([p[k] for p in parts]) for k in range(4)]
+    return out[0], out[1], out[2], out[3], new_tp.reshape(-1), counts

@@ -56,9 +56,12 @@ def grid_geometry(m: int = GRID_M, ofs_exp: int = GRID_OFS_EXP) -> dict:
 
 
 def cell_index(v: torch.Tensor, geo: dict) -> torch.Tensor:
-    """The kernel's cell of every value (fp32 arithmetic, bit for bit)."""
+    """The kernel's cell of every value (fp32 arithmetic, bit for bit: csrc/pair_rows.hip ``grid_cell`` -- a value below
+    the grid, negative or NaN lands in the LAST cell, which is never tabulated)."""
     u = (v.to(torch.float32) + geo["ofs"]).view(torch.int32).to(torch.int64) & 0xffffffff
-    return ((u >> geo["shift"]) - geo["base"]).clamp_(0, geo["n"] - 1)
+    c = (u >> geo["shift"]) - geo["base"]
+    last = geo["n"] - 1
+    return torch.where(c < 0, torch.full_like(c, last), c.clamp_max(last))
 
 
 def _f_and_grad(x, y, ta, tc, td, be, st):
@@ -129,6 +132,9 @@ def classify(tab: torch.Tensor, st: torch.Tensor, geo: dict, chunk: int = 1 << 1
     lo, hi = (e[:-1] - pad).clamp_min(0.0), e[1:] + pad
     ta, tc, td, be = tab[:, 0], tab[:, 1], tab[:, 2], tab[:, 3]
     convex = be >= 0
+    # a unit that is zero identically (LayerNorm gain and bias exactly 0: a pruned unit) is inactive everywhere and owes
+    # no correction in any cell: it must not make every cell of the grid ambiguous
+    dead = (ta.abs() + tc.abs() + td.abs() + be.abs()) == 0
     words = torch.empty((n * n, (tab.shape[0] + 31) // 32), dtype=torch.int64, device=dev)
     clean = torch.empty(n * n, dtype=torch.bool, device=dev)
     for a in range(0, n * n, chunk):
@@ -144,7 +150,7 @@ def classify(tab: torch.Tensor, st: torch.Tensor, geo: dict, chunk: int = 1 << 1
         spread = gx.abs() * (0.5 * (x1 - x0))[:, None] + gy.abs() * (0.5 * (y1 - y0))[:, None]
         fmin = torch.where(convex, fc - spread, cmin)
         fmax = torch.where(convex, cmax, fc + spread)
-        clean[idx] = ((fmin > 0) | (fmax < 0)).all(dim=1)
+        clean[idx] = ((fmin > 0) | (fmax < 0) | dead).all(dim=1)
         words[idx] = _pack(fc > 0)
     # the open-ended last cell of either axis is never clean
     g = clean.view(n, n)

@@ -67,6 +67,7 @@ class LPFormer(nn.Module):
         self.core._z_cache = None
         self.core._y_cache = None
         self.core._enc_cache = None
+        self.core._drop_sample_state()     # (the entry sample and the choices made from it belong to the old graph)
         self._bound = key
 
     def forward(self, batch: torch.Tensor, x: torch.Tensor, edge_index: torch.Tensor, ppr_matrix) -> torch.Tensor:

@@ -208,6 +208,29 @@ def test_masked_adjacency_override_vs_reference():
         np.testing.assert_array_equal(ix, fx[f"masked_sel_{tag}_ix"])
         np.testing.assert_array_equal(pa.view(np.uint32), fx[f"masked_sel_{tag}_pa"].view(np.uint32))
         np.testing.assert_array_equal(pb.view(np.uint32), fx[f"masked_sel_{tag}_pb"].view(np.uint32))
+    # ... which took the override as a DIFFERENCE to the resident adjacency (selection over the walk indexes + the patch of
+    # lpformer_amd/mask_delta.py); the same through the general kernels over a CSR built from the override, and with the
+    # removed edges named explicitly (lpformer_amd.RemovedEdges) -- all three bit-exact
+    assert model._delta_cache[0] is masked_adj and model._delta_cache[2] is not None and model._delta_cache[2].numel() > 0
+    ei = fx["edge_index"].astype(np.int64)
+    kept = set((keep[0] * n + keep[1]).tolist()) | set((keep[1] * n + keep[0]).tolist())
+    removed = ei[:, [k not in kept for k in (ei[0] * n + ei[1]).tolist()]]
+    assert removed.shape[1] > 0
+    import lpformer_amd
+    for form in ("general", "removed"):
+        model.use_mask_delta = form != "general"
+        model._delta_cache = None
+        ov = masked_adj if form == "general" else lpformer_amd.RemovedEdges(torch.from_numpy(removed))
+        infos2 = model.compute_node_mask(mb, False, ov)
+        assert (model._delta_cache is None) == (form == "general")
+        for tag, info in zip(("cn", "onehop", "non1hop"), infos2):
+            ix, pa, pb = (t.cpu().numpy() for t in info)
+            np.testing.assert_array_equal(ix, fx[f"masked_sel_{tag}_ix"])
+            np.testing.assert_array_equal(pa.view(np.uint32), fx[f"masked_sel_{tag}_pa"].view(np.uint32))
+            np.testing.assert_array_equal(pb.view(np.uint32), fx[f"masked_sel_{tag}_pb"].view(np.uint32))
+        feats = model(mb, adj_mask=ov)            # (eval mode: the fused kernels behind a CSR of the override)
+        assert _err(feats.cpu(), fx["masked_combined_feats"]) <= TOL
+    model.use_mask_delta = True
     feats = model(mb, adj_mask=masked_adj)
     assert _err(feats.cpu(), fx["masked_combined_feats"]) <= TOL
     assert _err(score.logits(feats).cpu(), fx["masked_logit"]) <= TOL

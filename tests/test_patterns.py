@@ -164,3 +164,25 @@ def test_nearest_pattern_is_the_hamming_nearest():
     dist = (bits(words)[:, None, :] != bits(chosen)[None, :, :]).sum(-1)
     assert torch.equal(got, dist.argmin(dim=1))
     assert int(patterns._popcount32(torch.tensor([0, 1, 0xffffffff, 0x80000001])).sum()) == 0 + 1 + 32 + 2
+
+
+def test_a_unit_that_is_zero_everywhere_does_not_make_every_cell_ambiguous():
+    """A pruned hidden unit (LayerNorm gain and bias exactly 0) is inactive at every point: it may not fail the
+    clean-cell test in every cell (coverage 0 %); and values just below zero land in the kernel's LAST cell."""
+    dim = 32
+    st = _state(dim, 5)
+    n_clean = []
+    for prune in (False, True):
+        if prune:
+            for k in fold.PE_KEYS:
+                st[f"{k}.norm.weight"][3] = 0.0
+                st[f"{k}.norm.bias"][3] = 0.0
+        pt = patterns.build(st, dim, 3, sample=None, device="cpu", m=3, ofs_exp=-8)
+        n_clean.append([s["clean"] for s in pt["stats"]])
+        if prune:
+            assert all(int(w) & (1 << 3) == 0 for w in pt["sign"][:, :, 0].reshape(-1).tolist())
+    assert min(n_clean[1]) > 0.0, "a dead unit flagged the whole grid"
+    assert all(b >= a - 1e-12 for a, b in zip(n_clean[0], n_clean[1]))   # (one unit fewer to cross a cell)
+    geo = patterns.grid_geometry()
+    below = torch.tensor([-2.0 ** -13, -2.0 ** -20])
+    assert patterns.cell_index(below, geo).tolist() == [geo["n"] - 1] * 2

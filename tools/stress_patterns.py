@@ -1,51 +1,17 @@
-"""One-off insurance: the pattern-table attention (select4 -> rows4 -> tail) against the oracle over random graphs,
-widths 128 / 256, mask modes, PE weights scaled so that the table's coverage goes from ~100 % to a few percent (the
-exact path from the named pattern carries the rest), trained-like LayerNorm offsets."""
-import itertools, os, sys, time
+"""The pattern-table stress sweep as a report (the same 48 cases run as tests: tests/test_gpu_timed_path.py::
+test_pattern_table_stress): select4 -> rows4 -> tail against the oracle over random graphs, widths 128 / 256, mask modes,
+PE weights scaled so that the table's coverage goes from ~100 % to a few percent."""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-import lpformer_amd
-from lpformer_amd import data as D
-from oracle import lpformer_oracle as O
-DEV = "cuda:0"
+from tests.test_gpu_timed_path import STRESS, stress_case  # noqa: E402
+
 worst = 0.0
-k = 0
-for dim, gain, th, seed in itertools.product((128, 256), (1.0, 6.0, 30.0, 120.0),
-                                             ((0.0, 1e-3, 1e-2), (0.0, 1e-2, 1.0), (1e-3, 1.0, 1.0)), (0, 1)):
-    k += 1
-    rng = np.random.default_rng(1000 + k)
-    n = int(rng.integers(300, 1500))
-    ei, w = D.chung_lu_graph(n, int(n * rng.uniform(3, 14)), gamma=float(rng.uniform(2.05, 2.8)), seed=k,
-                             max_weight=int(rng.integers(0, 2)) * 5)
-    x = rng.standard_normal((n, 24)).astype(np.float32)
-    ppr = lpformer_amd.calc_ppr(ei, n, 0.15, 10.0 ** rng.uniform(-4.3, -3))
-    d = D.build_data(ei, x, n, edge_weight=w, ppr=ppr)
-    cfg = D.train_args_for(dict(thresholds=th, dim=dim, gnn_layers=1, residual=False))
-    torch.manual_seed(seed + 10 * k)
-    model = lpformer_amd.LinkTransformer(cfg, d, device=DEV).to(DEV).eval()
-    score = lpformer_amd.mlp_score(2 * dim, 2 * dim, 1, 2).to(DEV).eval()
-    with torch.no_grad():
-        for enc in (getattr(model, nm) for nm in ("ppr_encoder_cn", "ppr_encoder_onehop", "ppr_encoder_non1hop") if hasattr(model, nm)):
-            enc.linears[0].weight.mul_(gain)
-            enc.linears[0].bias.mul_(float(rng.uniform(0.2, 2.0)))
-            enc.norm.bias.add_(float(rng.uniform(0, 0.5)) * torch.randn_like(enc.norm.bias))
-            enc.norm.weight.mul_(1.0 + 0.3 * torch.randn_like(enc.norm.weight))
-    model.attention_impl = "flip"
-    model.PT_EXACT_MAX = float("inf")
-    P = {f"model.{kk}": v.detach().cpu().numpy() for kk, v in model.state_dict().items()}
-    P.update({f"score.{kk}": v.detach().cpu().numpy() for kk, v in score.state_dict().items()})
-    batch = D.sample_pairs(ei, n, int(rng.integers(200, 900)), seed=k)
-    ref = O.forward(batch, x, O.gcn_norm(ei, w, n), O.symmetric_mask_csr(ei, n),
-                    (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P, dict(cfg, pred_layers=2))
-    assert model._uses_select4() and model._uses_rows()
-    lg = model.score_pairs(torch.from_numpy(batch).to(DEV), model.propagate(), score, logits=True)
-    assert model.check_selection()
-    raw, left = model._flip_stats()
-    cov = [s["covered"] for s in model._pattern_tables(model._fold())["stats"]]
-    err = float(np.abs(lg.cpu().numpy() - ref["logit"]).max()) / max(1.0, float(np.abs(ref["logit"]).max()))
+for k, (dim, gain, th, seed) in enumerate(STRESS, 1):
+    err, raw, left, cov, mode, n_sel = stress_case(k, dim, gain, th, seed)
     worst = max(worst, err)
-    n_sel = sum(ref["sel"][t][0].shape[1] for t in ref["sel"] if ref["sel"][t] is not None and ref["sel"][t][0] is not None)
-    print(f"{k:3d} D={dim} gain={gain:5.1f} th={th} mode={model.mask:5s} n={n:4d} entries={n_sel:6d} flips raw {raw:6.2f} left {left:5.2f} "
+    print(f"{k:3d} D={dim} gain={gain:5.1f} th={th} mode={mode:5s} entries={n_sel:6d} flips raw {raw:6.2f} left {left:5.2f} "
           f"covered {[None if c is None else round(c, 3) for c in cov]} rel err {err:.2e}", flush=True)
     assert err <= 1e-4, "MISMATCH"
 print("worst relative logit error", worst)

@@ -22,13 +22,19 @@ class _ST:  # torch_sparse.SparseTensor look-alike on the device (what the refer
     def __init__(self, r, c, v, n): self._r, self._c, self._v, self._n = r, c, v, n
     def coo(self): return self._r, self._c, self._v
     def sparse_sizes(self): return (self._n, self._n)
-masked_mode = os.environ.get("LPF_TRAIN_MASKED", "")       # "", "gpu" or "cpu"
+# "": no override; "gpu" / "cpu": adj_prop AND adj_mask rebuilt per batch (--mask-input, the pubmed script); "mask": adj_mask
+# only (every OGB script: train_model.py:38-46 without --mask-input); "removed": lpformer_amd.RemovedEdges(edges)
+masked_mode = os.environ.get("LPF_TRAIN_MASKED", "")
+if os.environ.get("LPF_MASK_DELTA"):
+    model.use_mask_delta = os.environ["LPF_MASK_DELTA"] != "0"
 wts = None if w is None else torch.from_numpy(w[ei[0] < ei[1]]).to(dev)
 def step(i):
     model.train(); score.train()
     idx = torch.randint(0, pos.shape[1], (bs,), device=dev)
     edges = pos[:, idx]
-    if masked_mode:
+    if masked_mode == "removed":
+        pos_loss = -torch.log(score(model(edges, adj_mask=lpformer_amd.RemovedEdges(edges))) + 1e-6).mean()
+    elif masked_mode:
         # train_model.py:40-51: the batch's positive edges removed from the propagation / typing adjacency
         keep = torch.ones(pos.shape[1], dtype=torch.bool, device=dev); keep[idx] = False
         k = pos[:, keep]
@@ -36,7 +42,7 @@ def step(i):
         v = None if wts is None else torch.cat([wts[keep], wts[keep]])
         if masked_mode == "cpu":
             r, c, v = r.cpu(), c.cpu(), None if v is None else v.cpu()
-        adjt = _ST(r, c, v, n)
+        adjt = _ST(r, c, v, n) if masked_mode != "mask" else None
         pos_loss = -torch.log(score(model(edges, adj_prop=adjt, adj_mask=_ST(r, c, None, n))) + 1e-6).mean()
     else:
         pos_loss = -torch.log(score(model(edges)) + 1e-6).mean()
