@@ -71,12 +71,14 @@ from lpformer_amd import data as D  # noqa: E402
 from lpformer_amd import dist as LD  # noqa: E402
 from lpformer_amd.profile import KernelTimer  # noqa: E402
 
-PMC_FILE = "r05_pmc_traffic_{config}.json"  # committed rocprofv3 PMC passes (one file per config) `traffic` is read from
+L2_PEAK_GBS = 34500.0     # MI355X_MICROARCH.md "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
+PMC_SQ_FILE = "r06_pmc_sq_{config}.json"   # committed SQ counter pass of the dominant kernel (tools/pmc_kernel.sh)
+PMC_FILE = "r06_pmc_traffic_{config}.json"  # committed rocprofv3 PMC passes (one file per config) `traffic` is read from
 # timing span (KernelTimer) -> the HIP kernel that runs under it (what `roofline.kernel` names)
 KERNEL_NAMES = {"pair_attention_rows": "pair_rows_kernel", "pair_attention_fused": "pair_flip_kernel / pair_fused_kernel",
                 "tail_chain": "tail_chain_kernel", "select_run": "select_run", "select_plan": "select3_plan_kernel",
                 "dense_chain_mlp_hidden": "dense_chain_kernel (+ q gather)", "pair_gather_q": "pair_gather_kernel",
-                "pair_attention_merge": "pair_merge_kernel"}
+                "pair_attention_merge": "pair_merge_kernel", "select_regions": "s4_regions_kernel"}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 
@@ -125,6 +127,19 @@ def build_problem(cfg, rank, world, threads, ppr_device=None, barrier=None):
     return ei, w, x, data, {"graph_s": t1 - t0, "ppr_s": t2 - t1}
 
 
+def relabel_cache_resident(rooflines):
+    """A byte-priced entry whose measured HBM traffic is less than half its algorithmic bytes runs out of the caches
+    (ddi-like / cora-like tables of a few MB: SURVEY 8(d)'s bytes never reach HBM): priced against the guide's L2 figure
+    instead, the HBM fraction kept beside it -- a `frac` above 1 is not a roofline fraction."""
+    for r in rooflines.values():
+        if r.get("bound") == "hbm" and r.get("traffic") and r.get("algorithmic") and r["algorithmic"] > 2.0 * r["traffic"]:
+            r["frac_of_hbm_peak"] = r["frac"]
+            r["bound"], r["peak"] = "l2", L2_PEAK_GBS
+            r["frac"] = round(r["achieved"] / L2_PEAK_GBS, 4)
+            r["note"] = ("tables cache-resident: counter traffic is under half the algorithmic bytes, priced against the "
+                         "aggregate L2 rate (MI355X_MICROARCH.md, 34.5 TB/s)")
+
+
 def pair_stats(data, batch):
     """Per-batch structural sizes (reported beside the roofline: what a both-rows walk would have touched)."""
     adj, ppr = data["adj_mask"], data["ppr"]
@@ -141,7 +156,7 @@ def slot_count(model, batch_t):
         ws = model._select4_device(batch_t, False)     # (ctl[0] is 8 x the fullest allocation region: an upper bound)
         return int(ws.ctl[1].item())
     ws = model._select_device(batch_t, False, None)
-    return int(ws.ctl[0].item())
+    return int(ws.ctl[1 if hasattr(ws, "blk_types") else 0].item())   # (behind lpf_select4: word 1, as above)
 
 
 def run_cpu_workers(sample, x_node, mask, ppr, P, cfg, n_proc, chunk):
@@ -419,6 +434,8 @@ def main():
     #      would time Python, not the kernels)
     rows_probe = None
     planned_by_form = {}
+    if os.environ.get("LPF_SELECT4_REGIONS"):                    # A/B aid: "0" = lpf_select3_plan / _run for the type-major consumers
+        model.select4_regions = os.environ["LPF_SELECT4_REGIONS"] != "0"
     if os.environ.get("LPF_TAIL_SKIP_EMPTY"):                    # A/B aid: "0" = the plain rows tail
         model.tail_skip_empty = os.environ["LPF_TAIL_SKIP_EMPTY"] != "0"
     if args.rows != "auto":
@@ -781,6 +798,7 @@ def main():
             c = model.count_dim
             tail_short = bool(model.tail_skip_empty and model._uses_rows())
             four = bool(model._uses_select4() and model._uses_rows())
+            four_r = bool(not four and model._uses_select4_regions())   # lpf_select4 + lpf_select4_regions (type-major consumers)
             q_rides = model.query_from == "table" and "pair_gather_q" not in kt
             # the WHOLE pair stage against the HBM roof: SURVEY 8(d)'s B_pair summed over the batch (what a both-rows
             # walk of the reference's algorithm must touch) / the measured step time
@@ -806,7 +824,10 @@ def main():
                 # (descriptor, offset, three segment starts), one 16-byte record per selected entry
                 # (one-launch form, select4.hip: no descriptors or offsets in memory -- per pair two ids, two 64-byte node
                 #  records, two 128-byte filters and a 16-byte table entry)
-                "select_run": ("hbm", 16.0 * slots + ((16.0 + 128.0 + 256.0 + 16.0) if four else 148.0) * bs + 16.0 * n_sel),
+                "select_run": ("hbm", 16.0 * slots + ((16.0 + 128.0 + 256.0 + 16.0) if (four or four_r) else 148.0) * bs + 16.0 * n_sel),
+                # pair-major -> type-major (lpf_select4_regions): a table entry in, three pointers out per pair, every kept
+                # record read and written once
+                "select_regions": ("hbm", (16.0 + 12.0) * bs + 2 * 16.0 * n_sel),
                 # plan kernel: two node ids, two 64-byte node records, descriptor + offset per pair
                 "select_plan": ("hbm", (16.0 + 2 * 64.0 + 128.0 + 8.0) * bs),
                 "select_export": ("hbm", 2 * 16.0 * n_sel + 40.0 * bs),
@@ -837,13 +858,14 @@ def main():
                 ach = units / dur_s / (1e9 if bound == "hbm" else 1e12)
                 kname = KERNEL_NAMES.get(name, name)
                 if name == "select_run":
-                    kname = "select4_kernel" if four else "select3_run_kernel"
+                    kname = "select4_kernel" if (four or four_r) else "select3_run_kernel"
                 if name == "pair_attention_fused":
                     kname = "pair_flip_kernel" if model.attention_kernel() == "flip" else "pair_fused_kernel"
                 rooflines[name] = {"kernel": kname, "span": name, "bound": bound, "achieved": round(ach, 2), "peak": peak,
                                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4),
                                    "traffic": None, "launch_ms": round(kt[name][2], 4),
-                                   "launches_per_step": kt[name][0] / args.steps}
+                                   "launches_per_step": kt[name][0] / args.steps,
+                                   "algorithmic": round(units, 0)}
             # HBM traffic per launch: NOT measured in this run -- read from the committed rocprofv3 PMC passes
             # (FETCH_SIZE / WRITE_SIZE, gfx950-corrected; tools/collect_profiles.sh) and tagged with that file
             try:
@@ -855,12 +877,25 @@ def main():
                 for name, r in rooflines.items():
                     key = {"tail_chain": "tail_chain_rows"}.get(name, name) if rows_form else name
                     if name == "select_run":
-                        key = "select4" if four else "select3_run"
+                        key = "select4" if (four or four_r) else "select3_run"
                     if name == "pair_attention_fused" and model.attention_kernel() != "flip":
                         key = "pair_attention_fused_mfma"
                     if key in pmc["kernels"]:
                         r["traffic"] = pmc["kernels"][key]["hbm_bytes_per_launch_corrected"]
                         r["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes at {pmc.get('commit', '?')})"
+            except (OSError, KeyError, ValueError):
+                pass
+            relabel_cache_resident(rooflines)
+            # how much of the dominant kernel's wave time is waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES of a committed SQ
+            # counter pass): "hbm" is a nominal bound for a kernel that waits on its own instruction chain
+            try:
+                sq = json.load(open(os.path.join(ROOT, "profiles", PMC_SQ_FILE.format(config=args.config))))
+                for name, r in rooflines.items():
+                    hit = sq["kernels"].get(r["kernel"].split("<")[0])
+                    if hit:
+                        r["wave_wait_frac"] = round(hit["SQ_WAIT_ANY"] / max(hit["SQ_WAVE_CYCLES"], 1.0), 4)
+                        r["valu_insts_per_launch"] = hit.get("SQ_INSTS_VALU")
+                        r["sq_source"] = f"profiles/{PMC_SQ_FILE.format(config=args.config)} at {sq.get('commit', '?')}"
             except (OSError, KeyError, ValueError):
                 pass
             if bf16 is not None and "pair_attention_fused_ms" in bf16:
@@ -901,7 +936,7 @@ def main():
             ach_floor = floor / (layer_ms * 1e-3) / 1e9
             rooflines[ename] = {"kernel": label, "bound": "hbm",
                                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic": round(byts, 0),
                                 "launch_ms": round(layer_ms, 4),
                                 # gathered bytes (every neighbour row counted, L2 / Infinity Cache
                                 # serve most of them) above; the compulsory floor (each row once) here
@@ -917,6 +952,9 @@ def main():
                     rooflines[ename]["traffic_source"] = f"{pmc_file} (offline rocprofv3 PMC passes)"
             except (OSError, KeyError, ValueError):
                 pass
+        relabel_cache_resident({k: v for k, v in rooflines.items() if k in ("gcn_layer_fused", "spmm_csr")})
+        if roofline is not None and roofline.get("span") in rooflines:   # (the headline entry follows its relabelled twin)
+            roofline.update({k: v for k, v in rooflines[roofline["span"]].items() if k != "batch_stats"})
 
         # ---- CPU baseline: the oracle's pair stage on a bounded sample of the same workload (rank 0, N = 1 only)
         cpu = None
@@ -947,7 +985,9 @@ def main():
                        "attention_form_probe_ms_per_step": rows_probe,
                        "selection_form": ("one launch, pair-major entries + a table entry per pair (select4.hip)"
                                           if model._uses_select4() and model._uses_rows() else
-                                          "plan + run launches, type-major regions (select3.hip)"),
+                                          ("one launch, pair-major (select4.hip) + lpf_select4_regions: type-major regions"
+                                           if model._uses_select4_regions() else
+                                           "plan + run launches, type-major regions (select3.hip)")),
                        "flip_break_even": model.FLIP_BREAK_EVEN.get(d),
                        # the activation-pattern table of the attention behind select4 (random-init weights): share of a
                        # sample's ordered (pa, pb) points per type whose cell holds a tabulated pattern, and the flipped

@@ -293,8 +293,24 @@ int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int
 int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
                 const void *adj_cv, const void *a1_cv, const void *px_cv, const void *t0_cv, const void *u_cv,
                 const void *mini, int32_t mode_cn, int32_t use_px, float th_cn, float th_1hop, float th_non1hop,
-                int64_t *ctl, void *pair_tab, int32_t *blk_cnt, void *entries, int64_t ent_cap, int32_t threads,
-                void *stream);
+                int64_t *ctl, void *pair_tab, int32_t *blk_cnt, void *blk_types, void *entries, int64_t ent_cap,
+                int32_t threads, void *stream);
+
+/* lpf_select4's result in the TYPE-MAJOR form of lpf_select3_run (what the matrix-core attention, the record-merging tail
+ * and lpf_select_export read): type_ptr int32[3][bs + 1] per-type segment pointers and three regions of `ent_cap` 16-byte
+ * records {pair | from_N(b) << 31, node, pa, pb} ordered by (pair, candidate slot) -- same sets, same values, same order
+ * inside a pair's segment as lpf_select3_* leave.  For hub-heavy batches (ogbl-ppa-like: a pair's walks run to thousands
+ * of candidate slots, a handful is kept) lpf_select4 + this launch cost the chip about half the CU-time of
+ * lpf_select3_plan + _run: a block of 64 pairs keeps one workgroup busy for as long as ITS walks take instead of every
+ * CU for as long as the batch's do.
+ *   blk_types  int32[ceil(bs / LPF_SELECT4_BLOCK)][4] {common neighbours, one-hop, >1-hop, 0} kept per block: pass the
+ *              same buffer to lpf_select4 (its optional blk_types argument; NULL there: not written)
+ *   ctl        lpf_select4's control block; receives [4..6] the totals per type and the sticky LPF_SELECT_ERR_ENTRY_CAP
+ *              when a region is too small (entries past ent_cap are dropped, type_ptr still counts them)
+ * One wavefront per block: the per-pair pointers are an in-wave scan on top of the sum of the blocks in front, the
+ * block's entries -- one contiguous run of the pair-major buffer -- move with ballot ranks. */
+int lpf_select4_regions(int64_t bs, const void *pair_tab, const void *blk_types, const void *entries4, int64_t ent_cap4,
+                        int32_t *type_ptr, void *regions, int64_t ent_cap, int64_t *ctl, void *stream);
 
 /* The reference's layout from the regions above: all CN entries sorted by (pair, node), then all 1-hop (the two runs
  * merged by node id), then all >1-hop (link_transformer.py:161-162); type_ptr64 int64[3*(bs+1)] relative per type,

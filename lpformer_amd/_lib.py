@@ -52,7 +52,8 @@ HIP_PROTOTYPES = {
                        i32, vp],
     "lpf_select3_plan": [i64, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp],
     "lpf_select3_run": [i64, vp, vp, vp, i64, vp, vp, vp, vp, f32, f32, f32, i32, vp, vp, i64, i32, vp],
-    "lpf_select4": [i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp, i64, i32, vp],
+    "lpf_select4": [i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, i64, i32, vp],
+    "lpf_select4_regions": [i64, vp, vp, vp, i64, vp, vp, i64, vp, vp],
     "lpf_select_export": [i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "lpf_pair_scores_f32": [i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lpf_pair_softmax_gather_f32": [i32, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp],

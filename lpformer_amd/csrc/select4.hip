@@ -57,6 +57,7 @@ struct Args4 {
     int64_t *ctl;
     int4 *pair_tab;      // [bs]
     int32_t *blk_cnt;    // [ceil(bs / 64)][2]: entries, pairs with entries
+    int4 *blk_types;     // optional [ceil(bs / 64)]: {common neighbours, one-hop, >1-hop, 0} kept per block (lpf_select4_regions)
     int4 *entries;       // [ent_cap]
     int64_t ent_cap;
 };
@@ -318,6 +319,16 @@ __global__ __launch_bounds__(NTH, 4) void select4_kernel(const Args4 A) {
         for (int dlt = 32; dlt > 0; dlt >>= 1) kept += __shfl_xor(kept, dlt, 64);
         const int64_t blk = (int64_t)blockIdx.x * NB + wave;
         if (lane == 0 && blk * S4_PAIRS < A.bs) reinterpret_cast<int2 *>(A.blk_cnt)[blk] = make_int2(kept, ne);
+        if (A.blk_types) {   // (wave-uniform) the block's kept entries by type: the type-major form's block bases are their sums
+            int c0 = (j < np && !ovf) ? cc.x : 0, c1 = (j < np && !ovf) ? cc.y : 0, c2 = (j < np && !ovf) ? cc.z : 0;
+#pragma unroll
+            for (int dlt = 32; dlt > 0; dlt >>= 1) {
+                c0 += __shfl_xor(c0, dlt, 64);
+                c1 += __shfl_xor(c1, dlt, 64);
+                c2 += __shfl_xor(c2, dlt, 64);
+            }
+            if (lane == 0 && blk * S4_PAIRS < A.bs) A.blk_types[blk] = make_int4(c0, c1, c2, 0);
+        }
     }
     if (tid < np) {
         const int4 c = *reinterpret_cast<const int4 *>(L.pcnt[tid]);
@@ -363,13 +374,14 @@ extern "C" int lpf_select4_set_stamps(void *buf) {
 extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, int64_t n_nodes, const void *node_rec,
                            const void *adj_cv, const void *a1_cv, const void *px_cv, const void *t0_cv, const void *u_cv,
                            const void *mini, int32_t mode_cn, int32_t use_px, float th_cn, float th_1hop,
-                           float th_non1hop, int64_t *ctl, void *pair_tab, int32_t *blk_cnt, void *entries,
-                           int64_t ent_cap, int32_t threads, void *stream) {
+                           float th_non1hop, int64_t *ctl, void *pair_tab, int32_t *blk_cnt, void *blk_types,
+                           void *entries, int64_t ent_cap, int32_t threads, void *stream) {
     if (bs == 0) return LPF_OK;
     LPF_REQUIRE(bs > 0 && bs < (1ll << 29) && batch && batch_ld >= bs && n_nodes > 0 && node_rec && adj_cv && a1_cv &&
                 (px_cv || !use_px) && u_cv && mini && ctl && pair_tab && blk_cnt && entries && ent_cap > 0 &&
                 ent_cap < (1ll << 31) && lpf_aligned16(node_rec) && lpf_aligned16(u_cv) && lpf_aligned16(mini) &&
-                lpf_aligned16(pair_tab) && lpf_aligned16(entries) && (reinterpret_cast<uintptr_t>(blk_cnt) & 7) == 0);
+                lpf_aligned16(pair_tab) && lpf_aligned16(entries) && (reinterpret_cast<uintptr_t>(blk_cnt) & 7) == 0 &&
+                lpf_aligned16(blk_types));
     Args4 a;
     a.bs = bs; a.batch = batch; a.batch_ld = batch_ld; a.n_nodes = n_nodes;
     a.rec = static_cast<const NodeRec *>(node_rec);
@@ -378,6 +390,7 @@ extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, i
     a.u_cv = static_cast<const int2 *>(u_cv); a.mini = static_cast<const uint32_t *>(mini);
     a.mode_cn = mode_cn; a.use_px = use_px; a.th_cn = th_cn; a.th_1 = th_1hop; a.th_n = th_non1hop;
     a.ctl = ctl; a.pair_tab = static_cast<int4 *>(pair_tab); a.blk_cnt = blk_cnt;
+    a.blk_types = static_cast<int4 *>(blk_types);
     a.entries = static_cast<int4 *>(entries); a.ent_cap = ent_cap;
     const int64_t nb = (bs + S4_PAIRS - 1) / S4_PAIRS;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -397,6 +410,115 @@ extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, i
     else if (nth == 512 && per == 1) hipLaunchKernelGGL((select4_kernel<512, 1>), grid, dim3(512), 0, s, a);
     else if (nth == 512 && per == 2) hipLaunchKernelGGL((select4_kernel<512, 2>), grid, dim3(512), 0, s, a);
     else return LPF_ERR_INVALID;
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+/* ---- pair-major -> type-major ---------------------------------------------------------------------------------- */
+namespace {
+
+struct ArgsR {
+    int64_t bs;
+    const int4 *pair_tab, *blk_types, *entries4;
+    int64_t ent_cap4;
+    int32_t *type_ptr;      // [3][bs + 1]
+    int4 *regions;          // [3][ent_cap]
+    int64_t ent_cap;
+    int64_t *ctl;
+};
+
+// One wavefront per block of 64 pairs (lane = pair).  A block's entries are one contiguous run of the pair-major buffer,
+// pair after pair, and the type-major regions are ordered by pair too: the k-th entry of type T of the run -- in run
+// order -- is entry  base_T(block) + k  of region T, base_T = the kept type-T entries of all blocks in front.  So the
+// per-pair pointers are an in-wave scan on top of the block bases, and the entries move with ballot ranks and three
+// running counters -- no search, no per-pair loop, a hub pair of hundreds of entries is walked by 64 lanes.
+__global__ __launch_bounds__(256) void s4_regions_kernel(const ArgsR A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nblk = (A.bs + S4_PAIRS - 1) / S4_PAIRS;
+    const int64_t B = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (B >= nblk) return;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // kept entries, by type, of the blocks in front
+    int64_t base[3] = {0, 0, 0};
+    for (int64_t i = lane; i < B; i += 64) {
+        const int4 v = A.blk_types[i];
+        base[0] += v.x > 0 ? v.x : 0;
+        base[1] += v.y > 0 ? v.y : 0;
+        base[2] += v.z > 0 ? v.z : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) base[t] += __shfl_xor((long long)base[t], dlt, 64);
+    const int64_t p = B * S4_PAIRS + lane;
+    const bool in = p < A.bs;
+    int4 e = in ? A.pair_tab[p] : make_int4(0, 0, 0, 0);
+    // (a table entry that does not lie inside the buffer counts as empty: nothing is read outside it)
+    if (e.x < 0 || e.y < 0 || e.z < 0 || e.w < 0 || (int64_t)e.x + e.y + e.z + e.w > A.ent_cap4) e = make_int4(0, 0, 0, 0);
+    int c[3] = {e.y, e.z, e.w}, x[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int v = c[t];
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int y = __shfl_up(v, dlt, 64);
+            if (lane >= dlt) v += y;
+        }
+        x[t] = v;
+        if (in) A.type_ptr[(int64_t)t * (A.bs + 1) + p] = (int32_t)(base[t] + v - c[t]);
+    }
+    int tot[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) tot[t] = __shfl(x[t], 63, 64);
+    if (B == nblk - 1 && lane == 0) {
+        bool over = false;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int64_t all = base[t] + tot[t];
+            A.type_ptr[(int64_t)t * (A.bs + 1) + A.bs] = (int32_t)(all < 0x7fffffff ? all : 0x7fffffff);
+            A.ctl[4 + t] = all;
+            over = over || all > A.ent_cap;
+        }
+        if (over) atomicOr(reinterpret_cast<unsigned long long *>(A.ctl + CTL_ERR), (unsigned long long)LPF_SELECT_ERR_ENTRY_CAP);
+    }
+    // the block's run: from the first entry of its first pair with entries
+    const uint64_t has = __ballot(c[0] + c[1] + c[2] > 0);
+    if (!has) return;
+    const int64_t start = __shfl(e.x, __builtin_ctzll(has), 64);
+    const int n_run = tot[0] + tot[1] + tot[2];
+    int run[3] = {0, 0, 0};
+    for (int i0 = 0; i0 < n_run; i0 += 64) {
+        const int i = i0 + lane;
+        int4 rec = make_int4(0, 0, 0, 0);
+        if (i < n_run) rec = A.entries4[start + i];
+        const int ty = i < n_run ? (int)(((uint32_t)rec.x >> 29) & 3u) : 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint64_t m = __ballot(ty == t + 1);
+            if (ty == t + 1) {
+                const int64_t dst = base[t] + run[t] + __popcll(m & lt_mask);
+                if (dst < A.ent_cap)      // (else: the sticky bit above -- the consumers write NaN rows)
+                    A.regions[(int64_t)t * A.ent_cap + dst] =
+                        make_int4((int32_t)((uint32_t)rec.x & ~(3u << 29)), rec.y, rec.z, rec.w);
+            }
+            run[t] += __popcll(m);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lpf_select4_regions(int64_t bs, const void *pair_tab, const void *blk_types, const void *entries4,
+                                   int64_t ent_cap4, int32_t *type_ptr, void *regions, int64_t ent_cap, int64_t *ctl,
+                                   void *stream) {
+    if (bs == 0) return LPF_OK;
+    LPF_REQUIRE(bs > 0 && bs < (1ll << 29) && pair_tab && blk_types && entries4 && ent_cap4 > 0 && type_ptr && regions &&
+                ent_cap > 0 && ent_cap < (1ll << 29) && ctl && lpf_aligned16(pair_tab) && lpf_aligned16(blk_types) &&
+                lpf_aligned16(entries4) && lpf_aligned16(regions));
+    const ArgsR a{bs, static_cast<const int4 *>(pair_tab), static_cast<const int4 *>(blk_types),
+                  static_cast<const int4 *>(entries4), ent_cap4, type_ptr, static_cast<int4 *>(regions), ent_cap, ctl};
+    const int64_t nblk = (bs + S4_PAIRS - 1) / S4_PAIRS;
+    hipLaunchKernelGGL(s4_regions_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

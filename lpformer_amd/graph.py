@@ -275,7 +275,9 @@ def gcn_norm_device(struct: DeviceCSR, stream=None) -> DeviceCSR:
     _lib.check(_lib.hip().lpf_gcn_norm_csr(struct.n, _lib.ptr(struct.rowptr), _lib.ptr(struct.col),
                                             _lib.ptr(struct.val), _lib.ptr(w_out), _lib.ptr(dis), st),
                "lpf_gcn_norm_csr")
-    return DeviceCSR(struct.rowptr, struct.col, w_out, struct.n, None)
+    out = DeviceCSR(struct.rowptr, struct.col, w_out, struct.n, None)
+    out.__dict__["_struct_val"] = struct.val     # (the raw weights: an override that only drops edges re-normalises them)
+    return out
 
 
 def ppr_filter_device(ppr: DeviceCSR, mode: int, theta: float) -> DeviceCSR:

@@ -524,6 +524,37 @@ class _Select4Workspace:
         return int(self.blk_cnt[:-2:2].sum().item())
 
 
+class _Select4RegionsWorkspace(_SelectWorkspace):
+    """``lpf_select4`` + ``lpf_select4_regions``: the one-launch selection for consumers of the TYPE-MAJOR form (the
+    matrix-core attention, the record-merging tail, ``lpf_select_export``).  Looks like a ``_SelectWorkspace`` to them
+    (``type_ptr``, ``entries``, ``ent_cap``, ``ctl`` with the sticky bits in word 3 and the totals per type in words
+    4-6); the pair-major half (``pair_tab``, ``blk_cnt``, ``blk_types``, ``entries4``) stays inside."""
+
+    def __init__(self, device, bs: int):
+        self.device, self.bs = device, bs
+        nblk = (bs + _lib.SELECT4_BLOCK - 1) // _lib.SELECT4_BLOCK
+        self.ctl = torch.zeros(32, dtype=torch.int64, device=device)            # LPF_SELECT4_CTL_WORDS
+        self.pair_tab = torch.zeros(4 * max(bs, 1), dtype=torch.int32, device=device)
+        self.blk_cnt = torch.zeros(2 * nblk + 2, dtype=torch.int32, device=device)
+        self.blk_types = torch.zeros(4 * nblk + 4, dtype=torch.int32, device=device)
+        self.type_ptr = torch.zeros(3 * (bs + 1), dtype=torch.int32, device=device)
+        self.ent_cap = self.ent_cap4 = self.item_cap = 0
+        self.entries = self.entries4 = self.item_pair = self.run_lb = None
+        self.calibrated = False
+
+    def ensure4(self, ent_cap4: int, shrink: bool = False):
+        if ent_cap4 > self.ent_cap4 or (shrink and ent_cap4 < self.ent_cap4 // 2):
+            self.ent_cap4 = int(ent_cap4)
+            self.entries4 = None
+            self.entries4 = torch.empty(self.ent_cap4 * 4, dtype=torch.int32, device=self.device)
+
+    def ensure(self, item_cap: int = 0, ent_cap: int = 0, shrink: bool = False):
+        if ent_cap > self.ent_cap or (shrink and ent_cap < self.ent_cap // 2):
+            self.ent_cap = int(ent_cap)
+            self.entries = None
+            self.entries = torch.empty(3 * self.ent_cap * 4, dtype=torch.int32, device=self.device)
+
+
 # ------------------------------------------------------------------------------------------ the model
 class LinkTransformer(nn.Module):
     """LPFormer link-representation model on MI355X.
@@ -622,6 +653,11 @@ class LinkTransformer(nn.Module):
         # (type-major regions, which lpf_select_export and the record-writing attention kernels keep using)
         self.select_blocks = True
         self.select4_threads = 0       # threads per workgroup of lpf_select4 (0 = default)
+        # consumers of the TYPE-MAJOR form (D < 128: the matrix-core attention; every model: compute_node_mask, the
+        # training step, the attention weights) behind lpf_select4 + lpf_select4_regions instead of lpf_select3_plan /
+        # _run: a block of 64 pairs occupies ONE workgroup for as long as its own walks take instead of the whole chip
+        # for as long as the batch's do -- about half the CU-time on hub-heavy batches (ppa-like, citation2-like)
+        self.select4_regions = True
         # the elementwise branch and the q projection only need X and the batch: they run on a second HIP stream
         # underneath the (latency/issue-bound) selection kernels.  False: everything on the caller's stream.
         self.use_side_stream = True
@@ -711,6 +747,11 @@ class LinkTransformer(nn.Module):
         dev = self.device
         if isinstance(obj, graph.RemovedEdges):
             raise TypeError("RemovedEdges describes a typing adjacency (the adj_mask argument), nothing else")
+        if kind == "prop" and not persistent:
+            g = self._prop_delta(obj)
+            if g is not None:
+                self._override[kind] = (obj, g)
+                return g
         if kind == "t0":    # per-model indexes: filtered on the device from the resident PPR matrix
             g = graph.ppr_filter_device_blocked(self._device_graph("ppr", obj), 0, self.thresh_non1hop)
         elif isinstance(obj, graph.CSR) and kind in ("mask", "ppr"):
@@ -1099,11 +1140,52 @@ class LinkTransformer(nn.Module):
         return hit[1]
 
     # ---------------------------------------------------------------------------------- selection
-    def _sel_ws(self, st, bs: int) -> "_SelectWorkspace":
+    def _sel_ws(self, st, bs: int, regions: Optional[bool] = None) -> "_SelectWorkspace":
+        """The type-major selection workspace of (stream, batch size); ``regions``: it must be (True) / must not be
+        (False) the one behind ``lpf_select4`` -- a workspace of the other kind is replaced; None: whatever is there."""
         key = ("sel2", st, bs)
         ws = self._ws.get(key)
-        if ws is None:
-            ws = self._ws[key] = _SelectWorkspace(self.device, bs)
+        if ws is None or (regions is not None and isinstance(ws, _Select4RegionsWorkspace) != regions):
+            ws = self._ws[key] = (_Select4RegionsWorkspace if regions else _SelectWorkspace)(self.device, bs)
+        return ws
+
+    def _regions_launch(self, ws, batch, wi):
+        """``lpf_select4`` + ``lpf_select4_regions`` on the current stream; no host sync."""
+        self._select4_launch(ws, batch, wi, regions=True)
+        with KernelTimer.span("select_regions"):
+            check(_lib.hip().lpf_select4_regions(batch.shape[1], ptr(ws.pair_tab), ptr(ws.blk_types), ptr(ws.entries4),
+                                                 ws.ent_cap4, ptr(ws.type_ptr), ptr(ws.entries), ws.ent_cap, ptr(ws.ctl),
+                                                 _stream(self.device)), "lpf_select4_regions")
+
+    def _uses_select4_regions(self, adj_mask=None) -> bool:
+        """True when the type-major consumers sit behind lpf_select4 + lpf_select4_regions."""
+        return self.select4_regions and self.select_blocks and adj_mask is None and self.use_select_index
+
+    def _select_regions_device(self, batch: torch.Tensor, test_set: bool) -> "_Select4RegionsWorkspace":
+        """As ``_select_device`` for the walk-index path, through the one-launch selection: sized from earlier batches
+        (a block reserves its candidate slots in the pair-major buffer, the regions hold the kept entries), a batch that
+        does not fit raises the sticky bits (NaN scores, ``check_selection()`` sizes again), the first batch of a
+        (stream, batch size) is sized exactly with synchronisations."""
+        st = _stream(self.device)
+        bs = batch.shape[1]
+        ws = self._sel_ws(st, bs, regions=True)
+        wi = self._select_graphs(test_set, None)
+        if not ws.calibrated:
+            ws.ensure4(16)
+            ws.ensure(ent_cap=16)
+            self._select4_launch(ws, batch, wi, regions=True)    # (token buffer: the kernel still reports the room it needs)
+            err, _ = ws.read_status()
+            need = int(ws.ctl[0].item())
+            ws.clear_errors()
+            if err & _lib.SELECT_ERR_NODE_RANGE:
+                raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
+            ws.ensure4(3 * need + 65536, shrink=True)
+            self._regions_launch(ws, batch, wi)                  # (token regions: the totals per type come back)
+            _, tot = ws.read_status()
+            ws.clear_errors()
+            ws.ensure(ent_cap=2 * max(tot) + 4096, shrink=True)
+            ws.calibrated = True
+        self._regions_launch(ws, batch, wi)
         return ws
 
     def _select_launch(self, ws, batch, graphs):
@@ -1187,9 +1269,11 @@ class LinkTransformer(nn.Module):
         sticky error bits in ``ws.ctl`` -- consumers clamp, the scores of such a batch come out as NaN, and
         ``check_selection()`` (called by the evaluation sweep and by every API that synchronises anyway) grows the
         workspace.  The first batch of a (stream, batch size) is sized exactly, with one synchronisation."""
+        if self._uses_select4_regions(adj_mask):
+            return self._select_regions_device(batch, test_set)
         st = _stream(self.device)
         bs = batch.shape[1]
-        ws = self._sel_ws(st, bs)
+        ws = self._sel_ws(st, bs, regions=False)
         graphs = self._select_graphs(test_set, adj_mask)
         if not ws.calibrated:
             # exact sizing, once (synchronises): the kernels count every selected entry even when the entry regions
@@ -1241,7 +1325,9 @@ class LinkTransformer(nn.Module):
         self._pt_choice = (self._folded[0], ok, self._refolds)
         return ok
 
-    def _select4_launch(self, ws, batch, wi):
+    def _select4_launch(self, ws, batch, wi, regions: bool = False):
+        """``lpf_select4`` into ``ws`` (a ``_Select4Workspace``, or -- ``regions`` -- the pair-major half of a
+        ``_Select4RegionsWorkspace``)."""
         lib, st = _lib.hip(), _stream(self.device)
         cn = 1 if self.mask == "cn" else 0
         with KernelTimer.span("select_run"):
@@ -1249,7 +1335,8 @@ class LinkTransformer(nn.Module):
                                   ptr(wi.a1_cv), ptr(wi.px_cv), ptr(wi.t0_cv), ptr(wi.u.cv), ptr(wi.mini), cn,
                                   1 if wi.use_px else 0, float(self.thresh_cn), float(self.thresh_1hop),
                                   float(self.thresh_non1hop), ptr(ws.ctl), ptr(ws.pair_tab), ptr(ws.blk_cnt),
-                                  ptr(ws.entries), ws.ent_cap, self.select4_threads, st), "lpf_select4")
+                                  ptr(getattr(ws, "blk_types", None)), ptr(ws.entries4 if regions else ws.entries),
+                                  ws.ent_cap4 if regions else ws.ent_cap, self.select4_threads, st), "lpf_select4")
 
     def _select4_device(self, batch: torch.Tensor, test_set: bool) -> "_Select4Workspace":
         """The one-launch selection for the hot path (``lpf_select4``): pair-major entries, a table entry per pair,
@@ -1302,6 +1389,45 @@ class LinkTransformer(nn.Module):
                 raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
             ws.calibrated = False   # re-size on the next batch
         return ok
+
+    def _prop_delta(self, obj):
+        """A propagation-matrix override (the ``--mask-input`` loop, src/train/train_model.py:47-56) that is the resident
+        graph minus some edges, as a graph SHARING the resident structure: the raw weights with the removed edges at 0,
+        re-normalised by ``lpf_gcn_norm_csr`` (degrees from what is left).  Nothing structural is rebuilt -- no sort of the
+        edge list, no degree-ordered tiles for the one-launch layer, no transposed structure for the backward pass
+        (4 ms per batch on the collab-like graph).  None: the override is a graph of its own (lpformer_amd/mask_delta.py)."""
+        own_obj = self.data.get("adj_t")
+        if not self.use_mask_delta or own_obj is None or obj is own_obj:
+            return None
+        own = self._device_graph("prop", own_obj)
+        raw = own.__dict__.get("_struct_val")
+        if raw is None:
+            return None
+        keys = own.__dict__.get("_edge_keys")
+        if keys is None:
+            keys = own.__dict__["_edge_keys"] = mask_delta.edge_keys(own.rowptr, own.col, own.n)
+        coo = graph.as_coo_device(obj, self.device)
+        if coo is None:
+            try:
+                row, col, val, nn = graph.as_coo_numpy(obj)
+            except TypeError:
+                return None
+            coo = (torch.from_numpy(np.ascontiguousarray(row)).to(self.device),
+                   torch.from_numpy(np.ascontiguousarray(col)).to(self.device),
+                   None if val is None else torch.from_numpy(np.ascontiguousarray(val)).to(self.device), nn)
+        if coo[3] != own.n:
+            return None
+        new_w = mask_delta.prop_weights_from_coo(keys, raw, coo[0], coo[1], coo[2], own.n)
+        if new_w is None:
+            return None
+        g = graph.gcn_norm_device(graph.DeviceCSR(own.rowptr, own.col, new_w, own.n, None))
+        for k in ("_fused_order", "_long_rows"):      # (functions of the structure alone: one dict for both graphs)
+            g.__dict__[k] = own.__dict__.setdefault(k, {})
+        for k in ("_long_rows_full", "_edge_keys"):
+            if k in own.__dict__:
+                g.__dict__[k] = own.__dict__[k]
+        g.__dict__["_structure_of"] = own
+        return g
 
     def _own_mask_keys(self, test_set: bool) -> torch.Tensor:
         """Sorted int64 keys row * N + col of the model's own typing adjacency (kept with its device graph)."""
@@ -1410,7 +1536,7 @@ class LinkTransformer(nn.Module):
                                         feats.data_ptr() + 4 * self.dim, ldf, self.count_dim, ptr(sel_pair),
                                         ptr(sel_node), ptr(sel_pa), ptr(sel_pb), st), "lpf_select_export")
         return {"bs": bs, "cap": max(cap, 1), "type_ptr": type_ptr, "sel_pair": sel_pair, "sel_node": sel_node,
-                "sel_pa": sel_pa, "sel_pb": sel_pb, "feats": feats, "ldf": ldf}
+                "sel_pa": sel_pa, "sel_pb": sel_pb, "feats": feats, "ldf": ldf, "tot": tuple(int(v) for v in tot)}
 
     def _prep_batch(self, batch) -> torch.Tensor:
         batch = torch.as_tensor(batch).to(self.device)

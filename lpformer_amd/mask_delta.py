@@ -87,47 +87,71 @@ def patch_selection(sel: dict, batch: torch.Tensor, rk: torch.Tensor, n: int, mo
     bs = batch.shape[1]
     dev = batch.device
     tp = sel["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)
-    n0, n1, n2 = (int(v) for v in tp[:, bs].tolist())
+    n0, n1, n2 = sel["tot"] if "tot" in sel else (int(v) for v in tp[:, bs].tolist())
     m, tot = n0 + n1, n0 + n1 + n2
     pair_i, node_i = sel["sel_pair"][:tot], sel["sel_node"][:tot]
     pa, pb = sel["sel_pa"][:tot], sel["sel_pb"][:tot]
     pair, node = pair_i[:m].long(), node_i[:m].long()
     a, b = batch[0][pair], batch[1][pair]
     in_a, in_b = _member(rk, a * n + node), _member(rk, b * n + node)
-    touched = in_a | in_b
-    idx = torch.arange(m, device=dev)
-    if mode == "cn":            # pair_adj = src * tgt (:232-234): common neighbours of the masked adjacency only
-        keep0 = ~touched
-        parts = [(pair_i[:m][keep0], node_i[:m][keep0], pa[:m][keep0], pb[:m][keep0])]
-        p1 = None
-    else:
-        is_cn = idx < n0
-        keep0 = is_cn & ~touched
-        keep1 = ~is_cn & ~touched
-        dem = is_cn & (in_a ^ in_b)
-        parts = [(pair_i[:m][keep0], node_i[:m][keep0], pa[:m][keep0], pb[:m][keep0])]
-        p1 = (pair_i[:m][keep1], node_i[:m][keep1], pa[:m][keep1], pb[:m][keep1])
-        di = torch.nonzero(dem).flatten()
-        if di.numel() > 0:      # common neighbours that lost ONE of their two edges: one-hop candidates now
+    # entries that touch no removed edge stay what they are, in their order (ONE compaction for both regions: the kept
+    # common neighbours still precede the kept one-hop nodes)
+    kept = torch.nonzero(~(in_a | in_b)).flatten()
+    kp, kn, ka, kb = pair_i[kept], node_i[kept], pa[kept], pb[kept]
+    types = (kept >= n0).long()                # 0: common neighbour, 1: one-hop (mode "cn": all 0)
+    if mode != "cn":
+        # common neighbours that lost ONE of their two edges: one-hop candidates now (pair_adj = 1, :237)
+        di = torch.nonzero((in_a ^ in_b)[:n0]).flatten()
+        if di.numel() > 0:
             dn = node[di]
             raw = lookup(torch.cat([a[di], b[di]]), torch.cat([dn, dn]))
             va, vb = round_trip1(raw[:di.numel()]), round_trip1(raw[di.numel():])
-            ok = (va >= th_1hop) & (vb >= th_1hop)
-            if bool(ok.any()):
+            ok = torch.nonzero((va >= th_1hop) & (vb >= th_1hop)).flatten()
+            if ok.numel() > 0:
                 dk = di[ok]
-                cat = [torch.cat([p1[0], pair_i[:m][dk]]), torch.cat([p1[1], node_i[:m][dk]]),
-                       torch.cat([p1[2], va[ok]]), torch.cat([p1[3], vb[ok]])]
-                order = torch.argsort(cat[0].long() * n + cat[1].long())
-                p1 = tuple(t[order] for t in cat)
-        parts.append(p1)
-        parts.append((pair_i[m:tot], node_i[m:tot], pa[m:tot], pb[m:tot]))
+                kp, kn = torch.cat([kp, pair_i[dk]]), torch.cat([kn, node_i[dk]])
+                ka, kb = torch.cat([ka, va[ok]]), torch.cat([kb, vb[ok]])
+                types = torch.cat([types, torch.ones_like(dk)])
+                # back into (type, pair, node) order
+                order = torch.argsort((types * bs + kp.long()) * n + kn.long())
+                kp, kn, ka, kb, types = kp[order], kn[order], ka[order], kb[order], types[order]
     counts = torch.zeros(3, bs, dtype=torch.int64, device=dev)
-    for t, part in enumerate(parts):
-        if t < 2:
-            counts[t] = torch.bincount(part[0].long(), minlength=bs)
-        else:
-            counts[t] = tp[2, 1:] - tp[2, :-1]
+    counts[:2] = torch.bincount(types * bs + kp.long(), minlength=2 * bs).view(2, bs)
+    counts[2] = tp[2, 1:] - tp[2, :-1]
     new_tp = torch.zeros(3, bs + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, dim=1, out=new_tp[:, 1:])
-    out = [torch.cat([p[k] for p in parts]) for k in range(4)]
-    return out[0], out[1], out[2], out[3], new_tp.reshape(-1), counts
+    if n2:
+        kp, kn = torch.cat([kp, pair_i[m:tot]]), torch.cat([kn, node_i[m:tot]])
+        ka, kb = torch.cat([ka, pa[m:tot]]), torch.cat([kb, pb[m:tot]])
+    return kp, kn, ka, kb, new_tp.reshape(-1), counts
+
+
+def prop_weights_from_coo(own_keys: torch.Tensor, own_w: torch.Tensor, row: torch.Tensor, col: torch.Tensor, val, n: int,
+                          min_kept: float = 0.5):
+    """A propagation-matrix override as a difference to the resident structure (the ``--mask-input`` loop,
+    src/train/train_model.py:47-56: the same edges minus the batch's positives, through GCNConv's ``gcn_norm``).
+
+    own_keys / own_w: sorted keys row * n + col and RAW weights of the resident GCN structure (every diagonal entry
+    included).  Returns the raw weights of the override laid out on THAT structure -- removed edges weigh 0, the
+    diagonal keeps its placeholder -- or None when the override is not a subset of the structure, weighs a kept edge
+    differently or keeps less than ``min_kept`` of the edges (it is then normalised as a graph of its own).  The
+    normalisation kernel (``lpf_gcn_norm_csr``) takes it from there: degrees from the weights that are left.  One host
+    synchronisation."""
+    row, col = row.long(), col.long()
+    off = row != col
+    mk = row * n + col
+    w = torch.ones(mk.numel(), dtype=torch.float32, device=mk.device) if val is None else val.float().reshape(-1)
+    pos = torch.searchsorted(own_keys, mk).clamp_(max=max(own_keys.numel() - 1, 0))
+    found = (own_keys[pos] == mk) | ~off
+    same = (own_w[pos] == w) | ~off
+    new_w = torch.zeros_like(own_w)
+    new_w[pos[off]] = w[off]                 # (duplicate entries of a non-coalesced override: the last one wins -- they are
+    #                                           equal to the resident weight or the override is rejected below)
+    r = torch.div(own_keys, n, rounding_mode="floor")
+    diag = own_keys - r * n == r
+    new_w[diag] = own_w[diag]
+    n_off_own = own_keys.numel() - n
+    ok, n_kept = (int(v) for v in torch.stack([(found & same).all().long(), (new_w != 0).sum() - diag.sum()]).tolist())
+    if not ok or n_kept < min_kept * max(n_off_own, 1):
+        return None
+    return new_w

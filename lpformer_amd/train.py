@@ -141,6 +141,13 @@ def _spmm_plain(a: graph.DeviceCSR, h: torch.Tensor, bias=None) -> torch.Tensor:
 def _transpose_csr(a: graph.DeviceCSR) -> graph.DeviceCSR:
     """A^T as a device CSR (cached on ``a``): needed for the gradient of the aggregation."""
     hit = a.__dict__.get("_transposed")
+    src = a.__dict__.get("_structure_of")
+    if hit is None and src is not None:
+        # an override that shares the resident graph's structure (LinkTransformer._prop_delta): the transposed structure
+        # and the permutation are the resident graph's, only the values are gathered again
+        t = _transpose_csr(src)
+        hit = a.__dict__["_transposed"] = graph.DeviceCSR(t.rowptr, t.col, a.val[src.__dict__["_transposed_order"]].contiguous(),
+                                                          a.n, None)
     if hit is None:
         n = a.n
         rows = torch.repeat_interleave(torch.arange(n, device=a.col.device), a.rowptr[1:] - a.rowptr[:-1])
@@ -151,6 +158,7 @@ def _transpose_csr(a: graph.DeviceCSR) -> graph.DeviceCSR:
         torch.cumsum(counts, 0, out=rowptr[1:])
         hit = a.__dict__["_transposed"] = graph.DeviceCSR(rowptr, rows[order].to(torch.int32).contiguous(),
                                                           a.val[order].contiguous(), n, None)
+        a.__dict__["_transposed_order"] = order
     return hit
 
 

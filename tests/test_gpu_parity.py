@@ -236,6 +236,33 @@ def test_masked_adjacency_override_vs_reference():
     assert _err(score.logits(feats).cpu(), fx["masked_logit"]) <= TOL
     h = model.propagate(masked_adjt)
     assert _err(h.cpu(), fx["masked_prop_x_node"]) <= TOL
+    # (an UNWEIGHTED override of a weighted graph, as the reference builds it: a graph of its own.  The same edges WITH the
+    #  resident weights share the resident structure -- raw weights with the removed edges at 0, re-normalised by
+    #  lpf_gcn_norm_csr -- and give what a graph built from them gives)
+    own_prop = model._device_graph("prop", model.data["adj_t"])
+    assert model._override["prop"][1].rowptr is not own_prop.rowptr
+
+    class _Weighted:
+        def __init__(self, r, c, v):
+            self._r, self._c, self._v = r, c, v
+
+        def coo(self):
+            return self._r, self._c, self._v
+
+        def sparse_sizes(self):
+            return (n, n)
+    km = np.array([k in kept for k in (ei[0] * n + ei[1]).tolist()])
+    wov = [torch.from_numpy(ei[0][km]).cuda(), torch.from_numpy(ei[1][km]).cuda(),
+           torch.from_numpy(fx["edge_weight"][km].astype(np.float32)).cuda()]
+    h_shared = model.propagate(_Weighted(*wov))
+    assert model._override["prop"][1].rowptr is own_prop.rowptr
+    model.use_mask_delta = False
+    model._override.clear()
+    h_own = model.propagate(_Weighted(*wov))
+    assert model._override["prop"][1].rowptr is not own_prop.rowptr
+    assert _err(h_shared.cpu(), h_own.cpu().numpy()) <= 1e-5 and _err(h_own.cpu(), h.cpu().numpy()) > 1e-4
+    model.use_mask_delta = True
+    model._override.clear()
     feats = model(mb, adj_prop=masked_adjt, adj_mask=masked_adj)
     assert _err(feats.cpu(), fx["masked_prop_combined_feats"]) <= TOL
     assert _err(score.logits(feats).cpu(), fx["masked_prop_logit"]) <= TOL

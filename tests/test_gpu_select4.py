@@ -206,3 +206,93 @@ def test_select4_replays_bitwise_and_ignores_where_blocks_land():
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(first, o)
+
+
+def _regions(model, batch, test_set, form):
+    """type_ptr [3, bs + 1] and the three regions' records as lpf_select3_run (form False) / lpf_select4 +
+    lpf_select4_regions (form True) leave them."""
+    from lpformer_amd.link_transformer import _Select4RegionsWorkspace
+    model.select4_regions = form
+    with torch.cuda.device(model.device):
+        for _attempt in range(3):
+            ws = model._select_device(batch, test_set)
+            if model.check_selection():
+                break
+        else:
+            raise AssertionError("the selection workspace could not be sized")
+    assert isinstance(ws, _Select4RegionsWorkspace) == form
+    bs = batch.shape[1]
+    tp = ws.type_ptr[:3 * (bs + 1)].view(3, bs + 1).cpu().numpy()
+    ent = ws.entries.view(3, ws.ent_cap, 4).cpu().numpy()
+    return tp, [ent[t, :tp[t, bs]].copy() for t in range(3)]
+
+
+@pytest.mark.parametrize("case", LP_CASES)
+def test_select4_regions_are_select3s_regions(case):
+    """``lpf_select4`` + ``lpf_select4_regions`` leave what ``lpf_select3_plan`` / ``_run`` leave -- the same segment
+    pointers, the same records in the same order (pair, candidate slot) -- so every consumer of the type-major form (the
+    matrix-core attention, the merging tail, ``lpf_select_export`` with its merge of the one-hop runs) reads either."""
+    fx = Fixture(case)
+    model, _ = _build(fx)
+    batch = model._prep_batch(torch.from_numpy(fx["batch"]))
+    tp4, ent4 = _regions(model, batch, fx.test_set, True)
+    tp3, ent3 = _regions(model, batch, fx.test_set, False)
+    np.testing.assert_array_equal(tp4, tp3)
+    for t in range(3):
+        np.testing.assert_array_equal(ent4[t], ent3[t])
+    # ... and the reference layout out of the export, bit-exact against the fixture
+    model.select4_regions = True
+    infos = model.compute_node_mask(torch.from_numpy(fx["batch"]), test_set=fx.test_set)
+    for tag, info in zip(("cn", "onehop", "non1hop"), infos):
+        if info is None:
+            assert tag not in fx.sel_tags()
+            continue
+        np.testing.assert_array_equal(info[0].cpu().numpy(), fx[f"sel_{tag}_ix"])
+        np.testing.assert_array_equal(info[1].cpu().numpy().view(np.uint32), fx[f"sel_{tag}_pa"].view(np.uint32))
+        np.testing.assert_array_equal(info[2].cpu().numpy().view(np.uint32), fx[f"sel_{tag}_pb"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name,scale,bs,seed", [("ppa", 0.02, 5000, 0), ("citation2", 0.01, 3001, 1), ("collab", 0.05, 777, 2),
+                                                ("ddi", 0.25, 300, 3), ("tiny", 1.0, 64, 4), ("tiny", 1.0, 1, 5)])
+def test_select4_regions_on_hub_heavy_and_ragged_batches(name, scale, bs, seed):
+    """Hub pairs whose walks span several slot batches, ragged last blocks, a one-pair batch, dense rows: regions and
+    pointers equal select3's; scores through the matrix-core attention behind either selection bitwise equal; a
+    workspace that is too small raises the sticky bit and the re-scored batch is right."""
+    cfg = dict(D.CONFIGS[name])
+    n = max(64, int(cfg["n"] * scale))
+    ei, w = D.chung_lu_graph(n, int(cfg["edges"] * scale), gamma=cfg["gamma"], seed=seed, max_weight=cfg["max_weight"])
+    x = np.random.default_rng(seed).standard_normal((n, 16)).astype(np.float32)
+    data = D.build_data(ei, x, n, edge_weight=w, eps=max(cfg["eps"], 1e-4))
+    args = D.train_args_for(dict(cfg, dim=64, gnn_layers=1))
+    torch.manual_seed(seed)
+    model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
+    score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(DEV).eval()
+    batch = model._prep_batch(torch.from_numpy(D.sample_pairs(ei, n, bs, seed=seed + 7)))
+    tp4, ent4 = _regions(model, batch, False, True)
+    tp3, ent3 = _regions(model, batch, False, False)
+    np.testing.assert_array_equal(tp4, tp3)
+    for t in range(3):
+        np.testing.assert_array_equal(ent4[t], ent3[t])
+    h = model.propagate()
+    out = {}
+    for form in (True, False):
+        model.select4_regions = form
+        for _attempt in range(3):
+            lg = model.score_pairs(batch, h, score, logits=True).clone()
+            if model.check_selection():
+                break
+        out[form] = lg
+    assert torch.isfinite(out[True]).all() and torch.equal(out[True], out[False])
+    # a region that is too small: sticky bit + NaN, then the right scores
+    model.select4_regions = True
+    ws = model._select_device(batch, False)
+    assert model.check_selection()
+    if int(tp4[:, -1].max()) > 16:
+        ws.ensure(ent_cap=8, shrink=True)
+        bad = model.score_pairs(batch, h, score, logits=True)
+        assert not model.check_selection() and torch.isnan(bad).any()
+        for _attempt in range(3):
+            again = model.score_pairs(batch, h, score, logits=True)
+            if model.check_selection():
+                break
+        assert torch.equal(again, out[True])

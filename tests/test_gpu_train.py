@@ -217,3 +217,57 @@ def test_cn_mode_training_step_with_masked_adjacency():
         opt.zero_grad()
         losses.append(l2.item())
     assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0]
+
+
+def test_overrides_taken_as_differences_train_like_graphs_of_their_own():
+    """The training loop's per-batch overrides (src/train/train_model.py:38-56) as DIFFERENCES to the resident graphs --
+    typing adjacency: selection over the walk indexes + the patch of lpformer_amd/mask_delta.py, also with the removed
+    edges named explicitly (``lpformer_amd.RemovedEdges``); propagation matrix (same edges, resident weights): the
+    resident structure with the removed edges' weights at 0, re-normalised, its transposed structure shared in the
+    backward pass -- against the same step with both overrides turned into graphs of their own (rounds 2-5): loss and
+    every gradient within 1e-5 relative."""
+    z, cfg = _load("train_step_d64")
+    n = cfg["n"]
+    ei = z["edge_index"].astype(np.int64)
+    w = z["edge_weight"].astype(np.float32)
+    edges = torch.from_numpy(z["pos_edges"]).to(DEV)
+    neg = torch.from_numpy(z["neg_edges"]).to(DEV)
+    gone = set((z["pos_edges"][0] * n + z["pos_edges"][1]).tolist()) | set((z["pos_edges"][1] * n + z["pos_edges"][0]).tolist())
+    km = np.array([k not in gone for k in (ei[0] * n + ei[1]).tolist()])
+    assert 0 < km.sum() < km.size
+
+    class _ST:
+        def __init__(self, r, c, v):
+            self._r, self._c, self._v = r, c, v
+
+        def coo(self):
+            return self._r, self._c, self._v
+
+        def sparse_sizes(self):
+            return (n, n)
+    r, c = torch.from_numpy(ei[0][km]).to(DEV), torch.from_numpy(ei[1][km]).to(DEV)
+    v = torch.from_numpy(w[km]).to(DEV)
+
+    def run(delta, removed):
+        model, score = _build(z, cfg)
+        model.train(); score.train()
+        model.use_mask_delta = delta
+        ov_mask = lpformer_amd.RemovedEdges(edges) if removed else _ST(r, c, None)
+        h = model(edges, adj_prop=_ST(r, c, v), adj_mask=ov_mask)
+        loss = (-torch.log(score(h) + 1e-6).mean() - torch.log(1 - score(model(neg)) + 1e-6).mean())
+        loss.backward()
+        shared = model._override["prop"][1].rowptr is model._device_graph("prop", model.data["adj_t"]).rowptr
+        grads = {k: p.grad.detach().clone() for k, p in list(model.named_parameters()) + list(score.named_parameters())
+                 if p.grad is not None}
+        return loss.item(), grads, shared, model._delta_cache
+
+    l0, g0, shared0, dc0 = run(False, False)
+    assert not shared0 and dc0 is None
+    for removed in (False, True):
+        l1, g1, shared1, dc1 = run(True, removed)
+        assert shared1 and dc1 is not None and dc1[2] is not None and dc1[2].numel() > 0
+        assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
+        assert set(g1) == set(g0)
+        for k in g0:
+            scale = max(float(g0[k].abs().max()), 1e-6)
+            assert float((g1[k] - g0[k]).abs().max()) / scale <= 1e-5, k

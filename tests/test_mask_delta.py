@@ -117,3 +117,37 @@ def test_an_override_that_is_not_a_subset_is_a_graph_of_its_own():
     e = torch.tensor([[absent[0], int(row[0]), -1, n], [absent[1], int(col[0]), 3, 2]])
     rk = mask_delta.removed_from_edges(own, e, n)
     assert rk.tolist() == sorted({int(row[0]) * n + int(col[0]), int(col[0]) * n + int(row[0])})
+
+
+def test_propagation_override_lands_on_the_resident_structure():
+    """``--mask-input`` (src/train/train_model.py:47-56): the propagation matrix of a batch is the resident graph minus
+    the batch's positives.  Its raw weights laid out on the resident GCN structure: kept edges their weight, removed
+    edges 0, the diagonal its placeholder; anything else (a foreign edge, another weight, most edges gone) is rejected."""
+    from lpformer_amd import graph as G
+    n = 120
+    ei, w = D.chung_lu_graph(n, 500, seed=3, max_weight=4)
+    st = G.gcn_structure_csr(ei, w, n)
+    rows = np.repeat(np.arange(n), np.diff(st.rowptr))
+    keys = torch.from_numpy(rows * n + st.col.astype(np.int64))
+    raw = torch.from_numpy(st.val)
+    rng = np.random.default_rng(0)
+    und = np.flatnonzero(ei[0] < ei[1])
+    gone = set(rng.choice(und, 40, replace=False).tolist())
+    gone_keys = {int(ei[0, i] * n + ei[1, i]) for i in gone} | {int(ei[1, i] * n + ei[0, i]) for i in gone}
+    keep = np.array([int(a * n + b) not in gone_keys for a, b in zip(ei[0], ei[1])])
+    perm = rng.permutation(int(keep.sum()))           # (any order: a SparseTensor-like object need not be sorted)
+    r, c, v = (torch.from_numpy(x[keep][perm]) for x in (ei[0], ei[1], w))
+    new_w = mask_delta.prop_weights_from_coo(keys, raw, r, c, v, n)
+    want = st.val.copy()
+    want[np.isin(rows * n + st.col, list(gone_keys))] = 0.0
+    np.testing.assert_array_equal(new_w.numpy(), want)
+    assert int((new_w == 0).sum()) == len(gone_keys)
+    # unweighted override of a weighted graph, a foreign edge, most edges gone: graphs of their own
+    assert mask_delta.prop_weights_from_coo(keys, raw, r, c, None, n) is None
+    absent = next((i, j) for i in range(n) for j in range(n) if i != j and i * n + j not in set(keys.tolist()))
+    r2, c2 = torch.cat([r, torch.tensor([absent[0]])]), torch.cat([c, torch.tensor([absent[1]])])
+    assert mask_delta.prop_weights_from_coo(keys, raw, r2, c2, torch.cat([v, torch.ones(1)]), n) is None
+    assert mask_delta.prop_weights_from_coo(keys, raw, r[:50], c[:50], v[:50], n) is None
+    # self-loops of the override are ignored (the normalisation sets every diagonal entry itself)
+    r3, c3 = torch.cat([r, torch.tensor([5])]), torch.cat([c, torch.tensor([5])])
+    np.testing.assert_array_equal(mask_delta.prop_weights_from_coo(keys, raw, r3, c3, torch.cat([v, torch.full((1,), 7.0)]), n).numpy(), want)
