@@ -432,19 +432,32 @@ struct ArgsR {
 // order -- is entry  base_T(block) + k  of region T, base_T = the kept type-T entries of all blocks in front.  So the
 // per-pair pointers are an in-wave scan on top of the block bases, and the entries move with ballot ranks and three
 // running counters -- no search, no per-pair loop, a hub pair of hundreds of entries is walked by 64 lanes.
-__global__ __launch_bounds__(256) void s4_regions_kernel(const ArgsR A) {
+__global__ __launch_bounds__(64) void s4_regions_kernel(const ArgsR A) {
     const int lane = threadIdx.x & 63;
     const int64_t nblk = (A.bs + S4_PAIRS - 1) / S4_PAIRS;
     const int64_t B = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (B >= nblk) return;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     // kept entries, by type, of the blocks in front
+    // (eight requests of a lane in flight at a time: 512 blocks -- a 32,768-pair batch -- are ONE round trip; a loop of
+    //  single requests waited for each in turn, 10 us for the last blocks of a launch that moves a few thousand records)
     int64_t base[3] = {0, 0, 0};
-    for (int64_t i = lane; i < B; i += 64) {
-        const int4 v = A.blk_types[i];
-        base[0] += v.x > 0 ? v.x : 0;
-        base[1] += v.y > 0 ? v.y : 0;
-        base[2] += v.z > 0 ? v.z : 0;
+    const int4 e_raw = B * S4_PAIRS + lane < A.bs ? A.pair_tab[B * S4_PAIRS + lane] : make_int4(0, 0, 0, 0);
+    for (int64_t i0 = 0; i0 < B; i0 += 64 * 8) {
+        int4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = i0 + 64 * u + lane;
+            v[u] = A.blk_types[i < B ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + 64 * u + lane < B) {
+                base[0] += v[u].x > 0 ? v[u].x : 0;
+                base[1] += v[u].y > 0 ? v[u].y : 0;
+                base[2] += v[u].z > 0 ? v[u].z : 0;
+            }
+        }
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(256) void s4_regions_kernel(const ArgsR A) {
         for (int dlt = 32; dlt > 0; dlt >>= 1) base[t] += __shfl_xor((long long)base[t], dlt, 64);
     const int64_t p = B * S4_PAIRS + lane;
     const bool in = p < A.bs;
-    int4 e = in ? A.pair_tab[p] : make_int4(0, 0, 0, 0);
+    int4 e = e_raw;      // (requested beside the block sums)
     // (a table entry that does not lie inside the buffer counts as empty: nothing is read outside it)
     if (e.x < 0 || e.y < 0 || e.z < 0 || e.w < 0 || (int64_t)e.x + e.y + e.z + e.w > A.ent_cap4) e = make_int4(0, 0, 0, 0);
     int c[3] = {e.y, e.z, e.w}, x[3];
@@ -518,7 +531,8 @@ extern "C" int lpf_select4_regions(int64_t bs, const void *pair_tab, const void 
     const ArgsR a{bs, static_cast<const int4 *>(pair_tab), static_cast<const int4 *>(blk_types),
                   static_cast<const int4 *>(entries4), ent_cap4, type_ptr, static_cast<int4 *>(regions), ent_cap, ctl};
     const int64_t nblk = (bs + S4_PAIRS - 1) / S4_PAIRS;
-    hipLaunchKernelGGL(s4_regions_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    // (a wavefront per workgroup: nothing is shared, and 512 single wavefronts spread over every CU)
+    hipLaunchKernelGGL(s4_regions_kernel, dim3((unsigned)nblk), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

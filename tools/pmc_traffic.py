@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 SHORT = [  # kernel-name fragment -> name used by bench.py's roofline table
-    ("select4_kernel", "select4"), ("select3_run_kernel", "select3_run"), ("select3_plan_kernel", "select_plan"),
+    ("select4_kernel", "select4"), ("s4_regions_kernel", "select_regions"), ("select3_run_kernel", "select3_run"), ("select3_plan_kernel", "select_plan"),
     ("select_run_kernel", "select_run_general"), ("select_plan_kernel", "select_plan"), ("select_export", "select_export"),
     ("pair_flip_kernel", "pair_attention_fused"), ("pair_fused_kernel", "pair_attention_fused_mfma"),
     ("pair_rows_kernel", "pair_attention_rows"),
