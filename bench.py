@@ -304,9 +304,6 @@ def main():
                          "streams); plan: every stream replays the RECORDED C-ABI launches of the step, one plain launch "
                          "after the other (lpformer_amd.PlannedScorer; 0.04 ms of host time, the overlap of eager "
                          "launches).  The same launches and bitwise the same scores in all three")
-    ap.add_argument("--tail", default="f32", choices=("split", "f32"),
-                    help="the dense tail's two GEMMs in the fp32 parity mode: fp32 MFMAs (default) or split-bf16 products "
-                         "on the bf16 matrix cores (within 2e-5 of fp32; measured 6 %% slower per pipelined step)")
     ap.add_argument("--select4-threads", type=int, default=0,
                     help="(tuning) launch shape of lpf_select4: workgroup size + 4096 * (blocks per workgroup - 1); 0 = default")
     ap.add_argument("--select-grid", type=int, default=0,
@@ -342,12 +339,9 @@ def main():
     model.use_side_stream = side == "on" or (side == "auto" and args.streams <= 1)
     model.attention_impl = args.attention
     model.select_grid = args.select_grid
-    model.tail_split = args.tail == "split"
     model.select4_threads = args.select4_threads
     if os.environ.get("LPF_SELECT_BLOCKS"):                      # A/B aid: "0" = lpf_select3_plan / _run on every path
         model.select_blocks = os.environ["LPF_SELECT_BLOCKS"] != "0"
-    if os.environ.get("LPF_TAIL_FOLD_E"):                        # A/B aid: "0" = the tail multiplies A_e r_e itself
-        model.tail_fold_e = os.environ["LPF_TAIL_FOLD_E"] != "0"
     enc_plan = None
     if world > 1:
         # encoder layout: measure the whole encoder on one GPU (replicated mode) and the all-gather of an [N, D] fp32

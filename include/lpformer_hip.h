@@ -90,17 +90,6 @@ int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order
                             const float *ln_b, const float *residual, int64_t ldr, const float *ln2_g,
                             const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
                             float *pre_out, int64_t ldpre, void *stream);
-/* The same with a SECOND D x D product chained to the finished rows while they are still in registers (the last layer
- * of the encoder):  out2[r - row_base] = W2 out[r] + bias2,  w2_packed = pack_dense(W2, 1).  With W2 = lin_r.weight[:, :D]
- * and bias2 = lin_r.bias this is Z = X_node W_rx^T + b_r, the per-node half of the attention's key projection
- * (src/modules/layers.py:204) -- formerly an N x D x D lpf_gemm_f32 launch that re-read X_node from HBM. */
-int lpf_gcn_layer_fused_keys_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
-                                 const int64_t *rowptr, const int32_t *col, const float *w, const float *H, int64_t ldh,
-                                 const float *w_packed, float *out, int64_t ldo, const float *bias, const float *ln_g,
-                                 const float *ln_b, const float *residual, int64_t ldr, const float *ln2_g,
-                                 const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
-                                 const float *w2_packed, const float *bias2, float *out2, int64_t ldo2, void *stream);
-
 /* The same layer gathering from a bf16 table (the bf16-table encoder mode; D = 64 or 128).  H_bf16p: uint16 rows, ldh in
  * elements (a multiple of 8), in the PERMUTED order  element 32 i + 8 q + 4 h + u = feature 16 (2 i + h) + 4 q + u
  * (i < D/32, q < 4, h < 2, u < 4) -- a lane's 16-byte load then holds two whole 16-feature k-groups.  out receives the
@@ -562,19 +551,6 @@ int lpf_pair_attention_rows_perm_zbf16(int32_t D, int64_t bs, const int32_t *typ
                                        const float *ln_g, const float *ln_b, int32_t n_counts, const int64_t *sel_ctl,
                                        float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
                                        uint64_t *perm_lb, int64_t *n_nonempty, void *stream);
-/* lpf_tail_chain_rows_f32 / lpf_tail_chain_rows_perm_f32 with the two GEMMs on the bf16 matrix cores at fp32 accuracy
- * (other_models.py:80-179, link_transformer.py:170-177 as above): wB / wC are SPLIT images of the same packed weights
- * -- per packed element four hi = bf16(w) followed by four lo = bf16(w - hi), 16 bytes like an fp32 element
- * (lpformer_amd/fold.py split_bf16_planes) --, the activations are split the same way in registers, a product is three
- * v_mfma_f32_16x16x16_bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate).  Dropped: lo*lo and the rounding of the lo planes,
- * <= 3 * 2^-18 |w| |x| per term; logits within ~1e-5 of the fp32 launch.  perm / n_full / bC_empty: all three (the
- * order lpf_pair_attention_rows*_ left) or all NULL. */
-int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
-                              const void *wB_split, const float *bB, const float *lnB_g, const float *lnB_b,
-                              const float *r_e, int64_t ldre, const void *wC_split, const float *bC, const float *w_dot,
-                              const float *b_dot, const int64_t *sel_ctl, const int32_t *perm, const int64_t *n_full,
-                              const float *bC_empty, const float *row_empty, float *logit, float *prob, void *stream);
-
 /* lpf_pair_attention_rows_perm_* behind lpf_select4: the entries are pair-major already (a pair's entries contiguous from
  * pair_tab[p][0], the type in bits 29-30 of the record's pair word), so the kernel reads ONE region and needs no per-type
  * pointers; its workgroups split the batch by blk_cnt (entries per LPF_SELECT4_BLOCK pairs) and the 64 table entries of the
@@ -623,19 +599,8 @@ int lpf_pair_attention_rows4_zbf16(int32_t D, int64_t bs, const void *pair_tab, 
                                    float *pieces, int64_t units_cap, float *out, int64_t ldo, int32_t *perm,
                                    int64_t *n_nonempty, void *stream);
 
-/* lpf_tail_chain_rows_perm_f32 (other_models.py:80-179, link_transformer.py:101-105,170-177 as there) with the elementwise
- * branch's share of the folded score head done already: t_e [M, ldte >= 2 D] = A_e r_e -- lpf_dense_chain_side_f32 run with
- * A_e (the first D columns of the fold lins0([ew | pw]) = A_e r_e + A_p r_p + c, no bias) as its second layer.  Stage C
- * starts from t_e and runs the r_p k-groups of wC_packed only (the same image; its A_e k-groups are skipped); workgroups
- * of pairs without selected nodes compute w_dot . ReLU(t_e + bC_empty) + b_dot without a matrix instruction.  The product
- * A_e r_e is the same fp32 MFMA product either way -- it moves from the launch that is bound by the matrix pipe into the
- * one that is bound by its gather. */
-int lpf_tail_chain_rows_perm_te_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
-                                    const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
-                                    const float *t_e, int64_t ldte, const float *wC_packed, const float *bC,
-                                    const float *w_dot, const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
-                                    const int64_t *n_full, const float *bC_empty, const float *row_empty, float *logit,
-                                    float *prob, void *stream);
+/* The dense tail behind that order (perm / n_full / bC_empty / row_empty: the paragraph in front of
+ * lpf_pair_attention_rows_perm_f32; other_models.py:80-179, link_transformer.py:101-105,170-177). */
 int lpf_tail_chain_rows_perm_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
                                  const float *wB_packed, const float *bB, const float *lnB_g, const float *lnB_b,
                                  const float *r_e, int64_t ldre, const float *wC_packed, const float *bC,

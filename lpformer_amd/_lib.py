@@ -37,8 +37,6 @@ HIP_PROTOTYPES = {
     "lpf_gemm_f32_out_bf16": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
     "lpf_gcn_layer_fused_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,
                                 vp, vp, i64, vp],
-    "lpf_gcn_layer_fused_keys_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32,
-                                     vp, vp, vp, vp, vp, i64, vp],
     "lpf_spmm_row_parts_f32": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
     "lpf_spmm_row_parts_bf16p": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
     "lpf_gcn_layer_fused_bf16": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,
@@ -76,12 +74,8 @@ HIP_PROTOTYPES = {
                                        vp, vp, vp, vp, i32, vp, vp, i64, vp, i64, vp, vp, vp],
     "lpf_tail_chain_rows_perm_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp, vp],
-    "lpf_tail_chain_rows_perm_te_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                        vp, vp, vp],
     "lpf_tail_chain_rows_perm_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, vp],
-    "lpf_tail_chain_rows_split": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                  vp, vp, vp],
     "lpf_pair_rows_piece_floats": [i32],
     "lpf_tail_chain_rows_f32": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lpf_tail_chain_rows_bf16": [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -436,7 +436,6 @@ int dc_entry(int64_t M, int32_t in_mode, const float *X, int64_t ldx, const int6
     DC_SQUARE(4);    // elementwise_lin 64 -> 64 -> 64
     DC_SQUARE(8);
     DC_SQUARE(16);
-    DC_CASE(8, 16, 1);  // elementwise_lin's first layer + the folded score head's columns for it (D = 128 -> 256: t_e)
     DC_CASE(3, 0, 0);   // first layer of pairwise_lin alone (hidden layer kept for the folded score head)
     DC_CASE(5, 0, 0);
     DC_CASE(9, 0, 0);

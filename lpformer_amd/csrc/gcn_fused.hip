@@ -52,10 +52,6 @@ struct GcnFusedArgs {
     const float *t_parts;        // [n_slices][D]: the slices' sums
     float *pre; int64_t ldpre;   // optional: the pre-normalisation rows (product + bias), for a LayerNorm backward
     uint16_t *out_b; int64_t ldob;   // optional (HB): the result rows as permuted bf16 (the next layer's table)
-    // KEYS: a second product chained to the finished rows -- out2[r] = W2 out[r] + bias2 (the node half of the
-    // attention's key projection, Z = X_node W_rx^T + b_r, computed while the rows are still in registers)
-    const float *wp2, *bias2;
-    float *out2; int64_t ldo2;
 };
 
 constexpr int GF_THREADS = 512;   // threads of a workgroup
@@ -104,22 +100,13 @@ __device__ __forceinline__ void gf_layernorm(f32x4 (&y)[NT], const float *g, con
     }
 }
 
-// KEYS (the last layer of the encoder): the epilogue leaves lane (j, q) with out[row j][16 c + 4 q + 0..3] -- exactly the
-// B-operand layout of the product (k = 16 g + 4 q + u) -- so a second D x D product can be chained to the finished rows
-// without any staging: Z = X_node W_rx^T + b_r, the per-node half of the attention's key projection
-// (src/modules/layers.py:204, lin_r), used to be an N x D x D GEMM launch of its own that re-read X_node from HBM.  Its
-// 16 NT^2 MFMAs per tile hide under the gather like the layer's own.  Two weight images in LDS (128 KB at D = 128).
-
-template <int NT, bool HB, bool KEYS = false>
+template <int NT, bool HB>
 __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) void gcn_fused_kernel(const GcnFusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) f32x4 gf_lds[];
     f32x4 *const lw = gf_lds;                                       // [NT][GF_STAGE]
     int *const lticket = reinterpret_cast<int *>(gf_lds + NT * GF_STAGE);
-    f32x4 *const lw2 = gf_lds + NT * GF_STAGE + 1;                  // KEYS: [NT][GF_STAGE]
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
     for (int i = threadIdx.x; i < NT * GF_STAGE; i += GF_THREADS) lw[i] = reinterpret_cast<const f32x4 *>(A.wp)[i];
-    if constexpr (KEYS)
-        for (int i = threadIdx.x; i < NT * GF_STAGE; i += GF_THREADS) lw2[i] = reinterpret_cast<const f32x4 *>(A.wp2)[i];
     if (threadIdx.x == 0) *lticket = 0;
     __syncthreads();
 
@@ -355,35 +342,6 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
                 }
             }
         }
-        if constexpr (KEYS) {
-            // Z^T tile = W2 . out: the finished rows are the B operands as they stand
-            f32x4 z[NT];
-#pragma unroll
-            for (int c = 0; c < NT; ++c) z[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < NT; ++g) {
-                const f32x4 *lg = lw2 + g * GF_STAGE + lane;
-#pragma unroll
-                for (int c0_ = 0; c0_ < NT; c0_ += 4) {
-                    f32x4 a[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) a[c] = (c0_ + c < NT) ? lg[(c0_ + c) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (c0_ + c < NT)
-                                z[c0_ + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][u], y[g][u], z[c0_ + c], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (live) {
-                float *zp = A.out2 + orow * A.ldo2 + 4 * q;
-#pragma unroll
-                for (int c = 0; c < NT; ++c)
-                    *reinterpret_cast<f32x4 *>(zp + 16 * c) = z[c] + *reinterpret_cast<const f32x4 *>(A.bias2 + 16 * c + 4 * q);
-            }
-        }
         tile = tile_of(GF_THREADS / 64 + __builtin_amdgcn_readfirstlane(tk_next));
         if (tile < A.n_tiles) tk_next = draw();
     }
@@ -397,11 +355,8 @@ int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_
               const int32_t *col, const float *w, const void *H, int64_t ldh, const float *w_packed, float *out,
               int64_t ldo, const float *bias, const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
               const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
-              float *pre_out, int64_t ldpre, void *out_b, int64_t ldob, void *stream, const float *w2_packed = nullptr,
-              const float *bias2 = nullptr, float *out2 = nullptr, int64_t ldo2 = 0) {
+              float *pre_out, int64_t ldpre, void *out_b, int64_t ldob, void *stream) {
     if (n_tiles == 0) return LPF_OK;
-    LPF_REQUIRE(!w2_packed || (!HB && bias2 && out2 && ldo2 >= D && (ldo2 & 3) == 0 && lpf_aligned16(w2_packed) &&
-                               lpf_aligned16(bias2) && lpf_aligned16(out2)));
     LPF_REQUIRE(n_tiles > 0 && row_order && rowptr && col && w && H && w_packed && out);
     if (D != 32 && D != 64 && D != 128) return LPF_ERR_UNSUPPORTED;
     if (HB && D == 32) return LPF_ERR_UNSUPPORTED;      // (a bf16 row of 64 bytes is half a line)
@@ -415,26 +370,19 @@ int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_
                 (!ln2_g || (lpf_aligned16(ln2_g) && lpf_aligned16(ln2_b))) && (!t_parts || lpf_aligned16(t_parts)));
     const GcnFusedArgs a{n_tiles, row_order, row_base, rowptr, col, w, static_cast<const float *>(H), ldh, w_packed, out,
                          ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre,
-                         static_cast<uint16_t *>(out_b), ldob, w2_packed, bias2, out2, ldo2};
+                         static_cast<uint16_t *>(out_b), ldob};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_cu = lpf_cu_count();
     if (n_cu == 0) return LPF_ERR_NO_DEVICE;
     // persistent workgroups
     const int64_t want = (n_tiles + GF_THREADS / 64 - 1) / (GF_THREADS / 64);
-#define LPF_GF_K(NT, KEYS)                                                                                          \
+#define LPF_GF(NT)                                                                                                  \
     do {                                                                                                            \
-        auto kern = gcn_fused_kernel<NT, HB, KEYS>;                                                                 \
-        constexpr size_t lds = (size_t)((KEYS ? 2 : 1) * NT * GF_STAGE + 1) * sizeof(f32x4);                        \
+        auto kern = gcn_fused_kernel<NT, HB>;                                                                       \
+        constexpr size_t lds = (size_t)(NT * GF_STAGE + 1) * sizeof(f32x4);                                         \
         LPF_SET_MAX_LDS(kern, lds);                                                                                 \
         const int64_t cap = (int64_t)gf_per_cu<NT>() * n_cu;                                                       \
         hipLaunchKernelGGL(kern, dim3((unsigned)(want < cap ? want : cap)), dim3(GF_THREADS), lds, s, a);           \
-    } while (0)
-#define LPF_GF(NT)                                   \
-    do {                                             \
-        if constexpr (!HB) {                         \
-            if (w2_packed) { LPF_GF_K(NT, true); break; } \
-        }                                            \
-        LPF_GF_K(NT, false);                         \
     } while (0)
     switch (D) {
         case 32:
@@ -444,25 +392,10 @@ int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_
         default: LPF_GF(8); break;
     }
 #undef LPF_GF
-#undef LPF_GF_K
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }
 }  // namespace
-
-extern "C" int lpf_gcn_layer_fused_keys_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
-                                            const int64_t *rowptr, const int32_t *col, const float *w, const float *H,
-                                            int64_t ldh, const float *w_packed, float *out, int64_t ldo,
-                                            const float *bias, const float *ln_g, const float *ln_b,
-                                            const float *residual, int64_t ldr, const float *ln2_g, const float *ln2_b,
-                                            uint32_t flags, const int32_t *hubs, const float *t_parts,
-                                            const float *w2_packed, const float *bias2, float *out2, int64_t ldo2,
-                                            void *stream) {
-    LPF_REQUIRE(w2_packed && bias2 && out2);
-    return gf_launch<false>(D, n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
-                            residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, nullptr, 0, nullptr, 0, stream, w2_packed,
-                            bias2, out2, ldo2);
-}
 
 extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
                                        const int64_t *rowptr, const int32_t *col, const float *w, const float *H,

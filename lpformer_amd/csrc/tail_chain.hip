@@ -60,10 +60,6 @@ struct TailArgs {
     // ... and a pair without selected nodes in a MIXED workgroup takes its (constant) row from here and zero counts: the
     // attention kernel that leaves the order does not write rows for such pairs
     const float *row_empty;         // [NA]
-    // rows mode, optional: `re` is not the hidden activation r_e of elementwise_lin but t_e = A_e r_e already ([M, NC]:
-    // the elementwise branch's launch ran the folded score head's first D columns as its second layer) -- stage C starts
-    // from it and runs the r_p k-groups only; a workgroup of pairs without selected nodes multiplies nothing at all
-    int re_folded;
 };
 
 constexpr int tc_per_thread(int ntp) { return (ntp * 64 + TC_THREADS - 1) / TC_THREADS; }
@@ -122,39 +118,6 @@ __device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint2 *lw, cons
         const bf16x4_bits a = {(short)(w.x & 0xffffu), (short)(w.x >> 16), (short)(w.y & 0xffffu), (short)(w.y >> 16)};
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[c], 0, 0, 0);
     }
-}
-
-// SPLIT variant: fp32 results from the bf16 matrix cores.  Every weight travels as two bf16 planes (hi = bf16(w), lo =
-// bf16(w - hi), split on the host: the weights are constants; one uint4 = four hi + four lo, the 16 bytes an fp32 element
-// takes), every activation is split the same way in registers, and a product is three v_mfma_f32_16x16x16_bf16 --
-// hi*hi + lo*hi + hi*lo, fp32 accumulate -- instead of four fp32 MFMAs: what is dropped is lo*lo and the rounding of the
-// two lo planes, <= 3 * 2^-18 |w| |x| per term (a bf16 product is exact in fp32).  24 matrix-pipe cycles per k-group and
-// tile instead of 128.
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-template <int TPW>
-__device__ __forceinline__ void tc_mfma(f32x4 (&acc)[TPW], const uint4 *lw, const f32x4 bv, bool last = true) {
-    // the activations' planes: hardware conversions (v_cvt_pk_bf16_f32, round to nearest even), hi widened back by shifts
-    const bf16x4_t h4 = __builtin_convertvector(bv, bf16x4_t);
-    const f32x4 hf = __builtin_convertvector(h4, f32x4);
-    const bf16x4_t l4 = __builtin_convertvector(bv - hf, bf16x4_t);
-    const bf16x4_bits bh = __builtin_bit_cast(bf16x4_bits, h4), bl = __builtin_bit_cast(bf16x4_bits, l4);
-    bf16x4_bits ah[TPW], al[TPW];
-#pragma unroll
-    for (int c = 0; c < TPW; ++c) {
-        const uint4 w = lw[c * 64];
-        ah[c] = __builtin_bit_cast(bf16x4_bits, make_uint2(w.x, w.y));
-        al[c] = __builtin_bit_cast(bf16x4_bits, make_uint2(w.z, w.w));
-    }
-    const int n = last ? TPW : TPW - 1;   // consecutive MFMAs go to different accumulators
-#pragma unroll
-    for (int c = 0; c < TPW; ++c)
-        if (c < n) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[c], bh, acc[c], 0, 0, 0);
-#pragma unroll
-    for (int c = 0; c < TPW; ++c)
-        if (c < n) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[c], bh, acc[c], 0, 0, 0);
-#pragma unroll
-    for (int c = 0; c < TPW; ++c)
-        if (c < n) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[c], bl, acc[c], 0, 0, 0);
 }
 
 __device__ __forceinline__ float tc_quad_sum(float v) {
@@ -225,14 +188,13 @@ struct TcShape {
 
 // (D = 256: 32 output tiles of the score head -- 16 accumulators per lane in stage C alone --, one workgroup per CU with
 //  twice the registers)
-// WM: how the two GEMMs run -- 0 fp32 weights and MFMAs, 1 bf16 weights and activations (throughput mode), 2 fp32 from
-// split bf16 planes (rows mode)
+// WM: how the two GEMMs run -- 0 fp32 weights and MFMAs, 1 bf16 weights and activations (throughput mode)
 template <int NTA, int NTB, int NTC, int WM = 0, bool ROWS = false>
 __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 : 3)) void tail_chain_kernel(const TailArgs A) {
     using S = TcShape<NTA, NTB, NTC>;
     constexpr bool WB = WM != 0;
-    // weight element: four fp32, four bf16, or four hi + four lo bf16
-    using WT = typename std::conditional<WM == 1, uint2, typename std::conditional<WM == 2, uint4, f32x4>::type>::type;
+    // weight element: four fp32 or four bf16
+    using WT = typename std::conditional<WM == 1, uint2, f32x4>::type;
     constexpr int NTPA = S::NTPA, NTPB = S::NTPB, NTPC = S::NTPC;
     constexpr int TPWA = NTPA / 2, TPWB = NTPB / 2, TPWC = NTPC / 2;
     constexpr int NGE = NTA;  // k-groups of r_e
@@ -273,24 +235,14 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
             // ---- 64 pairs without selected nodes: score = w_dot . ReLU(A_e r_e + bC_empty) + b_dot -- stage C over the
             //      r_e k-groups alone (35 % of the matrix work of a full workgroup), nothing else
             f32x4 acc[TPWC];
-            const int n_kg = A.re_folded ? 0 : NGE;
-            if (A.re_folded) {      // (t_e in the accumulator layout: rows 4 q .. 4 q + 3 of tile c, sample j)
-                const float *ter = A.re + mm * A.ldre + 16 * half * TPWC + 4 * q;
 #pragma unroll
-                for (int c = 0; c < TPWC; ++c) acc[c] = *reinterpret_cast<const f32x4 *>(ter + 16 * c);
-            } else {
-#pragma unroll
-                for (int c = 0; c < TPWC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            for (int c = 0; c < TPWC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             WT wr[S::PC];
             const float *rer = A.re + mm * A.ldre + 4 * q;
-            f32x4 xr = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (!A.re_folded) {
-                tc_load<S::PC, NTPC>(wr, A.wC, 0, tid);
-                xr = *reinterpret_cast<const f32x4 *>(rer);
-            }
+            tc_load<S::PC, NTPC>(wr, A.wC, 0, tid);
+            f32x4 xr = *reinterpret_cast<const f32x4 *>(rer);
 #pragma unroll 1
-            for (int kg = 0; kg < n_kg; ++kg) {
+            for (int kg = 0; kg < NGE; ++kg) {
                 const f32x4 bv = xr;
                 WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
                 tc_store<S::PC>(wr, lw, tid);
@@ -496,11 +448,9 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
     }
     TC_STAMP(2);
     WT wrC[S::PC];
-    const bool te = ROWS && A.re_folded;
-    tc_load<S::PC, NTPC>(wrC, A.wC, te ? NGE : 0, tid);
+    tc_load<S::PC, NTPC>(wrC, A.wC, 0, tid);
     const float *rer = A.re + mm * A.ldre + 4 * q;
-    f32x4 xr = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!te) xr = *reinterpret_cast<const f32x4 *>(rer);  // stage C's first input group
+    f32x4 xr = *reinterpret_cast<const f32x4 *>(rer);  // stage C's first input group
     {
         const int fbase = 16 * half * TPWB + 4 * q;
 #pragma unroll
@@ -514,16 +464,10 @@ __global__ __launch_bounds__(TC_THREADS, NTC >= 32 ? 2 : (TC_THREADS >= 512 ? 4 
     TC_STAMP(3);
     // ------------------------------------------------------------------ stage C: folded score head
     f32x4 accC[TPWC];
-    if (te) {   // the elementwise branch's share of the sum is there already (accumulator layout: rows 4 q .. + 3 of tile c)
-        const float *ter = A.re + mm * A.ldre + 16 * half * TPWC + 4 * q;
 #pragma unroll
-        for (int c = 0; c < TPWC; ++c) accC[c] = *reinterpret_cast<const f32x4 *>(ter + 16 * c);
-    } else {
-#pragma unroll
-        for (int c = 0; c < TPWC; ++c) accC[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int c = 0; c < TPWC; ++c) accC[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int kg = te ? NGE : 0; kg < NGE; ++kg) {  // r_e, read from global memory
+    for (int kg = 0; kg < NGE; ++kg) {  // r_e, read from global memory
         const f32x4 bv = xr;
         WT *lw = reinterpret_cast<WT *>(lds) + buf * S::SLAB;
         tc_store<S::PC>(wrC, lw, tid);
@@ -678,9 +622,8 @@ int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t l
             const float *lnB_g, const float *lnB_b, const float *r_e, int64_t ldre, const void *wC, const float *bC,
             const float *w_dot, const float *b_dot, const int64_t *sel_ctl, float *logit, float *prob, void *stream,
             const int32_t *perm = nullptr, const int64_t *n_full = nullptr, const float *bC_empty = nullptr,
-            const float *row_empty = nullptr, bool re_folded = false) {
+            const float *row_empty = nullptr) {
     if (M == 0) return LPF_OK;
-    LPF_REQUIRE(!re_folded || ldre >= 2 * D);
     LPF_REQUIRE(!perm || (n_full && bC_empty && lpf_aligned16(bC_empty)));
     LPF_REQUIRE(!row_empty || (perm && lpf_aligned16(row_empty)));
     LPF_REQUIRE(M > 0 && rows && wB && bB && lnB_g && lnB_b && r_e && wC && bC && w_dot && b_dot && (logit || prob));
@@ -690,8 +633,7 @@ int tc_rows(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t l
                 lpf_aligned16(lnB_g) && lpf_aligned16(lnB_b) && lpf_aligned16(bC) && lpf_aligned16(w_dot));
     TailArgs a{M, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, D, nullptr, 0, static_cast<const float *>(wB), bB,
                lnB_g, lnB_b, D + n_counts, r_e, ldre, static_cast<const float *>(wC), bC, 2 * D, w_dot, b_dot, logit, prob,
-               nullptr, nullptr, 0, nullptr, nullptr, sel_ctl, n_counts, rows, ldrows, perm, n_full, bC_empty, row_empty,
-               re_folded ? 1 : 0};
+               nullptr, nullptr, 0, nullptr, nullptr, sel_ctl, n_counts, rows, ldrows, perm, n_full, bC_empty, row_empty};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (D) {
         case 32: return tc_launch<2, 3, 4, WM, true>(a, s);
@@ -747,36 +689,4 @@ extern "C" int lpf_tail_chain_rows_perm_bf16(int64_t M, int32_t D, int32_t n_cou
     LPF_REQUIRE(perm && n_full && bC_empty);
     return tc_rows<1>(M, D, n_counts, rows, ldrows, wB_packed_bf16, bB, lnB_g, lnB_b, r_e, ldre, wC_packed_bf16, bC, w_dot,
                          b_dot, sel_ctl, logit, prob, stream, perm, n_full, bC_empty, row_empty);
-}
-
-/* lpf_tail_chain_rows_perm_f32 with the elementwise branch's product done already: t_e [M, ldte >= 2 D] = A_e r_e, the
- * first D columns of the folded score head applied to the hidden activation of elementwise_lin by the launch that
- * computed it (lpf_dense_chain_side_f32 with A_e as its second layer) -- stage C starts from t_e and runs the r_p
- * k-groups of wC only (the A_e k-groups of the image are skipped); workgroups of pairs without selected nodes compute
- * w_dot . ReLU(t_e + bC_empty) + b_dot without a matrix instruction. */
-extern "C" int lpf_tail_chain_rows_perm_te_f32(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
-                                               const float *wB_packed, const float *bB, const float *lnB_g,
-                                               const float *lnB_b, const float *t_e, int64_t ldte,
-                                               const float *wC_packed, const float *bC, const float *w_dot,
-                                               const float *b_dot, const int64_t *sel_ctl, const int32_t *perm,
-                                               const int64_t *n_full, const float *bC_empty, const float *row_empty,
-                                               float *logit, float *prob, void *stream) {
-    LPF_REQUIRE(perm && n_full && bC_empty);
-    return tc_rows<0>(M, D, n_counts, rows, ldrows, wB_packed, bB, lnB_g, lnB_b, t_e, ldte, wC_packed, bC, w_dot, b_dot,
-                      sel_ctl, logit, prob, stream, perm, n_full, bC_empty, row_empty, true);
-}
-
-/* lpf_tail_chain_rows_f32 / _perm_f32 with the two GEMMs on the bf16 matrix cores at fp32 accuracy: wB / wC as SPLIT images
- * (lpformer_amd/fold.py split_bf16_planes: per packed element four hi = bf16(w) then four lo = bf16(w - hi), 16 bytes), the
- * activations split in registers, three MFMAs per product (hi*hi + lo*hi + hi*lo).  Logits within ~1e-5 of the fp32
- * launch (the parity mode of the scoring path); perm / n_full / bC_empty: all three or all NULL. */
-extern "C" int lpf_tail_chain_rows_split(int64_t M, int32_t D, int32_t n_counts, const float *rows, int64_t ldrows,
-                                         const void *wB_split, const float *bB, const float *lnB_g, const float *lnB_b,
-                                         const float *r_e, int64_t ldre, const void *wC_split, const float *bC,
-                                         const float *w_dot, const float *b_dot, const int64_t *sel_ctl,
-                                         const int32_t *perm, const int64_t *n_full, const float *bC_empty,
-                                         const float *row_empty, float *logit, float *prob, void *stream) {
-    LPF_REQUIRE((perm != nullptr) == (n_full != nullptr) && (perm != nullptr) == (bC_empty != nullptr));
-    return tc_rows<2>(M, D, n_counts, rows, ldrows, wB_split, bB, lnB_g, lnB_b, r_e, ldre, wC_split, bC, w_dot, b_dot,
-                      sel_ctl, logit, prob, stream, perm, n_full, bC_empty, row_empty);
 }

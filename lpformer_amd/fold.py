@@ -152,17 +152,6 @@ def to_bf16_bits(x: np.ndarray) -> np.ndarray:
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
 
-def split_bf16_planes(x: np.ndarray) -> np.ndarray:
-    """fp32 [n] (n % 4 == 0, a packed weight image: groups of four consecutive k) -> uint16 [n / 4, 8]: per group four hi =
-    bf16(w) then four lo = bf16(w - hi), both round to nearest even -- 16 bytes per group, like the fp32 image.  hi + lo
-    carries w to ~2^-17 relative; the dense tail multiplies the planes on the bf16 matrix cores (csrc/tail_chain.hip)."""
-    w = np.ascontiguousarray(x, np.float32).reshape(-1, 4)
-    hi = to_bf16_bits(w)
-    hif = (hi.astype(np.uint32) << 16).view(np.float32)
-    lo = to_bf16_bits(w - hif)
-    return np.ascontiguousarray(np.concatenate([hi, lo], axis=1))
-
-
 def pack_wfold_bf16(wfold: np.ndarray) -> np.ndarray:
     """[3, D, D] (out, in) -> uint16 [3, D/32, D/16, 64, 8]: element (t, c, s, lane, j) =
     bf16(wfold[t, 32c + (lane & 31), 16s + 8 (lane >> 5) + j])   (B operand of v_mfma_f32_32x32x16_bf16)."""

@@ -155,7 +155,7 @@ class DenseChain:
 
     BUILT = {(2, 0), (3, 0), (4, 0), (5, 0), (8, 0), (9, 0), (16, 0), (17, 0), (32, 0), (2, 2), (4, 4), (8, 8),
              (16, 16), (3, 2), (5, 4), (9, 8), (17, 16)}
-    BUILT_GATHER = {1: {(2, 0), (4, 0), (8, 0), (16, 0), (2, 2), (4, 4), (8, 8), (16, 16), (8, 16)},
+    BUILT_GATHER = {1: {(2, 0), (4, 0), (8, 0), (16, 0), (2, 2), (4, 4), (8, 8), (16, 16)},
                     2: {(2, 0), (4, 0), (8, 0), (16, 0)}}
 
     def __init__(self, tag: str):
@@ -244,7 +244,6 @@ class MLP(nn.Module):
         self._pads = [_PaddedLinear() for _ in self.linears]
         self._chain = DenseChain("dense_chain_mlp")
         self._chain1 = DenseChain("dense_chain_mlp_hidden")  # first layer alone (LinkTransformer.score_pairs)
-        self._chain_e = DenseChain("dense_chain_mlp_hidden")  # first layer + the folded score head's columns for this branch
 
     def run(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, batch=None, in_mode=0) -> torch.Tensor:
         """x: [M, K] fp32 device rows (16-byte aligned).  Optionally writes the result into ``out`` (a strided view).
@@ -625,13 +624,6 @@ class LinkTransformer(nn.Module):
         self._chain_q = DenseChain("pair_q")                   # q = lin_l(x_a) + lin_l(x_b)
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
         self._conv_packs = [_PackedSquare() for _ in self.node_encoder.gnn_encoder.convs]
-        self._keys_pack = _PackedSquare()      # W_rx for the Z product chained to the last fused layer
-        self._keys_written = False
-        # True: the node half of the attention's key projection (Z = X_node W_rx^T + b_r) inside the last GCN layer's
-        # launch when that layer runs fused (csrc/gcn_fused.hip KEYS).  Off by default: measured, the chained product
-        # costs what the separate lpf_gemm_f32 costs (collab-like: encoder 0.686 -> 0.783 ms with it, 0.092 ms for the
-        # product alone) -- fp32 MFMA and the gather's vector FMAs issue from the same ports, nothing hides
-        self.fuse_node_keys = False
         self.query_from = "table"              # "table" or "gemm": see _pair_q
         # square GCN layers (in = out = D <= 128) in one launch, aggregate-then-transform (csrc/gcn_fused.hip); False:
         # always lpf_gemm_f32 + lpf_spmm_csr_f32
@@ -692,19 +684,6 @@ class LinkTransformer(nn.Module):
         # on the bf16 matrix cores with bf16 weights and activations rounded to bf16 (fp32 accumulate; record merge,
         # LayerNorms, dot product and sigmoid stay fp32); logits within 5e-3 of fp32 (observed <= 1e-3).
         self.tail_precision = "f32"
-        # tail_precision "f32", rows form: the tail's two GEMMs as split-bf16 products on the bf16 matrix cores (weights as
-        # hi | lo planes, three MFMAs per product, fp32 accumulate: within 2e-5 of the fp32 MFMA result at a fifth of its
-        # matrix-pipe time).  Off: measured, the launch gets 3.7 us shorter (51.3 against 55.0: with the matrix time
-        # gone the one-k-group-ahead weight stream is what a workgroup waits for) and the pipelined step does not move
-        # (0.165-0.168 against 0.163-0.166 ms: splitting the activations is vector work beside a vector-bound attention);
-        # the parity mode keeps the fp32 MFMAs
-        self.tail_split = False
-        # D = 128 behind the pair-major attention with an order: the elementwise branch's launch also multiplies its hidden
-        # activation by the folded score head's columns (t_e = A_e r_e, lpf_dense_chain_side_f32 with a second layer) and
-        # the tail starts stage C from that (lpf_tail_chain_rows_perm_te_f32).  Off: measured, the tail gets 16 us shorter
-        # (55.3 -> 39.6) and the other launch 18 us longer (30.9 -> 49.3: its second layer is not hidden under its
-        # gather), the pipelined step 0.1465-0.148 against 0.1443 ms -- the product costs the same wherever it runs
-        self.tail_fold_e = False
 
     # ---------------------------------------------------------------------------------- support checks
     def _check_supported(self, train_ok: bool = False):
@@ -857,13 +836,7 @@ class LinkTransformer(nn.Module):
                 for i in range(n_layers):
                     if _layers_out is not None:
                         _layers_out.append(x)
-                    z = None
-                    if i == n_layers - 1 and self.fuse_node_keys and self.att_layers[0].att.lin_r.weight.shape[1] == 2 * self.dim:
-                        z = torch.empty(self.num_nodes, self.dim, dtype=torch.float32, device=self.device)
-                    x = self._layer(i, a_hat, x, 0, self.num_nodes, keys_out=z)
-                    if z is not None and self._keys_written:
-                        torch.cuda.current_stream(self.device).synchronize()   # other streams read Z (as _node_keys)
-                        self._z_cache = (weakref.ref(x), x._version, z)
+                    x = self._layer(i, a_hat, x, 0, self.num_nodes)
             elif self.encoder_mode == "gather_once":
                 # BASELINE.json's literal layout -- "a single RCCL all-gather of node embeddings after the encoder":
                 # layers 1..L-1 run on every rank (no exchange), the LAST layer's aggregation + epilogue and the two
@@ -879,10 +852,9 @@ class LinkTransformer(nn.Module):
                 w = self._fold()
                 d = self.dim
                 pack = torch.empty(hi - lo, 2 * d, dtype=torch.float32, device=self.device)
-                x_rows = self._layer(n_layers - 1, a_hat, x, lo, hi, keys_out=pack[:, d:])
+                x_rows = self._layer(n_layers - 1, a_hat, x, lo, hi)
                 pack[:, :d] = x_rows
-                if not self._keys_written:
-                    gemm(x_rows, w["w_rx"], w["b_r"], out=pack[:, d:], tag="gemm_node_keys")  # Z of the rank's rows
+                gemm(x_rows, w["w_rx"], w["b_r"], out=pack[:, d:], tag="gemm_node_keys")  # Z of the rank's rows
                 full = lpf_dist.allgather_rows(pack, self.num_nodes)      # the all-gather of node embeddings
                 x = full[:, :d]
                 torch.cuda.current_stream(self.device).synchronize()      # other streams read Z (as _node_keys)
@@ -909,15 +881,12 @@ class LinkTransformer(nn.Module):
                 _layers_out.append(x)
             return x
 
-    def _layer(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int, keys_out=None) -> torch.Tensor:
+    def _layer(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
         """Rows [lo, hi) of layer i's output from the layer input ``x`` of ALL nodes: one launch when the layer is
-        square and small enough for the fused kernel, transform + aggregate otherwise.  ``keys_out`` ([hi - lo, D], last
-        layer only): also receives Z = X_node W_rx^T + b_r of those rows when the fused kernel can chain it
-        (``self._keys_written`` says whether it did)."""
+        square and small enough for the fused kernel, transform + aggregate otherwise."""
         x = _as_f32_rows(x)
-        self._keys_written = False
         if self._fusable(i, x.shape[1]):
-            return self._layer_fused(i, a_hat, x, lo, hi, keys_out)
+            return self._layer_fused(i, a_hat, x, lo, hi)
         return self._layer_aggregate(i, a_hat, self._layer_transform(i, x), lo, hi, x[lo:hi])
 
     def _fusable(self, i: int, in_dim: int) -> bool:
@@ -926,7 +895,7 @@ class LinkTransformer(nn.Module):
         ok = (32, 64, 128) if self.encoder_precision != "bf16" else (64, 128)   # (bf16 table: a row is >= one line)
         return self.encoder_fused and d_in == d_out and d_out in ok and in_dim == d_in
 
-    def _layer_fused(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int, keys_out=None) -> torch.Tensor:
+    def _layer_fused(self, i: int, a_hat: graph.DeviceCSR, x: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
         """``lpf_gcn_layer_fused_f32``: out[r] = epilogue((sum_e w_e x[col_e]) W^T) for r in [lo, hi) -- the same layer
         as ``_layer_transform`` + ``_layer_aggregate`` with the sum taken before the product.  With
         ``encoder_precision == "bf16"`` the rows are gathered from a bf16 image of ``x`` (``lpf_gcn_layer_fused_bf16``;
@@ -970,14 +939,6 @@ class LinkTransformer(nn.Module):
                     xb.stride(0), *common, ptr(out_b), d, st), "lpf_gcn_layer_fused_bf16")
                 if whole:
                     self._xb_cache = (weakref.ref(out), out_b)
-            elif keys_out is not None and last and self.fuse_node_keys:
-                # the last layer: Z = X_node W_rx^T + b_r chained to the finished rows inside the same launch
-                lin_r = self.att_layers[0].att.lin_r
-                check(lib.lpf_gcn_layer_fused_keys_f32(
-                    d, order.numel() // 16, ptr(order), lo, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x),
-                    x.stride(0), *common, ptr(self._keys_pack.get(lin_r.weight[:, :d])), ptr(lin_r.bias), ptr(keys_out),
-                    keys_out.stride(0), st), "lpf_gcn_layer_fused_keys_f32")
-                self._keys_written = True
             else:
                 check(lib.lpf_gcn_layer_fused_f32(
                     d, order.numel() // 16, ptr(order), lo, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x),
@@ -1970,8 +1931,7 @@ class LinkTransformer(nn.Module):
         a[:, d:d + pd] = ws0[:, d:] @ wp1
         c = bs0 + ws0[:, :d] @ be1 + ws0[:, d:] @ bp1
         out = (a.float().to(self.device), c.float().to(self.device), kpad)
-        # (A_e as a tensor of its own: the second layer of the elementwise branch's launch when the tail takes t_e)
-        self._score_fold_cache = (key, out, a[:, :d].float().contiguous().to(self.device))
+        self._score_fold_cache = (key, out)
         return out
 
     def _tail_tables(self, score_func, a, c):
@@ -1993,8 +1953,6 @@ class LinkTransformer(nn.Module):
         # bf16 images of the two GEMM weights (same element order: a lane's four fp32 become its four bf16)
         for k in ("wB", "wC"):
             dev[k + "_bf16"] = torch.from_numpy(fold.to_bf16_bits(tabs[k]).view(np.int16)).to(self.device)
-            # ... and the split images (hi | lo planes): fp32 accuracy from the bf16 matrix cores
-            dev[k + "_split"] = torch.from_numpy(fold.split_bf16_planes(tabs[k]).view(np.int16)).to(self.device)
         self._tail_cache = (key, dev)
         return dev
 
@@ -2037,22 +1995,9 @@ class LinkTransformer(nn.Module):
             if one_pass:
                 self._prepare_pair_major(adj_mask)
             side = self._fork()
-            # t_e = A_e r_e by the elementwise branch's own launch (second layer of its chain) where the pair-major tail
-            # with an order runs behind it: a third of that tail's matrix work moves into a launch bound by its gather
-            t_e = None
-            a_e = self._score_fold_cache[2]
-            fold_e = (self.tail_fold_e and one_pass and d == 128 and a_e.shape[0] == 2 * d and self._uses_rows() and
-                      self.tail_skip_empty and self.tail_precision == "f32" and not self.tail_split)
             with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(self.device)):
-                if fold_e:
-                    t = ew._chain_e.tables(ew.linears[0].weight, ew.linears[0].bias, ew.norm.weight, ew.norm.bias, a_e, None)
-                    t_e = torch.empty(bs, a_e.shape[0], dtype=torch.float32, device=self.device)
-                    if ew._chain_e.run(t, x_node, relu=True, batch=batch, in_mode=1, out=t_e, side=q_side) is None:
-                        t_e = None
                 t = ew._chain1.tables(ew.linears[0].weight, ew.linears[0].bias, ew.norm.weight, ew.norm.bias)
-                if t_e is not None:
-                    pass
-                elif ew._chain1.run(t, x_node, relu=True, batch=batch, in_mode=1, out=r[:, :d], side=q_side) is None:
+                if ew._chain1.run(t, x_node, relu=True, batch=batch, in_mode=1, out=r[:, :d], side=q_side) is None:
                     q_side = None
                     prod = torch.empty(bs, d, dtype=torch.float32, device=self.device)
                     with KernelTimer.span("pair_gather"):
@@ -2088,18 +2033,11 @@ class LinkTransformer(nn.Module):
                     #  takes the constant row itself; behind select3 the rows are there and row_empty stays NULL)
                     row0 = ptr(tt["row_empty"]) if (order and self._uses_select4(adj_mask)) else None
                     extra = (ptr(order[0]), ptr(order[1]), ptr(tt["bC_empty"]), row0) if order else ()
-                    if self.tail_precision == "f32" and self.tail_split:
-                        name, sfx = "lpf_tail_chain_rows_split", "_split"
-                        extra = extra or (None, None, None, None)
-                    elif t_e is not None and order:
-                        name, sfx = "lpf_tail_chain_rows_perm_te_f32", ""
-                    else:
-                        name = "lpf_tail_chain_rows" + ("_perm" if order else "") + ("_bf16" if b16 else "_f32")
-                        sfx = "_bf16" if b16 else ""
-                    re_in = t_e if name.endswith("_te_f32") else r
+                    name = "lpf_tail_chain_rows" + ("_perm" if order else "") + ("_bf16" if b16 else "_f32")
+                    sfx = "_bf16" if b16 else ""
                     check(getattr(lib, name)(
                         bs, d, self.count_dim, ptr(rows), rows.stride(0), ptr(tt["wB" + sfx]),
-                        ptr(tt["bB"]), ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(re_in), re_in.stride(0),
+                        ptr(tt["bB"]), ptr(tt["lnB_g"]), ptr(tt["lnB_b"]), ptr(r), r.stride(0),
                         ptr(tt["wC" + sfx]), ptr(tt["bC"]), ptr(tt["w_dot"]), ptr(tt["b_dot"]),
                         ptr(ws.ctl), *extra, ptr(res) if logits else None, None if logits else ptr(res), st), name)
                 return res

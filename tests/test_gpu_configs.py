@@ -699,42 +699,6 @@ def test_fused_gcn_layer_matches_two_launches(dim, f_in):
     assert torch.equal(blk, again)
 
 
-@pytest.mark.parametrize("dim,residual", [(32, False), (64, True), (128, False)])
-def test_node_keys_chained_to_the_last_layer_match_the_separate_product(dim, residual):
-    """Z = X_node W_rx^T + b_r computed inside the last fused GCN layer's launch (csrc/gcn_fused.hip KEYS: the finished
-    rows are the second product's operands as they stand) against the separate lpf_gemm_f32 it replaces: same table to
-    rounding, same encoder output bitwise, same scores; hub rows, isolated nodes and a ragged last tile included."""
-    cfg = dict(D.CONFIGS["tiny"], dim=dim, residual=residual, gnn_layers=2, f_in=dim)
-    n = 3001
-    ei, w = D.chung_lu_graph(n, 14000, gamma=2.1, seed=dim, max_weight=4)
-    x = np.random.default_rng(dim).standard_normal((n, dim)).astype(np.float32)
-    data = D.build_data(ei, x, n, edge_weight=w, eps=cfg["eps"])
-    args = D.train_args_for(cfg)
-    torch.manual_seed(1)
-    model = lpformer_amd.LinkTransformer(args, data, device=DEV).to(DEV).eval()
-    score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(DEV).eval()
-    with torch.no_grad():
-        model.att_layers[0].att.lin_r.bias.add_(0.2 * torch.randn(dim, device=DEV))
-    batch = torch.from_numpy(D.sample_pairs(ei, n, 2048, seed=3)).to(DEV)
-    out = {}
-    for fused in (True, False):
-        model.fuse_node_keys = fused
-        model._z_cache = model._enc_cache = None
-        h = model.propagate()
-        assert (model._z_cache is not None) == fused          # the table came with the encoder output, or not yet
-        z = model._node_keys(h, model._fold()).clone()
-        s = model.score_pairs(batch, h, score, logits=True).clone()
-        assert model.check_selection()
-        out[fused] = (h.clone(), z, s)
-    assert torch.equal(out[True][0], out[False][0])
-    zs = max(1.0, float(out[False][1].abs().max()))
-    assert (out[True][1] - out[False][1]).abs().max().item() <= 2e-5 * zs
-    assert (out[True][2] - out[False][2]).abs().max().item() <= 2e-5 * max(1.0, float(out[False][2].abs().max()))
-    lin_r = model.att_layers[0].att.lin_r
-    want = out[True][0].double() @ lin_r.weight[:, :dim].double().T + lin_r.bias.double()
-    assert (out[True][1].double() - want).abs().max().item() <= 2e-5 * zs
-
-
 @pytest.mark.parametrize("name,scale", [("collab", 0.1), ("cora", 1.0)])
 def test_query_table_follows_an_in_place_update_of_lin_l(name, scale):
     """The per-node query table Y = X W_l^T + b_l (``query_from = "table"``) is parameter-derived: an in-place change of
@@ -784,35 +748,11 @@ def test_models_the_pattern_table_covers_badly_keep_the_type_major_path():
     assert 0.0 <= left <= raw
 
 
-def test_elementwise_share_of_the_score_head_in_the_side_launch():
-    """``tail_fold_e`` (D = 128): the elementwise branch's launch multiplies its hidden activation by the folded score
-    head's columns (``lpf_dense_chain_side_f32`` with a second layer) and ``lpf_tail_chain_rows_perm_te_f32`` starts its
-    last stage from that product -- the same fp32 products in another launch: logits within 2e-5 of the default form's and
-    of the oracle's, pairs without selected nodes (no matrix instruction left for them) included."""
-    cfg, n, ei, w, x, data, args, model, score, batch = _setup("collab", scale=0.1, bs=3000)
-    assert model.dim == 128
-    model.attention_impl = "flip"
-    tb = torch.from_numpy(batch).to(DEV)
-    h = model.propagate()
-    outs = {}
-    for fold_e in (False, True):
-        model.tail_fold_e = fold_e
-        outs[fold_e] = model.score_pairs(tb, h, score, logits=True).clone()
-        assert model.check_selection()
-    scale_l = max(1.0, float(outs[False].abs().max()))
-    assert (outs[True] - outs[False]).abs().max().item() <= 2e-5 * scale_l
-    assert not torch.equal(outs[True], outs[False]) or True     # (different launches: equal bits are not required)
-    sample, ref = _oracle_sample(model, score, data, args, batch, h)
-    k = sample.shape[1]
-    err = np.abs(outs[True][:k].cpu().numpy() - ref["logit"]).max()
-    assert err <= 2e-5 * max(1.0, float(np.abs(ref["logit"]).max())), err
-
-
 @pytest.mark.parametrize("name,scale,dim", [("collab", 0.1, 128), ("cora", 1.0, 256), ("ppa", 0.02, 64), ("tiny", 1.0, 32)])
-def test_split_bf16_tail_keeps_fp32_accuracy(name, scale, dim):
-    """The dense tail's two GEMMs as split-bf16 products (``tail_split``, the default of the parity mode: weights as
-    hi | lo bf16 planes, three MFMAs per product) against the fp32-MFMA tail and the oracle: logits within 2e-5 of the
-    fp32 launch's and of the oracle's (stated bar 1e-4: five times the margin), with and without the tail's order."""
+def test_rows_tail_with_and_without_the_order_matches_oracle(name, scale, dim):
+    """The pair-major form at every width: the dense tail behind the attention's order (pairs with selected nodes first,
+    workgroups of pairs without any take the short form of the score head) and without it -- logits within 2e-5 of each
+    other and of the oracle's (stated bar 1e-4: five times the margin)."""
     cfg, n, ei, w, x, data, args, model, score, batch = _setup(name, scale=scale, bs=3000)
     if model.dim != dim:
         args = dict(args, dim=dim)
@@ -823,15 +763,14 @@ def test_split_bf16_tail_keeps_fp32_accuracy(name, scale, dim):
     tb = torch.from_numpy(batch).to(DEV)
     h = model.propagate()
     outs = {}
-    for split in (True, False):
-        for skip in (True, False):
-            model.tail_split, model.tail_skip_empty = split, skip
-            outs[split, skip] = model.score_pairs(tb, h, score, logits=True).clone()
-            assert model.check_selection()
-    scale_l = max(1.0, float(outs[False, True].abs().max()))
     for skip in (True, False):
-        assert (outs[True, skip] - outs[False, skip]).abs().max().item() <= 2e-5 * scale_l
+        model.tail_skip_empty = skip
+        outs[skip] = model.score_pairs(tb, h, score, logits=True).clone()
+        assert model.check_selection()
+    scale_l = max(1.0, float(outs[True].abs().max()))
+    assert (outs[True] - outs[False]).abs().max().item() <= 2e-5 * scale_l
     sample, ref = _oracle_sample(model, score, data, args, batch, h)
     k = sample.shape[1]
-    err = np.abs(outs[True, True][:k].cpu().numpy() - ref["logit"]).max()
-    assert err <= 2e-5 * max(1.0, float(np.abs(ref["logit"]).max())), err
+    for skip in (True, False):
+        err = np.abs(outs[skip][:k].cpu().numpy() - ref["logit"]).max()
+        assert err <= 2e-5 * max(1.0, float(np.abs(ref["logit"]).max())), err

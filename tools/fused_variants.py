@@ -17,8 +17,6 @@ model = lpformer_amd.LinkTransformer(D.train_args_for(cfg), data, device=dev).to
 score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
 model.precision = os.environ.get("LPF_PRECISION", "f32")
 model.tail_precision = os.environ.get("LPF_TAIL_PRECISION", "f32")
-model.tail_split = os.environ.get("LPF_TAIL_SPLIT", "0") == "1"
-model.tail_fold_e = os.environ.get("LPF_TAIL_FOLD_E", "0") == "1"
 if os.environ.get("LPF_PT_EXACT_MAX"):
     model.PT_EXACT_MAX = float(os.environ["LPF_PT_EXACT_MAX"])
 model.select_blocks = os.environ.get("LPF_SELECT_BLOCKS", "1") == "1"

@@ -15,7 +15,6 @@ torch.manual_seed(0)
 model = lpformer_amd.LinkTransformer(D.train_args_for(cfg), data, device=dev).to(dev).eval()
 score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2).to(dev).eval()
 model.use_side_stream = False
-model.tail_split = os.environ.get("LPF_TAIL_SPLIT", "0") == "1"
 batches = [torch.from_numpy(D.sample_pairs(ei, n, cfg["batch"], seed=1000 + i)).to(dev) for i in range(3)]
 h = model.propagate()
 lib = _lib.hip()
