@@ -6,6 +6,7 @@ MI355X_MICROARCH.md "HBM") + WRITE_SIZE_KB * 1024.  Warm-up launches (first half
 import csv
 import glob
 import json
+import re
 import sys
 from collections import defaultdict
 
@@ -36,8 +37,8 @@ def collect(d, counter):
                 continue
             for frag, short in SHORT:
                 if frag in r["Kernel_Name"]:
-                    if short == "tail_chain" and r["Kernel_Name"].rstrip().rstrip(")").split("(")[0].rstrip().endswith("true>"):
-                        short = "tail_chain_rows"
+                    if short == "tail_chain" and re.search(r"tail_chain_kernel<[^>]*true>", r["Kernel_Name"]):
+                        short = "tail_chain_rows"   # (the rows form: last template argument)
                     acc[short].append(float(r["Counter_Value"]))
                     break
     return {k: v[len(v) // 2:] for k, v in acc.items()}

@@ -1,19 +1,21 @@
 """GPU timeline of the bench's steady state from a rocprofv3 --kernel-trace CSV.
 
-Window: from the start of the `lo`-th to the start of the `hi`-th select_plan launch (one per step).  Reports the
-span per step, the union of kernel-busy time, the sum of kernel durations (overlap) and the largest idle gaps."""
+Window: the last `steps` steps of the trace, a step = one launch of the selection kernel (select4_kernel; traces of
+rounds 1-4: the plan kernel) -- run the bench with --no-kernel-timing --no-bf16 --no-cpu-baseline --weights random so that the
+timed window is the last thing that launches it.  Reports the span per step, the union of kernel-busy time, the sum of
+kernel durations (overlap) and the largest idle gaps."""
 import csv
 import sys
 from collections import defaultdict
 
 path = sys.argv[1]
-lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (12, 42)
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rows = list(csv.DictReader(open(path)))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-marks = [s for s, e, n in ks if "_plan_kernel" in n]
-w0, w1 = marks[lo], marks[hi]
+marks = [s for s, e, n in ks if "select4_kernel" in n] or [s for s, e, n in ks if "_plan_kernel" in n]
+steps = min(steps, len(marks) - 1)
+w0, w1 = marks[-steps - 1], marks[-1]
 win = [(s, e, n) for s, e, n in ks if w0 <= s < w1]
-steps = hi - lo
 busy, cur_s, cur_e, gaps = 0, win[0][0], win[0][1], []
 for s, e, n in win[1:]:
     if s > cur_e:
