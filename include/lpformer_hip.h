@@ -275,7 +275,7 @@ int lpf_select3_run(int64_t bs, const void *desc, const int64_t *offs, const int
  *             regions)  [3] STICKY error bits as above  [10] completion counter, [16..23] allocation counters (zero
  *             between launches)
  * A block that does not fit below ent_cap leaves empty pairs and raises LPF_SELECT_ERR_ENTRY_CAP (consumers write NaN
- * rows while the bit is set).  threads: launch shape, workgroup size (512 or 1024) + 4096 * (blocks of 64 pairs a workgroup
+ * rows while the bit is set).  threads: launch shape, workgroup size (256, 512 or 1024) + 4096 * (blocks of 64 pairs a workgroup
  * takes together - 1); 0 = the default (1024 threads; 2 blocks while that gives every CU a workgroup, else 1). */
 #define LPF_SELECT4_BLOCK 64
 #define LPF_SELECT4_CTL_WORDS 32

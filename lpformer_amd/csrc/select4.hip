@@ -409,6 +409,7 @@ extern "C" int lpf_select4(int64_t bs, const int64_t *batch, int64_t batch_ld, i
     else if (nth == 1024 && per == 4) hipLaunchKernelGGL((select4_kernel<1024, 4>), grid, dim3(1024), 0, s, a);
     else if (nth == 512 && per == 1) hipLaunchKernelGGL((select4_kernel<512, 1>), grid, dim3(512), 0, s, a);
     else if (nth == 512 && per == 2) hipLaunchKernelGGL((select4_kernel<512, 2>), grid, dim3(512), 0, s, a);
+    else if (nth == 256 && per == 1) hipLaunchKernelGGL((select4_kernel<256, 1>), grid, dim3(256), 0, s, a);
     else return LPF_ERR_INVALID;
     LPF_CHECK_LAUNCH();
     return LPF_OK;

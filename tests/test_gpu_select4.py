@@ -67,7 +67,7 @@ def _assert_sets_equal(got, want, tags):
 
 # launch shapes: workgroup size + 4096 * (blocks of 64 pairs per workgroup - 1); 0 = the default (1,024 threads; two
 # blocks per workgroup for batches that still give every CU a workgroup then, one otherwise)
-SHAPES = [0, 1024, 4096 + 1024, 512, 4096 + 512, 3 * 4096 + 1024]
+SHAPES = [0, 1024, 4096 + 1024, 512, 4096 + 512, 3 * 4096 + 1024, 256]
 
 
 @pytest.mark.parametrize("case", LP_CASES)
