@@ -1137,6 +1137,7 @@ class LinkTransformer(nn.Module):
             self._select4_launch(ws, batch, wi, regions=True)    # (token buffer: the kernel still reports the room it needs)
             err, _ = ws.read_status()
             need = int(ws.ctl[0].item())
+            ws.shape = self._select4_shape(bs, int(ws.ctl[1].item()))
             ws.clear_errors()
             if err & _lib.SELECT_ERR_NODE_RANGE:
                 raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
@@ -1286,6 +1287,21 @@ class LinkTransformer(nn.Module):
         self._pt_choice = (self._folded[0], ok, self._refolds)
         return ok
 
+    # Launch shape of lpf_select4 from what the first batch of a (stream, batch size) showed (round 6, same-lease interleaved
+    # A/B under the pipelined bench, profiles/r06_select4_shapes_pipelined.txt): where a batch gives every CU two
+    # workgroups even at one block of 64 pairs each and a block holds a few thousand candidate slots -- collab-like 3,000,
+    # ppa-like 4,500 -- 512-thread workgroups of ONE block (two to a CU, their phases out of step; they also fit beside
+    # another kernel's workgroup) take the step down 1-3.5 % (collab-like 0.1434-0.1456 -> 0.1381-0.1423, 0.1365 -> 0.1350
+    # on a faster lease; ppa-like 0.0833 -> 0.0805-0.0829); blocks of ~1,400 slots (citation2-like: +4 %) or a batch of a
+    # few hundred blocks (ddi-like, cora-like: equal) keep the library's default (1,024 threads, two blocks).
+    S4_SHAPE_SLOTS = (2000, 6000)
+
+    def _select4_shape(self, bs: int, slots: int) -> int:
+        nblk = (bs + _lib.SELECT4_BLOCK - 1) // _lib.SELECT4_BLOCK
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        lo, hi = self.S4_SHAPE_SLOTS
+        return 512 if (nblk >= 2 * n_cu and lo <= slots / max(nblk, 1) <= hi) else 0
+
     def _select4_launch(self, ws, batch, wi, regions: bool = False):
         """``lpf_select4`` into ``ws`` (a ``_Select4Workspace``, or -- ``regions`` -- the pair-major half of a
         ``_Select4RegionsWorkspace``)."""
@@ -1297,7 +1313,8 @@ class LinkTransformer(nn.Module):
                                   1 if wi.use_px else 0, float(self.thresh_cn), float(self.thresh_1hop),
                                   float(self.thresh_non1hop), ptr(ws.ctl), ptr(ws.pair_tab), ptr(ws.blk_cnt),
                                   ptr(getattr(ws, "blk_types", None)), ptr(ws.entries4 if regions else ws.entries),
-                                  ws.ent_cap4 if regions else ws.ent_cap, self.select4_threads, st), "lpf_select4")
+                                  ws.ent_cap4 if regions else ws.ent_cap,
+                                  self.select4_threads or getattr(ws, "shape", 0), st), "lpf_select4")
 
     def _select4_device(self, batch: torch.Tensor, test_set: bool) -> "_Select4Workspace":
         """The one-launch selection for the hot path (``lpf_select4``): pair-major entries, a table entry per pair,
@@ -1316,6 +1333,7 @@ class LinkTransformer(nn.Module):
             ws.ensure(ent_cap=16)
             self._select4_launch(ws, batch, wi)      # (token buffer: the kernel still reports the room it needs)
             err, need = ws.read_status()
+            ws.shape = self._select4_shape(bs, int(ws.ctl[1].item()))
             ws.clear_errors()
             if err & _lib.SELECT_ERR_NODE_RANGE:
                 raise IndexError(f"batch holds node ids outside [0, {self.num_nodes})")
