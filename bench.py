@@ -640,7 +640,10 @@ def main():
         ref_l = model.score_pairs(batches[0], h, score, logits=True).clone()
         model.precision = model.tail_precision = "bf16"
         got_l = model.score_pairs(batches[0], h, score, logits=True)
-        bf16 = {"value": round(world * bs * args.steps / el16, 1), "unit": "pairs/s",
+        bf16 = {"role": ("an option, not a throughput mode: at D >= 128 the attention waits on its instruction chain, not "
+                         "on bytes (DESIGN.md section 8, row g1)" if d >= 128 else
+                         "bf16 node table + bf16 matrix cores in the attention and the tail"),
+                "value": round(world * bs * args.steps / el16, 1), "unit": "pairs/s",
                 "ms_per_step": round(el16 * 1e3 / args.steps, 4),
                 "max_abs_logit_diff_vs_f32": float((got_l - ref_l).abs().max()),
                 "what": "bf16 storage of the node table Z; attention: "
