@@ -985,7 +985,7 @@ def main():
                                           ("one launch, pair-major (select4.hip) + lpf_select4_regions: type-major regions"
                                            if model._uses_select4_regions() else
                                            "plan + run launches, type-major regions (select3.hip)")),
-                       "flip_break_even": model.FLIP_BREAK_EVEN.get(d),
+                       "flip_break_even": model.flip_break_even() if d >= 128 else None,
                        # the activation-pattern table of the attention behind select4 (random-init weights): share of a
                        # sample's ordered (pa, pb) points per type whose cell holds a tabulated pattern, and the flipped
                        # units per entry left for the exact path (lpformer_amd/patterns.py)

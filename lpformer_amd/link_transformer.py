@@ -1263,12 +1263,15 @@ class LinkTransformer(nn.Module):
         typing adjacency through the walk indexes, feeding the pair-major attention."""
         return self.select_blocks and adj_mask is None and self.use_select_index and self._patterns_pay()
 
-    # Above this many flipped units per entry LEFT for the exact path (entries in flagged cells, counted against the
-    # tabulated patterns their cells name) the pair-major kernel behind select4 is taken to lose to the type-major form,
-    # whose exact path is the rule rather than the exception.  Measured point (cora-like, D = 256: PPR values of 0.01 ...
-    # 0.25 spread over hundreds of patterns, 8 tabulated): 3.0 left of 15.3 -- attention 96.6 us + selection 13.5 against
-    # 100.1 + 34.2 for select3 + the type-major kernel; counted against the pattern of (0, 0) it was 9.8 left and 168 us
-    PT_EXACT_MAX = 4.0
+    # Flipped units per entry LEFT for the exact path (entries in flagged cells, counted against the tabulated patterns
+    # their cells name) above which the pair-major kernel behind select4 would be taken to lose to the type-major form, whose
+    # exact path is the rule rather than the exception.  Round 6 measured the two forms over a sweep of PE weights
+    # (tools/pt_breakeven.py, profiles/r06_pt_breakeven_d128.txt / _d256.txt; both now behind lpf_select4): at D = 128 the
+    # table form is ahead at 0.0 / 0.27 / 0.62 / 5.4 / 11.6 / 12.1 units left (110 / 151 / 193 / 496 / 728 / 777 us for
+    # selection + attention against 141 / 246 / 348 / 653 / 1,002 / 826) and 9 % behind at ONE point (8.1 left: 568 against
+    # 517); at D = 256 it is ahead at every point (3.0 ... 43 left).  Far up there both lose to the matrix-core kernel
+    # anyway (`attention_kernel`).  So the gate is open by default; the mechanism stays for callers and tests.
+    PT_EXACT_MAX = float("inf")
 
     def _patterns_pay(self) -> bool:
         """False when the activation-pattern table covers too little of this model's entries (``PT_EXACT_MAX``): the hot
@@ -1578,6 +1581,17 @@ class LinkTransformer(nn.Module):
     # of units of the PE hidden layer that leave the activation pattern of (0, 0), csrc/pair_fused.hip does the whole
     # D x D product whatever the weights are.
     FLIP_BREAK_EVEN = {128: 5.0, 256: 24.0}
+    # ... and of the table form of the activation-pattern kernel behind select4, in units per entry LEFT for its exact path
+    # (tools/pt_breakeven.py, profiles/r06_pt_breakeven_*.txt): at D = 128 its launch takes 68 / 110 / 151 / 454 us at 0 /
+    # 0.27 / 0.62 / 5.4 units left against 165 us for the matrix-core kernel (+ 16 us for the regions its selection then
+    # needs); at D = 256 96 / 132 / 263 us at 3.0 / 6.1 / 21.6 left against 93 (+ 8): the two lines cross at ~0.9 and ~3.4
+    PT_BREAK_EVEN = {128: 0.8, 256: 3.4}
+
+    def flip_break_even(self) -> float:
+        """The threshold `attention_kernel` holds `flips_per_entry()` against: units left for the exact path of the table
+        form where the model runs it, all flipped units otherwise."""
+        table = self.PT_BREAK_EVEN if self._uses_select4() else self.FLIP_BREAK_EVEN
+        return table.get(self.dim, 6.0)
 
     @_on_device
     def _entry_sample(self, n_pairs: int = 4096, seed: int = 0):
@@ -1728,7 +1742,7 @@ class LinkTransformer(nn.Module):
                 return last[1]
             if self.training:
                 return "flip"
-            choice = "flip" if self.flips_per_entry() <= self.FLIP_BREAK_EVEN.get(self.dim, 6.0) else "mfma"
+            choice = "flip" if self.flips_per_entry() <= self.flip_break_even() else "mfma"
             self._auto_choice = (self._folded[0], choice, self._refolds)
             return choice
         return self.attention_impl

@@ -728,8 +728,9 @@ def test_query_table_follows_an_in_place_update_of_lin_l(name, scale):
 
 
 def test_models_the_pattern_table_covers_badly_keep_the_type_major_path():
-    """``_patterns_pay``: above ``PT_EXACT_MAX`` flipped units per entry left for the exact path the hot path goes back to
-    select3 + the type-major attention kernel -- the same scores (within the bar of two kernel forms), checked on the same
+    """``_patterns_pay``: above ``PT_EXACT_MAX`` flipped units per entry left for the exact path (open by default since
+    round 6: the table form measured ahead almost everywhere) the hot path goes back to the type-major attention kernel
+    behind lpf_select4 + lpf_select4_regions -- the same scores (within the bar of two kernel forms), checked on the same
     model by moving the threshold."""
     cfg, n, ei, w, x, data, args, model, score, batch = _setup("collab", scale=0.1, bs=3000)
     model.attention_impl = "flip"

@@ -166,12 +166,12 @@ def test_auto_attention_choice_follows_the_weights(dim):
                         (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), P, dict(cfg, pred_layers=2))
         flips = model.flips_per_entry()
         chosen.append((model.attention_kernel(), flips))
-        assert (flips <= model.FLIP_BREAK_EVEN[dim]) == (chosen[-1][0] == "flip")
+        assert (flips <= model.flip_break_even()) == (chosen[-1][0] == "flip")
         lg = model.score_pairs(torch.from_numpy(batch).to(DEV), model.propagate(), score, logits=True)
         assert model.check_selection()
         assert np.abs(lg.cpu().numpy() - ref["logit"]).max() <= TOL * max(1.0, float(np.abs(ref["logit"]).max()))
     assert [c[0] for c in chosen] == ["flip", "mfma"], chosen
-    assert chosen[0][1] < model.FLIP_BREAK_EVEN[dim] < chosen[1][1], chosen
+    assert chosen[0][1] < model.flip_break_even() < chosen[1][1], chosen
     # a loop that alternates optimiser steps with scoring does not pay the estimate (a selection + host reads) per step:
     # with the default spacing the last choice stands until enough parameter versions have gone by, and training never asks
     model.flip_recheck_every = 16

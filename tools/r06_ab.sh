@@ -5,8 +5,8 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 BARGS="--gpus 1 --steps 20 --warmup 5 --weights random --no-cpu-baseline --no-bf16 --rows on ${BENCH_ARGS:-}"
 while IFS= read -r ex; do
-  touch lpformer_amd/csrc/pair_rows.hip lpformer_amd/csrc/tail_chain.hip
-  make -C lpformer_amd/csrc EXTRA="$ex" > gpurun_out/ab_build.log 2>&1 || { echo "[$ex] build failed"; tail -5 gpurun_out/ab_build.log; continue; }
+  for f in ${TOUCH:-pair_rows tail_chain}; do touch lpformer_amd/csrc/$f.hip; done
+  make -C lpformer_amd/csrc -j8 EXTRA="$ex" > gpurun_out/ab_build.log 2>&1 || { echo "[$ex] build failed"; tail -5 gpurun_out/ab_build.log; continue; }
   for i in 1 2; do
     python3 bench.py $BARGS > gpurun_out/ab_bench.log 2>&1
     echo "[$ex] $(tail -1 gpurun_out/ab_bench.log | python3 -c "
@@ -17,5 +17,5 @@ print(d['value'], d['ms_per_step'], d.get('ms_per_step_repeats'), c['launch'][:1
   done
   [ -n "${SERIAL:-}" ] && echo "[$ex] serial: $(timeout 300 python3 tools/fused_variants.py 2>&1 | tail -1 | cut -c1-330)"
 done <<< "${VARIANTS:-}"
-touch lpformer_amd/csrc/pair_rows.hip lpformer_amd/csrc/tail_chain.hip
-make -C lpformer_amd/csrc > /dev/null 2>&1
+for f in ${TOUCH:-pair_rows tail_chain}; do touch lpformer_amd/csrc/$f.hip; done
+make -C lpformer_amd/csrc -j8 > /dev/null 2>&1
