@@ -25,7 +25,11 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DC_GROUPS = 4;                 // 16-sample groups per workgroup
+#ifndef LPF_DC_GROUPS   /* (tuning aid: 16-sample groups per workgroup.  2 is valid where a weight stage -- padded to 512
+                          float4 by fold.pack_dense -- is a whole number of 256-thread passes: D >= 128) */
+#define LPF_DC_GROUPS 4
+#endif
+constexpr int DC_GROUPS = LPF_DC_GROUPS;     // 16-sample groups per workgroup
 constexpr int DC_WAVES = 2 * DC_GROUPS;      // wavefronts per workgroup (a pair per group)
 constexpr int DC_THREADS = 64 * DC_WAVES;
 
