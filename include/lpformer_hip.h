@@ -34,7 +34,7 @@ extern "C" {
 #define LPF_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see lpf_last_hip_error)  */
 #define LPF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                            */
 
-#define LPF_ABI_VERSION 8
+#define LPF_ABI_VERSION 9
 
 /* GEMM / row-wise epilogue flags */
 #define LPF_FLAG_RELU 1u
@@ -90,6 +90,16 @@ int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order
                             const float *ln_b, const float *residual, int64_t ldr, const float *ln2_g,
                             const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
                             float *pre_out, int64_t ldpre, void *stream);
+/* The layer as the TRAINING forward and backward launch it (lpformer_amd/train.py GcnFusedFn; reference: the autograd
+ * graph of GCNConv + LayerNorm + ReLU, src/models/other_models.py:61-76): no residual, no second LayerNorm, and one more
+ * optional output -- agg_out (float[n][ldagg]) receives the AGGREGATED rows sum_e w_e H[col_e] the product is taken of,
+ * what the weight gradient dW = dU^T agg needs.  The backward launches it once more over the transposed graph with the
+ * transposed weight image and no epilogue: dX = (A^T dU) W. */
+int lpf_gcn_layer_fused_train_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
+                                  const int64_t *rowptr, const int32_t *col, const float *w, const float *H, int64_t ldh,
+                                  const float *w_packed, float *out, int64_t ldo, const float *bias, const float *ln_g,
+                                  const float *ln_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
+                                  float *pre_out, int64_t ldpre, float *agg_out, int64_t ldagg, void *stream);
 /* The same layer gathering from a bf16 table (the bf16-table encoder mode; D = 64 or 128).  H_bf16p: uint16 rows, ldh in
  * elements (a multiple of 8), in the PERMUTED order  element 32 i + 8 q + 4 h + u = feature 16 (2 i + h) + 4 q + u
  * (i < D/32, q < 4, h < 2, u < 4) -- a lane's 16-byte load then holds two whole 16-feature k-groups.  out receives the

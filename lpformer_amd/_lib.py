@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "liblpformer_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "liblpformer_host.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 FLAG_RELU = 1
 SELECT_ERR_NODE_RANGE, SELECT_ERR_ITEM_CAP, SELECT_ERR_ENTRY_CAP = 1, 2, 4
 ROWS_PERM_LB_WORDS = 1025      # LPF_ROWS_PERM_LB_WORDS (include/lpformer_hip.h)
@@ -39,6 +39,8 @@ HIP_PROTOTYPES = {
                                 vp, vp, i64, vp],
     "lpf_spmm_row_parts_f32": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
     "lpf_spmm_row_parts_bf16p": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
+    "lpf_gcn_layer_fused_train_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, u32, vp, vp, vp, i64,
+                                      vp, i64, vp],
     "lpf_gcn_layer_fused_bf16": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,
                                  vp, vp, i64, vp],
     "lpf_spmm_csr_bf16": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],

@@ -52,6 +52,7 @@ struct GcnFusedArgs {
     const float *t_parts;        // [n_slices][D]: the slices' sums
     float *pre; int64_t ldpre;   // optional: the pre-normalisation rows (product + bias), for a LayerNorm backward
     uint16_t *out_b; int64_t ldob;   // optional (HB): the result rows as permuted bf16 (the next layer's table)
+    float *agg; int64_t ldagg;   // optional: the AGGREGATED rows (sum_e w_e H[col_e], before the product), for dW = dU^T agg
 };
 
 constexpr int GF_THREADS = 512;   // threads of a workgroup
@@ -270,6 +271,15 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
             gather(std::false_type{});
         }
 
+        const int64_t orow = row - A.row_base;
+        if constexpr (!HB) {
+            if (A.agg && live) {     // (the training forward: the weight gradient of the layer is dU^T agg)
+                float *gp = A.agg + orow * A.ldagg + 4 * q;
+#pragma unroll
+                for (int g = 0; g < NT; ++g) *reinterpret_cast<f32x4 *>(gp + 16 * g) = acc[g];
+            }
+        }
+
         // out^T tile = W . acc: NT output tiles x NT k-groups x 4 MFMAs
         f32x4 y[NT];
 #pragma unroll
@@ -303,7 +313,6 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
 #pragma unroll
             for (int c = 0; c < NT; ++c) y[c] += *reinterpret_cast<const f32x4 *>(A.bias + 16 * c + 4 * q);
         }
-        const int64_t orow = row - A.row_base;
         if (A.pre && live) {
             float *pp = A.pre + orow * A.ldpre + 4 * q;
 #pragma unroll
@@ -355,7 +364,7 @@ int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_
               const int32_t *col, const float *w, const void *H, int64_t ldh, const float *w_packed, float *out,
               int64_t ldo, const float *bias, const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
               const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
-              float *pre_out, int64_t ldpre, void *out_b, int64_t ldob, void *stream) {
+              float *pre_out, int64_t ldpre, void *out_b, int64_t ldob, float *agg_out, int64_t ldagg, void *stream) {
     if (n_tiles == 0) return LPF_OK;
     LPF_REQUIRE(n_tiles > 0 && row_order && rowptr && col && w && H && w_packed && out);
     if (D != 32 && D != 64 && D != 128) return LPF_ERR_UNSUPPORTED;
@@ -365,12 +374,13 @@ int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_
     LPF_REQUIRE((!ln_g) == (!ln_b) && (!ln2_g) == (!ln2_b) && (!hubs) == (!t_parts));
     LPF_REQUIRE(!pre_out || (ldpre >= D && (ldpre & 3) == 0 && lpf_aligned16(pre_out)));
     LPF_REQUIRE(!out_b || (HB && ldob >= D && (ldob & 7) == 0 && lpf_aligned16(out_b)));
+    LPF_REQUIRE(!agg_out || (!HB && ldagg >= D && (ldagg & 3) == 0 && lpf_aligned16(agg_out)));
     LPF_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= D && lpf_aligned16(residual)));
     LPF_REQUIRE((!bias || lpf_aligned16(bias)) && (!ln_g || (lpf_aligned16(ln_g) && lpf_aligned16(ln_b))) &&
                 (!ln2_g || (lpf_aligned16(ln2_g) && lpf_aligned16(ln2_b))) && (!t_parts || lpf_aligned16(t_parts)));
     const GcnFusedArgs a{n_tiles, row_order, row_base, rowptr, col, w, static_cast<const float *>(H), ldh, w_packed, out,
                          ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre,
-                         static_cast<uint16_t *>(out_b), ldob};
+                         static_cast<uint16_t *>(out_b), ldob, agg_out, ldagg};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_cu = lpf_cu_count();
     if (n_cu == 0) return LPF_ERR_NO_DEVICE;
@@ -405,7 +415,18 @@ extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t
                                        const int32_t *hubs, const float *t_parts, float *pre_out, int64_t ldpre,
                                        void *stream) {
     return gf_launch<false>(D, n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
-                            residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre, nullptr, 0, stream);
+                            residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int lpf_gcn_layer_fused_train_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
+                                             const int64_t *rowptr, const int32_t *col, const float *w, const float *H,
+                                             int64_t ldh, const float *w_packed, float *out, int64_t ldo,
+                                             const float *bias, const float *ln_g, const float *ln_b, uint32_t flags,
+                                             const int32_t *hubs, const float *t_parts, float *pre_out, int64_t ldpre,
+                                             float *agg_out, int64_t ldagg, void *stream) {
+    return gf_launch<false>(D, n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
+                            nullptr, 0, nullptr, nullptr, flags, hubs, t_parts, pre_out, ldpre, nullptr, 0, agg_out, ldagg,
+                            stream);
 }
 
 extern "C" int lpf_gcn_layer_fused_bf16(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
@@ -415,5 +436,5 @@ extern "C" int lpf_gcn_layer_fused_bf16(int32_t D, int64_t n_tiles, const int32_
                                         const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *hubs,
                                         const float *t_parts, void *out_bf16p, int64_t ldob, void *stream) {
     return gf_launch<true>(D, n_tiles, row_order, row_base, rowptr, col, w, H_bf16p, ldh, w_packed, out, ldo, bias, ln_g,
-                           ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, nullptr, 0, out_bf16p, ldob, stream);
+                           ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, nullptr, 0, out_bf16p, ldob, nullptr, 0, stream);
 }

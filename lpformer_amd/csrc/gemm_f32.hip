@@ -338,60 +338,114 @@ extern "C" int lpf_gemm_f32_out_bf16(int64_t M, int32_t N, int32_t K, const floa
 // Weight gradient of a Linear layer: dW[N, K] = dY[M, N]^T X[M, K] -- the reduction runs over the M rows (hundreds of
 // thousands in the encoder), the output is one or a few 128 x 128 tiles.  lpf_gemm_f32 on transposed copies gave that
 // single tile to a single workgroup (1.1 ms per call, 3/4 of a training step).  Here the rows are split into chunks,
-// a workgroup computes the partial product of one chunk for one output tile (wave w: output rows [32 w, 32 w + 32) x
-// 128 columns; v_mfma_f32_32x32x2_f32 with k = row of the chunk: lane (i, half) feeds A[i][m = 2 s + half] =
+// a workgroup computes the partial product of one chunk for one output tile (a wavefront: 32 output rows x up to 128
+// columns; v_mfma_f32_32x32x2_f32 with k = row of the chunk: lane (i, half) feeds A[i][m = 2 s + half] =
 // dY[m][n0 + i] and B[m][c0 + i] = X[m][c0 + i], both coalesced 128-byte row pieces straight from global memory),
-// writes it to a partial buffer, and a second kernel adds the partials in chunk order (deterministic).
+// writes it to a partial buffer, and a second kernel adds the partials in order (deterministic).
+//
+// Round 6.  (a) A wavefront keeps P = 4 rounds of eight rows in flight (P register sets, the loop unrolled over them):
+// a round's 20 loads are issued three rounds of MFMAs (3 x 1,024 matrix-pipe cycles, twice that with the SIMD's other
+// wavefront) before they are awaited.  With the loads issued and awaited inside the round (rounds 4-5) a workgroup spent
+// most of its life waiting: 125 us per call on the collab-like encoder shape.
+// Every load is unconditional -- rows and columns past the end are clamped to the last valid one and zeroed when
+// used -- so that the wait before a round's MFMAs counts exactly the younger loads it may leave in flight.
+// Measured alone (rocprofv3, collab-like encoder shape M = 235,868, N = K = 128, tools/r06_tn_isolate.sh): 113 us; the
+// loads alone (-DLPF_TN_NOMFMA) 52 us, the matrix work alone (-DLPF_TN_NOLOAD) 90 us -- 1,856 MFMAs per SIMD at ~92
+// cycles each where the instruction's issue rate is 64: the launch is bound by the fp32 matrix pipe, not by memory.
+// (b) Narrow outputs: with N <= 64 (<= 32) the workgroup's four wavefronts form G = 2 (4) groups that take every G-th
+// round of the chunk and write partials of their own; K <= 64 instantiates two column tiles instead of four.  (Before:
+// wavefronts 2, 3 and column tiles 2, 3 multiplied zeros -- 296 us per call on the ppa-like encoder, D = 64.)
 namespace {
 
+__host__ static inline int tn_groups(int N) { return N <= 32 ? 4 : (N <= 64 ? 2 : 1); }
+
 // rows of a chunk: about 512 chunks per output tile column (two workgroups per CU), at least 64 rows each
-__host__ static inline int64_t tn_chunks(int64_t M) {
+__host__ static inline int64_t tn_chunk_rows(int64_t M) {
     int64_t rows = (M + 511) / 512;
     if (rows < 64) rows = 64;
-    rows = (rows + 7) & ~7ll;  // whole rounds of eight rows
+    return (rows + 7) & ~7ll;  // whole rounds of eight rows
+}
+__host__ static inline int64_t tn_chunks(int64_t M) {
+    const int64_t rows = tn_chunk_rows(M);
     return (M + rows - 1) / rows;
 }
 
+template <int KC, int P>
 __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(int64_t M, int N, int K, const float *__restrict__ A,
                                                               int64_t lda, const float *__restrict__ B, int64_t ldb,
-                                                              float *__restrict__ part, int64_t rows_per_chunk) {
+                                                              float *__restrict__ part, int64_t rows_per_chunk, int G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.y * 128 + wave * 32, k0 = blockIdx.z * 128;
+    const int per_group = 4 / G;                           // wavefronts (32-row output tiles) of a group
+    const int tile = wave % per_group, grp = wave / per_group;
+    const int n0 = blockIdx.y * 128 + tile * 32, k0 = blockIdx.z * (32 * KC);
+    if (n0 >= N) return;                                   // (no barrier in this kernel)
     const int64_t m_lo = (int64_t)blockIdx.x * rows_per_chunk;
     int64_t m_hi = m_lo + rows_per_chunk;
     if (m_hi > M) m_hi = M;
-    f32x16 acc[4];
+    f32x16 acc[KC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < KC; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     const bool a_ok = n0 + li < N;
-    bool b_ok[4];
+    bool b_ok[KC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) b_ok[c] = k0 + 32 * c + li < K;
-    const float *ap = A + n0 + li;
-    const float *bp = B + k0 + li;
-    // eight rows (four MFMA steps) per round: their loads are all in flight before the first MFMA of the round
-    for (int64_t m = m_lo; m < m_hi; m += 8) {
-        float av[4], bv[4][4];
+    for (int c = 0; c < KC; ++c) b_ok[c] = k0 + 32 * c + li < K;
+    const float *ap = A + (a_ok ? n0 + li : N - 1);
+    const float *bp[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) bp[c] = B + (b_ok[c] ? k0 + 32 * c + li : K - 1);
+    auto fetch = [&](int64_t m, float (&a)[4], float (&b)[4][KC]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int64_t mm = m + 2 * s + lh;
-            const bool ok = mm < m_hi;
-            av[s] = (ok && a_ok) ? ap[mm * lda] : 0.f;
+            int64_t mm = m + 2 * s + lh;
+            if (mm > M - 1) mm = M - 1;
+#ifdef LPF_TN_NOLOAD      // (timing aid: the matrix work alone)
+            a[s] = __int_as_float(0x3f800000 | ((int)mm & 0xffff));
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bv[s][c] = (ok && b_ok[c]) ? bp[mm * ldb + 32 * c] : 0.f;
+            for (int c = 0; c < KC; ++c) b[s][c] = __int_as_float(0x3f800000 | (((int)mm + c) & 0xffff));
+#else
+            a[s] = ap[mm * lda];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) b[s][c] = bp[c][mm * ldb];
+#endif
         }
+    };
+    auto mma = [&](int64_t m, const float (&a)[4], const float (&b)[4][KC]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s) {
+            const bool ok = m + 2 * s + lh < m_hi;
+            const float x = (ok && a_ok) ? a[s] : 0.f;
+#ifdef LPF_TN_NOMFMA      // (timing aid: the loads alone)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s][c], acc[c], 0, 0, 0);
+            for (int c = 0; c < KC; ++c) acc[c][s] += x * ((ok && b_ok[c]) ? b[s][c] : 0.f);
+#else
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, (ok && b_ok[c]) ? b[s][c] : 0.f, acc[c], 0, 0, 0);
+#endif
+        }
+    };
+    const int64_t step = 8 * G;                            // rows between two rounds of this group
+    float a[P][4], b[P][4][KC];
+#pragma unroll
+    for (int p = 0; p < P; ++p) fetch(m_lo + 8 * grp + step * p, a[p], b[p]);
+    for (int64_t m = m_lo + 8 * grp; m < m_hi; m += step * P) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            mma(m + step * p, a[p], b[p]);                 // (a round past the chunk's end multiplies zeros)
+            // (the scheduler otherwise sinks the loads to just above their use, three rounds later: no prefetch left)
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(m + step * (P + p), a[p], b[p]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    // partial tile: part[chunk][n][k] (n < N, k < K), accumulator register r of lane (li, lh) = row (r&3)+8(r>>2)+4 lh
-    float *pp = part + (int64_t)blockIdx.x * N * K;
+    // partial tile: part[chunk * G + group][n][k] (n < N, k < K), accumulator register r of lane (li, lh) = row
+    // (r & 3) + 8 (r >> 2) + 4 lh
+    float *pp = part + ((int64_t)blockIdx.x * G + grp) * N * K;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < KC; ++c) {
         const int k = k0 + 32 * c + li;
         if (k >= K) continue;
 #pragma unroll
@@ -426,7 +480,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(int64_t elems, int 
 
 extern "C" int64_t lpf_gemm_tn_workspace_floats(int64_t M, int32_t N, int32_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return tn_chunks(M) * (int64_t)N * K;
+    return tn_chunks(M) * tn_groups(N) * (int64_t)N * K;
 }
 
 extern "C" int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B,
@@ -439,15 +493,19 @@ extern "C" int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, 
             if (hipMemsetAsync(C + (int64_t)n * ldc, 0, sizeof(float) * K, s) != hipSuccess) return LPF_ERR_LAUNCH;
         return LPF_OK;
     }
-    int64_t rows = (M + 511) / 512;
-    if (rows < 64) rows = 64;
-    rows = (rows + 7) & ~7ll;  // whole rounds of eight rows (as in tn_chunks)
-    const int64_t chunks = (M + rows - 1) / rows;
-    dim3 grid((unsigned)chunks, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
-    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows);
+    const int64_t rows = tn_chunk_rows(M), chunks = tn_chunks(M);
+    const int G = tn_groups(N);
+    // (K > 64 as two-tile launches of twice the workgroups, four wavefronts per SIMD: 5-10 % slower, measured)
+    if (K <= 64) {
+        dim3 grid((unsigned)chunks, (unsigned)((N + 127) / 128), (unsigned)((K + 63) / 64));
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 4>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows, G);
+    } else {
+        dim3 grid((unsigned)chunks, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 3>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows, G);
+    }
     const int64_t elems = (int64_t)N * K;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s, elems,
-                       (int)chunks, workspace, C, K, ldc);
+                       (int)(chunks * G), workspace, C, K, ldc);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

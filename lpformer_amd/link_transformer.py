@@ -130,12 +130,15 @@ class _PackedSquare:
         self._key = None
         self._w = None
 
-    def get(self, weight: torch.Tensor) -> torch.Tensor:
-        key = (weight.data_ptr(), weight._version, weight.device)
+    def get(self, weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+        """The image of ``weight`` -- or (``transposed``, the training backward: dx = (A^T du) W) of its transpose."""
+        key = (weight.data_ptr(), weight._version, weight.device, transposed)
         if key != self._key:
             # fold.pack_dense(w, 1) with torch operators on the weight's own device: in training the weight changes
             # every step, and a host round trip per layer and step would cost more than the launch it feeds
             w = weight.detach().to(torch.float32)
+            if transposed:
+                w = w.t()
             n, k = w.shape
             nt, ng = ((n + 15) // 16 + 1) & ~1, (k + 15) // 16
             wp = torch.zeros(nt * 16, ng * 16, dtype=torch.float32, device=w.device)
@@ -624,6 +627,7 @@ class LinkTransformer(nn.Module):
         self._chain_q = DenseChain("pair_q")                   # q = lin_l(x_a) + lin_l(x_b)
         self._conv_pads = [_PaddedLinear() for _ in self.node_encoder.gnn_encoder.convs]
         self._conv_packs = [_PackedSquare() for _ in self.node_encoder.gnn_encoder.convs]
+        self._conv_packs_t = [_PackedSquare() for _ in self.node_encoder.gnn_encoder.convs]   # (W^T: train.py)
         self.query_from = "table"              # "table" or "gemm": see _pair_q
         # square GCN layers (in = out = D <= 128) in one launch, aggregate-then-transform (csrc/gcn_fused.hip); False:
         # always lpf_gemm_f32 + lpf_spmm_csr_f32

@@ -264,44 +264,56 @@ class GcnLayerFn(torch.autograd.Function):
         return dt, None, dbias, dg, db
 
 
+def _fused_layer(a: graph.DeviceCSR, x2: torch.Tensor, wp: torch.Tensor, bias=None, ln_w=None, ln_b=None, flags: int = 0,
+                 pre: bool = False, agg: bool = False):
+    """One launch of ``lpf_gcn_layer_fused_train_f32`` over the whole graph ``a``: out = epilogue((a x2) Wp^T) -> (out,
+    pre-norm rows or None, aggregated rows or None).  Hub rows go through their slice sums first (csrc/gcn_fused.hip)."""
+    n, d = a.n, x2.shape[1]
+    lib, st = _lib.hip(), _stream(x2)
+    cache = a.__dict__.setdefault("_fused_order", {})
+    if (0, n) not in cache:
+        cache[(0, n)] = graph.fused_row_order(a.rowptr, 0, n)
+    order, hubs, parts = cache[(0, n)]
+    t_parts = None
+    if hubs is not None:
+        t_parts = torch.empty(parts.shape[0], d, dtype=torch.float32, device=x2.device)
+        check(lib.lpf_spmm_row_parts_f32(d, ptr(parts), parts.shape[0], ptr(a.col), ptr(a.val), ptr(x2), x2.stride(0),
+                                         ptr(t_parts), st), "lpf_spmm_row_parts_f32")
+    out = torch.empty(n, d, dtype=torch.float32, device=x2.device)
+    u = torch.empty(n, d, dtype=torch.float32, device=x2.device) if pre else None
+    h = torch.empty(n, d, dtype=torch.float32, device=x2.device) if agg else None
+    check(lib.lpf_gcn_layer_fused_train_f32(
+        d, order.numel() // 16, ptr(order), 0, ptr(a.rowptr), ptr(a.col), ptr(a.val), ptr(x2), x2.stride(0), ptr(wp),
+        ptr(out), d, ptr(bias), ptr(ln_w), ptr(ln_b), flags, ptr(hubs), ptr(t_parts), ptr(u), d, ptr(h), d, st),
+        "lpf_gcn_layer_fused_train_f32")
+    return out, u, h
+
+
 class GcnFusedFn(torch.autograd.Function):
     """A square GCN layer WITH its Linear, r = ReLU(LN(A_hat (x W^T) + b)), forward in ONE launch
-    (lpf_gcn_layer_fused_f32, csrc/gcn_fused.hip: aggregate, then transform; the pre-norm rows are written beside the
-    result for the backward).  Backward = the chain of LinearFn and GcnLayerFn: fused LayerNorm/ReLU backward (+ bias
-    gradient), aggregation with A_hat^T, dW = dT^T x, dx = dT W."""
+    (lpf_gcn_layer_fused_train_f32, csrc/gcn_fused.hip: aggregate, then transform; the pre-norm rows u and the aggregated
+    rows h = A_hat x are written beside the result for the backward).  Backward: fused LayerNorm/ReLU backward (+ bias
+    gradient) -> du; dW = du^T h (no aggregation: h is the forward's); dx = (A_hat^T du) W -- the SAME launch over the
+    transposed graph with the transposed weight image and no epilogue, and none at all for the first layer, whose input
+    takes no gradient.  (Rounds 4-5: A_hat^T du by lpf_spmm_csr_f32, then two GEMMs, in every layer.)"""
 
     @staticmethod
     def forward(ctx, model, i, x, weight, a_hat, conv_bias, ln_w, ln_b):
-        from . import graph
         x2 = _rows4(x)
-        n, d = a_hat.n, x2.shape[1]
-        lib, st = _lib.hip(), _stream(x2)
-        cache = a_hat.__dict__.setdefault("_fused_order", {})
-        if (0, n) not in cache:
-            cache[(0, n)] = graph.fused_row_order(a_hat.rowptr, 0, n)
-        order, hubs, parts = cache[(0, n)]
-        t_parts = None
-        if hubs is not None:
-            t_parts = torch.empty(parts.shape[0], d, dtype=torch.float32, device=x2.device)
-            check(lib.lpf_spmm_row_parts_f32(d, ptr(parts), parts.shape[0], ptr(a_hat.col), ptr(a_hat.val), ptr(x2),
-                                             x2.stride(0), ptr(t_parts), st), "lpf_spmm_row_parts_f32")
-        r = torch.empty(n, d, dtype=torch.float32, device=x2.device)
-        u = torch.empty(n, d, dtype=torch.float32, device=x2.device)
-        check(lib.lpf_gcn_layer_fused_f32(
-            d, order.numel() // 16, ptr(order), 0, ptr(a_hat.rowptr), ptr(a_hat.col), ptr(a_hat.val), ptr(x2), x2.stride(0),
-            ptr(model._conv_packs[i].get(weight)), ptr(r), d, ptr(conv_bias), ptr(ln_w), ptr(ln_b), None, 0, None, None,
-            _lib.FLAG_RELU, ptr(hubs), ptr(t_parts), ptr(u), d, st), "lpf_gcn_layer_fused_f32")
-        ctx.save_for_backward(x2, weight, u, ln_w, ln_b)
-        ctx.a_hat = a_hat
+        r, u, h = _fused_layer(a_hat, x2, model._conv_packs[i].get(weight), conv_bias, ln_w, ln_b, _lib.FLAG_RELU,
+                               pre=True, agg=True)
+        ctx.save_for_backward(h, weight, u, ln_w, ln_b)
+        ctx.a_hat, ctx.pack_t = a_hat, model._conv_packs_t[i]
         return r
 
     @staticmethod
     def backward(ctx, dr):
-        x2, weight, u, ln_w, ln_b = ctx.saved_tensors
+        h, weight, u, ln_w, ln_b = ctx.saved_tensors
         du, dg, db, dbias = _ln_relu_bwd(u, dr.contiguous(), ln_w, ln_b)
-        dt = _spmm_plain(_transpose_csr(ctx.a_hat), du)
-        dx = _gemm(dt, weight.t().contiguous()).contiguous() if ctx.needs_input_grad[2] else None
-        dw = _gemm_tn(dt, x2)
+        dw = _gemm_tn(du, h)
+        dx = None
+        if ctx.needs_input_grad[2]:
+            dx = _fused_layer(_transpose_csr(ctx.a_hat), _rows4(du), ctx.pack_t.get(weight, transposed=True))[0]
         return None, None, dx, dw, None, dbias, dg, db
 
 

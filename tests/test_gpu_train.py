@@ -271,3 +271,53 @@ def test_overrides_taken_as_differences_train_like_graphs_of_their_own():
         for k in g0:
             scale = max(float(g0[k].abs().max()), 1e-6)
             assert float((g1[k] - g0[k]).abs().max()) / scale <= 1e-5, k
+
+
+@pytest.mark.parametrize("dim", [128, 64, 32])
+def test_fused_layer_backward_matches_fp64_autograd(dim):
+    """``train.GcnFusedFn`` (round 6: forward writes the aggregated rows, backward = LayerNorm/ReLU backward, dW = du^T h,
+    dx = ONE more launch of the fused layer over the transposed graph with the transposed weight image) against torch
+    autograd in fp64 of r = ReLU(LN(A (x W^T) + b)) -- on a DIRECTED weighted graph (A^T != A) with hub rows (> 64
+    entries: the slice-sum path, both directions), isolated rows and a row count that is no multiple of 16."""
+    from lpformer_amd import data as D
+    from lpformer_amd import train
+    n = 5003
+    ei, _ = D.chung_lu_graph(n, 40000, gamma=2.1, seed=2)
+    rng = np.random.default_rng(dim)
+    keep = rng.random(ei.shape[1]) < 0.6                     # drop 40 % of the directed entries: no symmetry left
+    r, c = ei[0][keep], ei[1][keep]
+    v = (rng.random(r.size) + 0.1).astype(np.float32) / 8
+    a = graph.csr_from_coo(r, c, v, n).to_device(DEV)
+    at = train._transpose_csr(a)
+    deg, deg_t = a.rowptr[1:] - a.rowptr[:-1], at.rowptr[1:] - at.rowptr[:-1]
+    assert int(deg.max()) > 64 and int(deg_t.max()) > 64 and int(deg.min()) == 0 and int(deg_t.min()) == 0
+    torch.manual_seed(dim)
+    x = torch.randn(n, dim, device=DEV, requires_grad=True)
+    w = (torch.randn(dim, dim, device=DEV) / dim ** 0.5).requires_grad_()
+    b, g, be = (t.requires_grad_() for t in (0.1 * torch.randn(dim, device=DEV), 1 + 0.1 * torch.randn(dim, device=DEV),
+                                             0.1 * torch.randn(dim, device=DEV)))
+    up = torch.randn(n, dim, device=DEV)
+
+    class _M:      # what GcnFusedFn reads of the model: the two weight-image caches
+        from lpformer_amd.link_transformer import _PackedSquare
+        _conv_packs, _conv_packs_t = [_PackedSquare()], [_PackedSquare()]
+    out = train.GcnFusedFn.apply(_M, 0, x, w, a, b, g, be)
+    (out * up).sum().backward()
+    got = [t.grad.clone() for t in (x, w, b, g, be)]
+    # fp64 reference
+    dense = torch.zeros(n, n, dtype=torch.float64, device=DEV)
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV), deg)
+    dense.index_put_((rows, a.col.long()), a.val.double(), accumulate=True)
+    xs = [t.detach().double().requires_grad_() for t in (x, w, b, g, be)]
+    ref = torch.relu(torch.nn.functional.layer_norm(dense @ (xs[0] @ xs[1].t()) + xs[2], (dim,), xs[3], xs[4]))
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    (ref * up.double()).sum().backward()
+    for name, gt, want in zip(("dx", "dW", "dbias", "dgamma", "dbeta"), got, (t.grad for t in xs)):
+        err, scale = float((gt.double() - want).abs().max()), max(1.0, float(want.abs().max()))
+        assert err <= 1e-4 * scale, (name, err, scale)
+    # the first layer's input takes no gradient: no launch over the transposed graph, the other gradients unchanged
+    x0 = x.detach()
+    for t in (w, b, g, be):
+        t.grad = None
+    (train.GcnFusedFn.apply(_M, 0, x0, w, a, b, g, be) * up).sum().backward()
+    assert torch.equal(w.grad, got[1]) and torch.equal(b.grad, got[2])

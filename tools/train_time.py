@@ -14,9 +14,12 @@ targs = dict(D.train_args_for(cfg), att_drop=0.1, dropout=0.1, gnn_drop=0.1, fea
 torch.manual_seed(0)
 model = lpformer_amd.LinkTransformer(targs, data, device=dev).to(dev)
 score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2, 0.1).to(dev)
-# (LPF_FUSED_ADAM=1: one multi-tensor launch per optimiser step instead of a dozen small kernels per parameter)
-opt = torch.optim.Adam(list(model.parameters()) + list(score.parameters()), lr=1e-3,
-                       fused=bool(os.environ.get("LPF_FUSED_ADAM")))
+# The reference's optimiser as it builds it (train_model.py:98: torch.optim.Adam(params, lr=..), every other argument the
+# default -- on device tensors torch then takes its multi-tensor "foreach" path; rounds 4-5 passed fused=False here,
+# which ALSO switches foreach off: 7 small kernels per parameter and step, 1.7 ms of a 13.9 ms step).
+# LPF_ADAM=fused | single: the one-launch and the per-tensor forms, for comparison.
+_adam = {"fused": dict(fused=True), "single": dict(foreach=False)}.get(os.environ.get("LPF_ADAM", ""), {})
+opt = torch.optim.Adam(list(model.parameters()) + list(score.parameters()), lr=1e-3, **_adam)
 pos = torch.from_numpy(ei[:, ei[0] < ei[1]]).to(dev)
 class _ST:  # torch_sparse.SparseTensor look-alike on the device (what the reference's loop builds per batch)
     def __init__(self, r, c, v, n): self._r, self._c, self._v, self._n = r, c, v, n
