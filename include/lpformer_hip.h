@@ -91,15 +91,21 @@ int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t *row_order
                             const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
                             float *pre_out, int64_t ldpre, void *stream);
 /* The layer as the TRAINING forward and backward launch it (lpformer_amd/train.py GcnFusedFn; reference: the autograd
- * graph of GCNConv + LayerNorm + ReLU, src/models/other_models.py:61-76): no residual, no second LayerNorm, and one more
- * optional output -- agg_out (float[n][ldagg]) receives the AGGREGATED rows sum_e w_e H[col_e] the product is taken of,
- * what the weight gradient dW = dU^T agg needs.  The backward launches it once more over the transposed graph with the
- * transposed weight image and no epilogue: dX = (A^T dU) W. */
+ * graph of GCNConv + LayerNorm + ReLU + dropout + residual, src/models/other_models.py:61-76): no second LayerNorm, and
+ *   agg_out (optional, float[n][ldagg]) receives the AGGREGATED rows sum_e w_e H[col_e] the product is taken of -- what
+ *     the weight gradient dW = dU^T agg needs;
+ *   drop_p > 0: F.dropout behind the ReLU (other_models.py:69), in the kernel -- element (row, feature) is kept and scaled
+ *     by 1 / (1 - drop_p) iff a counter-based hash of (drop_seed, row, feature) passes p (csrc/lpf_common.h
+ *     lpf_drop_bits: no mask tensor; lpf_layernorm_relu_drop_bwd_f32 recomputes it); then residual (optional) is added.
+ * out = residual + dropout(ReLU(LN((A H) W^T + bias))).  The backward launches it once more over the transposed graph
+ * with the transposed weight image, no epilogue, residual = the gradient that arrived through the skip connection:
+ * dX = dOut + (A^T dU) W. */
 int lpf_gcn_layer_fused_train_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
                                   const int64_t *rowptr, const int32_t *col, const float *w, const float *H, int64_t ldh,
                                   const float *w_packed, float *out, int64_t ldo, const float *bias, const float *ln_g,
-                                  const float *ln_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
-                                  float *pre_out, int64_t ldpre, float *agg_out, int64_t ldagg, void *stream);
+                                  const float *ln_b, const float *residual, int64_t ldr, uint32_t flags,
+                                  const int32_t *hubs, const float *t_parts, float *pre_out, int64_t ldpre,
+                                  float *agg_out, int64_t ldagg, float drop_p, uint64_t drop_seed, void *stream);
 /* The same layer gathering from a bf16 table (the bf16-table encoder mode; D = 64 or 128).  H_bf16p: uint16 rows, ldh in
  * elements (a multiple of 8), in the PERMUTED order  element 32 i + 8 q + 4 h + u = feature 16 (2 i + h) + 4 q + u
  * (i < D/32, q < 4, h < 2, u < 4) -- a lane's 16-byte load then holds two whole 16-feature k-groups.  out receives the
@@ -165,6 +171,13 @@ int64_t lpf_layernorm_bwd_workspace_floats(int32_t D);
 int lpf_layernorm_relu_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
                                const float *gamma, const float *beta, float *dx, int64_t lddx, float *dgamma,
                                float *dbeta, float *dxsum, float *workspace, void *stream);
+/* The same backward behind the in-kernel dropout of lpf_gcn_layer_fused_train_f32: the forward was
+ * y = dropout(ReLU(LN(x))) with (drop_p, drop_seed); dy is scaled by 1 / (1 - drop_p) where (row, feature) was kept and
+ * dropped where it was not -- the mask is recomputed from the seed (rows are numbered from 0). */
+int lpf_layernorm_relu_drop_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
+                                    const float *gamma, const float *beta, float drop_p, uint64_t drop_seed, float *dx,
+                                    int64_t lddx, float *dgamma, float *dbeta, float *dxsum, float *workspace,
+                                    void *stream);
 int lpf_layernorm_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy,
                           const float *gamma, float *dx, int64_t lddx, float *dgamma, float *dbeta, float *workspace,
                           void *stream);

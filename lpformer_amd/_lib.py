@@ -18,7 +18,7 @@ SELECT_ERR_NODE_RANGE, SELECT_ERR_ITEM_CAP, SELECT_ERR_ENTRY_CAP = 1, 2, 4
 ROWS_PERM_LB_WORDS = 1025      # LPF_ROWS_PERM_LB_WORDS (include/lpformer_hip.h)
 SELECT4_BLOCK = 64             # LPF_SELECT4_BLOCK
 
-i32, i64, f32, f64, u32, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32, C.c_void_p
+i32, i64, f32, f64, u32, u64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32, C.c_uint64, C.c_void_p
 
 # name -> argument types (every entry point returns int unless listed in _RESTYPE)
 HIP_PROTOTYPES = {
@@ -32,6 +32,7 @@ HIP_PROTOTYPES = {
     "lpf_layernorm_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp],
     "lpf_layernorm_bwd_workspace_floats": [i32],
     "lpf_layernorm_relu_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp],
+    "lpf_layernorm_relu_drop_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, f32, u64, vp, i64, vp, vp, vp, vp, vp],
     "lpf_gemm_tn_f32": [i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp],
     "lpf_gemm_tn_workspace_floats": [i64, i32, i32],
     "lpf_gemm_f32_out_bf16": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
@@ -39,8 +40,8 @@ HIP_PROTOTYPES = {
                                 vp, vp, i64, vp],
     "lpf_spmm_row_parts_f32": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
     "lpf_spmm_row_parts_bf16p": [i32, vp, i64, vp, vp, vp, i64, vp, vp],
-    "lpf_gcn_layer_fused_train_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, u32, vp, vp, vp, i64,
-                                      vp, i64, vp],
+    "lpf_gcn_layer_fused_train_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, u32, vp, vp,
+                                      vp, i64, vp, i64, f32, u64, vp],
     "lpf_gcn_layer_fused_bf16": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,
                                  vp, vp, i64, vp],
     "lpf_spmm_csr_bf16": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp, i64, vp],

@@ -53,6 +53,9 @@ struct GcnFusedArgs {
     float *pre; int64_t ldpre;   // optional: the pre-normalisation rows (product + bias), for a LayerNorm backward
     uint16_t *out_b; int64_t ldob;   // optional (HB): the result rows as permuted bf16 (the next layer's table)
     float *agg; int64_t ldagg;   // optional: the AGGREGATED rows (sum_e w_e H[col_e], before the product), for dW = dU^T agg
+    uint32_t drop_thresh;        // training: dropout behind the ReLU (lpf_common.h lpf_drop_bits; 0 = none)
+    float drop_scale;            // 1 / (1 - p)
+    uint64_t drop_seed;
 };
 
 constexpr int GF_THREADS = 512;   // threads of a workgroup
@@ -101,7 +104,9 @@ __device__ __forceinline__ void gf_layernorm(f32x4 (&y)[NT], const float *g, con
     }
 }
 
-template <int NT, bool HB>
+// TRAIN: the training launches (lpf_gcn_layer_fused_train_f32) -- the aggregated rows written out, dropout behind the
+// ReLU; an instantiation of its own so that the inference kernels keep their registers.
+template <int NT, bool HB, bool TRAIN>
 __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) void gcn_fused_kernel(const GcnFusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) f32x4 gf_lds[];
     f32x4 *const lw = gf_lds;                                       // [NT][GF_STAGE]
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
         }
 
         const int64_t orow = row - A.row_base;
-        if constexpr (!HB) {
+        if constexpr (TRAIN) {
             if (A.agg && live) {     // (the training forward: the weight gradient of the layer is dU^T agg)
                 float *gp = A.agg + orow * A.ldagg + 4 * q;
 #pragma unroll
@@ -325,6 +330,17 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[c][r] = fmaxf(y[c][r], 0.f);
         }
+        if constexpr (TRAIN) {
+            if (A.drop_thresh) {     // (training: F.dropout behind the layer, other_models.py:69; the mask is a function of
+                                     //  (seed, row, feature) that the LayerNorm/ReLU backward recomputes)
+                const uint32_t rk = lpf_drop_row_key(row, A.drop_seed);
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        y[c][r] = lpf_drop_bits(rk, 16 * c + 4 * q + r, A.drop_seed) >= A.drop_thresh ? y[c][r] * A.drop_scale : 0.f;
+            }
+        }
         if (A.residual && live) {
             const float *rp = A.residual + orow * A.ldr + 4 * q;
 #pragma unroll
@@ -359,12 +375,13 @@ __global__ __launch_bounds__(GF_THREADS, GF_THREADS * gf_per_cu<NT>() / 256) voi
 }  // namespace
 
 namespace {
-template <bool HB>
+template <bool HB, bool TRAIN = false>
 int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base, const int64_t *rowptr,
               const int32_t *col, const float *w, const void *H, int64_t ldh, const float *w_packed, float *out,
               int64_t ldo, const float *bias, const float *ln_g, const float *ln_b, const float *residual, int64_t ldr,
               const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *hubs, const float *t_parts,
-              float *pre_out, int64_t ldpre, void *out_b, int64_t ldob, float *agg_out, int64_t ldagg, void *stream) {
+              float *pre_out, int64_t ldpre, void *out_b, int64_t ldob, float *agg_out, int64_t ldagg, float drop_p,
+              uint64_t drop_seed, void *stream) {
     if (n_tiles == 0) return LPF_OK;
     LPF_REQUIRE(n_tiles > 0 && row_order && rowptr && col && w && H && w_packed && out);
     if (D != 32 && D != 64 && D != 128) return LPF_ERR_UNSUPPORTED;
@@ -374,13 +391,15 @@ int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_
     LPF_REQUIRE((!ln_g) == (!ln_b) && (!ln2_g) == (!ln2_b) && (!hubs) == (!t_parts));
     LPF_REQUIRE(!pre_out || (ldpre >= D && (ldpre & 3) == 0 && lpf_aligned16(pre_out)));
     LPF_REQUIRE(!out_b || (HB && ldob >= D && (ldob & 7) == 0 && lpf_aligned16(out_b)));
-    LPF_REQUIRE(!agg_out || (!HB && ldagg >= D && (ldagg & 3) == 0 && lpf_aligned16(agg_out)));
+    LPF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || TRAIN));
+    LPF_REQUIRE(!agg_out || (TRAIN && ldagg >= D && (ldagg & 3) == 0 && lpf_aligned16(agg_out)));
     LPF_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= D && lpf_aligned16(residual)));
     LPF_REQUIRE((!bias || lpf_aligned16(bias)) && (!ln_g || (lpf_aligned16(ln_g) && lpf_aligned16(ln_b))) &&
                 (!ln2_g || (lpf_aligned16(ln2_g) && lpf_aligned16(ln2_b))) && (!t_parts || lpf_aligned16(t_parts)));
     const GcnFusedArgs a{n_tiles, row_order, row_base, rowptr, col, w, static_cast<const float *>(H), ldh, w_packed, out,
                          ldo, bias, ln_g, ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre,
-                         static_cast<uint16_t *>(out_b), ldob, agg_out, ldagg};
+                         static_cast<uint16_t *>(out_b), ldob, agg_out, ldagg, lpf_drop_threshold(drop_p),
+                         1.0f / (1.0f - drop_p), drop_seed};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_cu = lpf_cu_count();
     if (n_cu == 0) return LPF_ERR_NO_DEVICE;
@@ -388,7 +407,7 @@ int gf_launch(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_
     const int64_t want = (n_tiles + GF_THREADS / 64 - 1) / (GF_THREADS / 64);
 #define LPF_GF(NT)                                                                                                  \
     do {                                                                                                            \
-        auto kern = gcn_fused_kernel<NT, HB>;                                                                       \
+        auto kern = gcn_fused_kernel<NT, HB, TRAIN>;                                                                       \
         constexpr size_t lds = (size_t)(NT * GF_STAGE + 1) * sizeof(f32x4);                                         \
         LPF_SET_MAX_LDS(kern, lds);                                                                                 \
         const int64_t cap = (int64_t)gf_per_cu<NT>() * n_cu;                                                       \
@@ -415,18 +434,19 @@ extern "C" int lpf_gcn_layer_fused_f32(int32_t D, int64_t n_tiles, const int32_t
                                        const int32_t *hubs, const float *t_parts, float *pre_out, int64_t ldpre,
                                        void *stream) {
     return gf_launch<false>(D, n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
-                            residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre, nullptr, 0, nullptr, 0, stream);
+                            residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, pre_out, ldpre, nullptr, 0, nullptr, 0, 0.f, 0, stream);
 }
 
 extern "C" int lpf_gcn_layer_fused_train_f32(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
                                              const int64_t *rowptr, const int32_t *col, const float *w, const float *H,
                                              int64_t ldh, const float *w_packed, float *out, int64_t ldo,
-                                             const float *bias, const float *ln_g, const float *ln_b, uint32_t flags,
-                                             const int32_t *hubs, const float *t_parts, float *pre_out, int64_t ldpre,
-                                             float *agg_out, int64_t ldagg, void *stream) {
-    return gf_launch<false>(D, n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
-                            nullptr, 0, nullptr, nullptr, flags, hubs, t_parts, pre_out, ldpre, nullptr, 0, agg_out, ldagg,
-                            stream);
+                                             const float *bias, const float *ln_g, const float *ln_b,
+                                             const float *residual, int64_t ldr, uint32_t flags, const int32_t *hubs,
+                                             const float *t_parts, float *pre_out, int64_t ldpre, float *agg_out,
+                                             int64_t ldagg, float drop_p, uint64_t drop_seed, void *stream) {
+    return gf_launch<false, true>(D, n_tiles, row_order, row_base, rowptr, col, w, H, ldh, w_packed, out, ldo, bias, ln_g, ln_b,
+                            residual, ldr, nullptr, nullptr, flags, hubs, t_parts, pre_out, ldpre, nullptr, 0, agg_out,
+                            ldagg, drop_p, drop_seed, stream);
 }
 
 extern "C" int lpf_gcn_layer_fused_bf16(int32_t D, int64_t n_tiles, const int32_t *row_order, int64_t row_base,
@@ -436,5 +456,5 @@ extern "C" int lpf_gcn_layer_fused_bf16(int32_t D, int64_t n_tiles, const int32_
                                         const float *ln2_g, const float *ln2_b, uint32_t flags, const int32_t *hubs,
                                         const float *t_parts, void *out_bf16p, int64_t ldob, void *stream) {
     return gf_launch<true>(D, n_tiles, row_order, row_base, rowptr, col, w, H_bf16p, ldh, w_packed, out, ldo, bias, ln_g,
-                           ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, nullptr, 0, out_bf16p, ldob, nullptr, 0, stream);
+                           ln_b, residual, ldr, ln2_g, ln2_b, flags, hubs, t_parts, nullptr, 0, out_bf16p, ldob, nullptr, 0, 0.f, 0, stream);
 }

@@ -81,3 +81,24 @@ __device__ __forceinline__ uint16_t lpf_f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float lpf_bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// Dropout inside a kernel (the training forward of the fused GCN layer and its LayerNorm/ReLU backward): element (row,
+// col) of a launch with 64-bit seed s is KEPT iff lpf_drop_bits(row key, col, s) >= threshold, threshold =
+// lpf_drop_threshold(p) -- a counter-based hash (two lowbias32 rounds), so the backward recomputes the forward's mask
+// from (seed, row, col) and no mask tensor exists.  Reference: F.dropout(x, p, training=True) behind every GCN layer
+// (src/models/other_models.py:69): Bernoulli(1 - p) keeps scaled by 1 / (1 - p); which elements are kept is random
+// there as here (parity is distributional: tests/test_gpu_train.py), p is met to 2^-32.
+__host__ __device__ __forceinline__ uint32_t lpf_mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t lpf_drop_row_key(int64_t row, uint64_t seed) {
+    return lpf_mix32((uint32_t)row * 0x9E3779B1u + (uint32_t)seed) ^ (uint32_t)((uint64_t)row >> 32);
+}
+__host__ __device__ __forceinline__ uint32_t lpf_drop_bits(uint32_t row_key, int col, uint64_t seed) {
+    return lpf_mix32(row_key + (uint32_t)col * 0x85EBCA77u + (uint32_t)(seed >> 32));
+}
+static inline uint32_t lpf_drop_threshold(float p) {   // keep iff bits >= threshold: P(drop) = threshold / 2^32
+    const double t = (double)p * 4294967296.0;
+    return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+}

@@ -161,12 +161,17 @@ namespace {
 // RELU variant (lpf_layernorm_relu_bwd_f32): the forward was y = ReLU(LN(x)), so dy only counts where gamma xhat + beta
 // > 0, and a third partial carries the column sums of dx -- the gradient of the bias that was added in front of the
 // LayerNorm (the GCN layer's `conv.bias`, other_models.py:66-69).
-template <int G, bool RELU>
+// DROP (lpf_layernorm_relu_drop_bwd_f32): the forward was y = dropout(ReLU(LN(x))) with the in-kernel mask of the fused
+// GCN layer (csrc/gcn_fused.hip, lpf_common.h lpf_drop_bits): dy is scaled by 1 / (1 - p) where (row, feature) was
+// kept and dropped where it was not, recomputed from the seed.
+template <int G, bool RELU, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, const float *__restrict__ x, int64_t ldx,
                                                             const float *__restrict__ dy, int64_t ldy,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float *__restrict__ dx,
-                                                            int64_t lddx, float *__restrict__ part) {
+                                                            int64_t lddx, float *__restrict__ part,
+                                                            uint32_t drop_thresh = 0, float drop_scale = 1.f,
+                                                            uint64_t drop_seed = 0) {
     constexpr int NG = 256 / G, NP = RELU ? 3 : 2;
     __shared__ float4 red[NP][NG][G];
     const int tid = threadIdx.x, grp = tid / G, lig = tid % G;
@@ -184,6 +189,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
         if (live) {
             xv = *reinterpret_cast<const float4 *>(x + r * ldx + off);
             dv = *reinterpret_cast<const float4 *>(dy + r * ldy + off);
+            if (DROP) {
+                const uint32_t rk = lpf_drop_row_key(r, drop_seed);
+                dv.x = lpf_drop_bits(rk, off + 0, drop_seed) >= drop_thresh ? dv.x * drop_scale : 0.f;
+                dv.y = lpf_drop_bits(rk, off + 1, drop_seed) >= drop_thresh ? dv.y * drop_scale : 0.f;
+                dv.z = lpf_drop_bits(rk, off + 2, drop_seed) >= drop_thresh ? dv.z * drop_scale : 0.f;
+                dv.w = lpf_drop_bits(rk, off + 3, drop_seed) >= drop_thresh ? dv.w * drop_scale : 0.f;
+            }
         }
         const float mean = lpf_group_sum<G>(xv.x + xv.y + xv.z + xv.w) / (float)D;
         float4 c = make_float4(xv.x - mean, xv.y - mean, xv.z - mean, xv.w - mean);
@@ -259,13 +271,14 @@ constexpr int LN_BWD_BLOCKS = 1024;
 extern "C" int64_t lpf_layernorm_bwd_workspace_floats(int32_t D) { return (int64_t)LN_BWD_BLOCKS * 3 * (D > 0 ? D : 0); }
 
 namespace {
-template <bool RELU>
+template <bool RELU, bool DROP = false>
 int ln_bwd_launch(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy, int64_t ldy, const float *gamma,
                   const float *beta, float *dx, int64_t lddx, float *dgamma, float *dbeta, float *dxsum,
-                  float *workspace, void *stream) {
+                  float *workspace, void *stream, float drop_p = 0.f, uint64_t drop_seed = 0) {
     if (D <= 0 || (D & 3) || D > 256) return LPF_ERR_UNSUPPORTED;
     LPF_REQUIRE(M >= 0 && gamma && dgamma && dbeta && workspace && lpf_aligned16(gamma) && lpf_aligned16(workspace) &&
                 (!RELU || (beta && dxsum && lpf_aligned16(beta))));
+    LPF_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
     hipStream_t s = static_cast<hipStream_t>(stream);
     int blocks = 0;
     if (M > 0) {
@@ -274,8 +287,9 @@ int ln_bwd_launch(int64_t M, int32_t D, const float *x, int64_t ldx, const float
         const int G = D <= 32 ? 8 : (D <= 64 ? 16 : (D <= 128 ? 32 : 64));
         const int64_t want = (M + 256 / G - 1) / (256 / G);
         blocks = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
-#define LPF_LNB(GG) hipLaunchKernelGGL((layernorm_bwd_kernel<GG, RELU>), dim3(blocks), dim3(256), 0, s, M, D, x, ldx, dy, \
-                                       ldy, gamma, beta, dx, lddx, workspace)
+#define LPF_LNB(GG) hipLaunchKernelGGL((layernorm_bwd_kernel<GG, RELU, DROP>), dim3(blocks), dim3(256), 0, s, M, D, x, ldx, \
+                                       dy, ldy, gamma, beta, dx, lddx, workspace, lpf_drop_threshold(drop_p),             \
+                                       1.0f / (1.0f - drop_p), drop_seed)
         switch (G) {
             case 8: LPF_LNB(8); break;
             case 16: LPF_LNB(16); break;
@@ -302,4 +316,14 @@ extern "C" int lpf_layernorm_relu_bwd_f32(int64_t M, int32_t D, const float *x, 
                                           const float *gamma, const float *beta, float *dx, int64_t lddx, float *dgamma,
                                           float *dbeta, float *dxsum, float *workspace, void *stream) {
     return ln_bwd_launch<true>(M, D, x, ldx, dy, ldy, gamma, beta, dx, lddx, dgamma, dbeta, dxsum, workspace, stream);
+}
+
+extern "C" int lpf_layernorm_relu_drop_bwd_f32(int64_t M, int32_t D, const float *x, int64_t ldx, const float *dy,
+                                               int64_t ldy, const float *gamma, const float *beta, float drop_p,
+                                               uint64_t drop_seed, float *dx, int64_t lddx, float *dgamma, float *dbeta,
+                                               float *dxsum, float *workspace, void *stream) {
+    if (drop_p == 0.f)
+        return ln_bwd_launch<true>(M, D, x, ldx, dy, ldy, gamma, beta, dx, lddx, dgamma, dbeta, dxsum, workspace, stream);
+    return ln_bwd_launch<true, true>(M, D, x, ldx, dy, ldy, gamma, beta, dx, lddx, dgamma, dbeta, dxsum, workspace, stream,
+                                     drop_p, drop_seed);
 }

@@ -224,8 +224,9 @@ class LnReluFn(torch.autograd.Function):
         return dx.reshape(ctx.shape), dg, db
 
 
-def _ln_relu_bwd(x2, dy2, weight, bias):
-    """(dx, dgamma, dbeta, column sums of dx) of y = ReLU(LN(x)) through lpf_layernorm_relu_bwd_f32."""
+def _ln_relu_bwd(x2, dy2, weight, bias, drop_p: float = 0.0, drop_seed: int = 0):
+    """(dx, dgamma, dbeta, column sums of dx) of y = ReLU(LN(x)) -- or, ``drop_p`` > 0, of y = dropout(ReLU(LN(x))) with
+    the in-kernel mask of the fused GCN layer -- through lpf_layernorm_relu_drop_bwd_f32."""
     d = x2.shape[1]
     dev = x2.device
     dx = torch.empty_like(x2)
@@ -234,9 +235,9 @@ def _ln_relu_bwd(x2, dy2, weight, bias):
     dxs = torch.empty(d, dtype=torch.float32, device=dev)
     lib = _lib.hip()
     ws = torch.empty(int(lib.lpf_layernorm_bwd_workspace_floats(d)), dtype=torch.float32, device=dev)
-    check(lib.lpf_layernorm_relu_bwd_f32(x2.shape[0], d, ptr(x2), x2.stride(0), ptr(dy2), dy2.stride(0), ptr(weight),
-                                         ptr(bias), ptr(dx), dx.stride(0), ptr(dg), ptr(db), ptr(dxs), ptr(ws),
-                                         _stream(x2)), "lpf_layernorm_relu_bwd_f32")
+    check(lib.lpf_layernorm_relu_drop_bwd_f32(x2.shape[0], d, ptr(x2), x2.stride(0), ptr(dy2), dy2.stride(0), ptr(weight),
+                                              ptr(bias), drop_p, drop_seed, ptr(dx), dx.stride(0), ptr(dg), ptr(db),
+                                              ptr(dxs), ptr(ws), _stream(x2)), "lpf_layernorm_relu_drop_bwd_f32")
     return dx, dg, db, dxs
 
 
@@ -265,9 +266,10 @@ class GcnLayerFn(torch.autograd.Function):
 
 
 def _fused_layer(a: graph.DeviceCSR, x2: torch.Tensor, wp: torch.Tensor, bias=None, ln_w=None, ln_b=None, flags: int = 0,
-                 pre: bool = False, agg: bool = False):
-    """One launch of ``lpf_gcn_layer_fused_train_f32`` over the whole graph ``a``: out = epilogue((a x2) Wp^T) -> (out,
-    pre-norm rows or None, aggregated rows or None).  Hub rows go through their slice sums first (csrc/gcn_fused.hip)."""
+                 pre: bool = False, agg: bool = False, residual=None, drop_p: float = 0.0, drop_seed: int = 0):
+    """One launch of ``lpf_gcn_layer_fused_train_f32`` over the whole graph ``a``:
+    out = residual + dropout(epilogue((a x2) Wp^T)) -> (out, pre-norm rows or None, aggregated rows or None).  Hub rows go
+    through their slice sums first (csrc/gcn_fused.hip)."""
     n, d = a.n, x2.shape[1]
     lib, st = _lib.hip(), _stream(x2)
     cache = a.__dict__.setdefault("_fused_order", {})
@@ -284,37 +286,77 @@ def _fused_layer(a: graph.DeviceCSR, x2: torch.Tensor, wp: torch.Tensor, bias=No
     h = torch.empty(n, d, dtype=torch.float32, device=x2.device) if agg else None
     check(lib.lpf_gcn_layer_fused_train_f32(
         d, order.numel() // 16, ptr(order), 0, ptr(a.rowptr), ptr(a.col), ptr(a.val), ptr(x2), x2.stride(0), ptr(wp),
-        ptr(out), d, ptr(bias), ptr(ln_w), ptr(ln_b), flags, ptr(hubs), ptr(t_parts), ptr(u), d, ptr(h), d, st),
-        "lpf_gcn_layer_fused_train_f32")
+        ptr(out), d, ptr(bias), ptr(ln_w), ptr(ln_b), ptr(residual), 0 if residual is None else residual.stride(0), flags,
+        ptr(hubs), ptr(t_parts), ptr(u), d, ptr(h), d, drop_p, drop_seed, st), "lpf_gcn_layer_fused_train_f32")
     return out, u, h
 
 
+_seed_state = [None, 0]
+
+
+def _next_drop_seed() -> int:
+    """A fresh 64-bit seed for an in-kernel dropout mask: a function of torch's seed (``torch.manual_seed`` makes a run
+    repeatable) and of how many masks were drawn under it -- no device generator, no synchronisation."""
+    base = torch.initial_seed()
+    if _seed_state[0] != base:
+        _seed_state[0], _seed_state[1] = base, 0
+    _seed_state[1] += 1
+    z = (base * 0x9E3779B97F4A7C15 + _seed_state[1] * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF    # splitmix64 finaliser
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def drop_keep_mask(seed: int, p: float, n: int, d: int, device) -> torch.Tensor:
+    """The keep mask [n, d] (bool) of the in-kernel dropout for (seed, p): csrc/lpf_common.h ``lpf_drop_bits`` restated
+    with torch integer arithmetic (test infrastructure and debugging; the kernels never read a mask)."""
+    m32 = 0xFFFFFFFF
+
+    def mix(h):
+        h = h ^ (h >> 16); h = (h * 0x7feb352d) & m32
+        h = h ^ (h >> 15); h = (h * 0x846ca68b) & m32
+        return h ^ (h >> 16)
+    rows = torch.arange(n, dtype=torch.int64, device=device)
+    cols = torch.arange(d, dtype=torch.int64, device=device)
+    rk = mix(((rows & m32) * 0x9E3779B1 + (seed & m32)) & m32) ^ (rows >> 32)
+    bits = mix((rk[:, None] + ((cols * 0x85EBCA77) & m32)[None, :] + (seed >> 32)) & m32)
+    t = p * 4294967296.0
+    thresh = 0 if t <= 0 else (4294967295 if t >= 4294967295.0 else int(t))
+    return bits >= thresh
+
+
 class GcnFusedFn(torch.autograd.Function):
-    """A square GCN layer WITH its Linear, r = ReLU(LN(A_hat (x W^T) + b)), forward in ONE launch
-    (lpf_gcn_layer_fused_train_f32, csrc/gcn_fused.hip: aggregate, then transform; the pre-norm rows u and the aggregated
-    rows h = A_hat x are written beside the result for the backward).  Backward: fused LayerNorm/ReLU backward (+ bias
-    gradient) -> du; dW = du^T h (no aggregation: h is the forward's); dx = (A_hat^T du) W -- the SAME launch over the
-    transposed graph with the transposed weight image and no epilogue, and none at all for the first layer, whose input
-    takes no gradient.  (Rounds 4-5: A_hat^T du by lpf_spmm_csr_f32, then two GEMMs, in every layer.)"""
+    """A square GCN layer WITH its Linear, dropout and skip connection,
+        y = [x +] dropout(ReLU(LN(A_hat (x W^T) + b)), p)            (other_models.py:66-75)
+    forward in ONE launch (lpf_gcn_layer_fused_train_f32, csrc/gcn_fused.hip: aggregate, then transform; the pre-norm
+    rows u and the aggregated rows h = A_hat x are written beside the result for the backward; the dropout mask is a hash
+    of (seed, row, feature), never stored).  Backward: fused dropout/ReLU/LayerNorm backward (+ bias gradient) -> du;
+    dW = du^T h (no aggregation: h is the forward's); dx = [dy +] (A_hat^T du) W -- the SAME launch over the transposed
+    graph with the transposed weight image, the skip connection's gradient as its residual, and no launch at all for
+    the first layer, whose input takes no gradient.  (Rounds 4-5: A_hat^T du by lpf_spmm_csr_f32, two GEMMs, dropout,
+    its backward and both additions as torch kernels, in every layer.)"""
 
     @staticmethod
-    def forward(ctx, model, i, x, weight, a_hat, conv_bias, ln_w, ln_b):
+    def forward(ctx, model, i, x, weight, a_hat, conv_bias, ln_w, ln_b, drop_p=0.0, skip=False):
         x2 = _rows4(x)
-        r, u, h = _fused_layer(a_hat, x2, model._conv_packs[i].get(weight), conv_bias, ln_w, ln_b, _lib.FLAG_RELU,
-                               pre=True, agg=True)
+        seed = _next_drop_seed() if drop_p > 0 else 0
+        y, u, h = _fused_layer(a_hat, x2, model._conv_packs[i].get(weight), conv_bias, ln_w, ln_b, _lib.FLAG_RELU,
+                               pre=True, agg=True, residual=x2 if skip else None, drop_p=drop_p, drop_seed=seed)
         ctx.save_for_backward(h, weight, u, ln_w, ln_b)
-        ctx.a_hat, ctx.pack_t = a_hat, model._conv_packs_t[i]
-        return r
+        ctx.a_hat, ctx.pack_t, ctx.drop, ctx.skip = a_hat, model._conv_packs_t[i], (drop_p, seed), skip
+        return y
 
     @staticmethod
-    def backward(ctx, dr):
+    def backward(ctx, dy):
         h, weight, u, ln_w, ln_b = ctx.saved_tensors
-        du, dg, db, dbias = _ln_relu_bwd(u, dr.contiguous(), ln_w, ln_b)
+        dy = _rows4(dy)
+        du, dg, db, dbias = _ln_relu_bwd(u, dy, ln_w, ln_b, *ctx.drop)
         dw = _gemm_tn(du, h)
         dx = None
         if ctx.needs_input_grad[2]:
-            dx = _fused_layer(_transpose_csr(ctx.a_hat), _rows4(du), ctx.pack_t.get(weight, transposed=True))[0]
-        return None, None, dx, dw, None, dbias, dg, db
+            dx = _fused_layer(_transpose_csr(ctx.a_hat), du, ctx.pack_t.get(weight, transposed=True),
+                              residual=dy if ctx.skip else None)[0]
+        return None, None, dx, dw, None, dbias, dg, db, None, None
 
 
 def layer_norm(x, weight, bias):
@@ -376,9 +418,10 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     for i, conv in enumerate(enc.convs):
         if enc.lns is not None and enc.relu and model._fusable(i, x.shape[1]):
             # a square layer: Linear + aggregation + bias + LayerNorm + ReLU forward in one launch
-            xi = GcnFusedFn.apply(model, i, x, conv.lin.weight, a_hat, conv.bias, enc.lns[i].weight, enc.lns[i].bias)
-            xi = F.dropout(xi, p=enc.dropout, training=True)
-            x = x + xi if (enc.residual and x.shape[-1] == xi.shape[-1]) else xi
+            # (a square layer is as wide as its input: the skip connection of other_models.py:72-75 applies whenever
+            # ``residual`` is set)
+            x = GcnFusedFn.apply(model, i, x, conv.lin.weight, a_hat, conv.bias, enc.lns[i].weight, enc.lns[i].bias,
+                                 float(enc.dropout), bool(enc.residual))
             continue
         t = linear(x, conv.lin.weight, None)
         if enc.lns is not None and enc.relu and t.shape[1] % 4 == 0 and t.shape[1] <= 256:

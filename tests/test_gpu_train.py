@@ -273,12 +273,16 @@ def test_overrides_taken_as_differences_train_like_graphs_of_their_own():
             assert float((g1[k] - g0[k]).abs().max()) / scale <= 1e-5, k
 
 
-@pytest.mark.parametrize("dim", [128, 64, 32])
-def test_fused_layer_backward_matches_fp64_autograd(dim):
-    """``train.GcnFusedFn`` (round 6: forward writes the aggregated rows, backward = LayerNorm/ReLU backward, dW = du^T h,
-    dx = ONE more launch of the fused layer over the transposed graph with the transposed weight image) against torch
-    autograd in fp64 of r = ReLU(LN(A (x W^T) + b)) -- on a DIRECTED weighted graph (A^T != A) with hub rows (> 64
-    entries: the slice-sum path, both directions), isolated rows and a row count that is no multiple of 16."""
+@pytest.mark.parametrize("dim,drop_p,skip", [(128, 0.0, False), (64, 0.0, True), (32, 0.0, False), (128, 0.25, True),
+                                             (64, 0.1, False), (32, 0.5, True)])
+def test_fused_layer_backward_matches_fp64_autograd(dim, drop_p, skip):
+    """``train.GcnFusedFn`` (round 6: forward writes the aggregated rows and applies dropout + the skip connection in the
+    launch; backward = dropout/ReLU/LayerNorm backward, dW = du^T h, dx = ONE more launch of the fused layer over the
+    transposed graph with the transposed weight image and the skip gradient as residual) against torch autograd in fp64
+    of y = [x +] mask * ReLU(LN(A (x W^T) + b)) / (1 - p) -- on a DIRECTED weighted graph (A^T != A) with hub rows (> 64
+    entries: the slice-sum path, both directions), isolated rows and a row count that is no multiple of 16.  The mask
+    of the fp64 side is ``train.drop_keep_mask``, the torch restatement of the kernels' hash: an element the kernels
+    and the restatement disagree on would show as an O(1) error."""
     from lpformer_amd import data as D
     from lpformer_amd import train
     n = 5003
@@ -301,16 +305,31 @@ def test_fused_layer_backward_matches_fp64_autograd(dim):
     class _M:      # what GcnFusedFn reads of the model: the two weight-image caches
         from lpformer_amd.link_transformer import _PackedSquare
         _conv_packs, _conv_packs_t = [_PackedSquare()], [_PackedSquare()]
-    out = train.GcnFusedFn.apply(_M, 0, x, w, a, b, g, be)
+    train._seed_state[:] = [None, 0]
+    seed = train._next_drop_seed()
+    train._seed_state[:] = [None, 0]                         # the launch below draws the same seed
+    out = train.GcnFusedFn.apply(_M, 0, x, w, a, b, g, be, drop_p, skip)
     (out * up).sum().backward()
     got = [t.grad.clone() for t in (x, w, b, g, be)]
     # fp64 reference
+    mask = train.drop_keep_mask(seed, drop_p, n, dim, DEV)
+    if drop_p > 0:
+        frac = float(mask.double().mean())
+        assert abs(frac - (1 - drop_p)) <= 4 * (drop_p * (1 - drop_p) / mask.numel()) ** 0.5 + 1e-9
+        # no row or column pattern: every row / column keeps about its share
+        assert float((mask.double().mean(0) - (1 - drop_p)).abs().max()) <= 6 * (drop_p * (1 - drop_p) / n) ** 0.5
+        assert float((mask.double().mean(1) - (1 - drop_p)).abs().max()) <= 6 * (drop_p * (1 - drop_p) / dim) ** 0.5
+    else:
+        assert bool(mask.all())
     dense = torch.zeros(n, n, dtype=torch.float64, device=DEV)
     rows = torch.repeat_interleave(torch.arange(n, device=DEV), deg)
     dense.index_put_((rows, a.col.long()), a.val.double(), accumulate=True)
     xs = [t.detach().double().requires_grad_() for t in (x, w, b, g, be)]
     ref = torch.relu(torch.nn.functional.layer_norm(dense @ (xs[0] @ xs[1].t()) + xs[2], (dim,), xs[3], xs[4]))
-    assert float((out.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    ref = ref * mask.double() / (1 - drop_p)
+    if skip:
+        ref = ref + xs[0]
+    assert float((out.detach().double() - ref.detach()).abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max()))
     (ref * up.double()).sum().backward()
     for name, gt, want in zip(("dx", "dW", "dbias", "dgamma", "dbeta"), got, (t.grad for t in xs)):
         err, scale = float((gt.double() - want).abs().max()), max(1.0, float(want.abs().max()))
@@ -319,5 +338,9 @@ def test_fused_layer_backward_matches_fp64_autograd(dim):
     x0 = x.detach()
     for t in (w, b, g, be):
         t.grad = None
-    (train.GcnFusedFn.apply(_M, 0, x0, w, a, b, g, be) * up).sum().backward()
+    train._seed_state[:] = [None, 0]
+    (train.GcnFusedFn.apply(_M, 0, x0, w, a, b, g, be, drop_p, skip) * up).sum().backward()
     assert torch.equal(w.grad, got[1]) and torch.equal(b.grad, got[2])
+    # another draw is another mask
+    if drop_p > 0:
+        assert not torch.equal(train.drop_keep_mask(train._next_drop_seed(), drop_p, n, dim, DEV), mask)

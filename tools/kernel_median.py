@@ -1,5 +1,5 @@
 """Median duration per (kernel, grid) of a rocprofv3 --kernel-trace csv.  Usage: kernel_median.py <dir> [name filter]"""
-import collections, csv, glob, sys
+import collections, csv, glob, re, sys
 
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 d = collections.defaultdict(list)
@@ -7,7 +7,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if flt in n:
-            d[(n.split("(")[0][-60:], r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])].append(
+            d[((re.search(r"(\w+_kernel(<[^>]*>)?)", n) or re.search(r"(\S+)", n)).group(1)[-60:], r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])].append(
                 (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in sorted(d.items()):
     v = sorted(v)
