@@ -344,3 +344,72 @@ def test_fused_layer_backward_matches_fp64_autograd(dim, drop_p, skip):
     # another draw is another mask
     if drop_p > 0:
         assert not torch.equal(train.drop_keep_mask(train._next_drop_seed(), drop_p, n, dim, DEV), mask)
+
+
+@pytest.mark.parametrize("dim", [32, 64, 128, 256])
+def test_attention_stage_training_kernels_match_fp64_autograd(dim):
+    """``train.PairAttentionFn`` (csrc/pair_train.hip: PE hidden layer, folded key projection, per-pair leaky-ReLU
+    attention with PyG's segment softmax -- layers.py:193-224, link_transformer.py:182-211) forward and every gradient
+    against torch autograd in fp64 of the same algebra, at all four lane groupings (D = 32 / 64 / 128 / 256), on ragged
+    pairs: empty pairs, pairs of 1 .. 3 entries (less than one trip of four), hub pairs of 37 and 130 entries, three
+    types with different sizes, nodes shared by many entries (the dZ atomics)."""
+    from lpformer_amd import train
+    torch.manual_seed(dim)
+    rng = np.random.default_rng(dim)
+    bs, n_nodes, n_t = 301, 500, 3
+    counts = rng.integers(0, 7, (n_t, bs))
+    counts[:, rng.random(bs) < 0.3] = 0                          # pairs without any entry
+    counts[0, 5], counts[1, 17], counts[2, 200] = 37, 130, 41    # hub pairs
+    seg = np.zeros((n_t, bs + 1), np.int64)
+    base = 0
+    tbase = [0]
+    for t in range(n_t):
+        seg[t, 0] = base
+        seg[t, 1:] = base + np.cumsum(counts[t])
+        base = int(seg[t, bs])
+        tbase.append(base)
+    n = base
+    e_node = torch.from_numpy(rng.integers(0, n_nodes, n).astype(np.int32)).to(DEV)
+    e_pa, e_pb = (torch.from_numpy(rng.random(n).astype(np.float32) * 0.05).to(DEV) for _ in range(2))
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, device=DEV)).requires_grad_()
+    z, q = mk(n_nodes, dim), mk(bs, dim)
+    att, bias = mk(dim, s=0.3), mk(dim, s=0.1)
+    wfold, bfold = mk(n_t, dim, dim, s=dim ** -0.5), mk(n_t, dim, s=0.1)
+    w1s, b1s = mk(n_t, dim, 2, s=3.0), mk(n_t, dim, s=0.2)
+    gams, bets = (1 + 0.1 * torch.randn(n_t, dim, device=DEV)).requires_grad_(), mk(n_t, dim, s=0.1)
+    params = (z, q, att, bias, wfold, bfold, w1s, b1s, gams, bets)
+    up = torch.randn(bs, dim, device=DEV)
+    out = train.PairAttentionFn.apply(*params, e_node, e_pa, e_pb, torch.from_numpy(seg.reshape(-1)).to(DEV), tbase)
+    (out * up).sum().backward()
+    got = [p.grad.clone() for p in params]
+    # fp64 restatement
+    P = [p.detach().double().requires_grad_() for p in params]
+    z_, q_, att_, bias_, wf_, bf_, w1_, b1_, g_, be_ = P
+    pair_of = np.zeros(n, np.int64)
+    type_of = np.zeros(n, np.int64)
+    for t in range(n_t):
+        for p in range(bs):
+            pair_of[seg[t, p]:seg[t, p + 1]] = p
+        type_of[tbase[t]:tbase[t + 1]] = t
+    pair_t, type_t = torch.from_numpy(pair_of).to(DEV), torch.from_numpy(type_of).to(DEV)
+    pa, pb = e_pa.double(), e_pb.double()
+
+    def hidden(x, y):
+        u = x[:, None] * w1_[type_t][:, :, 0] + y[:, None] * w1_[type_t][:, :, 1] + b1_[type_t]
+        mu, var = u.mean(1, keepdim=True), u.var(1, unbiased=False, keepdim=True)
+        return torch.relu((u - mu) / torch.sqrt(var + 1e-5) * g_[type_t] + be_[type_t])
+    h = hidden(pa, pb) + hidden(pb, pa)
+    kp = torch.einsum("ed,eod->eo", h, wf_[type_t]) + bf_[type_t]
+    k = z_[e_node.long()] + kp
+    s = (torch.nn.functional.leaky_relu(k * q_[pair_t], 0.2) * att_).sum(1)
+    smax = torch.full((bs,), -float("inf"), dtype=torch.float64, device=DEV).scatter_reduce(0, pair_t, s.detach(), "amax")
+    w = torch.exp(s - smax[pair_t])
+    den = torch.zeros(bs, dtype=torch.float64, device=DEV).index_add(0, pair_t, w) + 1e-16
+    ref = torch.zeros(bs, dim, dtype=torch.float64, device=DEV).index_add(0, pair_t, (w / den[pair_t])[:, None] * k) + bias_
+    err = float((out.detach().double() - ref.detach()).abs().max())
+    assert err <= 2e-5 * max(1.0, float(ref.detach().abs().max())), err
+    (ref * up.double()).sum().backward()
+    names = ("dz", "dq", "datt", "dbias", "dwfold", "dbfold", "dw1", "db1", "dgamma", "dbeta")
+    for name, g, want in zip(names, got, (p.grad for p in P)):
+        e, scale = float((g.double() - want).abs().max()), max(1.0, float(want.abs().max()))
+        assert e <= 2e-4 * scale, (name, e, scale)
