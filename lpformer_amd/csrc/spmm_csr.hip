@@ -258,24 +258,36 @@ __global__ __launch_bounds__(256) void spmm_row_parts_kernel(const int64_t *__re
     }
 }
 
-// deg^-1/2 with the diagonal forced to weight 1 (torch_sparse.fill_diag semantics)
-__global__ void gcn_deg_kernel(int64_t n, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                               const float *__restrict__ w, float *__restrict__ dis) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// deg^-1/2 with the diagonal forced to weight 1 (torch_sparse.fill_diag semantics).  One WAVEFRONT per row, lanes strided
+// over the row's entries, the 64 partial sums added in a fixed butterfly order (deterministic).  (Until round 6 one
+// THREAD per row: the launch lasted as long as the longest hub row read one entry at a time -- 0.41 + 0.63 ms for the two
+// kernels on the collab-like graph, paid per batch by a training loop that overrides the propagation matrix.)
+__global__ __launch_bounds__(256) void gcn_deg_kernel(int64_t n, const int64_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ col, const float *__restrict__ w,
+                                                      float *__restrict__ dis) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
+    const int64_t lo = rowptr[i], hi = rowptr[i + 1];
     float deg = 0.f;
-    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) deg += (col[e] == i) ? 1.0f : (w ? w[e] : 1.0f);
-    float d = powf(deg, -0.5f);
-    dis[i] = isinf(d) ? 0.f : d;
+    for (int64_t e = lo + lane; e < hi; e += 64) deg += (col[e] == i) ? 1.0f : (w ? w[e] : 1.0f);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) deg += __shfl_xor(deg, m, 64);
+    if (lane == 0) {
+        const float d = powf(deg, -0.5f);
+        dis[i] = isinf(d) ? 0.f : d;
+    }
 }
 
-__global__ void gcn_scale_kernel(int64_t n, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                 const float *__restrict__ w, const float *__restrict__ dis,
-                                 float *__restrict__ w_out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void gcn_scale_kernel(int64_t n, const int64_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ col, const float *__restrict__ w,
+                                                        const float *__restrict__ dis, float *__restrict__ w_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const float di = dis[i];
-    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    const int64_t lo = rowptr[i], hi = rowptr[i + 1];
+    for (int64_t e = lo + lane; e < hi; e += 64) {
         const int32_t c = col[e];
         const float v = (c == i) ? 1.0f : (w ? w[e] : 1.0f);
         w_out[e] = (v * di) * dis[c];  // same association as gcn_norm: (w * dis[row]) * dis[col]
@@ -289,7 +301,8 @@ extern "C" int lpf_gcn_norm_csr(int64_t n, const int64_t *rowptr, const int32_t 
     if (n == 0) return LPF_OK;
     LPF_REQUIRE(n > 0 && rowptr && col && w_out && dis_tmp);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const unsigned blocks = (unsigned)((n + 255) / 256);
+    LPF_REQUIRE(n < (1ll << 33));
+    const unsigned blocks = (unsigned)((n + 3) / 4);     // four rows (wavefronts) per workgroup
     hipLaunchKernelGGL(gcn_deg_kernel, dim3(blocks), dim3(256), 0, s, n, rowptr, col, w_in, dis_tmp);
     hipLaunchKernelGGL(gcn_scale_kernel, dim3(blocks), dim3(256), 0, s, n, rowptr, col, w_in, dis_tmp, w_out);
     LPF_CHECK_LAUNCH();

@@ -416,7 +416,7 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     x = model._features()
     x = F.dropout(x, p=model.node_encoder.feat_drop, training=True)
     for i, conv in enumerate(enc.convs):
-        if enc.lns is not None and enc.relu and model._fusable(i, x.shape[1]):
+        if enc.lns is not None and enc.relu and model._fusable(i, x.shape[1]) and 0.0 <= float(enc.dropout) < 1.0:
             # a square layer: Linear + aggregation + bias + LayerNorm + ReLU forward in one launch
             # (a square layer is as wide as its input: the skip connection of other_models.py:72-75 applies whenever
             # ``residual`` is set)
