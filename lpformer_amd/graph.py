@@ -189,7 +189,8 @@ def self_ppr(adj: CSR, ppr: CSR) -> np.ndarray:
 
 
 class RemovedEdges:
-    """An adjacency override stated as a DIFFERENCE: the model's own typing adjacency minus these undirected edges.
+    """An adjacency override stated as a DIFFERENCE: the model's own typing adjacency (``adj_mask=``) -- or propagation
+    matrix (``adj_prop=``, the ``--mask-input`` loop, src/train/train_model.py:47-56) -- minus these undirected edges.
 
     The reference's training loop rebuilds the masked adjacency of every batch from all training edges
     (src/train/train_model.py:38-46: ``adjmask[perm] = 0; SparseTensor.from_edge_index(train_pos[adjmask])...``).

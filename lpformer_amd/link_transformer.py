@@ -728,13 +728,17 @@ class LinkTransformer(nn.Module):
         if hit is not None and hit[0] is obj:
             return hit[1]
         dev = self.device
-        if isinstance(obj, graph.RemovedEdges):
-            raise TypeError("RemovedEdges describes a typing adjacency (the adj_mask argument), nothing else")
+        if isinstance(obj, graph.RemovedEdges) and kind != "prop":
+            raise TypeError("RemovedEdges describes a difference to the model's own typing adjacency (adj_mask) or "
+                            "propagation matrix (adj_prop), nothing else")
         if kind == "prop" and not persistent:
             g = self._prop_delta(obj)
             if g is not None:
                 self._override[kind] = (obj, g)
                 return g
+            if isinstance(obj, graph.RemovedEdges):
+                raise ValueError("adj_prop=RemovedEdges(...) needs the model's own data['adj_t'] resident with its raw "
+                                 "weights (a graph this model normalised itself)")
         if kind == "t0":    # per-model indexes: filtered on the device from the resident PPR matrix
             g = graph.ppr_filter_device_blocked(self._device_graph("ppr", obj), 0, self.thresh_non1hop)
         elif isinstance(obj, graph.CSR) and kind in ("mask", "ppr"):
@@ -1383,7 +1387,8 @@ class LinkTransformer(nn.Module):
         edge list, no degree-ordered tiles for the one-launch layer, no transposed structure for the backward pass
         (4 ms per batch on the collab-like graph).  None: the override is a graph of its own (lpformer_amd/mask_delta.py)."""
         own_obj = self.data.get("adj_t")
-        if not self.use_mask_delta or own_obj is None or obj is own_obj:
+        named = isinstance(obj, graph.RemovedEdges)
+        if own_obj is None or obj is own_obj or not (self.use_mask_delta or named):
             return None
         own = self._device_graph("prop", own_obj)
         raw = own.__dict__.get("_struct_val")
@@ -1392,6 +1397,11 @@ class LinkTransformer(nn.Module):
         keys = own.__dict__.get("_edge_keys")
         if keys is None:
             keys = own.__dict__["_edge_keys"] = mask_delta.edge_keys(own.rowptr, own.col, own.n)
+        if isinstance(obj, graph.RemovedEdges):
+            # the difference named (no tensor of all the kept edges was built): the removed edges' raw weights to 0
+            e = obj.edges if isinstance(obj.edges, torch.Tensor) else torch.as_tensor(np.asarray(obj.edges))
+            new_w = mask_delta.prop_weights_minus_edges(keys, raw, e.to(self.device), own.n)
+            return self._share_structure(own, new_w)
         coo = graph.as_coo_device(obj, self.device)
         if coo is None:
             try:
@@ -1406,6 +1416,12 @@ class LinkTransformer(nn.Module):
         new_w = mask_delta.prop_weights_from_coo(keys, raw, coo[0], coo[1], coo[2], own.n)
         if new_w is None:
             return None
+        return self._share_structure(own, new_w)
+
+    @staticmethod
+    def _share_structure(own: graph.DeviceCSR, new_w: torch.Tensor) -> graph.DeviceCSR:
+        """The propagation matrix of raw weights ``new_w`` laid out on ``own``'s structure: normalised, sharing rowptr /
+        col, the one-launch layer's tiles and (train.py) the transposed structure."""
         g = graph.gcn_norm_device(graph.DeviceCSR(own.rowptr, own.col, new_w, own.n, None))
         for k in ("_fused_order", "_long_rows"):      # (functions of the structure alone: one dict for both graphs)
             g.__dict__[k] = own.__dict__.setdefault(k, {})

@@ -155,3 +155,21 @@ def prop_weights_from_coo(own_keys: torch.Tensor, own_w: torch.Tensor, row: torc
     if not ok or n_kept < min_kept * max(n_off_own, 1):
         return None
     return new_w
+
+
+def prop_weights_minus_edges(own_keys: torch.Tensor, own_w: torch.Tensor, edges: torch.Tensor, n: int) -> torch.Tensor:
+    """The raw weights of the resident GCN structure with the undirected ``edges`` [2, K] removed (both directions at 0;
+    the diagonal keeps its placeholder, edges the structure does not hold and ids out of range are ignored) --
+    ``adj_prop=RemovedEdges(edges)``: what ``prop_weights_from_coo`` derives from a tensor of all the kept edges, without
+    the tensor.  No host synchronisation."""
+    e = edges.long().reshape(2, -1)
+    ok = (e[0] >= 0) & (e[0] < n) & (e[1] >= 0) & (e[1] < n) & (e[0] != e[1])
+    q = torch.cat([e[0] * n + e[1], e[1] * n + e[0]])
+    ok2 = torch.cat([ok, ok])
+    new_w = own_w.clone()
+    if own_keys.numel() == 0 or q.numel() == 0:
+        return new_w
+    pos = torch.searchsorted(own_keys, q).clamp_(max=own_keys.numel() - 1)
+    hit = (own_keys[pos] == q) & ok2
+    new_w[pos[hit]] = 0.0
+    return new_w

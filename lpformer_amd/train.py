@@ -148,6 +148,15 @@ def _transpose_csr(a: graph.DeviceCSR) -> graph.DeviceCSR:
         t = _transpose_csr(src)
         hit = a.__dict__["_transposed"] = graph.DeviceCSR(t.rowptr, t.col, a.val[src.__dict__["_transposed_order"]].contiguous(),
                                                           a.n, None)
+        # functions of the structure alone -- the one-launch layer's degree-ordered tiles and hub slices, the long-row
+        # list of lpf_spmm_csr_f32 -- are the resident transposed graph's (recomputing them was a sort over the rows
+        # and a host synchronisation per batch: 1.7 of the 15 ms of a step that overrides the propagation matrix)
+        hit.__dict__["_fused_order"] = t.__dict__.setdefault("_fused_order", {})
+        if t.__dict__.get("_long_rows_full") is None:
+            deg = t.rowptr[1:] - t.rowptr[:-1]
+            rows = torch.nonzero(deg > 128).flatten().to(torch.int32)
+            t.__dict__["_long_rows_full"] = rows if rows.numel() else False
+        hit.__dict__["_long_rows_full"] = t.__dict__["_long_rows_full"]
     if hit is None:
         n = a.n
         rows = torch.repeat_interleave(torch.arange(n, device=a.col.device), a.rowptr[1:] - a.rowptr[:-1])

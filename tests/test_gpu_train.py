@@ -253,7 +253,9 @@ def test_overrides_taken_as_differences_train_like_graphs_of_their_own():
         model.train(); score.train()
         model.use_mask_delta = delta
         ov_mask = lpformer_amd.RemovedEdges(edges) if removed else _ST(r, c, None)
-        h = model(edges, adj_prop=_ST(r, c, v), adj_mask=ov_mask)
+        # ("both": the propagation matrix named as a difference too -- no tensor of the kept edges at all)
+        ov_prop = lpformer_amd.RemovedEdges(edges) if removed == "both" else _ST(r, c, v)
+        h = model(edges, adj_prop=ov_prop, adj_mask=ov_mask)
         loss = (-torch.log(score(h) + 1e-6).mean() - torch.log(1 - score(model(neg)) + 1e-6).mean())
         loss.backward()
         shared = model._override["prop"][1].rowptr is model._device_graph("prop", model.data["adj_t"]).rowptr
@@ -263,7 +265,7 @@ def test_overrides_taken_as_differences_train_like_graphs_of_their_own():
 
     l0, g0, shared0, dc0 = run(False, False)
     assert not shared0 and dc0 is None
-    for removed in (False, True):
+    for removed in (False, True, "both"):
         l1, g1, shared1, dc1 = run(True, removed)
         assert shared1 and dc1 is not None and dc1[2] is not None and dc1[2].numel() > 0
         assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))

@@ -151,3 +151,11 @@ def test_propagation_override_lands_on_the_resident_structure():
     # self-loops of the override are ignored (the normalisation sets every diagonal entry itself)
     r3, c3 = torch.cat([r, torch.tensor([5])]), torch.cat([c, torch.tensor([5])])
     np.testing.assert_array_equal(mask_delta.prop_weights_from_coo(keys, raw, r3, c3, torch.cat([v, torch.full((1,), 7.0)]), n).numpy(), want)
+    # the same difference NAMED (adj_prop=RemovedEdges(edges)): identical weights, with edges the structure does not hold,
+    # self-loops, ids out of range and both orientations ignored / merged
+    gone_e = np.array([[ei[0, i], ei[1, i]] for i in gone], dtype=np.int64).T
+    extra = np.array([[absent[0], 7, -1, n, gone_e[1, 0]], [absent[1], 7, 3, 2, gone_e[0, 0]]], dtype=np.int64)
+    named = mask_delta.prop_weights_minus_edges(keys, raw, torch.from_numpy(np.concatenate([gone_e, extra], axis=1)), n)
+    np.testing.assert_array_equal(named.numpy(), want)
+    np.testing.assert_array_equal(mask_delta.prop_weights_minus_edges(keys, raw, torch.zeros(2, 0, dtype=torch.int64), n).numpy(),
+                                  st.val)

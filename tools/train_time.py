@@ -26,7 +26,8 @@ class _ST:  # torch_sparse.SparseTensor look-alike on the device (what the refer
     def coo(self): return self._r, self._c, self._v
     def sparse_sizes(self): return (self._n, self._n)
 # "": no override; "gpu" / "cpu": adj_prop AND adj_mask rebuilt per batch (--mask-input, the pubmed script); "mask": adj_mask
-# only (every OGB script: train_model.py:38-46 without --mask-input); "removed": lpformer_amd.RemovedEdges(edges);
+# only (every OGB script: train_model.py:38-46 without --mask-input); "removed": lpformer_amd.RemovedEdges(edges) as
+# adj_mask, "removed_both": as adj_mask and adj_prop;
 # "mask_raw" / "gpu_raw": the same overrides as unsorted look-alike objects (what this tool passed until round 6)
 masked_mode = os.environ.get("LPF_TRAIN_MASKED", "")
 if os.environ.get("LPF_MASK_DELTA"):
@@ -38,6 +39,9 @@ def step(i):
     edges = pos[:, idx]
     if masked_mode == "removed":
         pos_loss = -torch.log(score(model(edges, adj_mask=lpformer_amd.RemovedEdges(edges))) + 1e-6).mean()
+    elif masked_mode == "removed_both":       # --mask-input with both differences named
+        rm = lpformer_amd.RemovedEdges(edges)
+        pos_loss = -torch.log(score(model(edges, adj_prop=rm, adj_mask=rm)) + 1e-6).mean()
     elif masked_mode:
         # train_model.py:40-51: the batch's positive edges removed from the propagation / typing adjacency
         keep = torch.ones(pos.shape[1], dtype=torch.bool, device=dev); keep[idx] = False
@@ -70,12 +74,17 @@ def step(i):
     return loss
 for i in range(3): step(i)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-k = 10
-for i in range(k): l = step(i)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / k
-print(f"train step ({bs} positives + {bs} negatives, two encoder passes): {dt * 1e3:.1f} ms  -> {2 * bs / dt / 1e3:.0f} k pairs/s, loss {float(l):.4f}")
+# five windows of ten steps, the MEDIAN reported (the step is host-paced in parts, and the pool's boxes share their host:
+# single windows of the same build differ by +-1 ms)
+k, wins = 10, []
+for _ in range(5):
+    t0 = time.perf_counter()
+    for i in range(k): l = step(i)
+    torch.cuda.synchronize()
+    wins.append((time.perf_counter() - t0) / k)
+dt = sorted(wins)[len(wins) // 2]
+print(f"train step ({bs} positives + {bs} negatives, two encoder passes): {dt * 1e3:.1f} ms  -> {2 * bs / dt / 1e3:.0f} k pairs/s, "
+      f"loss {float(l.detach()):.4f} (windows {' '.join(f'{w * 1e3:.1f}' for w in wins)})")
 if os.environ.get("LPF_TRAIN_PROFILE"):
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
