@@ -155,6 +155,11 @@ int lpf_gemm_f32_out_bf16(int64_t M, int32_t N, int32_t K, const float *A, int64
 int64_t lpf_gemm_tn_workspace_floats(int64_t M, int32_t N, int32_t K);
 int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                     float *C, int64_t ldc, float *workspace, void *stream);
+/* The same product with the column sums of A beside it: colsum[n] = sum_m A[m][n] -- the bias gradient of the Linear
+ * layer whose weight gradient C is (dY^T X and dY^T 1 in one pass over dY; replaces a lpf_colsum_f32 launch pair per
+ * layer of the training step).  Same workspace. */
+int lpf_gemm_tn_colsum_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
+                           float *C, int64_t ldc, float *colsum, float *workspace, void *stream);
 
 /* y[i,:] = LN(x[i,:]; g, b) (then ReLU if flagged), in place allowed (nn.LayerNorm eps 1e-5, biased variance).
  * other_models.py:131-132, layers.py:78.  D <= 1024. g/b NULL -> plain ReLU / identity. */

@@ -34,6 +34,7 @@ HIP_PROTOTYPES = {
     "lpf_layernorm_relu_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "lpf_layernorm_relu_drop_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, f32, u64, vp, i64, vp, vp, vp, vp, vp],
     "lpf_gemm_tn_f32": [i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp],
+    "lpf_gemm_tn_colsum_f32": [i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp],
     "lpf_gemm_tn_workspace_floats": [i64, i32, i32],
     "lpf_gemm_f32_out_bf16": [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, u32, vp],
     "lpf_gcn_layer_fused_f32": [i32, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, u32, vp,

@@ -373,7 +373,8 @@ __host__ static inline int64_t tn_chunks(int64_t M) {
 template <int KC, int P>
 __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(int64_t M, int N, int K, const float *__restrict__ A,
                                                               int64_t lda, const float *__restrict__ B, int64_t ldb,
-                                                              float *__restrict__ part, int64_t rows_per_chunk, int G) {
+                                                              float *__restrict__ part, int64_t rows_per_chunk, int G,
+                                                              float *__restrict__ colpart) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int per_group = 4 / G;                           // wavefronts (32-row output tiles) of a group
@@ -412,11 +413,13 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(int64_t M, int N, 
 #endif
         }
     };
+    float asum = 0.f;      // column sum of A over this wavefront's rows (the bias gradient beside dW), rows of parity lh
     auto mma = [&](int64_t m, const float (&a)[4], const float (&b)[4][KC]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool ok = m + 2 * s + lh < m_hi;
             const float x = (ok && a_ok) ? a[s] : 0.f;
+            asum += x;
 #ifdef LPF_TN_NOMFMA      // (timing aid: the loads alone)
 #pragma unroll
             for (int c = 0; c < KC; ++c) acc[c][s] += x * ((ok && b_ok[c]) ? b[s][c] : 0.f);
@@ -443,6 +446,10 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(int64_t M, int N, 
     }
     // partial tile: part[chunk * G + group][n][k] (n < N, k < K), accumulator register r of lane (li, lh) = row
     // (r & 3) + 8 (r >> 2) + 4 lh
+    if (colpart && blockIdx.z == 0) {      // colpart[chunk * G + group][n]
+        const float tot = asum + __shfl_xor(asum, 32, 64);
+        if (lh == 0 && a_ok) colpart[((int64_t)blockIdx.x * G + grp) * N + n0 + li] = tot;
+    }
     float *pp = part + ((int64_t)blockIdx.x * G + grp) * N * K;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
@@ -458,21 +465,28 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(int64_t M, int N, 
 
 // 32 output elements x 8 slices of the chunk list per workgroup: a slice adds its chunks in order, the slices meet in
 // LDS and are added in slice order (deterministic)
+// (elements elems .. elems + n_col - 1: the column sums of A, from colpart[chunk][n])
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(int64_t elems, int chunks, const float *__restrict__ part,
-                                                             float *__restrict__ C, int K, int64_t ldc) {
+                                                             float *__restrict__ C, int K, int64_t ldc, int n_col,
+                                                             const float *__restrict__ colpart,
+                                                             float *__restrict__ colsum) {
     __shared__ float red[8][33];
     const int ex = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int64_t e = (int64_t)blockIdx.x * 32 + ex;
     float s = 0.f;
-    if (e < elems)
+    if (e < elems) {
         for (int c = slice; c < chunks; c += 8) s += part[(int64_t)c * elems + e];
+    } else if (e < elems + n_col) {
+        for (int c = slice; c < chunks; c += 8) s += colpart[(int64_t)c * n_col + (e - elems)];
+    }
     red[slice][ex] = s;
     __syncthreads();
-    if (slice == 0 && e < elems) {
+    if (slice == 0 && e < elems + n_col) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) t += red[i][ex];
-        C[(e / K) * ldc + (e % K)] = t;
+        if (e < elems) C[(e / K) * ldc + (e % K)] = t;
+        else colsum[e - elems] = t;
     }
 }
 
@@ -480,32 +494,54 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(int64_t elems, int 
 
 extern "C" int64_t lpf_gemm_tn_workspace_floats(int64_t M, int32_t N, int32_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return tn_chunks(M) * tn_groups(N) * (int64_t)N * K;
+    return tn_chunks(M) * tn_groups(N) * ((int64_t)N * K + N);      // (+ N: the column-sum partials of _colsum_f32)
 }
 
-extern "C" int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B,
-                               int64_t ldb, float *C, int64_t ldc, float *workspace, void *stream) {
-    if (N == 0 || K == 0) return LPF_OK;
-    LPF_REQUIRE(M >= 0 && N > 0 && K > 0 && C && ldc >= K && (M == 0 || (A && B && workspace && lda >= N && ldb >= K)));
+namespace {
+int tn_launch(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
+              int64_t ldc, float *colsum, float *workspace, void *stream) {
+    if (N == 0) return LPF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (K == 0 && !colsum) return LPF_OK;
+    LPF_REQUIRE(M >= 0 && N > 0 && K > 0 && C && ldc >= K && (M == 0 || (A && B && workspace && lda >= N && ldb >= K)));
     if (M == 0) {
         for (int n = 0; n < N; ++n)
             if (hipMemsetAsync(C + (int64_t)n * ldc, 0, sizeof(float) * K, s) != hipSuccess) return LPF_ERR_LAUNCH;
+        if (colsum && hipMemsetAsync(colsum, 0, sizeof(float) * N, s) != hipSuccess) return LPF_ERR_LAUNCH;
         return LPF_OK;
     }
     const int64_t rows = tn_chunk_rows(M), chunks = tn_chunks(M);
     const int G = tn_groups(N);
+    float *colpart = colsum ? workspace + chunks * G * (int64_t)N * K : nullptr;
     // (K > 64 as two-tile launches of twice the workgroups, four wavefronts per SIMD: 5-10 % slower, measured)
     if (K <= 64) {
         dim3 grid((unsigned)chunks, (unsigned)((N + 127) / 128), (unsigned)((K + 63) / 64));
-        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 4>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows, G);
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 4>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows, G,
+                           colpart);
     } else {
         dim3 grid((unsigned)chunks, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
-        hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 3>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows, G);
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 3>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, workspace, rows, G,
+                           colpart);
     }
     const int64_t elems = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s, elems,
-                       (int)(chunks * G), workspace, C, K, ldc);
+    const int n_col = colsum ? N : 0;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((elems + n_col + 31) / 32)), dim3(256), 0, s, elems,
+                       (int)(chunks * G), workspace, C, K, ldc, n_col, colpart, colsum);
     LPF_CHECK_LAUNCH();
     return LPF_OK;
+}
+}  // namespace
+
+extern "C" int lpf_gemm_tn_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B,
+                               int64_t ldb, float *C, int64_t ldc, float *workspace, void *stream) {
+    if (N == 0 || K == 0) return LPF_OK;
+    return tn_launch(M, N, K, A, lda, B, ldb, C, ldc, nullptr, workspace, stream);
+}
+
+extern "C" int lpf_gemm_tn_colsum_f32(int64_t M, int32_t N, int32_t K, const float *A, int64_t lda, const float *B,
+                                      int64_t ldb, float *C, int64_t ldc, float *colsum, float *workspace,
+                                      void *stream) {
+    if (N == 0 || K == 0) return LPF_OK;
+    LPF_REQUIRE(colsum != nullptr);
+    return tn_launch(M, N, K, A, lda, B, ldb, C, ldc, colsum, workspace, stream);
 }

@@ -69,17 +69,23 @@ def _gemm(a: torch.Tensor, w: torch.Tensor, bias=None) -> torch.Tensor:
     return out
 
 
-def _gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a[M, N]^T @ b[M, K] -> [N, K] through lpf_gemm_tn_f32 (the weight gradient of a Linear)."""
+def _gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
+    """a[M, N]^T @ b[M, K] -> [N, K] through lpf_gemm_tn_f32 (the weight gradient of a Linear); ``colsum``: also the
+    column sums of ``a`` (the bias gradient) from the same pass -> (dW, db)."""
     a, b = a.contiguous(), b.contiguous()
     m, n = a.shape
     k = b.shape[1]
     out = torch.empty(n, k, dtype=torch.float32, device=a.device)
     lib = _lib.hip()
     ws = torch.empty(max(int(lib.lpf_gemm_tn_workspace_floats(m, n, k)), 1), dtype=torch.float32, device=a.device)
+    if colsum and n > 0 and k > 0:
+        cs = torch.empty(n, dtype=torch.float32, device=a.device)
+        check(lib.lpf_gemm_tn_colsum_f32(m, n, k, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+                                         ptr(cs), ptr(ws), _stream(a)), "lpf_gemm_tn_colsum_f32")
+        return out, cs
     check(lib.lpf_gemm_tn_f32(m, n, k, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), ptr(ws),
                               _stream(a)), "lpf_gemm_tn_f32")
-    return out
+    return (out, _colsum(a)) if colsum else out
 
 
 def _colsum(x: torch.Tensor) -> torch.Tensor:
@@ -110,9 +116,12 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _gemm(dy, weight.t().contiguous()).contiguous()        # [M, N] @ [K, N]^T
-        if ctx.needs_input_grad[1]:
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_db:
+            dw, db = _gemm_tn(dy, x, colsum=True)                         # dY^T X and dY^T 1 in one pass over dY
+        elif ctx.needs_input_grad[1]:
             dw = _gemm_tn(dy, x)                                          # dY^T X, rows split over the GPU
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        elif want_db:
             db = _colsum(dy)
         return dx, dw, db
 
@@ -614,10 +623,8 @@ class PairAttentionFn(torch.autograd.Function):
             check(lib.lpf_gemm_f32(m, d, d, ptr(dk[lo:]), d, ptr(wt), d, None, None, 0, ptr(dh[lo:]), d, 0, st),
                   "lpf_gemm_f32")
             ws = torch.empty(max(int(lib.lpf_gemm_tn_workspace_floats(m, d, d)), 1), dtype=torch.float32, device=dev)
-            check(lib.lpf_gemm_tn_f32(m, d, d, ptr(dk[lo:]), d, ptr(h[lo:]), d, ptr(dwfold[t]), d, ptr(ws), st),
-                  "lpf_gemm_tn_f32")                                       # dWfold = dK^T H
-            check(lib.lpf_colsum_f32(m, d, ptr(dk[lo:]), d, ptr(dbfold[t]), ptr(_partial_ws(d, 1, dev)), st),
-                  "lpf_colsum_f32")
+            check(lib.lpf_gemm_tn_colsum_f32(m, d, d, ptr(dk[lo:]), d, ptr(h[lo:]), d, ptr(dwfold[t]), d, ptr(dbfold[t]),
+                                             ptr(ws), st), "lpf_gemm_tn_colsum_f32")   # dWfold = dK^T H, dbfold = dK^T 1
             check(lib.lpf_pe_hidden_bwd_f32(m, d, ptr(w1s[t]), ptr(b1s[t]), ptr(gams[t]), ptr(bets[t]),
                                             e_pa.data_ptr() + 4 * lo, e_pb.data_ptr() + 4 * lo, ptr(dh[lo:]), d,
                                             ptr(g5[t]), ptr(_partial_ws(d, 5, dev)), st), "lpf_pe_hidden_bwd_f32")

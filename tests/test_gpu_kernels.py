@@ -323,7 +323,8 @@ def test_gemm_tn_weight_gradient():
     torch; ragged N / K / M, a single row, and an empty input."""
     from lpformer_amd import train
     torch.manual_seed(11)
-    for m, n, k in ((100_003, 128, 128), (4097, 132, 260), (1, 7, 5), (300, 1, 1433), (0, 16, 8)):
+    for m, n, k in ((100_003, 128, 128), (4097, 132, 260), (1, 7, 5), (300, 1, 1433), (0, 16, 8), (50_001, 64, 64), (9000, 32, 64),
+                    (7000, 40, 200)):
         a = torch.randn(m, n, device=DEV)
         b = torch.randn(m, k, device=DEV)
         got = train._gemm_tn(a, b)
@@ -331,6 +332,12 @@ def test_gemm_tn_weight_gradient():
         scale = max(1.0, float(want.abs().max()))
         assert got.shape == (n, k) and float((got.double() - want).abs().max()) <= 2e-5 * scale * max(1.0, m ** 0.5 / 30)
         assert torch.equal(got, train._gemm_tn(a, b))      # deterministic reduction order
+        # with the column sums of A (the bias gradient) from the same pass: the product bitwise the same
+        got2, cs = train._gemm_tn(a, b, colsum=True)
+        assert torch.equal(got2, got) and cs.shape == (n,)
+        want_cs = a.double().sum(0)
+        assert float((cs.double() - want_cs).abs().max()) <= 2e-5 * max(1.0, float(want_cs.abs().max())) * max(1.0, m ** 0.5 / 30)
+        assert torch.equal(cs, train._gemm_tn(a, b, colsum=True)[1])
 
 
 def test_layernorm_backward_kernel():
