@@ -116,7 +116,8 @@ def patch_selection(sel: dict, batch: torch.Tensor, rk: torch.Tensor, n: int, mo
                 order = torch.argsort((types * bs + kp.long()) * n + kn.long())
                 kp, kn, ka, kb, types = kp[order], kn[order], ka[order], kb[order], types[order]
     counts = torch.zeros(3, bs, dtype=torch.int64, device=dev)
-    counts[:2] = torch.bincount(types * bs + kp.long(), minlength=2 * bs).view(2, bs)
+    counts[:2] = torch.zeros(2 * bs, dtype=torch.int64, device=dev).index_add_(
+        0, types * bs + kp.long(), torch.ones(kp.numel(), dtype=torch.int64, device=dev)).view(2, bs)   # (no host read-back)
     counts[2] = tp[2, 1:] - tp[2, :-1]
     new_tp = torch.zeros(3, bs + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, dim=1, out=new_tp[:, 1:])

@@ -100,6 +100,23 @@ def _colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_wt_cache: dict = {}
+
+
+def _transposed(weight: torch.Tensor) -> torch.Tensor:
+    """``weight.t().contiguous()`` kept per (storage, version): a step runs every Linear's backward twice (positives and
+    negatives, src/train/train_model.py:59,66) on the same parameter version."""
+    if not isinstance(weight, torch.nn.Parameter):      # (a temporary's storage may be another tensor's a moment later)
+        return weight.t().contiguous()
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
+    hit = _wt_cache.get(key)
+    if hit is None:
+        if len(_wt_cache) >= 128:
+            _wt_cache.clear()
+        hit = _wt_cache[key] = weight.detach().t().contiguous()
+    return hit
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T (+ b); forward and both gradients on the fp32 matrix cores (lpf_gemm_f32)."""
 
@@ -115,7 +132,7 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _gemm(dy, weight.t().contiguous()).contiguous()        # [M, N] @ [K, N]^T
+            dx = _gemm(dy, _transposed(weight)).contiguous()            # [M, N] @ [K, N]^T
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and want_db:
             dw, db = _gemm_tn(dy, x, colsum=True)                         # dY^T X and dY^T 1 in one pass over dY
@@ -463,7 +480,7 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     with torch.no_grad():
         s = model._select(batch, test_set, adj_mask)
         tp = s["type_ptr"][:3 * (bs + 1)].view(3, bs + 1)
-        tot = [int(v) for v in tp[:, bs].tolist()]
+        tot = list(s["tot"]) if "tot" in s else [int(v) for v in tp[:, bs].tolist()]   # (read with the selection's status)
         n_all = sum(tot)
         e_pair, e_node = s["sel_pair"][:n_all], s["sel_node"][:n_all]
         e_pa, e_pb = s["sel_pa"][:n_all], s["sel_pb"][:n_all]
@@ -471,14 +488,18 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
             # drop_pairwise (link_transformer.py:322-337): ceil(n (1 - p)) entries of a random permutation survive, CN
             # and 1-hop together, >1-hop separately (:257-260).  The survivors are kept in (type, pair) order -- the
             # reference leaves them in permuted order, which only the summation order of its scatters can see.
+            # (the survivors' positions sorted: sizes known on the host, no boolean mask -- five masked selections were five
+            #  compactions with a host synchronisation each)
             n01 = tot[0] + tot[1]
-            keep = torch.zeros(n_all, dtype=torch.bool, device=dev)
-            keep[drop_pairwise(n01, model.att_drop, dev)] = True
+            parts = [drop_pairwise(n01, model.att_drop, dev)]
             if tot[2] > 0:
-                keep[n01 + drop_pairwise(tot[2], model.att_drop, dev)] = True
-            tid = torch.repeat_interleave(torch.arange(3, device=dev), torch.tensor(tot, device=dev))[keep]
-            e_pair, e_node, e_pa, e_pb = e_pair[keep], e_node[keep], e_pa[keep], e_pb[keep]
-            cnt = torch.bincount(tid * bs + e_pair.long(), minlength=3 * bs).view(3, bs)
+                parts.append(n01 + drop_pairwise(tot[2], model.att_drop, dev))
+            idx = torch.sort(torch.cat(parts)).values
+            tid = (idx >= tot[0]).long() + (idx >= n01).long()
+            e_pair, e_node, e_pa, e_pb = e_pair[idx], e_node[idx], e_pa[idx], e_pb[idx]
+            # (index_add_, not bincount: torch's bincount reads the largest key back to the host first)
+            cnt = torch.zeros(3 * bs, dtype=torch.int64, device=dev).index_add_(
+                0, tid * bs + e_pair.long(), torch.ones(idx.numel(), dtype=torch.int64, device=dev)).view(3, bs)
         else:
             cnt = (tp[:, 1:] - tp[:, :-1]).long()
         tot = [int(v) for v in cnt.sum(dim=1).tolist()]
