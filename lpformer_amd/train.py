@@ -25,6 +25,7 @@ applied to (CN + 1-hop) together and to (>1-hop) separately (:257-260); the perm
 from __future__ import annotations
 
 import math
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -104,17 +105,23 @@ _wt_cache: dict = {}
 
 
 def _transposed(weight: torch.Tensor) -> torch.Tensor:
-    """``weight.t().contiguous()`` kept per (storage, version): a step runs every Linear's backward twice (positives and
-    negatives, src/train/train_model.py:59,66) on the same parameter version."""
-    if not isinstance(weight, torch.nn.Parameter):      # (a temporary's storage may be another tensor's a moment later)
+    """``weight.t().contiguous()`` kept per PARAMETER OBJECT and version: a step runs every Linear's backward twice
+    (positives and negatives, src/train/train_model.py:59,66) on the same parameter version.  The entry holds a weak
+    reference to the parameter and is valid only for that very object (an address or a storage pointer alone can be a
+    later model's parameter at the same version); temporaries are never cached."""
+    if not isinstance(weight, torch.nn.Parameter):
         return weight.t().contiguous()
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
-    hit = _wt_cache.get(key)
-    if hit is None:
-        if len(_wt_cache) >= 128:
+    hit = _wt_cache.get(id(weight))
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    if len(_wt_cache) >= 256:
+        for k in [k for k, v in _wt_cache.items() if v[0]() is None]:
+            del _wt_cache[k]
+        if len(_wt_cache) >= 256:
             _wt_cache.clear()
-        hit = _wt_cache[key] = weight.detach().t().contiguous()
-    return hit
+    wt = weight.detach().t().contiguous()
+    _wt_cache[id(weight)] = (weakref.ref(weight), weight._version, wt)
+    return wt
 
 
 class LinearFn(torch.autograd.Function):

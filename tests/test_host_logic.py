@@ -497,3 +497,33 @@ def test_recorded_plan_moves_every_pointer_into_the_ids():
     plan._plan.append(("k3", bad, (1,), ()))
     with pytest.raises(_lib.LpfError):
         plan._replay(base)
+
+
+def test_transposed_weight_cache_follows_the_parameter_object_and_its_version():
+    """train._transposed keeps W^T across the two passes of a step: valid for the SAME parameter object at the SAME
+    version only (a storage address is not an identity: the next model's parameter can live there at the same version --
+    the failure this test's rule replaced showed as wrong gradients in whichever model was built second)."""
+    import gc
+    from lpformer_amd import train
+    p = torch.nn.Parameter(torch.randn(3, 5))
+    t1 = train._transposed(p)
+    assert torch.equal(t1, p.detach().t()) and train._transposed(p) is t1
+    with torch.no_grad():
+        p.add_(1.0)                                   # an optimiser step: same object, next version
+    t2 = train._transposed(p)
+    assert t2 is not t1 and torch.equal(t2, p.detach().t())
+    # another parameter object at the same address and version count is another parameter
+    key, ver = id(p), p._version
+    entry = train._wt_cache[key]
+    del p
+    gc.collect()
+    assert entry[0]() is None                         # (the cache does not keep parameters alive)
+    q = torch.nn.Parameter(torch.randn(3, 5))
+    with torch.no_grad():
+        q.add_(0.0)
+    train._wt_cache[id(q)] = (entry[0], q._version, t2)      # what a recycled id would find
+    assert torch.equal(train._transposed(q), q.detach().t())
+    # temporaries are never cached
+    n = len(train._wt_cache)
+    v = torch.randn(4, 2)
+    assert torch.equal(train._transposed(v), v.t()) and len(train._wt_cache) == n
