@@ -46,9 +46,12 @@ def removed_from_edges(own: torch.Tensor, edges: torch.Tensor, n: int) -> torch.
     """Directed keys of the undirected ``edges`` [2, K] that the adjacency ``own`` (sorted keys) holds: sorted, unique."""
     e = edges.long().reshape(2, -1)
     ok = (e[0] >= 0) & (e[0] < n) & (e[1] >= 0) & (e[1] < n)
-    e = e[:, ok]
-    q = torch.unique(torch.cat([e[0] * n + e[1], e[1] * n + e[0]]))
-    return q[_member(own, q)]
+    ok = torch.cat([ok, ok])
+    q = torch.where(ok, torch.cat([e[0] * n + e[1], e[1] * n + e[0]]), torch.zeros((), dtype=torch.int64, device=e.device))
+    # keys that are out of range or that the adjacency does not hold become -1; one more -1 is appended so that the sorted
+    # unique keys ALWAYS start with it: ONE host read-back (unique's size) instead of one per filter
+    q = torch.where(ok & _member(own, q), q, torch.full((), -1, dtype=torch.int64, device=e.device))
+    return torch.unique(torch.cat([q, torch.full((1,), -1, dtype=torch.int64, device=e.device)]))[1:]
 
 
 def removed_from_coo(own: torch.Tensor, row: torch.Tensor, col: torch.Tensor, n: int, limit: int):
@@ -76,6 +79,15 @@ def round_trip1(v: torch.Tensor) -> torch.Tensor:
     return (v * one + one) - one
 
 
+def _positions(mask: torch.Tensor, count: int) -> torch.Tensor:
+    """Indices of the ``count`` set elements of ``mask`` (count known on the host: no read-back where torch offers the
+    fixed-size form on this device)."""
+    try:
+        return torch.nonzero_static(mask, size=count).flatten()
+    except (RuntimeError, NotImplementedError, AttributeError):
+        return torch.nonzero(mask).flatten()
+
+
 def patch_selection(sel: dict, batch: torch.Tensor, rk: torch.Tensor, n: int, mode: str, th_1hop: float, lookup):
     """The selection of the MASKED adjacency from the selection ``sel`` of the resident one.
 
@@ -96,13 +108,16 @@ def patch_selection(sel: dict, batch: torch.Tensor, rk: torch.Tensor, n: int, mo
     in_a, in_b = _member(rk, a * n + node), _member(rk, b * n + node)
     # entries that touch no removed edge stay what they are, in their order (ONE compaction for both regions: the kept
     # common neighbours still precede the kept one-hop nodes)
-    kept = torch.nonzero(~(in_a | in_b)).flatten()
+    keep_m = ~(in_a | in_b)
+    demote_m = (in_a ^ in_b)[:n0]
+    n_kept, n_di = (int(v) for v in torch.stack([keep_m.sum(), demote_m.sum()]).tolist())     # (one read-back for both)
+    kept = _positions(keep_m, n_kept)
     kp, kn, ka, kb = pair_i[kept], node_i[kept], pa[kept], pb[kept]
     types = (kept >= n0).long()                # 0: common neighbour, 1: one-hop (mode "cn": all 0)
     if mode != "cn":
         # common neighbours that lost ONE of their two edges: one-hop candidates now (pair_adj = 1, :237)
-        di = torch.nonzero((in_a ^ in_b)[:n0]).flatten()
-        if di.numel() > 0:
+        di = _positions(demote_m, n_di)
+        if n_di > 0:
             dn = node[di]
             raw = lookup(torch.cat([a[di], b[di]]), torch.cat([dn, dn]))
             va, vb = round_trip1(raw[:di.numel()]), round_trip1(raw[di.numel():])
