@@ -182,3 +182,62 @@ def test_auto_attention_choice_follows_the_weights(dim):
     model.train()
     assert model.attention_kernel() == "mfma" and model._flip_est is est
     model.eval()
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[7][0] <= 0.0], ids=[f"seed{c[0]}_d{c[4]}" for c in CASES if c[7][0] <= 0.0])
+def test_removed_edges_selection_is_the_selection_of_the_masked_graph(case):
+    """The training loop's masked typing adjacency (src/train/train_model.py:38-46; link_transformer.py:229-250,438-443)
+    on random graphs, through all three forms of the override -- the resident-index selection patched over the entries
+    that touch a removed edge (the override as a coalesced tensor: the difference found on the device; and
+    ``RemovedEdges``: the difference named) against the general kernels over a CSR built from the override --
+    bit-exact, and against the ORACLE's selection of the masked graph.  Batches: positives whose edges are removed
+    (hub endpoints repeat), their reverses, duplicates, non-edges."""
+    seed, n, edges, gamma, dim, layers, residual, th, eps, weighted = case
+    rng = np.random.default_rng(300 + seed)
+    ei, w = D.chung_lu_graph(n, edges, gamma=gamma, seed=seed, max_weight=6 if weighted else 0)
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    ppr = lpformer_amd.calc_ppr(ei, n, 0.15, eps)
+    d = D.build_data(ei, x, n, edge_weight=w, ppr=ppr)
+    cfg = D.train_args_for(dict(thresholds=th, dim=dim, gnn_layers=layers, residual=residual))
+    torch.manual_seed(seed)
+    model = lpformer_amd.LinkTransformer(cfg, d, device=DEV).to(DEV).eval()
+    und = ei[:, ei[0] < ei[1]]
+    hub = np.argsort(np.bincount(ei[0], minlength=n))[-4:]
+    at_hub = und[:, np.isin(und[0], hub) | np.isin(und[1], hub)]
+    pos = np.concatenate([und[:, rng.integers(0, und.shape[1], 300)], at_hub[:, rng.integers(0, at_hub.shape[1], 100)]], axis=1)
+    batch = np.concatenate([pos, pos[::-1, :40], pos[:, :25], rng.integers(0, n, (2, 60))], axis=1).astype(np.int64)
+    gone = set((pos[0] * n + pos[1]).tolist()) | set((pos[1] * n + pos[0]).tolist())
+    keep = np.array([k not in gone for k in (ei[0] * n + ei[1]).tolist()])
+    kr, kc = torch.from_numpy(ei[0][keep]).to(DEV), torch.from_numpy(ei[1][keep]).to(DEV)
+    masked_t = torch.sparse_coo_tensor(torch.stack([kr, kc]), torch.ones(kr.numel(), dtype=torch.int32, device=DEV),
+                                       (n, n)).coalesce()
+    tb = torch.from_numpy(batch)
+
+    def select(ov, delta):
+        model.use_mask_delta = delta
+        model._delta_cache = None
+        model._override.clear()
+        out = [tuple(t.cpu().numpy() for t in info) for info in model.compute_node_mask(tb, False, ov) if info is not None]
+        assert (model._delta_cache is not None) == delta
+        return out
+    general = select(masked_t, False)
+    for ov in (masked_t, lpformer_amd.RemovedEdges(torch.from_numpy(pos))):
+        got = select(ov, True)
+        assert len(got) == len(general)
+        for a, b in zip(got, general):
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+            np.testing.assert_array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    # ... and the oracle on the masked graph (>1-hop exclusion from the UNMASKED adjacency)
+    mask_full = O.symmetric_mask_csr(ei, n)
+    masked = O.symmetric_mask_csr(ei[:, keep], n)
+    want = O.select_nodes(batch, masked, (ppr.rowptr, ppr.col.astype(np.int64), ppr.val), th, n=n, adj_unmasked=mask_full)
+    tags = ("cn", "onehop", "non1hop")[:len(general)]
+    for tag, g in zip(tags, general):
+        ix, a, b = want[tag] if tag in want else (np.zeros((2, 0), np.int64), np.zeros(0, np.float32), np.zeros(0, np.float32))
+        np.testing.assert_array_equal(g[0], ix)
+        np.testing.assert_array_equal(g[1].view(np.uint32), a.view(np.uint32))
+        np.testing.assert_array_equal(g[2].view(np.uint32), b.view(np.uint32))
+    plain = [tuple(t.cpu().numpy() for t in info) for info in model.compute_node_mask(tb, False, None) if info is not None]
+    changed = any(p[0].shape != g[0].shape for p, g in zip(plain, general))
+    assert changed, "the removed edges must matter"
