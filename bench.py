@@ -719,7 +719,7 @@ def main():
             opt.step()
             opt.zero_grad()
             if it < 5 or it >= args.train_steps - 5:
-                losses.append(float(loss))
+                losses.append(float(loss.detach()))
         torch.cuda.synchronize()
         train_s = time.perf_counter() - t0
         model.eval(); score.eval()
