@@ -725,14 +725,20 @@ int lpf_pair_attention_train_fwd_f32(int64_t bs, int64_t n_entries, int32_t D, c
                                      const int32_t *e_node, const float *Z, int64_t ldz, const float *KP, int64_t ldk,
                                      const float *q, int64_t ldq, const float *att, const float *bias, float *out,
                                      int64_t ldo, float *score, float *pmax, float *pinv, void *stream);
-/* Gradients of the above from dout: dK[e] (entry-major), dZ[node_e] += dk_e (dZ zeroed by the caller), dq[p],
- * datt_dbias float[2][D]; workspace k = 2. */
+/* Gradients of the above from dout: dK[e] (entry-major), dq[p], datt_dbias float[2][D]; workspace k = 2.  dZ: NULL (the
+ * caller sums dK by node with lpf_segment_rows_sum_f32: deterministic) or float[N][lddz], zeroed by the caller, to which
+ * dk_e is added at row node_e with float atomics (order of the additions not fixed). */
 int lpf_pair_attention_train_bwd_f32(int64_t bs, int64_t n_entries, int32_t D, const int64_t *seg,
                                      const int32_t *e_node, const float *Z, int64_t ldz, const float *KP, int64_t ldk,
                                      const float *q, int64_t ldq, const float *att, const float *bias, const float *out,
                                      int64_t ldo, const float *score, const float *pmax, const float *pinv,
                                      const float *dout, int64_t lddo, float *dK, int64_t lddk, float *dZ, int64_t lddz,
                                      float *dq, int64_t lddq, float *datt_dbias, float *workspace, void *stream);
+/* dst[key] = sum of src[order[j]] over each run of equal keys in keys_sorted (ascending j: a fixed order) -- the gradient
+ * of a row gather without atomics: keys_sorted / order = the node ids of the entries sorted and the permutation that sorts
+ * them, src = dK, dst = dZ (rows no key names are left untouched: zero them first).  D in {32, 64, 128, 256}. */
+int lpf_segment_rows_sum_f32(int64_t n, int32_t D, const int32_t *keys_sorted, const int64_t *order, const float *src,
+                             int64_t lds, float *dst, int64_t ldd, void *stream);
 /* Gradient of lpf_pair_gather_f32: dX[a_k] += dsum[k] + dmul[k] * X[b_k], dX[b_k] += dsum[k] + dmul[k] * X[a_k]
  * (dmul or dsum may be NULL; dX is accumulated into). */
 int lpf_pair_scatter_add_f32(int64_t bs, int32_t D, const int64_t *batch, int64_t batch_ld, int64_t n_rows,

@@ -104,6 +104,7 @@ HIP_PROTOTYPES = {
     "lpf_colsum_f32": [i64, i32, vp, i64, vp, vp, vp],
     "lpf_pair_attention_train_fwd_f32": [i64, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp,
                                          vp],
+    "lpf_segment_rows_sum_f32": [i64, i32, vp, vp, vp, i64, vp, i64, vp],
     "lpf_pair_attention_train_bwd_f32": [i64, i64, i32, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp,
                                          vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp],
     "lpf_pair_scatter_add_f32": [i64, i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp],

@@ -12,7 +12,7 @@
 // forward writes H and KP (entry-major [n, D]) and the raw scores, and the backward recomputes k_e from Z and KP.
 // Backward of the attention, per pair p with upstream gradient do_p (c_p = do_p . (o_p - bias) = sum_e alpha_e dalpha_e):
 //     dalpha_e = do_p . k_e ;  ds_e = alpha_e (dalpha_e - c_p)
-//     dk_e = alpha_e do_p + ds_e att * lrelu'(k_e q_p) * q_p          -> dK[e] (entry-major) and dZ[v_e] += dk_e (atomics)
+//     dk_e = alpha_e do_p + ds_e att * lrelu'(k_e q_p) * q_p          -> dK[e] (entry-major); dZ[v] = sum of dk_e over node v's entries
 //     dq_p = sum_e ds_e att * lrelu'(k_e q_p) * k_e ;  datt = sum ds_e lrelu(k_e q_p) ;  dbias = sum_p do_p
 // then dH_t = dK_t Wfold_t, dWfold_t = dK_t^T H_t (lpf_gemm_f32 / lpf_gemm_tn_f32), dbfold_t = column sums of dK_t, and
 // the LayerNorm / first-layer gradients of the hidden layer (pe_hidden_bwd).
@@ -20,7 +20,9 @@
 // Layout: entries sorted by (type, pair): e_pair / e_node / e_pa / e_pb [n], seg[3][bs+1] = first entry of pair p's
 // type-t segment (global entry indices; seg[t][bs] = end of type t).  G = D/4 lanes own one entry row (pe_hidden) or
 // one pair (attention), 16 bytes per lane and access.  Column sums over entries / pairs go through per-block partials
-// that a second small kernel adds in block order: every gradient except dZ (float atomics) is deterministic.
+// that a second small kernel adds in block order; dZ is summed run by run of the entries sorted by node
+// (segment_sum_kernel; float atomics only when the caller passes a dZ to the backward kernel itself): every gradient of
+// this stage is deterministic.  (The endpoint scatter of lpf_pair_scatter_add_f32 still adds with atomics.)
 #include "lpf_common.h"
 
 namespace {
@@ -365,9 +367,11 @@ __global__ __launch_bounds__(PT_THREADS) void pair_attn_train_bwd_kernel(const A
                     gq.x += dqv[0]; gq.y += dqv[1]; gq.z += dqv[2]; gq.w += dqv[3];
                     datt.x += da[0]; datt.y += da[1]; datt.z += da[2]; datt.w += da[3];
                     *reinterpret_cast<float4 *>(A.dK + e * A.lddk + off) = make_float4(dk[0], dk[1], dk[2], dk[3]);
-                    float *dz = A.dZ + (int64_t)v * A.lddz + off;
-                    unsafeAtomicAdd(dz + 0, dk[0]); unsafeAtomicAdd(dz + 1, dk[1]);
-                    unsafeAtomicAdd(dz + 2, dk[2]); unsafeAtomicAdd(dz + 3, dk[3]);
+                    if (A.dZ) {   // (dZ = nullptr: the caller sums dK by node itself, lpf_segment_rows_sum_f32)
+                        float *dz = A.dZ + (int64_t)v * A.lddz + off;
+                        unsafeAtomicAdd(dz + 0, dk[0]); unsafeAtomicAdd(dz + 1, dk[1]);
+                        unsafeAtomicAdd(dz + 2, dk[2]); unsafeAtomicAdd(dz + 3, dk[3]);
+                    }
                 }
                 }
             }
@@ -423,6 +427,38 @@ __global__ __launch_bounds__(PT_THREADS) void pair_scatter_kernel(int64_t bs, in
         unsafeAtomicAdd(da + 0, ga.x); unsafeAtomicAdd(da + 1, ga.y); unsafeAtomicAdd(da + 2, ga.z); unsafeAtomicAdd(da + 3, ga.w);
         unsafeAtomicAdd(db + 0, gb.x); unsafeAtomicAdd(db + 1, gb.y); unsafeAtomicAdd(db + 2, gb.z); unsafeAtomicAdd(db + 3, gb.w);
     }
+}
+
+// ------------------------------------------------------------------------------------------- rows summed by key
+// dst[key] = sum of src[order[j]] over the run of equal keys in the SORTED key list (j ascending: deterministic) -- the
+// gradient of a row gather, Z[node_e] -> dZ[v] = sum_{e: node_e = v} dK[e], without atomics: 4 D float atomics per entry
+// were 210 of the attention backward's 375 us on a collab-like training batch.  One lane group per position of the sorted
+// list; a position that does not start a run leaves at once, the head of a run walks it, four rows requested per trip.
+template <int G>
+__global__ __launch_bounds__(PT_THREADS) void segment_sum_kernel(int64_t n, const int32_t *__restrict__ keys,
+                                                                 const int64_t *__restrict__ order,
+                                                                 const float *__restrict__ src, int64_t lds,
+                                                                 float *__restrict__ dst, int64_t ldd) {
+    const int lane = threadIdx.x & 63, grp = lane / G, off = 4 * (lane % G);
+    const int64_t i = ((int64_t)blockIdx.x * (PT_THREADS / 64) + (threadIdx.x >> 6)) * (64 / G) + grp;
+    if (i >= n) return;
+    const int32_t key = keys[i];
+    if (i > 0 && keys[i - 1] == key) return;       // not the head of its run
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t j0 = i; j0 < n && keys[j0] == key; j0 += 4) {
+        float4 v[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            in[u] = j0 + u < n && keys[j0 + u] == key;
+            v[u] = in[u] ? *reinterpret_cast<const float4 *>(src + order[j0 + u] * lds + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (in[u]) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        if (!in[3]) break;
+    }
+    *reinterpret_cast<float4 *>(dst + (int64_t)key * ldd + off) = acc;
 }
 
 inline int pt_blocks(int64_t units, int per_block) {
@@ -517,12 +553,13 @@ extern "C" int lpf_pair_attention_train_bwd_f32(int64_t bs, int64_t n_entries, i
                                                 float *dK, int64_t lddk, float *dZ, int64_t lddz, float *dq, int64_t lddq,
                                                 float *datt_dbias, float *workspace, void *stream) {
     if (bs == 0) return LPF_OK;
-    LPF_REQUIRE(bs > 0 && n_entries >= 0 && seg && Z && q && att && bias && out && pmax && pinv && dout && dZ && dq &&
+    LPF_REQUIRE(bs > 0 && n_entries >= 0 && seg && Z && q && att && bias && out && pmax && pinv && dout && dq &&
                 datt_dbias && workspace && (n_entries == 0 || (e_node && KP && score && dK)) && ldz >= D && ldk >= D &&
                 ldq >= D && ldo >= D && lddo >= D && lddk >= D && lddz >= D && lddq >= D &&
                 ((ldz | ldk | ldq | ldo | lddo | lddk | lddz | lddq) & 3) == 0 && lpf_aligned16(Z) && lpf_aligned16(q) &&
                 lpf_aligned16(att) && lpf_aligned16(bias) && lpf_aligned16(out) && lpf_aligned16(dout) &&
-                lpf_aligned16(dZ) && lpf_aligned16(dq) && (n_entries == 0 || (lpf_aligned16(KP) && lpf_aligned16(dK))));
+                (!dZ || lpf_aligned16(dZ)) && lpf_aligned16(dq) &&
+                (n_entries == 0 || (lpf_aligned16(KP) && lpf_aligned16(dK))));
     AttnArgs a{};
     a.bs = bs; a.n = n_entries; a.D = D; a.seg = seg; a.e_node = e_node; a.Z = Z; a.ldz = ldz;
     a.KP = KP ? KP : Z; a.ldk = ldk; a.q = q; a.ldq = ldq; a.att = att; a.bias = bias;
@@ -550,6 +587,21 @@ extern "C" int lpf_pair_scatter_add_f32(int64_t bs, int32_t D, const int64_t *ba
     hipStream_t s = static_cast<hipStream_t>(stream);
     PT_DISPATCH(D, hipLaunchKernelGGL(pair_scatter_kernel<GG>, dim3(pt_blocks(bs, 4 * (64 / GG))), dim3(PT_THREADS), 0, s,
                                       bs, (int)D, batch, batch_ld, n_rows, X, ldx, dmul, ldm, dsum, lds, dX, lddx));
+    LPF_CHECK_LAUNCH();
+    return LPF_OK;
+}
+
+extern "C" int lpf_segment_rows_sum_f32(int64_t n, int32_t D, const int32_t *keys_sorted, const int64_t *order,
+                                        const float *src, int64_t lds, float *dst, int64_t ldd, void *stream) {
+    if (n == 0) return LPF_OK;
+    LPF_REQUIRE(n > 0 && keys_sorted && order && src && dst && lds >= D && ldd >= D && ((lds | ldd) & 3) == 0 &&
+                lpf_aligned16(src) && lpf_aligned16(dst));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PT_DISPATCH(D, {
+        const int per_block = (PT_THREADS / 64) * (64 / GG);
+        hipLaunchKernelGGL(segment_sum_kernel<GG>, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(PT_THREADS), 0, s,
+                           n, keys_sorted, order, src, lds, dst, ldd);
+    });
     LPF_CHECK_LAUNCH();
     return LPF_OK;
 }

@@ -509,14 +509,35 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
                 0, tid * bs + e_pair.long(), torch.ones(idx.numel(), dtype=torch.int64, device=dev)).view(3, bs)
         else:
             cnt = (tp[:, 1:] - tp[:, :-1]).long()
-        tot = [int(v) for v in cnt.sum(dim=1).tolist()]
+        # The DISTINCT nodes of the batch's entries (a few tens of thousands of the graph's nodes; a handful for random
+        # negatives): the node half of lin_r, its two gradient products and the gradient of its row gather run over those
+        # rows only, and the entries' gradients meet per node in the sorted order found here (no atomics).  Their number
+        # comes back to the host with the per-type totals below: one read-back for both.
+        n_kept = int(e_node.numel())
+        if n_kept > 0:
+            keys, order = torch.sort(e_node, stable=True)
+            head = torch.ones(n_kept, dtype=torch.bool, device=dev)
+            head[1:] = keys[1:] != keys[:-1]
+            uid = torch.cumsum(head, 0) - 1                       # rank of the node of each sorted position
+            back = torch.cat([cnt.sum(dim=1), uid[-1:] + 1]).tolist()
+        else:
+            back = cnt.sum(dim=1).tolist() + [0]
+        tot, n_uniq = [int(v) for v in back[:3]], int(back[3])
         tbase = [0, tot[0], tot[0] + tot[1], tot[0] + tot[1] + tot[2]]
         seg = torch.zeros(3, bs + 1, dtype=torch.int64, device=dev)
         torch.cumsum(cnt, dim=1, out=seg[:, 1:])
         seg += torch.tensor(tbase[:3], dtype=torch.int64, device=dev)[:, None]
         # (copies: the export arrays live in per-stream workspaces that the next forward overwrites, and the backward
         #  pass of THIS forward still needs them)
-        e_node = e_node.to(torch.int32).clone()
+        if n_kept > 0:
+            nodes_u = torch.zeros(n_uniq, dtype=torch.int64, device=dev).scatter_(0, uid, keys.long())   # (a run writes one value)
+            e_node = torch.empty(n_kept, dtype=torch.int32, device=dev)
+            e_node[order] = uid.to(torch.int32)                   # entries -> rows of the compact node table
+            node_sort = (uid.to(torch.int32), order)
+        else:
+            nodes_u = torch.zeros(1, dtype=torch.int64, device=dev)          # (a valid row for the kernels' pointers)
+            e_node = e_node.to(torch.int32).clone()
+            node_sort = None
         e_pa, e_pb = e_pa.clone(), e_pb.clone()
         counts = cnt.float()
     # ---- positional encodings + attention (link_transformer.py:182-211, layers.py:161-224): dedicated kernels
@@ -524,7 +545,7 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     encoders = [model.ppr_encoder_cn, getattr(model, "ppr_encoder_onehop", None),
                 getattr(model, "ppr_encoder_non1hop", None)][:n_types]
     w_rx, w_rp = att.lin_r.weight[:, :d], att.lin_r.weight[:, d:]
-    z = linear(x_node, w_rx, att.lin_r.bias)                        # node half of lin_r, once per node
+    z = linear(x_node.index_select(0, nodes_u), w_rx, att.lin_r.bias)     # node half of lin_r, once per DISTINCT node
     # q = lin_l(x_a) + lin_l(x_b) (:212-215) = lin_l.weight (x_a + x_b) + 2 lin_l.bias: one [BS, D] x [D, D] product per
     # batch instead of an N x D x D one per encoder pass (forward, dX and dW: three of them, ~0.2 ms each on collab-like)
     q = linear(PairGatherFn.apply(x_node, batch, False), att.lin_l.weight, 2.0 * att.lin_l.bias)
@@ -536,7 +557,7 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     gams = torch.stack([e.norm.weight for e in encoders])
     bets = torch.stack([e.norm.bias for e in encoders])
     out = PairAttentionFn.apply(z, q, att.att.reshape(-1), att.bias, wfold, bfold, w1s, b1s, gams, bets, e_node, e_pa,
-                                e_pb, seg, tuple(tbase))
+                                e_pb, seg, tuple(tbase), node_sort)
     layer = model.att_layers[0]
     out = layer_norm(out, layer.post_att_norm.weight, layer.post_att_norm.bias)
     out = F.dropout(out, p=layer.dropout, training=True)
@@ -590,7 +611,9 @@ class PairAttentionFn(torch.autograd.Function):
     lpf_gemm_f32 / lpf_gemm_tn_f32 for the entry-sized products (dH = dK Wfold, dWfold = dK^T H)."""
 
     @staticmethod
-    def forward(ctx, z, q, att, bias, wfold, bfold, w1s, b1s, gams, bets, e_node, e_pa, e_pb, seg, tbase):
+    def forward(ctx, z, q, att, bias, wfold, bfold, w1s, b1s, gams, bets, e_node, e_pa, e_pb, seg, tbase, node_sort=None):
+        """z: rows the entries' ``e_node`` index (the node table, or -- forward_train -- its rows for the batch's distinct
+        nodes); ``node_sort`` = (sorted e_node, the permutation that sorts it) when the caller has them."""
         lib, st = _lib.hip(), _stream(z)
         z, q = z.contiguous(), q.contiguous()
         att, bias = att.contiguous(), bias.contiguous()
@@ -618,7 +641,7 @@ class PairAttentionFn(torch.autograd.Function):
                                                    st), "lpf_pair_attention_train_fwd_f32")
         ctx.save_for_backward(z, q, att, bias, wfold, w1s, b1s, gams, bets, e_node, e_pa, e_pb, seg, h, kp, out, score,
                               pmax, pinv)
-        ctx.tbase = tbase
+        ctx.tbase, ctx.node_sort = tbase, node_sort
         return out
 
     @staticmethod
@@ -635,8 +658,14 @@ class PairAttentionFn(torch.autograd.Function):
         dab = torch.empty(2, d, dtype=torch.float32, device=dev)
         check(lib.lpf_pair_attention_train_bwd_f32(
             bs, n, d, ptr(seg), ptr(e_node), ptr(z), z.stride(0), ptr(kp), d, ptr(q), d, ptr(att), ptr(bias), ptr(out), d,
-            ptr(score), ptr(pmax), ptr(pinv), ptr(dout), d, ptr(dk), d, ptr(dz), dz.stride(0), ptr(dq), d, ptr(dab),
+            ptr(score), ptr(pmax), ptr(pinv), ptr(dout), d, ptr(dk), d, None, dz.stride(0), ptr(dq), d, ptr(dab),
             ptr(_partial_ws(d, 2, dev)), st), "lpf_pair_attention_train_bwd_f32")
+        if n > 0:
+            # dZ[v] = sum of dK over the entries of node v, run by run of the sorted node list (no atomics: 4 D of them per
+            # entry were more than half of the kernel above; and dZ is now the same bits from run to run)
+            keys, order = ctx.node_sort if ctx.node_sort is not None else torch.sort(e_node, stable=True)
+            check(lib.lpf_segment_rows_sum_f32(n, d, ptr(keys), ptr(order), ptr(dk), d, ptr(dz), dz.stride(0), st),
+                  "lpf_segment_rows_sum_f32")
         n_t = wfold.shape[0]
         dwfold = torch.zeros_like(wfold)
         dbfold = torch.zeros(n_t, d, dtype=torch.float32, device=dev)
@@ -658,7 +687,7 @@ class PairAttentionFn(torch.autograd.Function):
                                             ptr(g5[t]), ptr(_partial_ws(d, 5, dev)), st), "lpf_pe_hidden_bwd_f32")
         dw1s = torch.stack([g5[:, 0], g5[:, 1]], dim=2)                    # [T, D, 2]
         return (dz, dq, dab[0], dab[1], dwfold, dbfold, dw1s, g5[:, 2], g5[:, 3], g5[:, 4], None, None, None, None,
-                None)
+                None, None)
 
 
 def score_train(score_func, x):
