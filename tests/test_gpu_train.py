@@ -415,3 +415,32 @@ def test_attention_stage_training_kernels_match_fp64_autograd(dim):
     for name, g, want in zip(names, got, (p.grad for p in P)):
         e, scale = float((g.double() - want).abs().max()), max(1.0, float(want.abs().max()))
         assert e <= 2e-4 * scale, (name, e, scale)
+
+
+def test_training_step_with_no_selected_node_at_all():
+    """Thresholds nothing passes: every pair's attention output is the bias, the entry arrays are empty, the node table of
+    the attention stage has no row to hold -- forward, backward and an optimiser step run, every gradient is finite, and
+    the parameters the empty stage cannot reach (PE encoders, att, lin_r) receive zeros or None, not garbage."""
+    from lpformer_amd import data as D
+    n = 600
+    ei, _ = D.chung_lu_graph(n, 2400, gamma=2.4, seed=4)
+    x = np.random.default_rng(2).standard_normal((n, 64)).astype(np.float32)
+    data = D.build_data(ei, x, n, eps=1e-3)
+    cfg = D.train_args_for(dict(thresholds=(0.99, 0.99, 0.99), dim=64, gnn_layers=2, residual=True))
+    cfg.update(att_drop=0.1, dropout=0.1, gnn_drop=0.1, feat_drop=0.1)
+    torch.manual_seed(0)
+    model = lpformer_amd.LinkTransformer(cfg, data, device=DEV).to(DEV).train()
+    score = lpformer_amd.mlp_score(model.out_dim, model.out_dim, 1, 2, 0.1).to(DEV).train()
+    opt = torch.optim.Adam(list(model.parameters()) + list(score.parameters()), lr=1e-3)
+    batch = torch.from_numpy(D.sample_pairs(ei, n, 256, seed=9)).to(DEV)
+    assert all(info is None or info[0].shape[1] == 0 for info in model.eval().compute_node_mask(batch))
+    model.train()
+    loss = -torch.log(score(model(batch)) + 1e-6).mean()
+    loss.backward()
+    assert torch.isfinite(loss)
+    for name, p in list(model.named_parameters()) + list(score.named_parameters()):
+        assert p.grad is None or torch.isfinite(p.grad).all(), name
+    for name, p in model.named_parameters():
+        if name.startswith("ppr_encoder") or name.startswith("att_layers.0.att.lin_r"):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+    opt.step()
