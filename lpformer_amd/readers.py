@@ -6,15 +6,21 @@ The dict has the schema the model reads on this package's CSR
 ``train_pos, train_pos_val, valid_pos, valid_neg, test_pos, test_neg`` the loops use (src/train/train_model.py,
 src/train/testing.py).
 
-PARITY UNPINNED for the file layouts: no dataset is available in the build container (no network), so the on-disk layout
-of the OGB link-property datasets is taken from the public OGB documentation --
+PARITY: pinned against the reference's own readers for everything the REFERENCE does -- tests/golden/make_reader_golden.py
+runs ``read_data_planetoid`` and ``read_data_ogb`` unmodified on tiny datasets (tests/golden/planetoid_tiny/, ogb_tiny/) and
+tests/test_readers.py compares every split tensor, the features, both adjacencies, both masks and both PPR matrices (bit
+for bit), for collab (year filter, weight-summing symmetrisation, validation edges in the test graph), ppa (HeaRT index
+files), ddi (feature-less table, quartered HeaRT validation set) and citation2 (source / target splits, directed PPR).
+UNPINNED is the one step the reference delegates to the ``ogb`` package, which is not available offline: raw files ->
+graph object.  Its layout is taken from the public OGB documentation --
 
     <root>/<name with '-' -> '_'>/raw/{edge, num-node-list, node-feat, edge_weight, edge_year}.csv.gz
     <root>/<name ...>/split/<time | throughput | target>/{train, valid, test}.pt      (torch-pickled dicts)
 
--- and the readers are tested on synthetic files written in that layout (tests/test_readers.py).  The HeaRT text
-layout (``{train,valid,test}_pos.txt``, ``{valid,test}_neg.txt``, ``gnn_feature``) is the one the reference itself
-parses (read_datasets.py:160-215).  What each step does follows the reference line by line and is cited there.
+-- with the inverse edges appended for the undirected datasets, and restated once more in the generator's stand-in
+dataset class.  The HeaRT text layout (``{train,valid,test}_pos.txt``, ``{valid,test}_neg.txt``, ``gnn_feature``) is the
+one the reference itself parses (read_datasets.py:160-215).  What each step does follows the reference line by line and
+is cited there.
 """
 from __future__ import annotations
 

@@ -265,8 +265,23 @@ def coalesce(edge_index, edge_attr=None, num_nodes=None, reduce="add"):
     return torch.stack([key // N, key % N])
 
 
-def to_undirected(edge_index, num_nodes=None):
-    return coalesce(torch.cat([edge_index, edge_index.flip(0)], dim=1), num_nodes=num_nodes)
+def to_undirected(edge_index, edge_attr=None, num_nodes=None, reduce="add"):
+    """torch_geometric.utils.to_undirected (2.2.0): both directions of every edge, duplicates merged, sorted by
+    (row, col); with ``edge_attr`` the attributes of merged entries are reduced ("add": summed) and the pair
+    (edge_index, edge_attr) is returned (src/util/read_datasets.py:96,276)."""
+    if isinstance(edge_attr, int):      # (the positional num_nodes of the old two-argument call)
+        edge_attr, num_nodes = None, edge_attr
+    both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    if edge_attr is None:
+        return coalesce(both, num_nodes=num_nodes)
+    if reduce not in ("add", "sum"):
+        raise NotImplementedError(reduce)
+    N = int(both.max()) + 1 if num_nodes is None else num_nodes
+    key = both[0].long() * N + both[1].long()
+    uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
+    attr = torch.cat([edge_attr, edge_attr], dim=0)
+    out = torch.zeros((uniq.numel(),) + tuple(attr.shape[1:]), dtype=attr.dtype).index_add_(0, inv, attr)
+    return torch.stack([uniq // N, uniq % N]), out
 
 
 # --------------------------------------------------------------------------- registration
@@ -275,6 +290,13 @@ def _mod(name, **attrs):
     m.__dict__.update(attrs)
     sys.modules[name] = m
     return m
+
+
+def degree(index, num_nodes=None, dtype=None):
+    """torch_geometric.utils.degree: occurrences of every node id in ``index`` (src/util/read_datasets.py:116,240)."""
+    n = int(index.max()) + 1 if num_nodes is None else int(num_nodes)
+    out = torch.zeros(n, dtype=dtype or torch.float32, device=index.device)
+    return out.scatter_add_(0, index.long(), torch.ones(index.numel(), dtype=out.dtype, device=index.device))
 
 
 def install():
@@ -290,7 +312,7 @@ def install():
     tg.nn.dense = _mod("torch_geometric.nn.dense")
     tg.nn.dense.linear = _mod("torch_geometric.nn.dense.linear", Linear=Linear)
     tg.nn.inits = _mod("torch_geometric.nn.inits", glorot=glorot, zeros=zeros)
-    tg.utils = _mod("torch_geometric.utils", softmax=softmax, coalesce=coalesce, to_undirected=to_undirected)
+    tg.utils = _mod("torch_geometric.utils", softmax=softmax, coalesce=coalesce, to_undirected=to_undirected, degree=degree)
     tg.typing = _mod("torch_geometric.typing", OptTensor=Optional[Tensor])
     tg.transforms = _mod("torch_geometric.transforms")
 

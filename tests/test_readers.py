@@ -5,6 +5,7 @@ import gzip
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from lpformer_amd import readers as R
@@ -153,3 +154,93 @@ def test_read_planetoid_layout(tmp_path):
     assert d["train_pos"].shape[0] == n                            # the self loop is gone
     assert d["adj_t"].col.size == 2 * n and d["full_adj_t"] is d["adj_t"] and d["ppr_test"] is d["ppr"]
     assert d["valid_neg"].shape == (10, 5, 2) and d["test_neg"].shape == (12, 5, 2)
+
+
+def test_planetoid_reader_matches_the_reference_reader():
+    """``readers.read_data_planetoid`` against what the REFERENCE's own ``read_data_planetoid``
+    (src/util/read_datasets.py:150-254, run unmodified by tests/golden/make_reader_golden.py) returned for the same files
+    -- tests/golden/planetoid_tiny/ in the HeaRT text layout: a self loop in the training file, nodes only a validation /
+    test positive names, the feature tensor, the HeaRT negative samples.  Node count, every split tensor, the features,
+    the propagation matrix, the typing adjacency and the PPR matrix (indices AND values, bit for bit)."""
+    from tests.golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "reader_planetoid.npz"))
+    src = os.path.join(GOLDEN_DIR, "planetoid_tiny")
+    torch.manual_seed(11)                       # (the reference draws train_pos_val from the global generator first thing)
+    d = R.read_data_planetoid(src, "tinycora", eps=1e-4)
+    n = int(z["num_nodes"])
+    assert d["num_nodes"] == n
+    for k in ("train_pos", "valid_pos", "test_pos", "valid_neg", "test_neg", "train_pos_val"):
+        np.testing.assert_array_equal(d[k].numpy(), z[k], err_msg=k)
+    np.testing.assert_array_equal(d["x"].numpy(), z["x"])
+
+    def coo(c):
+        rows = np.repeat(np.arange(c.n, dtype=np.int64), np.diff(c.rowptr))
+        return rows, c.col.astype(np.int64), c.val
+    # adj_t: SparseTensor.from_edge_index(edge_index, ones) -- rows sorted, columns in file order within a row there;
+    # sorted by (row, col) here: compared as sets of (row, col, value)
+    r, c, v = coo(d["adj_t"])
+    want = sorted(zip(z["adj_row"].tolist(), z["adj_col"].tolist(), z["adj_val"].tolist()))
+    assert sorted(zip(r.tolist(), c.tolist(), v.tolist())) == want
+    assert d["full_adj_t"] is d["adj_t"] or coo(d["full_adj_t"])[1].tolist() == c.tolist()
+    r, c, _ = coo(d["adj_mask"])
+    np.testing.assert_array_equal(np.stack([r, c]), z["mask_index"])            # (coalesced: sorted on both sides)
+    assert (z["mask_val"] == 1).all()
+    np.testing.assert_array_equal(np.diff(d["adj_t"].rowptr).astype(np.float32), z["degree"])
+    r, c, v = coo(d["ppr"])
+    np.testing.assert_array_equal(np.stack([r, c]), z["ppr_index"])
+    np.testing.assert_array_equal(v.view(np.uint32), z["ppr_val"].view(np.uint32))
+    assert d["ppr_test"] is d["ppr"]
+    # --heart: the sampled negatives replace the files' (:243-250)
+    torch.manual_seed(11)
+    h = R.read_data_planetoid(src, "tinycora", eps=1e-4, heart_dir=os.path.join(src, "heart"))
+    np.testing.assert_array_equal(h["valid_neg"].numpy(), z["heart_valid_neg"])
+    np.testing.assert_array_equal(h["test_neg"].numpy(), z["heart_test_neg"])
+    np.testing.assert_array_equal(h["train_pos"].numpy(), z["train_pos"])
+
+
+OGB_CASES = [("ogbl-collab", True, False), ("ogbl-collab", False, False), ("ogbl-ppa", False, True), ("ogbl-ddi", False, True),
+             ("ogbl-ddi", False, False), ("ogbl-citation2", False, False)]
+
+
+@pytest.mark.parametrize("name,val_in_test,heart", OGB_CASES, ids=[f"{c[0]}-val{int(c[1])}-heart{int(c[2])}" for c in OGB_CASES])
+def test_ogb_reader_matches_the_reference_reader(name, val_in_test, heart):
+    """``readers.read_data_ogb`` on tests/golden/ogb_tiny/ (four tiny datasets in the raw OGB layout) against what the
+    REFERENCE's ``read_data_ogb`` (src/util/read_datasets.py:20-148 with ``filter_by_year`` :259-280, run unmodified by
+    tests/golden/make_reader_golden.py) made of the graph objects built from the same files: the year filter and the
+    weight-summing symmetrisation of collab, validation edges in the test graph (given twice / reversed: coalesced before
+    they are appended), ppa's HeaRT index files, ddi's feature-less table and its quartered validation set, citation2's
+    source / target splits, its symmetrised adjacency with reciprocal citations summed and its PPR over the DIRECTED list.
+    What stays an assumption is the step before: raw files -> graph object, the OGB package's (documented) behaviour,
+    restated in the generator's ``_OgbDataset``."""
+    from tests.golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "reader_ogb.npz"))
+    tag = f"{name}|{int(val_in_test)}|{int(heart)}|"
+    root = os.path.join(GOLDEN_DIR, "ogb_tiny")
+    torch.manual_seed(5)        # (train_pos_val, ddi's xavier table and its validation subset come from the global generator)
+    d = R.read_data_ogb(root, name, eps=1e-3, dim=16, use_val_in_test=val_in_test,
+                        heart_dir=os.path.join(root, "heart") if heart else None)
+    n = int(z[tag + "num_nodes"])
+    assert d["num_nodes"] == n
+    for k in ("train_pos", "train_pos_val", "valid_pos", "valid_neg", "test_pos", "test_neg"):
+        np.testing.assert_array_equal(d[k].numpy(), z[tag + k], err_msg=k)
+    np.testing.assert_array_equal(d["x"].detach().numpy(), z[tag + "x"])
+
+    def dense(c):
+        m = np.zeros((n, n))
+        np.add.at(m, (np.repeat(np.arange(n), np.diff(c.rowptr)), c.col.astype(np.int64)), 1.0 if c.val is None else c.val)
+        return m
+    for key in ("adj_t", "full_adj_t"):         # (the reference keeps duplicate entries where a list has them: compared summed)
+        r, c, v = z[tag + key]
+        want = np.zeros((n, n))
+        np.add.at(want, (r.astype(np.int64), c.astype(np.int64)), v)
+        np.testing.assert_array_equal(dense(d[key]), want, err_msg=key)
+    for key in ("adj_mask", "full_adj_mask"):
+        c = d[key]
+        got = np.stack([np.repeat(np.arange(n, dtype=np.int64), np.diff(c.rowptr)), c.col.astype(np.int64)])
+        np.testing.assert_array_equal(got, z[tag + key + "_index"], err_msg=key)
+        assert (z[tag + key + "_val"] == 1).all()
+    for key in ("ppr", "ppr_test"):
+        c = d[key]
+        got = np.stack([np.repeat(np.arange(n, dtype=np.int64), np.diff(c.rowptr)), c.col.astype(np.int64)])
+        np.testing.assert_array_equal(got, z[tag + key + "_index"], err_msg=key)
+        np.testing.assert_array_equal(c.val.view(np.uint32), z[tag + key + "_val"].view(np.uint32), err_msg=key)
