@@ -36,6 +36,9 @@ class GraphedScorer:
         (default: a new one).  The model's per-stream workspaces behind it are the scorer's: give it a stream nothing
         else scores on while the scorer is in use (a caller that rebuilds scorers often hands the same few streams back
         instead of leaving a set of workspaces behind for every new one)."""
+        if getattr(model, "_multi_head", False):
+            raise NotImplementedError("recorded plans and captured graphs replay the single-head inference launches; a "
+                                      "model with num_heads > 1 scores through model.score_pairs(...)")
         self.model, self.score_func, self.h = model, score_func, h
         self.test_set, self.logits = test_set, logits
         dev = model.device

@@ -690,10 +690,20 @@ class LinkTransformer(nn.Module):
         self.tail_precision = "f32"
 
     # ---------------------------------------------------------------------------------- support checks
-    def _check_supported(self, train_ok: bool = False):
-        if self.num_layers != 1 or self.train_args["num_heads"] != 1:
-            raise NotImplementedError("the HIP path covers trans_layers=1, num_heads=1 (every shipped script); the "
-                                      "reference is shape-inconsistent for heads>1 with layers>1")
+    @property
+    def _multi_head(self) -> bool:
+        """num_heads > 1 (layers.py:129-135,180-224): the head-by-head path of lpformer_amd/train.py ``pair_stage`` -- the
+        training step's kernels, one pass per head over the shared selection -- serves evaluation too; the one-launch
+        inference kernels (select4 / pair_rows / tail_chain, the folded score head, recorded plans) are single-head."""
+        return int(self.train_args["num_heads"]) > 1
+
+    def _check_supported(self, train_ok: bool = False, heads_ok: bool = False):
+        if self.num_layers != 1:
+            raise NotImplementedError("trans_layers = 1 only (every shipped script; with more layers the reference is "
+                                      "shape-consistent for two layers and one head only, link_transformer.py:55-62)")
+        if self._multi_head and not heads_ok:
+            raise NotImplementedError("num_heads > 1 runs through forward / calc_pairwise / pair_features / score_pairs "
+                                      "(head by head); this entry point is built on the single-head inference kernels")
         if self.dim not in (32, 64, 128, 256):
             raise NotImplementedError("dim must be one of 32, 64, 128, 256 for the gfx950 kernels")
         if self.training and not train_ok:
@@ -834,7 +844,7 @@ class LinkTransformer(nn.Module):
         exchange) or ROW-SHARDED: a rank transforms and aggregates only its block of node rows and the transformed
         rows are all-gathered once per layer (RCCL over xGMI), plus one all-gather of the output.
         ``_layers_out`` (tests): a list that receives every layer's input and the final output."""
-        self._check_supported()
+        self._check_supported(heads_ok=True)
         with torch.no_grad():
             a_hat = self._device_graph("prop", self._data_obj("adj", test_set) if adj is None else adj)
             n_layers = len(self.node_encoder.gnn_encoder.convs)
@@ -1555,7 +1565,7 @@ class LinkTransformer(nn.Module):
         """Reference-format selection result (:214-276): three tuples (ix int64 [2,n], ppr_src, ppr_tgt) for CN,
         1-hop and >1-hop nodes (None for >1-hop in "1-hop" mode, for both in "cn" mode), each sorted by (pair
         position, node)."""
-        self._check_supported()
+        self._check_supported(heads_ok=True)
         with torch.no_grad():
             batch = self._prep_batch(batch)
             s = self._select(batch, test_set, adj)
@@ -1942,8 +1952,13 @@ class LinkTransformer(nn.Module):
     def calc_pairwise(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False, _out=None):
         """Pairwise branch (:132-178): selection -> PE + attention -> counts -> ``pairwise_lin``.
         Returns ([BS, D], att_weights or None)."""
-        self._check_supported()
+        self._check_supported(heads_ok=True)
         _require_gpu(X_node, "calc_pairwise")
+        if self._multi_head:
+            pw = self._pair_stage_heads(batch, X_node, test_set, adj_mask, return_weights)[1]
+            if _out is not None:
+                _out.copy_(pw)
+            return (pw if _out is None else _out), None
         with torch.no_grad():
             batch = self._prep_batch(batch)
             for _attempt in range(3):
@@ -2014,12 +2029,12 @@ class LinkTransformer(nn.Module):
         expression (src/train/testing.py:29-31,113-117) -- with the three Linear layers around the module boundary
         folded into one (``_score_fold``): probabilities (or logits) of shape [BS].  Falls back to the unfolded
         modules when the score head is not the two-layer MLP every script uses."""
-        self._check_supported()
+        self._check_supported(heads_ok=True)
         _require_gpu(X_node, "score_pairs")
         two_layer = (len(score_func.lins) == 2 and score_func.lins[1].out_features == 1 and
                      len(self.elementwise_lin.linears) == 2 and len(self.pairwise_lin.linears) == 2 and
                      not (score_func.training and score_func.dropout > 0))
-        if not two_layer:
+        if not two_layer or self._multi_head:
             feats = self.pair_features(batch, X_node, test_set=test_set, adj_mask=adj_mask)
             return score_func.logits(feats) if logits else score_func(feats)
         self._fold_memo = None
@@ -2147,18 +2162,29 @@ class LinkTransformer(nn.Module):
         + ``elementwise_lin`` + ``calc_pairwise`` (src/train/testing.py:96-121)."""
         if self.training:
             # autograd graph on the device: GEMMs, aggregation and selection through the C ABI (lpformer_amd/train.py)
-            self._check_supported(train_ok=True)
+            self._check_supported(train_ok=True, heads_ok=True)
             if return_weights:
                 raise NotImplementedError("return_weights is an evaluation-time debugging aid (layers.py:69-75)")
             from . import train as lpf_train
             return lpf_train.forward_train(self, batch, adj_prop, adj_mask, test_set)
-        self._check_supported()
+        self._check_supported(heads_ok=True)
         with torch.no_grad():
             batch = self._prep_batch(batch)
             x_node = self._propagate_reusing(adj_prop, test_set)
             out = self.pair_features(batch, x_node, test_set=test_set, adj_mask=adj_mask,
                                      return_weights=return_weights)
             return out
+
+    def _pair_stage_heads(self, batch, X_node, test_set, adj_mask, return_weights=False):
+        """Evaluation-mode pair stage of a multi-head model: lpformer_amd/train.py ``pair_stage`` with every dropout and the
+        random attention drop off, no autograd graph -> (elementwise [BS, D], pairwise [BS, D])."""
+        if return_weights:
+            raise NotImplementedError("return_weights (layers.py:69-75: the heads' weights averaged, a debugging aid) is "
+                                      "available for num_heads = 1")
+        from . import train as lpf_train
+        with torch.no_grad():
+            return lpf_train.pair_stage(self, _as_f32_rows(X_node), self._prep_batch(batch), adj_mask, test_set,
+                                        training=False)
 
     def _propagate_reusing(self, adj_prop, test_set):
         """``propagate`` for ``forward`` in eval mode.  The reference's evaluation loop calls ``model(edges)`` per batch
@@ -2185,7 +2211,11 @@ class LinkTransformer(nn.Module):
     @_on_device
     def pair_features(self, batch, X_node, test_set=False, adj_mask=None, return_weights=False):
         """[elementwise_lin(X[a]*X[b]) | calc_pairwise(...)] written straight into one [BS, 2D] buffer."""
-        self._check_supported()
+        self._check_supported(heads_ok=True)
+        if self._multi_head:
+            ew, pw = self._pair_stage_heads(batch, X_node, test_set, adj_mask, return_weights)
+            comb = torch.cat([ew, pw], dim=-1)
+            return (comb, None) if return_weights else comb
         with torch.no_grad():
             d = self.dim
             batch = self._prep_batch(batch)

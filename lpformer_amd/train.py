@@ -409,7 +409,7 @@ def layer_norm(x, weight, bias):
     return LayerNormFn.apply(x, weight, bias)
 
 
-def _mlp(mod, x):
+def _mlp(mod, x, training: bool = True):
     """The reference's MLP (other_models.py:125-138): (Linear -> LayerNorm -> ReLU -> dropout)* -> Linear."""
     for lin in mod.linears[:-1]:
         x = linear(x, lin.weight, lin.bias)
@@ -419,7 +419,7 @@ def _mlp(mod, x):
             if mod.norm is not None:
                 x = layer_norm(x, mod.norm.weight, mod.norm.bias)
             x = F.relu(x)
-        x = F.dropout(x, p=mod.dropout, training=True)
+        x = F.dropout(x, p=mod.dropout, training=training)
     last = mod.linears[-1]
     return linear(x, last.weight, last.bias)
 
@@ -449,9 +449,15 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     """``LinkTransformer.forward`` in training mode (link_transformer.py:82-178 with the dropouts of
     node_encoder.py:40, other_models.py:69, layers.py:80 and the random attention drop of :257-260) -> [BS, 2D] with
     an autograd graph."""
-    dev = model.device
     batch = model._prep_batch(batch)
-    bs, d = batch.shape[1], model.dim
+    x_node = encoder_train(model, adj_prop, test_set)
+    ew, pw = pair_stage(model, x_node, batch, adj_mask, test_set, training=True)
+    return torch.cat([ew, pw], dim=-1)
+
+
+def encoder_train(model, adj_prop=None, test_set=False):
+    """The node encoder in training mode (node_encoder.py:35-44, other_models.py:61-76, link_transformer.py:127) ->
+    x_node [N, D] with an autograd graph."""
     enc = model.node_encoder.gnn_encoder
     a_hat = model._device_graph("prop", model._data_obj("adj", test_set) if adj_prop is None else adj_prop)
     # ---- encoder (node_encoder.py:35-44, other_models.py:61-76, link_transformer.py:127)
@@ -480,8 +486,19 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
                 xi = F.relu(xi)
         x = x + xi if (enc.residual and x.shape[-1] == xi.shape[-1]) else xi
     x_node = layer_norm(x, model.gnn_norm.weight, model.gnn_norm.bias)
-    x_node = x_node.contiguous()
-    ew = _mlp(model.elementwise_lin, PairGatherFn.apply(x_node, batch, True))            # x_a * x_b (:101-102)
+    return x_node.contiguous()
+
+
+def pair_stage(model, x_node, batch, adj_mask=None, test_set=False, training: bool = True):
+    """Everything behind the encoder (link_transformer.py:100-107,132-178): the elementwise branch, the selection, the
+    positional encodings, the attention layer -- EVERY HEAD of it (layers.py:193-224: ``lin_l`` / ``lin_r`` produce H
+    blocks of D features, head h attends with its block, its ``att`` row and its slice of the bias; the blocks are
+    concatenated, :180-183) --, the count features and ``pairwise_lin`` -> (elementwise [BS, D], pairwise [BS, D]).
+    ``training``: dropouts and the random attention drop on, an autograd graph is built when gradients are enabled;
+    off: the evaluation-mode forward of a model the one-launch inference kernels do not cover (num_heads > 1)."""
+    dev = model.device
+    bs, d = batch.shape[1], model.dim
+    ew = _mlp(model.elementwise_lin, PairGatherFn.apply(x_node, batch, True), training)  # x_a * x_b (:101-102)
     # ---- selection (integer work, no gradient) in the reference's layout, then the random attention drop
     n_types = {"all": 3, "1-hop": 2, "cn": 1}[model.mask]
     with torch.no_grad():
@@ -491,7 +508,7 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
         n_all = sum(tot)
         e_pair, e_node = s["sel_pair"][:n_all], s["sel_node"][:n_all]
         e_pa, e_pb = s["sel_pa"][:n_all], s["sel_pb"][:n_all]
-        if model.att_drop > 0 and n_all > 0:
+        if training and model.att_drop > 0 and n_all > 0:
             # drop_pairwise (link_transformer.py:322-337): ceil(n (1 - p)) entries of a random permutation survive, CN
             # and 1-hop together, >1-hop separately (:257-260).  The survivors are kept in (type, pair) order -- the
             # reference leaves them in permuted order, which only the summation order of its scatters can see.
@@ -544,23 +561,32 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
     att = model.att_layers[0].att
     encoders = [model.ppr_encoder_cn, getattr(model, "ppr_encoder_onehop", None),
                 getattr(model, "ppr_encoder_non1hop", None)][:n_types]
-    w_rx, w_rp = att.lin_r.weight[:, :d], att.lin_r.weight[:, d:]
-    z = linear(x_node.index_select(0, nodes_u), w_rx, att.lin_r.bias)     # node half of lin_r, once per DISTINCT node
-    # q = lin_l(x_a) + lin_l(x_b) (:212-215) = lin_l.weight (x_a + x_b) + 2 lin_l.bias: one [BS, D] x [D, D] product per
-    # batch instead of an N x D x D one per encoder pass (forward, dX and dW: three of them, ~0.2 ms each on collab-like)
-    q = linear(PairGatherFn.apply(x_node, batch, False), att.lin_l.weight, 2.0 * att.lin_l.bias)
-    # the second PE Linear folded into the PE half of lin_r: k_e = Z[v] + (W_rp W2_t) h_e + W_rp (2 b2_t)
-    wfold = torch.stack([linear(w_rp, e.linears[1].weight.t()) for e in encoders])
-    bfold = torch.stack([linear(2.0 * e.linears[1].bias[None, :], w_rp)[0] for e in encoders])
+    heads = int(model.train_args["num_heads"])
+    x_u = x_node.index_select(0, nodes_u)                           # rows of the batch's DISTINCT nodes
+    x_sum = PairGatherFn.apply(x_node, batch, False)                # x_a + x_b
     w1s = torch.stack([e.linears[0].weight for e in encoders])
     b1s = torch.stack([e.linears[0].bias for e in encoders])
     gams = torch.stack([e.norm.weight for e in encoders])
     bets = torch.stack([e.norm.bias for e in encoders])
-    out = PairAttentionFn.apply(z, q, att.att.reshape(-1), att.bias, wfold, bfold, w1s, b1s, gams, bets, e_node, e_pa,
-                                e_pb, seg, tuple(tbase), node_sort)
+    att_rows = att.att.reshape(heads, d)
+    outs = []
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        w_r = att.lin_r.weight[sl]
+        w_rx, w_rp = w_r[:, :d], w_r[:, d:]
+        z = linear(x_u, w_rx, att.lin_r.bias[sl])                   # node half of lin_r, once per DISTINCT node
+        # q = lin_l(x_a) + lin_l(x_b) (:212-215) = lin_l.weight (x_a + x_b) + 2 lin_l.bias: one [BS, D] x [D, D] product
+        # per batch instead of an N x D x D one per encoder pass
+        q = linear(x_sum, att.lin_l.weight[sl], 2.0 * att.lin_l.bias[sl])
+        # the second PE Linear folded into the PE half of lin_r: k_e = Z[v] + (W_rp W2_t) h_e + W_rp (2 b2_t)
+        wfold = torch.stack([linear(w_rp, e.linears[1].weight.t()) for e in encoders])
+        bfold = torch.stack([linear(2.0 * e.linears[1].bias[None, :], w_rp)[0] for e in encoders])
+        outs.append(PairAttentionFn.apply(z, q, att_rows[h], att.bias[sl], wfold, bfold, w1s, b1s, gams, bets, e_node,
+                                          e_pa, e_pb, seg, tuple(tbase), node_sort))
+    out = outs[0] if heads == 1 else torch.cat(outs, dim=1)
     layer = model.att_layers[0]
     out = layer_norm(out, layer.post_att_norm.weight, layer.post_att_norm.bias)
-    out = F.dropout(out, p=layer.dropout, training=True)
+    out = F.dropout(out, p=layer.dropout, training=training)
     # ---- count features + pairwise_lin (link_transformer.py:170-177, 340-356)
     if n_types == 3:
         cf = torch.stack([counts[0], counts[1], counts[2], counts[0] + counts[1]], dim=1)
@@ -568,8 +594,8 @@ def forward_train(model, batch, adj_prop=None, adj_mask=None, test_set=False):
         cf = torch.stack([counts[0], counts[1], counts[0] + counts[1]], dim=1)
     else:
         cf = counts[0][:, None]
-    pw = _mlp(model.pairwise_lin, torch.cat([out, cf], dim=1))
-    return torch.cat([ew, pw], dim=-1)
+    pw = _mlp(model.pairwise_lin, torch.cat([out, cf], dim=1), training)
+    return ew, pw
 
 
 class PairGatherFn(torch.autograd.Function):

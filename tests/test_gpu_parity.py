@@ -341,3 +341,34 @@ def test_forward_reuses_encoder_output_only_while_nothing_changed():
     assert torch.equal(model(batch, test_set=False), fresh(False))
     model.reuse_encoder_output = False
     assert torch.equal(model(batch, test_set=True), fresh(True)) and model._enc_cache is not None
+
+
+def test_two_heads_vs_reference():
+    """num_heads = 2 (src/modules/layers.py:129-135,180-224; ``lp_all_d64_heads2``, recorded from the reference): every
+    head attends with its block of lin_l / lin_r and its row of att over the shared selection, the blocks are
+    concatenated, post_att_norm and pairwise_lin run over 2 D (+ counts) features -- through forward, calc_pairwise,
+    pair_features and score_pairs, which take the head-by-head path of lpformer_amd/train.py in evaluation mode; the
+    single-head entry points (recorded plans, return_weights) refuse loudly."""
+    import lpformer_amd
+    fx = Fixture("lp_all_d64_heads2")
+    assert fx.cfg["num_heads"] == 2
+    model, score = _build(fx)
+    assert model._multi_head and model.att_layers[0].att.lin_r.weight.shape == (128, 128)
+    batch = torch.from_numpy(fx["batch"]).cuda()
+    x_node = model.propagate(test_set=fx.test_set)
+    assert _err(x_node.cpu(), fx["x_node"]) <= TOL
+    infos = model.compute_node_mask(batch, fx.test_set)
+    for tag, info in zip(("cn", "onehop", "non1hop"), infos):
+        np.testing.assert_array_equal(info[0].cpu().numpy(), fx[f"sel_{tag}_ix"])
+    pw, attw = model.calc_pairwise(batch, x_node, test_set=fx.test_set)
+    assert attw is None and _err(pw.cpu(), fx["pairwise_feats"]) <= TOL
+    feats = model(batch, test_set=fx.test_set)
+    assert feats.shape == (batch.shape[1], 128) and _err(feats.cpu(), fx["combined_feats"]) <= TOL
+    assert _err(model.pair_features(batch, x_node, test_set=fx.test_set).cpu(), fx["combined_feats"]) <= TOL
+    assert _err(score.logits(feats).cpu(), fx["logit"]) <= TOL
+    assert _err(model.score_pairs(batch, x_node, score, test_set=fx.test_set).cpu(), fx["prob"]) <= TOL
+    assert _err(model.score_pairs(batch, x_node, score, test_set=fx.test_set, logits=True).cpu(), fx["logit"]) <= TOL
+    with pytest.raises(NotImplementedError):
+        model(batch, test_set=fx.test_set, return_weights=True)
+    with pytest.raises(NotImplementedError):
+        lpformer_amd.PlannedScorer(model, score, x_node, batch)

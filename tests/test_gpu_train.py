@@ -17,7 +17,7 @@ from tests.golden_util import GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TRAIN_CASES = ["train_step_d64", "train_step_d64_residual"]
+TRAIN_CASES = ["train_step_d64", "train_step_d64_residual", "train_step_d64_heads2"]     # (heads2: num_heads = 2)
 
 
 def _load(name):
