@@ -695,15 +695,17 @@ class LinkTransformer(nn.Module):
         """num_heads > 1 (layers.py:129-135,180-224): the head-by-head path of lpformer_amd/train.py ``pair_stage`` -- the
         training step's kernels, one pass per head over the shared selection -- serves evaluation too; the one-launch
         inference kernels (select4 / pair_rows / tail_chain, the folded score head, recorded plans) are single-head."""
-        return int(self.train_args["num_heads"]) > 1
+        return int(self.train_args["num_heads"]) > 1 or self.num_layers > 1      # (two layers take the same path)
 
     def _check_supported(self, train_ok: bool = False, heads_ok: bool = False):
-        if self.num_layers != 1:
-            raise NotImplementedError("trans_layers = 1 only (every shipped script; with more layers the reference is "
-                                      "shape-consistent for two layers and one head only, link_transformer.py:55-62)")
+        if self.num_layers > 2 or (self.num_layers == 2 and (int(self.train_args["num_heads"]) != 1 or self.dim > 128)):
+            raise NotImplementedError("trans_layers = 1, or 2 with num_heads = 1 and dim <= 128: the reference's layer "
+                                      "stack is shape-consistent for nothing else (link_transformer.py:55-62: the first "
+                                      "of two layers is 2 dim wide, its halves feed the second)")
         if self._multi_head and not heads_ok:
-            raise NotImplementedError("num_heads > 1 runs through forward / calc_pairwise / pair_features / score_pairs "
-                                      "(head by head); this entry point is built on the single-head inference kernels")
+            raise NotImplementedError("num_heads > 1 / trans_layers = 2 run through forward / calc_pairwise / pair_features "
+                                      "/ score_pairs (layer by layer, head by head); this entry point is built on the "
+                                      "one-layer, one-head inference kernels")
         if self.dim not in (32, 64, 128, 256):
             raise NotImplementedError("dim must be one of 32, 64, 128, 256 for the gfx950 kernels")
         if self.training and not train_ok:

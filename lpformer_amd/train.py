@@ -558,35 +558,38 @@ def pair_stage(model, x_node, batch, adj_mask=None, test_set=False, training: bo
         e_pa, e_pb = e_pa.clone(), e_pb.clone()
         counts = cnt.float()
     # ---- positional encodings + attention (link_transformer.py:182-211, layers.py:161-224): dedicated kernels
-    att = model.att_layers[0].att
     encoders = [model.ppr_encoder_cn, getattr(model, "ppr_encoder_onehop", None),
                 getattr(model, "ppr_encoder_non1hop", None)][:n_types]
     heads = int(model.train_args["num_heads"])
     x_u = x_node.index_select(0, nodes_u)                           # rows of the batch's DISTINCT nodes
-    x_sum = PairGatherFn.apply(x_node, batch, False)                # x_a + x_b
     w1s = torch.stack([e.linears[0].weight for e in encoders])
     b1s = torch.stack([e.linears[0].bias for e in encoders])
     gams = torch.stack([e.norm.weight for e in encoders])
     bets = torch.stack([e.norm.bias for e in encoders])
-    att_rows = att.att.reshape(heads, d)
-    outs = []
-    for h in range(heads):
-        sl = slice(h * d, (h + 1) * d)
-        w_r = att.lin_r.weight[sl]
-        w_rx, w_rp = w_r[:, :d], w_r[:, d:]
-        z = linear(x_u, w_rx, att.lin_r.bias[sl])                   # node half of lin_r, once per DISTINCT node
-        # q = lin_l(x_a) + lin_l(x_b) (:212-215) = lin_l.weight (x_a + x_b) + 2 lin_l.bias: one [BS, D] x [D, D] product
-        # per batch instead of an N x D x D one per encoder pass
-        q = linear(x_sum, att.lin_l.weight[sl], 2.0 * att.lin_l.bias[sl])
-        # the second PE Linear folded into the PE half of lin_r: k_e = Z[v] + (W_rp W2_t) h_e + W_rp (2 b2_t)
-        wfold = torch.stack([linear(w_rp, e.linears[1].weight.t()) for e in encoders])
-        bfold = torch.stack([linear(2.0 * e.linears[1].bias[None, :], w_rp)[0] for e in encoders])
-        outs.append(PairAttentionFn.apply(z, q, att_rows[h], att.bias[sl], wfold, bfold, w1s, b1s, gams, bets, e_node,
-                                          e_pa, e_pb, seg, tuple(tbase), node_sort))
-    out = outs[0] if heads == 1 else torch.cat(outs, dim=1)
-    layer = model.att_layers[0]
-    out = layer_norm(out, layer.post_att_norm.weight, layer.post_att_norm.bias)
-    out = F.dropout(out, p=layer.dropout, training=training)
+    out = None
+    for li, layer in enumerate(model.att_layers):
+        # Every layer attends over the SAME selection and positional encodings (link_transformer.py:150-152,167-168); its
+        # "edge" input is cat(x_a, x_b) for the first layer and the previous layer's output after it, halved either way
+        # (layers.py:209-214): q = lin_l(e1) + lin_l(e2) = lin_l.weight (e1 + e2) + 2 lin_l.bias -- one [BS, .] product.
+        att = layer.att
+        c = att.att.shape[-1]                                       # out_channels: dim, or 2 dim in the first of two layers
+        e_sum = PairGatherFn.apply(x_node, batch, False) if li == 0 else out[:, :d] + out[:, d:]
+        att_rows = att.att.reshape(heads, c)
+        outs = []
+        for h in range(heads):
+            sl = slice(h * c, (h + 1) * c)
+            w_r = att.lin_r.weight[sl]
+            w_rx, w_rp = w_r[:, :d], w_r[:, d:]
+            z = linear(x_u, w_rx, att.lin_r.bias[sl])               # node half of lin_r, once per DISTINCT node
+            q = linear(e_sum, att.lin_l.weight[sl], 2.0 * att.lin_l.bias[sl])
+            # the second PE Linear folded into the PE half of lin_r: k_e = Z[v] + (W_rp W2_t) h_e + W_rp (2 b2_t)
+            wfold = torch.stack([linear(w_rp, e.linears[1].weight.t()) for e in encoders])
+            bfold = torch.stack([linear(2.0 * e.linears[1].bias[None, :], w_rp)[0] for e in encoders])
+            outs.append(PairAttentionFn.apply(z, q, att_rows[h], att.bias[sl], wfold, bfold, w1s, b1s, gams, bets, e_node,
+                                              e_pa, e_pb, seg, tuple(tbase), node_sort))
+        out = outs[0] if heads == 1 else torch.cat(outs, dim=1)
+        out = layer_norm(out, layer.post_att_norm.weight, layer.post_att_norm.bias)
+        out = F.dropout(out, p=layer.dropout, training=training)
     # ---- count features + pairwise_lin (link_transformer.py:170-177, 340-356)
     if n_types == 3:
         cf = torch.stack([counts[0], counts[1], counts[2], counts[0] + counts[1]], dim=1)
@@ -645,18 +648,21 @@ class PairAttentionFn(torch.autograd.Function):
         att, bias = att.contiguous(), bias.contiguous()
         wfold, bfold = wfold.contiguous(), bfold.contiguous()
         w1s, b1s, gams, bets = w1s.contiguous(), b1s.contiguous(), gams.contiguous(), bets.contiguous()
-        bs, d, n = q.shape[0], q.shape[1], int(e_node.numel())
+        # d: width of the keys, the queries and the output (the layer's out_channels); dh: width of the PE hidden layer
+        # (the model's dim) -- equal except in the first of two attention layers, whose out_channels is 2 dim
+        # (link_transformer.py:55-58)
+        bs, d, n, dh = q.shape[0], q.shape[1], int(e_node.numel()), w1s.shape[1]
         dev = z.device
-        h = torch.empty(max(n, 1), d, dtype=torch.float32, device=dev)
+        h = torch.empty(max(n, 1), dh, dtype=torch.float32, device=dev)
         kp = torch.empty(max(n, 1), d, dtype=torch.float32, device=dev)
         for t in range(wfold.shape[0]):
             lo, hi = tbase[t], tbase[t + 1]
             if hi <= lo:
                 continue
-            check(lib.lpf_pe_hidden_fwd_f32(hi - lo, d, ptr(w1s[t]), ptr(b1s[t]), ptr(gams[t]), ptr(bets[t]),
-                                            e_pa.data_ptr() + 4 * lo, e_pb.data_ptr() + 4 * lo, ptr(h[lo:]), d, st),
+            check(lib.lpf_pe_hidden_fwd_f32(hi - lo, dh, ptr(w1s[t]), ptr(b1s[t]), ptr(gams[t]), ptr(bets[t]),
+                                            e_pa.data_ptr() + 4 * lo, e_pb.data_ptr() + 4 * lo, ptr(h[lo:]), dh, st),
                   "lpf_pe_hidden_fwd_f32")
-            check(lib.lpf_gemm_f32(hi - lo, d, d, ptr(h[lo:]), d, ptr(wfold[t]), d, ptr(bfold[t]), None, 0, ptr(kp[lo:]),
+            check(lib.lpf_gemm_f32(hi - lo, d, dh, ptr(h[lo:]), dh, ptr(wfold[t]), dh, ptr(bfold[t]), None, 0, ptr(kp[lo:]),
                                    d, 0, st), "lpf_gemm_f32")
         out = torch.empty(bs, d, dtype=torch.float32, device=dev)
         score = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
@@ -676,7 +682,7 @@ class PairAttentionFn(torch.autograd.Function):
          pinv) = ctx.saved_tensors
         lib, st, tbase = _lib.hip(), _stream(z), ctx.tbase
         dout = dout.contiguous()
-        bs, d, n = q.shape[0], q.shape[1], int(e_node.numel())
+        bs, d, n, dh_w = q.shape[0], q.shape[1], int(e_node.numel()), w1s.shape[1]
         dev = z.device
         dk = torch.empty(max(n, 1), d, dtype=torch.float32, device=dev)
         dz = torch.zeros_like(z)
@@ -695,22 +701,22 @@ class PairAttentionFn(torch.autograd.Function):
         n_t = wfold.shape[0]
         dwfold = torch.zeros_like(wfold)
         dbfold = torch.zeros(n_t, d, dtype=torch.float32, device=dev)
-        g5 = torch.zeros(n_t, 5, d, dtype=torch.float32, device=dev)
-        dh = torch.empty(max(n, 1), d, dtype=torch.float32, device=dev)
+        g5 = torch.zeros(n_t, 5, dh_w, dtype=torch.float32, device=dev)
+        dh = torch.empty(max(n, 1), dh_w, dtype=torch.float32, device=dev)
         for t in range(n_t):
             lo, hi = tbase[t], tbase[t + 1]
             if hi <= lo:
                 continue
             m = hi - lo
-            wt = wfold[t].t().contiguous()                                  # dH = dK Wfold
-            check(lib.lpf_gemm_f32(m, d, d, ptr(dk[lo:]), d, ptr(wt), d, None, None, 0, ptr(dh[lo:]), d, 0, st),
+            wt = wfold[t].t().contiguous()                                  # dH = dK Wfold: [m, d] x [d, dh]
+            check(lib.lpf_gemm_f32(m, dh_w, d, ptr(dk[lo:]), d, ptr(wt), d, None, None, 0, ptr(dh[lo:]), dh_w, 0, st),
                   "lpf_gemm_f32")
-            ws = torch.empty(max(int(lib.lpf_gemm_tn_workspace_floats(m, d, d)), 1), dtype=torch.float32, device=dev)
-            check(lib.lpf_gemm_tn_colsum_f32(m, d, d, ptr(dk[lo:]), d, ptr(h[lo:]), d, ptr(dwfold[t]), d, ptr(dbfold[t]),
-                                             ptr(ws), st), "lpf_gemm_tn_colsum_f32")   # dWfold = dK^T H, dbfold = dK^T 1
-            check(lib.lpf_pe_hidden_bwd_f32(m, d, ptr(w1s[t]), ptr(b1s[t]), ptr(gams[t]), ptr(bets[t]),
-                                            e_pa.data_ptr() + 4 * lo, e_pb.data_ptr() + 4 * lo, ptr(dh[lo:]), d,
-                                            ptr(g5[t]), ptr(_partial_ws(d, 5, dev)), st), "lpf_pe_hidden_bwd_f32")
+            ws = torch.empty(max(int(lib.lpf_gemm_tn_workspace_floats(m, d, dh_w)), 1), dtype=torch.float32, device=dev)
+            check(lib.lpf_gemm_tn_colsum_f32(m, d, dh_w, ptr(dk[lo:]), d, ptr(h[lo:]), dh_w, ptr(dwfold[t]), dh_w,
+                                             ptr(dbfold[t]), ptr(ws), st), "lpf_gemm_tn_colsum_f32")   # dWfold = dK^T H, dbfold = dK^T 1
+            check(lib.lpf_pe_hidden_bwd_f32(m, dh_w, ptr(w1s[t]), ptr(b1s[t]), ptr(gams[t]), ptr(bets[t]),
+                                            e_pa.data_ptr() + 4 * lo, e_pb.data_ptr() + 4 * lo, ptr(dh[lo:]), dh_w,
+                                            ptr(g5[t]), ptr(_partial_ws(dh_w, 5, dev)), st), "lpf_pe_hidden_bwd_f32")
         dw1s = torch.stack([g5[:, 0], g5[:, 1]], dim=2)                    # [T, D, 2]
         return (dz, dq, dab[0], dab[1], dwfold, dbfold, dw1s, g5[:, 2], g5[:, 3], g5[:, 4], None, None, None, None,
                 None, None)

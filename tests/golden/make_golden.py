@@ -119,7 +119,7 @@ def make_pairs(rng, n, edge_index, bs, isolated):
 # ----------------------------------------------------------------------------- one fixture
 def build_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, residual=False,
                layer_norm=True, relu=True, weighted=False, n_isolated=0, power=0.0, jitter=False,
-               val_in_test=False, masked=False, num_heads=1):
+               val_in_test=False, masked=False, num_heads=1, trans_layers=1):
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     from torch_sparse import SparseTensor  # shim
@@ -160,7 +160,7 @@ def build_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, 
         data.update(full_adj_t=adj_t, full_adj_mask=adj_mask, ppr_test=ppr)
 
     train_args = {"thresh_cn": th_cn, "thresh_1hop": th_1, "thresh_non1hop": th_n, "dim": dim,
-                  "trans_layers": 1, "num_heads": num_heads, "att_drop": 0.1, "dropout": 0.1, "gnn_drop": 0.1,
+                  "trans_layers": trans_layers, "num_heads": num_heads, "att_drop": 0.1, "dropout": 0.1, "gnn_drop": 0.1,
                   "feat_drop": 0.1, "gcn_cache": False, "gnn_layers": gnn_layers, "residual": residual,
                   "layer_norm": layer_norm, "relu": relu}
     model = LinkTransformer(train_args, data, device="cpu")
@@ -257,7 +257,7 @@ def build_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, 
 
 
 def build_train_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, bs, *, residual=False, weighted=False,
-                     power=0.0, n_isolated=0, mask_input=True, num_negative=1, num_heads=1):
+                     power=0.0, n_isolated=0, mask_input=True, num_negative=1, num_heads=1, trans_layers=1):
     """One training step of the reference (src/train/train_model.py:35-66) on CPU: model.train() with every dropout
     probability set to 0 (so the step is deterministic), positives scored with their edges removed from the typing
     adjacency (and, with mask_input, from the propagation adjacency), negatives drawn here, loss =
@@ -276,7 +276,7 @@ def build_train_case(name, seed, n, m, f_in, dim, gnn_layers, thresholds, eps, b
     data = {"x": torch.from_numpy(x), "adj_t": adj_t, "adj_mask": adj_mask, "ppr": ppr, "num_nodes": n,
             "full_adj_t": adj_t, "full_adj_mask": adj_mask, "ppr_test": ppr}
     train_args = {"thresh_cn": th_cn, "thresh_1hop": th_1, "thresh_non1hop": th_n, "dim": dim,
-                  "trans_layers": 1, "num_heads": num_heads, "att_drop": 0.0, "dropout": 0.0, "gnn_drop": 0.0,
+                  "trans_layers": trans_layers, "num_heads": num_heads, "att_drop": 0.0, "dropout": 0.0, "gnn_drop": 0.0,
                   "feat_drop": 0.0, "gcn_cache": False, "gnn_layers": gnn_layers, "residual": residual,
                   "layer_norm": True, "relu": True}
     model = LinkTransformer(train_args, data, device="cpu")
@@ -385,6 +385,13 @@ def main(only=()):
                eps=1e-3, bs=160, power=0.4, n_isolated=3, jitter=True, num_heads=2)
     build_train_case("train_step_d64_heads2", 13, n=280, m=850, f_in=32, dim=64, gnn_layers=2,
                      thresholds=(0, 1e-3, 3e-3), eps=1e-3, bs=80, weighted=True, power=0.4, mask_input=False, num_heads=2)
+    # trans_layers = 2 (link_transformer.py:55-62; one head -- the only multi-layer stack the reference is shape-consistent
+    # for): the first layer is 2 dim wide, its output's halves are the second layer's "edge" input; both attend over the
+    # same selection and positional encodings
+    build_case("lp_all_d64_layers2", 14, n=300, m=1000, f_in=24, dim=64, gnn_layers=2, thresholds=(0, 1e-3, 3e-3),
+               eps=1e-3, bs=160, power=0.4, n_isolated=3, jitter=True, trans_layers=2)
+    build_train_case("train_step_d32_layers2", 15, n=260, m=800, f_in=32, dim=32, gnn_layers=2,
+                     thresholds=(0, 1e-3, 3e-3), eps=1e-3, bs=80, power=0.4, mask_input=False, trans_layers=2)
     build_ppr_case("ppr_push_small", 7, n=220, m=600, eps_list=[1e-3, 1e-4], n_isolated=5)
     build_ppr_case("ppr_push_powerlaw", 8, n=300, m=1500, eps_list=[1e-3], power=0.9)
 

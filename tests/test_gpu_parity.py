@@ -343,17 +343,21 @@ def test_forward_reuses_encoder_output_only_while_nothing_changed():
     assert torch.equal(model(batch, test_set=True), fresh(True)) and model._enc_cache is not None
 
 
-def test_two_heads_vs_reference():
-    """num_heads = 2 (src/modules/layers.py:129-135,180-224; ``lp_all_d64_heads2``, recorded from the reference): every
-    head attends with its block of lin_l / lin_r and its row of att over the shared selection, the blocks are
-    concatenated, post_att_norm and pairwise_lin run over 2 D (+ counts) features -- through forward, calc_pairwise,
-    pair_features and score_pairs, which take the head-by-head path of lpformer_amd/train.py in evaluation mode; the
-    single-head entry points (recorded plans, return_weights) refuse loudly."""
+@pytest.mark.parametrize("case", ["lp_all_d64_heads2", "lp_all_d64_layers2"])
+def test_two_heads_and_two_layers_vs_reference(case):
+    """num_heads = 2 (src/modules/layers.py:129-135,180-224) and trans_layers = 2 (src/models/link_transformer.py:55-62,
+    150-152,167-168), recorded from the reference.  Heads: every head attends with its block of lin_l / lin_r and its
+    row of att over the shared selection, the blocks are concatenated, post_att_norm and pairwise_lin run over 2 D
+    (+ counts) features.  Layers: the first is 2 D wide, the halves of its output are the second one's "edge" input, both
+    attend over the same selection and positional encodings.  Through forward, calc_pairwise, pair_features and
+    score_pairs, which take the layer-by-layer, head-by-head path of lpformer_amd/train.py in evaluation mode; the
+    one-layer one-head entry points (recorded plans, return_weights) refuse loudly."""
     import lpformer_amd
-    fx = Fixture("lp_all_d64_heads2")
-    assert fx.cfg["num_heads"] == 2
+    fx = Fixture(case)
+    assert (fx.cfg["num_heads"], fx.cfg["trans_layers"]) in ((2, 1), (1, 2))
     model, score = _build(fx)
     assert model._multi_head and model.att_layers[0].att.lin_r.weight.shape == (128, 128)
+    assert len(model.att_layers) == fx.cfg["trans_layers"]
     batch = torch.from_numpy(fx["batch"]).cuda()
     x_node = model.propagate(test_set=fx.test_set)
     assert _err(x_node.cpu(), fx["x_node"]) <= TOL

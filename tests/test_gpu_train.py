@@ -17,7 +17,8 @@ from tests.golden_util import GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TRAIN_CASES = ["train_step_d64", "train_step_d64_residual", "train_step_d64_heads2"]     # (heads2: num_heads = 2)
+TRAIN_CASES = ["train_step_d64", "train_step_d64_residual", "train_step_d64_heads2", "train_step_d32_layers2"]
+# (heads2: num_heads = 2; layers2: trans_layers = 2, the first layer 2 dim wide)
 
 
 def _load(name):
