@@ -97,6 +97,10 @@ def score_edges(model, score_func, edges, batch_size: int = 32768, *, h: Optiona
     main = torch.cuda.current_stream(dev)
     start = 0
     n_full = total // batch_size
+    if getattr(model, "_multi_head", False):
+        # (num_heads > 1 / two attention layers: layer by layer, head by head through train.py's pair_stage -- no recorded
+        #  plan exists for it, and its selection reads its status back per batch: one lane)
+        plans, streams = False, 1
     if plans is None:
         plans = n_full >= PLAN_MIN_BATCHES * max(1, min(streams, n_full))
     if plans and n_full > 0 and _planned_sweep(model, score_func, batch, out, h, batch_size, n_full, test_set, streams,

@@ -376,3 +376,7 @@ def test_two_heads_and_two_layers_vs_reference(case):
         model(batch, test_set=fx.test_set, return_weights=True)
     with pytest.raises(NotImplementedError):
         lpformer_amd.PlannedScorer(model, score, x_node, batch)
+    # the evaluation sweep (lpformer_amd/evaluate.py) takes the eager path for such a model
+    from lpformer_amd import evaluate
+    sweep = evaluate.score_edges(model, score, batch.t(), batch_size=64, h=x_node, test_set=fx.test_set, logits=True)
+    assert _err(sweep.cpu(), fx["logit"]) <= TOL
