@@ -71,8 +71,13 @@ class LPFormer(nn.Module):
         self._bound = key
 
     def forward(self, batch: torch.Tensor, x: torch.Tensor, edge_index: torch.Tensor, ppr_matrix) -> torch.Tensor:
-        """Logits [BS] for the candidate pairs ``batch`` [2, BS]."""
+        """Logits [BS] for the candidate pairs ``batch`` [2, BS].  In training mode (gradients enabled) the autograd path
+        of lpformer_amd/train.py: encoder, selection, attention and score head with their dropouts, logits without the
+        sigmoid (``BCEWithLogitsLoss``-style loops)."""
         self._bind(x, edge_index, ppr_matrix)
+        if self.training and torch.is_grad_enabled():
+            from . import train as lpf_train
+            return lpf_train.score_train(self.score, self.core(batch), logits=True)
         h = self.core.propagate()
         for _attempt in range(4):
             out = self.core.score_pairs(batch, h, self.score, logits=True)

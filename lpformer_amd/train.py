@@ -722,10 +722,12 @@ class PairAttentionFn(torch.autograd.Function):
                 None, None)
 
 
-def score_train(score_func, x):
-    """``mlp_score.forward`` in training mode (other_models.py:173-179): (Linear, ReLU, dropout)* Linear, sigmoid."""
+def score_train(score_func, x, logits: bool = False):
+    """``mlp_score.forward`` in training mode (other_models.py:173-179): (Linear, ReLU, dropout)* Linear, sigmoid
+    (``logits``: without the sigmoid -- the PyG-style facade returns those)."""
     for lin in score_func.lins[:-1]:
         x = F.relu(linear(x, lin.weight, lin.bias))
         x = F.dropout(x, p=score_func.dropout, training=True)
     last = score_func.lins[-1]
-    return torch.sigmoid(linear(x, last.weight, last.bias)).squeeze(-1)
+    y = linear(x, last.weight, last.bias).squeeze(-1)
+    return y if logits else torch.sigmoid(y)

@@ -157,6 +157,27 @@ def test_pyg_style_facade_matches_core():
     assert (want - got).abs().max().item() <= 1e-6
     sp = lpformer_amd.LPFormer.calc_sparse_ppr(torch.from_numpy(ei), n, 0.15, cfg["eps"])
     assert sp._nnz() == ppr.nnz
+    # training mode: logits with an autograd graph (all dropouts 0 here: the same numbers), gradients = the core's
+    tx, te = torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV)
+    for mod in (m, core2, score):
+        mod.train()
+    for mod in (m.core, core2):
+        mod.att_drop = 0.0
+        mod.node_encoder.feat_drop = 0.0
+        mod.node_encoder.gnn_encoder.dropout = 0.0
+        mod.att_layers[0].dropout = 0.0
+        mod.elementwise_lin.dropout = mod.pairwise_lin.dropout = 0.0
+    m.score.dropout = score.dropout = 0.0
+    lg = m(tb, tx, te, ppr)
+    assert lg.requires_grad and (lg.detach() - got).abs().max().item() <= 1e-4
+    torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.ones_like(lg)).backward()
+    from lpformer_amd import train as lpf_train
+    ref = lpf_train.score_train(score, core2(tb), logits=True)
+    torch.nn.functional.binary_cross_entropy_with_logits(ref, torch.ones_like(ref)).backward()
+    for (k, p), (_, q) in zip(m.core.named_parameters(), core2.named_parameters()):
+        if q.grad is not None:
+            scale = max(float(q.grad.abs().max()), 1e-6)
+            assert p.grad is not None and float((p.grad - q.grad).abs().max()) / scale <= 1e-4, k
 
 
 def test_batches_pipelined_on_two_streams_match_serial():
