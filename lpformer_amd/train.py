@@ -336,14 +336,24 @@ def _fused_layer(a: graph.DeviceCSR, x2: torch.Tensor, wp: torch.Tensor, bias=No
 _seed_state = [None, 0]
 
 
-def _next_drop_seed() -> int:
-    """A fresh 64-bit seed for an in-kernel dropout mask: a function of torch's seed (``torch.manual_seed`` makes a run
-    repeatable) and of how many masks were drawn under it -- no device generator, no synchronisation."""
-    base = torch.initial_seed()
-    if _seed_state[0] != base:
-        _seed_state[0], _seed_state[1] = base, 0
-    _seed_state[1] += 1
-    z = (base * 0x9E3779B97F4A7C15 + _seed_state[1] * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF    # splitmix64 finaliser
+def _next_drop_seed(device=None) -> int:
+    """A fresh 64-bit seed for an in-kernel dropout mask, drawn the way torch's own dropout kernels draw their Philox
+    counters: from the device's default generator -- its seed and its current offset, which is then advanced -- so that
+    ``torch.manual_seed`` (re-)starts the sequence exactly as it does for torch's random operators.  Host-side state
+    only: no device generator launch, no synchronisation.  (Without a device -- CPU tests -- a counter under
+    ``torch.initial_seed()``.)"""
+    if device is not None and torch.device(device).type == "cuda":
+        dev = torch.device(device)
+        gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        base, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + 4)
+    else:
+        base = torch.initial_seed()
+        if _seed_state[0] != base:
+            _seed_state[0], _seed_state[1] = base, 0
+        _seed_state[1] += 1
+        off = _seed_state[1]
+    z = (base * 0x9E3779B97F4A7C15 + off * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF    # splitmix64 finaliser
     z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
     z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
     return z ^ (z >> 31)
@@ -381,7 +391,7 @@ class GcnFusedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, i, x, weight, a_hat, conv_bias, ln_w, ln_b, drop_p=0.0, skip=False):
         x2 = _rows4(x)
-        seed = _next_drop_seed() if drop_p > 0 else 0
+        seed = _next_drop_seed(x2.device) if drop_p > 0 else 0
         y, u, h = _fused_layer(a_hat, x2, model._conv_packs[i].get(weight), conv_bias, ln_w, ln_b, _lib.FLAG_RELU,
                                pre=True, agg=True, residual=x2 if skip else None, drop_p=drop_p, drop_seed=seed)
         ctx.save_for_backward(h, weight, u, ln_w, ln_b)
@@ -498,7 +508,14 @@ def pair_stage(model, x_node, batch, adj_mask=None, test_set=False, training: bo
     off: the evaluation-mode forward of a model the one-launch inference kernels do not cover (num_heads > 1)."""
     dev = model.device
     bs, d = batch.shape[1], model.dim
-    ew = _mlp(model.elementwise_lin, PairGatherFn.apply(x_node, batch, True), training)  # x_a * x_b (:101-102)
+    end_sort = None
+    if torch.is_grad_enabled() and x_node.requires_grad and bs > 0:
+        # the endpoints sorted once: both endpoint gathers (x_a * x_b here, x_a + x_b for the queries) sum their gradients
+        # node by node in this order -- with the by-node sum of the attention stage and the deterministic reductions of
+        # every other kernel, a seeded training step gives the same bits every time it is run
+        k, o = torch.sort(batch.reshape(-1), stable=True)
+        end_sort = (k.to(torch.int32), o)
+    ew = _mlp(model.elementwise_lin, PairGatherFn.apply(x_node, batch, True, end_sort), training)  # x_a * x_b (:101-102)
     # ---- selection (integer work, no gradient) in the reference's layout, then the random attention drop
     n_types = {"all": 3, "1-hop": 2, "cn": 1}[model.mask]
     with torch.no_grad():
@@ -573,7 +590,7 @@ def pair_stage(model, x_node, batch, adj_mask=None, test_set=False, training: bo
         # (layers.py:209-214): q = lin_l(e1) + lin_l(e2) = lin_l.weight (e1 + e2) + 2 lin_l.bias -- one [BS, .] product.
         att = layer.att
         c = att.att.shape[-1]                                       # out_channels: dim, or 2 dim in the first of two layers
-        e_sum = PairGatherFn.apply(x_node, batch, False) if li == 0 else out[:, :d] + out[:, d:]
+        e_sum = PairGatherFn.apply(x_node, batch, False, end_sort) if li == 0 else out[:, :d] + out[:, d:]
         att_rows = att.att.reshape(heads, c)
         outs = []
         for h in range(heads):
@@ -606,7 +623,10 @@ class PairGatherFn(torch.autograd.Function):
     through lpf_pair_gather_f32; the gradient is scattered back with float atomics (lpf_pair_scatter_add_f32)."""
 
     @staticmethod
-    def forward(ctx, x, batch, product):
+    def forward(ctx, x, batch, product, end_sort=None):
+        """``end_sort`` = (sorted endpoint ids cat(a, b) as int32, the permutation that sorts them): the backward then sums
+        the endpoint gradients node by node in that order (``lpf_segment_rows_sum_f32``: no atomics, the same bits from run
+        to run); without it they are added with float atomics (``lpf_pair_scatter_add_f32``)."""
         x = x.contiguous()
         bs, d = batch.shape[1], x.shape[1]
         out = torch.empty(bs, d, dtype=torch.float32, device=x.device)
@@ -614,7 +634,7 @@ class PairGatherFn(torch.autograd.Function):
         check(_lib.hip().lpf_pair_gather_f32(bs, d, ptr(batch), batch.stride(0), x.shape[0], ptr(x), x.stride(0), *args,
                                              _stream(x)), "lpf_pair_gather_f32")
         ctx.save_for_backward(x, batch)
-        ctx.product = product
+        ctx.product, ctx.end_sort = product, end_sort
         return out
 
     @staticmethod
@@ -623,11 +643,20 @@ class PairGatherFn(torch.autograd.Function):
         dout = dout.contiguous()
         bs, d = batch.shape[1], x.shape[1]
         dx = torch.zeros_like(x)
+        if ctx.end_sort is not None and bs > 0 and d in (32, 64, 128, 256):
+            keys, order = ctx.end_sort
+            if ctx.product:       # d(x_a * x_b): dX[a] += dout * x_b, dX[b] += dout * x_a
+                src = torch.cat([dout * x.index_select(0, batch[1]), dout * x.index_select(0, batch[0])])
+            else:                 # d(x_a + x_b)
+                src = torch.cat([dout, dout])
+            check(_lib.hip().lpf_segment_rows_sum_f32(2 * bs, d, ptr(keys), ptr(order), ptr(src), d, ptr(dx), dx.stride(0),
+                                                      _stream(x)), "lpf_segment_rows_sum_f32")
+            return dx, None, None, None
         dm, ds = (dout, None) if ctx.product else (None, dout)
         check(_lib.hip().lpf_pair_scatter_add_f32(bs, d, ptr(batch), batch.stride(0), x.shape[0], ptr(x), x.stride(0),
                                                   ptr(dm), d, ptr(ds), d, ptr(dx), dx.stride(0), _stream(x)),
               "lpf_pair_scatter_add_f32")
-        return dx, None, None
+        return dx, None, None, None
 
 
 def _partial_ws(d: int, k: int, device) -> torch.Tensor:
