@@ -22,7 +22,8 @@
 // one pair (attention), 16 bytes per lane and access.  Column sums over entries / pairs go through per-block partials
 // that a second small kernel adds in block order; dZ is summed run by run of the entries sorted by node
 // (segment_sum_kernel; float atomics only when the caller passes a dZ to the backward kernel itself): every gradient of
-// this stage is deterministic.  (The endpoint scatter of lpf_pair_scatter_add_f32 still adds with atomics.)
+// this stage is deterministic.  (lpf_pair_scatter_add_f32, the endpoint scatter with atomics, is what a caller
+// without a sorted endpoint list gets; the training step sums by node there too.)
 #include "lpf_common.h"
 
 namespace {
